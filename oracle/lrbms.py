@@ -1,0 +1,525 @@
+"""CPU oracle for the LRBMS hot path -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+NumPy/SciPy fp64 restatement of
+
+* ``discretize``                     python/dune/pylrbms/discretize_elliptic_block_swipdg.py:530-811
+* ``discretize_lhs`` / ``_rhs``      ...block_swipdg.py:381-527
+* ``OswaldInterpolationErrorOperator.apply``   ...block_swipdg.py:83-122
+* ``FluxReconstructionOperator.apply``         ...block_swipdg.py:148-176
+* ``assemble_estimator_diffusive_flux_{aa,bb,ab}``  ...block_swipdg.py:319-378
+* ``EstimatorBase._estimate_elliptic`` / ``alpha`` / ``gamma``  python/dune/pylrbms/estimators.py:45-130
+* ``LRBMSReductor._reduce``          python/dune/pylrbms/reductor.py:33-73
+* the generic reduced solve the driver calls at python/scripts/online_adaptive_lrbms.py:141
+
+The integrands evaluated by the absent dune-gdt are restated from the published
+SWIPDG / OS2015 formulas; every choice the reference tree does
+not determine is fixed here and listed in DESIGN.md section 3.  PARITY UNPINNED.
+
+All matrices use the block DG mapper numbering ``dof = 3 * (ii * n_T + e_local) + v``.
+"""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from .quadrature import TRI_BARY, TRI_W, EDGE_T, EDGE_W
+
+SIGMA_INNER_P1 = 8.0      # dune-gdt swipdg inner_sigma(polorder <= 1)
+SIGMA_BOUNDARY_P1 = 14.0  # dune-gdt swipdg boundary_sigma(polorder <= 1)
+BETA_2D = 1.0             # 1 / (d - 1)
+
+
+def _feval(fn, x, centers, keys):
+    out = np.asarray(fn(x, centers, keys), dtype=np.float64)
+    return np.broadcast_to(out, x.shape[:-1]).copy()
+
+
+class OracleDiscretization:
+    """Everything ``discretize`` builds (block_swipdg.py:530-811), as scipy matrices."""
+
+    def __init__(self, mesh, lambda_funcs, thetas, kappa, f, lambda_bar, lambda_hat, mu_bar, mu_hat,
+                 accumulate_coupling_across_q=False, oswald_zero_on='physical'):
+        self.mesh = mesh
+        self.lambda_funcs = list(lambda_funcs)
+        self.thetas = list(thetas)
+        self.Q = len(self.lambda_funcs)
+        self.kappa = np.asarray(kappa, dtype=np.float64).reshape(2, 2)
+        self.f, self.lambda_bar, self.lambda_hat = f, lambda_bar, lambda_hat
+        self.mu_bar, self.mu_hat = mu_bar, mu_hat
+        self.accumulate_coupling_across_q = accumulate_coupling_across_q
+        assert oswald_zero_on in ('physical', 'subdomain')
+        self.oswald_zero_on = oswald_zero_on
+        self.S = mesh.num_subdomains
+        self.nT = mesh.elements_per_subdomain
+        self.n = 3 * self.nT
+        self.ndof = 3 * mesh.num_elements
+        self._geometry()
+        self._assemble_system()
+        self._assemble_rhs()
+        self._assemble_products()
+        self._assemble_flux_reconstruction()
+        self._assemble_oswald()
+        self._assemble_estimator_operators()
+
+    # ------------------------------------------------------------------ geometry / sampling
+    def _geometry(self):
+        m = self.mesh
+        self.xq = np.einsum('kv,evd->ekd', TRI_BARY, m.points)         # [nE, 7, 2]
+        self.kgrad = np.einsum('ab,eib->eia', self.kappa, m.grads)      # kappa grad phi_i
+        self.stiff = np.einsum('eia,eja->eij', m.grads, self.kgrad)     # grad phi_i . kappa grad phi_j
+        Em, fm = m.face_minus[:, 0], m.face_minus[:, 1]
+        a = m.points[Em, (fm + 1) % 3]
+        b = m.points[Em, (fm + 2) % 3]
+        self.xf = a[:, None, :] + EDGE_T[None, :, None] * (b - a)[:, None, :]   # [nF, 3, 2]
+        nF = m.num_faces
+        phim = np.zeros((nF, 3, 3))                                     # [face, i, k]
+        ar = np.arange(nF)
+        phim[ar, (fm + 1) % 3, :] = 1.0 - EDGE_T[None, :]
+        phim[ar, (fm + 2) % 3, :] = EDGE_T[None, :]
+        self.phim = phim
+        Ep = np.maximum(m.face_plus[:, 0], 0)
+        d = self.xf - m.points[Ep, 0][:, None, :]
+        phip = np.einsum('fia,fka->fik', m.grads[Ep], d)
+        phip[:, 0, :] += 1.0
+        phip[m.face_plus[:, 0] < 0] = 0.0
+        self.phip = phip
+        n = m.face_normal
+        self.delta = np.einsum('fa,ab,fb->f', n, self.kappa, n)          # n^T kappa n (kappa constant)
+        self.gnm = np.einsum('fia,fa->fi', self.kgrad[Em], n)            # kappa grad phi_i^- . n
+        self.gnp = np.einsum('fia,fa->fi', self.kgrad[Ep], n)
+        self.gnp[m.face_plus[:, 0] < 0] = 0.0
+
+    def _vol(self, fn):
+        m = self.mesh
+        return _feval(fn, self.xq, m.elem_center, m.elem_key)           # [nE, 7]
+
+    def _face_sides(self, fn):
+        m = self.mesh
+        Em = m.face_minus[:, 0]
+        Ep = np.maximum(m.face_plus[:, 0], 0)
+        vm = _feval(fn, self.xf, m.elem_center[Em], m.elem_key[Em])
+        vp = _feval(fn, self.xf, m.elem_center[Ep], m.elem_key[Ep])
+        return vm, vp                                                   # [nF, 3] each
+
+    def _coo(self, rows_e, cols_e, blocks):
+        """Scatter 3x3 blocks [k, i, j] to (3*rows_e+i, 3*cols_e+j)."""
+        i = np.arange(3)
+        r = (3 * rows_e[:, None, None] + i[None, :, None]) + 0 * i[None, None, :]
+        c = (3 * cols_e[:, None, None] + i[None, None, :]) + 0 * i[None, :, None]
+        return sp.coo_matrix((blocks.ravel(), (r.ravel(), c.ravel())), shape=(self.ndof, self.ndof)).tocsr()
+
+    # ------------------------------------------------------------------ SWIPDG system (K1-K4)
+    def _swipdg_face_blocks(self, lam_m, lam_p):
+        """The four inner-face blocks of SURVEY App. A.2 for every face, integrated with EDGE_W."""
+        m = self.mesh
+        L = m.face_length
+        wq = EDGE_W[None, :] * L[:, None]                                # [nF, 3]
+        gamma = 0.5 * self.delta          # delta^+ delta^- / (delta^+ + delta^-) with constant kappa
+        wm = wp = 0.5
+        sigma = 0.5 * (lam_m + lam_p) * SIGMA_INNER_P1 * gamma[:, None] / (L[:, None] ** BETA_2D)
+        gm = lam_m[:, None, :] * self.gnm[:, :, None]                    # [f, i, k] (D^- grad phi_i^- . n)
+        gp = lam_p[:, None, :] * self.gnp[:, :, None]
+        pm, pp = self.phim, self.phip
+        e = np.einsum
+        # [row i (test), col j (ansatz)]
+        mm = (-wm * e('fjk,fik,fk->fij', gm, pm, wq) - wm * e('fjk,fik,fk->fij', pm, gm, wq)
+              + e('fk,fjk,fik,fk->fij', sigma, pm, pm, wq))
+        mp = (-wp * e('fjk,fik,fk->fij', gp, pm, wq) + wm * e('fjk,fik,fk->fij', pp, gm, wq)
+              - e('fk,fjk,fik,fk->fij', sigma, pp, pm, wq))
+        pm_ = (wm * e('fjk,fik,fk->fij', gm, pp, wq) - wp * e('fjk,fik,fk->fij', pm, gp, wq)
+               - e('fk,fjk,fik,fk->fij', sigma, pm, pp, wq))
+        pp_ = (wp * e('fjk,fik,fk->fij', gp, pp, wq) + wp * e('fjk,fik,fk->fij', pp, gp, wq)
+               + e('fk,fjk,fik,fk->fij', sigma, pp, pp, wq))
+        return mm, mp, pm_, pp_
+
+    def _swipdg_boundary_block(self, lam_m):
+        m = self.mesh
+        L = m.face_length
+        wq = EDGE_W[None, :] * L[:, None]
+        sigma = lam_m * SIGMA_BOUNDARY_P1 * self.delta[:, None] / (L[:, None] ** BETA_2D)
+        g = lam_m[:, None, :] * self.gnm[:, :, None]
+        pm = self.phim
+        e = np.einsum
+        return (-e('fjk,fik,fk->fij', g, pm, wq) - e('fjk,fik,fk->fij', pm, g, wq)
+                + e('fk,fjk,fik,fk->fij', sigma, pm, pm, wq))
+
+    def _assemble_system(self):
+        """discretize_lhs (block_swipdg.py:381-507): local (volume + inner faces, all-Neumann, :399-406),
+        coupling (:409-423) and Dirichlet boundary (:426-437) parts per affine component."""
+        m = self.mesh
+        Em, Ep = m.face_minus[:, 0], m.face_plus[:, 0]
+        inner = m.face_kind == 0
+        coupl = m.face_kind == 1
+        bnd = m.face_kind == 2
+        earange = np.arange(m.num_elements)
+        self.lam_vol, self.lam_face = [], []
+        self.A_local, self.A_coupling, self.A_boundary, self.A = [], [], [], []
+        acc = None
+        for q, fn in enumerate(self.lambda_funcs):
+            lv = self._vol(fn)
+            lm, lp = self._face_sides(fn)
+            self.lam_vol.append(lv)
+            self.lam_face.append((lm, lp))
+            lam_int = (lv * TRI_W[None, :]).sum(axis=1) * m.area        # int_T lambda_q
+            A_vol = self._coo(earange, earange, lam_int[:, None, None] * self.stiff)
+            mm, mp, pm_, pp_ = self._swipdg_face_blocks(lm, lp)
+
+            def faces(mask):
+                return (self._coo(Em[mask], Em[mask], mm[mask]) + self._coo(Em[mask], Ep[mask], mp[mask]) +
+                        self._coo(Ep[mask], Em[mask], pm_[mask]) + self._coo(Ep[mask], Ep[mask], pp_[mask]))
+            A_loc = A_vol + faces(inner)
+            A_cpl = faces(coupl)
+            if self.accumulate_coupling_across_q:      # reference quirk, SURVEY App. B-7 (:551-565 vs :581-583)
+                acc = A_cpl if acc is None else acc + A_cpl
+                A_cpl = acc.copy()
+            bb = self._swipdg_boundary_block(lm)
+            A_bnd = self._coo(Em[bnd], Em[bnd], bb[bnd])
+            self.A_local.append(A_loc)
+            self.A_coupling.append(A_cpl)
+            self.A_boundary.append(A_bnd)
+            self.A.append((A_loc + A_cpl + A_bnd).tocsr())
+
+    def block(self, M, ii, jj):
+        n = self.n
+        return M[ii * n:(ii + 1) * n, jj * n:(jj + 1) * n]
+
+    # ------------------------------------------------------------------ rhs (K5) and scalars
+    def _assemble_rhs(self):
+        """discretize_rhs (block_swipdg.py:510-527) and the scalars of :776-783."""
+        m = self.mesh
+        fv = self._vol(self.f)
+        self.f_vol = fv
+        b = np.einsum('ek,k,ki,e->ei', fv, TRI_W, TRI_BARY, m.area)     # [nE, 3]
+        self.b = b.reshape(-1)
+        f2 = (fv ** 2 * TRI_W[None, :]).sum(axis=1) * m.area
+        self.local_eta_rf_squared = f2.reshape(self.S, self.nT).sum(axis=1)
+        lh = self._vol(self.lambda_hat)
+        self.lam_hat_vol = lh
+        kmin = float(np.linalg.eigvalsh(0.5 * (self.kappa + self.kappa.T)).min())
+        self.min_diffusion_evs = lh.reshape(self.S, -1).min(axis=1) * kmin
+        self.subdomain_diameters = np.array([m.subdomain_diameter(ii) for ii in range(self.S)])
+
+    # ------------------------------------------------------------------ products (K6)
+    def _assemble_products(self):
+        """Local energy product (elliptic + penalty at mu_bar, :651-677), L2 mass (:662,:679),
+        E_ii(lambda_bar) (:685-691)."""
+        m = self.mesh
+        earange = np.arange(m.num_elements)
+        Em, Ep = m.face_minus[:, 0], m.face_plus[:, 0]
+        inner = m.face_kind == 0
+        outer = m.face_kind != 0
+        L = m.face_length
+        wq = EDGE_W[None, :] * L[:, None]
+        pm, pp = self.phim, self.phip
+        e = np.einsum
+        energy = None
+        self.penalty = []
+        for q in range(self.Q):
+            lv = self.lam_vol[q]
+            lm, lp = self.lam_face[q]
+            lam_int = (lv * TRI_W[None, :]).sum(axis=1) * m.area
+            ell = self._coo(earange, earange, lam_int[:, None, None] * self.stiff)
+            sig = 0.5 * (lm + lp) * SIGMA_INNER_P1 * (0.5 * self.delta)[:, None] / (L[:, None] ** BETA_2D)
+            mm = e('fk,fjk,fik,fk->fij', sig, pm, pm, wq)
+            mp = -e('fk,fjk,fik,fk->fij', sig, pp, pm, wq)
+            pm_ = -e('fk,fjk,fik,fk->fij', sig, pm, pp, wq)
+            pp_ = e('fk,fjk,fik,fk->fij', sig, pp, pp, wq)
+            pen = (self._coo(Em[inner], Em[inner], mm[inner]) + self._coo(Em[inner], Ep[inner], mp[inner]) +
+                   self._coo(Ep[inner], Em[inner], pm_[inner]) + self._coo(Ep[inner], Ep[inner], pp_[inner]))
+            # faces on the boundary of the subdomain (coupling or domain): all-Dirichlet on the
+            # subdomain layer (:537-539,:658) -> boundary penalty with the inside coefficient, per side
+            sbm = lm * SIGMA_BOUNDARY_P1 * self.delta[:, None] / (L[:, None] ** BETA_2D)
+            sbp = lp * SIGMA_BOUNDARY_P1 * self.delta[:, None] / (L[:, None] ** BETA_2D)
+            bm = e('fk,fjk,fik,fk->fij', sbm, pm, pm, wq)
+            bp = e('fk,fjk,fik,fk->fij', sbp, pp, pp, wq)
+            cpl = m.face_kind == 1
+            pen = pen + self._coo(Em[outer], Em[outer], bm[outer]) + self._coo(Ep[cpl], Ep[cpl], bp[cpl])
+            self.penalty.append(pen.tocsr())
+            th = float(self.thetas[q](self.mu_bar))
+            term = th * (ell + pen)
+            energy = term if energy is None else energy + term
+        self.energy_product = energy.tocsr()
+        mass = (1.0 + np.eye(3))[None, :, :] * (m.area / 12.0)[:, None, None]
+        self.l2_product = self._coo(earange, earange, mass)
+        lb = self._vol(self.lambda_bar)
+        lb_int = (lb * TRI_W[None, :]).sum(axis=1) * m.area
+        self.elliptic_bar = self._coo(earange, earange, lb_int[:, None, None] * self.stiff)
+
+    # ------------------------------------------------------------------ flux reconstruction (K8)
+    def _assemble_flux_reconstruction(self):
+        """RT0 face DoFs of the SWIPDG diffusive flux as one sparse
+        [faces x dofs] matrix per affine component; FluxReconstructionOperator.apply
+        (block_swipdg.py:148-176) is then a restriction of F_q @ v."""
+        m = self.mesh
+        Em, Ep = m.face_minus[:, 0], m.face_plus[:, 0]
+        L = m.face_length
+        has_p = Ep >= 0
+        self.F = []
+        for q in range(self.Q):
+            lm, lp = self.lam_face[q]
+            sig = 0.5 * (lm + lp) * SIGMA_INNER_P1 * (0.5 * self.delta)[:, None] / (L[:, None] ** BETA_2D)
+            sigb = lm * SIGMA_BOUNDARY_P1 * self.delta[:, None] / (L[:, None] ** BETA_2D)
+            # inner / coupling faces (weights w^- = w^+ = 1/2 for constant kappa)
+            cm = np.einsum('k,fk,fj->fj', EDGE_W, -0.5 * lm, self.gnm) + np.einsum('k,fk,fjk->fj', EDGE_W, sig, self.phim)
+            cp = np.einsum('k,fk,fj->fj', EDGE_W, -0.5 * lp, self.gnp) - np.einsum('k,fk,fjk->fj', EDGE_W, sig, self.phip)
+            # Dirichlet boundary faces
+            cb = np.einsum('k,fk,fj->fj', EDGE_W, -lm, self.gnm) + np.einsum('k,fk,fjk->fj', EDGE_W, sigb, self.phim)
+            cm = np.where(has_p[:, None], cm, cb)
+            rows = np.repeat(np.arange(m.num_faces), 3)
+            colm = (3 * Em[:, None] + np.arange(3)[None, :]).ravel()
+            Fm = sp.coo_matrix((cm.ravel(), (rows, colm)), shape=(m.num_faces, self.ndof))
+            idx = np.nonzero(has_p)[0]
+            rows_p = np.repeat(idx, 3)
+            colp = (3 * Ep[idx][:, None] + np.arange(3)[None, :]).ravel()
+            Fp = sp.coo_matrix((cp[idx].ravel(), (rows_p, colp)), shape=(m.num_faces, self.ndof))
+            self.F.append((Fm + Fp).tocsr())
+
+    def flux_reconstruction_apply(self, q, s, U):
+        """FluxReconstructionOperator(s).apply(U) for one affine component (block_swipdg.py:148-176).
+        U: [n, k] on subdomain ``s``.  Returns one [n_rt(ii), k] block per ii in neighborhood_of(s)."""
+        n = self.n
+        r = self.F[q][:, s * n:(s + 1) * n] @ U
+        return [r[self.mesh.rt_faces[ii]] for ii in self.mesh.neighborhood_of(s)]
+
+    # ------------------------------------------------------------------ Oswald interpolation (K7)
+    def _assemble_oswald(self):
+        """Vertex averaging over the neighbourhood space of ``ii`` as sparse blocks
+        Avg[ii][kk] (n x n): rows = DoFs of ii, columns = DoFs of kk in neighborhood_of(ii)."""
+        m = self.mesh
+        n, nT = self.n, self.nT
+        self.Avg = []
+        for ii in range(self.S):
+            hood = m.neighborhood_of(ii)
+            hood_set = set(hood)
+            rows = {kk: [] for kk in hood}
+            cols = {kk: [] for kk in hood}
+            vals = {kk: [] for kk in hood}
+            for el in range(nT):
+                E = m.elem_offset[ii] + el
+                for v in range(3):
+                    g = int(m.triangles[E, v])
+                    adj = [(E2, v2) for (E2, v2) in m.vertex_adjacency[g] if int(m.elem_subdomain[E2]) in hood_set]
+                    if self.oswald_zero_on == 'physical':
+                        dirichlet = bool(m.vertex_on_boundary[g])
+                    else:  # every vertex on the boundary of the neighbourhood-restricted subdomain ii
+                        dirichlet = any(int(m.elem_subdomain[E2]) != ii for (E2, _) in m.vertex_adjacency[g]) \
+                            or bool(m.vertex_on_boundary[g])
+                    if dirichlet:
+                        continue
+                    w = 1.0 / len(adj)
+                    for (E2, v2) in adj:
+                        kk = int(m.elem_subdomain[E2])
+                        rows[kk].append(3 * el + v)
+                        cols[kk].append(3 * int(m.elem_local[E2]) + v2)
+                        vals[kk].append(w)
+            self.Avg.append({kk: sp.coo_matrix((vals[kk], (rows[kk], cols[kk])), shape=(n, n)).tocsr()
+                             for kk in hood})
+
+    def oswald_interpolation_error_apply(self, s, U):
+        """OswaldInterpolationErrorOperator(s).apply(U) (block_swipdg.py:83-122): one [n, k] block per
+        ii in neighborhood_of(s): delta_{ii,s} U - I_os^{ii}[U extended by zero]|_{ii}."""
+        out = []
+        for ii in self.mesh.neighborhood_of(s):
+            blk = -(self.Avg[ii][s] @ U)
+            if ii == s:
+                blk = blk + U
+            out.append(blk)
+        return out
+
+    # ------------------------------------------------------------------ estimator operators (K9)
+    def _assemble_estimator_operators(self):
+        """Div_ii (:722-729), df_aa / df_ab / df_bb products (:319-378) in subdomain-local numbering."""
+        m = self.mesh
+        nT, n = self.nT, self.n
+        kinv = np.linalg.inv(self.kappa)
+        lh = self.lam_hat_vol
+        wa = TRI_W[None, :] * m.area[:, None]                          # [nE, 7]
+        # psi_{T,f}(x) = sign * |e| / (2|T|) * (x - p_f)
+        coef = m.elem_face_sign * m.face_length[m.elem_face] / (2.0 * m.area[:, None])   # [nE, 3]
+        psi = coef[:, :, None, None] * (self.xq[:, None, :, :] - m.points[:, :, None, :])   # [nE, f, k, 2]
+        self.caa = [[None] * self.Q for _ in range(self.Q)]
+        earange = np.arange(m.num_elements)
+        for q in range(self.Q):
+            for q2 in range(self.Q):
+                c = (self.lam_vol[q] * self.lam_vol[q2] / lh * wa).sum(axis=1)
+                self.caa[q][q2] = self._coo(earange, earange, c[:, None, None] * self.stiff)
+        # element-local blocks
+        self.ab_blocks = [np.einsum('ek,eia,efka->eif', self.lam_vol[q] / lh * wa, m.grads, psi)
+                          for q in range(self.Q)]                      # [nE, i, f]
+        self.bb_blocks = np.einsum('ek,efka,ab,egkb->efg', wa / lh, psi, kinv, psi)      # [nE, f, g]
+        # Div_ii maps RT0 coefficients to the DG *coefficients* of div r (piecewise constant, so all three
+        # rows of an element are equal): only this reading makes r_fd = b.(Div r) = int f div r and
+        # r_dd = (Div r)^T M (Div r) = ||div r||^2 (:744-748) consistent, and it reproduces the
+        # residual known-answer 1.45e-01 of linearelliptic_block_swipdg_decomp.py:42.
+        self.div_blocks = np.repeat((m.elem_face_sign * m.face_length[m.elem_face] / m.area[:, None])[:, None, :],
+                                    3, axis=1)
+        self.Div, self.Aab, self.Bbb, self.n_rt = [], [[] for _ in range(self.Q)], [], []
+        i3 = np.arange(3)
+        for ii in range(self.S):
+            E0 = m.elem_offset[ii]
+            nrt = len(m.rt_faces[ii])
+            self.n_rt.append(nrt)
+            loc = np.array([[m.rt_local[ii][int(gf)] for gf in m.elem_face[E]] for E in range(E0, E0 + nT)])
+            r = (3 * np.arange(nT)[:, None, None] + i3[None, :, None]) + 0 * i3[None, None, :]
+            c = loc[:, None, :] + 0 * i3[None, :, None]
+            self.Div.append(sp.coo_matrix((self.div_blocks[E0:E0 + nT].ravel(), (r.ravel(), c.ravel())),
+                                          shape=(n, nrt)).tocsr())
+            for q in range(self.Q):
+                self.Aab[q].append(sp.coo_matrix((self.ab_blocks[q][E0:E0 + nT].ravel(), (r.ravel(), c.ravel())),
+                                                 shape=(n, nrt)).tocsr())
+            rr = loc[:, :, None] + 0 * i3[None, None, :]
+            cc = loc[:, None, :] + 0 * i3[None, :, None]
+            self.Bbb.append(sp.coo_matrix((self.bb_blocks[E0:E0 + nT].ravel(), (rr.ravel(), cc.ravel())),
+                                          shape=(nrt, nrt)).tocsr())
+
+    # ------------------------------------------------------------------ parameter functionals
+    def theta(self, mu):
+        return np.array([float(t(mu)) for t in self.thetas])
+
+    def alpha(self, mu, mu_ref, first_only=True):
+        """estimators.py:114-121 -- as written the ``return`` sits inside the loop."""
+        result = np.inf
+        for t in self.thetas:
+            ratio = float(t(mu)) / float(t(mu_ref))
+            assert ratio > 0
+            result = min(result, ratio)
+            if first_only:
+                return result
+        return result
+
+    def gamma(self, mu, mu_ref):
+        """estimators.py:123-130."""
+        return max(float(t(mu)) / float(t(mu_ref)) for t in self.thetas)
+
+    # ------------------------------------------------------------------ FOM solve (not on the hot path)
+    def assemble_global(self, mu):
+        th = self.theta(mu)
+        A = None
+        for q in range(self.Q):
+            A = th[q] * self.A[q] if A is None else A + th[q] * self.A[q]
+        return A.tocsc()
+
+    def solve(self, mu):
+        """DuneDiscretization._solve (block_swipdg.py:219-225) with a direct solver; returns [S, n]."""
+        u = spla.spsolve(self.assemble_global(mu), self.b)
+        return u.reshape(self.S, self.n)
+
+    # ------------------------------------------------------------------ FOM estimate
+    def estimate(self, U, mu, decompose=False, sqrt_local=False, alpha_first_only=True):
+        """EllipticEstimator.estimate for a full-order block vector U [S, n] (estimators.py:45-112)."""
+        bases = [U[ii][:, None] for ii in range(self.S)]
+        red = OracleReductor(self, bases).reduce(project_system=False)
+        return red.estimate(np.ones((self.S, 1)), mu, decompose=decompose, sqrt_local=sqrt_local,
+                            alpha_first_only=alpha_first_only)
+
+
+class OracleReductor:
+    """LRBMSReductor (reductor.py:17-78) on plain arrays: ``bases[ii]`` is [n, N_ii]."""
+
+    def __init__(self, d, bases):
+        self.d = d
+        self.bases = [np.asarray(b, dtype=np.float64) for b in bases]
+
+    def image_bases(self):
+        """reductor.py:40-43 (OI_i) and :51-60 (RT_i, one slab of columns per affine component)."""
+        d, m = self.d, self.d.mesh
+        OI, RT = [], []
+        for s in range(d.S):
+            OI.append(d.oswald_interpolation_error_apply(s, self.bases[s]))
+            per_q = [d.flux_reconstruction_apply(q, s, self.bases[s]) for q in range(d.Q)]
+            RT.append([np.hstack([per_q[q][i] for q in range(d.Q)]) for i in range(len(m.neighborhood_of(s)))])
+        return OI, RT
+
+    def reduce(self, project_system=True):
+        d, m = self.d, self.d.mesh
+        OI, RT = self.image_bases()
+        rd = OracleReducedModel(d, [b.shape[1] for b in self.bases])
+        n = d.n
+        for ii in range(d.S):
+            hood = m.neighborhood_of(ii)
+            V = self.bases[ii]
+            # local_oi_projection / local_rt_projection (block_swipdg.py:700-717): component ``ii`` of every
+            # neighbour's image basis, stacked in neighbourhood order
+            Wt = np.hstack([OI[kk][m.neighborhood_of(kk).index(ii)] for kk in hood])
+            Rt = np.hstack([RT[kk][m.neighborhood_of(kk).index(ii)] for kk in hood])
+            E = d.block(d.elliptic_bar, ii, ii)
+            M = d.block(d.l2_product, ii, ii)
+            rd.nc.append(Wt.T @ (E @ Wt))                                  # :733
+            D = d.Div[ii] @ Rt
+            b_ii = d.b[ii * n:(ii + 1) * n]
+            rd.r_fd.append(b_ii @ D)                                       # :744
+            rd.r_dd.append(D.T @ (M @ D))                                  # :747
+            rd.df_aa.append([[V.T @ (d.block(d.caa[q][q2], ii, ii) @ V) for q2 in range(d.Q)]
+                             for q in range(d.Q)])                         # :752-760
+            rd.df_bb.append(Rt.T @ (d.Bbb[ii] @ Rt))                       # :762
+            rd.df_ab.append([V.T @ (d.Aab[q][ii] @ Rt) for q in range(d.Q)])   # :765-770
+            if project_system:
+                rd.rhs.append(V.T @ b_ii)
+                rd.energy.append(V.T @ (d.block(d.energy_product, ii, ii) @ V))
+                rd.l2.append(V.T @ (M @ V))
+                rd.op.append({jj: [V.T @ (d.block(d.A[q], ii, jj) @ self.bases[jj]) for q in range(d.Q)]
+                              for jj in hood})
+        return rd
+
+    def reconstruct(self, u):
+        return [self.bases[ii] @ u[ii] for ii in range(self.d.S)]
+
+
+class OracleReducedModel:
+    """The reduced discretization ``rd``: block-sparse reduced operators + reduced estimator.
+
+    Column order of the RT-type operators for subdomain ii: neighbourhood slot (sorted) major,
+    then affine component q, then basis index -- i.e. the order ``bases['RT_kk']`` is filled at
+    reductor.py:55-60 (all q appended per subdomain) stacked over kk in neighborhood_of(ii)."""
+
+    def __init__(self, d, sizes):
+        self.d = d
+        self.sizes = list(sizes)
+        self.nc, self.r_fd, self.r_dd, self.df_aa, self.df_bb, self.df_ab = [], [], [], [], [], []
+        self.rhs, self.energy, self.l2, self.op = [], [], [], []
+
+    def assemble(self, mu):
+        d = self.d
+        th = d.theta(mu)
+        off = np.concatenate(([0], np.cumsum(self.sizes)))
+        A = np.zeros((off[-1], off[-1]))
+        for ii in range(d.S):
+            for jj, blocks in self.op[ii].items():
+                A[off[ii]:off[ii + 1], off[jj]:off[jj + 1]] = sum(th[q] * blocks[q] for q in range(d.Q))
+        return A, np.concatenate(self.rhs), off
+
+    def solve(self, mu):
+        """rd.solve(mu) (online_adaptive_lrbms.py:141): (sum_q theta_q A_q^red) u = b^red, dense LU."""
+        A, b, off = self.assemble(mu)
+        u = np.linalg.solve(A, b)
+        return [u[off[ii]:off[ii + 1]] for ii in range(self.d.S)]
+
+    def estimate(self, u, mu, decompose=False, sqrt_local=False, alpha_first_only=True):
+        """_estimate_elliptic (estimators.py:45-112) on reduced coefficients u[ii] (len N_ii).
+        ``sqrt_local`` / ``alpha_first_only`` switch the quirks of SURVEY App. B-1 / B-2."""
+        d, m = self.d, self.d.mesh
+        th = d.theta(mu)
+        S = d.S
+        eta_nc, eta_r, eta_df = np.zeros(S), np.zeros(S), np.zeros(S)
+        for ii in range(S):
+            hood = m.neighborhood_of(ii)
+            uo = np.concatenate([np.asarray(u[kk]) for kk in hood])
+            ur = np.concatenate([np.concatenate([th[q] * np.asarray(u[kk]) for q in range(d.Q)]) for kk in hood])
+            ui = np.asarray(u[ii])
+            eta_nc[ii] = uo @ self.nc[ii] @ uo
+            r = d.local_eta_rf_squared[ii] - 2.0 * (self.r_fd[ii] @ ur) + ur @ self.r_dd[ii] @ ur
+            eta_r[ii] = r * (1.0 / np.pi ** 2) / d.min_diffusion_evs[ii] * d.subdomain_diameters[ii] ** 2
+            df = sum(th[q] * th[q2] * (ui @ self.df_aa[ii][q][q2] @ ui) for q in range(d.Q) for q2 in range(d.Q))
+            df += ur @ self.df_bb[ii] @ ur
+            df += 2.0 * sum(th[q] * (ui @ self.df_ab[ii][q] @ ur) for q in range(d.Q))
+            eta_df[ii] = df
+        if sqrt_local:
+            eta_nc, eta_r, eta_df = np.sqrt(np.abs(eta_nc)), np.sqrt(np.abs(eta_r)), np.sqrt(np.abs(eta_df))
+        a_bar = d.alpha(mu, d.mu_bar, alpha_first_only)
+        g_bar = d.gamma(mu, d.mu_bar)
+        a_hat = d.alpha(mu, d.mu_hat, alpha_first_only)
+        eta = np.sqrt(g_bar) * np.linalg.norm(eta_nc) + (1.0 / np.sqrt(a_hat)) * np.linalg.norm(eta_r + eta_df)
+        eta *= 1.0 / np.sqrt(a_bar)
+        if decompose:
+            ind = (2.0 / a_bar) * (g_bar * eta_nc ** 2 + (1.0 / a_hat) * (eta_r + eta_df) ** 2)
+            return eta, (eta_nc, eta_r, eta_df), ind
+        return eta
