@@ -1,0 +1,176 @@
+/*
+ * lrbms_hip.h -- C ABI of liblrbms_hip.so: the MI355X (gfx950) hot path of dune-community/pylrbms.
+ *
+ * Drop-in boundary.  In the reference the lower boundary of this path is a set of
+ * pybind11 objects from dune-gdt / dune-xt (factories returning operators with .assemble()/.matrix(),
+ * walkers, Matrix/Vector with the buffer protocol).  Here it is flat device arrays:
+ *
+ *   - the caller (Python/torch, or any host) allocates EVERY input/output buffer in device memory and passes
+ *     raw pointers + sizes; the library never frees caller memory ("caller-allocated, callee fills", as the
+ *     caller-supplied matrix `ll` at reference discretize_elliptic_block_swipdg.py:402-406);
+ *   - library-owned state (the subdomain template, the neighbour table) lives in an opaque lrbms_ctx;
+ *   - every entry point returns int (0 = LRBMS_OK, < 0 = LRBMS_E_*); no C++ exception crosses the ABI;
+ *     lrbms_last_error(ctx) gives the message;
+ *   - every launch goes to the hipStream_t passed as `stream` (void*; NULL = default stream); calls on one
+ *     ctx are not re-entrant, different ctxs are independent.
+ *
+ * All floating point data is fp64, all index data int32.  Array shapes are C-contiguous, written [a][b][c].
+ *   S      = number of subdomains owned by this ctx ("local")
+ *   S_ext  = S + halo subdomains (neighbours owned by other ranks); local subdomains come first
+ *   n_T, n = 3 n_T, n_rt, ncf : elements / DG DoFs / RT0 DoFs per subdomain, faces per subdomain side
+ *   Q      = affine diffusion components, N = local reduced basis size (uniform), C = 5 Q N, W = 5 N
+ *   slots  : neighbourhood slots in sorted order 0=S 1=W 2=self 3=E 4=N; sides 0=S 1=W 2=E 3=N
+ *   NS=16  : samples per element: 7 volume points (Radon rule) then 3 Gauss points on each of the 3 faces,
+ *            face f parametrised from local vertex f+1 to f+2
+ */
+#ifndef LRBMS_HIP_H
+#define LRBMS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRBMS_OK 0
+#define LRBMS_E_INVALID (-1)   /* bad argument / shape */
+#define LRBMS_E_HIP (-2)       /* a HIP runtime call failed */
+#define LRBMS_E_STATE (-3)     /* mesh not uploaded yet */
+#define LRBMS_E_NOT_CONVERGED (-4)
+
+#define LRBMS_NS 16
+
+typedef struct lrbms_ctx lrbms_ctx;
+
+/* Host-side description of the subdomain template (pylrbms_amd.grid.SubdomainTemplate) and of the
+ * local neighbour table.  Replaces what the reference gets from make_cube_dd_subdomains_grid
+ * (grid.py:18-30), make_block_dg_space / make_rt_space (block_swipdg.py:543-546) and
+ * compute_pattern / compute_coupling_pattern (:548-568). */
+typedef struct {
+  int32_t kx, ky, n_T, n_rt, n_vertices, ncf;
+  double hx, hy;
+  double kappa[4];              /* constant 2x2 diffusion tensor, row-major */
+  const int32_t* nb_elem;       /* [n_T][3]  >=0 inner neighbour element, <0: -(1+side) */
+  const int32_t* nb_face;       /* [n_T][3]  local face index in the inner neighbour */
+  const int32_t* nb_elem_out;   /* [n_T][3]  element in the neighbouring subdomain (side faces) */
+  const int32_t* nb_face_out;   /* [n_T][3] */
+  const int32_t* elem_side_pos; /* [n_T][3]  position of a side face along its side */
+  const int32_t* elem_rt;       /* [n_T][3]  RT0 DoF of (element, face) */
+  const int32_t* face_sign;     /* [n_T][3]  +1/-1 orientation (S/W sides -1, overridden on the domain boundary) */
+  const int32_t* dof_vertex;    /* [n]       lattice vertex of a DG DoF */
+  const int32_t* vdof_ptr;      /* [n_vertices+1] CSR vertex -> DoFs */
+  const int32_t* vdof_idx;      /* [n] */
+  const int32_t* rt_e0;         /* [n_rt] primary element of an RT0 face ... */
+  const int32_t* rt_f0;         /* [n_rt] ... and its local face */
+  const int32_t* rt_e1;         /* [n_rt] secondary element (own subdomain if inner, neighbour's if side, -1) */
+  const int32_t* rt_f1;         /* [n_rt] */
+  const int32_t* rt_side;       /* [n_rt] -1 inner, else side */
+  const int32_t* side_elem;     /* [4][ncf] our element at position pos of a side */
+  const int32_t* side_elem_out; /* [4][ncf] the neighbour's element there */
+  const int32_t* side_count;    /* [4] */
+  const double* grad;           /* [n_T][3][2] grad phi_i */
+  const double* area;           /* [n_T] */
+  const double* normal;         /* [n_T][3][2] outward unit normals */
+  const double* face_len;       /* [n_T][3] */
+  const double* points;         /* [n_T][3][2] vertex coordinates relative to the subdomain origin */
+} lrbms_mesh_desc;
+
+/* -- context ------------------------------------------------------------------------------------------- */
+int lrbms_ctx_create(int device, lrbms_ctx** out);
+int lrbms_ctx_destroy(lrbms_ctx* ctx);
+const char* lrbms_last_error(lrbms_ctx* ctx);
+const char* lrbms_version(void);
+
+/* Upload template + neighbour table.  nbr [S][5]: index into the S_ext ordering per slot, -1 = none,
+ * nbr[s][2] == s.  (K0; reference grid.py:8-42, block_swipdg.py:66-70,78,393,421.) */
+int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* desc, int32_t S, int32_t S_ext, const int32_t* nbr);
+
+/* -- offline assembly (not in the timed project+estimate region) ---------------------------------------- */
+/* K1-K3: SWIPDG system per affine component; replaces make_elliptic_swipdg_affine_factor_matrix_operator
+ * + the coupling / boundary assemblers (block_swipdg.py:399-437) and the block axpy of :475-497.
+ *   lam    [Q][S_ext][n_T][NS]  samples of lambda_q
+ *   A_diag [Q][S][n_T][4][9]    block-ELL: block 0 = (e,e), block 1+f = (e, inner neighbour across face f)
+ *   A_cpl  [Q][S][4][ncf][9]    block (ii, neighbour at side) per coupling face: rows side_elem, cols side_elem_out */
+int lrbms_assemble_swipdg(lrbms_ctx* ctx, int32_t Q, const double* lam, double* A_diag, double* A_cpl, void* stream);
+
+/* K5 + scalars: replaces make_l2_volume_vector_functional (block_swipdg.py:518-521), apply_l2_product,
+ * min_diffusion_eigenvalue (:776-783).
+ *   f_smp [S][n_T][7], lhat [S][n_T][7]  ->  b [S][n], f2 [S] = ||f||^2_{L2(Omega_ii)}, ceps [S] */
+int lrbms_assemble_rhs(lrbms_ctx* ctx, const double* f_smp, const double* lhat, double* b, double* f2, double* ceps,
+                       void* stream);
+
+/* K6 + K9: local products and estimator operators (block_swipdg.py:319-378, :644-691, :722-729).
+ *   theta_bar [Q]                          host pointer, theta_q(mu_bar)
+ *   lbar, lhat [S][n_T][7]
+ *   P_diag [S][n_T][4][9]                  energy product (elliptic + penalty at mu_bar), block-ELL
+ *   ebar   [S][n_T]                        int_T lambda_bar         (E_ii = ebar * stiffness template)
+ *   caa    [Q][Q][S][n_T]                  int_T lambda_q lambda_q' / lambda_hat
+ *   Aab    [Q][S][n_T][3][3]               df_ab element blocks [i][f]
+ *   Bbb    [S][n_T][3][3]                  df_bb element blocks [f][g] */
+int lrbms_assemble_products(lrbms_ctx* ctx, int32_t Q, const double* theta_bar, const double* lam, const double* lbar,
+                            const double* lhat, double* P_diag, double* ebar, double* caa, double* Aab, double* Bbb,
+                            void* stream);
+
+/* K8 (assembly half): coefficient rows of the RT0 diffusive-flux reconstruction
+ * (RS2017_apply_diffusive_flux_reconstruction_in_neighborhood, block_swipdg.py:165-169).
+ *   F [Q][S][n_rt][6]: r_e = sum_i F[..][i] v(e0, i) + F[..][3+i] v(e1, i) */
+int lrbms_assemble_flux(lrbms_ctx* ctx, int32_t Q, const double* lam, double* F, void* stream);
+
+/* -- project + estimate-offline (the timed region: K7 + K8 + P1 + P2) ------------------------------------ */
+/* K7: OswaldInterpolationErrorOperator.apply (block_swipdg.py:83-122), target-major.
+ *   V [S_ext][n][N]  ->  Wt [S][n][5 N], column (slot, j) = component ii of oi_kk.apply(V_kk)[j] */
+int lrbms_oswald_apply(lrbms_ctx* ctx, int32_t N, const double* V, double* Wt, void* stream);
+
+/* K8: FluxReconstructionOperator.apply (block_swipdg.py:148-176), target-major.
+ *   V [S_ext][n][N], F  ->  Rt [S][n_rt][5 Q N], column (slot, q, j) */
+int lrbms_flux_reconstruct(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* F, const double* V, double* Rt,
+                           void* stream);
+
+/* P1: Galerkin projection of the system (project_system over d.operator / d.rhs / products; reductor.py:70).
+ *   work   >= Q S n N doubles of scratch
+ *   B_sys  [Q][S][5][N][N]   block (ii, neighbour in slot) of V^T A_q V, zero where no neighbour
+ *   rhs_red[S][N], E_red [S][N][N] (energy product), M_red [S][N][N] (L2) */
+int lrbms_project_system(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* A_diag,
+                         const double* A_cpl, const double* P_diag, const double* b, double* work, double* B_sys,
+                         double* rhs_red, double* E_red, double* M_red, void* stream);
+
+/* P2: projected estimator operators nc_i, r_fd_i, r_dd_i, df_aa_i, df_bb_i, df_ab_i
+ * (block_swipdg.py:733-770 projected at reductor.py:70).
+ *   work     >= lrbms_estimator_work_size(...) doubles of scratch
+ *   G_nc  [S][W][W]; r_fd [S][C]; G_rdd [S][C][C]; G_bb [S][C][C]; G_ab [Q][S][N][C]; G_aa [Q][Q][S][N][N] */
+int64_t lrbms_estimator_work_size(lrbms_ctx* ctx, int32_t Q, int32_t N);
+int lrbms_estimator_grams(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* Wt, const double* Rt,
+                          const double* ebar, const double* caa, const double* Aab, const double* Bbb,
+                          const double* b, double* work, double* G_nc, double* r_fd, double* G_rdd, double* G_bb,
+                          double* G_ab, double* G_aa, void* stream);
+
+/* -- online --------------------------------------------------------------------------------------------- */
+/* E1: EstimatorBase._estimate_elliptic on reduced coefficients (estimators.py:45-112), per-subdomain part.
+ *   theta [Q] host; u [S_ext][N]; f2, ceps [S]; hdiam scalar
+ *   eta_loc [3][S]: nc, r (scaled by (1/pi^2)/c_eps h^2), df -- squared quantities exactly as estimators.py:71-91 */
+int lrbms_reduced_estimate(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u,
+                           const double* G_nc, const double* r_fd, const double* G_rdd, const double* G_bb,
+                           const double* G_ab, const double* G_aa, const double* f2, const double* ceps, double hdiam,
+                           double* eta_loc, void* stream);
+
+/* O1: rd.solve(mu): (sum_q theta_q B_sys_q) u = rhs_red by block-Jacobi preconditioned CG on the block-sparse
+ * reduced system (single rank: S_ext == S).  work >= lrbms_reduced_solve_work_size doubles.
+ * Returns LRBMS_E_NOT_CONVERGED if the relative residual is above rtol after max_iter.  info[0] = iterations,
+ * info[1] = final relative residual (host pointers, may be NULL). */
+int64_t lrbms_reduced_solve_work_size(lrbms_ctx* ctx, int32_t N);
+int lrbms_reduced_solve(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* B_sys,
+                        const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
+                        void* stream);
+
+/* -- helpers used by the host shim and the parity tests ------------------------------------------------- */
+/* y [S][n][M] = blockELL(A [S][n_T][4][9]) x [S][n][M]   (diagonal blocks only, no coupling) */
+int lrbms_blockell_apply(lrbms_ctx* ctx, int32_t M, const double* A, const double* x, double* y, void* stream);
+/* G[b] (Mx x My) = alpha * X[b]^T diag(rowscale) Y[b]; X [batch][K][ldx], Y [batch][K][ldy]; fp64 MFMA */
+int lrbms_gemm_tn(lrbms_ctx* ctx, int32_t batch, int32_t K, int32_t Mx, int32_t My, const double* X, int64_t sx,
+                  int32_t ldx, const double* Y, int64_t sy, int32_t ldy, double* G, int64_t sg, int32_t ldg,
+                  const double* rowscale, double alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRBMS_HIP_H */

@@ -1,0 +1,59 @@
+"""Build liblrbms_hip.so in-tree with hipcc for gfx950 (no JIT cache: the .so travels with the repo snapshot)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'liblrbms_hip.so')
+SOURCES = ['capi.hip', 'assemble.hip', 'apply.hip', 'gemm.hip', 'online.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError('hipcc not found')
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'lrbms_hip.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force=False, verbose=False):
+    """Compile every HIP translation unit and link the shared library.  Returns the library path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, 'csrc', '_obj')
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for {}:\n{}'.format(src, r.stderr))
+        if verbose and r.stderr:
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n{}'.format(r.stderr))
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_native(force='--force' in sys.argv, verbose=True))

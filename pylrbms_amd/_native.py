@@ -1,0 +1,329 @@
+"""ctypes binding of liblrbms_hip.so (C ABI: include/lrbms_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails this module raises.  PyTorch is only the
+device-array container (allocation, stream handle); every number is produced by the HIP kernels.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblrbms_hip.so')
+
+c_i32, c_i64, c_dbl, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+_P_I32 = ctypes.POINTER(c_i32)
+_P_DBL = ctypes.POINTER(c_dbl)
+
+
+class MeshDesc(ctypes.Structure):
+    _fields_ = ([(k, c_i32) for k in ('kx', 'ky', 'n_T', 'n_rt', 'n_vertices', 'ncf')] +
+                [('hx', c_dbl), ('hy', c_dbl), ('kappa', c_dbl * 4)] +
+                [(k, _P_I32) for k in ('nb_elem', 'nb_face', 'nb_elem_out', 'nb_face_out', 'elem_side_pos', 'elem_rt',
+                                       'face_sign', 'dof_vertex', 'vdof_ptr', 'vdof_idx', 'rt_e0', 'rt_f0', 'rt_e1',
+                                       'rt_f1', 'rt_side', 'side_elem', 'side_elem_out', 'side_count')] +
+                [(k, _P_DBL) for k in ('grad', 'area', 'normal', 'face_len', 'points')])
+
+
+# name -> (restype, argtypes); exactly the symbols include/lrbms_hip.h declares
+SIGNATURES = {
+    'lrbms_version': (ctypes.c_char_p, []),
+    'lrbms_ctx_create': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_vp)]),
+    'lrbms_ctx_destroy': (ctypes.c_int, [c_vp]),
+    'lrbms_last_error': (ctypes.c_char_p, [c_vp]),
+    'lrbms_mesh_upload': (ctypes.c_int, [c_vp, ctypes.POINTER(MeshDesc), c_i32, c_i32, _P_I32]),
+    'lrbms_assemble_swipdg': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'lrbms_assemble_rhs': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'lrbms_assemble_products': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'lrbms_assemble_flux': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'lrbms_oswald_apply': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'lrbms_flux_reconstruct': (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'lrbms_project_system': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 11),
+    'lrbms_estimator_work_size': (c_i64, [c_vp, c_i32, c_i32]),
+    'lrbms_estimator_grams': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 16),
+    'lrbms_reduced_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 9 + [c_dbl, c_vp, c_vp]),
+    'lrbms_reduced_solve_work_size': (c_i64, [c_vp, c_i32]),
+    'lrbms_reduced_solve': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
+    'lrbms_blockell_apply': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'lrbms_gemm_tn': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp,
+                                     c_i64, c_i32, c_vp, c_dbl, c_vp]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """Load liblrbms_hip.so and bind every declared symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise NativeError('{} is missing: run `python __graft_entry__.py` (or pylrbms_amd/_build.py) to build the HIP '
+                          'extension; there is no CPU fallback'.format(path))
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)         # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = restype, argtypes
+    _lib = lib
+    return lib
+
+
+def _i32p(a):
+    return a.ctypes.data_as(_P_I32)
+
+
+def _dblp(a):
+    return a.ctypes.data_as(_P_DBL)
+
+
+class NativeContext:
+    """One lrbms_ctx per (process, device).  Tensor arguments must be contiguous float64 CUDA tensors on that device;
+    shapes are checked here, on the host, before any kernel may dereference them."""
+
+    def __init__(self, device_index=0):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise NativeError('no HIP device visible: the LRBMS hot path has no CPU fallback')
+        self.lib = load_library()
+        self.device = torch.device('cuda', device_index)
+        handle = c_vp()
+        rc = self.lib.lrbms_ctx_create(device_index, ctypes.byref(handle))
+        if rc != 0:
+            raise NativeError('lrbms_ctx_create failed with code {}'.format(rc))
+        self.handle = handle
+        self._keep = None
+        self.S = self.S_ext = None
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.lrbms_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.lrbms_last_error(self.handle)
+            raise NativeError('{} failed ({}): {}'.format(what, rc, msg.decode() if msg else ''))
+
+    def _stream(self):
+        return c_vp(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ptr(self, t, shape, name):
+        torch = self.torch
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.float64 or t.device != self.device:
+            raise NativeError('{}: expected a float64 tensor on {}'.format(name, self.device))
+        if tuple(t.shape) != tuple(shape):
+            raise NativeError('{}: expected shape {}, got {}'.format(name, tuple(shape), tuple(t.shape)))
+        if not t.is_contiguous():
+            raise NativeError('{}: tensor must be contiguous'.format(name))
+        return c_vp(t.data_ptr())
+
+    def empty(self, *shape):
+        return self.torch.empty(*shape, dtype=self.torch.float64, device=self.device)
+
+    def zeros(self, *shape):
+        return self.torch.zeros(*shape, dtype=self.torch.float64, device=self.device)
+
+    def from_numpy(self, a):
+        return self.torch.from_numpy(np.array(a, dtype=np.float64, order='C', copy=True)).to(self.device)
+
+    # ------------------------------------------------------------------ mesh
+    def mesh_upload(self, template, kappa, nbr, S, S_ext):
+        t = template
+        self.t, self.S, self.S_ext = t, int(S), int(S_ext)
+        self.n_T, self.n, self.n_rt, self.ncf = t.n_T, t.n, t.n_rt, t.ncf
+        arrs = {}
+        d = MeshDesc()
+        d.kx, d.ky, d.n_T, d.n_rt, d.n_vertices, d.ncf = t.kx, t.ky, t.n_T, t.n_rt, t.n_vertices, t.ncf
+        d.hx, d.hy = t.hx, t.hy
+        kap = np.asarray(kappa, dtype=np.float64).reshape(4)
+        for i in range(4):
+            d.kappa[i] = kap[i]
+        for k in ('nb_elem', 'nb_face', 'nb_elem_out', 'nb_face_out', 'elem_side_pos', 'elem_rt', 'face_sign',
+                  'dof_vertex', 'vdof_ptr', 'vdof_idx', 'rt_e0', 'rt_f0', 'rt_e1', 'rt_f1', 'rt_side', 'side_elem',
+                  'side_elem_out', 'side_count'):
+            arrs[k] = np.ascontiguousarray(getattr(t, k), dtype=np.int32)
+            setattr(d, k, _i32p(arrs[k]))
+        for k in ('grad', 'area', 'normal', 'face_len', 'points'):
+            arrs[k] = np.ascontiguousarray(getattr(t, k), dtype=np.float64)
+            setattr(d, k, _dblp(arrs[k]))
+        nb = np.ascontiguousarray(nbr, dtype=np.int32)
+        assert nb.shape == (S, 5)
+        rc = self.lib.lrbms_mesh_upload(self.handle, ctypes.byref(d), S, S_ext, _i32p(nb))
+        self._keep = (arrs, nb)
+        self._check(rc, 'lrbms_mesh_upload')
+
+    # ------------------------------------------------------------------ assembly
+    def assemble_swipdg(self, lam):
+        Q = lam.shape[0]
+        A_diag = self.empty(Q, self.S, self.n_T, 4, 9)
+        A_cpl = self.empty(Q, self.S, 4, self.ncf, 9)
+        rc = self.lib.lrbms_assemble_swipdg(self.handle, Q, self._ptr(lam, (Q, self.S_ext, self.n_T, 16), 'lam'),
+                                            c_vp(A_diag.data_ptr()), c_vp(A_cpl.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_assemble_swipdg')
+        return A_diag, A_cpl
+
+    def assemble_rhs(self, f_smp, lhat):
+        b, f2, ceps = self.empty(self.S, self.n), self.empty(self.S), self.empty(self.S)
+        rc = self.lib.lrbms_assemble_rhs(self.handle, self._ptr(f_smp, (self.S, self.n_T, 7), 'f_smp'),
+                                         self._ptr(lhat, (self.S, self.n_T, 7), 'lhat'), c_vp(b.data_ptr()),
+                                         c_vp(f2.data_ptr()), c_vp(ceps.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_assemble_rhs')
+        return b, f2, ceps
+
+    def assemble_products(self, theta_bar, lam, lbar, lhat):
+        Q = lam.shape[0]
+        th = np.ascontiguousarray(theta_bar, dtype=np.float64)
+        assert th.shape == (Q,)
+        P_diag = self.empty(self.S, self.n_T, 4, 9)
+        ebar = self.empty(self.S, self.n_T)
+        caa = self.empty(Q, Q, self.S, self.n_T)
+        Aab = self.empty(Q, self.S, self.n_T, 3, 3)
+        Bbb = self.empty(self.S, self.n_T, 3, 3)
+        rc = self.lib.lrbms_assemble_products(
+            self.handle, Q, _dblp(th), self._ptr(lam, (Q, self.S_ext, self.n_T, 16), 'lam'),
+            self._ptr(lbar, (self.S, self.n_T, 7), 'lbar'), self._ptr(lhat, (self.S, self.n_T, 7), 'lhat'),
+            c_vp(P_diag.data_ptr()), c_vp(ebar.data_ptr()), c_vp(caa.data_ptr()), c_vp(Aab.data_ptr()),
+            c_vp(Bbb.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_assemble_products')
+        return P_diag, ebar, caa, Aab, Bbb
+
+    def assemble_flux(self, lam):
+        Q = lam.shape[0]
+        F = self.empty(Q, self.S, self.n_rt, 6)
+        rc = self.lib.lrbms_assemble_flux(self.handle, Q, self._ptr(lam, (Q, self.S_ext, self.n_T, 16), 'lam'),
+                                          c_vp(F.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_assemble_flux')
+        return F
+
+    # ------------------------------------------------------------------ project + estimate-offline
+    def oswald_apply(self, V, out=None):
+        N = V.shape[2]
+        Wt = out if out is not None else self.empty(self.S, self.n, 5 * N)
+        rc = self.lib.lrbms_oswald_apply(self.handle, N, self._ptr(V, (self.S_ext, self.n, N), 'V'),
+                                         self._ptr(Wt, (self.S, self.n, 5 * N), 'Wt'), self._stream())
+        self._check(rc, 'lrbms_oswald_apply')
+        return Wt
+
+    def flux_reconstruct(self, F, V, out=None):
+        Q, N = F.shape[0], V.shape[2]
+        Rt = out if out is not None else self.empty(self.S, self.n_rt, 5 * Q * N)
+        rc = self.lib.lrbms_flux_reconstruct(self.handle, Q, N, self._ptr(F, (Q, self.S, self.n_rt, 6), 'F'),
+                                             self._ptr(V, (self.S_ext, self.n, N), 'V'),
+                                             self._ptr(Rt, (self.S, self.n_rt, 5 * Q * N), 'Rt'), self._stream())
+        self._check(rc, 'lrbms_flux_reconstruct')
+        return Rt
+
+    def project_system(self, V, A_diag, A_cpl, P_diag, b, work=None, out=None):
+        Q, N, S = A_diag.shape[0], V.shape[2], self.S
+        if work is None:
+            work = self.empty(Q * S * self.n * N)
+        if work.numel() < Q * S * self.n * N:
+            raise NativeError('project_system: work too small')
+        if out is None:
+            out = (self.empty(Q, S, 5, N, N), self.empty(S, N), self.empty(S, N, N), self.empty(S, N, N))
+        B_sys, rhs_red, E_red, M_red = out
+        rc = self.lib.lrbms_project_system(
+            self.handle, Q, N, self._ptr(V, (self.S_ext, self.n, N), 'V'),
+            self._ptr(A_diag, (Q, S, self.n_T, 4, 9), 'A_diag'), self._ptr(A_cpl, (Q, S, 4, self.ncf, 9), 'A_cpl'),
+            self._ptr(P_diag, (S, self.n_T, 4, 9), 'P_diag'), self._ptr(b, (S, self.n), 'b'), c_vp(work.data_ptr()),
+            self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'), self._ptr(rhs_red, (S, N), 'rhs_red'),
+            self._ptr(E_red, (S, N, N), 'E_red'), self._ptr(M_red, (S, N, N), 'M_red'), self._stream())
+        self._check(rc, 'lrbms_project_system')
+        return B_sys, rhs_red, E_red, M_red
+
+    def estimator_work_size(self, Q, N):
+        sz = self.lib.lrbms_estimator_work_size(self.handle, Q, N)
+        if sz < 0:
+            raise NativeError('lrbms_estimator_work_size failed')
+        return int(sz)
+
+    def estimator_grams(self, V, Wt, Rt, ebar, caa, Aab, Bbb, b, work=None, out=None):
+        Q, N, S = caa.shape[0], V.shape[2], self.S
+        W, C = 5 * N, 5 * Q * N
+        need = self.estimator_work_size(Q, N)
+        if work is None:
+            work = self.empty(need)
+        if work.numel() < need:
+            raise NativeError('estimator_grams: work too small')
+        if out is None:
+            out = (self.empty(S, W, W), self.empty(S, C), self.empty(S, C, C), self.empty(S, C, C),
+                   self.empty(Q, S, N, C), self.empty(Q, Q, S, N, N))
+        G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = out
+        rc = self.lib.lrbms_estimator_grams(
+            self.handle, Q, N, self._ptr(V, (self.S_ext, self.n, N), 'V'), self._ptr(Wt, (S, self.n, W), 'Wt'),
+            self._ptr(Rt, (S, self.n_rt, C), 'Rt'), self._ptr(ebar, (S, self.n_T), 'ebar'),
+            self._ptr(caa, (Q, Q, S, self.n_T), 'caa'), self._ptr(Aab, (Q, S, self.n_T, 3, 3), 'Aab'),
+            self._ptr(Bbb, (S, self.n_T, 3, 3), 'Bbb'), self._ptr(b, (S, self.n), 'b'), c_vp(work.data_ptr()),
+            self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, C, C), 'G_rdd'),
+            self._ptr(G_bb, (S, C, C), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
+            self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._stream())
+        self._check(rc, 'lrbms_estimator_grams')
+        return G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa
+
+    # ------------------------------------------------------------------ online
+    def reduced_estimate(self, theta, u, grams, f2, ceps, hdiam):
+        G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = grams
+        Q, S, N = G_ab.shape[0], self.S, G_ab.shape[2]
+        W, C = 5 * N, 5 * Q * N
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        assert th.shape == (Q,)
+        eta = self.empty(3, S)
+        rc = self.lib.lrbms_reduced_estimate(
+            self.handle, Q, N, _dblp(th), self._ptr(u, (self.S_ext, N), 'u'), self._ptr(G_nc, (S, W, W), 'G_nc'),
+            self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, C, C), 'G_rdd'), self._ptr(G_bb, (S, C, C), 'G_bb'),
+            self._ptr(G_ab, (Q, S, N, C), 'G_ab'), self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._ptr(f2, (S,), 'f2'),
+            self._ptr(ceps, (S,), 'ceps'), float(hdiam), c_vp(eta.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_reduced_estimate')
+        return eta
+
+    def reduced_solve(self, theta, B_sys, rhs_red, rtol=1e-13, max_iter=20000, work=None):
+        Q, S, N = B_sys.shape[0], self.S, B_sys.shape[3]
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        assert th.shape == (Q,)
+        need = int(self.lib.lrbms_reduced_solve_work_size(self.handle, N))
+        if work is None:
+            work = self.empty(need)
+        if work.numel() < need:
+            raise NativeError('reduced_solve: work too small')
+        u = self.empty(S, N)
+        info = np.zeros(2)
+        rc = self.lib.lrbms_reduced_solve(self.handle, Q, N, _dblp(th), self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'),
+                                          self._ptr(rhs_red, (S, N), 'rhs_red'), c_vp(work.data_ptr()),
+                                          c_vp(u.data_ptr()), float(rtol), int(max_iter), _dblp(info), self._stream())
+        self._check(rc, 'lrbms_reduced_solve')
+        return u, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
+
+    # ------------------------------------------------------------------ helpers
+    def blockell_apply(self, A, x):
+        M = x.shape[2]
+        y = self.empty(self.S, self.n, M)
+        rc = self.lib.lrbms_blockell_apply(self.handle, M, self._ptr(A, (self.S, self.n_T, 4, 9), 'A'),
+                                           self._ptr(x, (self.S, self.n, M), 'x'), c_vp(y.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_blockell_apply')
+        return y
+
+    def gemm_tn(self, X, Y, rowscale=None, alpha=1.0):
+        """G[b] = alpha X[b]^T diag(rowscale) Y[b] for X [B, K, Mx], Y [B, K, My]."""
+        B, K, Mx = X.shape
+        My = Y.shape[2]
+        assert Y.shape[:2] == (B, K)
+        G = self.empty(B, Mx, My)
+        rs = c_vp(rowscale.data_ptr()) if rowscale is not None else c_vp(None)
+        rc = self.lib.lrbms_gemm_tn(self.handle, B, K, Mx, My, self._ptr(X, (B, K, Mx), 'X'), K * Mx, Mx,
+                                    self._ptr(Y, (B, K, My), 'Y'), K * My, My, c_vp(G.data_ptr()), Mx * My, My, rs,
+                                    float(alpha), self._stream())
+        self._check(rc, 'lrbms_gemm_tn')
+        return G

@@ -1,0 +1,234 @@
+// C ABI of liblrbms_hip.so (declared in include/lrbms_hip.h): context, mesh upload, argument checks, dispatch.
+#include <cmath>
+#include <cstring>
+
+#include "lrbms_dev.h"
+
+int64_t estimator_work_size(lrbms_ctx* ctx, int Q, int N);
+int64_t reduced_solve_work_size(lrbms_ctx* ctx, int N);
+
+namespace {
+
+template <typename T>
+int upload(lrbms_ctx* ctx, const T* host, size_t count, const T** dev) {
+  if (!host) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: null template array");
+  void* p = nullptr;
+  LRBMS_HIP_CHECK(ctx, hipMalloc(&p, sizeof(T) * (count ? count : 1)));
+  ctx->owned.push_back(p);
+  LRBMS_HIP_CHECK(ctx, hipMemcpy(p, host, sizeof(T) * count, hipMemcpyHostToDevice));
+  *dev = static_cast<const T*>(p);
+  return LRBMS_OK;
+}
+
+void free_owned(lrbms_ctx* ctx) {
+  for (void* p : ctx->owned) (void)hipFree(p);
+  ctx->owned.clear();
+  ctx->nbr = nullptr;
+  ctx->has_mesh = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lrbms_version(void) { return "lrbms_hip 0.1.0 (gfx950)"; }
+
+int lrbms_ctx_create(int device, lrbms_ctx** out) {
+  if (!out) return LRBMS_E_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return LRBMS_E_HIP;
+  if (hipSetDevice(device) != hipSuccess) return LRBMS_E_HIP;
+  lrbms_ctx* ctx = new (std::nothrow) lrbms_ctx();
+  if (!ctx) return LRBMS_E_INVALID;
+  ctx->device = device;
+  *out = ctx;
+  return LRBMS_OK;
+}
+
+int lrbms_ctx_destroy(lrbms_ctx* ctx) {
+  if (!ctx) return LRBMS_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  free_owned(ctx);
+  delete ctx;
+  return LRBMS_OK;
+}
+
+const char* lrbms_last_error(lrbms_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* d, int32_t S, int32_t S_ext, const int32_t* nbr) {
+  if (!ctx || !d || !nbr) return LRBMS_E_INVALID;
+  if (S <= 0 || S_ext < S) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: need 0 < S <= S_ext");
+  if (d->kx <= 0 || d->ky <= 0 || d->n_T != 8 * d->kx * d->ky || d->n_rt <= 0 ||
+      d->n_vertices != (2 * d->kx + 1) * (2 * d->ky + 1) || d->ncf != 2 * (d->kx > d->ky ? d->kx : d->ky))
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: inconsistent template sizes");
+  for (int i = 0; i < S; ++i) {
+    for (int k = 0; k < 5; ++k) {
+      const int v = nbr[i * 5 + k];
+      if (v < -1 || v >= S_ext) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: neighbour index out of range");
+    }
+    if (nbr[i * 5 + 2] != i) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: nbr[s][2] must be s");
+  }
+  // validate the template indices on the host before any kernel may dereference them
+  const int nT = d->n_T, n = 3 * nT;
+  for (int i = 0; i < 3 * nT; ++i) {
+    if (d->nb_elem[i] >= nT || d->nb_elem[i] < -4) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: nb_elem out of range");
+    if (d->nb_elem[i] < 0 && (d->nb_elem_out[i] < 0 || d->nb_elem_out[i] >= nT || d->elem_side_pos[i] < 0 ||
+                              d->elem_side_pos[i] >= d->ncf || d->nb_face_out[i] < 0 || d->nb_face_out[i] > 2))
+      return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: side face pairing out of range");
+    if (d->nb_face[i] < 0 || d->nb_face[i] > 2) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: nb_face out of range");
+    if (d->elem_rt[i] < 0 || d->elem_rt[i] >= d->n_rt) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: elem_rt out of range");
+    if (d->dof_vertex[i] < 0 || d->dof_vertex[i] >= d->n_vertices || d->vdof_idx[i] < 0 || d->vdof_idx[i] >= n)
+      return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: vertex star out of range");
+  }
+  if (d->vdof_ptr[0] != 0 || d->vdof_ptr[d->n_vertices] != n) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: bad vdof_ptr");
+  for (int v = 0; v < d->n_vertices; ++v)
+    if (d->vdof_ptr[v + 1] < d->vdof_ptr[v]) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: vdof_ptr not monotone");
+  for (int r = 0; r < d->n_rt; ++r) {
+    if (d->rt_e0[r] < 0 || d->rt_e0[r] >= nT || d->rt_f0[r] < 0 || d->rt_f0[r] > 2 || d->rt_side[r] < -1 || d->rt_side[r] > 3 ||
+        d->rt_e1[r] < 0 || d->rt_e1[r] >= nT || d->rt_f1[r] < 0 || d->rt_f1[r] > 2)
+      return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: rt face table out of range");
+  }
+  for (int sd = 0; sd < 4; ++sd) {
+    if (d->side_count[sd] < 0 || d->side_count[sd] > d->ncf) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: side_count");
+    for (int p = 0; p < d->side_count[sd]; ++p)
+      if (d->side_elem[sd * d->ncf + p] < 0 || d->side_elem[sd * d->ncf + p] >= nT || d->side_elem_out[sd * d->ncf + p] < 0 ||
+          d->side_elem_out[sd * d->ncf + p] >= nT)
+        return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: side element out of range");
+  }
+
+  LRBMS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  free_owned(ctx);
+  Tmpl& t = ctx->t;
+  t.kx = d->kx; t.ky = d->ky; t.nT = nT; t.n = n; t.nrt = d->n_rt; t.nv = d->n_vertices;
+  t.nvx = 2 * d->kx + 1; t.nvy = 2 * d->ky + 1; t.ncf = d->ncf; t.hx = d->hx; t.hy = d->hy;
+  std::memcpy(t.kappa, d->kappa, sizeof(double) * 4);
+  const double det = t.kappa[0] * t.kappa[3] - t.kappa[1] * t.kappa[2];
+  if (!(det > 0.0)) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: kappa must be positive definite");
+  t.kinv[0] = t.kappa[3] / det; t.kinv[1] = -t.kappa[1] / det; t.kinv[2] = -t.kappa[2] / det; t.kinv[3] = t.kappa[0] / det;
+  const double a = t.kappa[0], b = 0.5 * (t.kappa[1] + t.kappa[2]), c = t.kappa[3];
+  t.kmin = 0.5 * (a + c) - std::sqrt(0.25 * (a - c) * (a - c) + b * b);
+  int rc;
+#define UP(field, count) if ((rc = upload(ctx, d->field, (size_t)(count), &t.field))) return rc
+  UP(nb_elem, 3 * nT); UP(nb_face, 3 * nT); UP(nb_elem_out, 3 * nT); UP(nb_face_out, 3 * nT); UP(elem_side_pos, 3 * nT);
+  UP(elem_rt, 3 * nT); UP(face_sign, 3 * nT); UP(dof_vertex, n); UP(vdof_ptr, d->n_vertices + 1); UP(vdof_idx, n);
+  UP(rt_e0, d->n_rt); UP(rt_f0, d->n_rt); UP(rt_e1, d->n_rt); UP(rt_f1, d->n_rt); UP(rt_side, d->n_rt);
+  UP(side_elem, 4 * d->ncf); UP(side_elem_out, 4 * d->ncf); UP(side_count, 4);
+  UP(grad, 6 * nT); UP(area, nT); UP(normal, 6 * nT); UP(face_len, 3 * nT); UP(points, 6 * nT);
+#undef UP
+  const int* nbr_dev = nullptr;
+  if ((rc = upload(ctx, nbr, (size_t)S * 5, &nbr_dev))) return rc;
+  ctx->nbr = const_cast<int*>(nbr_dev);
+  ctx->S = S;
+  ctx->S_ext = S_ext;
+  ctx->has_mesh = true;
+  return LRBMS_OK;
+}
+
+#define CHECK_Q_N(ctx, Q, N)                                                                        \
+  do {                                                                                              \
+    if ((Q) < 1 || (Q) > 8) return lrbms_fail(ctx, LRBMS_E_INVALID, "Q must be in 1..8");            \
+    if ((N) < 1) return lrbms_fail(ctx, LRBMS_E_INVALID, "N must be >= 1");                          \
+  } while (0)
+#define CHECK_PTR(ctx, p) \
+  do { if (!(p)) return lrbms_fail(ctx, LRBMS_E_INVALID, "null pointer: " #p); } while (0)
+
+int lrbms_assemble_swipdg(lrbms_ctx* ctx, int32_t Q, const double* lam, double* A_diag, double* A_cpl, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, 1); CHECK_PTR(ctx, lam); CHECK_PTR(ctx, A_diag); CHECK_PTR(ctx, A_cpl);
+  return launch_assemble_swipdg(ctx, Q, lam, A_diag, A_cpl, (hipStream_t)stream);
+}
+
+int lrbms_assemble_rhs(lrbms_ctx* ctx, const double* f_smp, const double* lhat, double* b, double* f2, double* ceps,
+                       void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_PTR(ctx, f_smp); CHECK_PTR(ctx, lhat); CHECK_PTR(ctx, b); CHECK_PTR(ctx, f2); CHECK_PTR(ctx, ceps);
+  return launch_assemble_rhs(ctx, f_smp, lhat, b, f2, ceps, (hipStream_t)stream);
+}
+
+int lrbms_assemble_products(lrbms_ctx* ctx, int32_t Q, const double* theta_bar, const double* lam, const double* lbar,
+                            const double* lhat, double* P_diag, double* ebar, double* caa, double* Aab, double* Bbb,
+                            void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, 1); CHECK_PTR(ctx, theta_bar); CHECK_PTR(ctx, lam); CHECK_PTR(ctx, lbar);
+  CHECK_PTR(ctx, lhat); CHECK_PTR(ctx, P_diag); CHECK_PTR(ctx, ebar); CHECK_PTR(ctx, caa); CHECK_PTR(ctx, Aab); CHECK_PTR(ctx, Bbb);
+  return launch_assemble_products(ctx, Q, theta_bar, lam, lbar, lhat, P_diag, ebar, caa, Aab, Bbb, (hipStream_t)stream);
+}
+
+int lrbms_assemble_flux(lrbms_ctx* ctx, int32_t Q, const double* lam, double* F, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, 1); CHECK_PTR(ctx, lam); CHECK_PTR(ctx, F);
+  return launch_assemble_flux(ctx, Q, lam, F, (hipStream_t)stream);
+}
+
+int lrbms_oswald_apply(lrbms_ctx* ctx, int32_t N, const double* V, double* Wt, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, 1, N); CHECK_PTR(ctx, V); CHECK_PTR(ctx, Wt);
+  return launch_oswald(ctx, N, V, Wt, (hipStream_t)stream);
+}
+
+int lrbms_flux_reconstruct(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* F, const double* V, double* Rt, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, F); CHECK_PTR(ctx, V); CHECK_PTR(ctx, Rt);
+  return launch_flux(ctx, Q, N, F, V, Rt, (hipStream_t)stream);
+}
+
+int lrbms_project_system(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* A_diag, const double* A_cpl,
+                         const double* P_diag, const double* b, double* work, double* B_sys, double* rhs_red, double* E_red,
+                         double* M_red, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, V); CHECK_PTR(ctx, A_diag); CHECK_PTR(ctx, A_cpl);
+  CHECK_PTR(ctx, P_diag); CHECK_PTR(ctx, b); CHECK_PTR(ctx, work); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red);
+  CHECK_PTR(ctx, E_red); CHECK_PTR(ctx, M_red);
+  if ((size_t)2 * 3 * ctx->t.ncf * N * sizeof(double) > 64 * 1024)
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "project_system: coupling tile exceeds 64 KB of LDS");
+  return launch_project_system(ctx, Q, N, V, A_diag, A_cpl, P_diag, b, work, B_sys, rhs_red, E_red, M_red, (hipStream_t)stream);
+}
+
+int64_t lrbms_estimator_work_size(lrbms_ctx* ctx, int32_t Q, int32_t N) {
+  if (!ctx || !ctx->has_mesh || Q < 1 || N < 1) return -1;
+  return estimator_work_size(ctx, Q, N);
+}
+
+int lrbms_estimator_grams(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* Wt, const double* Rt,
+                          const double* ebar, const double* caa, const double* Aab, const double* Bbb, const double* b,
+                          double* work, double* G_nc, double* r_fd, double* G_rdd, double* G_bb, double* G_ab, double* G_aa,
+                          void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, V); CHECK_PTR(ctx, Wt); CHECK_PTR(ctx, Rt); CHECK_PTR(ctx, ebar);
+  CHECK_PTR(ctx, caa); CHECK_PTR(ctx, Aab); CHECK_PTR(ctx, Bbb); CHECK_PTR(ctx, b); CHECK_PTR(ctx, work); CHECK_PTR(ctx, G_nc);
+  CHECK_PTR(ctx, r_fd); CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa);
+  return launch_estimator_grams(ctx, Q, N, V, Wt, Rt, ebar, caa, Aab, Bbb, b, work, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa,
+                                (hipStream_t)stream);
+}
+
+int lrbms_reduced_estimate(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u, const double* G_nc,
+                           const double* r_fd, const double* G_rdd, const double* G_bb, const double* G_ab, const double* G_aa,
+                           const double* f2, const double* ceps, double hdiam, double* eta_loc, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, u); CHECK_PTR(ctx, G_nc); CHECK_PTR(ctx, r_fd);
+  CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa); CHECK_PTR(ctx, f2); CHECK_PTR(ctx, ceps);
+  CHECK_PTR(ctx, eta_loc);
+  if ((size_t)(5 * N + 5 * Q * N + 256) * sizeof(double) > 64 * 1024)
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate: coefficient tile exceeds 64 KB of LDS");
+  return launch_reduced_estimate(ctx, Q, N, theta, u, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, f2, ceps, hdiam, eta_loc,
+                                 (hipStream_t)stream);
+}
+
+int64_t lrbms_reduced_solve_work_size(lrbms_ctx* ctx, int32_t N) {
+  if (!ctx || !ctx->has_mesh || N < 1) return -1;
+  return reduced_solve_work_size(ctx, N);
+}
+
+int lrbms_reduced_solve(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* B_sys, const double* rhs_red,
+                        double* work, double* u, double rtol, int32_t max_iter, double* info, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red);
+  CHECK_PTR(ctx, work); CHECK_PTR(ctx, u);
+  return launch_reduced_solve(ctx, Q, N, theta, B_sys, rhs_red, work, u, rtol, max_iter, info, (hipStream_t)stream);
+}
+
+int lrbms_blockell_apply(lrbms_ctx* ctx, int32_t M, const double* A, const double* x, double* y, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, 1, M); CHECK_PTR(ctx, A); CHECK_PTR(ctx, x); CHECK_PTR(ctx, y);
+  return launch_blockell_apply(ctx, ctx->S, M, A, (long)ctx->t.nT * 36, x, y, (hipStream_t)stream);
+}
+
+int lrbms_gemm_tn(lrbms_ctx* ctx, int32_t batch, int32_t K, int32_t Mx, int32_t My, const double* X, int64_t sx, int32_t ldx,
+                  const double* Y, int64_t sy, int32_t ldy, double* G, int64_t sg, int32_t ldg, const double* rowscale,
+                  double alpha, void* stream) {
+  if (!ctx) return LRBMS_E_INVALID;
+  CHECK_PTR(ctx, X); CHECK_PTR(ctx, Y); CHECK_PTR(ctx, G);
+  return launch_gemm_tn(ctx, batch, K, Mx, My, X, sx, ldx, Y, sy, ldy, G, sg, ldg, rowscale, alpha, (hipStream_t)stream);
+}
+
+}  // extern "C"

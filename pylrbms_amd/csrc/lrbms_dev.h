@@ -1,0 +1,102 @@
+// Internal definitions shared by the HIP translation units of liblrbms_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/lrbms_hip.h"
+
+// Device view of the subdomain template (all pointers into one ctx-owned device allocation).
+struct Tmpl {
+  int kx, ky, nT, n, nrt, nv, nvx, nvy, ncf;
+  double hx, hy;
+  double kappa[4], kinv[4], kmin;
+  const int *nb_elem, *nb_face, *nb_elem_out, *nb_face_out, *elem_side_pos, *elem_rt, *face_sign;
+  const int *dof_vertex, *vdof_ptr, *vdof_idx;
+  const int *rt_e0, *rt_f0, *rt_e1, *rt_f1, *rt_side;
+  const int *side_elem, *side_elem_out, *side_count;
+  const double *grad, *area, *normal, *face_len, *points;
+};
+
+struct lrbms_ctx {
+  int device = 0;
+  bool has_mesh = false;
+  Tmpl t{};
+  int S = 0, S_ext = 0;
+  int* nbr = nullptr;             // [S][5] device
+  std::vector<void*> owned;       // device allocations to free
+  std::string err;
+};
+
+#define LRBMS_NQV 7
+#define LRBMS_NQF 3
+
+// SWIPDG constants (dune-gdt elliptic-ipdg.hh: inner_sigma / boundary_sigma for polorder <= 1), beta = 1/(d-1) = 1
+#define SIGMA_INNER 8.0
+#define SIGMA_BOUNDARY 14.0
+
+// 7-point Radon rule (degree 5) in barycentric coordinates and 3-point Gauss on [0,1];
+// same rule the oracle fixes in oracle/quadrature.py (documented in DESIGN.md section 3).
+__device__ __constant__ static const double c_tri_w[7] = {
+    0.225, 0.13239415278850618, 0.13239415278850618, 0.13239415278850618,
+    0.12593918054482715, 0.12593918054482715, 0.12593918054482715};
+__device__ __constant__ static const double c_tri_b[7][3] = {
+    {1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0},
+    {0.05971587178976982, 0.47014206410511509, 0.47014206410511509},
+    {0.47014206410511509, 0.05971587178976982, 0.47014206410511509},
+    {0.47014206410511509, 0.47014206410511509, 0.05971587178976982},
+    {0.79742698535308732, 0.10128650732345634, 0.10128650732345634},
+    {0.10128650732345634, 0.79742698535308732, 0.10128650732345634},
+    {0.10128650732345634, 0.10128650732345634, 0.79742698535308732}};
+__device__ __constant__ static const double c_edge_t[3] = {0.11270166537925831, 0.5, 0.88729833462074169};
+__device__ __constant__ static const double c_edge_w[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
+
+__host__ __device__ inline int side_to_slot(int side) { return side < 2 ? side : side + 1; }
+__host__ __device__ inline int slot_to_side(int slot) { return slot < 2 ? slot : slot - 1; }  // slot != 2
+
+static inline int lrbms_fail(lrbms_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define LRBMS_HIP_CHECK(ctx, expr)                                                                  \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      return lrbms_fail(ctx, LRBMS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+  } while (0)
+
+#define LRBMS_REQUIRE_MESH(ctx)                                                      \
+  do {                                                                               \
+    if (!(ctx)) return LRBMS_E_INVALID;                                              \
+    if (!(ctx)->has_mesh) return lrbms_fail(ctx, LRBMS_E_STATE, "mesh not uploaded"); \
+  } while (0)
+
+#define LRBMS_LAUNCH_CHECK(ctx) LRBMS_HIP_CHECK(ctx, hipGetLastError())
+
+// launchers implemented in the other translation units
+int launch_assemble_swipdg(lrbms_ctx*, int Q, const double* lam, double* A_diag, double* A_cpl, hipStream_t);
+int launch_assemble_rhs(lrbms_ctx*, const double* f_smp, const double* lhat, double* b, double* f2, double* ceps, hipStream_t);
+int launch_assemble_products(lrbms_ctx*, int Q, const double* theta_bar_dev, const double* lam, const double* lbar,
+                             const double* lhat, double* P_diag, double* ebar, double* caa, double* Aab, double* Bbb,
+                             hipStream_t);
+int launch_assemble_flux(lrbms_ctx*, int Q, const double* lam, double* F, hipStream_t);
+int launch_oswald(lrbms_ctx*, int N, const double* V, double* Wt, hipStream_t);
+int launch_flux(lrbms_ctx*, int Q, int N, const double* F, const double* V, double* Rt, hipStream_t);
+int launch_blockell_apply(lrbms_ctx*, int S, int M, const double* A, long sA, const double* x, double* y, hipStream_t);
+int launch_gemm_tn(lrbms_ctx*, int batch, int K, int Mx, int My, const double* X, long sx, int ldx, const double* Y,
+                   long sy, int ldy, double* G, long sg, int ldg, const double* rowscale, double alpha, hipStream_t);
+int launch_project_system(lrbms_ctx*, int Q, int N, const double* V, const double* A_diag, const double* A_cpl,
+                          const double* P_diag, const double* b, double* work, double* B_sys, double* rhs_red,
+                          double* E_red, double* M_red, hipStream_t);
+int launch_estimator_grams(lrbms_ctx*, int Q, int N, const double* V, const double* Wt, const double* Rt,
+                           const double* ebar, const double* caa, const double* Aab, const double* Bbb, const double* b,
+                           double* work, double* G_nc, double* r_fd, double* G_rdd, double* G_bb, double* G_ab,
+                           double* G_aa, hipStream_t);
+int launch_reduced_estimate(lrbms_ctx*, int Q, int N, const double* theta_dev, const double* u, const double* G_nc,
+                            const double* r_fd, const double* G_rdd, const double* G_bb, const double* G_ab,
+                            const double* G_aa, const double* f2, const double* ceps, double hdiam, double* eta_loc,
+                            hipStream_t);
+int launch_reduced_solve(lrbms_ctx*, int Q, int N, const double* theta, const double* B_sys, const double* rhs_red,
+                         double* work, double* u, double rtol, int max_iter, double* info, hipStream_t);

@@ -1,0 +1,323 @@
+// Online kernels.
+//
+// E1 streams every projected estimator operator of a subdomain once (HBM-bound: ~3.3 MB per subdomain at N = 40)
+// and forms the quadratic forms with fixed-order reductions.  O1 solves the block-sparse reduced system by
+// block-Jacobi preconditioned CG; the matrix (S x 5 blocks of N x N) is assembled once per mu and then lives in
+// the Infinity Cache for the iteration.  All reductions are fixed-order trees (no fp64 atomics) so that results are
+// bitwise reproducible run to run.
+#include "lrbms_dev.h"
+
+struct QVec { double v[8]; };
+
+namespace {
+
+__device__ inline double block_reduce_sum(double v, double* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  double out = red[0];
+  __syncthreads();
+  return out;
+}
+
+// sum_r x[r] sum_c G[r][c] y[c]: waves over rows, lanes over columns (coalesced), per-thread partial
+__device__ inline double quad_partial(const double* __restrict__ G, int ld, int rows, int cols, const double* x,
+                                      const double* y) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  double acc = 0.0;
+  for (int r = wave; r < rows; r += nw) {
+    const double xr = x[r];
+    if (xr == 0.0) continue;
+    const double* row = G + (long)r * ld;
+    double s = 0.0;
+    for (int c = lane; c < cols; c += 64) s += row[c] * y[c];
+    acc += xr * s;
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// E1: one workgroup per subdomain.
+__global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __restrict__ nbr, int Q, int N, QVec theta,
+                                                          const double* __restrict__ u, const double* __restrict__ G_nc,
+                                                          const double* __restrict__ r_fd, const double* __restrict__ G_rdd,
+                                                          const double* __restrict__ G_bb, const double* __restrict__ G_ab,
+                                                          const double* __restrict__ G_aa, const double* __restrict__ f2,
+                                                          const double* __restrict__ ceps, double hdiam,
+                                                          double* __restrict__ eta_loc) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x;
+  const int W = 5 * N, C = 5 * Q * N;
+  double* uo = lds;            // [W]
+  double* ur = lds + W;        // [C]
+  double* red = ur + C;        // [256]
+  for (int i = threadIdx.x; i < W; i += blockDim.x) {
+    const int slot = i / N, j = i % N;
+    const int s2 = nbr[s * 5 + slot];
+    const double val = s2 >= 0 ? u[(long)s2 * N + j] : 0.0;
+    uo[i] = val;
+    for (int q = 0; q < Q; ++q) ur[(slot * Q + q) * N + j] = theta.v[q] * val;
+  }
+  __syncthreads();
+  const double* ui = uo + 2 * N;
+  double p_nc = quad_partial(G_nc + (long)s * W * W, W, W, W, uo, uo);
+  double p_rdd = quad_partial(G_rdd + (long)s * C * C, C, C, C, ur, ur);
+  double p_bb = quad_partial(G_bb + (long)s * C * C, C, C, C, ur, ur);
+  double p_rfd = 0.0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) p_rfd += r_fd[(long)s * C + c] * ur[c];
+  double p_ab = 0.0, p_aa = 0.0;
+  for (int q = 0; q < Q; ++q) {
+    p_ab += theta.v[q] * quad_partial(G_ab + ((long)q * S + s) * N * C, C, N, C, ui, ur);
+    for (int q2 = 0; q2 < Q; ++q2)
+      p_aa += theta.v[q] * theta.v[q2] * quad_partial(G_aa + (((long)q * Q + q2) * S + s) * N * N, N, N, N, ui, ui);
+  }
+  const double nc = block_reduce_sum(p_nc, red);
+  const double rdd = block_reduce_sum(p_rdd, red);
+  const double bb = block_reduce_sum(p_bb, red);
+  const double rfd = block_reduce_sum(p_rfd, red);
+  const double ab = block_reduce_sum(p_ab, red);
+  const double aa = block_reduce_sum(p_aa, red);
+  if (threadIdx.x == 0) {
+    const double pi = 3.14159265358979323846;
+    eta_loc[s] = nc;
+    eta_loc[S + s] = (f2[s] - 2.0 * rfd + rdd) * ((1.0 / (pi * pi)) / ceps[s]) * hdiam * hdiam;   // estimators.py:88-91
+    eta_loc[2 * S + s] = aa + bb + 2.0 * ab;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// O1 pieces
+// Amu[s][slot] = sum_q theta_q B_sys[q][s][slot]
+__global__ __launch_bounds__(256) void k_assemble_mu(long per_q, int Q, QVec theta, const double* __restrict__ B_sys,
+                                                     double* __restrict__ Amu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_q; i += (long)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int q = 0; q < Q; ++q) acc += theta.v[q] * B_sys[(long)q * per_q + i];
+    Amu[i] = acc;
+  }
+}
+
+// Dinv[s] = inverse of the SPD diagonal block Amu[s][2] by Gauss-Jordan without pivoting in LDS (N <= 64)
+__global__ __launch_bounds__(64) void k_block_inverse(int N, const double* __restrict__ Amu, double* __restrict__ Dinv) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x;
+  double* A = lds;           // [N][N]
+  double* I = lds + N * N;   // [N][N]
+  const double* src = Amu + ((long)s * 5 + 2) * N * N;
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
+    A[i] = src[i];
+    I[i] = (i / N == i % N) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int r = threadIdx.x;
+  for (int k = 0; k < N; ++k) {
+    const double piv = 1.0 / A[k * N + k];
+    __syncthreads();
+    if (r < N) {
+      A[k * N + r] *= piv;   // thread r scales column entries of row k
+      I[k * N + r] *= piv;
+    }
+    __syncthreads();
+    if (r < N && r != k) {
+      const double f = A[r * N + k];
+      for (int c = 0; c < N; ++c) {
+        A[r * N + c] -= f * A[k * N + c];
+        I[r * N + c] -= f * I[k * N + c];
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) Dinv[(long)s * N * N + i] = I[i];
+}
+
+// y_s = sum_slot Amu[s][slot] p_{nbr(s,slot)};  partial[s] = p_s . y_s.  One wave per subdomain.
+__global__ __launch_bounds__(64) void k_cg_matvec(const int* __restrict__ nbr, int N, const double* __restrict__ Amu,
+                                                  const double* __restrict__ p, double* __restrict__ y,
+                                                  double* __restrict__ partial) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x;
+  double* ps = lds;  // [5][N]
+  for (int i = threadIdx.x; i < 5 * N; i += 64) {
+    const int s2 = nbr[s * 5 + i / N];
+    ps[i] = s2 >= 0 ? p[(long)s2 * N + i % N] : 0.0;
+  }
+  __syncthreads();
+  double dot = 0.0;
+  for (int r = threadIdx.x; r < N; r += 64) {
+    double acc = 0.0;
+    for (int slot = 0; slot < 5; ++slot) {
+      if (nbr[s * 5 + slot] < 0) continue;
+      const double* row = Amu + (((long)s * 5 + slot) * N + r) * N;
+      for (int c = 0; c < N; ++c) acc += row[c] * ps[slot * N + c];
+    }
+    y[(long)s * N + r] = acc;
+    dot += acc * ps[2 * N + r];
+  }
+  for (int off = 32; off > 0; off >>= 1) dot += __shfl_down(dot, off, 64);
+  if (threadIdx.x == 0) partial[s] = dot;
+}
+
+// scal[dst] = sum_s partial[s] (fixed-order tree); optionally alpha = scal[num] / scal[dst] etc. handled by `mode`:
+//   mode 0: scal[0] = sum (rz_old at start), scal[3] = sum (|r0|^2 proxy)
+//   mode 1: scal[1] = pAp = sum; scal[2] = alpha = scal[0] / pAp
+//   mode 2: rz_new = sum; scal[4] = beta = rz_new / scal[0]; scal[0] = rz_new
+__global__ __launch_bounds__(1024) void k_cg_reduce(int S, const double* __restrict__ partial, double* __restrict__ scal,
+                                                    int mode) {
+  __shared__ double red[1024];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) acc += partial[i];
+  const double sum = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) {
+    if (mode == 0) {
+      scal[0] = sum;
+      scal[3] = sum;
+    } else if (mode == 1) {
+      scal[1] = sum;
+      scal[2] = scal[0] / sum;
+    } else {
+      scal[4] = sum / scal[0];
+      scal[0] = sum;
+    }
+  }
+}
+
+// x += alpha p; r -= alpha y; z = Dinv r; partial[s] = r_s . z_s; partial2[s] = r_s . r_s.  One wave per subdomain.
+__global__ __launch_bounds__(64) void k_cg_update(int N, const double* __restrict__ Dinv, const double* __restrict__ scal,
+                                                  int first, double* __restrict__ x, double* __restrict__ r,
+                                                  const double* __restrict__ p, const double* __restrict__ y,
+                                                  double* __restrict__ z, double* __restrict__ partial,
+                                                  double* __restrict__ partial2) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x;
+  double* rs = lds;  // [N]
+  const double alpha = first ? 0.0 : scal[2];
+  for (int i = threadIdx.x; i < N; i += 64) {
+    const long g = (long)s * N + i;
+    if (!first) x[g] += alpha * p[g];
+    const double rv = r[g] - alpha * (first ? 0.0 : y[g]);
+    r[g] = rv;
+    rs[i] = rv;
+  }
+  __syncthreads();
+  double dot = 0.0, rr = 0.0;
+  for (int i = threadIdx.x; i < N; i += 64) {
+    const double* row = Dinv + ((long)s * N + i) * N;
+    double acc = 0.0;
+    for (int c = 0; c < N; ++c) acc += row[c] * rs[c];
+    z[(long)s * N + i] = acc;
+    dot += acc * rs[i];
+    rr += rs[i] * rs[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    dot += __shfl_down(dot, off, 64);
+    rr += __shfl_down(rr, off, 64);
+  }
+  if (threadIdx.x == 0) {
+    partial[s] = dot;
+    partial2[s] = rr;
+  }
+}
+
+// p = z + beta p
+__global__ __launch_bounds__(256) void k_cg_direction(long total, const double* __restrict__ scal, int first,
+                                                      const double* __restrict__ z, double* __restrict__ p) {
+  const double beta = first ? 0.0 : scal[4];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    p[i] = z[i] + beta * p[i];
+}
+
+__global__ __launch_bounds__(1024) void k_sum_to(int S, const double* __restrict__ partial, double* __restrict__ dst) {
+  __shared__ double red[1024];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) acc += partial[i];
+  const double sum = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) *dst = sum;
+}
+
+}  // namespace
+
+int launch_reduced_estimate(lrbms_ctx* ctx, int Q, int N, const double* theta, const double* u, const double* G_nc,
+                            const double* r_fd, const double* G_rdd, const double* G_bb, const double* G_ab,
+                            const double* G_aa, const double* f2, const double* ceps, double hdiam, double* eta_loc,
+                            hipStream_t st) {
+  QVec th;
+  for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
+  const size_t lds = sizeof(double) * (5 * N + 5 * Q * N + 256);
+  hipLaunchKernelGGL(k_reduced_estimate, dim3(ctx->S), dim3(256), lds, st, ctx->S, ctx->nbr, Q, N, th, u, G_nc, r_fd,
+                     G_rdd, G_bb, G_ab, G_aa, f2, ceps, hdiam, eta_loc);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
+}
+
+int64_t reduced_solve_work_size(lrbms_ctx* ctx, int N) {
+  const long S = ctx->S;
+  return S * 5 * N * N + S * N * N + 4 * S * N + 2 * S + 16;
+}
+
+int launch_reduced_solve(lrbms_ctx* ctx, int Q, int N, const double* theta, const double* B_sys, const double* rhs_red,
+                         double* work, double* u, double rtol, int max_iter, double* info, hipStream_t st) {
+  if (ctx->S_ext != ctx->S) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve needs all subdomains on one rank");
+  if (N > 64) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve: N > 64 not supported by the block inverse");
+  const int S = ctx->S;
+  QVec th;
+  for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
+  double* Amu = work;
+  double* Dinv = Amu + (long)S * 5 * N * N;
+  double* r = Dinv + (long)S * N * N;
+  double* z = r + (long)S * N;
+  double* p = z + (long)S * N;
+  double* y = p + (long)S * N;
+  double* partial = y + (long)S * N;
+  double* partial2 = partial + S;
+  double* scal = partial2 + S;   // [0] rz, [1] pAp, [2] alpha, [3] rz0, [4] beta, [5] rr
+  const long per_q = (long)S * 5 * N * N;
+  const long vec = (long)S * N;
+  hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256),
+                     0, st, per_q, Q, th, B_sys, Amu);
+  LRBMS_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, Amu, Dinv);
+  LRBMS_LAUNCH_CHECK(ctx);
+  // x0 = 0, r0 = b
+  LRBMS_HIP_CHECK(ctx, hipMemsetAsync(u, 0, sizeof(double) * vec, st));
+  LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(r, rhs_red, sizeof(double) * vec, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_cg_update, dim3(S), dim3(64), sizeof(double) * N, st, N, Dinv, scal, 1, u, r, p, y, z, partial, partial2);
+  LRBMS_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(k_cg_reduce, dim3(1), dim3(1024), 0, st, S, partial, scal, 0);
+  hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(1024), 0, st, S, partial2, scal + 5);
+  hipLaunchKernelGGL(k_cg_direction, dim3((unsigned)((vec + 255) / 256)), dim3(256), 0, st, vec, scal, 1, z, p);
+  LRBMS_LAUNCH_CHECK(ctx);
+  double host_scal[8];
+  LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, scal, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
+  LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  const double rr0 = host_scal[5];
+  double rel = 1.0;
+  int it = 0;
+  if (rr0 == 0.0) {
+    if (info) { info[0] = 0; info[1] = 0.0; }
+    return LRBMS_OK;
+  }
+  const int check_every = 10;
+  while (it < max_iter) {
+    for (int k = 0; k < check_every && it < max_iter; ++k, ++it) {
+      hipLaunchKernelGGL(k_cg_matvec, dim3(S), dim3(64), sizeof(double) * 5 * N, st, ctx->nbr, N, Amu, p, y, partial);
+      hipLaunchKernelGGL(k_cg_reduce, dim3(1), dim3(1024), 0, st, S, partial, scal, 1);
+      hipLaunchKernelGGL(k_cg_update, dim3(S), dim3(64), sizeof(double) * N, st, N, Dinv, scal, 0, u, r, p, y, z, partial, partial2);
+      hipLaunchKernelGGL(k_cg_reduce, dim3(1), dim3(1024), 0, st, S, partial, scal, 2);
+      hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(1024), 0, st, S, partial2, scal + 5);
+      hipLaunchKernelGGL(k_cg_direction, dim3((unsigned)((vec + 255) / 256)), dim3(256), 0, st, vec, scal, 0, z, p);
+    }
+    LRBMS_LAUNCH_CHECK(ctx);
+    LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, scal, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
+    LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    rel = sqrt(host_scal[5] / rr0);
+    if (!(rel == rel)) return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve: NaN residual (system not SPD?)");
+    if (rel <= rtol) break;
+  }
+  if (info) { info[0] = it; info[1] = rel; }
+  if (rel > rtol) return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve: CG did not reach rtol");
+  return LRBMS_OK;
+}

@@ -1,0 +1,165 @@
+"""Host-side driver of the HIP hot path: owns the device arrays of one rank and sequences the C-ABI calls.
+
+Data layout in HBM (all fp64, C-contiguous; S = local subdomains, S_ext = S + halo):
+
+    lam    [Q][S_ext][n_T][16]   coefficient samples (7 volume + 3x3 face points per element)
+    A_diag [Q][S][n_T][4][9]     SWIPDG diagonal blocks, block-ELL over the element adjacency template
+    A_cpl  [Q][S][4][ncf][9]     SWIPDG coupling blocks per side face
+    V      [S_ext][n][N]         local reduced bases, DoF-major (basis index contiguous)
+    Wt     [S][n][5N]            Oswald image bases restricted to the target subdomain (slot-major columns)
+    Rt     [S][n_rt][5QN]        RT0 flux-reconstruction image bases (slot, q, basis) columns
+    B_sys  [Q][S][5][N][N]       projected system blocks; G_* projected estimator operators (see include/lrbms_hip.h)
+
+The reference builds the same quantities as pyMOR operators in ``discretize`` / ``LRBMSReductor._reduce``
+(discretize_elliptic_block_swipdg.py:530-811, reductor.py:33-73).
+"""
+import numpy as np
+
+from pylrbms_amd._native import NativeContext, NativeError
+
+_s15 = np.sqrt(15.0)
+_b1, _b2 = (6.0 + _s15) / 21.0, (6.0 - _s15) / 21.0
+TRI_BARY = np.array([[1 / 3, 1 / 3, 1 / 3],
+                     [1 - 2 * _b1, _b1, _b1], [_b1, 1 - 2 * _b1, _b1], [_b1, _b1, 1 - 2 * _b1],
+                     [1 - 2 * _b2, _b2, _b2], [_b2, 1 - 2 * _b2, _b2], [_b2, _b2, 1 - 2 * _b2]])
+EDGE_T = np.array([0.5 - 0.5 * np.sqrt(0.6), 0.5, 0.5 + 0.5 * np.sqrt(0.6)])
+
+
+def sample_points(grid, subdomains):
+    """Quadrature points of every element of the given subdomains: x [len, n_T, 16, 2] (7 volume points, then the
+    3 Gauss points of face 0, 1, 2 running from local vertex f+1 to f+2), centres [len, n_T, 2], keys [len, n_T, 3]."""
+    t = grid.template
+    origins = np.stack([grid.subdomain_origin(int(s)) for s in subdomains])           # [len, 2]
+    pts = t.points[None] + origins[:, None, None, :]                                    # [len, n_T, 3, 2]
+    vol = np.einsum('kv,sevd->sekd', TRI_BARY, pts)
+    faces = []
+    for f in range(3):
+        a, b = pts[:, :, (f + 1) % 3], pts[:, :, (f + 2) % 3]
+        faces.append(a[:, :, None, :] + EDGE_T[None, None, :, None] * (b - a)[:, :, None, :])
+    x = np.concatenate([vol] + faces, axis=2)
+    centers = pts.mean(axis=2)
+    keys = grid.element_keys(subdomains)
+    return x, centers, keys
+
+
+def sample_function(fn, x, centers, keys, volume_only=False):
+    if volume_only:
+        x = x[:, :, :7]
+    c = np.broadcast_to(centers[:, :, None, :], x.shape)
+    k = np.broadcast_to(keys[:, :, None, :], x.shape[:-1] + (3,))
+    out = np.asarray(fn(x, c, k), dtype=np.float64)
+    return np.ascontiguousarray(np.broadcast_to(out, x.shape[:-1]))
+
+
+class Engine:
+    """All device state of one rank for one discretization."""
+
+    def __init__(self, grid, lambda_funcs, kappa, f, lambda_bar, lambda_hat, theta_bar, device_index=0):
+        self.grid = grid
+        t = grid.template
+        self.t = t
+        local = list(grid.subdomains_on_rank)
+        lset = set(local)
+        halo = sorted({j for s in local for j in grid.neighboring_subdomains(s)} - lset)
+        self.local, self.halo = local, halo
+        self.ext = local + halo
+        pos = {g: i for i, g in enumerate(self.ext)}
+        self.ext_pos = pos
+        nbr = np.full((len(local), 5), -1, dtype=np.int32)
+        for i, s in enumerate(local):
+            for slot in range(5):
+                g = grid.neighbor_slots[s, slot]
+                if g >= 0:
+                    nbr[i, slot] = pos[int(g)]
+        self.nbr = nbr
+        self.S, self.S_ext = len(local), len(self.ext)
+        self.Q = len(lambda_funcs)
+        kap = np.asarray(getattr(kappa, 'value', kappa), dtype=np.float64).reshape(2, 2)
+        self.kappa = kap
+        self.ctx = NativeContext(device_index)
+        self.ctx.mesh_upload(t, kap, nbr, self.S, self.S_ext)
+        self.hdiam = grid.subdomain_diameter(0)
+
+        # ---- coefficient sampling on the host, then one H2D copy each
+        x, c, k = sample_points(grid, self.ext)
+        lam = np.stack([sample_function(fn, x, c, k) for fn in lambda_funcs])           # [Q, S_ext, n_T, 16]
+        xl, cl, kl = x[:self.S], c[:self.S], k[:self.S]
+        self.lam = self.ctx.from_numpy(lam)
+        self.f_smp = self.ctx.from_numpy(sample_function(f, xl, cl, kl, volume_only=True))
+        self.lbar = self.ctx.from_numpy(sample_function(lambda_bar, xl, cl, kl, volume_only=True))
+        self.lhat = self.ctx.from_numpy(sample_function(lambda_hat, xl, cl, kl, volume_only=True))
+        self.theta_bar = np.asarray(theta_bar, dtype=np.float64)
+        self.assembled = False
+
+    # ------------------------------------------------------------------ offline assembly (K1-K6, K8a, K9)
+    def assemble(self):
+        c = self.ctx
+        self.A_diag, self.A_cpl = c.assemble_swipdg(self.lam)
+        self.b, self.f2, self.ceps = c.assemble_rhs(self.f_smp, self.lhat)
+        self.P_diag, self.ebar, self.caa, self.Aab, self.Bbb = c.assemble_products(self.theta_bar, self.lam, self.lbar,
+                                                                                  self.lhat)
+        self.F = c.assemble_flux(self.lam)
+        self.assembled = True
+        return self
+
+    # ------------------------------------------------------------------ timed region: K7 + K8 + P1 + P2
+    def alloc_reduce_buffers(self, N):
+        c, S, Q, n, n_rt = self.ctx, self.S, self.Q, self.t.n, self.t.n_rt
+        W, C = 5 * N, 5 * Q * N
+        work = c.empty(max(c.estimator_work_size(Q, N), Q * S * n * N))
+        return {
+            'N': N, 'Wt': c.empty(S, n, W), 'Rt': c.empty(S, n_rt, C), 'work': work,
+            'sys': (c.empty(Q, S, 5, N, N), c.empty(S, N), c.empty(S, N, N), c.empty(S, N, N)),
+            'grams': (c.empty(S, W, W), c.empty(S, C), c.empty(S, C, C), c.empty(S, C, C), c.empty(Q, S, N, C),
+                      c.empty(Q, Q, S, N, N)),
+        }
+
+    def project_and_estimate(self, V, buffers=None, project_system=True):
+        """One pass of the hot path over all local subdomains.  ``V`` [S_ext, n, N] must already hold the halo."""
+        if not self.assembled:
+            raise NativeError('assemble() must run before project_and_estimate()')
+        N = V.shape[2]
+        buf = buffers if buffers is not None else self.alloc_reduce_buffers(N)
+        if buf['N'] != N:
+            raise NativeError('buffers were allocated for N={}'.format(buf['N']))
+        c = self.ctx
+        c.oswald_apply(V, out=buf['Wt'])
+        c.flux_reconstruct(self.F, V, out=buf['Rt'])
+        if project_system:
+            c.project_system(V, self.A_diag, self.A_cpl, self.P_diag, self.b, work=buf['work'], out=buf['sys'])
+        c.estimator_grams(V, buf['Wt'], buf['Rt'], self.ebar, self.caa, self.Aab, self.Bbb, self.b, work=buf['work'],
+                          out=buf['grams'])
+        return buf
+
+    # ------------------------------------------------------------------ online
+    def reduced_estimate(self, theta, u, grams):
+        return self.ctx.reduced_estimate(theta, u, grams, self.f2, self.ceps, self.hdiam)
+
+    def reduced_solve(self, theta, B_sys, rhs_red, rtol=1e-13, max_iter=20000):
+        return self.ctx.reduced_solve(theta, B_sys, rhs_red, rtol=rtol, max_iter=max_iter)
+
+
+# ---------------------------------------------------------------------- layout converters (host, for API / tests)
+def blockell_to_dense(template, vals):
+    """[n_T][4][9] block-ELL values of one subdomain -> dense [n, n] (inspection / ``.matrix()`` of the API shim)."""
+    t = template
+    vals = np.asarray(vals).reshape(t.n_T, 4, 3, 3)
+    out = np.zeros((t.n, t.n))
+    for e in range(t.n_T):
+        out[3 * e:3 * e + 3, 3 * e:3 * e + 3] += vals[e, 0]
+        for f in range(3):
+            nb = t.nb_elem[e, f]
+            if nb >= 0:
+                out[3 * e:3 * e + 3, 3 * nb:3 * nb + 3] += vals[e, 1 + f]
+    return out
+
+
+def coupling_to_dense(template, vals, side):
+    """[ncf][9] coupling blocks of one (subdomain, side) -> dense [n, n] block (rows: own DoFs, cols: neighbour's)."""
+    t = template
+    vals = np.asarray(vals).reshape(t.ncf, 3, 3)
+    out = np.zeros((t.n, t.n))
+    for p in range(t.side_count[side]):
+        ei, eo = t.side_elem[side, p], t.side_elem_out[side, p]
+        out[3 * ei:3 * ei + 3, 3 * eo:3 * eo + 3] += vals[p]
+    return out
