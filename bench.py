@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Benchmark of the LRBMS offline hot path (project + estimate-offline: K7 + K8 + P1 + P2 of SURVEY.md section 8).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2] [--no-cpu-baseline]
+
+One "step" = one pass of the hot path over all subdomains of the synthetic multiscale-diffusion problem
+(BASELINE.json config 3: 32x32 subdomains, local basis dim 40, fp64): Oswald image bases, RT0 flux-reconstruction
+image bases, Galerkin projection of the block SWIPDG system and of every estimator operator.  Inputs (assembled
+operators, bases) are resident in HBM before the timed region.  For N > 1 the subdomains are tiled over the ranks
+(strong scaling, as BASELINE.json config 4) and every step starts with the halo all-gather of neighbour basis rows.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    'cfg2': {'num_subdomains': [8, 8], 'N': 20, 'coarse_per_subdomain': 4},
+    'cfg3': {'num_subdomains': [32, 32], 'N': 40, 'coarse_per_subdomain': 4},
+}
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md (HBM3E spec) and SURVEY.md section 8d (fp64 matrix)
+PEAK_HBM_GBS = 8000.0
+PEAK_FP64_MFMA_TFLOPS = 78.6
+
+
+def algorithmic_flops_per_subdomain(n, n_rt, n_T, N, Q, m=5, n_c=24):
+    """Canonical count of SURVEY.md section 8(d) (full GEMM count, interior subdomain)."""
+    nnz_A, nnz_c, nnz_E, nnz_M, nnz_aa = 12 * n, 72, 3 * n, 3 * n, 3 * n
+    nnz_Div = nnz_ab = 9 * n_T
+    nnz_B = 5 * n_rt
+    C = Q * m * N
+    F_P1 = Q * (2 * nnz_A * N + 2 * n * N * N) + (m - 1) * Q * (2 * nnz_c * N + 2 * n_c * N * N) + 2 * n * N + \
+        (2 * nnz_M * N + 2 * n * N * N)
+    F_nc = 2 * nnz_E * m * N + 2 * n * (m * N) ** 2
+    F_r = 2 * nnz_Div * C + 2 * n * C + 2 * nnz_M * C + 2 * n * C * C
+    F_bb = 2 * nnz_B * C + 2 * n_rt * C * C
+    F_ab = Q * (2 * nnz_ab * C + 2 * n * N * C)
+    F_aa = Q * Q * (2 * nnz_aa * N + 2 * n * N * N)
+    return F_P1 + F_nc + F_r + F_bb + F_ab + F_aa
+
+
+def algorithmic_bytes_per_subdomain(n, n_rt, n_T, N, Q, m=5, n_c=24):
+    """inputs once, outputs once, intermediates W, R, D written + read."""
+    C = Q * m * N
+    nnz_A = 12 * n
+    inputs = 8 * n * N + 8 * (m - 1) * n_c * N + 12 * (Q * nnz_A + (m - 1) * Q * 72 + 3 * n * (2 + Q * Q) + 9 * n_T * (1 + Q) + 5 * n_rt)
+    inter = 2 * (8 * m * n * N + 8 * Q * m * n_rt * N + 8 * n * C)
+    outputs = 8 * (Q * m * N * N + (m * N) ** 2 + 2 * C * C + Q * N * C + Q * Q * N * N + C)
+    return inputs + inter + outputs
+
+
+def make_bases_host(subdomains, n, N, seed=0):
+    V = np.empty((len(subdomains), n, N))
+    for i, s in enumerate(subdomains):
+        rng = np.random.default_rng(seed + int(s))
+        V[i, :, 0] = 1.0
+        V[i, :, 1:] = rng.standard_normal((n, N - 1))
+    return V
+
+
+_POOL_STATE = {}
+
+
+def _pool_reduce(chunk):
+    from oracle.lrbms import OracleReductor
+    d, V = _POOL_STATE['d'], _POOL_STATE['V']
+    OracleReductor(d, [V[ii] for ii in range(d.S)]).reduce(subdomains=chunk)
+    return len(chunk)
+
+
+def cpu_baseline(N, coarse, sample_subdomains=(16, 16), repeats=1):
+    """The oracle (kind "port") timed on a bounded sample of the same workload: same synthetic problem family and
+    basis size on a smaller subdomain grid.  Only OracleReductor.reduce() -- the same region the GPU times -- is timed."""
+    from threadpoolctl import threadpool_limits
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from common import oracle_from_problem
+    from oracle.lrbms import OracleReductor
+    from pylrbms_amd import multiscale_problem
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(sample_subdomains), 'coarse_per_subdomain': coarse})
+    d = oracle_from_problem(p).precompute_blocks()
+    V = make_bases_host(range(d.S), d.n, N)
+    import multiprocessing as mp
+    cores = min(os.cpu_count() or 1, 16)
+    with threadpool_limits(limits=1):
+        # (i) one core, the way the reference runs (single-threaded per rank, reductor.py:19 ignores num_cpus)
+        t0 = time.perf_counter()
+        OracleReductor(d, [V[ii] for ii in range(d.S)]).reduce()
+        one = d.S / (time.perf_counter() - t0)
+        # (ii) all host cores: target subdomains farmed over a fork()ed process pool
+        _POOL_STATE['d'], _POOL_STATE['V'] = d, V
+        chunks = [list(c) for c in np.array_split(np.arange(d.S), 4 * cores) if len(c)]
+        with mp.get_context('fork').Pool(cores) as pool:
+            t0 = time.perf_counter()
+            pool.map(_pool_reduce, chunks)
+            allc = d.S / (time.perf_counter() - t0)
+    return {'value': allc, 'unit': 'subdomains/s', 'cores': cores, 'kind': 'port', 'value_1core': one,
+            'sample': 'oracle.lrbms.OracleReductor.reduce() (NumPy/SciPy fp64) on {}x{} subdomains of the same synthetic '
+                      'multiscale problem, N={}, k_c={}: value = target subdomains farmed over a {}-process pool '
+                      '(1 BLAS thread each), value_1core = one process, one thread'
+                      .format(sample_subdomains[0], sample_subdomains[1], N, coarse, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='cfg3', choices=sorted(CONFIGS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node {} for --gpus {}'.format(args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd.engine import Engine
+    from pylrbms_amd.parallel import Communicator, HaloExchange, HaloPlan
+    cfg = CONFIGS[args.config]
+    N = cfg['N']
+    comm = Communicator(rank, world)
+    pcfg = {'num_subdomains': cfg['num_subdomains'], 'coarse_per_subdomain': cfg['coarse_per_subdomain']}
+    p = multiscale_problem.init_grid_and_problem(pcfg, mpi_comm=comm)
+    grid = p['grid']
+    lam = p['lambda']
+    theta_bar = np.array([c.evaluate(p['mu_bar']) for c in lam['coefficients']])
+    eng = Engine(grid, lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], theta_bar,
+                 device_index=local_rank)
+    eng.assemble()
+    t = grid.template
+    S_total = grid.num_subdomains
+
+    # local bases (constant + seeded random columns); the halo slabs are filled by the exchange inside each step
+    V = eng.ctx.zeros(eng.S_ext, t.n, N)
+    V[:eng.S] = eng.ctx.from_numpy(make_bases_host(eng.local, t.n, N))
+    halo = None
+    if world > 1:
+        from pylrbms_amd.grid import DDSubdomainsGrid
+        plan = HaloPlan(lambda r: DDSubdomainsGrid(grid.lower_left, grid.upper_right, grid.K, grid.P, rank=r,
+                                                   world_size=world), world, rank)
+        halo = HaloExchange(plan, N, V.device)
+    buf = eng.alloc_reduce_buffers(N)
+
+    def step():
+        if halo is not None:
+            halo(V)
+        eng.project_and_estimate(V, buf)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=V.device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = S_total * args.steps / elapsed
+
+    if rank == 0:
+        Q = eng.Q
+        flops = algorithmic_flops_per_subdomain(t.n, t.n_rt, t.n_T, N, Q)
+        byts = algorithmic_bytes_per_subdomain(t.n, t.n_rt, t.n_T, N, Q)
+        # device time of one pass on this rank's stream (HIP events on the launch stream)
+        dev_s_per_step = 1e-3 * dev_ms / args.steps
+        s_rank = eng.S
+        ach_tflops = flops * s_rank / dev_s_per_step / 1e12
+        ach_gbs = byts * s_rank / dev_s_per_step / 1e9
+        roofline = {'bound': 'mfma', 'achieved': ach_tflops, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': ach_tflops / PEAK_FP64_MFMA_TFLOPS, 'traffic': None,
+                    'kernel': 'whole project+estimate pass (sequence of launches; dominant kernel k_gemm_tn)',
+                    'flops_per_subdomain': flops, 'bytes_per_subdomain': byts,
+                    'hbm_achieved_GBs': ach_gbs, 'hbm_frac': ach_gbs / PEAK_HBM_GBS,
+                    'device_ms_per_step': 1e3 * dev_s_per_step}
+        out = {'metric': 'offline project+estimate throughput', 'value': value, 'unit': 'subdomains/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+               'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+               'config': {'workload': 'BASELINE.json config {}: 2D multiscale diffusion, {}x{} subdomains, k_c={} '
+                                      '(n={} DG DoFs, n_rt={} RT0 DoFs per subdomain), Q={}, local basis dim {}'
+                                      .format(args.config[-1], cfg['num_subdomains'][0], cfg['num_subdomains'][1],
+                                              cfg['coarse_per_subdomain'], t.n, t.n_rt, Q, N),
+                          'subdomains': S_total, 'N': N, 'Q': Q, 'parallelism': 'subdomain tiles x{}'.format(world)},
+               'roofline': roofline}
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(N, cfg['coarse_per_subdomain'])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

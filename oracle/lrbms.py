@@ -52,6 +52,7 @@ class OracleDiscretization:
         self.nT = mesh.elements_per_subdomain
         self.n = 3 * self.nT
         self.ndof = 3 * mesh.num_elements
+        self._block_cache = {}
         self._geometry()
         self._assemble_system()
         self._assemble_rhs()
@@ -179,8 +180,26 @@ class OracleDiscretization:
             self.A.append((A_loc + A_cpl + A_bnd).tocsr())
 
     def block(self, M, ii, jj):
-        n = self.n
-        return M[ii * n:(ii + 1) * n, jj * n:(jj + 1) * n]
+        """Block (ii, jj) of a matrix in block-mapper numbering; memoised, since the reference holds its local and
+        coupling matrices as separate objects (block_swipdg.py:386-396,:551-565) and never slices a global one."""
+        key = (id(M), ii, jj)
+        hit = self._block_cache.get(key)
+        if hit is None:
+            n = self.n
+            hit = M[ii * n:(ii + 1) * n, :][:, jj * n:(jj + 1) * n].tocsr()
+            self._block_cache[key] = hit
+        return hit
+
+    def precompute_blocks(self):
+        """Fill the block cache for everything ``OracleReductor.reduce`` touches (untimed setup of the CPU baseline)."""
+        for ii in range(self.S):
+            for M in [self.elliptic_bar, self.l2_product, self.energy_product] + \
+                    [self.caa[q][q2] for q in range(self.Q) for q2 in range(self.Q)]:
+                self.block(M, ii, ii)
+            for jj in self.mesh.neighborhood_of(ii):
+                for q in range(self.Q):
+                    self.block(self.A[q], ii, jj)
+        return self
 
     # ------------------------------------------------------------------ rhs (K5) and scalars
     def _assemble_rhs(self):
@@ -419,22 +438,26 @@ class OracleReductor:
         self.d = d
         self.bases = [np.asarray(b, dtype=np.float64) for b in bases]
 
-    def image_bases(self):
+    def image_bases(self, sources=None):
         """reductor.py:40-43 (OI_i) and :51-60 (RT_i, one slab of columns per affine component)."""
         d, m = self.d, self.d.mesh
-        OI, RT = [], []
-        for s in range(d.S):
-            OI.append(d.oswald_interpolation_error_apply(s, self.bases[s]))
+        OI, RT = [None] * d.S, [None] * d.S
+        for s in (range(d.S) if sources is None else sources):
+            OI[s] = d.oswald_interpolation_error_apply(s, self.bases[s])
             per_q = [d.flux_reconstruction_apply(q, s, self.bases[s]) for q in range(d.Q)]
-            RT.append([np.hstack([per_q[q][i] for q in range(d.Q)]) for i in range(len(m.neighborhood_of(s)))])
+            RT[s] = [np.hstack([per_q[q][i] for q in range(d.Q)]) for i in range(len(m.neighborhood_of(s)))]
         return OI, RT
 
-    def reduce(self, project_system=True):
+    def reduce(self, project_system=True, subdomains=None):
+        """``subdomains``: restrict the projection to these target subdomains (used to farm the CPU baseline over a
+        process pool; the returned model then only holds their entries, in that order)."""
         d, m = self.d, self.d.mesh
-        OI, RT = self.image_bases()
+        targets = list(range(d.S)) if subdomains is None else list(subdomains)
+        sources = None if subdomains is None else sorted({kk for ii in targets for kk in m.neighborhood_of(ii)})
+        OI, RT = self.image_bases(sources)
         rd = OracleReducedModel(d, [b.shape[1] for b in self.bases])
         n = d.n
-        for ii in range(d.S):
+        for ii in targets:
             hood = m.neighborhood_of(ii)
             V = self.bases[ii]
             # local_oi_projection / local_rt_projection (block_swipdg.py:700-717): component ``ii`` of every

@@ -1,0 +1,140 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, subdomains tiled over ranks, ONE exchange step.
+
+The reference's only parallelism is MPI domain decomposition: subdomains are the unit of
+independent work (discretize_elliptic_block_swipdg.py:66-70, estimators.py:70) and the two ``mpi_norm`` calls at
+estimators.py:100-101 are its only live collectives on this path.  Here:
+
+* every rank owns a contiguous 2D tile of subdomains (``DDSubdomainsGrid._partition``) and computes everything for
+  its own target subdomains ``ii`` -- including the images W^{kk}|_ii, R^{kk}|_ii of its neighbours' bases -- so
+  the projection needs a single halo exchange of neighbour basis rows and no second exchange;
+* the halo carries only the DoF rows of elements that touch the shared side (what the coupling blocks, the Oswald
+  vertex stars and the flux reconstruction read), packed into one buffer and moved by one RCCL all-gather over xGMI;
+* the estimator norms (C2/C3) are one all-reduce of 2 doubles per estimated vector.
+
+Works with any torch.distributed backend (``nccl`` = RCCL on the GPUs, ``gloo`` in the CPU tests).
+"""
+import numpy as np
+
+
+class Communicator:
+    """Minimal stand-in for the ``mpi_comm`` argument of the reference API (rank / size only)."""
+
+    def __init__(self, rank=0, size=1, group=None):
+        self.rank, self.size, self.group = rank, size, group
+
+    @classmethod
+    def from_torch_distributed(cls, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return cls()
+        return cls(dist.get_rank(group), dist.get_world_size(group), group)
+
+
+def side_rows(template):
+    """For each side 0..3 the sorted DoF rows of all elements having a vertex on that side."""
+    t = template
+    lat = t.tri_lattice
+    on = [lat[:, :, 1] == 0, lat[:, :, 0] == 0, lat[:, :, 0] == 2 * t.kx, lat[:, :, 1] == 2 * t.ky]
+    rows = []
+    for sd in range(4):
+        elems = np.nonzero(on[sd].any(axis=1))[0]
+        rows.append(np.sort((3 * elems[:, None] + np.arange(3)[None, :]).ravel()).astype(np.int64))
+    return rows
+
+
+class HaloPlan:
+    """Who sends which rows of which subdomain: derived by every rank from the grid partition alone (no handshake)."""
+
+    def __init__(self, grid_factory, world_size, rank):
+        """``grid_factory(rank)`` returns the DDSubdomainsGrid as seen by ``rank`` (same global grid, other tile)."""
+        grids = [grid_factory(r) for r in range(world_size)]
+        g = grids[rank]
+        self.rank, self.world_size = rank, world_size
+        t = g.template
+        rows = side_rows(t)
+        opposite = {0: 3, 1: 2, 2: 1, 3: 0}
+        owner = {}
+        for r, gr in enumerate(grids):
+            for s in gr.subdomains_on_rank:
+                owner[s] = r
+        slot_of_side = (0, 1, 3, 4)
+        # send list of rank r: for each owned subdomain s and each side whose neighbour lives elsewhere,
+        # the rows of s touching that side.  Deterministic order: (s ascending, side ascending).
+        self.send_items = []      # per rank: list of (subdomain, side)
+        for r, gr in enumerate(grids):
+            items = []
+            for s in gr.subdomains_on_rank:
+                for sd in range(4):
+                    j = g.neighbor_slots[s, slot_of_side[sd]]
+                    if j >= 0 and owner[int(j)] != r:
+                        items.append((s, sd))
+            self.send_items.append(items)
+        self.row_counts = [len(rw) for rw in rows]
+        self.rows = rows
+        self.send_sizes = [sum(self.row_counts[sd] for (_, sd) in items) for items in self.send_items]
+        self.max_rows = max(self.send_sizes) if self.send_sizes else 0
+        # local gather index (into the flattened [S_ext * n] row space of the local V) for my own send buffer
+        local = list(g.subdomains_on_rank)
+        lpos = {s: i for i, s in enumerate(local)}
+        halo = sorted({int(j) for s in local for j in g.neighboring_subdomains(s)} - set(local))
+        hpos = {s: len(local) + i for i, s in enumerate(halo)}
+        self.S, self.S_ext, self.n = len(local), len(local) + len(halo), t.n
+        idx = []
+        for (s, sd) in self.send_items[rank]:
+            idx.append(lpos[s] * t.n + rows[sd])
+        self.pack_index = np.concatenate(idx) if idx else np.zeros(0, dtype=np.int64)
+        # scatter: for every other rank's send buffer, which of its rows land in my halo slabs and where
+        src, dst = [], []
+        for r in range(world_size):
+            if r == rank:
+                continue
+            off = 0
+            for (s, sd) in self.send_items[r]:
+                cnt = self.row_counts[sd]
+                j = int(g.neighbor_slots[s, slot_of_side[sd]])
+                if s in hpos and j in lpos:          # s is my halo because its neighbour j on that side is mine
+                    src.append(r * self.max_rows + off + np.arange(cnt))
+                    dst.append(hpos[s] * t.n + rows[sd])
+                off += cnt
+        self.unpack_src = np.concatenate(src) if src else np.zeros(0, dtype=np.int64)
+        self.unpack_dst = np.concatenate(dst) if dst else np.zeros(0, dtype=np.int64)
+        self.opposite = opposite
+
+
+class HaloExchange:
+    """Fills the halo slabs V[S:] from the neighbours' owners with one all-gather."""
+
+    def __init__(self, plan, N, device, dtype=None, group=None):
+        import torch
+        self.torch, self.plan, self.group = torch, plan, group
+        dtype = dtype or torch.float64
+        self.send = torch.zeros(max(plan.max_rows, 1), N, dtype=dtype, device=device)
+        self.recv = torch.zeros(plan.world_size * max(plan.max_rows, 1), N, dtype=dtype, device=device)
+        self.pack_index = torch.from_numpy(plan.pack_index).to(device)
+        self.unpack_src = torch.from_numpy(plan.unpack_src).to(device)
+        self.unpack_dst = torch.from_numpy(plan.unpack_dst).to(device)
+        self.count = len(plan.pack_index)
+
+    def __call__(self, V):
+        """V [S_ext, n, N] contiguous; rows of the halo slabs that the kernels read are overwritten in place."""
+        import torch.distributed as dist
+        torch = self.torch
+        if self.plan.world_size == 1:
+            return V
+        flat = V.view(-1, V.shape[2])
+        if self.count:
+            torch.index_select(flat, 0, self.pack_index, out=self.send[:self.count])
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        if len(self.unpack_src):
+            flat.index_copy_(0, self.unpack_dst, self.recv.index_select(0, self.unpack_src))
+        return V
+
+
+def global_norms(local_eta_nc, local_eta_r_plus_df, group=None):
+    """The two ``mpi_norm`` collectives of estimators.py:100-101 fused into one all-reduce (sum of squares)."""
+    import torch
+    import torch.distributed as dist
+    sq = torch.stack([(local_eta_nc ** 2).sum(), (local_eta_r_plus_df ** 2).sum()])
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sq, group=group)
+    return torch.sqrt(sq)
