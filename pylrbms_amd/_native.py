@@ -62,6 +62,9 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # torch bundles its own libamdhip64: import it FIRST so that our NEEDED libamdhip64.so.7 resolves to the copy
+    # torch uses (two HIP runtimes in one process do not share devices, streams or allocations)
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise NativeError('{} is missing: run `python __graft_entry__.py` (or pylrbms_amd/_build.py) to build the HIP '
                           'extension; there is no CPU fallback'.format(path))
