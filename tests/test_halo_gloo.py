@@ -1,0 +1,86 @@
+"""The N > 1 path on CPU: world_size-2 (and 4) gloo processes exchange halo basis rows with HaloExchange and check
+that every row the kernels read from a neighbour's slab equals the owner's row."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pylrbms_amd.grid import DDSubdomainsGrid
+from pylrbms_amd.parallel import HaloExchange, HaloPlan, side_rows
+
+P, KC, N = (4, 4), 2, 3
+
+
+def _global_V(grid):
+    rng = np.random.default_rng(1234)
+    return rng.standard_normal((grid.num_subdomains, grid.template.n, N))
+
+
+def _worker(rank, world, port, results):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        mk = lambda r: DDSubdomainsGrid([0, 0], [1, 1], (P[0] * KC, P[1] * KC), P, rank=r, world_size=world)  # noqa: E731
+        grid = mk(rank)
+        plan = HaloPlan(mk, world, rank)
+        Vg = _global_V(grid)
+        local = grid.subdomains_on_rank
+        halo = sorted({j for s in local for j in grid.neighboring_subdomains(s)} - set(local))
+        V = torch.zeros(len(local) + len(halo), grid.template.n, N, dtype=torch.float64)
+        V[:len(local)] = torch.from_numpy(Vg[local])
+        HaloExchange(plan, N, V.device)(V)
+        rows = side_rows(grid.template)
+        ok = True
+        checked = 0
+        for h, s in enumerate(halo):
+            for sd in range(4):
+                j = grid.neighbor_slots[s, (0, 1, 3, 4)[sd]]
+                if j >= 0 and int(j) in local:
+                    got = V[len(local) + h, rows[sd]].numpy()
+                    ok &= bool(np.array_equal(got, Vg[s][rows[sd]]))
+                    checked += 1
+        ok &= bool(np.array_equal(V[:len(local)].numpy(), Vg[local]))
+        # fused estimator norms (estimators.py:100-101)
+        from pylrbms_amd.parallel import global_norms
+        a = torch.tensor([float(s) for s in local], dtype=torch.float64)
+        norms = global_norms(a, 2 * a)
+        want = np.sqrt(sum(s * s for s in range(grid.num_subdomains)))
+        ok &= abs(float(norms[0]) - want) < 1e-12 and abs(float(norms[1]) - 2 * want) < 1e-12
+        results[rank] = (ok, checked)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_halo_exchange_gloo(world):
+    port = 29500 + (os.getpid() % 2000) + world
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
+    assert len(results) == world
+    for r in range(world):
+        ok, checked = results[r]
+        assert ok and checked > 0
+
+
+def test_side_rows_cover_what_the_kernels_read():
+    t = DDSubdomainsGrid([0, 0], [1, 1], (8, 8), (2, 2)).template
+    rows = side_rows(t)
+    opposite = {0: 3, 1: 2, 2: 1, 3: 0}
+    for sd in range(4):
+        need = set()
+        osd = opposite[sd]           # the neighbour across our side `sd` shows us its side `osd`
+        for p in range(t.side_count[sd]):
+            e = t.side_elem_out[sd, p]
+            need |= {3 * e, 3 * e + 1, 3 * e + 2}            # flux reconstruction + coupling blocks
+        nvx, nvy = t.nvx, t.nvy
+        for v in range(t.n_vertices):
+            lx, ly = v % nvx, v // nvx
+            on = [ly == 0, lx == 0, lx == nvx - 1, ly == nvy - 1][osd]
+            if on:
+                need |= set(int(i) for i in t.vdof_idx[t.vdof_ptr[v]:t.vdof_ptr[v + 1]])   # Oswald vertex stars
+        assert need <= set(int(r) for r in rows[osd])

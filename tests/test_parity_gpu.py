@@ -1,0 +1,160 @@
+"""Parity of the HIP hot path (through the C ABI) with the CPU oracle -- runs on the MI355X box (`-m gpu`).
+
+Tolerance: fp64, relative to the largest entry of each reference array: 1e-11 for assembled / projected arrays
+(observed ~1e-15), 1e-10 for the reduced solve (north_star: online reduced solve within 1e-10)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+
+from common import (compare_all, energy_orthonormalize, make_bases, oracle_from_problem, theta_bar_of, theta_of)
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-11
+
+
+def _engine(p):
+    from pylrbms_amd.engine import Engine
+    lam = p['lambda']
+    return Engine(p['grid'], lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'],
+                  theta_bar_of(p)).assemble()
+
+
+def _problems():
+    from pylrbms_amd import OS2015_academic_problem, multiscale_problem, thermalblock_problem
+    return {
+        # BASELINE.json config 1
+        'thermalblock_2x2': (lambda: thermalblock_problem.init_grid_and_problem(
+            {'num_subdomains': [2, 2], 'half_num_fine_elements_per_subdomain_and_dim': 4}), 2, (0.5, 1.0, 0.2, 0.8)),
+        'os2015_2x2': (lambda: OS2015_academic_problem.init_grid_and_problem(
+            {'num_subdomains': [2, 2], 'half_num_fine_elements_per_subdomain_and_dim': 4}), 3, 0.3),
+        'os2015_4x4_h8': (lambda: OS2015_academic_problem.init_grid_and_problem(
+            {'num_subdomains': [4, 4], 'half_num_fine_elements_per_subdomain_and_dim': 8}), 5, 1.0),
+        # edge cases: a single subdomain (no neighbours), strips, ragged template (kx != ky), N = 1, odd N
+        'single_subdomain': (lambda: multiscale_problem.init_grid_and_problem(
+            {'num_subdomains': [1, 1], 'coarse_per_subdomain': 3}), 4, 0.5),
+        'strip_1x4': (lambda: multiscale_problem.init_grid_and_problem(
+            {'num_subdomains': [1, 4], 'coarse_per_subdomain': 2}), 1, 0.9),
+        'multiscale_5x3_N7': (lambda: multiscale_problem.init_grid_and_problem(
+            {'num_subdomains': [5, 3], 'coarse_per_subdomain': 2}), 7, 0.15),
+        # BASELINE.json config 2 geometry (k_c = 4, N = 20) on a smaller subdomain grid
+        'multiscale_4x3_kc4_N20': (lambda: multiscale_problem.init_grid_and_problem(
+            {'num_subdomains': [4, 3], 'coarse_per_subdomain': 4}), 20, 0.7),
+    }
+
+
+@pytest.mark.parametrize('name', list(_problems()))
+def test_every_array_matches_the_oracle(name):
+    mk, N, mu = _problems()[name]
+    p = mk()
+    eng = _engine(p)
+    d = oracle_from_problem(p)
+    V = energy_orthonormalize(make_bases(d.S, d.n, N, seed=3), d)
+    res = compare_all(p, eng, V, mu)
+    its = res.pop('cg_iterations')
+    assert its > 0
+    bad = {k: v for k, v in res.items() if not (v < (1e-10 if k == 'u_solve' else TOL))}
+    assert not bad, bad
+
+
+def test_rectangular_template():
+    """kx != ky: 6x2 coarse squares in 3x1 subdomains."""
+    from pylrbms_amd.functions import make_constant_function_2x2, make_expression_function_1x1
+    from pylrbms_amd.grid import DDSubdomainsGrid, make_boundary_info
+    from pylrbms_amd.parameters import ExpressionParameterFunctional
+    grid = DDSubdomainsGrid([0, 0], [3, 1], (6, 4), (3, 1))
+    pt = {'diffusion': (1,)}
+    p = {'grid': grid, 'boundary_info': make_boundary_info(grid, {'type': 'xt.grid.boundaryinfo.alldirichlet'}),
+         'lambda': {'functions': [make_expression_function_1x1(grid, 'x', '1+x[0]*x[1]'),
+                                  make_expression_function_1x1(grid, 'x', '0.5+sin(x[0])*sin(x[0])')],
+                    'coefficients': [ExpressionParameterFunctional('1.', pt), ExpressionParameterFunctional('diffusion', pt)]},
+         'lambda_bar': make_expression_function_1x1(grid, 'x', '1.5+x[0]*x[1]+sin(x[0])*sin(x[0])'),
+         'lambda_hat': make_expression_function_1x1(grid, 'x', '1.5+x[0]*x[1]+sin(x[0])*sin(x[0])'),
+         'kappa': make_constant_function_2x2(grid, [[2., 0.5], [0.5, 1.]]),      # anisotropic constant tensor
+         'f': make_expression_function_1x1(grid, 'x', 'exp(x[0])*cos(3*x[1])'),
+         'mu_bar': (1.,), 'mu_hat': (1.,)}
+    eng = _engine(p)
+    d = oracle_from_problem(p)
+    V = energy_orthonormalize(make_bases(d.S, d.n, 6, seed=5), d)
+    res = compare_all(p, eng, V, 0.45)
+    res.pop('cg_iterations')
+    bad = {k: v for k, v in res.items() if not (v < (1e-10 if k == 'u_solve' else TOL))}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('name', ['os2015_2x2', 'thermalblock_2x2', 'multiscale_3x3'])
+def test_golden_fixtures(name):
+    """The committed (oracle-generated) vectors: stored inputs V, mu -> stored u, eta triple, Gram blocks."""
+    from make_golden import CASES
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'), allow_pickle=False)
+    mk, N, mu = CASES[name]
+    p = mk()
+    eng = _engine(p)
+    grid = p['grid']
+    S = grid.num_subdomains
+    V = eng.ctx.from_numpy(ref['V'])
+    buf = eng.project_and_estimate(V)
+    host = lambda x: x.detach().cpu().numpy()  # noqa: E731
+    assert np.abs(host(eng.b).reshape(-1) - ref['b']).max() < TOL * np.abs(ref['b']).max()
+    assert np.allclose(host(eng.f2), ref['f2'], rtol=TOL) and np.allclose(host(eng.ceps), ref['ceps'], rtol=TOL)
+    assert np.abs(host(buf['sys'][1]) - ref['rhs_red']).max() < TOL * np.abs(ref['rhs_red']).max()
+    assert np.abs(host(buf['sys'][2]) - ref['E_red']).max() < TOL * np.abs(ref['E_red']).max()
+    theta = theta_of(p, mu)
+    u, info = eng.reduced_solve(theta, buf['sys'][0], buf['sys'][1])
+    assert np.linalg.norm(host(u) - ref['u']) < 1e-10 * np.linalg.norm(ref['u'])
+    eta = host(eng.reduced_estimate(theta, eng.ctx.from_numpy(ref['u']), buf['grams']))
+    for row, key in enumerate(('eta_nc', 'eta_r', 'eta_df')):
+        assert np.abs(eta[row] - ref[key]).max() < 1e-10 * max(np.abs(ref[key]).max(), 1e-300), key
+    # FOM estimate = the same pipeline with the full-order vector as a one-column basis
+    U = eng.ctx.from_numpy(ref['fom_u'][:, :, None])
+    bufU = eng.project_and_estimate(U, project_system=False)
+    etaU = host(eng.reduced_estimate(theta, eng.ctx.from_numpy(np.ones((S, 1))), bufU['grams']))
+    for row, key in enumerate(('fom_eta_nc', 'fom_eta_r', 'fom_eta_df')):
+        assert np.abs(etaU[row] - ref[key]).max() < 1e-9 * max(np.abs(ref[key]).max(), 1e-300), key
+
+
+def test_full_size_properties_config2():
+    """BASELINE.json config 2 at full size (8x8 subdomains, N = 20) through size-independent properties:
+    symmetry of every Gram, linearity (reduced estimate of u == estimate of the reconstruction V u as a one-column
+    basis), and agreement of the fp64-MFMA GEMM with torch.matmul on the same device operands."""
+    import torch
+    from pylrbms_amd import multiscale_problem
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': [8, 8], 'coarse_per_subdomain': 4})
+    eng = _engine(p)
+    S, n, N = eng.S, eng.t.n, 20
+    V = eng.ctx.from_numpy(make_bases(S, n, N, seed=2))
+    buf = eng.project_and_estimate(V)
+    G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = buf['grams']
+    for G in (G_nc, G_rdd, G_bb):
+        assert float((G - G.transpose(1, 2)).abs().max()) <= 1e-12 * float(G.abs().max())
+    B_sys = buf['sys'][0]
+    assert float((B_sys[:, :, 2] - B_sys[:, :, 2].transpose(2, 3)).abs().max()) <= 1e-12 * float(B_sys.abs().max())
+    ref = torch.matmul(buf['Wt'].transpose(1, 2), buf['Wt'])
+    got = eng.ctx.gemm_tn(buf['Wt'], buf['Wt'])
+    assert float((ref - got).abs().max()) <= 1e-12 * float(ref.abs().max())
+    theta = theta_of(p, 0.35)
+    rng = np.random.default_rng(5)
+    u = eng.ctx.from_numpy(rng.standard_normal((S, N)))
+    eta = eng.reduced_estimate(theta, u, buf['grams'])
+    U = torch.einsum('snk,sk->sn', V, u)[:, :, None].contiguous()
+    bufU = eng.project_and_estimate(U, project_system=False)
+    etaU = eng.reduced_estimate(theta, eng.ctx.from_numpy(np.ones((S, 1))), bufU['grams'])
+    scale = etaU.abs().max(dim=1, keepdim=True).values
+    assert float(((eta - etaU).abs() / scale).max()) < 1e-9
+
+
+def test_native_argument_checks_raise():
+    from pylrbms_amd._native import NativeError
+    from pylrbms_amd import multiscale_problem
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': [2, 2], 'coarse_per_subdomain': 2})
+    eng = _engine(p)
+    with pytest.raises(NativeError):
+        eng.ctx.oswald_apply(eng.ctx.zeros(eng.S, eng.t.n + 1, 3))        # wrong shape
+    with pytest.raises(NativeError):
+        eng.ctx.oswald_apply(eng.ctx.zeros(eng.S, eng.t.n, 3).float())    # wrong dtype
+    with pytest.raises(NativeError):
+        eng.ctx.reduced_solve(np.array([1.0, -1.0]), *eng.project_and_estimate(eng.ctx.zeros(eng.S, eng.t.n, 2))['sys'][:2])
