@@ -165,6 +165,10 @@ int lrbms_reduced_solve(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* thet
 /* -- helpers used by the host shim and the parity tests ------------------------------------------------- */
 /* y [S][n][M] = blockELL(A [S][n_T][4][9]) x [S][n][M]   (diagonal blocks only, no coupling) */
 int lrbms_blockell_apply(lrbms_ctx* ctx, int32_t M, const double* A, const double* x, double* y, void* stream);
+/* y [S][n][M] = sum_q theta_q (A_diag_q x_s + sum_sides A_cpl_q[side] x_neighbour): the full-order block operator
+ * (BlockOperator of block_swipdg.py:500-507 applied to a block vector); x [S_ext][n][M] with halo filled; theta host. */
+int lrbms_fom_apply(lrbms_ctx* ctx, int32_t Q, int32_t M, const double* theta, const double* A_diag, const double* A_cpl,
+                    const double* x, double* y, void* stream);
 /* G[b] (Mx x My) = alpha * X[b]^T diag(rowscale) Y[b]; X [batch][K][ldx], Y [batch][K][ldy]; fp64 MFMA */
 int lrbms_gemm_tn(lrbms_ctx* ctx, int32_t batch, int32_t K, int32_t Mx, int32_t My, const double* X, int64_t sx,
                   int32_t ldx, const double* Y, int64_t sy, int32_t ldy, double* G, int64_t sg, int32_t ldg,

@@ -45,6 +45,7 @@ SIGNATURES = {
     'lrbms_reduced_solve_work_size': (c_i64, [c_vp, c_i32]),
     'lrbms_reduced_solve': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms_blockell_apply': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'lrbms_fom_apply': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'lrbms_gemm_tn': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp,
                                      c_i64, c_i32, c_vp, c_dbl, c_vp]),
 }
@@ -316,6 +317,18 @@ class NativeContext:
         rc = self.lib.lrbms_blockell_apply(self.handle, M, self._ptr(A, (self.S, self.n_T, 4, 9), 'A'),
                                            self._ptr(x, (self.S, self.n, M), 'x'), c_vp(y.data_ptr()), self._stream())
         self._check(rc, 'lrbms_blockell_apply')
+        return y
+
+    def fom_apply(self, theta, A_diag, A_cpl, x, out=None):
+        Q, M = A_diag.shape[0], x.shape[2]
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        assert th.shape == (Q,)
+        y = out if out is not None else self.empty(self.S, self.n, M)
+        rc = self.lib.lrbms_fom_apply(self.handle, Q, M, _dblp(th), self._ptr(A_diag, (Q, self.S, self.n_T, 4, 9), 'A_diag'),
+                                      self._ptr(A_cpl, (Q, self.S, 4, self.ncf, 9), 'A_cpl'),
+                                      self._ptr(x, (self.S_ext, self.n, M), 'x'), self._ptr(y, (self.S, self.n, M), 'y'),
+                                      self._stream())
+        self._check(rc, 'lrbms_fom_apply')
         return y
 
     def gemm_tn(self, X, Y, rowscale=None, alpha=1.0):

@@ -122,6 +122,46 @@ __global__ __launch_bounds__(256) void k_blockell_apply(Tmpl t, int S, int M, co
   }
 }
 
+// Full-order block operator: y_s = sum_q theta_q (A_diag_q x_s + coupling blocks x_neighbour)
+struct QVecA { double v[8]; };
+__global__ __launch_bounds__(256) void k_fom_apply(Tmpl t, int S, const int* __restrict__ nbr, int Q, QVecA theta, int M,
+                                                   const double* __restrict__ A_diag, const double* __restrict__ A_cpl,
+                                                   const double* __restrict__ x, double* __restrict__ y) {
+  const long total = (long)S * t.nT * M;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % M);
+    const long se = idx / M;
+    const int e = (int)(se % t.nT), s = (int)(se / t.nT);
+    double acc[3] = {0, 0, 0};
+    for (int b = 0; b < 4; ++b) {
+      int e2 = e, s2 = s, side = -1;
+      if (b > 0) {
+        const int nb = t.nb_elem[e * 3 + b - 1];
+        if (nb >= 0) {
+          e2 = nb;
+        } else {
+          side = -1 - nb;
+          s2 = nbr[s * 5 + side_to_slot(side)];
+          if (s2 < 0) continue;
+          e2 = t.nb_elem_out[e * 3 + b - 1];
+        }
+      }
+      const double* xr = x + ((long)s2 * t.n + 3 * e2) * M + c;
+      const double x0 = xr[0], x1 = xr[M], x2 = xr[2 * M];
+      for (int q = 0; q < Q; ++q) {
+        const double* blk = side < 0 ? A_diag + (((long)q * S + s) * t.nT + e) * 36 + b * 9
+                                     : A_cpl + ((((long)q * S + s) * 4 + side) * t.ncf + t.elem_side_pos[e * 3 + b - 1]) * 9;
+        const double th = theta.v[q];
+        for (int i = 0; i < 3; ++i) acc[i] += th * (blk[i * 3] * x0 + blk[i * 3 + 1] * x1 + blk[i * 3 + 2] * x2);
+      }
+    }
+    double* yr = y + ((long)s * t.n + 3 * e) * M + c;
+    yr[0] = acc[0];
+    yr[M] = acc[1];
+    yr[2 * M] = acc[2];
+  }
+}
+
 // y[s][3e+i][c] = scal[s][e] * sum_j K_e[i][j] x[s][3e+j][c]  (mode 0: K_e = stiffness template;
 // mode 1: K_e = mass template |T|/12 (1 + delta_ij), scal ignored)
 __global__ __launch_bounds__(256) void k_elemdiag_apply(Tmpl t, int S, int M, int mode, const double* __restrict__ scal,
@@ -300,6 +340,17 @@ int launch_blockell_apply(lrbms_ctx* ctx, int S, int M, const double* A, long sA
                           hipStream_t st) {
   const Tmpl& t = ctx->t;
   hipLaunchKernelGGL(k_blockell_apply, dim3(grid_for((long)S * t.nT * M)), dim3(256), 0, st, t, S, M, A, sA, x, y);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
+}
+
+int launch_fom_apply(lrbms_ctx* ctx, int Q, int M, const double* theta, const double* A_diag, const double* A_cpl,
+                     const double* x, double* y, hipStream_t st) {
+  const Tmpl& t = ctx->t;
+  QVecA th;
+  for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
+  hipLaunchKernelGGL(k_fom_apply, dim3(grid_for((long)ctx->S * t.nT * M)), dim3(256), 0, st, t, ctx->S, ctx->nbr, Q, th, M,
+                     A_diag, A_cpl, x, y);
   LRBMS_LAUNCH_CHECK(ctx);
   return LRBMS_OK;
 }

@@ -223,6 +223,13 @@ int lrbms_blockell_apply(lrbms_ctx* ctx, int32_t M, const double* A, const doubl
   return launch_blockell_apply(ctx, ctx->S, M, A, (long)ctx->t.nT * 36, x, y, (hipStream_t)stream);
 }
 
+int lrbms_fom_apply(lrbms_ctx* ctx, int32_t Q, int32_t M, const double* theta, const double* A_diag, const double* A_cpl,
+                    const double* x, double* y, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, M); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, A_diag); CHECK_PTR(ctx, A_cpl);
+  CHECK_PTR(ctx, x); CHECK_PTR(ctx, y);
+  return launch_fom_apply(ctx, Q, M, theta, A_diag, A_cpl, x, y, (hipStream_t)stream);
+}
+
 int lrbms_gemm_tn(lrbms_ctx* ctx, int32_t batch, int32_t K, int32_t Mx, int32_t My, const double* X, int64_t sx, int32_t ldx,
                   const double* Y, int64_t sy, int32_t ldy, double* G, int64_t sg, int32_t ldg, const double* rowscale,
                   double alpha, void* stream) {

@@ -85,6 +85,8 @@ int launch_assemble_flux(lrbms_ctx*, int Q, const double* lam, double* F, hipStr
 int launch_oswald(lrbms_ctx*, int N, const double* V, double* Wt, hipStream_t);
 int launch_flux(lrbms_ctx*, int Q, int N, const double* F, const double* V, double* Rt, hipStream_t);
 int launch_blockell_apply(lrbms_ctx*, int S, int M, const double* A, long sA, const double* x, double* y, hipStream_t);
+int launch_fom_apply(lrbms_ctx*, int Q, int M, const double* theta, const double* A_diag, const double* A_cpl,
+                     const double* x, double* y, hipStream_t);
 int launch_gemm_tn(lrbms_ctx*, int batch, int K, int Mx, int My, const double* X, long sx, int ldx, const double* Y,
                    long sy, int ldy, double* G, long sg, int ldg, const double* rowscale, double alpha, hipStream_t);
 int launch_project_system(lrbms_ctx*, int Q, int N, const double* V, const double* A_diag, const double* A_cpl,

@@ -1,0 +1,255 @@
+"""``discretize`` of the block-SWIPDG LRBMS discretization
+(reference python/dune/pylrbms/discretize_elliptic_block_swipdg.py:530-811).
+
+Same entry point and return value ``(d, data)``; ``d`` answers what the reference's ``DuneDiscretization`` is asked on
+the hot path: ``solve``, ``estimate``, ``operators[...]``, ``products['l2']``, ``solution_space.subspaces[i].id``,
+``parse_parameter``, ``parameter_space``, ``unblock``, ``shape_functions``, ``neighborhoods``, ``estimator`` with
+``flux_reconstruction`` / ``oswald_interpolation_error``.  All arithmetic is done by the HIP kernels through
+``pylrbms_amd.engine.Engine``; nothing here computes on the CPU besides coefficient sampling and index bookkeeping.
+
+Out of scope in this round: ``solve_for_local_correction`` (online enrichment), ``visualize``.
+"""
+import numpy as np
+
+from pylrbms_amd.engine import Engine, blockell_to_dense
+from pylrbms_amd.estimators import EllipticEstimator
+from pylrbms_amd.parallel import Communicator, HaloExchange, HaloPlan
+from pylrbms_amd.parameters import CubicParameterSpace, parse_parameter
+from pylrbms_amd.vectorarrays import BlockVectorArray, BlockVectorSpace, SubSpace
+
+
+class OperatorHandle:
+    """Named view of one operator of ``d.operators`` (the reference stores pyMOR operators there,
+    block_swipdg.py:676,733-770).  ``matrix()`` copies the local sparse matrix to the host for inspection."""
+
+    def __init__(self, name, kind, subdomain, discretization):
+        self.name, self.kind, self.subdomain, self._d = name, kind, subdomain, discretization
+
+    def matrix(self):
+        eng, ii = self._d.engine, self._d.engine.local.index(self.subdomain)
+        t = eng.t
+        if self.kind == 'local_energy_dg_product':
+            return blockell_to_dense(t, eng.P_diag[ii].cpu().numpy())
+        if self.kind == 'l2':
+            out = np.zeros((t.n, t.n))
+            for e in range(t.n_T):
+                out[3 * e:3 * e + 3, 3 * e:3 * e + 3] = t.area[e] / 12.0 * (1.0 + np.eye(3))
+            return out
+        raise NotImplementedError('matrix() of {} (a Concatenation in the reference)'.format(self.name))
+
+
+class LinearImageOperator:
+    """``d.estimator.oswald_interpolation_error`` / ``.flux_reconstruction``: ``apply(U)`` runs the K7 / K8 kernel and
+    returns the target-major image array ``[S, rows, 5 * cols]`` (see include/lrbms_hip.h)."""
+
+    def __init__(self, discretization, kind):
+        self._d, self.kind = discretization, kind
+        self.linear = True
+
+    def apply(self, U, mu=None):
+        d = self._d
+        V = d._with_halo(U.tensor)
+        if self.kind == 'oswald':
+            return d.engine.ctx.oswald_apply(V)
+        return d.engine.ctx.flux_reconstruct(d.engine.F, V)
+
+
+class DuneDiscretization:
+    """Block-SWIPDG discretization living on one GPU (one rank's tile of subdomains)."""
+
+    def __init__(self, engine, grid_and_problem_data, solver_options, mpi_comm):
+        self.engine = engine
+        self.grid = grid_and_problem_data['grid']
+        self.data = None
+        self.solver_options = solver_options
+        self.mpi_comm = mpi_comm if mpi_comm is not None else Communicator()
+        p = grid_and_problem_data
+        lam = p['lambda']
+        self.lambda_coeffs = lam['coefficients'] if isinstance(lam, dict) else None
+        self.parameter_type = p.get('parameter_type', {})
+        self.neighborhoods = [self.grid.neighborhood_of(ii) for ii in range(self.grid.num_subdomains)]
+        self.enrichment_data = (self.grid, None, p['lambda'], p['kappa'], p['f'], None)
+        n = engine.t.n
+        self.solution_space = BlockVectorSpace([SubSpace(n, 'domain_{}'.format(ii)) for ii in engine.local])
+        self.name = 'block_swipdg'
+        self._halo = {}
+        self.parameter_space = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _with_halo(self, t_local):
+        """[S, n, L] -> [S_ext, n, L] with the halo slabs filled (one all-gather when sharded)."""
+        eng = self.engine
+        if eng.S_ext == eng.S:
+            return t_local.contiguous()
+        import torch
+        L = t_local.shape[2]
+        V = torch.zeros(eng.S_ext, eng.t.n, L, dtype=t_local.dtype, device=t_local.device)
+        V[:eng.S] = t_local
+        if L not in self._halo:
+            g = self.grid
+            from pylrbms_amd.grid import DDSubdomainsGrid
+            plan = HaloPlan(lambda r: DDSubdomainsGrid(g.lower_left, g.upper_right, g.K, g.P, rank=r,
+                                                       world_size=g.world_size), g.world_size, g.rank)
+            self._halo[L] = HaloExchange(plan, L, V.device, group=getattr(self.mpi_comm, 'group', None))
+        return self._halo[L](V)
+
+    def parse_parameter(self, mu):
+        return parse_parameter(mu, self.parameter_type)
+
+    def theta(self, mu):
+        mu = self.parse_parameter(mu)
+        return np.array([c.evaluate(mu) for c in self.lambda_coeffs])
+
+    def with_(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+        return self
+
+    # ------------------------------------------------------------------ reference API
+    def unblock(self, U):
+        return U.data                                                     # block-mapper ordering == global ordering
+
+    def visualize(self, U, *args, **kwargs):
+        return None
+
+    def shape_functions(self, subdomain, order=0):
+        """block_swipdg.py:187-200: only ``order=0`` (the constant) works in the reference (App. B-4)."""
+        assert 0 <= order <= 1
+        if order == 1:
+            raise NotImplementedError('order=1 calls the undefined dune_project in the reference (block_swipdg.py:197)')
+        space = BlockVectorSpace([self.solution_space.subspaces[self.engine.local.index(subdomain)]])
+        return BlockVectorArray(self.engine.ctx.zeros(1, self.engine.t.n, 1) + 1.0, space)
+
+    def solve(self, mu, inverse_options=None):
+        """``DuneDiscretization._solve`` (block_swipdg.py:219-225).  The reference hands the global matrix to ISTL
+        (bicgstab.ilut); here: Jacobi-preconditioned CG on the SPD block operator, matvec = ``lrbms_fom_apply``.
+        (Snapshot generation is not on the hot path: SURVEY.md section 8f #2.)"""
+        import torch
+        import torch.distributed as dist
+        eng = self.engine
+        theta = self.theta(mu)
+        opts = inverse_options or {}
+        rtol = float(opts.get('precision', 1e-12)) if isinstance(opts, dict) else 1e-12
+        rtol = min(rtol, 1e-10)
+        max_iter = int(opts.get('max_iter', 20000)) if isinstance(opts, dict) else 20000
+        max_iter = max(max_iter, 20000)
+        group = getattr(self.mpi_comm, 'group', None)
+        sharded = eng.S_ext != eng.S
+
+        def dot(a, b):
+            v = (a * b).sum()
+            if sharded:
+                dist.all_reduce(v, group=group)
+            return v
+
+        def apply(x):
+            return eng.ctx.fom_apply(theta, eng.A_diag, eng.A_cpl, self._with_halo(x))
+
+        # diagonal of A(mu): diagonal 3x3 blocks of the block-ELL storage
+        diag = sum(float(theta[q]) * eng.A_diag[q][:, :, 0].reshape(eng.S, eng.t.n_T, 3, 3).diagonal(dim1=2, dim2=3)
+                   for q in range(eng.Q)).reshape(eng.S, eng.t.n, 1)
+        b = eng.b.reshape(eng.S, eng.t.n, 1)
+        x = torch.zeros_like(b)
+        r = b.clone()
+        z = r / diag
+        p = z.clone()
+        rz = dot(r, z)
+        bb = float(dot(b, b))
+        if bb == 0.0:
+            return BlockVectorArray(x, self.solution_space)
+        for it in range(max_iter):
+            Ap = apply(p)
+            alpha = rz / dot(p, Ap)
+            x += alpha * p
+            r -= alpha * Ap
+            if it % 25 == 24 and float(dot(r, r)) <= (rtol ** 2) * bb:
+                break
+            z = r / diag
+            rz_new = dot(r, z)
+            p = z + (rz_new / rz) * p
+            rz = rz_new
+        else:
+            raise RuntimeError('FOM CG did not converge')
+        return BlockVectorArray(x, self.solution_space)
+
+    def _local_estimates(self, U, mu):
+        """Per-subdomain nc / r / df for every vector of a full-order array: the vectors become a ``len(U)``-column
+        basis pushed through K7 / K8 / P2, and the k-th unit coefficient vector selects the k-th pairwise form."""
+        import torch
+        eng = self.engine
+        theta = self.theta(mu)
+        V = self._with_halo(U.tensor)
+        L = V.shape[2]
+        buf = eng.project_and_estimate(V, project_system=False)
+        out = []
+        for k in range(L):
+            u = eng.ctx.zeros(eng.S_ext, L)
+            u[:, k] = 1.0
+            out.append(eng.reduced_estimate(theta, u, buf['grams']))
+        eta = torch.stack(out, dim=2)                                      # [3, S, L]
+        return eta[0], eta[1], eta[2]
+
+    def estimate(self, U, mu=None, decompose=False):
+        return self.estimator.estimate(U, self.parse_parameter(mu), self, decompose=decompose)
+
+    def solve_for_local_correction(self, subdomain, Us, mu=None, inverse_options=None):
+        raise NotImplementedError('online enrichment (block_swipdg.py:227-316) is SURVEY.md section 8f "next" #1')
+
+
+def discretize(grid_and_problem_data, solver_options=None, mpi_comm=None, device_index=None):
+    """Reference block_swipdg.py:530-811.  Returns ``(d, data)`` with ``data`` keys as at :631-637."""
+    p = grid_and_problem_data
+    grid = p['grid']
+    lambda_, kappa = p['lambda'], p['kappa']
+    if isinstance(lambda_, dict):
+        lambda_funcs, lambda_coeffs = lambda_['functions'], lambda_['coefficients']
+    else:
+        from pylrbms_amd.parameters import ConstantParameterFunctional
+        lambda_funcs, lambda_coeffs = [lambda_], [ConstantParameterFunctional(1.)]
+        p = dict(p, **{'lambda': {'functions': lambda_funcs, 'coefficients': lambda_coeffs}})
+    f = p['f']
+    if isinstance(f, dict):                                               # block_swipdg.py:589-595,:739-748,:780-785
+        if len(f['functions']) != 1 or f['coefficients'][0] != 1:
+            raise NotImplementedError('the residual operators exist only for one f component with coefficient 1')
+        f = f['functions'][0]
+    mu_bar, mu_hat = p['mu_bar'], p['mu_hat']
+    theta_bar = np.array([c.evaluate(mu_bar) for c in lambda_coeffs])
+    if device_index is None:
+        import torch
+        device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    engine = Engine(grid, lambda_funcs, kappa, f, p['lambda_bar'], p['lambda_hat'], theta_bar, device_index=device_index)
+    engine.assemble()
+
+    d = DuneDiscretization(engine, p, solver_options, mpi_comm)
+    operators = {}
+    for ii in engine.local:
+        for kind in ('nc', 'r_fd', 'r_dd', 'df_aa', 'df_bb', 'df_ab', 'local_energy_dg_product'):
+            name = '{}_{}'.format(kind, ii)
+            operators[name] = OperatorHandle(name, kind, ii, d)
+    d.operators = operators
+    d.products = {'l2': [OperatorHandle('l2_{}'.format(ii), 'l2', ii, d) for ii in engine.local]}
+    oi_op, fr_op = LinearImageOperator(d, 'oswald'), LinearImageOperator(d, 'flux')
+    ones = np.ones(engine.S)
+    d.estimator = EllipticEstimator(grid, engine.ceps, engine.hdiam * ones, engine.f2, lambda_coeffs, mu_bar, mu_hat,
+                                    fr_op, oswald_interpolation_error=oi_op, mpi_comm=d.mpi_comm)
+    parameter_range = p['parameter_range'] if 'parameter_range' in p else (0.1, 1.0)
+    d.parameter_space = CubicParameterSpace(d.parameter_type, parameter_range[0], parameter_range[1])
+
+    class _BlockSpace:                                                    # data['block_space'] (block_swipdg.py:632)
+        num_blocks = grid.num_subdomains
+
+        class mapper:
+            size = grid.num_subdomains * engine.t.n
+
+        @staticmethod
+        def local_space(ii):
+            class _Local:
+                @staticmethod
+                def size():
+                    return engine.t.n
+            return _Local
+
+    data = dict(grid=grid, block_space=_BlockSpace, local_projections=[], local_rt_projections=[],
+                local_oi_projections=[], local_div_ops=[], local_l2_products=d.products['l2'])
+    d.data = data
+    return d, data

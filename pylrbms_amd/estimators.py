@@ -1,0 +1,98 @@
+"""Localized a-posteriori error estimator (reference python/dune/pylrbms/estimators.py:28-136).
+
+Same class names, constructor arguments and return values as the reference's ``EstimatorBase`` /
+``EllipticEstimator``.  The per-subdomain loop of ``_estimate_elliptic`` (estimators.py:70-91: six
+``pairwise_apply2`` / ``apply`` calls per subdomain) is ONE launch of the HIP kernel behind
+``lrbms_reduced_estimate`` on the projected operators; full-order vectors take the same route after being pushed
+through the Oswald / flux-reconstruction kernels as a ``len(U)``-column basis.
+
+Reference quirks kept as written, switchable:
+* B-1 ``sqrt_local=False``: the local indicators stay squared (estimators.py:71-101);
+* B-2 ``alpha_first_only=True``: ``alpha`` returns inside its loop (estimators.py:121).
+"""
+import numpy as np
+
+from pylrbms_amd.parallel import global_norms
+
+
+class EstimatorBase:
+
+    def __init__(self, grid, min_diffusion_evs, subdomain_diameters, local_eta_rf_squared, lambda_coeffs, mu_bar, mu_hat,
+                 flux_reconstruction, oswald_interpolation_error, mpi_comm, global_rt_space=None, global_dg_space=None,
+                 sqrt_local=False, alpha_first_only=True):
+        self.grid = grid
+        self.min_diffusion_evs = min_diffusion_evs
+        self.subdomain_diameters = subdomain_diameters
+        self.local_eta_rf_squared = local_eta_rf_squared
+        self.lambda_coeffs = lambda_coeffs
+        self.mu_bar = mu_bar
+        self.mu_hat = mu_hat
+        self.flux_reconstruction = flux_reconstruction
+        self.oswald_interpolation_error = oswald_interpolation_error
+        self.num_subdomains = len(grid.subdomains_on_rank)
+        self.mpi_comm = mpi_comm
+        self.global_rt_space = global_rt_space
+        self.global_dg_space = global_dg_space
+        self.sqrt_local = sqrt_local
+        self.alpha_first_only = alpha_first_only
+
+    def with_(self, **kwargs):
+        import copy
+        new = copy.copy(self)
+        for k, v in kwargs.items():
+            setattr(new, k, v)
+        return new
+
+    def _local_indicators(self, U, mu, d):
+        """Returns (local_eta_nc, local_eta_r, local_eta_df), each ``[num_subdomains, len(U)]`` torch tensors."""
+        return d._local_estimates(U, mu)
+
+    def _estimate_elliptic(self, U, mu, d, elliptic_reconstruction=False, decompose=False):
+        if elliptic_reconstruction:
+            assert False                                                   # estimators.py:63-64
+        alpha_mu_mu_bar = self.alpha(self.lambda_coeffs, mu, self.mu_bar)
+        gamma_mu_mu_bar = self.gamma(self.lambda_coeffs, mu, self.mu_bar)
+        alpha_mu_mu_hat = self.alpha(self.lambda_coeffs, mu, self.mu_hat)
+        local_eta_nc, local_eta_r, local_eta_df = self._local_indicators(U, mu, d)
+        if self.sqrt_local:
+            local_eta_nc, local_eta_r, local_eta_df = (x.abs().sqrt() for x in (local_eta_nc, local_eta_r, local_eta_df))
+        group = getattr(self.mpi_comm, 'group', None)
+        etas = []
+        for k in range(local_eta_nc.shape[1]):
+            norms = global_norms(local_eta_nc[:, k], local_eta_r[:, k] + local_eta_df[:, k], group)   # :100-101
+            eta = np.sqrt(gamma_mu_mu_bar) * float(norms[0]) + (1. / np.sqrt(alpha_mu_mu_hat)) * float(norms[1])
+            etas.append(eta * 1. / np.sqrt(alpha_mu_mu_bar))
+        eta = etas[0] if len(etas) == 1 else np.array(etas)
+        if decompose:
+            nc, r, df = (x.cpu().numpy() for x in (local_eta_nc, local_eta_r, local_eta_df))
+            local_indicators = np.array(
+                [(2. / alpha_mu_mu_bar) * (gamma_mu_mu_bar * nc[ii] ** 2 + (1. / alpha_mu_mu_hat) * (r[ii] + df[ii]) ** 2)
+                 for ii in range(self.num_subdomains)])                    # :105-109
+            return eta, (nc, r, df), local_indicators
+        return eta
+
+    def alpha(self, thetas, mu, mu_bar):
+        result = np.inf
+        for theta in thetas:
+            theta_mu = theta.evaluate(mu)
+            theta_mu_bar = theta.evaluate(mu_bar)
+            assert theta_mu / theta_mu_bar > 0
+            result = np.min((result, theta_mu / theta_mu_bar))
+            if self.alpha_first_only:
+                return result                                              # estimators.py:121 (inside the loop)
+        return result
+
+    def gamma(self, thetas, mu, mu_bar):
+        result = -np.inf
+        for theta in thetas:
+            theta_mu = theta.evaluate(mu)
+            theta_mu_bar = theta.evaluate(mu_bar)
+            assert theta_mu / theta_mu_bar > 0
+            result = np.max((result, theta_mu / theta_mu_bar))
+        return result
+
+
+class EllipticEstimator(EstimatorBase):
+
+    def estimate(self, U, mu, d, decompose=False):
+        return self._estimate_elliptic(U, mu, d, False, decompose)

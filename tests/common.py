@@ -168,8 +168,11 @@ def compare_all(p, engine, V, mu, do_solve=True):
     G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = [host(x) for x in buf['grams']]
     errs = {k: 0.0 for k in ('B_sys', 'rhs_red', 'E_red', 'M_red', 'G_nc', 'r_fd', 'G_rdd', 'G_bb', 'G_ab', 'G_aa')}
     sys_scale = max(np.abs(rd.op[ii][ii][q]).max() for ii in range(S) for q in range(Q))
-    ab_scale = max(max(np.abs(rd.df_ab[ii][q]).max() for ii in range(S) for q in range(Q)), 1e-300)
-    aa_scale = max(max(np.abs(rd.df_aa[ii][q][q2]).max() for ii in range(S) for q in range(Q) for q2 in range(Q)), 1e-300)
+    # floors: a constant basis (N = 1) has zero gradient, so df_aa / df_ab are exactly 0 up to rounding noise
+    vscale = float(np.abs(V).max()) ** 2
+    ab_scale = max(max(np.abs(rd.df_ab[ii][q]).max() for ii in range(S) for q in range(Q)), vscale)
+    aa_scale = max(max(np.abs(rd.df_aa[ii][q][q2]).max() for ii in range(S) for q in range(Q) for q2 in range(Q)),
+                   vscale)
     for ii in range(S):
         sl = slots_of(grid, ii)
         for q in range(Q):

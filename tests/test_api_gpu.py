@@ -1,0 +1,108 @@
+"""Drop-in API on the GPU: the call sequence of the reference driver python/scripts/online_adaptive_lrbms.py:65-151
+(init problem -> discretize -> d.solve / d.estimate -> ParallelLRBMSReductor(order=0) -> extend_basis(snapshots) ->
+reduce -> rd.solve / rd.estimate -> reconstruct -> d.estimate(reconstruction)), checked against the oracle."""
+import numpy as np
+import pytest
+
+from common import oracle_from_problem
+from oracle.lrbms import OracleReductor
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(problem_module, config, mus, mu_test):
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    from pylrbms_amd.reductor import ExtensionError, ParallelLRBMSReductor
+    p = problem_module.init_grid_and_problem(config)
+    solver_options = {'max_iter': '400', 'precision': '1e-6', 'type': 'bicgstab.ilut'}
+    d, data = discretize(p, solver_options={'inverse': solver_options}, mpi_comm=None)
+    block_space = data['block_space']
+    o = oracle_from_problem(p)
+
+    # Phase 3: FOM solve + estimate
+    mu = d.parse_parameter(mu_test)
+    U = d.solve(mu)
+    U_ref = o.solve(mu_test)
+    assert np.abs(U.data.reshape(o.S, o.n) - U_ref).max() < 1e-8 * np.abs(U_ref).max()
+    eta, (nc, r, df), ind = d.estimate(U, mu=mu, decompose=True)
+    Ut = U.data.reshape(o.S, o.n)
+    eta_o, (nc_o, r_o, df_o), ind_o = o.estimate(Ut, mu_test, decompose=True)
+    assert abs(eta - eta_o) < 1e-9 * eta_o
+    for a, b in ((nc[:, 0], nc_o), (r[:, 0], r_o), (df[:, 0], df_o), (ind[:, 0], ind_o)):
+        assert np.abs(a - b).max() < 1e-9 * np.abs(b).max()
+
+    # reductor with the local energy products, constant shape functions, two snapshots
+    reductor = ParallelLRBMSReductor(
+        d, products=[d.operators['local_energy_dg_product_{}'.format(ii)] for ii in range(block_space.num_blocks)],
+        order=0)
+    snaps = []
+    for m in mus:
+        S_ = d.solve(m)
+        snaps.append(S_.data.reshape(o.S, o.n))
+        try:
+            reductor.extend_basis(S_)
+        except ExtensionError:
+            pass
+    N = reductor.basis_size()
+    assert N == 1 + len(mus)
+    rd = reductor.reduce()
+    assert rd.solution_space.dim == o.S * N
+
+    # local bases are energy-orthonormal
+    E = rd.E_red.cpu().numpy()
+    assert np.abs(E - np.eye(N)[None]).max() < 1e-9
+
+    u = rd.solve(mu)
+    ur = reductor.reconstruct(u)
+    # oracle: Galerkin solution in the same span (basis independent)
+    bases = [np.stack([np.ones(o.n)] + [s[ii] for s in snaps], axis=1) for ii in range(o.S)]
+    ored = OracleReductor(o, bases)
+    ord_ = ored.reduce()
+    ur_o = np.stack(ored.reconstruct(ord_.solve(mu_test)))
+    assert np.abs(ur.data.reshape(o.S, o.n) - ur_o).max() < 1e-8 * np.abs(ur_o).max()
+
+    est_red = rd.estimate(u, mu=mu)
+    est_rec = d.estimate(ur, mu=mu)
+    est_o = o.estimate(ur_o, mu_test)
+    assert abs(est_red - est_rec) < 1e-8 * est_rec         # online_adaptive_lrbms.py:145-149
+    assert abs(est_red - est_o) < 1e-7 * est_o
+    eta2, (nc2, r2, df2), ind2 = rd.estimate(u, mu=mu, decompose=True)
+    assert nc2.shape == (o.S, 1) and ind2.shape == (o.S, 1)
+    return d, rd, reductor
+
+
+def test_reference_driver_sequence_os2015():
+    from pylrbms_amd import OS2015_academic_problem
+    config = {'num_subdomains': [2, 2], 'half_num_fine_elements_per_subdomain_and_dim': 4}   # online_adaptive_lrbms.py:56-61
+    d, rd, reductor = _run(OS2015_academic_problem, config, mus=[(0.1,), (1.0,)], mu_test=0.1)
+    # the online loop returns immediately when the target is met (online_enrichment.py:81-83)
+    from pylrbms_amd.online_enrichment import AdaptiveEnrichment
+    loop = AdaptiveEnrichment(None, d, d.data['block_space'], reductor, rd, target_error=1e6, marking_doerfler_theta=0.8,
+                              marking_max_age=0)
+    U, rd2, _ = loop.solve(0.5, enrichment_steps=1)
+    assert rd2 is rd and len(U) == 1
+    with pytest.raises(NotImplementedError):
+        reductor.enrich_local(0, U, None)
+
+
+def test_reference_driver_sequence_thermalblock():
+    """BASELINE.json config 1: 2D thermal block, 2x2 subdomains."""
+    from pylrbms_amd import thermalblock_problem
+    config = {'num_subdomains': [2, 2], 'half_num_fine_elements_per_subdomain_and_dim': 4}
+    _run(thermalblock_problem, config, mus=[(0.1, 0.1, 0.1, 0.1), (1.0, 1.0, 1.0, 1.0), (1.0, 0.1, 0.3, 0.7)],
+         mu_test=(0.4, 0.9, 0.2, 0.6))
+
+
+def test_fom_apply_matches_the_oracle_operator():
+    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': [3, 4], 'coarse_per_subdomain': 2})
+    d, _ = discretize(p)
+    o = oracle_from_problem(p)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((o.S, o.n, 3))
+    eng = d.engine
+    y = eng.ctx.fom_apply(d.theta(0.37), eng.A_diag, eng.A_cpl, eng.ctx.from_numpy(x)).cpu().numpy()
+    A = o.assemble_global(0.37)
+    ref = (A @ x.reshape(o.ndof, 3)).reshape(o.S, o.n, 3)
+    assert np.abs(y - ref).max() < 1e-12 * np.abs(ref).max()

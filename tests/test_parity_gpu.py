@@ -156,5 +156,6 @@ def test_native_argument_checks_raise():
         eng.ctx.oswald_apply(eng.ctx.zeros(eng.S, eng.t.n + 1, 3))        # wrong shape
     with pytest.raises(NativeError):
         eng.ctx.oswald_apply(eng.ctx.zeros(eng.S, eng.t.n, 3).float())    # wrong dtype
-    with pytest.raises(NativeError):
-        eng.ctx.reduced_solve(np.array([1.0, -1.0]), *eng.project_and_estimate(eng.ctx.zeros(eng.S, eng.t.n, 2))['sys'][:2])
+    buf = eng.project_and_estimate(eng.ctx.from_numpy(make_bases(eng.S, eng.t.n, 2, seed=1)))
+    with pytest.raises(NativeError):                                      # LRBMS_E_NOT_CONVERGED surfaces as an error
+        eng.ctx.reduced_solve(np.array([1.0, 0.5]), buf['sys'][0], buf['sys'][1], rtol=1e-30, max_iter=3)
