@@ -89,7 +89,7 @@ def test_reference_driver_sequence_thermalblock():
     """BASELINE.json config 1: 2D thermal block, 2x2 subdomains."""
     from pylrbms_amd import thermalblock_problem
     config = {'num_subdomains': [2, 2], 'half_num_fine_elements_per_subdomain_and_dim': 4}
-    _run(thermalblock_problem, config, mus=[(0.1, 0.1, 0.1, 0.1), (1.0, 1.0, 1.0, 1.0), (1.0, 0.1, 0.3, 0.7)],
+    _run(thermalblock_problem, config, mus=[(0.1, 1.0, 1.0, 1.0), (1.0, 0.1, 1.0, 1.0), (1.0, 0.1, 0.3, 0.7)],
          mu_test=(0.4, 0.9, 0.2, 0.6))
 
 
