@@ -68,6 +68,9 @@ typedef struct {
   const int32_t* side_elem;     /* [4][ncf] our element at position pos of a side */
   const int32_t* side_elem_out; /* [4][ncf] the neighbour's element there */
   const int32_t* side_count;    /* [4] */
+  int32_t ntouch;               /* row length of touch_elem */
+  const int32_t* touch_elem;    /* [4][ntouch] elements with a vertex on the side, -1 padded */
+  const int32_t* touch_count;   /* [4] */
   const double* grad;           /* [n_T][3][2] grad phi_i */
   const double* area;           /* [n_T] */
   const double* normal;         /* [n_T][3][2] outward unit normals */
@@ -143,6 +146,19 @@ int lrbms_estimator_grams(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V,
                           const double* ebar, const double* caa, const double* Aab, const double* Bbb,
                           const double* b, double* work, double* G_nc, double* r_fd, double* G_rdd, double* G_bb,
                           double* G_ab, double* G_aa, void* stream);
+
+/* Fused form of the whole timed region (K7 + K8 + P1 + P2) that exploits the support of the neighbour images:
+ * same outputs as lrbms_oswald_apply + lrbms_flux_reconstruct + lrbms_project_system + lrbms_estimator_grams, but the
+ * padded image bases Wt / Rt are never materialised.  Supported for N <= 64 and Q N <= 128
+ * (lrbms_fused_supported); work >= lrbms_fused_work_size doubles. */
+int lrbms_fused_supported(lrbms_ctx* ctx, int32_t Q, int32_t N);
+int64_t lrbms_fused_work_size(lrbms_ctx* ctx, int32_t Q, int32_t N);
+int lrbms_project_estimate_fused(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* F,
+                                 const double* A_diag, const double* A_cpl, const double* P_diag, const double* b,
+                                 const double* ebar, const double* caa, const double* Aab, const double* Bbb,
+                                 double* work, double* B_sys, double* rhs_red, double* E_red, double* M_red,
+                                 double* G_nc, double* r_fd, double* G_rdd, double* G_bb, double* G_ab, double* G_aa,
+                                 void* stream);
 
 /* -- online --------------------------------------------------------------------------------------------- */
 /* E1: EstimatorBase._estimate_elliptic on reduced coefficients (estimators.py:45-112), per-subdomain part.

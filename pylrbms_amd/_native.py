@@ -22,6 +22,7 @@ class MeshDesc(ctypes.Structure):
                 [(k, _P_I32) for k in ('nb_elem', 'nb_face', 'nb_elem_out', 'nb_face_out', 'elem_side_pos', 'elem_rt',
                                        'face_sign', 'dof_vertex', 'vdof_ptr', 'vdof_idx', 'rt_e0', 'rt_f0', 'rt_e1',
                                        'rt_f1', 'rt_side', 'side_elem', 'side_elem_out', 'side_count')] +
+                [('ntouch', c_i32), ('touch_elem', _P_I32), ('touch_count', _P_I32)] +
                 [(k, _P_DBL) for k in ('grad', 'area', 'normal', 'face_len', 'points')])
 
 
@@ -41,6 +42,9 @@ SIGNATURES = {
     'lrbms_project_system': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 11),
     'lrbms_estimator_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_estimator_grams': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 16),
+    'lrbms_fused_supported': (ctypes.c_int, [c_vp, c_i32, c_i32]),
+    'lrbms_fused_work_size': (c_i64, [c_vp, c_i32, c_i32]),
+    'lrbms_project_estimate_fused': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 22),
     'lrbms_reduced_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 9 + [c_dbl, c_vp, c_vp]),
     'lrbms_reduced_solve_work_size': (c_i64, [c_vp, c_i32]),
     'lrbms_reduced_solve': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
@@ -152,12 +156,13 @@ class NativeContext:
         d = MeshDesc()
         d.kx, d.ky, d.n_T, d.n_rt, d.n_vertices, d.ncf = t.kx, t.ky, t.n_T, t.n_rt, t.n_vertices, t.ncf
         d.hx, d.hy = t.hx, t.hy
+        d.ntouch = t.ntouch
         kap = np.asarray(kappa, dtype=np.float64).reshape(4)
         for i in range(4):
             d.kappa[i] = kap[i]
         for k in ('nb_elem', 'nb_face', 'nb_elem_out', 'nb_face_out', 'elem_side_pos', 'elem_rt', 'face_sign',
                   'dof_vertex', 'vdof_ptr', 'vdof_idx', 'rt_e0', 'rt_f0', 'rt_e1', 'rt_f1', 'rt_side', 'side_elem',
-                  'side_elem_out', 'side_count'):
+                  'side_elem_out', 'side_count', 'touch_elem', 'touch_count'):
             arrs[k] = np.ascontiguousarray(getattr(t, k), dtype=np.int32)
             setattr(d, k, _i32p(arrs[k]))
         for k in ('grad', 'area', 'normal', 'face_len', 'points'):
@@ -276,6 +281,35 @@ class NativeContext:
             self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._stream())
         self._check(rc, 'lrbms_estimator_grams')
         return G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa
+
+    def fused_supported(self, Q, N):
+        return bool(self.lib.lrbms_fused_supported(self.handle, Q, N))
+
+    def fused_work_size(self, Q, N):
+        sz = self.lib.lrbms_fused_work_size(self.handle, Q, N)
+        if sz < 0:
+            raise NativeError('lrbms_fused_work_size failed')
+        return int(sz)
+
+    def project_estimate_fused(self, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, sys_out, gram_out):
+        Q, N, S = A_diag.shape[0], V.shape[2], self.S
+        W, C = 5 * N, 5 * Q * N
+        if work.numel() < self.fused_work_size(Q, N):
+            raise NativeError('project_estimate_fused: work too small')
+        B_sys, rhs_red, E_red, M_red = sys_out
+        G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = gram_out
+        rc = self.lib.lrbms_project_estimate_fused(
+            self.handle, Q, N, self._ptr(V, (self.S_ext, self.n, N), 'V'), self._ptr(F, (Q, S, self.n_rt, 6), 'F'),
+            self._ptr(A_diag, (Q, S, self.n_T, 4, 9), 'A_diag'), self._ptr(A_cpl, (Q, S, 4, self.ncf, 9), 'A_cpl'),
+            self._ptr(P_diag, (S, self.n_T, 4, 9), 'P_diag'), self._ptr(b, (S, self.n), 'b'),
+            self._ptr(ebar, (S, self.n_T), 'ebar'), self._ptr(caa, (Q, Q, S, self.n_T), 'caa'),
+            self._ptr(Aab, (Q, S, self.n_T, 3, 3), 'Aab'), self._ptr(Bbb, (S, self.n_T, 3, 3), 'Bbb'),
+            c_vp(work.data_ptr()), self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'), self._ptr(rhs_red, (S, N), 'rhs_red'),
+            self._ptr(E_red, (S, N, N), 'E_red'), self._ptr(M_red, (S, N, N), 'M_red'),
+            self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, C, C), 'G_rdd'),
+            self._ptr(G_bb, (S, C, C), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
+            self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._stream())
+        self._check(rc, 'lrbms_project_estimate_fused')
 
     # ------------------------------------------------------------------ online
     def reduced_estimate(self, theta, u, grams, f2, ceps, hdiam):

@@ -344,6 +344,14 @@ int launch_blockell_apply(lrbms_ctx* ctx, int S, int M, const double* A, long sA
   return LRBMS_OK;
 }
 
+int launch_project_coupling(lrbms_ctx* ctx, int Q, int N, const double* V, const double* A_cpl, double* B_sys, hipStream_t st) {
+  const Tmpl& t = ctx->t;
+  const size_t lds = sizeof(double) * 2 * 3 * t.ncf * N;
+  hipLaunchKernelGGL(k_project_coupling, dim3(4, ctx->S, Q), dim3(256), lds, st, t, ctx->S, ctx->nbr, N, V, A_cpl, B_sys);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
+}
+
 int launch_fom_apply(lrbms_ctx* ctx, int Q, int M, const double* theta, const double* A_diag, const double* A_cpl,
                      const double* x, double* y, hipStream_t st) {
   const Tmpl& t = ctx->t;

@@ -6,6 +6,13 @@
 
 int64_t estimator_work_size(lrbms_ctx* ctx, int Q, int N);
 int64_t reduced_solve_work_size(lrbms_ctx* ctx, int N);
+int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N);
+bool fused_supported(lrbms_ctx* ctx, int Q, int N);
+int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V, const double* F, const double* A_diag,
+                                  const double* A_cpl, const double* P_diag, const double* b, const double* ebar,
+                                  const double* caa, const double* Aab, const double* Bbb, double* work, double* B_sys,
+                                  double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd, double* G_rdd,
+                                  double* G_bb, double* G_ab, double* G_aa, hipStream_t st);
 
 namespace {
 
@@ -114,6 +121,15 @@ int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* d, int32_t S, int32
   UP(elem_rt, 3 * nT); UP(face_sign, 3 * nT); UP(dof_vertex, n); UP(vdof_ptr, d->n_vertices + 1); UP(vdof_idx, n);
   UP(rt_e0, d->n_rt); UP(rt_f0, d->n_rt); UP(rt_e1, d->n_rt); UP(rt_f1, d->n_rt); UP(rt_side, d->n_rt);
   UP(side_elem, 4 * d->ncf); UP(side_elem_out, 4 * d->ncf); UP(side_count, 4);
+  if (d->ntouch <= 0 || !d->touch_elem || !d->touch_count) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: touch table missing");
+  for (int sd = 0; sd < 4; ++sd) {
+    if (d->touch_count[sd] < 0 || d->touch_count[sd] > d->ntouch) return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: touch_count");
+    for (int p = 0; p < d->touch_count[sd]; ++p)
+      if (d->touch_elem[sd * d->ntouch + p] < 0 || d->touch_elem[sd * d->ntouch + p] >= nT)
+        return lrbms_fail(ctx, LRBMS_E_INVALID, "mesh_upload: touch_elem out of range");
+  }
+  t.ntouch = d->ntouch;
+  UP(touch_elem, 4 * d->ntouch); UP(touch_count, 4);
   UP(grad, 6 * nT); UP(area, nT); UP(normal, 6 * nT); UP(face_len, 3 * nT); UP(points, 6 * nT);
 #undef UP
   const int* nbr_dev = nullptr;
@@ -192,6 +208,29 @@ int lrbms_estimator_grams(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V,
   CHECK_PTR(ctx, r_fd); CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa);
   return launch_estimator_grams(ctx, Q, N, V, Wt, Rt, ebar, caa, Aab, Bbb, b, work, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa,
                                 (hipStream_t)stream);
+}
+
+int lrbms_fused_supported(lrbms_ctx* ctx, int32_t Q, int32_t N) {
+  if (!ctx || !ctx->has_mesh || Q < 1 || Q > 8 || N < 1) return 0;
+  return fused_supported(ctx, Q, N) ? 1 : 0;
+}
+
+int64_t lrbms_fused_work_size(lrbms_ctx* ctx, int32_t Q, int32_t N) {
+  if (!ctx || !ctx->has_mesh || Q < 1 || N < 1) return -1;
+  return fused_work_size(ctx, Q, N);
+}
+
+int lrbms_project_estimate_fused(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* F, const double* A_diag,
+                                 const double* A_cpl, const double* P_diag, const double* b, const double* ebar,
+                                 const double* caa, const double* Aab, const double* Bbb, double* work, double* B_sys,
+                                 double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd, double* G_rdd,
+                                 double* G_bb, double* G_ab, double* G_aa, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, V); CHECK_PTR(ctx, F); CHECK_PTR(ctx, A_diag); CHECK_PTR(ctx, A_cpl);
+  CHECK_PTR(ctx, P_diag); CHECK_PTR(ctx, b); CHECK_PTR(ctx, ebar); CHECK_PTR(ctx, caa); CHECK_PTR(ctx, Aab); CHECK_PTR(ctx, Bbb);
+  CHECK_PTR(ctx, work); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red); CHECK_PTR(ctx, E_red); CHECK_PTR(ctx, M_red);
+  CHECK_PTR(ctx, G_nc); CHECK_PTR(ctx, r_fd); CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa);
+  return launch_project_estimate_fused(ctx, Q, N, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, B_sys, rhs_red, E_red,
+                                       M_red, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, (hipStream_t)stream);
 }
 
 int lrbms_reduced_estimate(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u, const double* G_nc,

@@ -1,0 +1,666 @@
+// Fused project + estimate-offline pass ("v2"): SURVEY.md section 8a rows K7 + K8 + P1 + P2 in seven launches that
+// never materialise the padded image bases Wt / Rt or any "operator x basis" intermediate in HBM.
+//
+// Why this shape.  Every operator of the path is a sum over fine elements T of a 3x3 (or 3x3-gathered) local
+// block, so every projected operator is   G = sum_T  X_T^T  L_T  Y_T   with X_T, Y_T the 3 local rows of a basis-like
+// operand.  Two facts make most of the canonical GEMM count of SURVEY 8(d) structurally zero:
+//   * the image of a NEIGHBOUR's basis restricted to the target subdomain lives only on the elements touching the
+//     shared side (Oswald: elements with a vertex on the side; flux: the 2k side faces), so all blocks of the big
+//     Gram matrices that involve a neighbour slot are rank-<=3*ntouch / rank-ncf updates ("thin" kernels, VALU);
+//   * blocks between two different neighbour slots are zero (or corner-element-only) and are only zero-filled.
+// What remains dense is the self x self part: V^T{A_q V, P V, M V, c K V, A_ab R}, W^T E W, R^T B R, D^T |T| D,
+// all with K = n (or n_T) -- these run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), with the "L_T Y_T"
+// operand built on the fly from L2-resident rows into LDS while another workgroup of the same CU issues MFMAs.
+//
+// Launches (grid = one workgroup per subdomain unless noted):
+//   k_flux_compact   R_self [S][n_rt][QN], R_side [S][4][ncf][QN]           (HBM-bound, tiny)
+//   k_f1<NTX>        X = V:  B_sys diag, E_red, M_red, G_aa, G_ab[:, self], rhs_red   (MFMA)
+//   k_f2<NR>         X = R~: G_bb[self,self], G_rdd[self,self], r_fd[self]            (MFMA)
+//   k_f3<NTX>        X = W_self: G_nc[self,self]                                      (MFMA)
+//   k_thin_nc        grid (4 sides, S): block-row `a` and block [self,a] of G_nc      (VALU)
+//   k_thin_rt        grid (4 sides, S): block-rows (a,q) / blocks [self,(a,q)] of G_bb, G_rdd, G_ab[:, a], r_fd[a]
+//   k_project_coupling (apply.hip): off-diagonal blocks of B_sys
+// Every output element is written exactly once (zeros included); all reductions have a fixed order.
+#include "lrbms_dev.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int EC = 4;               // elements per K-chunk (12 DG rows = 3 MFMA k-steps)
+constexpr int F1_NTY = 8;           // Y column tiles per wave in k_f1
+constexpr int F1_YW = 4 * F1_NTY * 16;   // 512 columns
+constexpr int F1_LDY = F1_YW + 16;  // row stride == 16 (mod 32) doubles: the 4 k-rows of a fragment hit disjoint banks
+
+__host__ __device__ constexpr int padded_ld(int tiles) { return (tiles * 16) % 32 == 16 ? tiles * 16 : tiles * 16 + 16; }
+
+__device__ inline void stiffness3(const Tmpl& t, int e, double K[9]) {
+  for (int i = 0; i < 3; ++i) {
+    const double gx = t.grad[(e * 3 + i) * 2], gy = t.grad[(e * 3 + i) * 2 + 1];
+    for (int j = 0; j < 3; ++j) {
+      const double hx = t.grad[(e * 3 + j) * 2], hy = t.grad[(e * 3 + j) * 2 + 1];
+      K[i * 3 + j] = gx * (t.kappa[0] * hx + t.kappa[1] * hy) + gy * (t.kappa[2] * hx + t.kappa[3] * hy);
+    }
+  }
+}
+
+// Oswald vertex data of DoF row r of subdomain s: inverse patch size (0 on the physical boundary) and, per side,
+// the matching lattice vertex of the neighbour (or -1).
+struct OsInfo {
+  int v;
+  double inv;
+  int vside[4];
+};
+
+__device__ inline OsInfo oswald_info(const Tmpl& t, const int* nbr_s, int r) {
+  OsInfo o;
+  o.v = t.dof_vertex[r];
+  const int lx = o.v % t.nvx, ly = o.v / t.nvx;
+  o.vside[0] = (ly == 0) ? lx + t.nvx * (t.nvy - 1) : -1;
+  o.vside[1] = (lx == 0) ? (t.nvx - 1) + t.nvx * ly : -1;
+  o.vside[2] = (lx == t.nvx - 1) ? t.nvx * ly : -1;
+  o.vside[3] = (ly == t.nvy - 1) ? lx : -1;
+  int cnt = t.vdof_ptr[o.v + 1] - t.vdof_ptr[o.v];
+  bool dirichlet = false;
+  for (int sd = 0; sd < 4; ++sd) {
+    if (o.vside[sd] < 0) continue;
+    if (nbr_s[side_to_slot(sd)] < 0)
+      dirichlet = true;
+    else
+      cnt += t.vdof_ptr[o.vside[sd] + 1] - t.vdof_ptr[o.vside[sd]];
+  }
+  o.inv = dirichlet ? 0.0 : 1.0 / (double)cnt;
+  return o;
+}
+
+__device__ inline double star_sum(const Tmpl& t, const double* Vs, int v, int N, int j) {
+  double acc = 0.0;
+  for (int p = t.vdof_ptr[v]; p < t.vdof_ptr[v + 1]; ++p) acc += Vs[(long)t.vdof_idx[p] * N + j];
+  return acc;
+}
+
+__device__ inline int face_sign_at(const Tmpl& t, const int* nbr_s, int e, int f) {
+  const int nb = t.nb_elem[e * 3 + f];
+  if (nb < 0 && nbr_s[side_to_slot(-1 - nb)] < 0) return 1;   // domain boundary: outward
+  return t.face_sign[e * 3 + f];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// compact flux reconstruction
+__global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
+                                                      const double* __restrict__ F, const double* __restrict__ V,
+                                                      double* __restrict__ Rself, double* __restrict__ Rside) {
+  const long total = (long)S * t.nrt * N;
+  const int QN = Q * N;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % N);
+    const long sr = idx / N;
+    const int r = (int)(sr % t.nrt), s = (int)(sr / t.nrt);
+    const int e0 = t.rt_e0[r], e1 = t.rt_e1[r], side = t.rt_side[r];
+    const int s2 = side >= 0 ? nbr[s * 5 + side_to_slot(side)] : -1;
+    double v0[3], v1[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) v0[i] = V[((long)s * t.n + 3 * e0 + i) * N + j];
+    if (side < 0)
+      for (int i = 0; i < 3; ++i) v1[i] = V[((long)s * t.n + 3 * e1 + i) * N + j];
+    else if (s2 >= 0)
+      for (int i = 0; i < 3; ++i) v1[i] = V[((long)s2 * t.n + 3 * e1 + i) * N + j];
+    for (int q = 0; q < Q; ++q) {
+      const double* f = F + (((long)q * S + s) * t.nrt + r) * 6;
+      const double self = f[0] * v0[0] + f[1] * v0[1] + f[2] * v0[2];
+      const double other = f[3] * v1[0] + f[4] * v1[1] + f[5] * v1[2];
+      Rself[((long)s * t.nrt + r) * QN + q * N + j] = side < 0 ? self + other : self;
+      if (side >= 0)
+        Rside[(((long)s * 4 + side) * t.ncf + t.elem_side_pos[e0 * 3 + t.rt_f0[r]]) * QN + q * N + j] = s2 >= 0 ? other : 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F1: X = V.  Column groups of Y (N columns each), destination = base + s * sstride + row * ld + col
+enum { G_SYS = 0, G_ENERGY = 1, G_MASS = 2, G_AA = 3, G_AB = 4 };
+struct Grp {
+  int kind, q, q2, ld;
+  double* dst;
+  long sstride;
+};
+struct GrpTable {
+  Grp g[12];
+  int n;
+};
+struct F1Args {
+  const double *V, *A_diag, *P_diag, *caa, *Aab, *Rself, *b;
+  double* rhs_red;   // may be null (written only by the launch that carries it)
+  int Q, N, S;
+};
+
+template <int NTX>
+__global__ __launch_bounds__(256, NTX <= 3 ? 2 : 1) void k_f1(Tmpl t, F1Args a, GrpTable gt) {
+  constexpr int LDX = padded_ld(NTX);
+  __shared__ double Xs[3 * EC * LDX];
+  __shared__ double Ys[3 * EC * F1_LDY];
+  __shared__ Grp grp[12];
+  __shared__ double red[256];
+  const int s = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int N = a.N, Q = a.Q, S = a.S, QN = Q * N;
+  const int ncols = gt.n * N;
+  if (tid < gt.n) grp[tid] = gt.g[tid];
+  for (int i = tid; i < 3 * EC * LDX; i += 256) Xs[i] = 0.0;
+  for (int i = tid; i < 3 * EC * F1_LDY; i += 256) Ys[i] = 0.0;
+  __syncthreads();
+
+  d4 acc[NTX][F1_NTY];
+  for (int i = 0; i < NTX; ++i)
+    for (int j = 0; j < F1_NTY; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int my_tiles = min(F1_NTY, max(0, (ncols + 15) / 16 - wave * F1_NTY));   // non-empty column tiles of this wave
+  const double* Vs = a.V + (long)s * t.n * N;
+  double rhs_part = 0.0;
+
+  for (int c0 = 0; c0 < t.nT; c0 += EC) {
+    for (int it = tid; it < EC * N; it += 256) {
+      const int el = it / N, j = it - el * N, T = c0 + el;
+      double vb[4][3];
+      for (int i = 0; i < 3; ++i) vb[0][i] = Vs[(long)(3 * T + i) * N + j];
+      for (int f = 0; f < 3; ++f) {
+        const int nb = t.nb_elem[T * 3 + f];
+        for (int i = 0; i < 3; ++i) vb[1 + f][i] = nb >= 0 ? Vs[(long)(3 * nb + i) * N + j] : 0.0;
+      }
+      for (int i = 0; i < 3; ++i) Xs[(3 * el + i) * LDX + j] = vb[0][i];
+      if (a.rhs_red) {
+        const double* be = a.b + (long)s * t.n + 3 * T;
+        rhs_part += be[0] * vb[0][0] + be[1] * vb[0][1] + be[2] * vb[0][2];
+      }
+      double K[9], kv[3];
+      stiffness3(t, T, K);
+      for (int i = 0; i < 3; ++i) kv[i] = K[i * 3] * vb[0][0] + K[i * 3 + 1] * vb[0][1] + K[i * 3 + 2] * vb[0][2];
+      for (int g = 0; g < gt.n; ++g) {
+        const int kind = grp[g].kind, q = grp[g].q, q2 = grp[g].q2;
+        double y[3] = {0, 0, 0};
+        if (kind == G_SYS || kind == G_ENERGY) {
+          const double* blk = (kind == G_SYS ? a.A_diag + ((long)q * S + s) * t.nT * 36 : a.P_diag + (long)s * t.nT * 36) + (long)T * 36;
+          for (int bb = 0; bb < 4; ++bb)
+            for (int i = 0; i < 3; ++i)
+              y[i] += blk[bb * 9 + i * 3] * vb[bb][0] + blk[bb * 9 + i * 3 + 1] * vb[bb][1] + blk[bb * 9 + i * 3 + 2] * vb[bb][2];
+        } else if (kind == G_MASS) {
+          const double m = t.area[T] / 12.0, sum = vb[0][0] + vb[0][1] + vb[0][2];
+          for (int i = 0; i < 3; ++i) y[i] = m * (sum + vb[0][i]);
+        } else if (kind == G_AA) {
+          const double c = a.caa[(((long)q * Q + q2) * S + s) * t.nT + T];
+          for (int i = 0; i < 3; ++i) y[i] = c * kv[i];
+        } else {  // G_AB: A_ab^q restricted to the self part of the flux image
+          const double* A = a.Aab + (((long)q * S + s) * t.nT + T) * 9;
+          double rv[3];
+          for (int f = 0; f < 3; ++f) rv[f] = a.Rself[((long)s * t.nrt + t.elem_rt[T * 3 + f]) * QN + q2 * N + j];
+          for (int i = 0; i < 3; ++i) y[i] = A[i * 3] * rv[0] + A[i * 3 + 1] * rv[1] + A[i * 3 + 2] * rv[2];
+        }
+        for (int i = 0; i < 3; ++i) Ys[(3 * el + i) * F1_LDY + g * N + j] = y[i];
+      }
+    }
+    __syncthreads();
+    for (int kk = 0; kk < 3 * EC; kk += 4) {
+      double av[NTX];
+      for (int i = 0; i < NTX; ++i) av[i] = Xs[(kk + lk) * LDX + i * 16 + li];
+      for (int jt = 0; jt < F1_NTY; ++jt) {
+        if (jt < my_tiles) {
+          const double bv = Ys[(kk + lk) * F1_LDY + (wave * F1_NTY + jt) * 16 + li];
+          for (int i = 0; i < NTX; ++i) acc[i][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[i][jt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: scatter the tiles to their destination arrays
+  for (int jt = 0; jt < F1_NTY; ++jt) {
+    const int col = (wave * F1_NTY + jt) * 16 + li;
+    if (jt >= my_tiles || col >= ncols) continue;
+    const int g = col / N, j = col - g * N;
+    double* dst = grp[g].dst + (long)s * grp[g].sstride + j;
+    const int ld = grp[g].ld;
+    for (int i = 0; i < NTX; ++i)
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + lk + 4 * r;
+        if (row < N) dst[(long)row * ld] = acc[i][jt][r];
+      }
+  }
+  if (a.rhs_red) {   // items are (el, j) with a fixed thread <-> (el, j) map when EC * N <= 256; otherwise strided
+    red[tid] = rhs_part;
+    __syncthreads();
+    if (EC * N <= 256) {
+      if (tid < N) {
+        double sum = 0.0;
+        for (int el = 0; el < EC; ++el) sum += red[el * N + tid];
+        a.rhs_red[(long)s * N + tid] = sum;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F2: X = element-gathered flux image R~ (3 face rows per element) and its divergence d (1 row per element).
+// One wave per column tile of the (Q N)-wide self block; NR row tiles.
+struct F2Args {
+  const double *Rself, *Bbb, *b;
+  const int* nbr;
+  double *G_bb, *G_rdd, *r_fd;
+  int Q, N, S;
+};
+
+template <int NR>
+__global__ __launch_bounds__(64 * NR) void k_f2(Tmpl t, F2Args a) {
+  constexpr int LD = padded_ld(NR);
+  __shared__ double Xb[3 * EC * LD], Yb[3 * EC * LD], Xd[EC * LD], Yd[EC * LD];
+  __shared__ double red[64 * NR];
+  const int s = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int nthreads = 64 * NR;
+  const int QN = a.Q * a.N, C = 5 * QN;
+  for (int i = tid; i < 3 * EC * LD; i += nthreads) Xb[i] = Yb[i] = 0.0;
+  for (int i = tid; i < EC * LD; i += nthreads) Xd[i] = Yd[i] = 0.0;
+  __syncthreads();
+  d4 accb[NR], accd[NR];
+  for (int i = 0; i < NR; ++i) accb[i] = accd[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* Rs = a.Rself + (long)s * t.nrt * QN;
+  const int* nbr_s = a.nbr + s * 5;
+  double rfd_part = 0.0;
+  for (int c0 = 0; c0 < t.nT; c0 += EC) {
+    for (int it = tid; it < EC * QN; it += nthreads) {
+      const int el = it / QN, c = it - el * QN, T = c0 + el;
+      double rv[3], coef[3];
+      for (int f = 0; f < 3; ++f) {
+        rv[f] = Rs[(long)t.elem_rt[T * 3 + f] * QN + c];
+        coef[f] = face_sign_at(t, nbr_s, T, f) * t.face_len[T * 3 + f] / t.area[T];
+      }
+      const double* B = a.Bbb + ((long)s * t.nT + T) * 9;
+      for (int f = 0; f < 3; ++f) {
+        Xb[(3 * el + f) * LD + c] = rv[f];
+        Yb[(3 * el + f) * LD + c] = B[f * 3] * rv[0] + B[f * 3 + 1] * rv[1] + B[f * 3 + 2] * rv[2];
+      }
+      const double d = coef[0] * rv[0] + coef[1] * rv[1] + coef[2] * rv[2];
+      Xd[el * LD + c] = d;
+      Yd[el * LD + c] = t.area[T] * d;
+      const double* be = a.b + (long)s * t.n + 3 * T;
+      rfd_part += (be[0] + be[1] + be[2]) * d;
+    }
+    __syncthreads();
+    const int ct = wave;   // this wave's column tile
+    for (int kk = 0; kk < 3 * EC; kk += 4) {
+      const double bv = Yb[(kk + lk) * LD + ct * 16 + li];
+      for (int i = 0; i < NR; ++i) accb[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xb[(kk + lk) * LD + i * 16 + li], bv, accb[i], 0, 0, 0);
+    }
+    {
+      const double bv = Yd[lk * LD + ct * 16 + li];
+      for (int i = 0; i < NR; ++i) accd[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xd[lk * LD + i * 16 + li], bv, accd[i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = wave * 16 + li;
+  if (col < QN) {
+    double* gb = a.G_bb + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
+    double* gd = a.G_rdd + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
+    for (int i = 0; i < NR; ++i)
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + lk + 4 * r;
+        if (row < QN) {
+          gb[(long)row * C] = accb[i][r];
+          gd[(long)row * C] = accd[i][r];
+        }
+      }
+  }
+  // r_fd self block: thread <-> (el, c) map is fixed when EC * QN <= nthreads
+  red[tid] = rfd_part;
+  __syncthreads();
+  if (EC * QN <= nthreads) {
+    if (tid < QN) {
+      double sum = 0.0;
+      for (int el = 0; el < EC; ++el) sum += red[el * QN + tid];
+      a.r_fd[(long)s * C + 2 * QN + tid] = sum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F3: X = W_self (Oswald interpolation error of the own basis), Y = E W_self.  One wave per column tile.
+struct F3Args {
+  const double *V, *ebar;
+  const int* nbr;
+  double* G_nc;
+  int N, S;
+};
+
+template <int NTX>
+__global__ __launch_bounds__(64 * NTX) void k_f3(Tmpl t, F3Args a) {
+  constexpr int LD = padded_ld(NTX);
+  __shared__ double Xs[3 * EC * LD], Ys[3 * EC * LD];
+  const int s = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int nthreads = 64 * NTX, N = a.N, W = 5 * N;
+  for (int i = tid; i < 3 * EC * LD; i += nthreads) Xs[i] = Ys[i] = 0.0;
+  __syncthreads();
+  d4 acc[NTX];
+  for (int i = 0; i < NTX; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* Vs = a.V + (long)s * t.n * N;
+  const int* nbr_s = a.nbr + s * 5;
+  for (int c0 = 0; c0 < t.nT; c0 += EC) {
+    for (int it = tid; it < EC * N; it += nthreads) {
+      const int el = it / N, j = it - el * N, T = c0 + el;
+      double w[3];
+      for (int i = 0; i < 3; ++i) {
+        const int r = 3 * T + i;
+        const OsInfo o = oswald_info(t, nbr_s, r);
+        w[i] = Vs[(long)r * N + j] - o.inv * star_sum(t, Vs, o.v, N, j);
+      }
+      double K[9];
+      stiffness3(t, T, K);
+      const double eb = a.ebar[(long)s * t.nT + T];
+      for (int i = 0; i < 3; ++i) {
+        Xs[(3 * el + i) * LD + j] = w[i];
+        Ys[(3 * el + i) * LD + j] = eb * (K[i * 3] * w[0] + K[i * 3 + 1] * w[1] + K[i * 3 + 2] * w[2]);
+      }
+    }
+    __syncthreads();
+    for (int kk = 0; kk < 3 * EC; kk += 4) {
+      const double bv = Ys[(kk + lk) * LD + wave * 16 + li];
+      for (int i = 0; i < NTX; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(kk + lk) * LD + i * 16 + li], bv, acc[i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = wave * 16 + li;
+  if (col < N) {
+    double* g = a.G_nc + (long)s * W * W + (long)(2 * N) * W + 2 * N + col;
+    for (int i = 0; i < NTX; ++i)
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + lk + 4 * r;
+        if (row < N) g[(long)row * W] = acc[i][r];
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Thin part of G_nc: workgroup (side a, subdomain s) writes block-row a (all 5 column blocks) and block [self, a].
+// K runs over the 3 * ntouch rows of the elements with a vertex on side a.
+template <int NMAX>
+__global__ __launch_bounds__(256) void k_thin_nc(Tmpl t, int S, const int* __restrict__ nbr, int N,
+                                                 const double* __restrict__ V, const double* __restrict__ ebar,
+                                                 double* __restrict__ G_nc) {
+  extern __shared__ double lds[];   // Wa [3 * ntouch][N]
+  const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
+  const int W = 5 * N;
+  double* G = G_nc + (long)s * W * W;
+  const int s2 = nbr[s * 5 + slot];
+  if (s2 < 0) {   // no neighbour: the whole block-row and the [self, a] block are zero
+    for (int i = tid; i < N * W; i += 256) G[(long)(slot * N + i / W) * W + i % W] = 0.0;
+    for (int i = tid; i < N * N; i += 256) G[(long)(2 * N + i / N) * W + slot * N + i % N] = 0.0;
+    return;
+  }
+  const int ne = t.touch_count[side];
+  const int* nbr_s = nbr + s * 5;
+  const double* Vs = V + (long)s * t.n * N;
+  // phase 1: Wa rows (image of the neighbour's basis on the touching elements)
+  for (int it = tid; it < 3 * ne * N; it += 256) {
+    const int row = it / N, j = it - row * N;
+    const int T = t.touch_elem[side * t.ntouch + row / 3], r = 3 * T + row % 3;
+    const OsInfo o = oswald_info(t, nbr_s, r);
+    double val = 0.0;
+    if (o.vside[side] >= 0 && o.inv != 0.0) val = -o.inv * star_sum(t, V + (long)s2 * t.n * N, o.vside[side], N, j);
+    lds[row * N + j] = val;
+  }
+  __syncthreads();
+  // phase 2: thread <-> output column c = (slot2, j); accumulators over the N rows of block-row a
+  for (int c = tid; c < W; c += 256) {
+    const int slot2 = c / N, j = c - slot2 * N;
+    double acc[NMAX];
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) acc[i] = 0.0;
+    const int sx = slot2 == 2 ? s : nbr[s * 5 + slot2];
+    if (sx >= 0) {
+      for (int p = 0; p < ne; ++p) {
+        const int T = t.touch_elem[side * t.ntouch + p];
+        double w[3];
+        bool any = false;
+        for (int i = 0; i < 3; ++i) {
+          const int r = 3 * T + i;
+          const OsInfo o = oswald_info(t, nbr_s, r);
+          if (slot2 == 2) {
+            w[i] = Vs[(long)r * N + j] - o.inv * star_sum(t, Vs, o.v, N, j);
+          } else {
+            const int sd2 = slot_to_side(slot2);
+            w[i] = (o.vside[sd2] >= 0 && o.inv != 0.0) ? -o.inv * star_sum(t, V + (long)sx * t.n * N, o.vside[sd2], N, j) : 0.0;
+          }
+          any |= (w[i] != 0.0);
+        }
+        if (!any) continue;
+        double K[9];
+        stiffness3(t, T, K);
+        const double eb = ebar[(long)s * t.nT + T];
+        for (int k = 0; k < 3; ++k) {
+          const double y = eb * (K[k * 3] * w[0] + K[k * 3 + 1] * w[1] + K[k * 3 + 2] * w[2]);
+          const double* wa = lds + (3 * p + k) * N;
+#pragma unroll
+          for (int i = 0; i < NMAX; ++i)
+            if (i < N) acc[i] += wa[i] * y;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i)
+      if (i < N) {
+        G[(long)(slot * N + i) * W + c] = acc[i];
+        if (slot2 == 2) G[(long)(2 * N + j) * W + slot * N + i] = acc[i];   // [self, a] = [a, self]^T
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Thin part of G_bb / G_rdd / G_ab / r_fd for side a: rank-ncf updates from the side faces.
+struct ThinRtArgs {
+  const double *V, *Rself, *Rside, *Bbb, *Aab, *b;
+  const int* nbr;
+  double *G_bb, *G_rdd, *G_ab, *r_fd;
+  int Q, N, S;
+};
+
+__global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
+  extern __shared__ double lds[];
+  const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
+  const int Q = a.Q, N = a.N, QN = Q * N, C = 5 * QN, S = a.S;
+  double* Gb = a.G_bb + (long)s * C * C;
+  double* Gd = a.G_rdd + (long)s * C * C;
+  const int s2 = a.nbr[s * 5 + slot];
+  const int np = t.side_count[side];
+  if (s2 < 0 || np == 0) {
+    for (long i = tid; i < (long)QN * C; i += 256) {
+      const long off = (long)(slot * QN + i / C) * C + i % C;
+      Gb[off] = 0.0;
+      Gd[off] = 0.0;
+    }
+    for (int i = tid; i < QN * QN; i += 256) {
+      const long off = (long)(2 * QN + i / QN) * C + slot * QN + i % QN;
+      Gb[off] = 0.0;
+      Gd[off] = 0.0;
+    }
+    for (int q = 0; q < Q; ++q)
+      for (int i = tid; i < N * QN; i += 256) a.G_ab[(((long)q * S + s) * N + i / QN) * C + slot * QN + i % QN] = 0.0;
+    for (int i = tid; i < QN; i += 256) a.r_fd[(long)s * C + slot * QN + i] = 0.0;
+    return;
+  }
+  double* Ra = lds;                 // [np][QN]   flux image of the neighbour on the side faces
+  double* Yb = Ra + np * QN;        // [np][QN]   (B_T R~_self)[f_p]
+  double* Dp = Yb + np * QN;        // [np][QN]   |T| c_p * d_T,self
+  double* Xab = Dp + np * QN;       // [Q][np][N] (A_ab^q)^T[:, f_p] V_T
+  double* sc = Xab + Q * np * N;    // [np][3]    B[f,f], |T| c^2, bsum * c
+  const int* nbr_s = a.nbr + s * 5;
+  const double* Rs = a.Rself + (long)s * t.nrt * QN;
+  for (int it = tid; it < np * QN; it += 256) {
+    const int p = it / QN, c = it - p * QN;
+    const int T = t.side_elem[side * t.ncf + p];
+    int fp = 0;
+    for (int f = 0; f < 3; ++f)
+      if (t.nb_elem[T * 3 + f] == -(1 + side)) fp = f;
+    Ra[it] = a.Rside[(((long)s * 4 + side) * t.ncf + p) * QN + c];
+    const double* B = a.Bbb + ((long)s * t.nT + T) * 9 + fp * 3;
+    double yb = 0.0, d = 0.0;
+    for (int g = 0; g < 3; ++g) {
+      const double rv = Rs[(long)t.elem_rt[T * 3 + g] * QN + c];
+      yb += B[g] * rv;
+      d += face_sign_at(t, nbr_s, T, g) * t.face_len[T * 3 + g] / t.area[T] * rv;
+    }
+    const double cp = face_sign_at(t, nbr_s, T, fp) * t.face_len[T * 3 + fp] / t.area[T];
+    Yb[it] = yb;
+    Dp[it] = t.area[T] * cp * d;
+    if (c == 0) {
+      const double* be = a.b + (long)s * t.n + 3 * T;
+      sc[p * 3] = B[fp];
+      sc[p * 3 + 1] = t.area[T] * cp * cp;
+      sc[p * 3 + 2] = (be[0] + be[1] + be[2]) * cp;
+    }
+  }
+  for (int it = tid; it < Q * np * N; it += 256) {
+    const int q = it / (np * N), rem = it - q * np * N, p = rem / N, i = rem - p * N;
+    const int T = t.side_elem[side * t.ncf + p];
+    int fp = 0;
+    for (int f = 0; f < 3; ++f)
+      if (t.nb_elem[T * 3 + f] == -(1 + side)) fp = f;
+    const double* A = a.Aab + (((long)q * S + s) * t.nT + T) * 9;
+    double x = 0.0;
+    for (int k = 0; k < 3; ++k) x += a.V[((long)s * t.n + 3 * T + k) * N + i] * A[k * 3 + fp];
+    Xab[it] = x;
+  }
+  __syncthreads();
+  // block-row a of G_bb / G_rdd (QN x C) and the transposed blocks [self, a]
+  for (long it = tid; it < (long)QN * C; it += 256) {
+    const int row = (int)(it / C), col = (int)(it - (long)row * C);
+    const int cslot = col / QN, cc = col - cslot * QN;
+    double vb = 0.0, vd = 0.0;
+    if (cslot == slot) {
+      for (int p = 0; p < np; ++p) {
+        const double rr = Ra[p * QN + row] * Ra[p * QN + cc];
+        vb += sc[p * 3] * rr;
+        vd += sc[p * 3 + 1] * rr;
+      }
+    } else if (cslot == 2) {
+      for (int p = 0; p < np; ++p) {
+        vb += Ra[p * QN + row] * Yb[p * QN + cc];
+        vd += Ra[p * QN + row] * Dp[p * QN + cc];
+      }
+      Gb[(long)(2 * QN + cc) * C + slot * QN + row] = vb;
+      Gd[(long)(2 * QN + cc) * C + slot * QN + row] = vd;
+    }
+    Gb[(long)(slot * QN + row) * C + col] = vb;
+    Gd[(long)(slot * QN + row) * C + col] = vd;
+  }
+  for (int it = tid; it < Q * N * QN; it += 256) {
+    const int q = it / (N * QN), rem = it - q * N * QN, i = rem / QN, cc = rem - i * QN;
+    double v = 0.0;
+    for (int p = 0; p < np; ++p) v += Xab[(q * np + p) * N + i] * Ra[p * QN + cc];
+    a.G_ab[(((long)q * S + s) * N + i) * C + slot * QN + cc] = v;
+  }
+  for (int c = tid; c < QN; c += 256) {
+    double v = 0.0;
+    for (int p = 0; p < np; ++p) v += sc[p * 3 + 2] * Ra[p * QN + c];
+    a.r_fd[(long)s * C + slot * QN + c] = v;
+  }
+}
+
+inline unsigned grid_for(long total) {
+  long g = (total + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace
+
+// defined in apply.hip
+int launch_project_coupling(lrbms_ctx* ctx, int Q, int N, const double* V, const double* A_cpl, double* B_sys, hipStream_t st);
+
+int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N) {
+  const Tmpl& t = ctx->t;
+  return (long)ctx->S * t.nrt * Q * N + (long)ctx->S * 4 * t.ncf * Q * N;
+}
+
+bool fused_supported(lrbms_ctx* ctx, int Q, int N) {
+  const Tmpl& t = ctx->t;
+  if (N > 64 || Q * N > 128 || t.nT % EC != 0) return false;
+  if ((size_t)3 * t.ntouch * N * sizeof(double) > 60 * 1024) return false;
+  if ((size_t)(3 * t.ncf * Q * N + Q * t.ncf * N + 3 * t.ncf) * sizeof(double) > 60 * 1024) return false;
+  if ((size_t)2 * 3 * t.ncf * N * sizeof(double) > 64 * 1024) return false;
+  return true;
+}
+
+int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V, const double* F, const double* A_diag,
+                                  const double* A_cpl, const double* P_diag, const double* b, const double* ebar,
+                                  const double* caa, const double* Aab, const double* Bbb, double* work, double* B_sys,
+                                  double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd, double* G_rdd,
+                                  double* G_bb, double* G_ab, double* G_aa, hipStream_t st) {
+  if (!fused_supported(ctx, Q, N)) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: unsupported N / Q / template size");
+  const Tmpl& t = ctx->t;
+  const int S = ctx->S, QN = Q * N, C = 5 * QN;
+  double* Rself = work;
+  double* Rside = work + (long)S * t.nrt * QN;
+  hipLaunchKernelGGL(k_flux_compact, dim3(grid_for((long)S * t.nrt * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside);
+  LRBMS_LAUNCH_CHECK(ctx);
+
+  // ---- F1: build the column-group list and launch in slices of at most F1_YW / N groups
+  std::vector<Grp> groups;
+  for (int q = 0; q < Q; ++q) groups.push_back({G_SYS, q, 0, N, B_sys + ((long)q * S * 5 + 2) * N * N, (long)5 * N * N});
+  groups.push_back({G_ENERGY, 0, 0, N, E_red, (long)N * N});
+  groups.push_back({G_MASS, 0, 0, N, M_red, (long)N * N});
+  for (int q = 0; q < Q; ++q)
+    for (int q2 = 0; q2 < Q; ++q2) groups.push_back({G_AA, q, q2, N, G_aa + ((long)q * Q + q2) * S * N * N, (long)N * N});
+  for (int q = 0; q < Q; ++q)
+    for (int q2 = 0; q2 < Q; ++q2)
+      groups.push_back({G_AB, q, q2, C, G_ab + (long)q * S * N * C + 2 * QN + q2 * N, (long)N * C});
+  const int per = std::min(12, F1_YW / N);
+  const int ntx = (N + 15) / 16;
+  bool first = true;
+  for (size_t g0 = 0; g0 < groups.size(); g0 += per) {
+    GrpTable gt;
+    gt.n = (int)std::min<size_t>(per, groups.size() - g0);
+    for (int i = 0; i < gt.n; ++i) gt.g[i] = groups[g0 + i];
+    F1Args a{V, A_diag, P_diag, caa, Aab, Rself, b, first ? rhs_red : nullptr, Q, N, S};
+    first = false;
+    switch (ntx) {
+      case 1: hipLaunchKernelGGL(k_f1<1>, dim3(S), dim3(256), 0, st, t, a, gt); break;
+      case 2: hipLaunchKernelGGL(k_f1<2>, dim3(S), dim3(256), 0, st, t, a, gt); break;
+      case 3: hipLaunchKernelGGL(k_f1<3>, dim3(S), dim3(256), 0, st, t, a, gt); break;
+      default: hipLaunchKernelGGL(k_f1<4>, dim3(S), dim3(256), 0, st, t, a, gt); break;
+    }
+    LRBMS_LAUNCH_CHECK(ctx);
+  }
+  // ---- F2
+  {
+    F2Args a{Rself, Bbb, b, ctx->nbr, G_bb, G_rdd, r_fd, Q, N, S};
+    const int nr = (QN + 15) / 16;
+    switch (nr) {
+      case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(64), 0, st, t, a); break;
+      case 2: hipLaunchKernelGGL(k_f2<2>, dim3(S), dim3(128), 0, st, t, a); break;
+      case 3: hipLaunchKernelGGL(k_f2<3>, dim3(S), dim3(192), 0, st, t, a); break;
+      case 4: hipLaunchKernelGGL(k_f2<4>, dim3(S), dim3(256), 0, st, t, a); break;
+      case 5: hipLaunchKernelGGL(k_f2<5>, dim3(S), dim3(320), 0, st, t, a); break;
+      case 6: hipLaunchKernelGGL(k_f2<6>, dim3(S), dim3(384), 0, st, t, a); break;
+      case 7: hipLaunchKernelGGL(k_f2<7>, dim3(S), dim3(448), 0, st, t, a); break;
+      default: hipLaunchKernelGGL(k_f2<8>, dim3(S), dim3(512), 0, st, t, a); break;
+    }
+    LRBMS_LAUNCH_CHECK(ctx);
+  }
+  // ---- F3
+  {
+    F3Args a{V, ebar, ctx->nbr, G_nc, N, S};
+    switch (ntx) {
+      case 1: hipLaunchKernelGGL(k_f3<1>, dim3(S), dim3(64), 0, st, t, a); break;
+      case 2: hipLaunchKernelGGL(k_f3<2>, dim3(S), dim3(128), 0, st, t, a); break;
+      case 3: hipLaunchKernelGGL(k_f3<3>, dim3(S), dim3(192), 0, st, t, a); break;
+      default: hipLaunchKernelGGL(k_f3<4>, dim3(S), dim3(256), 0, st, t, a); break;
+    }
+    LRBMS_LAUNCH_CHECK(ctx);
+  }
+  // ---- thin parts
+  {
+    const size_t lds = sizeof(double) * 3 * t.ntouch * N;
+    if (N <= 16) hipLaunchKernelGGL(k_thin_nc<16>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, G_nc);
+    else if (N <= 32) hipLaunchKernelGGL(k_thin_nc<32>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, G_nc);
+    else if (N <= 48) hipLaunchKernelGGL(k_thin_nc<48>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, G_nc);
+    else hipLaunchKernelGGL(k_thin_nc<64>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, G_nc);
+    LRBMS_LAUNCH_CHECK(ctx);
+    ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, G_bb, G_rdd, G_ab, r_fd, Q, N, S};
+    const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf);
+    hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, st, t, a);
+    LRBMS_LAUNCH_CHECK(ctx);
+  }
+  return launch_project_coupling(ctx, Q, N, V, A_cpl, B_sys, st);
+}

@@ -16,6 +16,8 @@ struct Tmpl {
   const int *dof_vertex, *vdof_ptr, *vdof_idx;
   const int *rt_e0, *rt_f0, *rt_e1, *rt_f1, *rt_side;
   const int *side_elem, *side_elem_out, *side_count;
+  int ntouch;
+  const int *touch_elem, *touch_count;
   const double *grad, *area, *normal, *face_len, *points;
 };
 

@@ -106,7 +106,7 @@ class Engine:
     def alloc_reduce_buffers(self, N):
         c, S, Q, n, n_rt = self.ctx, self.S, self.Q, self.t.n, self.t.n_rt
         W, C = 5 * N, 5 * Q * N
-        work = c.empty(max(c.estimator_work_size(Q, N), Q * S * n * N))
+        work = c.empty(max(c.estimator_work_size(Q, N), Q * S * n * N, c.fused_work_size(Q, N)))
         return {
             'N': N, 'Wt': c.empty(S, n, W), 'Rt': c.empty(S, n_rt, C), 'work': work,
             'sys': (c.empty(Q, S, 5, N, N), c.empty(S, N), c.empty(S, N, N), c.empty(S, N, N)),
@@ -114,8 +114,10 @@ class Engine:
                       c.empty(Q, Q, S, N, N)),
         }
 
-    def project_and_estimate(self, V, buffers=None, project_system=True):
-        """One pass of the hot path over all local subdomains.  ``V`` [S_ext, n, N] must already hold the halo."""
+    def project_and_estimate(self, V, buffers=None, project_system=True, fused=None):
+        """One pass of the hot path over all local subdomains.  ``V`` [S_ext, n, N] must already hold the halo.
+        ``fused=None`` picks the fused pass (csrc/fused.hip) whenever the library supports (Q, N) and falls back to the
+        unfused HIP kernels otherwise (both are GPU paths; the unfused one also materialises the image bases Wt, Rt)."""
         if not self.assembled:
             raise NativeError('assemble() must run before project_and_estimate()')
         N = V.shape[2]
@@ -123,6 +125,12 @@ class Engine:
         if buf['N'] != N:
             raise NativeError('buffers were allocated for N={}'.format(buf['N']))
         c = self.ctx
+        if fused is None:
+            fused = c.fused_supported(self.Q, N)
+        if fused:
+            c.project_estimate_fused(V, self.F, self.A_diag, self.A_cpl, self.P_diag, self.b, self.ebar, self.caa, self.Aab,
+                                     self.Bbb, buf['work'], buf['sys'], buf['grams'])
+            return buf
         c.oswald_apply(V, out=buf['Wt'])
         c.flux_reconstruct(self.F, V, out=buf['Rt'])
         if project_system:

@@ -173,6 +173,15 @@ class SubdomainTemplate:
         self.vdof_ptr = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
         self.vdof_idx = order.astype(np.int32)
 
+        # ---- elements having at least one vertex on a side (support of the neighbours' Oswald images), padded table
+        on = [lat[:, :, 1] == 0, lat[:, :, 0] == 0, lat[:, :, 0] == 2 * kx, lat[:, :, 1] == 2 * ky]
+        lists = [np.nonzero(o.any(axis=1))[0] for o in on]
+        self.ntouch = max(len(l) for l in lists)
+        self.touch_elem = np.full((4, self.ntouch), -1, dtype=np.int32)
+        self.touch_count = np.array([len(l) for l in lists], dtype=np.int32)
+        for sd in range(4):
+            self.touch_elem[sd, :len(lists[sd])] = lists[sd]
+
 
 class DDSubdomainsGrid:
     """What ``make_cube_dd_subdomains_grid__*`` returns in the reference, for the structured case."""

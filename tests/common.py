@@ -147,7 +147,10 @@ def compare_all(p, engine, V, mu, do_solve=True):
 
     # ---- apply + projections
     Vd = eng.ctx.from_numpy(V)
-    buf = eng.project_and_estimate(Vd)
+    buf = eng.project_and_estimate(Vd, fused=False)
+    fbuf = None
+    if eng.ctx.fused_supported(Q, N):
+        fbuf = eng.project_and_estimate(Vd, eng.alloc_reduce_buffers(N), fused=True)
     red = OracleReductor(d, [V[ii] for ii in range(S)])
     OI, RT = red.image_bases()
     mesh = d.mesh
@@ -190,6 +193,11 @@ def compare_all(p, engine, V, mu, do_solve=True):
         errs['G_rdd'] = max(errs['G_rdd'], rel_err(G_rdd[ii], expand_square(rd.r_dd[ii], grid, ii, None, Q * N)))
         errs['G_bb'] = max(errs['G_bb'], rel_err(G_bb[ii], expand_square(rd.df_bb[ii], grid, ii, None, Q * N)))
     res.update(errs)
+    if fbuf is not None:      # the fused pass must produce the same arrays as the unfused kernels (and the oracle)
+        names = ('B_sys', 'rhs_red', 'E_red', 'M_red', 'G_nc', 'r_fd', 'G_rdd', 'G_bb', 'G_ab', 'G_aa')
+        for name, a, b in zip(names, list(fbuf['sys']) + list(fbuf['grams']), list(buf['sys']) + list(buf['grams'])):
+            a, b = host(a), host(b)
+            res['fused_' + name] = float(np.abs(a - b).max() / max(np.abs(b).max(), vscale * 1e-3))
 
     # ---- online: estimate for a random coefficient vector, then solve + estimate
     theta = theta_of(p, mu)
