@@ -1,4 +1,4 @@
-// Fused project + estimate-offline pass ("v2"): SURVEY.md section 8a rows K7 + K8 + P1 + P2 in seven launches that
+// Fused project + estimate-offline pass ("v2"): SURVEY.md section 8a rows K7 + K8 + P1 + P2 in eight launches that
 // never materialise the padded image bases Wt / Rt or any "operator x basis" intermediate in HBM.
 //
 // Why this shape.  Every operator of the path is a sum over fine elements T of a 3x3 (or 3x3-gathered) local
@@ -12,12 +12,17 @@
 // all with K = n (or n_T) -- these run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), with the "L_T Y_T"
 // operand built on the fly from L2-resident rows into LDS while another workgroup of the same CU issues MFMAs.
 //
+// Staging is wave-uniform: wave w of a workgroup builds the three rows of element c0 + w, lanes run over basis
+// columns.  Everything that depends only on the element (3x3 blocks, stiffness, coefficients, adjacency) is then
+// wave-uniform and comes through the scalar cache (s_load), leaving the vector memory pipe to the basis rows.
+//
 // Launches (grid = one workgroup per subdomain unless noted):
-//   k_flux_compact   R_self [S][n_rt][QN], R_side [S][4][ncf][QN]           (HBM-bound, tiny)
-//   k_f1<NTX>        X = V:  B_sys diag, E_red, M_red, G_aa, G_ab[:, self], rhs_red   (MFMA)
-//   k_f2<NR>         X = R~: G_bb[self,self], G_rdd[self,self], r_fd[self]            (MFMA)
-//   k_f3<NTX>        X = W_self: G_nc[self,self]                                      (MFMA)
-//   k_thin_nc        grid (4 sides, S): block-row `a` and block [self,a] of G_nc      (VALU)
+//   k_flux_compact   R_self [S][n_rt][QN], R_side [S][4][ncf][QN]                      (HBM-bound, small)
+//   k_vertex_avg     Oswald vertex averages Avg_self [S][nv][N], Avg_side [S][4][nvs][N] (HBM-bound, small)
+//   k_f1<NTX>        X = V:  B_sys diag, E_red, M_red, G_aa, G_ab[:, self], rhs_red     (MFMA)
+//   k_f2<NR>         X = R~: G_bb[self,self], G_rdd[self,self], r_fd[self]              (MFMA)
+//   k_f3<NTX>        X = W_self: G_nc[self,self]                                        (MFMA)
+//   k_thin_nc        grid (4 sides, S): block-row `a` and block [self,a] of G_nc        (VALU, write-bound)
 //   k_thin_rt        grid (4 sides, S): block-rows (a,q) / blocks [self,(a,q)] of G_bb, G_rdd, G_ab[:, a], r_fd[a]
 //   k_project_coupling (apply.hip): off-diagonal blocks of B_sys
 // Every output element is written exactly once (zeros included); all reductions have a fixed order.
@@ -27,12 +32,15 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int EC = 4;               // elements per K-chunk (12 DG rows = 3 MFMA k-steps)
-constexpr int F1_NTY = 8;           // Y column tiles per wave in k_f1
-constexpr int F1_YW = 4 * F1_NTY * 16;   // 512 columns
+constexpr int EC = 4;               // elements per K-chunk (12 DG rows = 3 MFMA k-steps) = staging waves
+constexpr int F1_NTY = 7;           // Y column tiles per wave in k_f1
+constexpr int F1_YW = 4 * F1_NTY * 16;   // 448 columns
 constexpr int F1_LDY = F1_YW + 16;  // row stride == 16 (mod 32) doubles: the 4 k-rows of a fragment hit disjoint banks
+constexpr int F1_MAXG = 12;
 
 __host__ __device__ constexpr int padded_ld(int tiles) { return (tiles * 16) % 32 == 16 ? tiles * 16 : tiles * 16 + 16; }
+
+__device__ inline int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 __device__ inline void stiffness3(const Tmpl& t, int e, double K[9]) {
   for (int i = 0; i < 3; ++i) {
@@ -44,23 +52,24 @@ __device__ inline void stiffness3(const Tmpl& t, int e, double K[9]) {
   }
 }
 
-// Oswald vertex data of DoF row r of subdomain s: inverse patch size (0 on the physical boundary) and, per side,
+// Oswald data of lattice vertex v of subdomain s: inverse patch size (0 on the physical boundary) and, per side,
 // the matching lattice vertex of the neighbour (or -1).
 struct OsInfo {
-  int v;
   double inv;
   int vside[4];
+  int pos[4];   // position of the vertex along the side
 };
 
-__device__ inline OsInfo oswald_info(const Tmpl& t, const int* nbr_s, int r) {
+__device__ inline OsInfo oswald_vertex(const Tmpl& t, const int* nbr_s, int v) {
   OsInfo o;
-  o.v = t.dof_vertex[r];
-  const int lx = o.v % t.nvx, ly = o.v / t.nvx;
+  const int lx = v % t.nvx, ly = v / t.nvx;
   o.vside[0] = (ly == 0) ? lx + t.nvx * (t.nvy - 1) : -1;
   o.vside[1] = (lx == 0) ? (t.nvx - 1) + t.nvx * ly : -1;
   o.vside[2] = (lx == t.nvx - 1) ? t.nvx * ly : -1;
   o.vside[3] = (ly == t.nvy - 1) ? lx : -1;
-  int cnt = t.vdof_ptr[o.v + 1] - t.vdof_ptr[o.v];
+  o.pos[0] = o.pos[3] = lx;
+  o.pos[1] = o.pos[2] = ly;
+  int cnt = t.vdof_ptr[v + 1] - t.vdof_ptr[v];
   bool dirichlet = false;
   for (int sd = 0; sd < 4; ++sd) {
     if (o.vside[sd] < 0) continue;
@@ -73,17 +82,13 @@ __device__ inline OsInfo oswald_info(const Tmpl& t, const int* nbr_s, int r) {
   return o;
 }
 
-__device__ inline double star_sum(const Tmpl& t, const double* Vs, int v, int N, int j) {
-  double acc = 0.0;
-  for (int p = t.vdof_ptr[v]; p < t.vdof_ptr[v + 1]; ++p) acc += Vs[(long)t.vdof_idx[p] * N + j];
-  return acc;
-}
-
 __device__ inline int face_sign_at(const Tmpl& t, const int* nbr_s, int e, int f) {
   const int nb = t.nb_elem[e * 3 + f];
   if (nb < 0 && nbr_s[side_to_slot(-1 - nb)] < 0) return 1;   // domain boundary: outward
   return t.face_sign[e * 3 + f];
 }
+
+__device__ inline int nvs_of(const Tmpl& t) { return t.nvx > t.nvy ? t.nvx : t.nvy; }
 
 // ---------------------------------------------------------------------------------------------------------
 // compact flux reconstruction
@@ -115,16 +120,64 @@ __global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* 
   }
 }
 
+// Oswald vertex averages: Avg_self[s][v][j] = inv(v) sum_{star_s(v)} V_s ;  Avg_side[s][sd][pos][j] = inv(v) sum over
+// the star of the matching vertex in the neighbour across side sd (0 if there is none).
+__global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __restrict__ nbr, int N,
+                                                    const double* __restrict__ V, double* __restrict__ AvgSelf,
+                                                    double* __restrict__ AvgSide) {
+  const long total = (long)S * t.nv * N;
+  const int nvs = nvs_of(t);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % N);
+    const long sv = idx / N;
+    const int v = (int)(sv % t.nv), s = (int)(sv / t.nv);
+    const OsInfo o = oswald_vertex(t, nbr + s * 5, v);
+    double acc = 0.0;
+    for (int p = t.vdof_ptr[v]; p < t.vdof_ptr[v + 1]; ++p) acc += V[((long)s * t.n + t.vdof_idx[p]) * N + j];
+    AvgSelf[idx] = o.inv * acc;
+    for (int sd = 0; sd < 4; ++sd) {
+      if (o.vside[sd] < 0) continue;
+      const int s2 = nbr[s * 5 + side_to_slot(sd)];
+      double a2 = 0.0;
+      if (s2 >= 0 && o.inv != 0.0) {
+        const int v2 = o.vside[sd];
+        for (int p = t.vdof_ptr[v2]; p < t.vdof_ptr[v2 + 1]; ++p) a2 += V[((long)s2 * t.n + t.vdof_idx[p]) * N + j];
+        a2 *= o.inv;
+      }
+      AvgSide[(((long)s * 4 + sd) * nvs + o.pos[sd]) * N + j] = a2;
+    }
+  }
+}
+
+// Oswald interpolation error rows of one element, one column: slot 2 = own basis, other slots = neighbour images
+__device__ inline void oswald_rows(const Tmpl& t, int s, int T, int slot, int N, int j, const double* __restrict__ V,
+                                   const double* __restrict__ AvgSelf, const double* __restrict__ AvgSide, double w[3]) {
+  const int nvs = nvs_of(t);
+  for (int i = 0; i < 3; ++i) {
+    const int r = 3 * T + i, v = t.dof_vertex[r];
+    if (slot == 2) {
+      w[i] = V[((long)s * t.n + r) * N + j] - AvgSelf[((long)s * t.nv + v) * N + j];
+    } else {
+      const int sd = slot_to_side(slot);
+      const int lx = v % t.nvx, ly = v / t.nvx;
+      const bool on = sd == 0 ? ly == 0 : sd == 1 ? lx == 0 : sd == 2 ? lx == t.nvx - 1 : ly == t.nvy - 1;
+      const int pos = (sd == 0 || sd == 3) ? lx : ly;
+      w[i] = on ? -AvgSide[(((long)s * 4 + sd) * nvs + pos) * N + j] : 0.0;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // F1: X = V.  Column groups of Y (N columns each), destination = base + s * sstride + row * ld + col
 enum { G_SYS = 0, G_ENERGY = 1, G_MASS = 2, G_AA = 3, G_AB = 4 };
 struct Grp {
   int kind, q, q2, ld;
   double* dst;
+  double* dst_t;   // optional transposed copy (symmetric pair of G_aa), same strides
   long sstride;
 };
 struct GrpTable {
-  Grp g[12];
+  Grp g[F1_MAXG];
   int n;
 };
 struct F1Args {
@@ -138,12 +191,15 @@ __global__ __launch_bounds__(256, NTX <= 3 ? 2 : 1) void k_f1(Tmpl t, F1Args a, 
   constexpr int LDX = padded_ld(NTX);
   __shared__ double Xs[3 * EC * LDX];
   __shared__ double Ys[3 * EC * F1_LDY];
-  __shared__ Grp grp[12];
-  __shared__ double red[256];
-  const int s = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  __shared__ double red[EC * 64];
+  __shared__ Grp grp[F1_MAXG];   // per-lane group lookup in the epilogue (the staging loop reads gt from SGPRs)
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = uniform(tid >> 6);
   const int N = a.N, Q = a.Q, S = a.S, QN = Q * N;
   const int ncols = gt.n * N;
-  if (tid < gt.n) grp[tid] = gt.g[tid];
+#pragma unroll
+  for (int g = 0; g < F1_MAXG; ++g)   // static indices only: a lane-indexed gt.g[tid] would spill the table to scratch
+    if (tid == g) grp[g] = gt.g[g];
   for (int i = tid; i < 3 * EC * LDX; i += 256) Xs[i] = 0.0;
   for (int i = tid; i < 3 * EC * F1_LDY; i += 256) Ys[i] = 0.0;
   __syncthreads();
@@ -154,17 +210,18 @@ __global__ __launch_bounds__(256, NTX <= 3 ? 2 : 1) void k_f1(Tmpl t, F1Args a, 
   const int my_tiles = min(F1_NTY, max(0, (ncols + 15) / 16 - wave * F1_NTY));   // non-empty column tiles of this wave
   const double* Vs = a.V + (long)s * t.n * N;
   double rhs_part = 0.0;
+  const int j = lane;
 
   for (int c0 = 0; c0 < t.nT; c0 += EC) {
-    for (int it = tid; it < EC * N; it += 256) {
-      const int el = it / N, j = it - el * N, T = c0 + el;
+    const int T = c0 + wave;                       // wave-uniform element
+    if (j < N) {
       double vb[4][3];
       for (int i = 0; i < 3; ++i) vb[0][i] = Vs[(long)(3 * T + i) * N + j];
       for (int f = 0; f < 3; ++f) {
         const int nb = t.nb_elem[T * 3 + f];
         for (int i = 0; i < 3; ++i) vb[1 + f][i] = nb >= 0 ? Vs[(long)(3 * nb + i) * N + j] : 0.0;
       }
-      for (int i = 0; i < 3; ++i) Xs[(3 * el + i) * LDX + j] = vb[0][i];
+      for (int i = 0; i < 3; ++i) Xs[(3 * wave + i) * LDX + j] = vb[0][i];
       if (a.rhs_red) {
         const double* be = a.b + (long)s * t.n + 3 * T;
         rhs_part += be[0] * vb[0][0] + be[1] * vb[0][1] + be[2] * vb[0][2];
@@ -173,7 +230,7 @@ __global__ __launch_bounds__(256, NTX <= 3 ? 2 : 1) void k_f1(Tmpl t, F1Args a, 
       stiffness3(t, T, K);
       for (int i = 0; i < 3; ++i) kv[i] = K[i * 3] * vb[0][0] + K[i * 3 + 1] * vb[0][1] + K[i * 3 + 2] * vb[0][2];
       for (int g = 0; g < gt.n; ++g) {
-        const int kind = grp[g].kind, q = grp[g].q, q2 = grp[g].q2;
+        const int kind = uniform(grp[g].kind), q = uniform(grp[g].q), q2 = uniform(grp[g].q2);
         double y[3] = {0, 0, 0};
         if (kind == G_SYS || kind == G_ENERGY) {
           const double* blk = (kind == G_SYS ? a.A_diag + ((long)q * S + s) * t.nT * 36 : a.P_diag + (long)s * t.nT * 36) + (long)T * 36;
@@ -192,44 +249,54 @@ __global__ __launch_bounds__(256, NTX <= 3 ? 2 : 1) void k_f1(Tmpl t, F1Args a, 
           for (int f = 0; f < 3; ++f) rv[f] = a.Rself[((long)s * t.nrt + t.elem_rt[T * 3 + f]) * QN + q2 * N + j];
           for (int i = 0; i < 3; ++i) y[i] = A[i * 3] * rv[0] + A[i * 3 + 1] * rv[1] + A[i * 3 + 2] * rv[2];
         }
-        for (int i = 0; i < 3; ++i) Ys[(3 * el + i) * F1_LDY + g * N + j] = y[i];
+        for (int i = 0; i < 3; ++i) Ys[(3 * wave + i) * F1_LDY + g * N + j] = y[i];
       }
     }
     __syncthreads();
+#pragma unroll
     for (int kk = 0; kk < 3 * EC; kk += 4) {
       double av[NTX];
+#pragma unroll
       for (int i = 0; i < NTX; ++i) av[i] = Xs[(kk + lk) * LDX + i * 16 + li];
-      for (int jt = 0; jt < F1_NTY; ++jt) {
-        if (jt < my_tiles) {
-          const double bv = Ys[(kk + lk) * F1_LDY + (wave * F1_NTY + jt) * 16 + li];
-          for (int i = 0; i < NTX; ++i) acc[i][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[i][jt], 0, 0, 0);
+#pragma unroll
+      for (int jt = 0; jt < F1_NTY; ++jt) {   // tiles beyond ncols multiply zero columns of Ys (harmless, branch-free)
+        const double bv = Ys[(kk + lk) * F1_LDY + (wave * F1_NTY + jt) * 16 + li];
+#pragma unroll
+        for (int i = 0; i < NTX; ++i) acc[i][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[i][jt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: scatter the tiles to their destination arrays (static accumulator indices only: any runtime
+  // index or early `continue` here makes the compiler keep `acc` in scratch for the whole kernel)
+#pragma unroll
+  for (int jt = 0; jt < F1_NTY; ++jt) {
+    const int col = (wave * F1_NTY + jt) * 16 + li;
+    const bool live = jt < my_tiles && col < ncols;
+    const int g = live ? col / N : 0, jj = col - g * N;
+    const int ld = grp[g].ld;
+    double* dst = grp[g].dst + (long)s * grp[g].sstride + jj;
+    double* dst_t = grp[g].dst_t ? grp[g].dst_t + (long)s * grp[g].sstride + (long)jj * ld : nullptr;
+#pragma unroll
+    for (int i = 0; i < NTX; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + lk + 4 * r;
+        const double val = acc[i][jt][r];
+        if (live && row < N) {
+          dst[(long)row * ld] = val;
+          if (dst_t) dst_t[row] = val;
         }
       }
     }
-    __syncthreads();
   }
-  // ---- epilogue: scatter the tiles to their destination arrays
-  for (int jt = 0; jt < F1_NTY; ++jt) {
-    const int col = (wave * F1_NTY + jt) * 16 + li;
-    if (jt >= my_tiles || col >= ncols) continue;
-    const int g = col / N, j = col - g * N;
-    double* dst = grp[g].dst + (long)s * grp[g].sstride + j;
-    const int ld = grp[g].ld;
-    for (int i = 0; i < NTX; ++i)
-      for (int r = 0; r < 4; ++r) {
-        const int row = i * 16 + lk + 4 * r;
-        if (row < N) dst[(long)row * ld] = acc[i][jt][r];
-      }
-  }
-  if (a.rhs_red) {   // items are (el, j) with a fixed thread <-> (el, j) map when EC * N <= 256; otherwise strided
-    red[tid] = rhs_part;
+  if (a.rhs_red) {   // fixed-order sum over the EC staging waves
+    red[wave * 64 + lane] = rhs_part;
     __syncthreads();
-    if (EC * N <= 256) {
-      if (tid < N) {
-        double sum = 0.0;
-        for (int el = 0; el < EC; ++el) sum += red[el * N + tid];
-        a.rhs_red[(long)s * N + tid] = sum;
-      }
+    if (tid < N) {
+      double sum = 0.0;
+      for (int w = 0; w < EC; ++w) sum += red[w * 64 + tid];
+      a.rhs_red[(long)s * N + tid] = sum;
     }
   }
 }
@@ -248,36 +315,47 @@ template <int NR>
 __global__ __launch_bounds__(64 * NR) void k_f2(Tmpl t, F2Args a) {
   constexpr int LD = padded_ld(NR);
   __shared__ double Xb[3 * EC * LD], Yb[3 * EC * LD], Xd[EC * LD], Yd[EC * LD];
-  __shared__ double red[64 * NR];
-  const int s = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  __shared__ double red[EC * 128];
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = uniform(tid >> 6);
   const int nthreads = 64 * NR;
   const int QN = a.Q * a.N, C = 5 * QN;
   for (int i = tid; i < 3 * EC * LD; i += nthreads) Xb[i] = Yb[i] = 0.0;
   for (int i = tid; i < EC * LD; i += nthreads) Xd[i] = Yd[i] = 0.0;
+  for (int i = tid; i < EC * 128; i += nthreads) red[i] = 0.0;
   __syncthreads();
   d4 accb[NR], accd[NR];
   for (int i = 0; i < NR; ++i) accb[i] = accd[i] = (d4){0.0, 0.0, 0.0, 0.0};
   const double* Rs = a.Rself + (long)s * t.nrt * QN;
   const int* nbr_s = a.nbr + s * 5;
-  double rfd_part = 0.0;
+  double rfd_part[2] = {0.0, 0.0};   // columns lane and lane + 64 (QN <= 128)
   for (int c0 = 0; c0 < t.nT; c0 += EC) {
-    for (int it = tid; it < EC * QN; it += nthreads) {
-      const int el = it / QN, c = it - el * QN, T = c0 + el;
-      double rv[3], coef[3];
+    for (int el = wave; el < EC; el += NR) {     // wave-uniform element(s)
+      const int T = c0 + el;
+      double coef[3];
+      int rt[3];
       for (int f = 0; f < 3; ++f) {
-        rv[f] = Rs[(long)t.elem_rt[T * 3 + f] * QN + c];
         coef[f] = face_sign_at(t, nbr_s, T, f) * t.face_len[T * 3 + f] / t.area[T];
+        rt[f] = t.elem_rt[T * 3 + f];
       }
       const double* B = a.Bbb + ((long)s * t.nT + T) * 9;
-      for (int f = 0; f < 3; ++f) {
-        Xb[(3 * el + f) * LD + c] = rv[f];
-        Yb[(3 * el + f) * LD + c] = B[f * 3] * rv[0] + B[f * 3 + 1] * rv[1] + B[f * 3 + 2] * rv[2];
-      }
-      const double d = coef[0] * rv[0] + coef[1] * rv[1] + coef[2] * rv[2];
-      Xd[el * LD + c] = d;
-      Yd[el * LD + c] = t.area[T] * d;
       const double* be = a.b + (long)s * t.n + 3 * T;
-      rfd_part += (be[0] + be[1] + be[2]) * d;
+      const double bsum = be[0] + be[1] + be[2], area = t.area[T];
+      for (int k = 0; k < 2; ++k) {
+        const int c = lane + 64 * k;
+        if (c < QN) {
+          double rv[3];
+          for (int f = 0; f < 3; ++f) rv[f] = Rs[(long)rt[f] * QN + c];
+          for (int f = 0; f < 3; ++f) {
+            Xb[(3 * el + f) * LD + c] = rv[f];
+            Yb[(3 * el + f) * LD + c] = B[f * 3] * rv[0] + B[f * 3 + 1] * rv[1] + B[f * 3 + 2] * rv[2];
+          }
+          const double d = coef[0] * rv[0] + coef[1] * rv[1] + coef[2] * rv[2];
+          Xd[el * LD + c] = d;
+          Yd[el * LD + c] = area * d;
+          rfd_part[k] += bsum * d;
+        }
+      }
     }
     __syncthreads();
     const int ct = wave;   // this wave's column tile
@@ -304,71 +382,73 @@ __global__ __launch_bounds__(64 * NR) void k_f2(Tmpl t, F2Args a) {
         }
       }
   }
-  // r_fd self block: thread <-> (el, c) map is fixed when EC * QN <= nthreads
-  red[tid] = rfd_part;
+  // r_fd self block: wave w staged elements w, w + NR, ... ; fixed-order sum over the (<= EC) staging waves
+  if (wave < EC) {
+    red[wave * 128 + lane] = rfd_part[0];
+    red[wave * 128 + 64 + lane] = rfd_part[1];
+  }
   __syncthreads();
-  if (EC * QN <= nthreads) {
-    if (tid < QN) {
-      double sum = 0.0;
-      for (int el = 0; el < EC; ++el) sum += red[el * QN + tid];
-      a.r_fd[(long)s * C + 2 * QN + tid] = sum;
-    }
+  for (int c = tid; c < QN; c += nthreads) {
+    double sum = 0.0;
+    for (int w = 0; w < EC; ++w) sum += red[w * 128 + c];
+    a.r_fd[(long)s * C + 2 * QN + c] = sum;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// F3: X = W_self (Oswald interpolation error of the own basis), Y = E W_self.  One wave per column tile.
+// F3: X = W_self (Oswald interpolation error of the own basis), Y = E W_self.  4 waves; tiles dealt round-robin.
 struct F3Args {
-  const double *V, *ebar;
-  const int* nbr;
+  const double *V, *ebar, *AvgSelf, *AvgSide;
   double* G_nc;
   int N, S;
 };
 
 template <int NTX>
-__global__ __launch_bounds__(64 * NTX) void k_f3(Tmpl t, F3Args a) {
+__global__ __launch_bounds__(256) void k_f3(Tmpl t, F3Args a) {
   constexpr int LD = padded_ld(NTX);
+  constexpr int NT = (NTX * NTX + 3) / 4;
   __shared__ double Xs[3 * EC * LD], Ys[3 * EC * LD];
-  const int s = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int nthreads = 64 * NTX, N = a.N, W = 5 * N;
-  for (int i = tid; i < 3 * EC * LD; i += nthreads) Xs[i] = Ys[i] = 0.0;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = uniform(tid >> 6);
+  const int N = a.N, W = 5 * N;
+  for (int i = tid; i < 3 * EC * LD; i += 256) Xs[i] = Ys[i] = 0.0;
   __syncthreads();
-  d4 acc[NTX];
-  for (int i = 0; i < NTX; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* Vs = a.V + (long)s * t.n * N;
-  const int* nbr_s = a.nbr + s * 5;
+  d4 acc[NT];
+  for (int i = 0; i < NT; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
   for (int c0 = 0; c0 < t.nT; c0 += EC) {
-    for (int it = tid; it < EC * N; it += nthreads) {
-      const int el = it / N, j = it - el * N, T = c0 + el;
-      double w[3];
-      for (int i = 0; i < 3; ++i) {
-        const int r = 3 * T + i;
-        const OsInfo o = oswald_info(t, nbr_s, r);
-        w[i] = Vs[(long)r * N + j] - o.inv * star_sum(t, Vs, o.v, N, j);
-      }
-      double K[9];
+    const int T = c0 + wave;
+    if (lane < N) {
+      double w[3], K[9];
+      oswald_rows(t, s, T, 2, N, lane, a.V, a.AvgSelf, a.AvgSide, w);
       stiffness3(t, T, K);
       const double eb = a.ebar[(long)s * t.nT + T];
       for (int i = 0; i < 3; ++i) {
-        Xs[(3 * el + i) * LD + j] = w[i];
-        Ys[(3 * el + i) * LD + j] = eb * (K[i * 3] * w[0] + K[i * 3 + 1] * w[1] + K[i * 3 + 2] * w[2]);
+        Xs[(3 * wave + i) * LD + lane] = w[i];
+        Ys[(3 * wave + i) * LD + lane] = eb * (K[i * 3] * w[0] + K[i * 3 + 1] * w[1] + K[i * 3 + 2] * w[2]);
       }
     }
     __syncthreads();
-    for (int kk = 0; kk < 3 * EC; kk += 4) {
-      const double bv = Ys[(kk + lk) * LD + wave * 16 + li];
-      for (int i = 0; i < NTX; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(kk + lk) * LD + i * 16 + li], bv, acc[i], 0, 0, 0);
-    }
+    for (int kk = 0; kk < 3 * EC; kk += 4)
+      for (int k = 0; k < NT; ++k) {
+        const int tile = wave + 4 * k;
+        if (tile < NTX * NTX) {
+          const int ti = tile / NTX, tj = tile - ti * NTX;
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(kk + lk) * LD + ti * 16 + li], Ys[(kk + lk) * LD + tj * 16 + li], acc[k], 0, 0, 0);
+        }
+      }
     __syncthreads();
   }
-  const int col = wave * 16 + li;
-  if (col < N) {
+  for (int k = 0; k < NT; ++k) {
+    const int tile = wave + 4 * k;
+    if (tile >= NTX * NTX) continue;
+    const int ti = tile / NTX, tj = tile - ti * NTX;
+    const int col = tj * 16 + li;
+    if (col >= N) continue;
     double* g = a.G_nc + (long)s * W * W + (long)(2 * N) * W + 2 * N + col;
-    for (int i = 0; i < NTX; ++i)
-      for (int r = 0; r < 4; ++r) {
-        const int row = i * 16 + lk + 4 * r;
-        if (row < N) g[(long)row * W] = acc[i][r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int row = ti * 16 + lk + 4 * r;
+      if (row < N) g[(long)row * W] = acc[k][r];
+    }
   }
 }
 
@@ -378,8 +458,9 @@ __global__ __launch_bounds__(64 * NTX) void k_f3(Tmpl t, F3Args a) {
 template <int NMAX>
 __global__ __launch_bounds__(256) void k_thin_nc(Tmpl t, int S, const int* __restrict__ nbr, int N,
                                                  const double* __restrict__ V, const double* __restrict__ ebar,
+                                                 const double* __restrict__ AvgSelf, const double* __restrict__ AvgSide,
                                                  double* __restrict__ G_nc) {
-  extern __shared__ double lds[];   // Wa [3 * ntouch][N]
+  extern __shared__ double lds[];   // Wa [3 * ntouch][N], then the transposed [self, a] block [N][N + 1]
   const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
   const int W = 5 * N;
   double* G = G_nc + (long)s * W * W;
@@ -390,16 +471,14 @@ __global__ __launch_bounds__(256) void k_thin_nc(Tmpl t, int S, const int* __res
     return;
   }
   const int ne = t.touch_count[side];
-  const int* nbr_s = nbr + s * 5;
-  const double* Vs = V + (long)s * t.n * N;
+  double* Wa = lds;
+  double* Tr = lds + 3 * t.ntouch * N;
   // phase 1: Wa rows (image of the neighbour's basis on the touching elements)
-  for (int it = tid; it < 3 * ne * N; it += 256) {
-    const int row = it / N, j = it - row * N;
-    const int T = t.touch_elem[side * t.ntouch + row / 3], r = 3 * T + row % 3;
-    const OsInfo o = oswald_info(t, nbr_s, r);
-    double val = 0.0;
-    if (o.vside[side] >= 0 && o.inv != 0.0) val = -o.inv * star_sum(t, V + (long)s2 * t.n * N, o.vside[side], N, j);
-    lds[row * N + j] = val;
+  for (int it = tid; it < ne * N; it += 256) {
+    const int p = it / N, j = it - p * N;
+    double w[3];
+    oswald_rows(t, s, t.touch_elem[side * t.ntouch + p], slot, N, j, V, AvgSelf, AvgSide, w);
+    for (int i = 0; i < 3; ++i) Wa[(3 * p + i) * N + j] = w[i];
   }
   __syncthreads();
   // phase 2: thread <-> output column c = (slot2, j); accumulators over the N rows of block-row a
@@ -413,25 +492,14 @@ __global__ __launch_bounds__(256) void k_thin_nc(Tmpl t, int S, const int* __res
       for (int p = 0; p < ne; ++p) {
         const int T = t.touch_elem[side * t.ntouch + p];
         double w[3];
-        bool any = false;
-        for (int i = 0; i < 3; ++i) {
-          const int r = 3 * T + i;
-          const OsInfo o = oswald_info(t, nbr_s, r);
-          if (slot2 == 2) {
-            w[i] = Vs[(long)r * N + j] - o.inv * star_sum(t, Vs, o.v, N, j);
-          } else {
-            const int sd2 = slot_to_side(slot2);
-            w[i] = (o.vside[sd2] >= 0 && o.inv != 0.0) ? -o.inv * star_sum(t, V + (long)sx * t.n * N, o.vside[sd2], N, j) : 0.0;
-          }
-          any |= (w[i] != 0.0);
-        }
-        if (!any) continue;
+        oswald_rows(t, s, T, slot2, N, j, V, AvgSelf, AvgSide, w);
+        if (w[0] == 0.0 && w[1] == 0.0 && w[2] == 0.0) continue;
         double K[9];
         stiffness3(t, T, K);
         const double eb = ebar[(long)s * t.nT + T];
         for (int k = 0; k < 3; ++k) {
           const double y = eb * (K[k * 3] * w[0] + K[k * 3 + 1] * w[1] + K[k * 3 + 2] * w[2]);
-          const double* wa = lds + (3 * p + k) * N;
+          const double* wa = Wa + (3 * p + k) * N;
 #pragma unroll
           for (int i = 0; i < NMAX; ++i)
             if (i < N) acc[i] += wa[i] * y;
@@ -442,8 +510,13 @@ __global__ __launch_bounds__(256) void k_thin_nc(Tmpl t, int S, const int* __res
     for (int i = 0; i < NMAX; ++i)
       if (i < N) {
         G[(long)(slot * N + i) * W + c] = acc[i];
-        if (slot2 == 2) G[(long)(2 * N + j) * W + slot * N + i] = acc[i];   // [self, a] = [a, self]^T
+        if (slot2 == 2) Tr[j * (N + 1) + i] = acc[i];   // [self, a] = [a, self]^T, staged for a coalesced store
       }
+  }
+  __syncthreads();
+  for (int it = tid; it < N * N; it += 256) {
+    const int j = it / N, i = it - j * N;
+    G[(long)(2 * N + j) * W + slot * N + i] = Tr[j * (N + 1) + i];
   }
 }
 
@@ -523,7 +596,7 @@ __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
     Xab[it] = x;
   }
   __syncthreads();
-  // block-row a of G_bb / G_rdd (QN x C) and the transposed blocks [self, a]
+  // block-row a of G_bb / G_rdd (QN x C): consecutive threads on consecutive columns
   for (long it = tid; it < (long)QN * C; it += 256) {
     const int row = (int)(it / C), col = (int)(it - (long)row * C);
     const int cslot = col / QN, cc = col - cslot * QN;
@@ -539,11 +612,20 @@ __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
         vb += Ra[p * QN + row] * Yb[p * QN + cc];
         vd += Ra[p * QN + row] * Dp[p * QN + cc];
       }
-      Gb[(long)(2 * QN + cc) * C + slot * QN + row] = vb;
-      Gd[(long)(2 * QN + cc) * C + slot * QN + row] = vd;
     }
     Gb[(long)(slot * QN + row) * C + col] = vb;
     Gd[(long)(slot * QN + row) * C + col] = vd;
+  }
+  // transposed blocks [self, a]: recomputed with the a-index fastest so that the stores coalesce
+  for (int it = tid; it < QN * QN; it += 256) {
+    const int cc = it / QN, row = it - cc * QN;
+    double vb = 0.0, vd = 0.0;
+    for (int p = 0; p < np; ++p) {
+      vb += Ra[p * QN + row] * Yb[p * QN + cc];
+      vd += Ra[p * QN + row] * Dp[p * QN + cc];
+    }
+    Gb[(long)(2 * QN + cc) * C + slot * QN + row] = vb;
+    Gd[(long)(2 * QN + cc) * C + slot * QN + row] = vd;
   }
   for (int it = tid; it < Q * N * QN; it += 256) {
     const int q = it / (N * QN), rem = it - q * N * QN, i = rem / QN, cc = rem - i * QN;
@@ -570,14 +652,15 @@ int launch_project_coupling(lrbms_ctx* ctx, int Q, int N, const double* V, const
 
 int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N) {
   const Tmpl& t = ctx->t;
-  return (long)ctx->S * t.nrt * Q * N + (long)ctx->S * 4 * t.ncf * Q * N;
+  const long nvs = t.nvx > t.nvy ? t.nvx : t.nvy;
+  return (long)ctx->S * t.nrt * Q * N + (long)ctx->S * 4 * t.ncf * Q * N + (long)ctx->S * t.nv * N + (long)ctx->S * 4 * nvs * N;
 }
 
 bool fused_supported(lrbms_ctx* ctx, int Q, int N) {
   const Tmpl& t = ctx->t;
   if (N > 64 || Q * N > 128 || t.nT % EC != 0) return false;
-  if ((size_t)3 * t.ntouch * N * sizeof(double) > 60 * 1024) return false;
-  if ((size_t)(3 * t.ncf * Q * N + Q * t.ncf * N + 3 * t.ncf) * sizeof(double) > 60 * 1024) return false;
+  if ((size_t)(3 * t.ntouch * N + N * (N + 1)) * sizeof(double) > 64 * 1024) return false;
+  if ((size_t)(3 * t.ncf * Q * N + Q * t.ncf * N + 3 * t.ncf) * sizeof(double) > 64 * 1024) return false;
   if ((size_t)2 * 3 * t.ncf * N * sizeof(double) > 64 * 1024) return false;
   return true;
 }
@@ -590,22 +673,30 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   if (!fused_supported(ctx, Q, N)) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: unsupported N / Q / template size");
   const Tmpl& t = ctx->t;
   const int S = ctx->S, QN = Q * N, C = 5 * QN;
+  const long nvs = t.nvx > t.nvy ? t.nvx : t.nvy;
   double* Rself = work;
-  double* Rside = work + (long)S * t.nrt * QN;
+  double* Rside = Rself + (long)S * t.nrt * QN;
+  double* AvgSelf = Rside + (long)S * 4 * t.ncf * QN;
+  double* AvgSide = AvgSelf + (long)S * t.nv * N;
   hipLaunchKernelGGL(k_flux_compact, dim3(grid_for((long)S * t.nrt * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside);
   LRBMS_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(k_vertex_avg, dim3(grid_for((long)S * t.nv * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide);
+  LRBMS_LAUNCH_CHECK(ctx);
+  (void)nvs;
 
   // ---- F1: build the column-group list and launch in slices of at most F1_YW / N groups
   std::vector<Grp> groups;
-  for (int q = 0; q < Q; ++q) groups.push_back({G_SYS, q, 0, N, B_sys + ((long)q * S * 5 + 2) * N * N, (long)5 * N * N});
-  groups.push_back({G_ENERGY, 0, 0, N, E_red, (long)N * N});
-  groups.push_back({G_MASS, 0, 0, N, M_red, (long)N * N});
+  for (int q = 0; q < Q; ++q) groups.push_back({G_SYS, q, 0, N, B_sys + ((long)q * S * 5 + 2) * N * N, nullptr, (long)5 * N * N});
+  groups.push_back({G_ENERGY, 0, 0, N, E_red, nullptr, (long)N * N});
+  groups.push_back({G_MASS, 0, 0, N, M_red, nullptr, (long)N * N});
   for (int q = 0; q < Q; ++q)
-    for (int q2 = 0; q2 < Q; ++q2) groups.push_back({G_AA, q, q2, N, G_aa + ((long)q * Q + q2) * S * N * N, (long)N * N});
+    for (int q2 = q; q2 < Q; ++q2)   // c^{q q'} is symmetric in (q, q'): G_aa[q'][q] = G_aa[q][q']^T
+      groups.push_back({G_AA, q, q2, N, G_aa + ((long)q * Q + q2) * S * N * N,
+                        q2 != q ? G_aa + ((long)q2 * Q + q) * S * N * N : nullptr, (long)N * N});
   for (int q = 0; q < Q; ++q)
     for (int q2 = 0; q2 < Q; ++q2)
-      groups.push_back({G_AB, q, q2, C, G_ab + (long)q * S * N * C + 2 * QN + q2 * N, (long)N * C});
-  const int per = std::min(12, F1_YW / N);
+      groups.push_back({G_AB, q, q2, C, G_ab + (long)q * S * N * C + 2 * QN + q2 * N, nullptr, (long)N * C});
+  const int per = std::min(F1_MAXG, F1_YW / N);
   const int ntx = (N + 15) / 16;
   bool first = true;
   for (size_t g0 = 0; g0 < groups.size(); g0 += per) {
@@ -640,22 +731,22 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   }
   // ---- F3
   {
-    F3Args a{V, ebar, ctx->nbr, G_nc, N, S};
+    F3Args a{V, ebar, AvgSelf, AvgSide, G_nc, N, S};
     switch (ntx) {
-      case 1: hipLaunchKernelGGL(k_f3<1>, dim3(S), dim3(64), 0, st, t, a); break;
-      case 2: hipLaunchKernelGGL(k_f3<2>, dim3(S), dim3(128), 0, st, t, a); break;
-      case 3: hipLaunchKernelGGL(k_f3<3>, dim3(S), dim3(192), 0, st, t, a); break;
+      case 1: hipLaunchKernelGGL(k_f3<1>, dim3(S), dim3(256), 0, st, t, a); break;
+      case 2: hipLaunchKernelGGL(k_f3<2>, dim3(S), dim3(256), 0, st, t, a); break;
+      case 3: hipLaunchKernelGGL(k_f3<3>, dim3(S), dim3(256), 0, st, t, a); break;
       default: hipLaunchKernelGGL(k_f3<4>, dim3(S), dim3(256), 0, st, t, a); break;
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
   // ---- thin parts
   {
-    const size_t lds = sizeof(double) * 3 * t.ntouch * N;
-    if (N <= 16) hipLaunchKernelGGL(k_thin_nc<16>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, G_nc);
-    else if (N <= 32) hipLaunchKernelGGL(k_thin_nc<32>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, G_nc);
-    else if (N <= 48) hipLaunchKernelGGL(k_thin_nc<48>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, G_nc);
-    else hipLaunchKernelGGL(k_thin_nc<64>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, G_nc);
+    const size_t lds = sizeof(double) * (3 * t.ntouch * N + N * (N + 1));
+    if (N <= 16) hipLaunchKernelGGL(k_thin_nc<16>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);
+    else if (N <= 32) hipLaunchKernelGGL(k_thin_nc<32>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);
+    else if (N <= 48) hipLaunchKernelGGL(k_thin_nc<48>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);
+    else hipLaunchKernelGGL(k_thin_nc<64>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);
     LRBMS_LAUNCH_CHECK(ctx);
     ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, G_bb, G_rdd, G_ab, r_fd, Q, N, S};
     const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf);
