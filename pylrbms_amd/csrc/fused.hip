@@ -189,23 +189,55 @@ struct F1Args {
 template <int NTX>
 __global__ __launch_bounds__(256, NTX <= 3 ? 2 : 1) void k_f1(Tmpl t, F1Args a, GrpTable gt) {
   constexpr int LDX = padded_ld(NTX);
+  constexpr int PRE = 4;                       // per-thread prefetch registers for the element data of the next chunk
   __shared__ double Xs[3 * EC * LDX];
   __shared__ double Ys[3 * EC * F1_LDY];
+  __shared__ double Eb[EC * 256];              // element data of the current chunk: A_q blocks, P block, A_ab^q blocks, c^{qq'}
   __shared__ double red[EC * 64];
   __shared__ Grp grp[F1_MAXG];   // per-lane group lookup in the epilogue (the staging loop reads gt from SGPRs)
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
   const int N = a.N, Q = a.Q, S = a.S, QN = Q * N;
   const int ncols = gt.n * N;
+  // per-element record: [36 Q] A_diag blocks, [36] P_diag block, [9 Q] A_ab blocks, [Q Q] c^{qq'}
+  const int oP = 36 * Q, oAb = oP + 36, oC = oAb + 9 * Q, ESTR = oC + Q * Q;    // <= 256 for Q <= 4
 #pragma unroll
   for (int g = 0; g < F1_MAXG; ++g)   // static indices only: a lane-indexed gt.g[tid] would spill the table to scratch
     if (tid == g) grp[g] = gt.g[g];
   for (int i = tid; i < 3 * EC * LDX; i += 256) Xs[i] = 0.0;
   for (int i = tid; i < 3 * EC * F1_LDY; i += 256) Ys[i] = 0.0;
+
+  // element-data fetch of chunk c0 into registers (coalesced 36- / 9-double runs; consumed from LDS by all lanes)
+  auto fetch = [&](int c0, double (&pre)[PRE]) {
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int i = tid + 256 * k;
+      double v = 0.0;
+      if (i < EC * ESTR) {
+        const int el = i / ESTR, o = i - el * ESTR, T = c0 + el;
+        if (o < oP) {
+          const int q = o / 36;
+          v = a.A_diag[(((long)q * S + s) * t.nT + T) * 36 + (o - 36 * q)];
+        } else if (o < oAb) {
+          v = a.P_diag[((long)s * t.nT + T) * 36 + (o - oP)];
+        } else if (o < oC) {
+          const int q = (o - oAb) / 9;
+          v = a.Aab[(((long)q * S + s) * t.nT + T) * 9 + (o - oAb - 9 * q)];
+        } else {
+          v = a.caa[((long)(o - oC) * S + s) * t.nT + T];
+        }
+      }
+      pre[k] = v;
+    }
+  };
+  double pre[PRE];
+  fetch(0, pre);
   __syncthreads();
 
   d4 acc[NTX][F1_NTY];
+#pragma unroll
   for (int i = 0; i < NTX; ++i)
+#pragma unroll
     for (int j = 0; j < F1_NTY; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
   const int my_tiles = min(F1_NTY, max(0, (ncols + 15) / 16 - wave * F1_NTY));   // non-empty column tiles of this wave
   const double* Vs = a.V + (long)s * t.n * N;
@@ -213,14 +245,26 @@ __global__ __launch_bounds__(256, NTX <= 3 ? 2 : 1) void k_f1(Tmpl t, F1Args a, 
   const int j = lane;
 
   for (int c0 = 0; c0 < t.nT; c0 += EC) {
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int i = tid + 256 * k;
+      if (i < EC * ESTR) Eb[(i / ESTR) * 256 + (i % ESTR)] = pre[k];
+    }
+    __syncthreads();
+    if (c0 + EC < t.nT) fetch(c0 + EC, pre);       // in flight during staging + MFMA of this chunk
     const int T = c0 + wave;                       // wave-uniform element
+    const double* Ee = Eb + wave * 256;
     if (j < N) {
       double vb[4][3];
+#pragma unroll
       for (int i = 0; i < 3; ++i) vb[0][i] = Vs[(long)(3 * T + i) * N + j];
+#pragma unroll
       for (int f = 0; f < 3; ++f) {
         const int nb = t.nb_elem[T * 3 + f];
+#pragma unroll
         for (int i = 0; i < 3; ++i) vb[1 + f][i] = nb >= 0 ? Vs[(long)(3 * nb + i) * N + j] : 0.0;
       }
+#pragma unroll
       for (int i = 0; i < 3; ++i) Xs[(3 * wave + i) * LDX + j] = vb[0][i];
       if (a.rhs_red) {
         const double* be = a.b + (long)s * t.n + 3 * T;
@@ -228,27 +272,35 @@ __global__ __launch_bounds__(256, NTX <= 3 ? 2 : 1) void k_f1(Tmpl t, F1Args a, 
       }
       double K[9], kv[3];
       stiffness3(t, T, K);
+#pragma unroll
       for (int i = 0; i < 3; ++i) kv[i] = K[i * 3] * vb[0][0] + K[i * 3 + 1] * vb[0][1] + K[i * 3 + 2] * vb[0][2];
       for (int g = 0; g < gt.n; ++g) {
         const int kind = uniform(grp[g].kind), q = uniform(grp[g].q), q2 = uniform(grp[g].q2);
         double y[3] = {0, 0, 0};
         if (kind == G_SYS || kind == G_ENERGY) {
-          const double* blk = (kind == G_SYS ? a.A_diag + ((long)q * S + s) * t.nT * 36 : a.P_diag + (long)s * t.nT * 36) + (long)T * 36;
+          const double* blk = Ee + (kind == G_SYS ? 36 * q : oP);
+#pragma unroll
           for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
             for (int i = 0; i < 3; ++i)
               y[i] += blk[bb * 9 + i * 3] * vb[bb][0] + blk[bb * 9 + i * 3 + 1] * vb[bb][1] + blk[bb * 9 + i * 3 + 2] * vb[bb][2];
         } else if (kind == G_MASS) {
           const double m = t.area[T] / 12.0, sum = vb[0][0] + vb[0][1] + vb[0][2];
+#pragma unroll
           for (int i = 0; i < 3; ++i) y[i] = m * (sum + vb[0][i]);
         } else if (kind == G_AA) {
-          const double c = a.caa[(((long)q * Q + q2) * S + s) * t.nT + T];
+          const double c = Ee[oC + q * Q + q2];
+#pragma unroll
           for (int i = 0; i < 3; ++i) y[i] = c * kv[i];
         } else {  // G_AB: A_ab^q restricted to the self part of the flux image
-          const double* A = a.Aab + (((long)q * S + s) * t.nT + T) * 9;
+          const double* A = Ee + oAb + 9 * q;
           double rv[3];
+#pragma unroll
           for (int f = 0; f < 3; ++f) rv[f] = a.Rself[((long)s * t.nrt + t.elem_rt[T * 3 + f]) * QN + q2 * N + j];
+#pragma unroll
           for (int i = 0; i < 3; ++i) y[i] = A[i * 3] * rv[0] + A[i * 3 + 1] * rv[1] + A[i * 3 + 2] * rv[2];
         }
+#pragma unroll
         for (int i = 0; i < 3; ++i) Ys[(3 * wave + i) * F1_LDY + g * N + j] = y[i];
       }
     }
@@ -314,43 +366,55 @@ struct F2Args {
 template <int NR>
 __global__ __launch_bounds__(64 * NR) void k_f2(Tmpl t, F2Args a) {
   constexpr int LD = padded_ld(NR);
-  __shared__ double Xb[3 * EC * LD], Yb[3 * EC * LD], Xd[EC * LD], Yd[EC * LD];
-  __shared__ double red[EC * 128];
+  constexpr int E2 = 8;                       // elements per chunk: 24 face rows (6 k-steps) + 8 divergence rows (2 k-steps)
+  extern __shared__ double dyn[];             // per-element scalars cached once: coef [nT][3], bsum [nT], rt [nT][3] (int)
+  __shared__ double Xb[3 * E2 * LD], Yb[3 * E2 * LD], Xd[E2 * LD], Yd[E2 * LD];
+  __shared__ double red[8 * 128];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
   const int nthreads = 64 * NR;
   const int QN = a.Q * a.N, C = 5 * QN;
-  for (int i = tid; i < 3 * EC * LD; i += nthreads) Xb[i] = Yb[i] = 0.0;
-  for (int i = tid; i < EC * LD; i += nthreads) Xd[i] = Yd[i] = 0.0;
-  for (int i = tid; i < EC * 128; i += nthreads) red[i] = 0.0;
+  double* coefs = dyn;
+  double* bsums = dyn + 3 * t.nT;
+  int* rts = reinterpret_cast<int*>(dyn + 4 * t.nT);
+  const int* nbr_s = a.nbr + s * 5;
+  for (int i = tid; i < 3 * t.nT; i += nthreads) {
+    const int T = i / 3, f = i - 3 * T;
+    coefs[i] = face_sign_at(t, nbr_s, T, f) * t.face_len[i] / t.area[T];
+    rts[i] = t.elem_rt[i];
+  }
+  for (int T = tid; T < t.nT; T += nthreads) {
+    const double* be = a.b + (long)s * t.n + 3 * T;
+    bsums[T] = be[0] + be[1] + be[2];
+  }
+  for (int i = tid; i < 3 * E2 * LD; i += nthreads) Xb[i] = Yb[i] = 0.0;
+  for (int i = tid; i < E2 * LD; i += nthreads) Xd[i] = Yd[i] = 0.0;
+  for (int i = tid; i < 8 * 128; i += nthreads) red[i] = 0.0;
   __syncthreads();
   d4 accb[NR], accd[NR];
+#pragma unroll
   for (int i = 0; i < NR; ++i) accb[i] = accd[i] = (d4){0.0, 0.0, 0.0, 0.0};
   const double* Rs = a.Rself + (long)s * t.nrt * QN;
-  const int* nbr_s = a.nbr + s * 5;
   double rfd_part[2] = {0.0, 0.0};   // columns lane and lane + 64 (QN <= 128)
-  for (int c0 = 0; c0 < t.nT; c0 += EC) {
-    for (int el = wave; el < EC; el += NR) {     // wave-uniform element(s)
+  for (int c0 = 0; c0 < t.nT; c0 += E2) {
+    for (int el = wave; el < E2; el += NR) {     // wave-uniform element(s)
       const int T = c0 + el;
-      double coef[3];
-      int rt[3];
-      for (int f = 0; f < 3; ++f) {
-        coef[f] = face_sign_at(t, nbr_s, T, f) * t.face_len[T * 3 + f] / t.area[T];
-        rt[f] = t.elem_rt[T * 3 + f];
-      }
+      const double c0f = coefs[3 * T], c1f = coefs[3 * T + 1], c2f = coefs[3 * T + 2];
+      const int r0 = rts[3 * T], r1 = rts[3 * T + 1], r2 = rts[3 * T + 2];
       const double* B = a.Bbb + ((long)s * t.nT + T) * 9;
-      const double* be = a.b + (long)s * t.n + 3 * T;
-      const double bsum = be[0] + be[1] + be[2], area = t.area[T];
+      const double bsum = bsums[T], area = t.area[T];
+#pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int c = lane + 64 * k;
         if (c < QN) {
-          double rv[3];
-          for (int f = 0; f < 3; ++f) rv[f] = Rs[(long)rt[f] * QN + c];
-          for (int f = 0; f < 3; ++f) {
-            Xb[(3 * el + f) * LD + c] = rv[f];
-            Yb[(3 * el + f) * LD + c] = B[f * 3] * rv[0] + B[f * 3 + 1] * rv[1] + B[f * 3 + 2] * rv[2];
-          }
-          const double d = coef[0] * rv[0] + coef[1] * rv[1] + coef[2] * rv[2];
+          const double rv0 = Rs[(long)r0 * QN + c], rv1 = Rs[(long)r1 * QN + c], rv2 = Rs[(long)r2 * QN + c];
+          Xb[(3 * el) * LD + c] = rv0;
+          Xb[(3 * el + 1) * LD + c] = rv1;
+          Xb[(3 * el + 2) * LD + c] = rv2;
+          Yb[(3 * el) * LD + c] = B[0] * rv0 + B[1] * rv1 + B[2] * rv2;
+          Yb[(3 * el + 1) * LD + c] = B[3] * rv0 + B[4] * rv1 + B[5] * rv2;
+          Yb[(3 * el + 2) * LD + c] = B[6] * rv0 + B[7] * rv1 + B[8] * rv2;
+          const double d = c0f * rv0 + c1f * rv1 + c2f * rv2;
           Xd[el * LD + c] = d;
           Yd[el * LD + c] = area * d;
           rfd_part[k] += bsum * d;
@@ -359,38 +423,42 @@ __global__ __launch_bounds__(64 * NR) void k_f2(Tmpl t, F2Args a) {
     }
     __syncthreads();
     const int ct = wave;   // this wave's column tile
-    for (int kk = 0; kk < 3 * EC; kk += 4) {
+#pragma unroll
+    for (int kk = 0; kk < 3 * E2; kk += 4) {
       const double bv = Yb[(kk + lk) * LD + ct * 16 + li];
+#pragma unroll
       for (int i = 0; i < NR; ++i) accb[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xb[(kk + lk) * LD + i * 16 + li], bv, accb[i], 0, 0, 0);
     }
-    {
-      const double bv = Yd[lk * LD + ct * 16 + li];
-      for (int i = 0; i < NR; ++i) accd[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xd[lk * LD + i * 16 + li], bv, accd[i], 0, 0, 0);
+#pragma unroll
+    for (int kk = 0; kk < E2; kk += 4) {
+      const double bv = Yd[(kk + lk) * LD + ct * 16 + li];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) accd[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xd[(kk + lk) * LD + i * 16 + li], bv, accd[i], 0, 0, 0);
     }
     __syncthreads();
   }
   const int col = wave * 16 + li;
-  if (col < QN) {
-    double* gb = a.G_bb + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
-    double* gd = a.G_rdd + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
-    for (int i = 0; i < NR; ++i)
-      for (int r = 0; r < 4; ++r) {
-        const int row = i * 16 + lk + 4 * r;
-        if (row < QN) {
-          gb[(long)row * C] = accb[i][r];
-          gd[(long)row * C] = accd[i][r];
-        }
+  double* gb = a.G_bb + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
+  double* gd = a.G_rdd + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i * 16 + lk + 4 * r;
+      const double vb = accb[i][r], vd = accd[i][r];
+      if (col < QN && row < QN) {
+        gb[(long)row * C] = vb;
+        gd[(long)row * C] = vd;
       }
+    }
   }
-  // r_fd self block: wave w staged elements w, w + NR, ... ; fixed-order sum over the (<= EC) staging waves
-  if (wave < EC) {
-    red[wave * 128 + lane] = rfd_part[0];
-    red[wave * 128 + 64 + lane] = rfd_part[1];
-  }
+  // r_fd self block: fixed-order sum over the staging waves
+  red[wave * 128 + lane] = rfd_part[0];
+  red[wave * 128 + 64 + lane] = rfd_part[1];
   __syncthreads();
   for (int c = tid; c < QN; c += nthreads) {
     double sum = 0.0;
-    for (int w = 0; w < EC; ++w) sum += red[w * 128 + c];
+    for (int w = 0; w < NR; ++w) sum += red[w * 128 + c];
     a.r_fd[(long)s * C + 2 * QN + c] = sum;
   }
 }
@@ -460,7 +528,7 @@ __global__ __launch_bounds__(256) void k_thin_nc(Tmpl t, int S, const int* __res
                                                  const double* __restrict__ V, const double* __restrict__ ebar,
                                                  const double* __restrict__ AvgSelf, const double* __restrict__ AvgSide,
                                                  double* __restrict__ G_nc) {
-  extern __shared__ double lds[];   // Wa [3 * ntouch][N], then the transposed [self, a] block [N][N + 1]
+  extern __shared__ double lds[];   // Wa [3 * ntouch][NMAX] (zero padded), then the transposed [self, a] block [N][N + 1]
   const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
   const int W = 5 * N;
   double* G = G_nc + (long)s * W * W;
@@ -472,13 +540,14 @@ __global__ __launch_bounds__(256) void k_thin_nc(Tmpl t, int S, const int* __res
   }
   const int ne = t.touch_count[side];
   double* Wa = lds;
-  double* Tr = lds + 3 * t.ntouch * N;
-  // phase 1: Wa rows (image of the neighbour's basis on the touching elements)
-  for (int it = tid; it < ne * N; it += 256) {
-    const int p = it / N, j = it - p * N;
-    double w[3];
-    oswald_rows(t, s, t.touch_elem[side * t.ntouch + p], slot, N, j, V, AvgSelf, AvgSide, w);
-    for (int i = 0; i < 3; ++i) Wa[(3 * p + i) * N + j] = w[i];
+  double* Tr = lds + 3 * t.ntouch * NMAX;
+  // phase 1: Wa rows (image of the neighbour's basis on the touching elements), padded with zero columns so that
+  // the inner products of phase 2 are branch-free
+  for (int it = tid; it < ne * NMAX; it += 256) {
+    const int p = it / NMAX, j = it - p * NMAX;
+    double w[3] = {0.0, 0.0, 0.0};
+    if (j < N) oswald_rows(t, s, t.touch_elem[side * t.ntouch + p], slot, N, j, V, AvgSelf, AvgSide, w);
+    for (int i = 0; i < 3; ++i) Wa[(3 * p + i) * NMAX + j] = w[i];
   }
   __syncthreads();
   // phase 2: thread <-> output column c = (slot2, j); accumulators over the N rows of block-row a
@@ -499,10 +568,9 @@ __global__ __launch_bounds__(256) void k_thin_nc(Tmpl t, int S, const int* __res
         const double eb = ebar[(long)s * t.nT + T];
         for (int k = 0; k < 3; ++k) {
           const double y = eb * (K[k * 3] * w[0] + K[k * 3 + 1] * w[1] + K[k * 3 + 2] * w[2]);
-          const double* wa = Wa + (3 * p + k) * N;
+          const double* wa = Wa + (3 * p + k) * NMAX;
 #pragma unroll
-          for (int i = 0; i < NMAX; ++i)
-            if (i < N) acc[i] += wa[i] * y;
+          for (int i = 0; i < NMAX; ++i) acc[i] += wa[i] * y;
         }
       }
     }
@@ -658,8 +726,8 @@ int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N) {
 
 bool fused_supported(lrbms_ctx* ctx, int Q, int N) {
   const Tmpl& t = ctx->t;
-  if (N > 64 || Q * N > 128 || t.nT % EC != 0) return false;
-  if ((size_t)(3 * t.ntouch * N + N * (N + 1)) * sizeof(double) > 64 * 1024) return false;
+  if (N > 64 || Q > 4 || Q * N > 128 || t.nT % 8 != 0 || t.nT > 1024) return false;
+  if ((size_t)(3 * t.ntouch * 64 + N * (N + 1)) * sizeof(double) > 64 * 1024) return false;
   if ((size_t)(3 * t.ncf * Q * N + Q * t.ncf * N + 3 * t.ncf) * sizeof(double) > 64 * 1024) return false;
   if ((size_t)2 * 3 * t.ncf * N * sizeof(double) > 64 * 1024) return false;
   return true;
@@ -717,15 +785,16 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   {
     F2Args a{Rself, Bbb, b, ctx->nbr, G_bb, G_rdd, r_fd, Q, N, S};
     const int nr = (QN + 15) / 16;
+    const size_t ldsf2 = sizeof(double) * 4 * t.nT + sizeof(int) * 3 * t.nT;
     switch (nr) {
-      case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(64), 0, st, t, a); break;
-      case 2: hipLaunchKernelGGL(k_f2<2>, dim3(S), dim3(128), 0, st, t, a); break;
-      case 3: hipLaunchKernelGGL(k_f2<3>, dim3(S), dim3(192), 0, st, t, a); break;
-      case 4: hipLaunchKernelGGL(k_f2<4>, dim3(S), dim3(256), 0, st, t, a); break;
-      case 5: hipLaunchKernelGGL(k_f2<5>, dim3(S), dim3(320), 0, st, t, a); break;
-      case 6: hipLaunchKernelGGL(k_f2<6>, dim3(S), dim3(384), 0, st, t, a); break;
-      case 7: hipLaunchKernelGGL(k_f2<7>, dim3(S), dim3(448), 0, st, t, a); break;
-      default: hipLaunchKernelGGL(k_f2<8>, dim3(S), dim3(512), 0, st, t, a); break;
+      case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(64), ldsf2, st, t, a); break;
+      case 2: hipLaunchKernelGGL(k_f2<2>, dim3(S), dim3(128), ldsf2, st, t, a); break;
+      case 3: hipLaunchKernelGGL(k_f2<3>, dim3(S), dim3(192), ldsf2, st, t, a); break;
+      case 4: hipLaunchKernelGGL(k_f2<4>, dim3(S), dim3(256), ldsf2, st, t, a); break;
+      case 5: hipLaunchKernelGGL(k_f2<5>, dim3(S), dim3(320), ldsf2, st, t, a); break;
+      case 6: hipLaunchKernelGGL(k_f2<6>, dim3(S), dim3(384), ldsf2, st, t, a); break;
+      case 7: hipLaunchKernelGGL(k_f2<7>, dim3(S), dim3(448), ldsf2, st, t, a); break;
+      default: hipLaunchKernelGGL(k_f2<8>, dim3(S), dim3(512), ldsf2, st, t, a); break;
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
@@ -742,7 +811,8 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   }
   // ---- thin parts
   {
-    const size_t lds = sizeof(double) * (3 * t.ntouch * N + N * (N + 1));
+    const int nmax = N <= 16 ? 16 : N <= 32 ? 32 : N <= 48 ? 48 : 64;
+    const size_t lds = sizeof(double) * (3 * t.ntouch * nmax + N * (N + 1));
     if (N <= 16) hipLaunchKernelGGL(k_thin_nc<16>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);
     else if (N <= 32) hipLaunchKernelGGL(k_thin_nc<32>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);
     else if (N <= 48) hipLaunchKernelGGL(k_thin_nc<48>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);
