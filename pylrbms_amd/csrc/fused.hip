@@ -26,6 +26,8 @@
 //   k_thin_rt        grid (4 sides, S): block-rows (a,q) / blocks [self,(a,q)] of G_bb, G_rdd, G_ab[:, a], r_fd[a]
 //   k_project_coupling (apply.hip): off-diagonal blocks of B_sys
 // Every output element is written exactly once (zeros included); all reductions have a fixed order.
+#include <cstdlib>
+
 #include "lrbms_dev.h"
 
 namespace {
@@ -184,97 +186,162 @@ struct F1Args {
   const double *V, *A_diag, *P_diag, *caa, *Aab, *Rself, *b;
   double* rhs_red;   // may be null (written only by the launch that carries it)
   int Q, N, S;
+  int dbg;           // timing experiments only (LRBMS_F1_DBG): 1 = skip the group loop, 2 = skip the MFMAs, 4 = skip prefetch
 };
 
-template <int NTX>
-__global__ __launch_bounds__(256, NTX <= 3 ? 2 : 1) void k_f1(Tmpl t, F1Args a, GrpTable gt) {
+// Software pipeline of one workgroup (wave w stages element c0 + w, lanes = basis columns):
+//   iteration c:  issue the global loads of chunk c+1 (basis rows of the element and of its three neighbours, flux rows,
+//                 element blocks) -> registers;  build X / Y rows of chunk c in LDS from the registers loaded one
+//                 iteration ago and the element blocks in LDS;  barrier;  MFMA over chunk c;  element blocks of chunk
+//                 c+1 -> LDS;  barrier.
+// so every L2 / HBM latency is covered by one staging + one MFMA phase.  blockIdx.y selects a slice of the column
+// groups (fewer accumulators per wave -> more workgroups per CU to cover what latency remains).
+template <int NTX, int NTY, int QP>
+__global__ __launch_bounds__(256, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, GrpTable gt1, GrpTable gt2) {
   constexpr int LDX = padded_ld(NTX);
-  constexpr int PRE = 4;                       // per-thread prefetch registers for the element data of the next chunk
+  constexpr int LDY = 4 * NTY * 16 + 16;
+  constexpr int PRE = 4;                       // per-thread prefetch registers for the element blocks of the next chunk
+  constexpr int QR = QP > 0 ? QP : 1;
+  extern __shared__ int idx[];                 // template adjacency cached once: nb_elem [nT][3], elem_rt [nT][3]
   __shared__ double Xs[3 * EC * LDX];
-  __shared__ double Ys[3 * EC * F1_LDY];
+  __shared__ double Ys[3 * EC * LDY];
   __shared__ double Eb[EC * 256];              // element data of the current chunk: A_q blocks, P block, A_ab^q blocks, c^{qq'}
   __shared__ double red[EC * 64];
-  __shared__ Grp grp[F1_MAXG];   // per-lane group lookup in the epilogue (the staging loop reads gt from SGPRs)
+  __shared__ Grp grp[F1_MAXG];
+  __shared__ int grp_n;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
   const int N = a.N, Q = a.Q, S = a.S, QN = Q * N;
-  const int ncols = gt.n * N;
-  // per-element record: [36 Q] A_diag blocks, [36] P_diag block, [9 Q] A_ab blocks, [Q Q] c^{qq'}
   const int oP = 36 * Q, oAb = oP + 36, oC = oAb + 9 * Q, ESTR = oC + Q * Q;    // <= 256 for Q <= 4
+  // select this slice's group table with static indices only (a runtime index into a kernel-argument array would
+  // make the compiler copy the tables to scratch)
 #pragma unroll
-  for (int g = 0; g < F1_MAXG; ++g)   // static indices only: a lane-indexed gt.g[tid] would spill the table to scratch
-    if (tid == g) grp[g] = gt.g[g];
+  for (int g = 0; g < F1_MAXG; ++g)
+    if (tid == g) grp[g] = blockIdx.y == 0 ? gt0.g[g] : blockIdx.y == 1 ? gt1.g[g] : gt2.g[g];
+  if (tid == 0) grp_n = blockIdx.y == 0 ? gt0.n : blockIdx.y == 1 ? gt1.n : gt2.n;
+  int* nbl = idx;
+  int* rtl = idx + 3 * t.nT;
+  for (int i = tid; i < 3 * t.nT; i += 256) {
+    nbl[i] = t.nb_elem[i];
+    rtl[i] = t.elem_rt[i];
+  }
   for (int i = tid; i < 3 * EC * LDX; i += 256) Xs[i] = 0.0;
-  for (int i = tid; i < 3 * EC * F1_LDY; i += 256) Ys[i] = 0.0;
+  for (int i = tid; i < 3 * EC * LDY; i += 256) Ys[i] = 0.0;
+  __syncthreads();
+  const int ng = uniform(grp_n);
+  const int ncols = ng * N;
+  bool want_ab = false;
+  for (int g = 0; g < ng; ++g) want_ab |= (grp[g].kind == G_AB);
+  const bool has_ab = uniform(want_ab ? 1 : 0) != 0;
+  const bool do_rhs = a.rhs_red != nullptr && blockIdx.y == 0;
 
-  // element-data fetch of chunk c0 into registers (coalesced 36- / 9-double runs; consumed from LDS by all lanes)
+  // element-block fetch: thread k-th item = entry o of element slot el of the chunk.  The (source pointer, stride per
+  // element, LDS slot) of each item is fixed for the whole kernel, so the per-chunk work is one load per item
+  // (no index arithmetic in the loop: the div / mod by ESTR happens once here).
+  const double* fsrc[PRE];
+  int fstr[PRE], fdst[PRE];
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+    const int i = tid + 256 * k;
+    fsrc[k] = nullptr;
+    fstr[k] = 0;
+    fdst[k] = 0;
+    if (i < EC * ESTR) {
+      const int el = i / ESTR, o = i - el * ESTR;
+      fdst[k] = el * 256 + o;
+      if (o < oP) {
+        const int q = o / 36;
+        fsrc[k] = a.A_diag + (((long)q * S + s) * t.nT + el) * 36 + (o - 36 * q);
+        fstr[k] = 36;
+      } else if (o < oAb) {
+        fsrc[k] = a.P_diag + ((long)s * t.nT + el) * 36 + (o - oP);
+        fstr[k] = 36;
+      } else if (o < oC) {
+        const int q = (o - oAb) / 9;
+        fsrc[k] = a.Aab + (((long)q * S + s) * t.nT + el) * 9 + (o - oAb - 9 * q);
+        fstr[k] = 9;
+      } else {
+        fsrc[k] = a.caa + ((long)(o - oC) * S + s) * t.nT + el;
+        fstr[k] = 1;
+      }
+    }
+  }
   auto fetch = [&](int c0, double (&pre)[PRE]) {
 #pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-      const int i = tid + 256 * k;
-      double v = 0.0;
-      if (i < EC * ESTR) {
-        const int el = i / ESTR, o = i - el * ESTR, T = c0 + el;
-        if (o < oP) {
-          const int q = o / 36;
-          v = a.A_diag[(((long)q * S + s) * t.nT + T) * 36 + (o - 36 * q)];
-        } else if (o < oAb) {
-          v = a.P_diag[((long)s * t.nT + T) * 36 + (o - oP)];
-        } else if (o < oC) {
-          const int q = (o - oAb) / 9;
-          v = a.Aab[(((long)q * S + s) * t.nT + T) * 9 + (o - oAb - 9 * q)];
-        } else {
-          v = a.caa[((long)(o - oC) * S + s) * t.nT + T];
-        }
-      }
-      pre[k] = v;
-    }
+    for (int k = 0; k < PRE; ++k) pre[k] = fsrc[k] ? fsrc[k][(long)c0 * fstr[k]] : 0.0;
   };
-  double pre[PRE];
-  fetch(0, pre);
-  __syncthreads();
-
-  d4 acc[NTX][F1_NTY];
+  auto stash = [&](const double (&pre)[PRE]) {
 #pragma unroll
-  for (int i = 0; i < NTX; ++i)
-#pragma unroll
-    for (int j = 0; j < F1_NTY; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-  const int my_tiles = min(F1_NTY, max(0, (ncols + 15) / 16 - wave * F1_NTY));   // non-empty column tiles of this wave
+    for (int k = 0; k < PRE; ++k)
+      if (fsrc[k]) Eb[fdst[k]] = pre[k];
+  };
   const double* Vs = a.V + (long)s * t.n * N;
-  double rhs_part = 0.0;
+  const double* Rs = a.Rself + (long)s * t.nrt * QN;
   const int j = lane;
-
-  for (int c0 = 0; c0 < t.nT; c0 += EC) {
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-      const int i = tid + 256 * k;
-      if (i < EC * ESTR) Eb[(i / ESTR) * 256 + (i % ESTR)] = pre[k];
-    }
-    __syncthreads();
-    if (c0 + EC < t.nT) fetch(c0 + EC, pre);       // in flight during staging + MFMA of this chunk
-    const int T = c0 + wave;                       // wave-uniform element
-    const double* Ee = Eb + wave * 256;
-    if (j < N) {
-      double vb[4][3];
+  const bool colj = j < N;
+  auto load_rows = [&](int T, double (&vb)[4][3], double (&rv)[3][QR]) {
+    if (colj) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) vb[0][i] = Vs[(long)(3 * T + i) * N + j];
 #pragma unroll
       for (int f = 0; f < 3; ++f) {
-        const int nb = t.nb_elem[T * 3 + f];
+        const int nb = nbl[T * 3 + f];
 #pragma unroll
         for (int i = 0; i < 3; ++i) vb[1 + f][i] = nb >= 0 ? Vs[(long)(3 * nb + i) * N + j] : 0.0;
       }
+      if (QP > 0 && has_ab) {
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+          for (int q2 = 0; q2 < QR; ++q2) rv[f][q2] = q2 < Q ? Rs[(long)rtl[T * 3 + f] * QN + q2 * N + j] : 0.0;
+      }
+    }
+  };
+
+  double pre[PRE];
+  double vb[4][3], rv[3][QR], nvb[4][3], nrv[3][QR];
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vb[bb][i] = nvb[bb][i] = 0.0;
+#pragma unroll
+  for (int f = 0; f < 3; ++f)
+#pragma unroll
+    for (int q2 = 0; q2 < QR; ++q2) rv[f][q2] = nrv[f][q2] = 0.0;
+  fetch(0, pre);
+  load_rows(wave, vb, rv);
+  stash(pre);
+  __syncthreads();
+
+  d4 acc[NTX][NTY];
+#pragma unroll
+  for (int i = 0; i < NTX; ++i)
+#pragma unroll
+    for (int jj = 0; jj < NTY; ++jj) acc[i][jj] = (d4){0.0, 0.0, 0.0, 0.0};
+  double rhs_part = 0.0;
+
+  for (int c0 = 0; c0 < t.nT; c0 += EC) {
+    const bool more = c0 + EC < t.nT;
+    if (more) {                                    // in flight during staging + MFMA of this chunk
+      if (!(a.dbg & 8)) fetch(c0 + EC, pre);
+      if (!(a.dbg & 4)) load_rows(c0 + EC + wave, nvb, nrv);
+    }
+    const int T = c0 + wave;                       // wave-uniform element
+    const double* Ee = Eb + wave * 256;
+    if (colj) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) Xs[(3 * wave + i) * LDX + j] = vb[0][i];
-      if (a.rhs_red) {
+      if (do_rhs) {
         const double* be = a.b + (long)s * t.n + 3 * T;
         rhs_part += be[0] * vb[0][0] + be[1] * vb[0][1] + be[2] * vb[0][2];
       }
-      double K[9], kv[3];
-      stiffness3(t, T, K);
+      double K[9], kv[3] = {0, 0, 0};
+      if (!(a.dbg & 16)) {
+        stiffness3(t, T, K);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) kv[i] = K[i * 3] * vb[0][0] + K[i * 3 + 1] * vb[0][1] + K[i * 3 + 2] * vb[0][2];
-      for (int g = 0; g < gt.n; ++g) {
+        for (int i = 0; i < 3; ++i) kv[i] = K[i * 3] * vb[0][0] + K[i * 3 + 1] * vb[0][1] + K[i * 3 + 2] * vb[0][2];
+      }
+      for (int g = 0; g < ((a.dbg & 1) ? 0 : ng); ++g) {
         const int kind = uniform(grp[g].kind), q = uniform(grp[g].q), q2 = uniform(grp[g].q2);
         double y[3] = {0, 0, 0};
         if (kind == G_SYS || kind == G_ENERGY) {
@@ -294,37 +361,59 @@ __global__ __launch_bounds__(256, NTX <= 3 ? 2 : 1) void k_f1(Tmpl t, F1Args a, 
           for (int i = 0; i < 3; ++i) y[i] = c * kv[i];
         } else {  // G_AB: A_ab^q restricted to the self part of the flux image
           const double* A = Ee + oAb + 9 * q;
-          double rv[3];
+          double r3[3];
+          if (QP > 0) {
 #pragma unroll
-          for (int f = 0; f < 3; ++f) rv[f] = a.Rself[((long)s * t.nrt + t.elem_rt[T * 3 + f]) * QN + q2 * N + j];
+            for (int f = 0; f < 3; ++f) {
+              r3[f] = rv[f][0];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) y[i] = A[i * 3] * rv[0] + A[i * 3 + 1] * rv[1] + A[i * 3 + 2] * rv[2];
+              for (int qq = 1; qq < QR; ++qq)
+                if (q2 == qq) r3[f] = rv[f][qq];
+            }
+          } else {
+#pragma unroll
+            for (int f = 0; f < 3; ++f) r3[f] = Rs[(long)rtl[T * 3 + f] * QN + q2 * N + j];
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) y[i] = A[i * 3] * r3[0] + A[i * 3 + 1] * r3[1] + A[i * 3 + 2] * r3[2];
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) Ys[(3 * wave + i) * F1_LDY + g * N + j] = y[i];
+        for (int i = 0; i < 3; ++i) Ys[(3 * wave + i) * LDY + g * N + j] = y[i];
       }
     }
     __syncthreads();
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int kk = 0; kk < 3 * EC; kk += 4) {
       double av[NTX];
 #pragma unroll
       for (int i = 0; i < NTX; ++i) av[i] = Xs[(kk + lk) * LDX + i * 16 + li];
 #pragma unroll
-      for (int jt = 0; jt < F1_NTY; ++jt) {   // tiles beyond ncols multiply zero columns of Ys (harmless, branch-free)
-        const double bv = Ys[(kk + lk) * F1_LDY + (wave * F1_NTY + jt) * 16 + li];
+      for (int jt = 0; jt < NTY; ++jt) {   // tiles beyond ncols multiply zero columns of Ys (harmless, branch-free)
+        const double bv = Ys[(kk + lk) * LDY + (wave * NTY + jt) * 16 + li];
 #pragma unroll
         for (int i = 0; i < NTX; ++i) acc[i][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[i][jt], 0, 0, 0);
       }
+    }
+    if (more && !(a.dbg & 8)) stash(pre);          // element blocks of the next chunk (all waves are past staging)
+    if (more) {
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) vb[bb][i] = nvb[bb][i];
+#pragma unroll
+      for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int q2 = 0; q2 < QR; ++q2) rv[f][q2] = nrv[f][q2];
     }
     __syncthreads();
   }
   // ---- epilogue: scatter the tiles to their destination arrays (static accumulator indices only: any runtime
   // index or early `continue` here makes the compiler keep `acc` in scratch for the whole kernel)
 #pragma unroll
-  for (int jt = 0; jt < F1_NTY; ++jt) {
-    const int col = (wave * F1_NTY + jt) * 16 + li;
-    const bool live = jt < my_tiles && col < ncols;
+  for (int jt = 0; jt < NTY; ++jt) {
+    const int col = (wave * NTY + jt) * 16 + li;
+    const bool live = col < ncols;
     const int g = live ? col / N : 0, jj = col - g * N;
     const int ld = grp[g].ld;
     double* dst = grp[g].dst + (long)s * grp[g].sstride + jj;
@@ -342,7 +431,7 @@ __global__ __launch_bounds__(256, NTX <= 3 ? 2 : 1) void k_f1(Tmpl t, F1Args a, 
       }
     }
   }
-  if (a.rhs_red) {   // fixed-order sum over the EC staging waves
+  if (do_rhs) {   // fixed-order sum over the EC staging waves
     red[wave * 64 + lane] = rhs_part;
     __syncthreads();
     if (tid < N) {
@@ -764,22 +853,40 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   for (int q = 0; q < Q; ++q)
     for (int q2 = 0; q2 < Q; ++q2)
       groups.push_back({G_AB, q, q2, C, G_ab + (long)q * S * N * C + 2 * QN + q2 * N, nullptr, (long)N * C});
-  const int per = std::min(F1_MAXG, F1_YW / N);
-  const int ntx = (N + 15) / 16;
-  bool first = true;
-  for (size_t g0 = 0; g0 < groups.size(); g0 += per) {
-    GrpTable gt;
-    gt.n = (int)std::min<size_t>(per, groups.size() - g0);
-    for (int i = 0; i < gt.n; ++i) gt.g[i] = groups[g0 + i];
-    F1Args a{V, A_diag, P_diag, caa, Aab, Rself, b, first ? rhs_red : nullptr, Q, N, S};
-    first = false;
-    switch (ntx) {
-      case 1: hipLaunchKernelGGL(k_f1<1>, dim3(S), dim3(256), 0, st, t, a, gt); break;
-      case 2: hipLaunchKernelGGL(k_f1<2>, dim3(S), dim3(256), 0, st, t, a, gt); break;
-      case 3: hipLaunchKernelGGL(k_f1<3>, dim3(S), dim3(256), 0, st, t, a, gt); break;
-      default: hipLaunchKernelGGL(k_f1<4>, dim3(S), dim3(256), 0, st, t, a, gt); break;
+  {
+    constexpr int NTY = 4;                                   // 4 waves x 4 column tiles = 256 columns per slice
+    const int per = std::min(F1_MAXG, (4 * NTY * 16) / N);
+    const int ntx = (N + 15) / 16;
+    const size_t ldsf1 = sizeof(int) * 6 * t.nT;
+    for (size_t g0 = 0; g0 < groups.size(); g0 += 3 * (size_t)per) {   // up to three slices per launch (grid.y)
+      GrpTable gt[3];
+      int nsl = 0;
+      for (int sl = 0; sl < 3; ++sl) {
+        gt[sl].n = 0;
+        const size_t b0 = g0 + (size_t)sl * per;
+        if (b0 >= groups.size()) continue;
+        gt[sl].n = (int)std::min<size_t>(per, groups.size() - b0);
+        for (int i = 0; i < gt[sl].n; ++i) gt[sl].g[i] = groups[b0 + i];
+        nsl = sl + 1;
+      }
+      const char* dbg_env = getenv("LRBMS_F1_DBG");
+      F1Args a{V, A_diag, P_diag, caa, Aab, Rself, b, g0 == 0 ? rhs_red : nullptr, Q, N, S, dbg_env ? atoi(dbg_env) : 0};
+      const dim3 grid(S, nsl);
+#define LRBMS_F1(NTXV)                                                                                              \
+  do {                                                                                                              \
+    if (Q == 1) hipLaunchKernelGGL((k_f1<NTXV, NTY, 1>), grid, dim3(256), ldsf1, st, t, a, gt[0], gt[1], gt[2]);      \
+    else if (Q == 2) hipLaunchKernelGGL((k_f1<NTXV, NTY, 2>), grid, dim3(256), ldsf1, st, t, a, gt[0], gt[1], gt[2]); \
+    else hipLaunchKernelGGL((k_f1<NTXV, NTY, 0>), grid, dim3(256), ldsf1, st, t, a, gt[0], gt[1], gt[2]);             \
+  } while (0)
+      switch (ntx) {
+        case 1: LRBMS_F1(1); break;
+        case 2: LRBMS_F1(2); break;
+        case 3: LRBMS_F1(3); break;
+        default: LRBMS_F1(4); break;
+      }
+#undef LRBMS_F1
+      LRBMS_LAUNCH_CHECK(ctx);
     }
-    LRBMS_LAUNCH_CHECK(ctx);
   }
   // ---- F2
   {
@@ -801,6 +908,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // ---- F3
   {
     F3Args a{V, ebar, AvgSelf, AvgSide, G_nc, N, S};
+    const int ntx = (N + 15) / 16;
     switch (ntx) {
       case 1: hipLaunchKernelGGL(k_f3<1>, dim3(S), dim3(256), 0, st, t, a); break;
       case 2: hipLaunchKernelGGL(k_f3<2>, dim3(S), dim3(256), 0, st, t, a); break;
