@@ -189,23 +189,24 @@ struct F1Args {
   int dbg;           // timing experiments only (LRBMS_F1_DBG): 1 = skip the group loop, 2 = skip the MFMAs, 4 = skip prefetch
 };
 
-// Software pipeline of one workgroup (wave w stages element c0 + w, lanes = basis columns):
-//   iteration c:  issue the global loads of chunk c+1 (basis rows of the element and of its three neighbours, flux rows,
-//                 element blocks) -> registers;  build X / Y rows of chunk c in LDS from the registers loaded one
-//                 iteration ago and the element blocks in LDS;  barrier;  MFMA over chunk c;  element blocks of chunk
-//                 c+1 -> LDS;  barrier.
-// so every L2 / HBM latency is covered by one staging + one MFMA phase.  blockIdx.y selects a slice of the column
-// groups (fewer accumulators per wave -> more workgroups per CU to cover what latency remains).
+// Producer / consumer workgroup of 8 waves (one workgroup per CU):
+//   waves 0-3 (producers): wave w builds the X / Y rows of element 4 c + w of chunk c in LDS buffer c & 1, with the
+//     global loads of chunk c + 1 (basis rows of the element and its three neighbours, flux rows, element blocks)
+//     already in flight; VALU + memory only.
+//   waves 4-7 (consumers): MFMA over chunk c from buffer c & 1 while the producers fill the other buffer; each owns
+//     NTY column tiles x NTX row tiles of accumulators.
+//   One s_barrier per chunk.  Waves w and w + 4 share a SIMD, so every SIMD holds one producer (VALU pipe) and one
+//   consumer (matrix pipe), which execute concurrently.
 template <int NTX, int NTY, int QP>
-__global__ __launch_bounds__(256, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, GrpTable gt1, GrpTable gt2) {
+__global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, GrpTable gt1, GrpTable gt2) {
   constexpr int LDX = padded_ld(NTX);
   constexpr int LDY = 4 * NTY * 16 + 16;
-  constexpr int PRE = 4;                       // per-thread prefetch registers for the element blocks of the next chunk
+  constexpr int PRE = 4;                       // per-lane prefetch registers for the element blocks (ESTR <= 256)
   constexpr int QR = QP > 0 ? QP : 1;
   extern __shared__ int idx[];                 // template adjacency cached once: nb_elem [nT][3], elem_rt [nT][3]
-  __shared__ double Xs[3 * EC * LDX];
-  __shared__ double Ys[3 * EC * LDY];
-  __shared__ double Eb[EC * 256];              // element data of the current chunk: A_q blocks, P block, A_ab^q blocks, c^{qq'}
+  __shared__ double Xs[2][3 * EC * LDX];
+  __shared__ double Ys[2][3 * EC * LDY];
+  __shared__ double Eb[EC * 256];              // per producer wave: A_q blocks, P block, A_ab^q blocks, c^{qq'} of its element
   __shared__ double red[EC * 64];
   __shared__ Grp grp[F1_MAXG];
   __shared__ int grp_n;
@@ -221,182 +222,204 @@ __global__ __launch_bounds__(256, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
   if (tid == 0) grp_n = blockIdx.y == 0 ? gt0.n : blockIdx.y == 1 ? gt1.n : gt2.n;
   int* nbl = idx;
   int* rtl = idx + 3 * t.nT;
-  for (int i = tid; i < 3 * t.nT; i += 256) {
+  for (int i = tid; i < 3 * t.nT; i += 512) {
     nbl[i] = t.nb_elem[i];
     rtl[i] = t.elem_rt[i];
   }
-  for (int i = tid; i < 3 * EC * LDX; i += 256) Xs[i] = 0.0;
-  for (int i = tid; i < 3 * EC * LDY; i += 256) Ys[i] = 0.0;
+  for (int i = tid; i < 2 * 3 * EC * LDX; i += 512) (&Xs[0][0])[i] = 0.0;
+  for (int i = tid; i < 2 * 3 * EC * LDY; i += 512) (&Ys[0][0])[i] = 0.0;
   __syncthreads();
   const int ng = uniform(grp_n);
   const int ncols = ng * N;
-  bool want_ab = false;
-  for (int g = 0; g < ng; ++g) want_ab |= (grp[g].kind == G_AB);
-  const bool has_ab = uniform(want_ab ? 1 : 0) != 0;
-  const bool do_rhs = a.rhs_red != nullptr && blockIdx.y == 0;
+  const int nchunks = t.nT / EC;
 
-  // element-block fetch: thread k-th item = entry o of element slot el of the chunk.  The (source pointer, stride per
-  // element, LDS slot) of each item is fixed for the whole kernel, so the per-chunk work is one load per item
-  // (no index arithmetic in the loop: the div / mod by ESTR happens once here).
-  const double* fsrc[PRE];
-  int fstr[PRE], fdst[PRE];
+  if (wave < EC) {
+    // ================================================= producers
+    bool want_ab = false;
+    for (int g = 0; g < ng; ++g) want_ab |= (grp[g].kind == G_AB);
+    const bool has_ab = uniform(want_ab ? 1 : 0) != 0;
+    const bool do_rhs = a.rhs_red != nullptr && blockIdx.y == 0;
+    // element-block fetch of this wave's element: lane item o = lane + 64 k; (pointer, per-element stride) fixed
+    const double* fsrc[PRE];
+    int fstr[PRE];
 #pragma unroll
-  for (int k = 0; k < PRE; ++k) {
-    const int i = tid + 256 * k;
-    fsrc[k] = nullptr;
-    fstr[k] = 0;
-    fdst[k] = 0;
-    if (i < EC * ESTR) {
-      const int el = i / ESTR, o = i - el * ESTR;
-      fdst[k] = el * 256 + o;
-      if (o < oP) {
-        const int q = o / 36;
-        fsrc[k] = a.A_diag + (((long)q * S + s) * t.nT + el) * 36 + (o - 36 * q);
-        fstr[k] = 36;
-      } else if (o < oAb) {
-        fsrc[k] = a.P_diag + ((long)s * t.nT + el) * 36 + (o - oP);
-        fstr[k] = 36;
-      } else if (o < oC) {
-        const int q = (o - oAb) / 9;
-        fsrc[k] = a.Aab + (((long)q * S + s) * t.nT + el) * 9 + (o - oAb - 9 * q);
-        fstr[k] = 9;
-      } else {
-        fsrc[k] = a.caa + ((long)(o - oC) * S + s) * t.nT + el;
-        fstr[k] = 1;
+    for (int k = 0; k < PRE; ++k) {
+      const int o = lane + 64 * k;
+      fsrc[k] = nullptr;
+      fstr[k] = 0;
+      if (o < ESTR) {
+        if (o < oP) {
+          const int q = o / 36;
+          fsrc[k] = a.A_diag + ((long)q * S + s) * t.nT * 36 + (o - 36 * q);
+          fstr[k] = 36;
+        } else if (o < oAb) {
+          fsrc[k] = a.P_diag + (long)s * t.nT * 36 + (o - oP);
+          fstr[k] = 36;
+        } else if (o < oC) {
+          const int q = (o - oAb) / 9;
+          fsrc[k] = a.Aab + ((long)q * S + s) * t.nT * 9 + (o - oAb - 9 * q);
+          fstr[k] = 9;
+        } else {
+          fsrc[k] = a.caa + ((long)(o - oC) * S + s) * t.nT;
+          fstr[k] = 1;
+        }
       }
     }
-  }
-  auto fetch = [&](int c0, double (&pre)[PRE]) {
+    double* Ee = Eb + wave * 256;
+    const double* Vs = a.V + (long)s * t.n * N;
+    const double* Rs = a.Rself + (long)s * t.nrt * QN;
+    const int j = lane;
+    const bool colj = j < N;
+    double pre[PRE], vb[4][3], rv[3][QR], nvb[4][3], nrv[3][QR];
+    auto fetch = [&](int T, double (&pr)[PRE]) {
 #pragma unroll
-    for (int k = 0; k < PRE; ++k) pre[k] = fsrc[k] ? fsrc[k][(long)c0 * fstr[k]] : 0.0;
-  };
-  auto stash = [&](const double (&pre)[PRE]) {
+      for (int k = 0; k < PRE; ++k) pr[k] = fsrc[k] ? fsrc[k][(long)T * fstr[k]] : 0.0;
+    };
+    auto load_rows = [&](int T, double (&vbx)[4][3], double (&rvx)[3][QR]) {
+      if (colj) {
 #pragma unroll
-    for (int k = 0; k < PRE; ++k)
-      if (fsrc[k]) Eb[fdst[k]] = pre[k];
-  };
-  const double* Vs = a.V + (long)s * t.n * N;
-  const double* Rs = a.Rself + (long)s * t.nrt * QN;
-  const int j = lane;
-  const bool colj = j < N;
-  auto load_rows = [&](int T, double (&vb)[4][3], double (&rv)[3][QR]) {
-    if (colj) {
+        for (int i = 0; i < 3; ++i) vbx[0][i] = Vs[(long)(3 * T + i) * N + j];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) vb[0][i] = Vs[(long)(3 * T + i) * N + j];
+        for (int f = 0; f < 3; ++f) {
+          const int nb = nbl[T * 3 + f];
 #pragma unroll
-      for (int f = 0; f < 3; ++f) {
-        const int nb = nbl[T * 3 + f];
+          for (int i = 0; i < 3; ++i) vbx[1 + f][i] = nb >= 0 ? Vs[(long)(3 * nb + i) * N + j] : 0.0;
+        }
+        if (QP > 0 && has_ab) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) vb[1 + f][i] = nb >= 0 ? Vs[(long)(3 * nb + i) * N + j] : 0.0;
+          for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int q2 = 0; q2 < QR; ++q2) rvx[f][q2] = q2 < Q ? Rs[(long)rtl[T * 3 + f] * QN + q2 * N + j] : 0.0;
+        }
       }
-      if (QP > 0 && has_ab) {
+    };
 #pragma unroll
-        for (int f = 0; f < 3; ++f)
+    for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-          for (int q2 = 0; q2 < QR; ++q2) rv[f][q2] = q2 < Q ? Rs[(long)rtl[T * 3 + f] * QN + q2 * N + j] : 0.0;
+      for (int i = 0; i < 3; ++i) vb[bb][i] = nvb[bb][i] = 0.0;
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+#pragma unroll
+      for (int q2 = 0; q2 < QR; ++q2) rv[f][q2] = nrv[f][q2] = 0.0;
+    fetch(wave, pre);
+    load_rows(wave, vb, rv);
+    double rhs_part = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+      const int T = c * EC + wave;                 // wave-uniform element
+      double* Xb = &Xs[c & 1][0];
+      double* Yb = &Ys[c & 1][0];
+#pragma unroll
+      for (int k = 0; k < PRE; ++k)                // this wave's element blocks -> its private LDS record
+        if (fsrc[k]) Ee[lane + 64 * k] = pre[k];
+      if (c + 1 < nchunks && !(a.dbg & 8)) {       // next chunk's loads, in flight during this staging
+        fetch(T + EC, pre);
+        load_rows(T + EC, nvb, nrv);
       }
-    }
-  };
-
-  double pre[PRE];
-  double vb[4][3], rv[3][QR], nvb[4][3], nrv[3][QR];
+      if (colj && !(a.dbg & 4)) {
 #pragma unroll
-  for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) vb[bb][i] = nvb[bb][i] = 0.0;
-#pragma unroll
-  for (int f = 0; f < 3; ++f)
-#pragma unroll
-    for (int q2 = 0; q2 < QR; ++q2) rv[f][q2] = nrv[f][q2] = 0.0;
-  fetch(0, pre);
-  load_rows(wave, vb, rv);
-  stash(pre);
-  __syncthreads();
-
-  d4 acc[NTX][NTY];
-#pragma unroll
-  for (int i = 0; i < NTX; ++i)
-#pragma unroll
-    for (int jj = 0; jj < NTY; ++jj) acc[i][jj] = (d4){0.0, 0.0, 0.0, 0.0};
-  double rhs_part = 0.0;
-
-  for (int c0 = 0; c0 < t.nT; c0 += EC) {
-    const bool more = c0 + EC < t.nT;
-    if (more) {                                    // in flight during staging + MFMA of this chunk
-      if (!(a.dbg & 8)) fetch(c0 + EC, pre);
-      if (!(a.dbg & 4)) load_rows(c0 + EC + wave, nvb, nrv);
-    }
-    const int T = c0 + wave;                       // wave-uniform element
-    const double* Ee = Eb + wave * 256;
-    if (colj) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) Xs[(3 * wave + i) * LDX + j] = vb[0][i];
-      if (do_rhs) {
-        const double* be = a.b + (long)s * t.n + 3 * T;
-        rhs_part += be[0] * vb[0][0] + be[1] * vb[0][1] + be[2] * vb[0][2];
-      }
-      double K[9], kv[3] = {0, 0, 0};
-      if (!(a.dbg & 16)) {
+        for (int i = 0; i < 3; ++i) Xb[(3 * wave + i) * LDX + j] = vb[0][i];
+        if (do_rhs) {
+          const double* be = a.b + (long)s * t.n + 3 * T;
+          rhs_part += be[0] * vb[0][0] + be[1] * vb[0][1] + be[2] * vb[0][2];
+        }
+        double K[9], kv[3];
         stiffness3(t, T, K);
 #pragma unroll
         for (int i = 0; i < 3; ++i) kv[i] = K[i * 3] * vb[0][0] + K[i * 3 + 1] * vb[0][1] + K[i * 3 + 2] * vb[0][2];
-      }
-      for (int g = 0; g < ((a.dbg & 1) ? 0 : ng); ++g) {
-        const int kind = uniform(grp[g].kind), q = uniform(grp[g].q), q2 = uniform(grp[g].q2);
-        double y[3] = {0, 0, 0};
-        if (kind == G_SYS || kind == G_ENERGY) {
-          const double* blk = Ee + (kind == G_SYS ? 36 * q : oP);
+        if (QP > 0 && ng == QP + 2 + (QP * (QP + 1)) / 2 + QP * QP) {
+          // ---- straight-line staging for the canonical group order [SYS q][ENERGY][MASS][AA q<=q'][AB q q'] with
+          // compile-time Q: no group-table reads or branches, every LDS operand address is an immediate, so the
+          // compiler batches the ds_reads of the whole element and one LDS latency is exposed instead of ~11
+          int g = 0;
+          auto put = [&](const double (&y)[3]) {
 #pragma unroll
-          for (int bb = 0; bb < 4; ++bb)
+            for (int i = 0; i < 3; ++i) Yb[(3 * wave + i) * LDY + g * N + j] = y[i];
+            ++g;
+          };
+          auto apply = [&](const double* blk) {
+            double y[3] = {0, 0, 0};
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-              y[i] += blk[bb * 9 + i * 3] * vb[bb][0] + blk[bb * 9 + i * 3 + 1] * vb[bb][1] + blk[bb * 9 + i * 3 + 2] * vb[bb][2];
-        } else if (kind == G_MASS) {
-          const double m = t.area[T] / 12.0, sum = vb[0][0] + vb[0][1] + vb[0][2];
+            for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-          for (int i = 0; i < 3; ++i) y[i] = m * (sum + vb[0][i]);
-        } else if (kind == G_AA) {
-          const double c = Ee[oC + q * Q + q2];
+              for (int i = 0; i < 3; ++i)
+                y[i] += blk[bb * 9 + i * 3] * vb[bb][0] + blk[bb * 9 + i * 3 + 1] * vb[bb][1] + blk[bb * 9 + i * 3 + 2] * vb[bb][2];
+            put(y);
+          };
 #pragma unroll
-          for (int i = 0; i < 3; ++i) y[i] = c * kv[i];
-        } else {  // G_AB: A_ab^q restricted to the self part of the flux image
-          const double* A = Ee + oAb + 9 * q;
-          double r3[3];
-          if (QP > 0) {
-#pragma unroll
-            for (int f = 0; f < 3; ++f) {
-              r3[f] = rv[f][0];
-#pragma unroll
-              for (int qq = 1; qq < QR; ++qq)
-                if (q2 == qq) r3[f] = rv[f][qq];
-            }
-          } else {
-#pragma unroll
-            for (int f = 0; f < 3; ++f) r3[f] = Rs[(long)rtl[T * 3 + f] * QN + q2 * N + j];
+          for (int q = 0; q < QP; ++q) apply(Ee + 36 * q);
+          apply(Ee + 36 * QP);
+          {
+            const double m = t.area[T] / 12.0, sum = vb[0][0] + vb[0][1] + vb[0][2];
+            const double y[3] = {m * (sum + vb[0][0]), m * (sum + vb[0][1]), m * (sum + vb[0][2])};
+            put(y);
           }
 #pragma unroll
-          for (int i = 0; i < 3; ++i) y[i] = A[i * 3] * r3[0] + A[i * 3 + 1] * r3[1] + A[i * 3 + 2] * r3[2];
+          for (int q = 0; q < QP; ++q)
+#pragma unroll
+            for (int q2 = q; q2 < QP; ++q2) {
+              const double cc = Ee[36 * QP + 36 + 9 * QP + q * QP + q2];
+              const double y[3] = {cc * kv[0], cc * kv[1], cc * kv[2]};
+              put(y);
+            }
+#pragma unroll
+          for (int q = 0; q < QP; ++q) {
+            const double* A = Ee + 36 * QP + 36 + 9 * q;
+#pragma unroll
+            for (int q2 = 0; q2 < QP; ++q2) {
+              const double y[3] = {A[0] * rv[0][q2] + A[1] * rv[1][q2] + A[2] * rv[2][q2],
+                                   A[3] * rv[0][q2] + A[4] * rv[1][q2] + A[5] * rv[2][q2],
+                                   A[6] * rv[0][q2] + A[7] * rv[1][q2] + A[8] * rv[2][q2]};
+              put(y);
+            }
+          }
+        } else
+        for (int g = 0; g < ((a.dbg & 1) ? 0 : ng); ++g) {
+          const int kind = uniform(grp[g].kind), q = uniform(grp[g].q), q2 = uniform(grp[g].q2);
+          double y[3] = {0, 0, 0};
+          if ((kind == G_SYS || kind == G_ENERGY) && (a.dbg & 16)) {   // timing experiment: same FMAs, no LDS operand reads
+            const double c1 = 1.25 + q, c2 = 0.75, c3 = -0.5;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+                y[i] += (c1 + bb) * vb[bb][0] + (c2 + i) * vb[bb][1] + (c3 - bb) * vb[bb][2];
+          } else if (kind == G_SYS || kind == G_ENERGY) {
+            const double* blk = Ee + (kind == G_SYS ? 36 * q : oP);
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+                y[i] += blk[bb * 9 + i * 3] * vb[bb][0] + blk[bb * 9 + i * 3 + 1] * vb[bb][1] + blk[bb * 9 + i * 3 + 2] * vb[bb][2];
+          } else if (kind == G_MASS) {
+            const double m = t.area[T] / 12.0, sum = vb[0][0] + vb[0][1] + vb[0][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) y[i] = m * (sum + vb[0][i]);
+          } else if (kind == G_AA) {
+            const double cc = Ee[oC + q * Q + q2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) y[i] = cc * kv[i];
+          } else {  // G_AB: A_ab^q restricted to the self part of the flux image
+            const double* A = Ee + oAb + 9 * q;
+            double r3[3];
+            if (QP > 0) {
+#pragma unroll
+              for (int f = 0; f < 3; ++f) {
+                r3[f] = rv[f][0];
+#pragma unroll
+                for (int qq = 1; qq < QR; ++qq)
+                  if (q2 == qq) r3[f] = rv[f][qq];
+              }
+            } else {
+#pragma unroll
+              for (int f = 0; f < 3; ++f) r3[f] = Rs[(long)rtl[T * 3 + f] * QN + q2 * N + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) y[i] = A[i * 3] * r3[0] + A[i * 3 + 1] * r3[1] + A[i * 3 + 2] * r3[2];
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) Yb[(3 * wave + i) * LDY + g * N + j] = y[i];
         }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) Ys[(3 * wave + i) * LDY + g * N + j] = y[i];
       }
-    }
-    __syncthreads();
-    if (!(a.dbg & 2))
-#pragma unroll
-    for (int kk = 0; kk < 3 * EC; kk += 4) {
-      double av[NTX];
-#pragma unroll
-      for (int i = 0; i < NTX; ++i) av[i] = Xs[(kk + lk) * LDX + i * 16 + li];
-#pragma unroll
-      for (int jt = 0; jt < NTY; ++jt) {   // tiles beyond ncols multiply zero columns of Ys (harmless, branch-free)
-        const double bv = Ys[(kk + lk) * LDY + (wave * NTY + jt) * 16 + li];
-#pragma unroll
-        for (int i = 0; i < NTX; ++i) acc[i][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[i][jt], 0, 0, 0);
-      }
-    }
-    if (more && !(a.dbg & 8)) stash(pre);          // element blocks of the next chunk (all waves are past staging)
-    if (more) {
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
@@ -405,34 +428,61 @@ __global__ __launch_bounds__(256, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
       for (int f = 0; f < 3; ++f)
 #pragma unroll
         for (int q2 = 0; q2 < QR; ++q2) rv[f][q2] = nrv[f][q2];
+      __syncthreads();                             // barrier c: buffer c & 1 is complete
     }
-    __syncthreads();
-  }
-  // ---- epilogue: scatter the tiles to their destination arrays (static accumulator indices only: any runtime
-  // index or early `continue` here makes the compiler keep `acc` in scratch for the whole kernel)
+    __syncthreads();                               // final barrier (matches the consumers' count)
+    if (do_rhs) red[wave * 64 + lane] = rhs_part;
+  } else {
+    // ================================================= consumers
+    const int cw = wave - EC;
+    d4 acc[NTX][NTY];
 #pragma unroll
-  for (int jt = 0; jt < NTY; ++jt) {
-    const int col = (wave * NTY + jt) * 16 + li;
-    const bool live = col < ncols;
-    const int g = live ? col / N : 0, jj = col - g * N;
-    const int ld = grp[g].ld;
-    double* dst = grp[g].dst + (long)s * grp[g].sstride + jj;
-    double* dst_t = grp[g].dst_t ? grp[g].dst_t + (long)s * grp[g].sstride + (long)jj * ld : nullptr;
+    for (int i = 0; i < NTX; ++i)
 #pragma unroll
-    for (int i = 0; i < NTX; ++i) {
+      for (int jj = 0; jj < NTY; ++jj) acc[i][jj] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < nchunks; ++c) {
+      __syncthreads();                             // barrier c
+      const double* Xb = &Xs[c & 1][0];
+      const double* Yb = &Ys[c & 1][0];
+      if (!(a.dbg & 2))
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = i * 16 + lk + 4 * r;
-        const double val = acc[i][jt][r];
-        if (live && row < N) {
-          dst[(long)row * ld] = val;
-          if (dst_t) dst_t[row] = val;
+      for (int kk = 0; kk < 3 * EC; kk += 4) {
+        double av[NTX];
+#pragma unroll
+        for (int i = 0; i < NTX; ++i) av[i] = Xb[(kk + lk) * LDX + i * 16 + li];
+#pragma unroll
+        for (int jt = 0; jt < NTY; ++jt) {         // tiles beyond ncols multiply zero columns (harmless, branch-free)
+          const double bv = Yb[(kk + lk) * LDY + (cw * NTY + jt) * 16 + li];
+#pragma unroll
+          for (int i = 0; i < NTX; ++i) acc[i][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[i][jt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                               // final barrier
+    // ---- epilogue: scatter the tiles to their destination arrays (static accumulator indices only)
+#pragma unroll
+    for (int jt = 0; jt < NTY; ++jt) {
+      const int col = (cw * NTY + jt) * 16 + li;
+      const bool live = col < ncols;
+      const int g = live ? col / N : 0, jj = col - g * N;
+      const int ld = grp[g].ld;
+      double* dst = grp[g].dst + (long)s * grp[g].sstride + jj;
+      double* dst_t = grp[g].dst_t ? grp[g].dst_t + (long)s * grp[g].sstride + (long)jj * ld : nullptr;
+#pragma unroll
+      for (int i = 0; i < NTX; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i * 16 + lk + 4 * r;
+          const double val = acc[i][jt][r];
+          if (live && row < N) {
+            dst[(long)row * ld] = val;
+            if (dst_t) dst_t[row] = val;
+          }
         }
       }
     }
   }
-  if (do_rhs) {   // fixed-order sum over the EC staging waves
-    red[wave * 64 + lane] = rhs_part;
+  if (a.rhs_red != nullptr && blockIdx.y == 0) {   // fixed-order sum over the EC producer waves
     __syncthreads();
     if (tid < N) {
       double sum = 0.0;
@@ -854,7 +904,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     for (int q2 = 0; q2 < Q; ++q2)
       groups.push_back({G_AB, q, q2, C, G_ab + (long)q * S * N * C + 2 * QN + q2 * N, nullptr, (long)N * C});
   {
-    constexpr int NTY = 4;                                   // 4 waves x 4 column tiles = 256 columns per slice
+    constexpr int NTY = 7;                                   // 4 consumer waves x 7 column tiles = 448 columns per slice
     const int per = std::min(F1_MAXG, (4 * NTY * 16) / N);
     const int ntx = (N + 15) / 16;
     const size_t ldsf1 = sizeof(int) * 6 * t.nT;
@@ -874,9 +924,9 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       const dim3 grid(S, nsl);
 #define LRBMS_F1(NTXV)                                                                                              \
   do {                                                                                                              \
-    if (Q == 1) hipLaunchKernelGGL((k_f1<NTXV, NTY, 1>), grid, dim3(256), ldsf1, st, t, a, gt[0], gt[1], gt[2]);      \
-    else if (Q == 2) hipLaunchKernelGGL((k_f1<NTXV, NTY, 2>), grid, dim3(256), ldsf1, st, t, a, gt[0], gt[1], gt[2]); \
-    else hipLaunchKernelGGL((k_f1<NTXV, NTY, 0>), grid, dim3(256), ldsf1, st, t, a, gt[0], gt[1], gt[2]);             \
+    if (Q == 1) hipLaunchKernelGGL((k_f1<NTXV, NTY, 1>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);      \
+    else if (Q == 2) hipLaunchKernelGGL((k_f1<NTXV, NTY, 2>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]); \
+    else hipLaunchKernelGGL((k_f1<NTXV, NTY, 0>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);             \
   } while (0)
       switch (ntx) {
         case 1: LRBMS_F1(1); break;
