@@ -49,6 +49,12 @@ int lrbms_ctx_create(int device, lrbms_ctx** out) {
   lrbms_ctx* ctx = new (std::nothrow) lrbms_ctx();
   if (!ctx) return LRBMS_E_INVALID;
   ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+    delete ctx;
+    return LRBMS_E_HIP;
+  }
   *out = ctx;
   return LRBMS_OK;
 }
@@ -57,6 +63,9 @@ int lrbms_ctx_destroy(lrbms_ctx* ctx) {
   if (!ctx) return LRBMS_E_INVALID;
   (void)hipSetDevice(ctx->device);
   free_owned(ctx);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
   return LRBMS_OK;
 }

@@ -661,69 +661,131 @@ __global__ __launch_bounds__(256) void k_f3(Tmpl t, F3Args a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // Thin part of G_nc: workgroup (side a, subdomain s) writes block-row a (all 5 column blocks) and block [self, a].
-// K runs over the 3 * ntouch rows of the elements with a vertex on side a.
-template <int NMAX>
-__global__ __launch_bounds__(256) void k_thin_nc(Tmpl t, int S, const int* __restrict__ nbr, int N,
+// K runs over the 3 * ntouch rows of the elements with a vertex on side a.  The two dense blocks [a, self] and
+// [a, a] are one small MFMA product  Wa^T [E Ws | E Wa]  (K = 3 ntouch, padded to a multiple of 4); the blocks
+// towards the other sides only see the corner elements and are done on the VALU.
+template <int NTX>
+__global__ __launch_bounds__(512) void k_thin_nc(Tmpl t, int S, const int* __restrict__ nbr, int N,
                                                  const double* __restrict__ V, const double* __restrict__ ebar,
                                                  const double* __restrict__ AvgSelf, const double* __restrict__ AvgSide,
                                                  double* __restrict__ G_nc) {
-  extern __shared__ double lds[];   // Wa [3 * ntouch][NMAX] (zero padded), then the transposed [self, a] block [N][N + 1]
+  constexpr int NMAX = 16 * NTX;
+  constexpr int LDA = padded_ld(NTX);
+  constexpr int NT2 = 2 * NTX;                  // column tiles of [self | a] (each block padded to NTX tiles)
+  constexpr int LDB = padded_ld(NT2);
+  constexpr int NW = 8;                         // waves per workgroup
+  constexpr int NACC = (NTX * NT2 + NW - 1) / NW;
+  extern __shared__ double lds[];               // Wa [KP][LDA], Yc [KP][LDB]
   const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
+  const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = uniform(tid >> 6);
   const int W = 5 * N;
   double* G = G_nc + (long)s * W * W;
   const int s2 = nbr[s * 5 + slot];
   if (s2 < 0) {   // no neighbour: the whole block-row and the [self, a] block are zero
-    for (int i = tid; i < N * W; i += 256) G[(long)(slot * N + i / W) * W + i % W] = 0.0;
-    for (int i = tid; i < N * N; i += 256) G[(long)(2 * N + i / N) * W + slot * N + i % N] = 0.0;
+    for (int i = tid; i < N * W; i += 512) G[(long)(slot * N + i / W) * W + i % W] = 0.0;
+    for (int i = tid; i < N * N; i += 512) G[(long)(2 * N + i / N) * W + slot * N + i % N] = 0.0;
     return;
   }
   const int ne = t.touch_count[side];
+  const int KP = (3 * t.ntouch + 3) & ~3;
   double* Wa = lds;
-  double* Tr = lds + 3 * t.ntouch * NMAX;
-  // phase 1: Wa rows (image of the neighbour's basis on the touching elements), padded with zero columns so that
-  // the inner products of phase 2 are branch-free
-  for (int it = tid; it < ne * NMAX; it += 256) {
-    const int p = it / NMAX, j = it - p * NMAX;
-    double w[3] = {0.0, 0.0, 0.0};
-    if (j < N) oswald_rows(t, s, t.touch_elem[side * t.ntouch + p], slot, N, j, V, AvgSelf, AvgSide, w);
-    for (int i = 0; i < 3; ++i) Wa[(3 * p + i) * NMAX + j] = w[i];
+  double* Yc = lds + KP * LDA;
+  __shared__ int side_mask[256];                // per touching element: which sides its vertices lie on
+  for (int i = tid; i < KP * LDA; i += 512) Wa[i] = 0.0;
+  for (int i = tid; i < KP * LDB; i += 512) Yc[i] = 0.0;
+  for (int p = tid; p < ne && p < 256; p += 512) {
+    const int T = t.touch_elem[side * t.ntouch + p];
+    int m = 0;
+    for (int i = 0; i < 3; ++i) {
+      const int v = t.dof_vertex[3 * T + i], lx = v % t.nvx, ly = v / t.nvx;
+      m |= (ly == 0 ? 1 : 0) | (lx == 0 ? 2 : 0) | (lx == t.nvx - 1 ? 4 : 0) | (ly == t.nvy - 1 ? 8 : 0);
+    }
+    side_mask[p] = m;
   }
   __syncthreads();
-  // phase 2: thread <-> output column c = (slot2, j); accumulators over the N rows of block-row a
-  for (int c = tid; c < W; c += 256) {
-    const int slot2 = c / N, j = c - slot2 * N;
-    double acc[NMAX];
+  // phase 1: rows of the touching elements: Wa (neighbour image), and E applied to the own / neighbour image
+  for (int it = tid; it < ne * N; it += 512) {
+    const int p = it / N, j = it - p * N;
+    const int T = t.touch_elem[side * t.ntouch + p];
+    double wa[3], ws[3], K[9];
+    oswald_rows(t, s, T, slot, N, j, V, AvgSelf, AvgSide, wa);
+    oswald_rows(t, s, T, 2, N, j, V, AvgSelf, AvgSide, ws);
+    stiffness3(t, T, K);
+    const double eb = ebar[(long)s * t.nT + T];
+    for (int k = 0; k < 3; ++k) {
+      Wa[(3 * p + k) * LDA + j] = wa[k];
+      Yc[(3 * p + k) * LDB + j] = eb * (K[k * 3] * ws[0] + K[k * 3 + 1] * ws[1] + K[k * 3 + 2] * ws[2]);
+      Yc[(3 * p + k) * LDB + NMAX + j] = eb * (K[k * 3] * wa[0] + K[k * 3 + 1] * wa[1] + K[k * 3 + 2] * wa[2]);
+    }
+  }
+  __syncthreads();
+  // phase 2: MFMA, tiles dealt round-robin to the 8 waves
+  d4 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < NMAX; ++i) acc[i] = 0.0;
-    const int sx = slot2 == 2 ? s : nbr[s * 5 + slot2];
+  for (int k = 0; k < NACC; ++k) acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < KP; kk += 4) {
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+      const int tile = wave + NW * k;
+      if (tile < NTX * NT2) {
+        const int ti = tile / NT2, tj = tile - ti * NT2;
+        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wa[(kk + lk) * LDA + ti * 16 + li], Yc[(kk + lk) * LDB + tj * 16 + li], acc[k], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    const int tile = wave + NW * k;
+    const int ti = tile / NT2, tj = tile - ti * NT2;
+    const int col = tj * 16 + li;                       // < NMAX: block [a, self]; >= NMAX: block [a, a]
+    const int jj = col < NMAX ? col : col - NMAX;
+    const int cslot = col < NMAX ? 2 : slot;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = ti * 16 + lk + 4 * r;
+      const double val = acc[k][r];
+      if (tile < NTX * NT2 && jj < N && row < N) {
+        G[(long)(slot * N + row) * W + cslot * N + jj] = val;
+        if (cslot == 2) G[(long)(2 * N + jj) * W + slot * N + row] = val;   // [self, a] = [a, self]^T
+      }
+    }
+  }
+  // phase 3: blocks [a, b] towards the other sides b (only elements touching both sides contribute; usually zero)
+  for (int c = tid; c < 3 * N; c += 512) {
+    const int which = c / N, j = c - which * N;       // which-th slot of {0, 1, 3, 4} without `slot`
+    int slot2 = -1, seen = 0;
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl) {
+      if (sl == 2 || sl == slot) continue;
+      if (seen == which) slot2 = sl;
+      ++seen;
+    }
+    double accv[NMAX];
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) accv[i] = 0.0;
+    const int sx = nbr[s * 5 + slot2];
     if (sx >= 0) {
+      const int bit2 = 1 << slot_to_side(slot2);
       for (int p = 0; p < ne; ++p) {
+        if (!(side_mask[p] & bit2)) continue;      // only elements that also touch side b contribute
         const int T = t.touch_elem[side * t.ntouch + p];
         double w[3];
         oswald_rows(t, s, T, slot2, N, j, V, AvgSelf, AvgSide, w);
-        if (w[0] == 0.0 && w[1] == 0.0 && w[2] == 0.0) continue;
         double K[9];
         stiffness3(t, T, K);
         const double eb = ebar[(long)s * t.nT + T];
         for (int k = 0; k < 3; ++k) {
           const double y = eb * (K[k * 3] * w[0] + K[k * 3 + 1] * w[1] + K[k * 3 + 2] * w[2]);
-          const double* wa = Wa + (3 * p + k) * NMAX;
+          const double* wa = Wa + (3 * p + k) * LDA;
 #pragma unroll
-          for (int i = 0; i < NMAX; ++i) acc[i] += wa[i] * y;
+          for (int i = 0; i < NMAX; ++i) accv[i] += wa[i] * y;
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < NMAX; ++i)
-      if (i < N) {
-        G[(long)(slot * N + i) * W + c] = acc[i];
-        if (slot2 == 2) Tr[j * (N + 1) + i] = acc[i];   // [self, a] = [a, self]^T, staged for a coalesced store
-      }
-  }
-  __syncthreads();
-  for (int it = tid; it < N * N; it += 256) {
-    const int j = it / N, i = it - j * N;
-    G[(long)(2 * N + j) * W + slot * N + i] = Tr[j * (N + 1) + i];
+      if (i < N) G[(long)(slot * N + i) * W + slot2 * N + j] = accv[i];
   }
 }
 
@@ -865,8 +927,11 @@ int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N) {
 
 bool fused_supported(lrbms_ctx* ctx, int Q, int N) {
   const Tmpl& t = ctx->t;
-  if (N > 64 || Q > 4 || Q * N > 128 || t.nT % 8 != 0 || t.nT > 1024) return false;
-  if ((size_t)(3 * t.ntouch * 64 + N * (N + 1)) * sizeof(double) > 64 * 1024) return false;
+  if (N > 64 || Q > 4 || Q * N > 128 || t.nT % 8 != 0 || t.nT > 1024 || t.ntouch > 256) return false;
+  {
+    const int ntx = (N + 15) / 16;
+    if ((size_t)((3 * t.ntouch + 3) & ~3) * (padded_ld(ntx) + padded_ld(2 * ntx)) * sizeof(double) > 64 * 1024) return false;
+  }
   if ((size_t)(3 * t.ncf * Q * N + Q * t.ncf * N + 3 * t.ncf) * sizeof(double) > 64 * 1024) return false;
   if ((size_t)2 * 3 * t.ncf * N * sizeof(double) > 64 * 1024) return false;
   return true;
@@ -890,7 +955,31 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   hipLaunchKernelGGL(k_vertex_avg, dim3(grid_for((long)S * t.nv * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide);
   LRBMS_LAUNCH_CHECK(ctx);
   (void)nvs;
+  // fork: the thin kernels (HBM-write / latency bound, few registers) go to the library's side stream so that they
+  // share the CUs with the MFMA kernels of the main stream; joined before returning control to the caller's stream
+  hipStream_t side = getenv("LRBMS_OVERLAP") ? ctx->side : st;   // measured: no gain for this kernel mix, off by default
+  if (side != st) {
+    LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
+    LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
+  }
 
+  // ---- thin parts
+  {
+    const int ntx = (N + 15) / 16;
+    const int kp = (3 * t.ntouch + 3) & ~3;
+    const size_t lds = sizeof(double) * (size_t)kp * (padded_ld(ntx) + padded_ld(2 * ntx));
+    switch (ntx) {
+      case 1: hipLaunchKernelGGL(k_thin_nc<1>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
+      case 2: hipLaunchKernelGGL(k_thin_nc<2>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
+      case 3: hipLaunchKernelGGL(k_thin_nc<3>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
+      default: hipLaunchKernelGGL(k_thin_nc<4>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
+    }
+    LRBMS_LAUNCH_CHECK(ctx);
+    ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, G_bb, G_rdd, G_ab, r_fd, Q, N, S};
+    const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf);
+    hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, side, t, a);
+    LRBMS_LAUNCH_CHECK(ctx);
+  }
   // ---- F1: build the column-group list and launch in slices of at most F1_YW / N groups
   std::vector<Grp> groups;
   for (int q = 0; q < Q; ++q) groups.push_back({G_SYS, q, 0, N, B_sys + ((long)q * S * 5 + 2) * N * N, nullptr, (long)5 * N * N});
@@ -967,19 +1056,13 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
-  // ---- thin parts
   {
-    const int nmax = N <= 16 ? 16 : N <= 32 ? 32 : N <= 48 ? 48 : 64;
-    const size_t lds = sizeof(double) * (3 * t.ntouch * nmax + N * (N + 1));
-    if (N <= 16) hipLaunchKernelGGL(k_thin_nc<16>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);
-    else if (N <= 32) hipLaunchKernelGGL(k_thin_nc<32>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);
-    else if (N <= 48) hipLaunchKernelGGL(k_thin_nc<48>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);
-    else hipLaunchKernelGGL(k_thin_nc<64>, dim3(4, S), dim3(256), lds, st, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);
-    LRBMS_LAUNCH_CHECK(ctx);
-    ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, G_bb, G_rdd, G_ab, r_fd, Q, N, S};
-    const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf);
-    hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, st, t, a);
-    LRBMS_LAUNCH_CHECK(ctx);
+    const int rc = launch_project_coupling(ctx, Q, N, V, A_cpl, B_sys, st);
+    if (rc) return rc;
   }
-  return launch_project_coupling(ctx, Q, N, V, A_cpl, B_sys, st);
+  if (side != st) {
+    LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, side));
+    LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+  }
+  return LRBMS_OK;
 }
