@@ -49,7 +49,9 @@ int lrbms_ctx_create(int device, lrbms_ctx** out) {
   lrbms_ctx* ctx = new (std::nothrow) lrbms_ctx();
   if (!ctx) return LRBMS_E_INVALID;
   ctx->device = device;
-  if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // lowest priority: the side work only fills idle resources
+  if (hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_lo) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete ctx;

@@ -44,6 +44,10 @@ __host__ __device__ constexpr int padded_ld(int tiles) { return (tiles * 16) % 3
 
 __device__ inline int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. it waits for every
+// global load in flight -- which would serialise the register prefetch of the next chunk behind each barrier.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ inline void stiffness3(const Tmpl& t, int e, double K[9]) {
   for (int i = 0; i < 3; ++i) {
     const double gx = t.grad[(e * 3 + i) * 2], gy = t.grad[(e * 3 + i) * 2 + 1];
@@ -301,21 +305,24 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     for (int f = 0; f < 3; ++f)
 #pragma unroll
       for (int q2 = 0; q2 < QR; ++q2) rv[f][q2] = nrv[f][q2] = 0.0;
+    double npre[PRE];
     fetch(wave, pre);
     load_rows(wave, vb, rv);
     double rhs_part = 0.0;
-    for (int c = 0; c < nchunks; ++c) {
+    // one pipeline step over (current, next) register sets; the sets alternate (loop unrolled by two, no copies)
+    auto step = [&](int c, const double (&pre)[PRE], const double (&vb)[4][3], const double (&rv)[3][QR],
+                    double (&npre)[PRE], double (&nvb)[4][3], double (&nrv)[3][QR]) {
       const int T = c * EC + wave;                 // wave-uniform element
       double* Xb = &Xs[c & 1][0];
       double* Yb = &Ys[c & 1][0];
 #pragma unroll
       for (int k = 0; k < PRE; ++k)                // this wave's element blocks -> its private LDS record
         if (fsrc[k]) Ee[lane + 64 * k] = pre[k];
-      if (c + 1 < nchunks && !(a.dbg & 8)) {       // next chunk's loads, in flight during this staging
-        fetch(T + EC, pre);
+      if (c + 1 < nchunks) {                       // next chunk's loads: in flight during this staging AND the barrier
+        fetch(T + EC, npre);
         load_rows(T + EC, nvb, nrv);
       }
-      if (colj && !(a.dbg & 4)) {
+      if (colj) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) Xb[(3 * wave + i) * LDX + j] = vb[0][i];
         if (do_rhs) {
@@ -373,17 +380,10 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
             }
           }
         } else
-        for (int g = 0; g < ((a.dbg & 1) ? 0 : ng); ++g) {
+        for (int g = 0; g < ng; ++g) {
           const int kind = uniform(grp[g].kind), q = uniform(grp[g].q), q2 = uniform(grp[g].q2);
           double y[3] = {0, 0, 0};
-          if ((kind == G_SYS || kind == G_ENERGY) && (a.dbg & 16)) {   // timing experiment: same FMAs, no LDS operand reads
-            const double c1 = 1.25 + q, c2 = 0.75, c3 = -0.5;
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-              for (int i = 0; i < 3; ++i)
-                y[i] += (c1 + bb) * vb[bb][0] + (c2 + i) * vb[bb][1] + (c3 - bb) * vb[bb][2];
-          } else if (kind == G_SYS || kind == G_ENERGY) {
+          if (kind == G_SYS || kind == G_ENERGY) {
             const double* blk = Ee + (kind == G_SYS ? 36 * q : oP);
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb)
@@ -420,17 +420,13 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
           for (int i = 0; i < 3; ++i) Yb[(3 * wave + i) * LDY + g * N + j] = y[i];
         }
       }
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) vb[bb][i] = nvb[bb][i];
-#pragma unroll
-      for (int f = 0; f < 3; ++f)
-#pragma unroll
-        for (int q2 = 0; q2 < QR; ++q2) rv[f][q2] = nrv[f][q2];
-      __syncthreads();                             // barrier c: buffer c & 1 is complete
+      lds_barrier();                               // barrier c: buffer c & 1 is complete (global loads stay in flight)
+    };
+    for (int c = 0; c < nchunks; c += 2) {         // nT is a multiple of 8, so nchunks is even
+      step(c, pre, vb, rv, npre, nvb, nrv);
+      step(c + 1, npre, nvb, nrv, pre, vb, rv);
     }
-    __syncthreads();                               // final barrier (matches the consumers' count)
+    lds_barrier();                                 // final barrier (matches the consumers' count)
     if (do_rhs) red[wave * 64 + lane] = rhs_part;
   } else {
     // ================================================= consumers
@@ -441,10 +437,9 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
 #pragma unroll
       for (int jj = 0; jj < NTY; ++jj) acc[i][jj] = (d4){0.0, 0.0, 0.0, 0.0};
     for (int c = 0; c < nchunks; ++c) {
-      __syncthreads();                             // barrier c
+      lds_barrier();                               // barrier c
       const double* Xb = &Xs[c & 1][0];
       const double* Yb = &Ys[c & 1][0];
-      if (!(a.dbg & 2))
 #pragma unroll
       for (int kk = 0; kk < 3 * EC; kk += 4) {
         double av[NTX];
@@ -458,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
         }
       }
     }
-    __syncthreads();                               // final barrier
+    lds_barrier();                                 // final barrier
     // ---- epilogue: scatter the tiles to their destination arrays (static accumulator indices only)
 #pragma unroll
     for (int jt = 0; jt < NTY; ++jt) {
@@ -502,16 +497,18 @@ struct F2Args {
   int Q, N, S;
 };
 
+// Same producer / consumer structure as k_f1: waves 0-3 stage the face rows R~_T, B_T R~_T, d_T, |T| d_T of element
+// 4 c + w into LDS buffer c & 1 (global loads of chunk c + 1 in flight), waves 4 .. 4 + NR - 1 own one column tile each
+// of the (Q N)-wide self blocks of G_bb and G_rdd (NR row tiles).  One barrier per chunk.
 template <int NR>
-__global__ __launch_bounds__(64 * NR) void k_f2(Tmpl t, F2Args a) {
+__global__ __launch_bounds__(64 * (NR + EC)) void k_f2(Tmpl t, F2Args a) {
   constexpr int LD = padded_ld(NR);
-  constexpr int E2 = 8;                       // elements per chunk: 24 face rows (6 k-steps) + 8 divergence rows (2 k-steps)
   extern __shared__ double dyn[];             // per-element scalars cached once: coef [nT][3], bsum [nT], rt [nT][3] (int)
-  __shared__ double Xb[3 * E2 * LD], Yb[3 * E2 * LD], Xd[E2 * LD], Yd[E2 * LD];
-  __shared__ double red[8 * 128];
+  __shared__ double Xb[2][3 * EC * LD], Yb[2][3 * EC * LD], Xd[2][EC * LD], Yd[2][EC * LD];
+  __shared__ double red[EC * 128];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
-  const int nthreads = 64 * NR;
+  const int nthreads = 64 * (NR + EC);
   const int QN = a.Q * a.N, C = 5 * QN;
   double* coefs = dyn;
   double* bsums = dyn + 3 * t.nT;
@@ -526,78 +523,119 @@ __global__ __launch_bounds__(64 * NR) void k_f2(Tmpl t, F2Args a) {
     const double* be = a.b + (long)s * t.n + 3 * T;
     bsums[T] = be[0] + be[1] + be[2];
   }
-  for (int i = tid; i < 3 * E2 * LD; i += nthreads) Xb[i] = Yb[i] = 0.0;
-  for (int i = tid; i < E2 * LD; i += nthreads) Xd[i] = Yd[i] = 0.0;
-  for (int i = tid; i < 8 * 128; i += nthreads) red[i] = 0.0;
+  for (int i = tid; i < 2 * 3 * EC * LD; i += nthreads) (&Xb[0][0])[i] = (&Yb[0][0])[i] = 0.0;
+  for (int i = tid; i < 2 * EC * LD; i += nthreads) (&Xd[0][0])[i] = (&Yd[0][0])[i] = 0.0;
+  for (int i = tid; i < EC * 128; i += nthreads) red[i] = 0.0;
   __syncthreads();
-  d4 accb[NR], accd[NR];
-#pragma unroll
-  for (int i = 0; i < NR; ++i) accb[i] = accd[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int nchunks = t.nT / EC;
   const double* Rs = a.Rself + (long)s * t.nrt * QN;
-  double rfd_part[2] = {0.0, 0.0};   // columns lane and lane + 64 (QN <= 128)
-  for (int c0 = 0; c0 < t.nT; c0 += E2) {
-    for (int el = wave; el < E2; el += NR) {     // wave-uniform element(s)
-      const int T = c0 + el;
-      const double c0f = coefs[3 * T], c1f = coefs[3 * T + 1], c2f = coefs[3 * T + 2];
+
+  if (wave < EC) {
+    // ================================================= producers
+    double rv[2][3], nrv[2][3], Bv[9], nBv[9];
+    auto load = [&](int T, double (&r)[2][3], double (&B)[9]) {
       const int r0 = rts[3 * T], r1 = rts[3 * T + 1], r2 = rts[3 * T + 2];
-      const double* B = a.Bbb + ((long)s * t.nT + T) * 9;
-      const double bsum = bsums[T], area = t.area[T];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int c = lane + 64 * k;
         if (c < QN) {
-          const double rv0 = Rs[(long)r0 * QN + c], rv1 = Rs[(long)r1 * QN + c], rv2 = Rs[(long)r2 * QN + c];
-          Xb[(3 * el) * LD + c] = rv0;
-          Xb[(3 * el + 1) * LD + c] = rv1;
-          Xb[(3 * el + 2) * LD + c] = rv2;
-          Yb[(3 * el) * LD + c] = B[0] * rv0 + B[1] * rv1 + B[2] * rv2;
-          Yb[(3 * el + 1) * LD + c] = B[3] * rv0 + B[4] * rv1 + B[5] * rv2;
-          Yb[(3 * el + 2) * LD + c] = B[6] * rv0 + B[7] * rv1 + B[8] * rv2;
+          r[k][0] = Rs[(long)r0 * QN + c];
+          r[k][1] = Rs[(long)r1 * QN + c];
+          r[k][2] = Rs[(long)r2 * QN + c];
+        } else {
+          r[k][0] = r[k][1] = r[k][2] = 0.0;
+        }
+      }
+      const double* Bp = a.Bbb + ((long)s * t.nT + T) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) B[i] = Bp[i];
+    };
+    load(wave, rv, Bv);
+    double rfd_part[2] = {0.0, 0.0};   // columns lane and lane + 64 (QN <= 128)
+    // One pipeline step: issue the loads of chunk c + 1 into the OTHER register set, stage chunk c from this one.
+    // The two sets alternate (loop unrolled by two, no register copies), so the wait for a load lands at its first
+    // use one step later and the L2 / HBM latency hides behind a full staging step plus the barrier.
+    auto step = [&](int c, const double (&cr)[2][3], const double (&cB)[9], double (&nr)[2][3], double (&nB)[9]) {
+      const int T = c * EC + wave, el = wave;
+      if (c + 1 < nchunks) load(T + EC, nr, nB);
+      double* xb = &Xb[c & 1][0];
+      double* yb = &Yb[c & 1][0];
+      double* xd = &Xd[c & 1][0];
+      double* yd = &Yd[c & 1][0];
+      const double c0f = coefs[3 * T], c1f = coefs[3 * T + 1], c2f = coefs[3 * T + 2];
+      const double bsum = bsums[T], area = t.area[T];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int cc = lane + 64 * k;
+        if (cc < QN) {
+          const double rv0 = cr[k][0], rv1 = cr[k][1], rv2 = cr[k][2];
+          xb[(3 * el) * LD + cc] = rv0;
+          xb[(3 * el + 1) * LD + cc] = rv1;
+          xb[(3 * el + 2) * LD + cc] = rv2;
+          yb[(3 * el) * LD + cc] = cB[0] * rv0 + cB[1] * rv1 + cB[2] * rv2;
+          yb[(3 * el + 1) * LD + cc] = cB[3] * rv0 + cB[4] * rv1 + cB[5] * rv2;
+          yb[(3 * el + 2) * LD + cc] = cB[6] * rv0 + cB[7] * rv1 + cB[8] * rv2;
           const double d = c0f * rv0 + c1f * rv1 + c2f * rv2;
-          Xd[el * LD + c] = d;
-          Yd[el * LD + c] = area * d;
+          xd[el * LD + cc] = d;
+          yd[el * LD + cc] = area * d;
           rfd_part[k] += bsum * d;
         }
       }
+      lds_barrier();                               // barrier c: buffer c & 1 complete (loads stay in flight)
+    };
+    for (int c = 0; c < nchunks; c += 2) {         // nT is a multiple of 8, so nchunks is even
+      step(c, rv, Bv, nrv, nBv);
+      step(c + 1, nrv, nBv, rv, Bv);
     }
-    __syncthreads();
-    const int ct = wave;   // this wave's column tile
+    lds_barrier();                                 // final barrier
+    red[wave * 128 + lane] = rfd_part[0];
+    red[wave * 128 + 64 + lane] = rfd_part[1];
+  } else {
+    // ================================================= consumers
+    const int ct = wave - EC;                      // this wave's column tile
+    d4 accb[NR], accd[NR];
 #pragma unroll
-    for (int kk = 0; kk < 3 * E2; kk += 4) {
-      const double bv = Yb[(kk + lk) * LD + ct * 16 + li];
+    for (int i = 0; i < NR; ++i) accb[i] = accd[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < nchunks; ++c) {
+      lds_barrier();                               // barrier c
+      const double* xb = &Xb[c & 1][0];
+      const double* yb = &Yb[c & 1][0];
+      const double* xd = &Xd[c & 1][0];
+      const double* yd = &Yd[c & 1][0];
 #pragma unroll
-      for (int i = 0; i < NR; ++i) accb[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xb[(kk + lk) * LD + i * 16 + li], bv, accb[i], 0, 0, 0);
+      for (int kk = 0; kk < 3 * EC; kk += 4) {
+        const double bv = yb[(kk + lk) * LD + ct * 16 + li];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) accb[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[(kk + lk) * LD + i * 16 + li], bv, accb[i], 0, 0, 0);
+      }
+      {
+        const double bv = yd[lk * LD + ct * 16 + li];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) accd[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[lk * LD + i * 16 + li], bv, accd[i], 0, 0, 0);
+      }
     }
+    lds_barrier();                                 // final barrier
+    const int col = ct * 16 + li;
+    double* gb = a.G_bb + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
+    double* gd = a.G_rdd + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
 #pragma unroll
-    for (int kk = 0; kk < E2; kk += 4) {
-      const double bv = Yd[(kk + lk) * LD + ct * 16 + li];
+    for (int i = 0; i < NR; ++i) {
 #pragma unroll
-      for (int i = 0; i < NR; ++i) accd[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xd[(kk + lk) * LD + i * 16 + li], bv, accd[i], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  const int col = wave * 16 + li;
-  double* gb = a.G_bb + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
-  double* gd = a.G_rdd + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
-#pragma unroll
-  for (int i = 0; i < NR; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = i * 16 + lk + 4 * r;
-      const double vb = accb[i][r], vd = accd[i][r];
-      if (col < QN && row < QN) {
-        gb[(long)row * C] = vb;
-        gd[(long)row * C] = vd;
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + lk + 4 * r;
+        const double vb = accb[i][r], vd = accd[i][r];
+        if (col < QN && row < QN) {
+          gb[(long)row * C] = vb;
+          gd[(long)row * C] = vd;
+        }
       }
     }
   }
-  // r_fd self block: fixed-order sum over the staging waves
-  red[wave * 128 + lane] = rfd_part[0];
-  red[wave * 128 + 64 + lane] = rfd_part[1];
+  // r_fd self block: fixed-order sum over the EC producer waves
   __syncthreads();
   for (int c = tid; c < QN; c += nthreads) {
     double sum = 0.0;
-    for (int w = 0; w < NR; ++w) sum += red[w * 128 + c];
+    for (int w = 0; w < EC; ++w) sum += red[w * 128 + c];
     a.r_fd[(long)s * C + 2 * QN + c] = sum;
   }
 }
@@ -865,7 +903,47 @@ __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
     Xab[it] = x;
   }
   __syncthreads();
-  // block-row a of G_bb / G_rdd (QN x C): consecutive threads on consecutive columns
+  // block-row a of G_bb / G_rdd (QN x C): consecutive threads on consecutive columns.  With an even QN every row
+  // segment is 16-byte aligned and the kernel -- which is bound by its 2 x QN x C doubles of stores -- writes
+  // double2 per lane: zero blocks as pure stores, the two non-zero blocks with two columns per thread.
+  if ((QN & 1) == 0) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int hq = QN / 2;
+    for (int it = tid; it < QN * 3 * hq; it += 256) {          // the three zero column blocks
+      const int row = it / (3 * hq), rem = it - row * 3 * hq, which = rem / hq, cc = 2 * (rem - which * hq);
+      int cslot = -1, seen = 0;
+#pragma unroll
+      for (int sl = 0; sl < 5; ++sl) {
+        if (sl == 2 || sl == slot) continue;
+        if (seen == which) cslot = sl;
+        ++seen;
+      }
+      const long off = (long)(slot * QN + row) * C + cslot * QN + cc;
+      *reinterpret_cast<d2*>(Gb + off) = (d2){0.0, 0.0};
+      *reinterpret_cast<d2*>(Gd + off) = (d2){0.0, 0.0};
+    }
+    for (int it = tid; it < QN * 2 * hq; it += 256) {          // blocks [a, a] and [a, self]
+      const int row = it / (2 * hq), rem = it - row * 2 * hq, which = rem / hq, cc = 2 * (rem - which * hq);
+      d2 vb = {0.0, 0.0}, vd = {0.0, 0.0};
+      if (which == 0) {
+        for (int p = 0; p < np; ++p) {
+          const double ra = Ra[p * QN + row];
+          const d2 rc = *reinterpret_cast<const d2*>(Ra + p * QN + cc);
+          vb += (sc[p * 3] * ra) * rc;
+          vd += (sc[p * 3 + 1] * ra) * rc;
+        }
+      } else {
+        for (int p = 0; p < np; ++p) {
+          const double ra = Ra[p * QN + row];
+          vb += ra * *reinterpret_cast<const d2*>(Yb + p * QN + cc);
+          vd += ra * *reinterpret_cast<const d2*>(Dp + p * QN + cc);
+        }
+      }
+      const long off = (long)(slot * QN + row) * C + (which == 0 ? slot : 2) * QN + cc;
+      *reinterpret_cast<d2*>(Gb + off) = vb;
+      *reinterpret_cast<d2*>(Gd + off) = vd;
+    }
+  } else
   for (long it = tid; it < (long)QN * C; it += 256) {
     const int row = (int)(it / C), col = (int)(it - (long)row * C);
     const int cslot = col / QN, cc = col - cslot * QN;
@@ -963,23 +1041,6 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
   }
 
-  // ---- thin parts
-  {
-    const int ntx = (N + 15) / 16;
-    const int kp = (3 * t.ntouch + 3) & ~3;
-    const size_t lds = sizeof(double) * (size_t)kp * (padded_ld(ntx) + padded_ld(2 * ntx));
-    switch (ntx) {
-      case 1: hipLaunchKernelGGL(k_thin_nc<1>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
-      case 2: hipLaunchKernelGGL(k_thin_nc<2>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
-      case 3: hipLaunchKernelGGL(k_thin_nc<3>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
-      default: hipLaunchKernelGGL(k_thin_nc<4>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
-    }
-    LRBMS_LAUNCH_CHECK(ctx);
-    ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, G_bb, G_rdd, G_ab, r_fd, Q, N, S};
-    const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf);
-    hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, side, t, a);
-    LRBMS_LAUNCH_CHECK(ctx);
-  }
   // ---- F1: build the column-group list and launch in slices of at most F1_YW / N groups
   std::vector<Grp> groups;
   for (int q = 0; q < Q; ++q) groups.push_back({G_SYS, q, 0, N, B_sys + ((long)q * S * 5 + 2) * N * N, nullptr, (long)5 * N * N});
@@ -1027,20 +1088,37 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       LRBMS_LAUNCH_CHECK(ctx);
     }
   }
+  // ---- thin parts
+  {
+    const int ntx = (N + 15) / 16;
+    const int kp = (3 * t.ntouch + 3) & ~3;
+    const size_t lds = sizeof(double) * (size_t)kp * (padded_ld(ntx) + padded_ld(2 * ntx));
+    switch (ntx) {
+      case 1: hipLaunchKernelGGL(k_thin_nc<1>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
+      case 2: hipLaunchKernelGGL(k_thin_nc<2>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
+      case 3: hipLaunchKernelGGL(k_thin_nc<3>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
+      default: hipLaunchKernelGGL(k_thin_nc<4>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
+    }
+    LRBMS_LAUNCH_CHECK(ctx);
+    ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, G_bb, G_rdd, G_ab, r_fd, Q, N, S};
+    const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf);
+    hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, side, t, a);
+    LRBMS_LAUNCH_CHECK(ctx);
+  }
   // ---- F2
   {
     F2Args a{Rself, Bbb, b, ctx->nbr, G_bb, G_rdd, r_fd, Q, N, S};
     const int nr = (QN + 15) / 16;
     const size_t ldsf2 = sizeof(double) * 4 * t.nT + sizeof(int) * 3 * t.nT;
     switch (nr) {
-      case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(64), ldsf2, st, t, a); break;
-      case 2: hipLaunchKernelGGL(k_f2<2>, dim3(S), dim3(128), ldsf2, st, t, a); break;
-      case 3: hipLaunchKernelGGL(k_f2<3>, dim3(S), dim3(192), ldsf2, st, t, a); break;
-      case 4: hipLaunchKernelGGL(k_f2<4>, dim3(S), dim3(256), ldsf2, st, t, a); break;
-      case 5: hipLaunchKernelGGL(k_f2<5>, dim3(S), dim3(320), ldsf2, st, t, a); break;
-      case 6: hipLaunchKernelGGL(k_f2<6>, dim3(S), dim3(384), ldsf2, st, t, a); break;
-      case 7: hipLaunchKernelGGL(k_f2<7>, dim3(S), dim3(448), ldsf2, st, t, a); break;
-      default: hipLaunchKernelGGL(k_f2<8>, dim3(S), dim3(512), ldsf2, st, t, a); break;
+      case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(320), ldsf2, st, t, a); break;
+      case 2: hipLaunchKernelGGL(k_f2<2>, dim3(S), dim3(384), ldsf2, st, t, a); break;
+      case 3: hipLaunchKernelGGL(k_f2<3>, dim3(S), dim3(448), ldsf2, st, t, a); break;
+      case 4: hipLaunchKernelGGL(k_f2<4>, dim3(S), dim3(512), ldsf2, st, t, a); break;
+      case 5: hipLaunchKernelGGL(k_f2<5>, dim3(S), dim3(576), ldsf2, st, t, a); break;
+      case 6: hipLaunchKernelGGL(k_f2<6>, dim3(S), dim3(640), ldsf2, st, t, a); break;
+      case 7: hipLaunchKernelGGL(k_f2<7>, dim3(S), dim3(704), ldsf2, st, t, a); break;
+      default: hipLaunchKernelGGL(k_f2<8>, dim3(S), dim3(768), ldsf2, st, t, a); break;
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
