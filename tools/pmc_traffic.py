@@ -1,0 +1,31 @@
+"""Sum FETCH_SIZE / WRITE_SIZE (rocprofv3 --pmc, KiB units) over the kernels of the passes of bench.py.
+usage: pmc_traffic.py NUM_PASSES DIR [DIR...]"""
+import collections
+import csv
+import glob
+import re
+import sys
+
+passes = int(sys.argv[1])
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+calls = collections.Counter()
+for d in sys.argv[2:]:
+    f = glob.glob(d + '/*/*counter_collection.csv')[0]
+    for r in csv.DictReader(open(f)):
+        m = re.search(r'(k_[a-z0-9_]+)', r['Kernel_Name'])
+        k = m.group(1) if m else r['Kernel_Name'][:24]
+        if r['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            tot[k][r['Counter_Name']] += float(r['Counter_Value'])
+            calls[(k, r['Counter_Name'])] += 1
+print('{:24s} {:>6s} {:>18s} {:>18s}'.format('kernel', 'calls', 'FETCH_SIZE MiB/call', 'WRITE_SIZE MiB/call'))
+sf = sw = 0.0
+for k, v in sorted(tot.items()):
+    nf, nw = calls[(k, 'FETCH_SIZE')], calls[(k, 'WRITE_SIZE')]
+    f = v.get('FETCH_SIZE', 0.0) / nf / 1024 if nf else 0.0
+    w = v.get('WRITE_SIZE', 0.0) / nw / 1024 if nw else 0.0
+    print('{:24s} {:6d} {:18.1f} {:18.1f}'.format(k, max(nf, nw), f, w))
+    if k.startswith('k_') and not k.startswith('k_assemble'):
+        sf += v.get('FETCH_SIZE', 0.0) / 1024 / passes
+        sw += v.get('WRITE_SIZE', 0.0) / 1024 / passes
+print('per pass (hot-path kernels): FETCH_SIZE {:.1f} MiB (x2 correction for wide coalesced reads on gfx950: {:.1f} MiB), '
+      'WRITE_SIZE {:.1f} MiB'.format(sf, 2 * sf, sw))
