@@ -48,6 +48,9 @@ SIGNATURES = {
     'lrbms_reduced_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 9 + [c_dbl, c_vp, c_vp]),
     'lrbms_reduced_solve_work_size': (c_i64, [c_vp, c_i32]),
     'lrbms_reduced_solve': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
+    'lrbms_reduced_solve_batch_work_size': (c_i64, [c_vp, c_i32, c_i32]),
+    'lrbms_reduced_solve_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL,
+                                                 c_vp]),
     'lrbms_blockell_apply': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'lrbms_fom_apply': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'lrbms_gemm_tn': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp,
@@ -342,6 +345,25 @@ class NativeContext:
                                           self._ptr(rhs_red, (S, N), 'rhs_red'), c_vp(work.data_ptr()),
                                           c_vp(u.data_ptr()), float(rtol), int(max_iter), _dblp(info), self._stream())
         self._check(rc, 'lrbms_reduced_solve')
+        return u, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
+
+    def reduced_solve_batch(self, thetas, B_sys, rhs_red, rtol=1e-13, max_iter=20000, work=None):
+        """thetas [nmu, Q] -> u [S, N, nmu] (mu fastest), info."""
+        Q, S, N = B_sys.shape[0], self.S, B_sys.shape[3]
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        nmu = th.shape[0]
+        assert th.shape == (nmu, Q)
+        need = int(self.lib.lrbms_reduced_solve_batch_work_size(self.handle, N, nmu))
+        if work is None:
+            work = self.empty(need)
+        if work.numel() < need:
+            raise NativeError('reduced_solve_batch: work too small')
+        u = self.empty(S, N, nmu)
+        info = np.zeros(2)
+        rc = self.lib.lrbms_reduced_solve_batch(self.handle, Q, N, nmu, _dblp(th), self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'),
+                                                self._ptr(rhs_red, (S, N), 'rhs_red'), c_vp(work.data_ptr()),
+                                                c_vp(u.data_ptr()), float(rtol), int(max_iter), _dblp(info), self._stream())
+        self._check(rc, 'lrbms_reduced_solve_batch')
         return u, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
 
     # ------------------------------------------------------------------ helpers

@@ -6,6 +6,10 @@
 
 int64_t estimator_work_size(lrbms_ctx* ctx, int Q, int N);
 int64_t reduced_solve_work_size(lrbms_ctx* ctx, int N);
+int64_t reduced_solve_batch_work_size(lrbms_ctx* ctx, int N, int nmu);
+int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const double* theta, const double* B_sys,
+                               const double* rhs_red, double* work, double* u, double rtol, int max_iter, double* info,
+                               hipStream_t st);
 int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N);
 bool fused_supported(lrbms_ctx* ctx, int Q, int N);
 int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V, const double* F, const double* A_diag,
@@ -266,6 +270,19 @@ int lrbms_reduced_solve(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* thet
   LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red);
   CHECK_PTR(ctx, work); CHECK_PTR(ctx, u);
   return launch_reduced_solve(ctx, Q, N, theta, B_sys, rhs_red, work, u, rtol, max_iter, info, (hipStream_t)stream);
+}
+
+int64_t lrbms_reduced_solve_batch_work_size(lrbms_ctx* ctx, int32_t N, int32_t nmu) {
+  if (!ctx || !ctx->has_mesh || N < 1 || nmu < 1) return -1;
+  return reduced_solve_batch_work_size(ctx, N, nmu);
+}
+
+int lrbms_reduced_solve_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* B_sys,
+                              const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
+                              void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red);
+  CHECK_PTR(ctx, work); CHECK_PTR(ctx, u);
+  return launch_reduced_solve_batch(ctx, Q, N, nmu, theta, B_sys, rhs_red, work, u, rtol, max_iter, info, (hipStream_t)stream);
 }
 
 int lrbms_blockell_apply(lrbms_ctx* ctx, int32_t M, const double* A, const double* x, double* y, void* stream) {

@@ -159,3 +159,26 @@ def test_native_argument_checks_raise():
     buf = eng.project_and_estimate(eng.ctx.from_numpy(make_bases(eng.S, eng.t.n, 2, seed=1)))
     with pytest.raises(NativeError):                                      # LRBMS_E_NOT_CONVERGED surfaces as an error
         eng.ctx.reduced_solve(np.array([1.0, 0.5]), buf['sys'][0], buf['sys'][1], rtol=1e-30, max_iter=3)
+
+
+def test_batched_reduced_solve_matches_single_and_oracle():
+    """O1 throughput form: 6 parameters in one batched PCG == 6 single solves == oracle dense solves."""
+    from pylrbms_amd import multiscale_problem
+    from oracle.lrbms import OracleReductor
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': [4, 3], 'coarse_per_subdomain': 2})
+    eng = _engine(p)
+    d = oracle_from_problem(p)
+    N = 6
+    V = energy_orthonormalize(make_bases(d.S, d.n, N, seed=9), d)
+    buf = eng.project_and_estimate(eng.ctx.from_numpy(V))
+    mus = [0.1, 0.25, 0.4, 0.55, 0.8, 1.0]
+    thetas = np.stack([theta_of(p, mu) for mu in mus])
+    ub, info = eng.ctx.reduced_solve_batch(thetas, buf['sys'][0], buf['sys'][1])
+    assert info['iterations'] > 0 and info['relative_residual'] <= 1e-13
+    ub = ub.cpu().numpy()
+    rd = OracleReductor(d, [V[ii] for ii in range(d.S)]).reduce()
+    for m, mu in enumerate(mus):
+        us, _ = eng.reduced_solve(thetas[m], buf['sys'][0], buf['sys'][1])
+        ref = np.stack(rd.solve(mu))
+        assert np.linalg.norm(ub[:, :, m] - ref) < 1e-10 * np.linalg.norm(ref)
+        assert np.linalg.norm(us.cpu().numpy() - ref) < 1e-10 * np.linalg.norm(ref)
