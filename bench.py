@@ -116,6 +116,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='cfg3', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-online', action='store_true')
     args = ap.parse_args()
 
     import torch
@@ -188,6 +189,31 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = S_total * args.steps / elapsed
 
+    online = None
+    if world == 1 and not args.no_online:
+        # online phase (O1) on the same problem: energy-orthonormalise the local bases (B1) with the projected energy
+        # product of the last pass, re-project, then solve 256 parameters in batches of 16
+        Lh = np.linalg.cholesky(buf['sys'][2].cpu().numpy())                 # [S, N, N], small: done on the host
+        LinvT = eng.ctx.from_numpy(np.linalg.inv(Lh).transpose(0, 2, 1))
+        Vo = torch.bmm(V[:eng.S], LinvT).contiguous()                        # columns orthonormal w.r.t. the energy product
+        bufo = eng.project_and_estimate(Vo, buf)
+        mus = np.random.default_rng(7).uniform(0.1, 1.0, size=256)
+        coeffs = lam['coefficients']
+        thetas = np.array([[c.evaluate(float(m)) for c in coeffs] for m in mus])
+        nb = 16 if N * 16 <= 768 else max(1, 768 // N)
+        eng.ctx.reduced_solve_batch(thetas[:nb], bufo['sys'][0], bufo['sys'][1])      # warm-up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        iters, worst = 0, 0.0
+        for b0 in range(0, len(mus), nb):
+            _, info = eng.ctx.reduced_solve_batch(thetas[b0:b0 + nb], bufo['sys'][0], bufo['sys'][1], rtol=1e-12)
+            iters, worst = max(iters, info['iterations']), max(worst, info['relative_residual'])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        online = {'metric': 'online reduced solves (O1)', 'value': len(mus) / dt, 'unit': 'mu-solves/s', 'parameters': len(mus),
+                  'batch': nb, 'reduced_dim': S_total * N, 'cg_iterations_max': iters, 'relative_residual_max': worst,
+                  'solver': 'block-Jacobi PCG on the block-sparse reduced system, rtol 1e-12'}
+
     if rank == 0:
         Q = eng.Q
         flops = algorithmic_flops_per_subdomain(t.n, t.n_rt, t.n_T, N, Q)
@@ -222,6 +248,8 @@ def main():
                                               cfg['coarse_per_subdomain'], t.n, t.n_rt, Q, N),
                           'subdomains': S_total, 'N': N, 'Q': Q, 'parallelism': 'subdomain tiles x{}'.format(world)},
                'roofline': roofline}
+        if online is not None:
+            out['online'] = online
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(N, cfg['coarse_per_subdomain'])
         print(json.dumps(out), flush=True)

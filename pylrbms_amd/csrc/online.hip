@@ -409,26 +409,27 @@ __global__ __launch_bounds__(256) void k_bcg_matvec(int S, const int* __restrict
 // mode 0: rz (initial).  scal layout: rz [BMAX], alpha [BMAX], beta [BMAX], rr [BMAX]
 __global__ __launch_bounds__(1024) void k_bcg_reduce(int S, int nmu, const double* __restrict__ partial,
                                                      const double* __restrict__ partial2, double* __restrict__ scal, int mode) {
-  __shared__ double red[1024];
-  const int tid = threadIdx.x;
-  for (int m = 0; m < nmu; ++m) {
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int m = threadIdx.x >> 6; m < nmu; m += nw) {       // wave m sums parameter m: lane-strided, then a fixed shuffle tree
     double a = 0.0, b = 0.0;
-    for (int i = tid; i < S; i += 1024) {
+    for (int i = lane; i < S; i += 64) {
       a += partial[(long)i * nmu + m];
       if (partial2) b += partial2[(long)i * nmu + m];
     }
-    const double sa = block_reduce_sum(a, red);
-    const double sb = partial2 ? block_reduce_sum(b, red) : 0.0;
-    if (tid == 0) {
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_down(a, off, 64);
+      b += __shfl_down(b, off, 64);
+    }
+    if (lane == 0) {
       if (mode == 0) {
-        scal[m] = sa;
+        scal[m] = a;
       } else if (mode == 1) {
-        scal[BMAX + m] = sa != 0.0 ? scal[m] / sa : 0.0;
+        scal[BMAX + m] = a != 0.0 ? scal[m] / a : 0.0;
       } else {
-        scal[2 * BMAX + m] = scal[m] != 0.0 ? sa / scal[m] : 0.0;
-        scal[m] = sa;
+        scal[2 * BMAX + m] = scal[m] != 0.0 ? a / scal[m] : 0.0;
+        scal[m] = a;
       }
-      if (partial2) scal[3 * BMAX + m] = sb;
+      if (partial2) scal[3 * BMAX + m] = b;
     }
   }
 }
