@@ -140,7 +140,11 @@ int lrbms_project_system(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V, 
 /* P2: projected estimator operators nc_i, r_fd_i, r_dd_i, df_aa_i, df_bb_i, df_ab_i
  * (block_swipdg.py:733-770 projected at reductor.py:70).
  *   work     >= lrbms_estimator_work_size(...) doubles of scratch
- *   G_nc  [S][W][W]; r_fd [S][C]; G_rdd [S][C][C]; G_bb [S][C][C]; G_ab [Q][S][N][C]; G_aa [Q][Q][S][N][N] */
+ *   G_nc  [S][W][W]; r_fd [S][C]; G_ab [Q][S][N][C]; G_aa [Q][Q][S][N][N]
+ *   G_rdd, G_bb [S][9][QN][QN]  block-compact: the (5 QN)^2 operator of subdomain ii only couples the own flux image
+ *     with itself and with each neighbour image (supported on the shared side faces), so only 9 of its 25 blocks are
+ *     non-zero (the reference keeps such operators as BlockOperators with None blocks, block_swipdg.py:336-338):
+ *     block 0 = [self,self], block 1 + side = [a,self] (= [self,a]^T), block 5 + side = [a,a]; rows / columns (q, j) */
 int64_t lrbms_estimator_work_size(lrbms_ctx* ctx, int32_t Q, int32_t N);
 int lrbms_estimator_grams(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* Wt, const double* Rt,
                           const double* ebar, const double* caa, const double* Aab, const double* Bbb,

@@ -271,7 +271,7 @@ class NativeContext:
         if work.numel() < need:
             raise NativeError('estimator_grams: work too small')
         if out is None:
-            out = (self.empty(S, W, W), self.empty(S, C), self.empty(S, C, C), self.empty(S, C, C),
+            out = (self.empty(S, W, W), self.empty(S, C), self.empty(S, 9, Q * N, Q * N), self.empty(S, 9, Q * N, Q * N),
                    self.empty(Q, S, N, C), self.empty(Q, Q, S, N, N))
         G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = out
         rc = self.lib.lrbms_estimator_grams(
@@ -279,8 +279,8 @@ class NativeContext:
             self._ptr(Rt, (S, self.n_rt, C), 'Rt'), self._ptr(ebar, (S, self.n_T), 'ebar'),
             self._ptr(caa, (Q, Q, S, self.n_T), 'caa'), self._ptr(Aab, (Q, S, self.n_T, 3, 3), 'Aab'),
             self._ptr(Bbb, (S, self.n_T, 3, 3), 'Bbb'), self._ptr(b, (S, self.n), 'b'), c_vp(work.data_ptr()),
-            self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, C, C), 'G_rdd'),
-            self._ptr(G_bb, (S, C, C), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
+            self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, Q * N, Q * N), 'G_rdd'),
+            self._ptr(G_bb, (S, 9, Q * N, Q * N), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
             self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._stream())
         self._check(rc, 'lrbms_estimator_grams')
         return G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa
@@ -309,8 +309,8 @@ class NativeContext:
             self._ptr(Aab, (Q, S, self.n_T, 3, 3), 'Aab'), self._ptr(Bbb, (S, self.n_T, 3, 3), 'Bbb'),
             c_vp(work.data_ptr()), self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'), self._ptr(rhs_red, (S, N), 'rhs_red'),
             self._ptr(E_red, (S, N, N), 'E_red'), self._ptr(M_red, (S, N, N), 'M_red'),
-            self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, C, C), 'G_rdd'),
-            self._ptr(G_bb, (S, C, C), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
+            self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, Q * N, Q * N), 'G_rdd'),
+            self._ptr(G_bb, (S, 9, Q * N, Q * N), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
             self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._stream())
         self._check(rc, 'lrbms_project_estimate_fused')
 
@@ -324,7 +324,7 @@ class NativeContext:
         eta = self.empty(3, S)
         rc = self.lib.lrbms_reduced_estimate(
             self.handle, Q, N, _dblp(th), self._ptr(u, (self.S_ext, N), 'u'), self._ptr(G_nc, (S, W, W), 'G_nc'),
-            self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, C, C), 'G_rdd'), self._ptr(G_bb, (S, C, C), 'G_bb'),
+            self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, Q * N, Q * N), 'G_rdd'), self._ptr(G_bb, (S, 9, Q * N, Q * N), 'G_bb'),
             self._ptr(G_ab, (Q, S, N, C), 'G_ab'), self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._ptr(f2, (S,), 'f2'),
             self._ptr(ceps, (S,), 'ceps'), float(hdiam), c_vp(eta.data_ptr()), self._stream())
         self._check(rc, 'lrbms_reduced_estimate')

@@ -315,6 +315,24 @@ __global__ __launch_bounds__(256) void k_project_coupling(Tmpl t, int S, const i
   }
 }
 
+// dense [S][C][C] (fixed 5-slot layout) -> block-compact [S][9][QN][QN]: block 0 = [self,self], 1 + side = [a,self],
+// 5 + side = [a,a]; every other block of the dense matrix is structurally zero (tests/common.py checks that)
+__global__ __launch_bounds__(256) void k_extract_blocks(int S, int QN, const double* __restrict__ dense, double* __restrict__ blocks) {
+  const int C = 5 * QN;
+  const long total = (long)S * 9 * QN * QN;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % QN);
+    long rest = idx / QN;
+    const int r = (int)(rest % QN);
+    rest /= QN;
+    const int b = (int)(rest % 9), s = (int)(rest / 9);
+    int rslot = 2, cslot = 2;
+    if (b >= 1 && b <= 4) rslot = side_to_slot(b - 1);
+    if (b >= 5) rslot = cslot = side_to_slot(b - 5);
+    blocks[idx] = dense[((long)s * C + rslot * QN + r) * C + cslot * QN + c];
+  }
+}
+
 inline unsigned grid_for(long total) {
   long g = (total + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -401,7 +419,7 @@ int launch_project_system(lrbms_ctx* ctx, int Q, int N, const double* V, const d
 int64_t estimator_work_size(lrbms_ctx* ctx, int Q, int N) {
   const Tmpl& t = ctx->t;
   const long C = 5L * Q * N;
-  return (long)ctx->S * t.n * C + (long)ctx->S * t.nT * C;
+  return (long)ctx->S * t.n * C + (long)ctx->S * t.nT * C + (long)ctx->S * C * C;   // Y, D, one dense Gram
 }
 
 int launch_estimator_grams(lrbms_ctx* ctx, int Q, int N, const double* V, const double* Wt, const double* Rt,
@@ -413,6 +431,8 @@ int launch_estimator_grams(lrbms_ctx* ctx, int Q, int N, const double* V, const 
   const int W = 5 * N, C = 5 * Q * N;
   double* Y = work;
   double* D = work + (long)S * t.n * C;
+  double* dense = D + (long)S * t.nT * C;      // dense [S][C][C] scratch, extracted into the block-compact outputs
+  const int QN = Q * N;
   int rc;
   // nc_ii = Wt^T E_ii Wt  (block_swipdg.py:733)
   hipLaunchKernelGGL(k_elemdiag_apply, dim3(grid_for((long)S * t.nT * W)), dim3(256), 0, st, t, S, W, 0, ebar, Wt, Y);
@@ -424,13 +444,17 @@ int launch_estimator_grams(lrbms_ctx* ctx, int Q, int N, const double* V, const 
   LRBMS_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(k_rfd, dim3((C + 255) / 256, S), dim3(256), 0, st, t, C, b, D, r_fd);
   LRBMS_LAUNCH_CHECK(ctx);
-  rc = launch_gemm_tn(ctx, S, t.nT, C, C, D, (long)t.nT * C, C, D, (long)t.nT * C, C, G_rdd, (long)C * C, C, t.area, 1.0, st);
+  rc = launch_gemm_tn(ctx, S, t.nT, C, C, D, (long)t.nT * C, C, D, (long)t.nT * C, C, dense, (long)C * C, C, t.area, 1.0, st);
   if (rc) return rc;
+  hipLaunchKernelGGL(k_extract_blocks, dim3(grid_for((long)S * 9 * QN * QN)), dim3(256), 0, st, S, QN, dense, G_rdd);
+  LRBMS_LAUNCH_CHECK(ctx);
   // df_bb = Rt^T B Rt (:762)
   hipLaunchKernelGGL(k_bb_apply, dim3(grid_for((long)S * t.nrt * C)), dim3(256), 0, st, t, S, C, Bbb, Rt, Y);
   LRBMS_LAUNCH_CHECK(ctx);
-  rc = launch_gemm_tn(ctx, S, t.nrt, C, C, Rt, (long)t.nrt * C, C, Y, (long)t.nrt * C, C, G_bb, (long)C * C, C, nullptr, 1.0, st);
+  rc = launch_gemm_tn(ctx, S, t.nrt, C, C, Rt, (long)t.nrt * C, C, Y, (long)t.nrt * C, C, dense, (long)C * C, C, nullptr, 1.0, st);
   if (rc) return rc;
+  hipLaunchKernelGGL(k_extract_blocks, dim3(grid_for((long)S * 9 * QN * QN)), dim3(256), 0, st, S, QN, dense, G_bb);
+  LRBMS_LAUNCH_CHECK(ctx);
   // df_ab^q = V^T A_ab^q Rt (:765-770)
   for (int q = 0; q < Q; ++q) {
     hipLaunchKernelGGL(k_ab_apply, dim3(grid_for((long)S * t.nT * C)), dim3(256), 0, st, t, S, C,

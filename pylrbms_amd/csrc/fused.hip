@@ -616,8 +616,8 @@ __global__ __launch_bounds__(64 * (NR + EC)) void k_f2(Tmpl t, F2Args a) {
     }
     lds_barrier();                                 // final barrier
     const int col = ct * 16 + li;
-    double* gb = a.G_bb + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
-    double* gd = a.G_rdd + (long)s * C * C + (long)(2 * QN) * C + 2 * QN + col;
+    double* gb = a.G_bb + (long)s * 9 * QN * QN + col;      // block 0 = [self, self] of the block-compact layout
+    double* gd = a.G_rdd + (long)s * 9 * QN * QN + col;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
 #pragma unroll
@@ -625,8 +625,8 @@ __global__ __launch_bounds__(64 * (NR + EC)) void k_f2(Tmpl t, F2Args a) {
         const int row = i * 16 + lk + 4 * r;
         const double vb = accb[i][r], vd = accd[i][r];
         if (col < QN && row < QN) {
-          gb[(long)row * C] = vb;
-          gd[(long)row * C] = vd;
+          gb[(long)row * QN] = vb;
+          gd[(long)row * QN] = vd;
         }
       }
     }
@@ -840,21 +840,15 @@ __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
   extern __shared__ double lds[];
   const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
   const int Q = a.Q, N = a.N, QN = Q * N, C = 5 * QN, S = a.S;
-  double* Gb = a.G_bb + (long)s * C * C;
-  double* Gd = a.G_rdd + (long)s * C * C;
+  // block-compact layout [S][9][QN][QN]: block 1 + side = [a, self], block 5 + side = [a, a]
+  double* Gb_as = a.G_bb + ((long)s * 9 + 1 + side) * QN * QN;
+  double* Gb_aa = a.G_bb + ((long)s * 9 + 5 + side) * QN * QN;
+  double* Gd_as = a.G_rdd + ((long)s * 9 + 1 + side) * QN * QN;
+  double* Gd_aa = a.G_rdd + ((long)s * 9 + 5 + side) * QN * QN;
   const int s2 = a.nbr[s * 5 + slot];
   const int np = t.side_count[side];
   if (s2 < 0 || np == 0) {
-    for (long i = tid; i < (long)QN * C; i += 256) {
-      const long off = (long)(slot * QN + i / C) * C + i % C;
-      Gb[off] = 0.0;
-      Gd[off] = 0.0;
-    }
-    for (int i = tid; i < QN * QN; i += 256) {
-      const long off = (long)(2 * QN + i / QN) * C + slot * QN + i % QN;
-      Gb[off] = 0.0;
-      Gd[off] = 0.0;
-    }
+    for (int i = tid; i < QN * QN; i += 256) Gb_as[i] = Gb_aa[i] = Gd_as[i] = Gd_aa[i] = 0.0;
     for (int q = 0; q < Q; ++q)
       for (int i = tid; i < N * QN; i += 256) a.G_ab[(((long)q * S + s) * N + i / QN) * C + slot * QN + i % QN] = 0.0;
     for (int i = tid; i < QN; i += 256) a.r_fd[(long)s * C + slot * QN + i] = 0.0;
@@ -903,76 +897,22 @@ __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
     Xab[it] = x;
   }
   __syncthreads();
-  // block-row a of G_bb / G_rdd (QN x C): consecutive threads on consecutive columns.  With an even QN every row
-  // segment is 16-byte aligned and the kernel -- which is bound by its 2 x QN x C doubles of stores -- writes
-  // double2 per lane: zero blocks as pure stores, the two non-zero blocks with two columns per thread.
-  if ((QN & 1) == 0) {
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const int hq = QN / 2;
-    for (int it = tid; it < QN * 3 * hq; it += 256) {          // the three zero column blocks
-      const int row = it / (3 * hq), rem = it - row * 3 * hq, which = rem / hq, cc = 2 * (rem - which * hq);
-      int cslot = -1, seen = 0;
-#pragma unroll
-      for (int sl = 0; sl < 5; ++sl) {
-        if (sl == 2 || sl == slot) continue;
-        if (seen == which) cslot = sl;
-        ++seen;
-      }
-      const long off = (long)(slot * QN + row) * C + cslot * QN + cc;
-      *reinterpret_cast<d2*>(Gb + off) = (d2){0.0, 0.0};
-      *reinterpret_cast<d2*>(Gd + off) = (d2){0.0, 0.0};
-    }
-    for (int it = tid; it < QN * 2 * hq; it += 256) {          // blocks [a, a] and [a, self]
-      const int row = it / (2 * hq), rem = it - row * 2 * hq, which = rem / hq, cc = 2 * (rem - which * hq);
-      d2 vb = {0.0, 0.0}, vd = {0.0, 0.0};
-      if (which == 0) {
-        for (int p = 0; p < np; ++p) {
-          const double ra = Ra[p * QN + row];
-          const d2 rc = *reinterpret_cast<const d2*>(Ra + p * QN + cc);
-          vb += (sc[p * 3] * ra) * rc;
-          vd += (sc[p * 3 + 1] * ra) * rc;
-        }
-      } else {
-        for (int p = 0; p < np; ++p) {
-          const double ra = Ra[p * QN + row];
-          vb += ra * *reinterpret_cast<const d2*>(Yb + p * QN + cc);
-          vd += ra * *reinterpret_cast<const d2*>(Dp + p * QN + cc);
-        }
-      }
-      const long off = (long)(slot * QN + row) * C + (which == 0 ? slot : 2) * QN + cc;
-      *reinterpret_cast<d2*>(Gb + off) = vb;
-      *reinterpret_cast<d2*>(Gd + off) = vd;
-    }
-  } else
-  for (long it = tid; it < (long)QN * C; it += 256) {
-    const int row = (int)(it / C), col = (int)(it - (long)row * C);
-    const int cslot = col / QN, cc = col - cslot * QN;
-    double vb = 0.0, vd = 0.0;
-    if (cslot == slot) {
-      for (int p = 0; p < np; ++p) {
-        const double rr = Ra[p * QN + row] * Ra[p * QN + cc];
-        vb += sc[p * 3] * rr;
-        vd += sc[p * 3 + 1] * rr;
-      }
-    } else if (cslot == 2) {
-      for (int p = 0; p < np; ++p) {
-        vb += Ra[p * QN + row] * Yb[p * QN + cc];
-        vd += Ra[p * QN + row] * Dp[p * QN + cc];
-      }
-    }
-    Gb[(long)(slot * QN + row) * C + col] = vb;
-    Gd[(long)(slot * QN + row) * C + col] = vd;
-  }
-  // transposed blocks [self, a]: recomputed with the a-index fastest so that the stores coalesce
+  // the two non-zero blocks of block-row a: [a, a] (rank-np with the side-face scalars) and [a, self]
   for (int it = tid; it < QN * QN; it += 256) {
-    const int cc = it / QN, row = it - cc * QN;
-    double vb = 0.0, vd = 0.0;
+    const int row = it / QN, cc = it - row * QN;
+    double vb = 0.0, vd = 0.0, wb = 0.0, wd = 0.0;
     for (int p = 0; p < np; ++p) {
-      vb += Ra[p * QN + row] * Yb[p * QN + cc];
-      vd += Ra[p * QN + row] * Dp[p * QN + cc];
+      const double ra = Ra[p * QN + row];
+      const double rr = ra * Ra[p * QN + cc];
+      vb += sc[p * 3] * rr;
+      vd += sc[p * 3 + 1] * rr;
+      wb += ra * Yb[p * QN + cc];
+      wd += ra * Dp[p * QN + cc];
     }
-    Gb[(long)(2 * QN + cc) * C + slot * QN + row] = vb;
-    Gd[(long)(2 * QN + cc) * C + slot * QN + row] = vd;
+    Gb_aa[it] = vb;
+    Gd_aa[it] = vd;
+    Gb_as[it] = wb;
+    Gd_as[it] = wd;
   }
   for (int it = tid; it < Q * N * QN; it += 256) {
     const int q = it / (N * QN), rem = it - q * N * QN, i = rem / QN, cc = rem - i * QN;

@@ -65,8 +65,20 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
   __syncthreads();
   const double* ui = uo + 2 * N;
   double p_nc = quad_partial(G_nc + (long)s * W * W, W, W, W, uo, uo);
-  double p_rdd = quad_partial(G_rdd + (long)s * C * C, C, C, C, ur, ur);
-  double p_bb = quad_partial(G_bb + (long)s * C * C, C, C, C, ur, ur);
+  // block-compact G_rdd / G_bb [S][9][QN][QN]: z^T G z = z_s^T G_ss z_s + sum_a (2 z_a^T G_as z_s + z_a^T G_aa z_a)
+  const int QN = Q * N;
+  const double* zs = ur + 2 * QN;
+  const double* Gd = G_rdd + (long)s * 9 * QN * QN;
+  const double* Gb = G_bb + (long)s * 9 * QN * QN;
+  double p_rdd = quad_partial(Gd, QN, QN, QN, zs, zs);
+  double p_bb = quad_partial(Gb, QN, QN, QN, zs, zs);
+  for (int side = 0; side < 4; ++side) {
+    const double* za = ur + (side < 2 ? side : side + 1) * QN;
+    p_rdd += 2.0 * quad_partial(Gd + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs) +
+             quad_partial(Gd + (long)(5 + side) * QN * QN, QN, QN, QN, za, za);
+    p_bb += 2.0 * quad_partial(Gb + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs) +
+            quad_partial(Gb + (long)(5 + side) * QN * QN, QN, QN, QN, za, za);
+  }
   double p_rfd = 0.0;
   for (int c = threadIdx.x; c < C; c += blockDim.x) p_rfd += r_fd[(long)s * C + c] * ur[c];
   double p_ab = 0.0, p_aa = 0.0;

@@ -8,7 +8,8 @@ Data layout in HBM (all fp64, C-contiguous; S = local subdomains, S_ext = S + ha
     V      [S_ext][n][N]         local reduced bases, DoF-major (basis index contiguous)
     Wt     [S][n][5N]            Oswald image bases restricted to the target subdomain (slot-major columns)
     Rt     [S][n_rt][5QN]        RT0 flux-reconstruction image bases (slot, q, basis) columns
-    B_sys  [Q][S][5][N][N]       projected system blocks; G_* projected estimator operators (see include/lrbms_hip.h)
+    B_sys  [Q][S][5][N][N]       projected system blocks; G_* projected estimator operators (see include/lrbms_hip.h;
+                                 G_rdd / G_bb are block-compact [S][9][QN][QN]: only the structurally non-zero blocks)
 
 The reference builds the same quantities as pyMOR operators in ``discretize`` / ``LRBMSReductor._reduce``
 (discretize_elliptic_block_swipdg.py:530-811, reductor.py:33-73).
@@ -110,7 +111,7 @@ class Engine:
         return {
             'N': N, 'Wt': c.empty(S, n, W), 'Rt': c.empty(S, n_rt, C), 'work': work,
             'sys': (c.empty(Q, S, 5, N, N), c.empty(S, N), c.empty(S, N, N), c.empty(S, N, N)),
-            'grams': (c.empty(S, W, W), c.empty(S, C), c.empty(S, C, C), c.empty(S, C, C), c.empty(Q, S, N, C),
+            'grams': (c.empty(S, W, W), c.empty(S, C), c.empty(S, 9, Q * N, Q * N), c.empty(S, 9, Q * N, Q * N), c.empty(Q, S, N, C),
                       c.empty(Q, Q, S, N, N)),
         }
 
