@@ -226,9 +226,15 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
   if (tid == 0) grp_n = blockIdx.y == 0 ? gt0.n : blockIdx.y == 1 ? gt1.n : gt2.n;
   int* nbl = idx;
   int* rtl = idx + 3 * t.nT;
+  double* Kl = reinterpret_cast<double*>(idx + 6 * t.nT);   // template stiffness K_T [nT][9] (same for all subdomains)
   for (int i = tid; i < 3 * t.nT; i += 512) {
     nbl[i] = t.nb_elem[i];
     rtl[i] = t.elem_rt[i];
+  }
+  for (int T = tid; T < t.nT; T += 512) {
+    double K[9];
+    stiffness3(t, T, K);
+    for (int i = 0; i < 9; ++i) Kl[T * 9 + i] = K[i];
   }
   for (int i = tid; i < 2 * 3 * EC * LDX; i += 512) (&Xs[0][0])[i] = 0.0;
   for (int i = tid; i < 2 * 3 * EC * LDY; i += 512) (&Ys[0][0])[i] = 0.0;
@@ -329,8 +335,8 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
           const double* be = a.b + (long)s * t.n + 3 * T;
           rhs_part += be[0] * vb[0][0] + be[1] * vb[0][1] + be[2] * vb[0][2];
         }
-        double K[9], kv[3];
-        stiffness3(t, T, K);
+        double kv[3];
+        const double* K = Kl + T * 9;
 #pragma unroll
         for (int i = 0; i < 3; ++i) kv[i] = K[i * 3] * vb[0][0] + K[i * 3 + 1] * vb[0][1] + K[i * 3 + 2] * vb[0][2];
         if (QP > 0 && ng == QP + 2 + (QP * (QP + 1)) / 2 + QP * QP) {
@@ -997,7 +1003,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     constexpr int NTY = 7;                                   // 4 consumer waves x 7 column tiles = 448 columns per slice
     const int per = std::min(F1_MAXG, (4 * NTY * 16) / N);
     const int ntx = (N + 15) / 16;
-    const size_t ldsf1 = sizeof(int) * 6 * t.nT;
+    const size_t ldsf1 = sizeof(int) * 6 * t.nT + sizeof(double) * 9 * t.nT;   // 6 nT ints: 8-byte aligned (nT % 8 == 0)
     for (size_t g0 = 0; g0 < groups.size(); g0 += 3 * (size_t)per) {   // up to three slices per launch (grid.y)
       GrpTable gt[3];
       int nsl = 0;
