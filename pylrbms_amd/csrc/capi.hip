@@ -53,11 +53,11 @@ int lrbms_ctx_create(int device, lrbms_ctx** out) {
   lrbms_ctx* ctx = new (std::nothrow) lrbms_ctx();
   if (!ctx) return LRBMS_E_INVALID;
   ctx->device = device;
-  int prio_lo = 0, prio_hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // lowest priority: the side work only fills idle resources
-  if (hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+  bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < 3 && ok; ++i)
+    ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
     delete ctx;
     return LRBMS_E_HIP;
   }
@@ -69,9 +69,11 @@ int lrbms_ctx_destroy(lrbms_ctx* ctx) {
   if (!ctx) return LRBMS_E_INVALID;
   (void)hipSetDevice(ctx->device);
   free_owned(ctx);
-  if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  for (int i = 0; i < 3; ++i) {
+    if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
+    if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+  }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
   return LRBMS_OK;
 }

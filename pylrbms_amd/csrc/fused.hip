@@ -979,12 +979,15 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   hipLaunchKernelGGL(k_vertex_avg, dim3(grid_for((long)S * t.nv * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide);
   LRBMS_LAUNCH_CHECK(ctx);
   (void)nvs;
-  // fork: the thin kernels (HBM-write / latency bound, few registers) go to the library's side stream so that they
-  // share the CUs with the MFMA kernels of the main stream; joined before returning control to the caller's stream
-  hipStream_t side = getenv("LRBMS_OVERLAP") ? ctx->side : st;   // measured: no gain for this kernel mix, off by default
-  if (side != st) {
+  // fork: F2 / F3, the thin kernels and the coupling projection are independent of each other and of F1 (they all read
+  // only V and the two prepare kernels' outputs); on separate streams their workgroups interleave on the CUs, which
+  // hides the latencies each of them exposes when it runs alone (they are latency-, not throughput-bound)
+  const bool multi = getenv("LRBMS_STREAMS") != nullptr;   // measured on MI355X / ROCm 7.2: 1.92 ms vs 1.81 ms serial -> off by default
+  hipStream_t s_rt = multi ? ctx->aux[0] : st, s_f23 = multi ? ctx->aux[1] : st, s_nc = multi ? ctx->aux[2] : st;
+  hipStream_t side = s_nc;
+  if (multi) {
     LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
-    LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
+    for (int i = 0; i < 3; ++i) LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
   }
 
   // ---- F1: build the column-group list and launch in slices of at most F1_YW / N groups
@@ -1048,7 +1051,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     LRBMS_LAUNCH_CHECK(ctx);
     ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, G_bb, G_rdd, G_ab, r_fd, Q, N, S};
     const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf);
-    hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, side, t, a);
+    hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, s_rt, t, a);
     LRBMS_LAUNCH_CHECK(ctx);
   }
   // ---- F2
@@ -1057,14 +1060,14 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     const int nr = (QN + 15) / 16;
     const size_t ldsf2 = sizeof(double) * 4 * t.nT + sizeof(int) * 3 * t.nT;
     switch (nr) {
-      case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(320), ldsf2, st, t, a); break;
-      case 2: hipLaunchKernelGGL(k_f2<2>, dim3(S), dim3(384), ldsf2, st, t, a); break;
-      case 3: hipLaunchKernelGGL(k_f2<3>, dim3(S), dim3(448), ldsf2, st, t, a); break;
-      case 4: hipLaunchKernelGGL(k_f2<4>, dim3(S), dim3(512), ldsf2, st, t, a); break;
-      case 5: hipLaunchKernelGGL(k_f2<5>, dim3(S), dim3(576), ldsf2, st, t, a); break;
-      case 6: hipLaunchKernelGGL(k_f2<6>, dim3(S), dim3(640), ldsf2, st, t, a); break;
-      case 7: hipLaunchKernelGGL(k_f2<7>, dim3(S), dim3(704), ldsf2, st, t, a); break;
-      default: hipLaunchKernelGGL(k_f2<8>, dim3(S), dim3(768), ldsf2, st, t, a); break;
+      case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(320), ldsf2, s_f23, t, a); break;
+      case 2: hipLaunchKernelGGL(k_f2<2>, dim3(S), dim3(384), ldsf2, s_f23, t, a); break;
+      case 3: hipLaunchKernelGGL(k_f2<3>, dim3(S), dim3(448), ldsf2, s_f23, t, a); break;
+      case 4: hipLaunchKernelGGL(k_f2<4>, dim3(S), dim3(512), ldsf2, s_f23, t, a); break;
+      case 5: hipLaunchKernelGGL(k_f2<5>, dim3(S), dim3(576), ldsf2, s_f23, t, a); break;
+      case 6: hipLaunchKernelGGL(k_f2<6>, dim3(S), dim3(640), ldsf2, s_f23, t, a); break;
+      case 7: hipLaunchKernelGGL(k_f2<7>, dim3(S), dim3(704), ldsf2, s_f23, t, a); break;
+      default: hipLaunchKernelGGL(k_f2<8>, dim3(S), dim3(768), ldsf2, s_f23, t, a); break;
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
@@ -1073,20 +1076,22 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     F3Args a{V, ebar, AvgSelf, AvgSide, G_nc, N, S};
     const int ntx = (N + 15) / 16;
     switch (ntx) {
-      case 1: hipLaunchKernelGGL(k_f3<1>, dim3(S), dim3(256), 0, st, t, a); break;
-      case 2: hipLaunchKernelGGL(k_f3<2>, dim3(S), dim3(256), 0, st, t, a); break;
-      case 3: hipLaunchKernelGGL(k_f3<3>, dim3(S), dim3(256), 0, st, t, a); break;
-      default: hipLaunchKernelGGL(k_f3<4>, dim3(S), dim3(256), 0, st, t, a); break;
+      case 1: hipLaunchKernelGGL(k_f3<1>, dim3(S), dim3(256), 0, s_f23, t, a); break;
+      case 2: hipLaunchKernelGGL(k_f3<2>, dim3(S), dim3(256), 0, s_f23, t, a); break;
+      case 3: hipLaunchKernelGGL(k_f3<3>, dim3(S), dim3(256), 0, s_f23, t, a); break;
+      default: hipLaunchKernelGGL(k_f3<4>, dim3(S), dim3(256), 0, s_f23, t, a); break;
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
   {
-    const int rc = launch_project_coupling(ctx, Q, N, V, A_cpl, B_sys, st);
+    const int rc = launch_project_coupling(ctx, Q, N, V, A_cpl, B_sys, s_nc);
     if (rc) return rc;
   }
-  if (side != st) {
-    LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, side));
-    LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+  if (multi) {
+    for (int i = 0; i < 3; ++i) {
+      LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
+      LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_join[i], 0));
+    }
   }
   return LRBMS_OK;
 }

@@ -28,8 +28,8 @@ struct lrbms_ctx {
   int S = 0, S_ext = 0;
   int* nbr = nullptr;             // [S][5] device
   std::vector<void*> owned;       // device allocations to free
-  hipStream_t side = nullptr;     // library-owned side stream: write-bound thin kernels overlap the MFMA kernels
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // library-owned streams: independent small kernels run concurrently
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   std::string err;
 };
 
