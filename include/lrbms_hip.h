@@ -173,6 +173,13 @@ int lrbms_reduced_estimate(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* t
                            const double* G_ab, const double* G_aa, const double* f2, const double* ceps, double hdiam,
                            double* eta_loc, void* stream);
 
+/* E1, throughput form: nmu <= 16 reduced solutions at once; theta [nmu][Q] host, u [S_ext][N][nmu] (mu fastest, the
+ * layout lrbms_reduced_solve_batch returns), eta_loc [3][S][nmu].  Every projected operator is read once per batch. */
+int lrbms_reduced_estimate_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* u,
+                                 const double* G_nc, const double* r_fd, const double* G_rdd, const double* G_bb,
+                                 const double* G_ab, const double* G_aa, const double* f2, const double* ceps, double hdiam,
+                                 double* eta_loc, void* stream);
+
 /* O1: rd.solve(mu): (sum_q theta_q B_sys_q) u = rhs_red by block-Jacobi preconditioned CG on the block-sparse
  * reduced system (single rank: S_ext == S).  work >= lrbms_reduced_solve_work_size doubles.
  * Returns LRBMS_E_NOT_CONVERGED if the relative residual is above rtol after max_iter.  info[0] = iterations,

@@ -46,6 +46,7 @@ SIGNATURES = {
     'lrbms_fused_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_project_estimate_fused': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 22),
     'lrbms_reduced_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 9 + [c_dbl, c_vp, c_vp]),
+    'lrbms_reduced_estimate_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL] + [c_vp] * 9 + [c_dbl, c_vp, c_vp]),
     'lrbms_reduced_solve_work_size': (c_i64, [c_vp, c_i32]),
     'lrbms_reduced_solve': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms_reduced_solve_batch_work_size': (c_i64, [c_vp, c_i32, c_i32]),
@@ -328,6 +329,24 @@ class NativeContext:
             self._ptr(G_ab, (Q, S, N, C), 'G_ab'), self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._ptr(f2, (S,), 'f2'),
             self._ptr(ceps, (S,), 'ceps'), float(hdiam), c_vp(eta.data_ptr()), self._stream())
         self._check(rc, 'lrbms_reduced_estimate')
+        return eta
+
+    def reduced_estimate_batch(self, thetas, u, grams, f2, ceps, hdiam):
+        """thetas [nmu, Q], u [S_ext, N, nmu] -> eta_loc [3, S, nmu]."""
+        G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = grams
+        Q, S, N = G_ab.shape[0], self.S, G_ab.shape[2]
+        W, C = 5 * N, 5 * Q * N
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        nmu = th.shape[0]
+        assert th.shape == (nmu, Q)
+        eta = self.empty(3, S, nmu)
+        rc = self.lib.lrbms_reduced_estimate_batch(
+            self.handle, Q, N, nmu, _dblp(th), self._ptr(u, (self.S_ext, N, nmu), 'u'), self._ptr(G_nc, (S, W, W), 'G_nc'),
+            self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, Q * N, Q * N), 'G_rdd'),
+            self._ptr(G_bb, (S, 9, Q * N, Q * N), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
+            self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._ptr(f2, (S,), 'f2'), self._ptr(ceps, (S,), 'ceps'), float(hdiam),
+            c_vp(eta.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_reduced_estimate_batch')
         return eta
 
     def reduced_solve(self, theta, B_sys, rhs_red, rtol=1e-13, max_iter=20000, work=None):

@@ -6,6 +6,10 @@
 
 int64_t estimator_work_size(lrbms_ctx* ctx, int Q, int N);
 int64_t reduced_solve_work_size(lrbms_ctx* ctx, int N);
+int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const double* theta, const double* u, const double* G_nc,
+                                  const double* r_fd, const double* G_rdd, const double* G_bb, const double* G_ab,
+                                  const double* G_aa, const double* f2, const double* ceps, double hdiam, double* eta_loc,
+                                  hipStream_t st);
 int64_t reduced_solve_batch_work_size(lrbms_ctx* ctx, int N, int nmu);
 int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const double* theta, const double* B_sys,
                                const double* rhs_red, double* work, double* u, double rtol, int max_iter, double* info,
@@ -260,6 +264,17 @@ int lrbms_reduced_estimate(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* t
     return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate: coefficient tile exceeds 64 KB of LDS");
   return launch_reduced_estimate(ctx, Q, N, theta, u, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, f2, ceps, hdiam, eta_loc,
                                  (hipStream_t)stream);
+}
+
+int lrbms_reduced_estimate_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* u,
+                                 const double* G_nc, const double* r_fd, const double* G_rdd, const double* G_bb,
+                                 const double* G_ab, const double* G_aa, const double* f2, const double* ceps, double hdiam,
+                                 double* eta_loc, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, u); CHECK_PTR(ctx, G_nc); CHECK_PTR(ctx, r_fd);
+  CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa); CHECK_PTR(ctx, f2); CHECK_PTR(ctx, ceps);
+  CHECK_PTR(ctx, eta_loc);
+  return launch_reduced_estimate_batch(ctx, Q, N, nmu, theta, u, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, f2, ceps, hdiam, eta_loc,
+                                       (hipStream_t)stream);
 }
 
 int64_t lrbms_reduced_solve_work_size(lrbms_ctx* ctx, int32_t N) {

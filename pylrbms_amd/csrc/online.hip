@@ -582,3 +582,137 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   if (rel > rtol) return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve_batch: CG did not reach rtol");
   return LRBMS_OK;
 }
+
+// =========================================================================================================
+// E1, throughput form: the local estimator terms of nmu <= 16 reduced solutions in one pass over the projected
+// operators.  Every operator entry is loaded once and used for all parameters (2 nmu flops per 8 bytes), so the
+// batch costs about one single-parameter estimate in HBM traffic.  Lanes own columns (their coefficient panel lives
+// in registers), waves stride over rows (row coefficients are LDS broadcasts); fixed-order wave + block reductions.
+namespace {
+
+constexpr int EB = 16;   // max parameters per estimate batch
+
+// acc[m] += w[m] * sum_{r, c} x[r][m] G[r][c] y[c][m]   (x, y in LDS as [row][nmu]; w optional per-parameter weight)
+__device__ inline void quad_batch(const double* __restrict__ G, int ld, int rows, int cols, const double* x, const double* y,
+                                  int nmu, const double* w, double factor, double (&acc)[EB]) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int c = lane; c < cols; c += 64) {
+    double yc[EB];
+#pragma unroll
+    for (int m = 0; m < EB; ++m) yc[m] = m < nmu ? factor * (w ? w[m] : 1.0) * y[c * nmu + m] : 0.0;
+    for (int r = wave; r < rows; r += nw) {
+      const double g = G[(long)r * ld + c];
+      const double* xr = x + r * nmu;
+#pragma unroll
+      for (int m = 0; m < EB; ++m)
+        if (m < nmu) acc[m] += (xr[m] * yc[m]) * g;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_reduced_estimate_batch(int S, const int* __restrict__ nbr, int Q, int N, int nmu,
+                                                                ThetaBatch th, const double* __restrict__ u,
+                                                                const double* __restrict__ G_nc, const double* __restrict__ r_fd,
+                                                                const double* __restrict__ G_rdd, const double* __restrict__ G_bb,
+                                                                const double* __restrict__ G_ab, const double* __restrict__ G_aa,
+                                                                const double* __restrict__ f2, const double* __restrict__ ceps,
+                                                                double hdiam, double* __restrict__ eta_loc) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = 5 * N, QN = Q * N, C = 5 * QN;
+  double* uo = lds;                 // [W][nmu]   coefficients of the own + neighbour bases
+  double* ur = uo + W * nmu;        // [C][nmu]   theta_q(mu_m) * coefficient, column order (slot, q, j)
+  double* thq = ur + C * nmu;       // [Q][nmu]   theta_q per parameter (weights of the aa / ab terms)
+  double* red = thq + 8 * EB;       // [4][3][EB]
+  for (int i = tid; i < W * nmu; i += 256) {
+    const int row = i / nmu, m = i - row * nmu, slot = row / N, j = row - slot * N;
+    const int s2 = nbr[s * 5 + slot];
+    const double val = s2 >= 0 ? u[((long)s2 * N + j) * nmu + m] : 0.0;
+    uo[i] = val;
+    for (int q = 0; q < Q; ++q) ur[((slot * Q + q) * N + j) * nmu + m] = th.v[m * 8 + q] * val;
+  }
+  for (int i = tid; i < Q * nmu; i += 256) thq[i] = th.v[(i % nmu) * 8 + i / nmu];
+  __syncthreads();
+  double a_nc[EB], a_r[EB], a_df[EB];
+#pragma unroll
+  for (int m = 0; m < EB; ++m) a_nc[m] = a_r[m] = a_df[m] = 0.0;
+  const double* ui = uo + 2 * N * nmu;
+  const double* zs = ur + 2 * QN * nmu;
+  quad_batch(G_nc + (long)s * W * W, W, W, W, uo, uo, nmu, nullptr, 1.0, a_nc);
+  const double* Gd = G_rdd + (long)s * 9 * QN * QN;
+  const double* Gb = G_bb + (long)s * 9 * QN * QN;
+  quad_batch(Gd, QN, QN, QN, zs, zs, nmu, nullptr, 1.0, a_r);
+  quad_batch(Gb, QN, QN, QN, zs, zs, nmu, nullptr, 1.0, a_df);
+  for (int side = 0; side < 4; ++side) {
+    const double* za = ur + (side < 2 ? side : side + 1) * QN * nmu;
+    quad_batch(Gd + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, nmu, nullptr, 2.0, a_r);
+    quad_batch(Gd + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, nmu, nullptr, 1.0, a_r);
+    quad_batch(Gb + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, nmu, nullptr, 2.0, a_df);
+    quad_batch(Gb + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, nmu, nullptr, 1.0, a_df);
+  }
+  // - 2 r_fd . ur  (a 1 x C "matrix" against the constant row coefficient 1)
+  if (wave == 0)
+    for (int c = lane; c < C; c += 64) {
+      const double g = r_fd[(long)s * C + c];
+#pragma unroll
+      for (int m = 0; m < EB; ++m)
+        if (m < nmu) a_r[m] -= 2.0 * g * ur[c * nmu + m];
+    }
+  for (int q = 0; q < Q; ++q) {
+    quad_batch(G_ab + ((long)q * S + s) * N * C, C, N, C, ui, ur, nmu, thq + q * nmu, 2.0, a_df);
+    for (int q2 = 0; q2 < Q; ++q2) {
+      double wq[EB];
+#pragma unroll
+      for (int m = 0; m < EB; ++m) wq[m] = m < nmu ? thq[q * nmu + m] * thq[q2 * nmu + m] : 0.0;
+      quad_batch(G_aa + (((long)q * Q + q2) * S + s) * N * N, N, N, N, ui, ui, nmu, wq, 1.0, a_df);
+    }
+  }
+  // fixed-order reductions: 64 lanes by shuffles, then the 4 waves through LDS
+#pragma unroll
+  for (int m = 0; m < EB; ++m) {
+    double v0 = a_nc[m], v1 = a_r[m], v2 = a_df[m];
+    for (int off = 32; off > 0; off >>= 1) {
+      v0 += __shfl_down(v0, off, 64);
+      v1 += __shfl_down(v1, off, 64);
+      v2 += __shfl_down(v2, off, 64);
+    }
+    if (lane == 0) {
+      red[(wave * 3 + 0) * EB + m] = v0;
+      red[(wave * 3 + 1) * EB + m] = v1;
+      red[(wave * 3 + 2) * EB + m] = v2;
+    }
+  }
+  __syncthreads();
+  if (tid < nmu) {
+    const double pi = 3.14159265358979323846;
+    double nc = 0.0, rr = 0.0, df = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      nc += red[(w * 3 + 0) * EB + tid];
+      rr += red[(w * 3 + 1) * EB + tid];
+      df += red[(w * 3 + 2) * EB + tid];
+    }
+    eta_loc[((long)0 * S + s) * nmu + tid] = nc;
+    eta_loc[((long)1 * S + s) * nmu + tid] = (f2[s] + rr) * ((1.0 / (pi * pi)) / ceps[s]) * hdiam * hdiam;   // estimators.py:88-91
+    eta_loc[((long)2 * S + s) * nmu + tid] = df;
+  }
+}
+
+}  // namespace
+
+int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const double* theta, const double* u, const double* G_nc,
+                                  const double* r_fd, const double* G_rdd, const double* G_bb, const double* G_ab,
+                                  const double* G_aa, const double* f2, const double* ceps, double hdiam, double* eta_loc,
+                                  hipStream_t st) {
+  if (nmu < 1 || nmu > EB) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: need 1 <= nmu <= 16");
+  const size_t lds = sizeof(double) * ((size_t)(5 * N + 5 * Q * N) * nmu + 8 * EB + 4 * 3 * EB);
+  if (lds > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
+  ThetaBatch th;
+  for (int m = 0; m < BMAX; ++m)
+    for (int q = 0; q < 8; ++q) th.v[m * 8 + q] = (m < nmu && q < Q) ? theta[m * Q + q] : 0.0;
+  if (lds > 64 * 1024)
+    LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_reduced_estimate_batch, dim3(ctx->S), dim3(256), lds, st, ctx->S, ctx->nbr, Q, N, nmu, th, u, G_nc, r_fd, G_rdd,
+                     G_bb, G_ab, G_aa, f2, ceps, hdiam, eta_loc);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
+}

@@ -184,3 +184,14 @@ def test_batched_reduced_solve_matches_single_and_oracle():
         ref = np.stack(rd.solve(mu))
         assert np.linalg.norm(ub[:, :, m] - ref) < 1e-10 * np.linalg.norm(ref)
         assert np.linalg.norm(us.cpu().numpy() - ref) < 1e-10 * np.linalg.norm(ref)
+    # E1 throughput form on the batched solutions == single-parameter kernel == oracle
+    ub_dev = eng.ctx.from_numpy(ub)
+    eta_b = eng.ctx.reduced_estimate_batch(thetas, ub_dev, buf['grams'], eng.f2, eng.ceps, eng.hdiam).cpu().numpy()
+    for m, mu in enumerate(mus):
+        um = np.ascontiguousarray(ub[:, :, m])
+        eta_s = eng.reduced_estimate(thetas[m], eng.ctx.from_numpy(um), buf['grams']).cpu().numpy()
+        _, (nc, r, df), _ = rd.estimate([um[ii] for ii in range(d.S)], mu, decompose=True)
+        for row, ref_row in enumerate((nc, r, df)):
+            scale = max(np.abs(ref_row).max(), 1e-300)
+            assert np.abs(eta_b[row, :, m] - ref_row).max() < 1e-9 * scale
+            assert np.abs(eta_s[row] - ref_row).max() < 1e-9 * scale
