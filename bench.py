@@ -236,11 +236,12 @@ def main():
         # FASTER than the canonical fp64-MFMA floor; what bounds it is HBM: every projected operator is written once
         # (3.3 GB at config 3) and the basis / operators are read once.  `achieved` uses the ALGORITHMIC bytes of
         # SURVEY 8(d) (8.74 MB per subdomain at config 3, intermediates W, R, D counted although the fused pass keeps
-        # them on chip); `traffic` is the measured HBM traffic per pass (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE,
-        # profiles/r01_v2_pmc_traffic.txt), only known for the profiled configuration.
+        # them on chip, and the two big Gram operators counted dense although they are stored block-compact);
+        # `traffic` is the measured HBM traffic per pass (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes,
+        # profiles/r01_final_pmc_traffic.txt), only known for the profiled configuration.
         traffic = None
         if args.config == 'cfg3' and world == 1:
-            traffic = (2 * 747.6 + 3470.7) * 1024 * 1024
+            traffic = (2 * 745.7 + 1869.2) * 1024 * 1024
         roofline = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': ach_gbs / PEAK_HBM_GBS, 'traffic': traffic,
                     'kernel': 'fused project+estimate pass: k_flux_compact, k_vertex_avg, k_f1, k_f2, k_f3, k_thin_nc, '
