@@ -88,7 +88,10 @@ def cpu_baseline(N, coarse, sample_subdomains=(16, 16), repeats=1):
     from oracle.lrbms import OracleReductor
     from pylrbms_amd import multiscale_problem
     p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(sample_subdomains), 'coarse_per_subdomain': coarse})
-    d = oracle_from_problem(p).precompute_blocks()
+    t_asm = time.perf_counter()
+    d = oracle_from_problem(p)
+    t_asm = time.perf_counter() - t_asm
+    d.precompute_blocks()
     V = make_bases_host(range(d.S), d.n, N)
     import multiprocessing as mp
     cores = min(os.cpu_count() or 1, 16)
@@ -105,6 +108,7 @@ def cpu_baseline(N, coarse, sample_subdomains=(16, 16), repeats=1):
             pool.map(_pool_reduce, chunks)
             allc = d.S / (time.perf_counter() - t0)
     return {'value': allc, 'unit': 'subdomains/s', 'cores': cores, 'kind': 'port', 'value_1core': one,
+            'assemble_subdomains_per_s_1core': d.S / t_asm,
             'sample': 'oracle.lrbms.OracleReductor.reduce() (NumPy/SciPy fp64) on {}x{} subdomains of the same synthetic '
                       'multiscale problem, N={}, k_c={}: value = target subdomains farmed over a {}-process pool '
                       '(1 BLAS thread each), value_1core = one process, one thread'
@@ -148,6 +152,13 @@ def main():
     eng = Engine(grid, lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], theta_bar,
                  device_index=local_rank)
     eng.assemble()
+    torch.cuda.synchronize()
+    ta0, ta1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ta0.record()
+    eng.assemble()                                   # K1-K6, K8 coefficients, K9 (reported separately)
+    ta1.record()
+    torch.cuda.synchronize()
+    assemble_ms = ta0.elapsed_time(ta1)
     t = grid.template
     S_total = grid.num_subdomains
 
@@ -258,6 +269,8 @@ def main():
                                               cfg['coarse_per_subdomain'], t.n, t.n_rt, Q, N),
                           'subdomains': S_total, 'N': N, 'Q': Q, 'parallelism': 'subdomain tiles x{}'.format(world)},
                'roofline': roofline}
+        out['assemble'] = {'metric': 'offline assembly K1-K6, K9 (+ flux coefficients)', 'ms': assemble_ms,
+                           'value': eng.S / (1e-3 * assemble_ms), 'unit': 'subdomains/s (this rank)'}
         if online is not None:
             out['online'] = online
         if not args.no_cpu_baseline:
