@@ -197,6 +197,24 @@ int lrbms_reduced_solve_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu,
                               const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
                               void* stream);
 
+/* -- online enrichment (SURVEY.md section 8f "next" #1) ---------------------------------------------------- */
+/* Dirichlet correction blocks of the neighbourhood problems: on every coupling face of subdomain s, the boundary-form
+ * diagonal block minus the inner-face block already contained in A_diag
+ * (make_elliptic_swipdg_matrix_operator_on_neighborhood with the all-Dirichlet local_boundary_info,
+ * block_swipdg.py:240-247, :794-795).   D_corr [Q][S][4][ncf][9], zero where there is no neighbour. */
+int lrbms_assemble_dirichlet_correction(lrbms_ctx* ctx, int32_t Q, const double* lam, double* D_corr, void* stream);
+
+/* DuneDiscretization.solve_for_local_correction (block_swipdg.py:227-316) for nmark marked subdomains at once:
+ * SWIPDG on N(ii) = ii + face neighbours with Dirichlet outer boundary, rhs = L2 functional of f, restricted to ii.
+ *   theta [Q] host, marked [nmark] host (subdomain indices), b [S][n], work (device, lrbms_local_correction_work_size
+ *   doubles), corr [nmark][n] out.  One workgroup per marked subdomain runs a block-Jacobi PCG in LDS / registers.
+ *   info (host, may be NULL) [nmark][2] = iterations, final relative residual.
+ * Returns LRBMS_E_NOT_CONVERGED if any neighbourhood is above rtol after max_iter.  Needs S_ext == S. */
+int64_t lrbms_local_correction_work_size(lrbms_ctx* ctx, int32_t nmark);
+int lrbms_local_correction_solve(lrbms_ctx* ctx, int32_t Q, const double* theta, int32_t nmark, const int32_t* marked,
+                                 const double* A_diag, const double* A_cpl, const double* D_corr, const double* b,
+                                 double* work, double* corr, double rtol, int32_t max_iter, double* info, void* stream);
+
 /* -- helpers used by the host shim and the parity tests ------------------------------------------------- */
 /* y [S][n][M] = blockELL(A [S][n_T][4][9]) x [S][n][M]   (diagonal blocks only, no coupling) */
 int lrbms_blockell_apply(lrbms_ctx* ctx, int32_t M, const double* A, const double* x, double* y, void* stream);

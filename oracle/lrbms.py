@@ -422,6 +422,85 @@ class OracleDiscretization:
         u = spla.spsolve(self.assemble_global(mu), self.b)
         return u.reshape(self.S, self.n)
 
+    # ------------------------------------------------------------------ online enrichment: local corrector problem
+    def local_correction_system(self, ii, mu):
+        """solve_for_local_correction (block_swipdg.py:227-316): the SWIPDG operator on the neighbourhood N(ii)
+        (``grid.neighborhood_of``: ii and its face neighbours) with the all-Dirichlet ``local_boundary_info`` of
+        :794-795 -- every face with exactly one side in N(ii) gets the boundary integrand seen from the inside
+        element -- and the L2 functional of f (:263-268).  Assembled from scratch on the faces of the neighbourhood
+        (not by editing the global matrix).  Returns (A_hood csr, b_hood, hood list, dof index array)."""
+        m = self.mesh
+        hood = sorted(m.neighborhood_of(ii))
+        inH = np.isin(m.elem_subdomain, hood)
+        Em, Ep = m.face_minus[:, 0], m.face_plus[:, 0]
+        m_in = inH[Em]
+        p_in = (Ep >= 0) & inH[np.maximum(Ep, 0)]
+        both = np.where(m_in & p_in)[0]
+        only_m = np.where(m_in & ~p_in)[0]
+        only_p = np.where(p_in & ~m_in)[0]
+        th = self.theta(mu)
+        e = np.einsum
+        elems = np.where(inH)[0]
+        A = None
+        for q, fn in enumerate(self.lambda_funcs):
+            lv = self.lam_vol[q]
+            lm_all, lp_all = self.lam_face[q]
+            lam_int = (lv[elems] * TRI_W[None, :]).sum(axis=1) * m.area[elems]
+            Aq = self._coo(elems, elems, lam_int[:, None, None] * self.stiff[elems])
+            # inner-face form on faces with both sides inside the neighbourhood
+            f = both
+            L = m.face_length[f]
+            wq = EDGE_W[None, :] * L[:, None]
+            lm, lp = lm_all[f], lp_all[f]
+            sigma = 0.5 * (lm + lp) * SIGMA_INNER_P1 * (0.5 * self.delta[f])[:, None] / (L[:, None] ** BETA_2D)
+            gm = lm[:, None, :] * self.gnm[f][:, :, None]
+            gp = lp[:, None, :] * self.gnp[f][:, :, None]
+            pm, pp = self.phim[f], self.phip[f]
+            mm = (-0.5 * e('fjk,fik,fk->fij', gm, pm, wq) - 0.5 * e('fjk,fik,fk->fij', pm, gm, wq)
+                  + e('fk,fjk,fik,fk->fij', sigma, pm, pm, wq))
+            mp = (-0.5 * e('fjk,fik,fk->fij', gp, pm, wq) + 0.5 * e('fjk,fik,fk->fij', pp, gm, wq)
+                  - e('fk,fjk,fik,fk->fij', sigma, pp, pm, wq))
+            pm_ = (0.5 * e('fjk,fik,fk->fij', gm, pp, wq) - 0.5 * e('fjk,fik,fk->fij', pm, gp, wq)
+                   - e('fk,fjk,fik,fk->fij', sigma, pm, pp, wq))
+            pp_ = (0.5 * e('fjk,fik,fk->fij', gp, pp, wq) + 0.5 * e('fjk,fik,fk->fij', pp, gp, wq)
+                   + e('fk,fjk,fik,fk->fij', sigma, pp, pp, wq))
+            Aq = Aq + (self._coo(Em[f], Em[f], mm) + self._coo(Em[f], Ep[f], mp) +
+                       self._coo(Ep[f], Em[f], pm_) + self._coo(Ep[f], Ep[f], pp_))
+            # Dirichlet form seen from the minus element (outward normal = face normal)
+            f = only_m
+            L = m.face_length[f]
+            wq = EDGE_W[None, :] * L[:, None]
+            lm = lm_all[f]
+            sigma = lm * SIGMA_BOUNDARY_P1 * self.delta[f][:, None] / (L[:, None] ** BETA_2D)
+            g = lm[:, None, :] * self.gnm[f][:, :, None]
+            pm = self.phim[f]
+            bm = (-e('fjk,fik,fk->fij', g, pm, wq) - e('fjk,fik,fk->fij', pm, g, wq)
+                  + e('fk,fjk,fik,fk->fij', sigma, pm, pm, wq))
+            Aq = Aq + self._coo(Em[f], Em[f], bm)
+            # ... and from the plus element (outward normal = - face normal)
+            f = only_p
+            L = m.face_length[f]
+            wq = EDGE_W[None, :] * L[:, None]
+            lp = lp_all[f]
+            sigma = lp * SIGMA_BOUNDARY_P1 * self.delta[f][:, None] / (L[:, None] ** BETA_2D)
+            g = -lp[:, None, :] * self.gnp[f][:, :, None]
+            pp = self.phip[f]
+            bp = (-e('fjk,fik,fk->fij', g, pp, wq) - e('fjk,fik,fk->fij', pp, g, wq)
+                  + e('fk,fjk,fik,fk->fij', sigma, pp, pp, wq))
+            Aq = Aq + self._coo(Ep[f], Ep[f], bp)
+            A = th[q] * Aq if A is None else A + th[q] * Aq
+        n = self.n
+        dofs = np.concatenate([np.arange(kk * n, (kk + 1) * n) for kk in hood])
+        A = A.tocsr()[dofs, :][:, dofs]
+        return A.tocsr(), self.b[dofs], hood, dofs
+
+    def solve_for_local_correction(self, ii, mu):
+        """The neighbourhood solution restricted to subdomain ii (block_swipdg.py:303-316); [n]."""
+        A, b, hood, _ = self.local_correction_system(ii, mu)
+        x = spla.spsolve(A.tocsc(), b)
+        k = hood.index(ii)
+        return x[k * self.n:(k + 1) * self.n]
+
     # ------------------------------------------------------------------ FOM estimate
     def estimate(self, U, mu, decompose=False, sqrt_local=False, alpha_first_only=True):
         """EllipticEstimator.estimate for a full-order block vector U [S, n] (estimators.py:45-112)."""

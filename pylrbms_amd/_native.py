@@ -52,6 +52,10 @@ SIGNATURES = {
     'lrbms_reduced_solve_batch_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_reduced_solve_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL,
                                                  c_vp]),
+    'lrbms_assemble_dirichlet_correction': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'lrbms_local_correction_work_size': (c_i64, [c_vp, c_i32]),
+    'lrbms_local_correction_solve': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_i32, _P_I32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl,
+                                                    c_i32, _P_DBL, c_vp]),
     'lrbms_blockell_apply': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'lrbms_fom_apply': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'lrbms_gemm_tn': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp,
@@ -384,6 +388,33 @@ class NativeContext:
                                                 c_vp(u.data_ptr()), float(rtol), int(max_iter), _dblp(info), self._stream())
         self._check(rc, 'lrbms_reduced_solve_batch')
         return u, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
+
+    # ------------------------------------------------------------------ online enrichment
+    def assemble_dirichlet_correction(self, lam):
+        Q = lam.shape[0]
+        D = self.empty(Q, self.S, 4, self.ncf, 9)
+        rc = self.lib.lrbms_assemble_dirichlet_correction(self.handle, Q, self._ptr(lam, (Q, self.S_ext, self.n_T, 16), 'lam'),
+                                                          c_vp(D.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_assemble_dirichlet_correction')
+        return D
+
+    def local_correction_solve(self, theta, marked, A_diag, A_cpl, D_corr, b, rtol=1e-12, max_iter=20000):
+        """marked: subdomain indices -> (corr [nmark, n], info [nmark, 2] = iterations, relative residual)."""
+        Q, S = A_diag.shape[0], self.S
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        assert th.shape == (Q,)
+        mk = np.ascontiguousarray(marked, dtype=np.int32)
+        nmark = int(mk.shape[0])
+        work = self.empty(int(self.lib.lrbms_local_correction_work_size(self.handle, nmark)))
+        corr = self.empty(nmark, self.n)
+        info = np.zeros((nmark, 2))
+        rc = self.lib.lrbms_local_correction_solve(
+            self.handle, Q, _dblp(th), nmark, mk.ctypes.data_as(_P_I32), self._ptr(A_diag, (Q, S, self.n_T, 4, 9), 'A_diag'),
+            self._ptr(A_cpl, (Q, S, 4, self.ncf, 9), 'A_cpl'), self._ptr(D_corr, (Q, S, 4, self.ncf, 9), 'D_corr'),
+            self._ptr(b, (S, self.n), 'b'), c_vp(work.data_ptr()), c_vp(corr.data_ptr()), float(rtol), int(max_iter),
+            _dblp(info), self._stream())
+        self._check(rc, 'lrbms_local_correction_solve')
+        return corr, info
 
     # ------------------------------------------------------------------ helpers
     def blockell_apply(self, A, x):

@@ -353,7 +353,52 @@ __global__ __launch_bounds__(256) void k_assemble_flux(Tmpl t, int S, int S_ext,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Neighbourhood (online enrichment) problems treat the outer boundary of N(ii) as a Dirichlet boundary
+// (block_swipdg.py:240-247 with the all-Dirichlet local_boundary_info of :794-795).  For a coupling face of
+// subdomain s that lies on such a boundary the diagonal block of the inside element changes from the inner-face
+// form (already summed into A_diag) to the boundary form:  D_corr = boundary_block - inner_self_block.
+// One thread per (s, e), grid.y = q; faces without a neighbouring subdomain keep D_corr = 0 (memset by the launcher).
+__global__ __launch_bounds__(256) void k_assemble_dcorr(Tmpl t, int S, int S_ext, const int* __restrict__ nbr,
+                                                        const double* __restrict__ lam, double* __restrict__ D_corr) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)S * t.nT) return;
+  const int q = blockIdx.y;
+  const int s = (int)(idx / t.nT), e = (int)(idx % t.nT);
+  const double* lam_q = lam + (long)q * S_ext * t.nT * LRBMS_NS;
+  const double* lam_e = lam_q + ((long)s * t.nT + e) * LRBMS_NS;
+  for (int f = 0; f < 3; ++f) {
+    const int nb = t.nb_elem[e * 3 + f];
+    if (nb >= 0) continue;
+    const int side = -1 - nb;
+    const int s2 = nbr[s * 5 + side_to_slot(side)];
+    if (s2 < 0) continue;
+    const double nx = t.normal[(e * 3 + f) * 2], ny = t.normal[(e * 3 + f) * 2 + 1];
+    const double len = t.face_len[e * 3 + f];
+    const double delta = n_kappa_n(t, nx, ny);
+    FaceSide m, p;
+    load_self_side(t, lam_e, e, f, nx, ny, m);
+    const int e2 = t.nb_elem_out[e * 3 + f];
+    load_other_side(t, lam_q + ((long)s2 * t.nT + e2) * LRBMS_NS, e2, t.nb_face_out[e * 3 + f], nx, ny, p);
+    double ss[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, so[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    swipdg_inner(m, p, len, delta, ss, so);
+    swipdg_boundary(m, len, delta, bd);
+    double* out = D_corr + ((((long)q * S + s) * 4 + side) * t.ncf + t.elem_side_pos[e * 3 + f]) * 9;
+    for (int i = 0; i < 9; ++i) out[i] = bd[i] - ss[i];
+  }
+}
+
 }  // namespace
+
+int launch_assemble_dcorr(lrbms_ctx* ctx, int Q, const double* lam, double* D_corr, hipStream_t st) {
+  const Tmpl& t = ctx->t;
+  LRBMS_HIP_CHECK(ctx, hipMemsetAsync(D_corr, 0, sizeof(double) * (size_t)Q * ctx->S * 4 * t.ncf * 9, st));
+  long total = (long)ctx->S * t.nT;
+  dim3 grid((unsigned)((total + 255) / 256), Q);
+  hipLaunchKernelGGL(k_assemble_dcorr, grid, dim3(256), 0, st, t, ctx->S, ctx->S_ext, ctx->nbr, lam, D_corr);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
+}
 
 int launch_assemble_swipdg(lrbms_ctx* ctx, int Q, const double* lam, double* A_diag, double* A_cpl, hipStream_t st) {
   const Tmpl& t = ctx->t;

@@ -14,6 +14,11 @@ int64_t reduced_solve_batch_work_size(lrbms_ctx* ctx, int N, int nmu);
 int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const double* theta, const double* B_sys,
                                const double* rhs_red, double* work, double* u, double rtol, int max_iter, double* info,
                                hipStream_t st);
+int launch_assemble_dcorr(lrbms_ctx* ctx, int Q, const double* lam, double* D_corr, hipStream_t st);
+int64_t local_correction_work_size(lrbms_ctx* ctx, int nmark);
+int launch_local_correction(lrbms_ctx* ctx, int Q, const double* theta, int nmark, const int32_t* marked, const double* A_diag,
+                            const double* A_cpl, const double* D_corr, const double* b, double* work, double* corr, double rtol,
+                            int max_iter, double* info, hipStream_t st);
 int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N);
 bool fused_supported(lrbms_ctx* ctx, int Q, int N);
 int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V, const double* F, const double* A_diag,
@@ -300,6 +305,25 @@ int lrbms_reduced_solve_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu,
   LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red);
   CHECK_PTR(ctx, work); CHECK_PTR(ctx, u);
   return launch_reduced_solve_batch(ctx, Q, N, nmu, theta, B_sys, rhs_red, work, u, rtol, max_iter, info, (hipStream_t)stream);
+}
+
+int lrbms_assemble_dirichlet_correction(lrbms_ctx* ctx, int32_t Q, const double* lam, double* D_corr, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, 1); CHECK_PTR(ctx, lam); CHECK_PTR(ctx, D_corr);
+  return launch_assemble_dcorr(ctx, Q, lam, D_corr, (hipStream_t)stream);
+}
+
+int64_t lrbms_local_correction_work_size(lrbms_ctx* ctx, int32_t nmark) {
+  if (!ctx || !ctx->has_mesh || nmark < 1) return -1;
+  return local_correction_work_size(ctx, nmark);
+}
+
+int lrbms_local_correction_solve(lrbms_ctx* ctx, int32_t Q, const double* theta, int32_t nmark, const int32_t* marked,
+                                 const double* A_diag, const double* A_cpl, const double* D_corr, const double* b,
+                                 double* work, double* corr, double rtol, int32_t max_iter, double* info, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, 1); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, marked); CHECK_PTR(ctx, A_diag);
+  CHECK_PTR(ctx, A_cpl); CHECK_PTR(ctx, D_corr); CHECK_PTR(ctx, b); CHECK_PTR(ctx, work); CHECK_PTR(ctx, corr);
+  return launch_local_correction(ctx, Q, theta, nmark, marked, A_diag, A_cpl, D_corr, b, work, corr, rtol, max_iter, info,
+                                 (hipStream_t)stream);
 }
 
 int lrbms_blockell_apply(lrbms_ctx* ctx, int32_t M, const double* A, const double* x, double* y, void* stream) {

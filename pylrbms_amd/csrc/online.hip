@@ -121,8 +121,12 @@ __global__ __launch_bounds__(64) void k_block_inverse(int N, const double* __res
   double* I = lds + N * N;   // [N][N]
   const double* src = Amu + ((long)s * 5 + 2) * N * N;
   for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
-    A[i] = src[i];
-    I[i] = (i / N == i % N) ? 1.0 : 0.0;
+    const bool diag = i / N == i % N;
+    const double a = src[i];
+    // a zero-padded basis column (ragged local basis sizes after online enrichment) has an exactly zero row and
+    // column: put 1 on its diagonal so that the padded unknown decouples and stays 0
+    A[i] = (diag && a == 0.0) ? 1.0 : a;
+    I[i] = diag ? 1.0 : 0.0;
   }
   __syncthreads();
   const int r = threadIdx.x;

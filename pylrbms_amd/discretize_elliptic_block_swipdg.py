@@ -7,7 +7,7 @@ the hot path: ``solve``, ``estimate``, ``operators[...]``, ``products['l2']``, `
 ``flux_reconstruction`` / ``oswald_interpolation_error``.  All arithmetic is done by the HIP kernels through
 ``pylrbms_amd.engine.Engine``; nothing here computes on the CPU besides coefficient sampling and index bookkeeping.
 
-Out of scope in this round: ``solve_for_local_correction`` (online enrichment), ``visualize``.
+Out of scope: ``visualize``.
 """
 import numpy as np
 
@@ -193,7 +193,27 @@ class DuneDiscretization:
         return self.estimator.estimate(U, self.parse_parameter(mu), self, decompose=decompose)
 
     def solve_for_local_correction(self, subdomain, Us, mu=None, inverse_options=None):
-        raise NotImplementedError('online enrichment (block_swipdg.py:227-316) is SURVEY.md section 8f "next" #1')
+        """block_swipdg.py:227-316.  ``Us`` (the current solution on the neighbourhood) is accepted and unused, as in
+        the reference, whose Dirichlet-lift functional is commented out (:250-261): the corrector is the solution of the
+        neighbourhood problem with homogeneous Dirichlet values on the outer boundary and right-hand side f."""
+        return self.solve_for_local_corrections([subdomain], mu, inverse_options=inverse_options)[0]
+
+    def solve_for_local_corrections(self, subdomains, mu=None, inverse_options=None):
+        """All corrector problems of one enrichment round in one launch (``lrbms_local_correction_solve``); returns
+        one single-vector array per subdomain, on the subdomain's local space."""
+        eng = self.engine
+        if eng.S_ext != eng.S:
+            raise NotImplementedError('local corrector solves on a sharded discretization')
+        opts = inverse_options if isinstance(inverse_options, dict) else {}
+        rtol = min(float(opts.get('precision', 1e-12)), 1e-10)
+        marked = [eng.local.index(int(ii)) for ii in subdomains]
+        corr, info = eng.local_corrections(self.theta(self.parse_parameter(mu)), marked, rtol=rtol)
+        self.last_local_correction_info = info
+        out = []
+        for k, i in enumerate(marked):
+            space = BlockVectorSpace([self.solution_space.subspaces[i]])
+            out.append(BlockVectorArray(corr[k].reshape(1, eng.t.n, 1), space))
+        return out
 
 
 def discretize(grid_and_problem_data, solver_options=None, mpi_comm=None, device_index=None):

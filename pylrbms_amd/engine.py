@@ -147,6 +147,16 @@ class Engine:
     def reduced_solve(self, theta, B_sys, rhs_red, rtol=1e-13, max_iter=20000):
         return self.ctx.reduced_solve(theta, B_sys, rhs_red, rtol=rtol, max_iter=max_iter)
 
+    # ------------------------------------------------------------------ online enrichment (section 8f "next" #1)
+    def local_corrections(self, theta, marked, rtol=1e-12, max_iter=20000):
+        """Neighbourhood corrector solves for the subdomains ``marked`` (local indices): [len(marked), n] + info."""
+        if not self.assembled:
+            raise NativeError('assemble() must run before local_corrections()')
+        if getattr(self, 'D_corr', None) is None:
+            self.D_corr = self.ctx.assemble_dirichlet_correction(self.lam)
+        return self.ctx.local_correction_solve(theta, marked, self.A_diag, self.A_cpl, self.D_corr, self.b, rtol=rtol,
+                                               max_iter=max_iter)
+
 
 # ---------------------------------------------------------------------- layout converters (host, for API / tests)
 def blockell_to_dense(template, vals):

@@ -1,9 +1,10 @@
 """Online adaptive enrichment (reference python/dune/pylrbms/online_enrichment.py:9-93).
 
 ``doerfler_marking`` is restated in full (pure host logic).  ``AdaptiveEnrichment`` keeps the reference's constructor
-and ``solve`` loop; the enrichment step itself (local corrector solves, ``reductor.enrich_local``) is the first "next"
-row of SURVEY.md section 8(f) and raises ``NotImplementedError`` in this round, so ``solve`` works whenever the
-estimated error is already below the target or ``enrichment_steps=0``."""
+and ``solve`` loop.  The enrichment step differs in how it is executed, not in what it computes: the reference calls
+``reductor.enrich_local`` for one marked subdomain after the other (:49-50); here all corrector problems of a round are
+solved by ONE kernel launch (one workgroup per marked neighbourhood, ``lrbms_local_correction_solve``) and the bases
+are extended by one masked Gram-Schmidt step, then ``reductor.reduce()`` re-runs the fused project+estimate pass."""
 import numpy as np
 
 
@@ -39,8 +40,11 @@ class AdaptiveEnrichment:
         marked_subdomains = set(doerfler_marking(indicators, self.marking_doerfler_theta))
         for ii in np.where(age_count > self.marking_max_age)[0]:
             marked_subdomains.add(ii)
-        for ii in marked_subdomains:
-            self.reductor.enrich_local(ii, U, mu)          # raises NotImplementedError in this round
+        if hasattr(self.reductor, 'enrich_local_batch'):
+            self.reductor.enrich_local_batch(sorted(marked_subdomains), U, mu)
+        else:
+            for ii in marked_subdomains:
+                self.reductor.enrich_local(ii, U, mu)
         self.rd = self.reductor.reduce()
         for ii in range(self.block_space.num_blocks):
             age_count[ii] = 1 if ii in marked_subdomains else age_count[ii] + 1
@@ -60,7 +64,7 @@ class AdaptiveEnrichment:
             if callback:
                 callback(self.rd, U, mu, {'eta': eta, 'local_problem_solves': local_problem_solves,
                                           'global RB size': self.rd.solution_space.dim,
-                                          'local RB sizes': [self.reductor.basis_size()] * self.block_space.num_blocks})
+                                          'local RB sizes': self.reductor.local_sizes()})
             if eta <= self.target_error:
                 return U, self.rd, self.reductor
             if enrichment_step > enrichment_steps:

@@ -8,8 +8,12 @@ bases (:51-60) and the Galerkin projection of the system and of every estimator 
 ``extend_basis`` restates the fork's ``GenericRBSystemReductor.extend_basis`` (absent from the tree; SURVEY.md
 section 8a row B1): per subdomain Gram-Schmidt against the local basis w.r.t. the supplied product (the local energy
 product, online_adaptive_lrbms.py:105-108), with re-orthogonalisation; products are applied with ``lrbms_blockell_apply``.
-This implementation keeps the local basis size uniform over subdomains (one HBM slab ``[S][n][N]``): an extension is
-all-or-nothing and raises ``ExtensionError`` if any block of the snapshot is numerically in the span of its basis.
+The local bases live in one HBM slab ``[S][n][N_max]``; a subdomain with fewer than ``N_max`` vectors (after online
+enrichment of only the marked subdomains, reductor.py:75-78) has zero columns behind its ``nloc[s]`` vectors.  Zero
+columns project to exactly zero rows / columns of every reduced operator, the reduced solve puts 1 on those diagonal
+entries (``k_block_inverse``), so the padded unknowns stay 0 and every kernel keeps its uniform shape.
+A global ``extend_basis`` is all-or-nothing and raises ``ExtensionError`` if any block of the snapshot is numerically
+in the span of its basis.
 """
 import numpy as np
 
@@ -33,7 +37,7 @@ class ReducedDiscretization:
         self.parameter_space = self.d.parameter_space
 
         class _Space:
-            dim = eng.grid.num_subdomains * N
+            dim = int(sum(reductor.local_sizes())) if eng.S == eng.grid.num_subdomains else eng.grid.num_subdomains * N
         self.solution_space = _Space
         self.operator = type('Op', (), {'source': _Space, 'range': _Space})
         self.operators = {'nc': self.grams[0], 'r_fd': self.grams[1], 'r_dd': self.grams[2], 'df_bb': self.grams[3],
@@ -88,9 +92,11 @@ class LRBMSReductor:
         self.products = products            # the local energy products; applied through the engine's P_diag
         self.num_cpus = num_cpus            # accepted and ignored, as in the reference (reductor.py:19)
         eng = d.engine
-        self._V = None                      # [S, n, N] device tensor
+        self._V = None                      # [S, n, N_max] device tensor
+        self._nloc = None                   # [S] host int array: number of basis vectors per local subdomain
         if bases is not None:
             self._V = self._bases_to_tensor(bases)
+            self._nloc = self._nloc_in
         if order is None and bases is None:
             order = 0
         if order is not None:
@@ -107,8 +113,9 @@ class LRBMSReductor:
             b = bases['domain_{}'.format(ii)]
             t = b.tensor[0] if isinstance(b, BlockVectorArray) else eng.ctx.from_numpy(np.asarray(b).T)
             blocks.append(t)
-        if len({tuple(b.shape) for b in blocks}) != 1:
-            raise NotImplementedError('local bases of different sizes (uniform N only)')
+        nmax = max(int(b.shape[1]) for b in blocks)
+        self._nloc_in = np.array([int(b.shape[1]) for b in blocks], dtype=np.int64)
+        blocks = [torch.nn.functional.pad(b, (0, nmax - int(b.shape[1]))) for b in blocks]   # ragged: zero columns
         return torch.stack(blocks).contiguous()
 
     @property
@@ -118,47 +125,102 @@ class LRBMSReductor:
         out = {}
         for i, ii in enumerate(eng.local):
             space = BlockVectorSpace([self.d.solution_space.subspaces[i]])
-            out['domain_{}'.format(ii)] = BlockVectorArray(self._V[i:i + 1], space) if self._V is not None else None
+            out['domain_{}'.format(ii)] = (BlockVectorArray(self._V[i:i + 1, :, :int(self._nloc[i])], space)
+                                           if self._V is not None else None)
         out.update(getattr(self, '_image_bases', {}))
         return out
 
     def basis_size(self):
+        """N_max: the width of the basis slab (== every local basis size while the bases are uniform)."""
         return 0 if self._V is None else int(self._V.shape[2])
+
+    def local_sizes(self):
+        """``[len(rb) for rb in reductor.bases]`` of online_enrichment.py:80."""
+        return [] if self._nloc is None else [int(v) for v in self._nloc]
 
     def _product_apply(self, X):
         """P X with P the local energy product (block-ELL) -- the product handed in at online_adaptive_lrbms.py:107."""
         return self.d.engine.ctx.blockell_apply(self.d.engine.P_diag, X.contiguous())
 
-    def _gram_schmidt_extend(self, U, atol=1e-13, rtol=1e-10):
-        """Orthonormalise the columns of U [S, n, L] against the current local bases and each other."""
+    def _orthonormalize_against_basis(self, v, atol=1e-13, rtol=1e-10):
+        """Gram-Schmidt (one re-orthogonalisation) of the single-column slab ``v`` [S, n, 1] against the local bases in
+        the energy product.  Returns the normalised slab and the per-subdomain mask of blocks that were NOT
+        (numerically) in the span of their basis."""
         import torch
         V = self._V
+        v = v.clone()
+        norm0 = torch.sqrt(torch.clamp((v * self._product_apply(v)).sum(dim=(1, 2)), min=0.0))
+        for _ in range(2):
+            if V is not None:
+                coef = torch.einsum('snk,snl->skl', V, self._product_apply(v))     # zero-padded columns give 0
+                v = v - torch.einsum('snk,skl->snl', V, coef)
+        norm = torch.sqrt(torch.clamp((v * self._product_apply(v)).sum(dim=(1, 2)), min=0.0))
+        ok = (norm > atol) & (norm > rtol * norm0)
+        v = torch.where(ok[:, None, None], v / torch.where(ok, norm, torch.ones_like(norm))[:, None, None],
+                        torch.zeros_like(v))
+        return v, ok
+
+    def _append_columns(self, v, ok):
+        """Write block s of ``v`` behind the ``nloc[s]`` vectors of subdomain s for every s with ``ok[s]``."""
+        import torch
+        eng = self.d.engine
+        ok_host = ok.cpu().numpy().astype(bool)
+        if self._V is None:
+            self._V = eng.ctx.zeros(eng.S, eng.t.n, 1)
+            self._nloc = np.zeros(eng.S, dtype=np.int64)
+        idx = np.where(ok_host)[0]
+        if len(idx) == 0:
+            return ok_host
+        if int(self._nloc[idx].max()) + 1 > self._V.shape[2]:
+            self._V = torch.cat([self._V, eng.ctx.zeros(eng.S, eng.t.n, 1)], dim=2).contiguous()
+        rows = torch.as_tensor(idx, device=self._V.device)
+        cols = torch.as_tensor(self._nloc[idx], device=self._V.device)
+        self._V[rows, :, cols] = v[rows, :, 0]
+        self._nloc[idx] += 1
+        return ok_host
+
+    def _gram_schmidt_extend(self, U):
+        """Extend EVERY local basis by the columns of U [S, n, L], one after the other (all-or-nothing per column)."""
+        eng = self.d.engine
         for k in range(U.shape[2]):
-            v = U[:, :, k:k + 1].clone()
-            norm0 = torch.sqrt((v * self._product_apply(v)).sum(dim=(1, 2)))
-            for _ in range(2):                                           # re-orthogonalise once
-                if V is not None:
-                    coef = torch.einsum('snk,snl->skl', V, self._product_apply(v))
-                    v = v - torch.einsum('snk,skl->snl', V, coef)
-            norm = torch.sqrt(torch.clamp((v * self._product_apply(v)).sum(dim=(1, 2)), min=0.0))
-            if bool(((norm <= atol) | (norm <= rtol * norm0)).any()):
+            if self._V is None:
+                self._V = eng.ctx.zeros(eng.S, eng.t.n, 0)
+                self._nloc = np.zeros(eng.S, dtype=np.int64)
+            v, ok = self._orthonormalize_against_basis(U[:, :, k:k + 1])
+            if not bool(ok.all()):
                 raise ExtensionError('snapshot block is (numerically) in the span of its local basis')
-            v = v / norm[:, None, None]
-            V = v if V is None else torch.cat([V, v], dim=2)
-        self._V = V.contiguous()
+            self._append_columns(v, ok)
 
     def extend_basis(self, U):
         """Restrict a global snapshot to every subdomain and extend all local bases (fork ``extend_basis``)."""
         self._gram_schmidt_extend(U.tensor)
 
     def extend_basis_local(self, U, _defer=False):
-        """Reference reductor.py:31,78: extend the basis of the one subdomain ``U`` lives on.  Uniform sizes are kept by
-        collecting one vector per subdomain before the slab grows (``_defer``); a lone local extension is not
-        supported in this round (it belongs to online enrichment)."""
-        if not _defer:
-            raise NotImplementedError('lone local basis extension (online enrichment) is not in this round')
-        self._pending = getattr(self, '_pending', [])
-        self._pending.append(U.tensor)
+        """Reference reductor.py:31,78: extend the basis of the ONE subdomain the single-block array ``U`` lives on.
+        ``_defer`` collects one vector per subdomain (constructor, reductor.py:29-31) and extends all at once."""
+        if _defer:
+            self._pending = getattr(self, '_pending', [])
+            self._pending.append(U.tensor)
+            return
+        eng = self.d.engine
+        ii = int(str(U.space.subspaces[0].id).split('_')[1])
+        ok = self._extend_marked([eng.local.index(ii)], U.tensor[:, :, :1])
+        if not ok[0]:
+            raise ExtensionError('local correction is (numerically) in the span of the local basis')
+
+    def _extend_marked(self, marked, vecs):
+        """Extend the bases of the local subdomains ``marked`` by the blocks ``vecs`` [len(marked), n, 1]; returns the
+        per-entry success flags (a block in the span of its basis is skipped)."""
+        import torch
+        eng = self.d.engine
+        full = eng.ctx.zeros(eng.S, eng.t.n, 1)
+        rows = torch.as_tensor(np.asarray(marked, dtype=np.int64), device=full.device)
+        full[rows] = vecs
+        v, ok = self._orthonormalize_against_basis(full)
+        mask = torch.zeros(eng.S, dtype=torch.bool, device=full.device)
+        mask[rows] = True
+        ok_host = self._append_columns(v, ok & mask)
+        return [bool(ok_host[i]) for i in marked]
 
     def _flush_local(self):
         import torch
@@ -195,8 +257,23 @@ class LRBMSReductor:
         return rec.block(i)
 
     def enrich_local(self, subdomain, U, mu=None):
-        """Reference reductor.py:75-78."""
-        raise NotImplementedError('online enrichment is SURVEY.md section 8f "next" #1')
+        """Reference reductor.py:75-78: corrector solve on the neighbourhood of ``subdomain``, then extend its basis."""
+        Us = None   # reconstruct_local of the neighbourhood (reductor.py:76) feeds only the commented-out Dirichlet lift
+        local_correction = self.d.solve_for_local_correction(subdomain, Us, mu, inverse_options=self.solver_options)
+        self.extend_basis_local(local_correction)
+
+    def enrich_local_batch(self, subdomains, U, mu=None):
+        """The loop of online_enrichment.py:49-50 as one batched corrector solve + one masked Gram-Schmidt step.
+        Returns the list of subdomains whose basis grew (a correction already in the span of its basis is skipped)."""
+        subdomains = [int(ii) for ii in subdomains]
+        if not subdomains:
+            return []
+        eng = self.d.engine
+        corrections = self.d.solve_for_local_corrections(subdomains, mu, inverse_options=self.solver_options)
+        import torch
+        vecs = torch.cat([c.tensor for c in corrections], dim=0)
+        ok = self._extend_marked([eng.local.index(ii) for ii in subdomains], vecs)
+        return [ii for ii, flag in zip(subdomains, ok) if flag]
 
 
 class ParallelLRBMSReductor(LRBMSReductor):

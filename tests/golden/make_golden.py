@@ -48,6 +48,8 @@ def build(name):
         'nc_centre': rd.nc[centre], 'r_dd_centre': rd.r_dd[centre], 'df_bb_centre': rd.df_bb[centre],
         'u': u, 'eta': np.array([eta]), 'eta_nc': nc, 'eta_r': r, 'eta_df': df, 'indicators': ind,
         'fom_u': U, 'fom_eta': np.array([eta_f]), 'fom_eta_nc': ncf, 'fom_eta_r': rf, 'fom_eta_df': dff,
+        # online enrichment: neighbourhood corrector of every subdomain at mu (block_swipdg.py:227-316)
+        'local_correction': np.stack([d.solve_for_local_correction(ii, mu) for ii in range(d.S)]),
     }
     return p, out
 

@@ -81,8 +81,8 @@ def test_reference_driver_sequence_os2015():
                               marking_max_age=0)
     U, rd2, _ = loop.solve(0.5, enrichment_steps=1)
     assert rd2 is rd and len(U) == 1
-    with pytest.raises(NotImplementedError):
-        reductor.enrich_local(0, U, None)
+    reductor.enrich_local(0, U, 0.5)                               # reductor.py:75-78 (tests/test_enrichment_gpu.py)
+    assert reductor.local_sizes() == [4, 3, 3, 3]
 
 
 def test_reference_driver_sequence_thermalblock():

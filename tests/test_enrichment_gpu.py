@@ -1,0 +1,169 @@
+"""Online enrichment (SURVEY.md section 8f "next" #1) on the GPU against the oracle:
+``DuneDiscretization.solve_for_local_correction`` (reference discretize_elliptic_block_swipdg.py:227-316),
+``LRBMSReductor.enrich_local`` (reductor.py:75-78) and the ``AdaptiveEnrichment`` loop (online_enrichment.py:25-93).
+
+The corrector problems are solved iteratively on the GPU (block-Jacobi PCG, rtol 1e-12) and directly by the oracle
+(SuperLU): the stated tolerance for the correction vectors is 1e-8 relative to the largest entry.  Reduced quantities
+on the ragged bases the enrichment produces are compared at 1e-7."""
+import numpy as np
+import pytest
+
+from common import oracle_from_problem
+from oracle.lrbms import OracleReductor
+
+pytestmark = pytest.mark.gpu
+
+CORR_TOL = 1e-8
+
+
+def _problem(name, config):
+    import importlib
+    return importlib.import_module('pylrbms_amd.' + name).init_grid_and_problem(config)
+
+
+@pytest.mark.parametrize('name,config,mu', [
+    ('multiscale_problem', {'num_subdomains': [3, 4], 'coarse_per_subdomain': 2}, 0.37),          # n = 96, all hood shapes
+    ('OS2015_academic_problem', {'num_subdomains': [4, 4], 'half_num_fine_elements_per_subdomain_and_dim': 16}, 0.1),  # n = 384
+    ('thermalblock_problem', {'num_subdomains': [2, 2], 'half_num_fine_elements_per_subdomain_and_dim': 8},
+     (0.4, 0.9, 0.2, 0.6)),                                                                       # Q = 4, every hood has 3 members
+    ('multiscale_problem', {'num_subdomains': [3, 3], 'coarse_per_subdomain': 6}, 1.0),           # n_T = 288: 2 elements / thread
+    ('multiscale_problem', {'num_subdomains': [2, 2], 'coarse_per_subdomain': 3}, 0.6),           # odd k, corner hoods only
+    ('OS2015_academic_problem', {'num_subdomains': [1, 3], 'half_num_fine_elements_per_subdomain_and_dim': 6}, 0.5),  # kx != ky, strip
+])
+def test_local_corrections_match_the_oracle(name, config, mu):
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    p = _problem(name, config)
+    d, _ = discretize(p)
+    o = oracle_from_problem(p)
+    subdomains = list(range(o.S))
+    got = d.solve_for_local_corrections(subdomains, mu)
+    info = d.last_local_correction_info
+    assert info.shape == (o.S, 2) and (info[:, 1] <= 1e-10).all() and (info[:, 0] >= 1).all()
+    for ii in subdomains:
+        ref = o.solve_for_local_correction(ii, mu)
+        x = got[ii].data.reshape(-1)
+        assert got[ii].space.subspaces[0].id == 'domain_{}'.format(ii)
+        assert np.abs(x - ref).max() < CORR_TOL * np.abs(ref).max(), (ii, np.abs(x - ref).max() / np.abs(ref).max())
+    # the single-subdomain entry point of the reference API gives the same vector (bit-identical: same kernel, same order)
+    one = d.solve_for_local_correction(subdomains[-1], None, mu)
+    assert np.array_equal(one.data, got[-1].data)
+
+
+def test_whole_domain_neighbourhood_reproduces_the_global_solution():
+    """3 x 1 subdomains: N(1) is the whole domain and its Dirichlet boundary is the physical one, so the corrector of
+    the middle subdomain IS the full-order solution there (size-independent consistency property)."""
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    p = _problem('OS2015_academic_problem', {'num_subdomains': [3, 1], 'half_num_fine_elements_per_subdomain_and_dim': 12})
+    d, _ = discretize(p)
+    U = d.solve(0.3).data.reshape(3, -1)
+    c = d.solve_for_local_correction(1, None, 0.3).data.reshape(-1)
+    assert np.abs(c - U[1]).max() < 1e-8 * np.abs(U[1]).max()
+
+
+def test_indefinite_neighbourhood_operator_is_reported():
+    """1 x 3 subdomains of 3 x 3 coarse squares on the unit square have elements of aspect ratio 3, for which the SWIPDG
+    penalties (8 / 14) do not make the form coercive: the oracle's neighbourhood matrix has a negative eigenvalue.  The
+    PCG must say so (p.Ap <= 0 -> LRBMS_E_NOT_CONVERGED), never return numbers."""
+    from pylrbms_amd._native import NativeError
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    p = _problem('multiscale_problem', {'num_subdomains': [1, 3], 'coarse_per_subdomain': 3})
+    o = oracle_from_problem(p)
+    A, _, _, _ = o.local_correction_system(0, 0.6)
+    assert np.linalg.eigvalsh(A.toarray()).min() < 0.0
+    d, _ = discretize(p)
+    with pytest.raises(NativeError, match='not SPD'):
+        d.solve_for_local_corrections([0], 0.6)
+
+
+def test_local_correction_argument_checks():
+    from pylrbms_amd._native import NativeError
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    p = _problem('multiscale_problem', {'num_subdomains': [2, 2], 'coarse_per_subdomain': 2})
+    d, _ = discretize(p)
+    eng = d.engine
+    with pytest.raises(NativeError):
+        eng.local_corrections(d.theta(0.5), [7])                 # subdomain index out of range
+    with pytest.raises(NativeError):
+        eng.local_corrections(d.theta(0.5), [0], max_iter=2)     # not converged is an error, not a silent result
+
+
+def test_enrich_local_and_ragged_reduced_model_match_the_oracle():
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    from pylrbms_amd.reductor import ExtensionError, LRBMSReductor
+    p = _problem('OS2015_academic_problem', {'num_subdomains': [3, 3], 'half_num_fine_elements_per_subdomain_and_dim': 12})
+    d, data = discretize(p)
+    o = oracle_from_problem(p)
+    reductor = LRBMSReductor(d, order=0)
+    reductor.extend_basis(d.solve(1.0))
+    mu = 0.1
+    rd = reductor.reduce()
+    U = rd.solve(mu)
+    # reference API, one subdomain (reductor.py:75-78) ...
+    reductor.enrich_local(4, U, mu)
+    assert reductor.local_sizes() == [2, 2, 2, 2, 3, 2, 2, 2, 2]
+    with pytest.raises(ExtensionError):
+        reductor.enrich_local(4, U, mu)                          # the corrector depends on (ii, mu) only: now in the span
+    # ... and the batched form used by AdaptiveEnrichment
+    grown = reductor.enrich_local_batch([0, 4, 8], U, mu)
+    assert grown == [0, 8] and reductor.local_sizes() == [3, 2, 2, 2, 3, 2, 2, 2, 3]
+    bases = reductor.bases
+    V = [bases['domain_{}'.format(ii)].tensor[0].cpu().numpy() for ii in range(o.S)]
+    assert [v.shape[1] for v in V] == reductor.local_sizes()
+    # the new vector spans the oracle's corrector together with the old basis
+    ref = o.solve_for_local_correction(4, mu)
+    coef, res, *_ = np.linalg.lstsq(V[4], ref, rcond=None)
+    assert np.abs(V[4] @ coef - ref).max() < 1e-7 * np.abs(ref).max()
+
+    rd = reductor.reduce()
+    assert rd.solution_space.dim == sum(reductor.local_sizes())
+    u = rd.solve(mu)
+    ored = OracleReductor(o, V).reduce()
+    u_o = ored.solve(mu)
+    N = reductor.basis_size()
+    for ii in range(o.S):
+        got = u.tensor[ii, :, 0].cpu().numpy()
+        assert np.abs(got[:len(u_o[ii])] - u_o[ii]).max() < 1e-7 * max(np.abs(x).max() for x in u_o)
+        assert (got[len(u_o[ii]):] == 0.0).all()                 # padded unknowns stay exactly zero
+    eta, (nc, r, df), ind = rd.estimate(u, mu=mu, decompose=True)
+    eta_o, (nc_o, r_o, df_o), ind_o = ored.estimate(u_o, mu, decompose=True)
+    assert abs(eta - eta_o) < 1e-7 * eta_o
+    for a, b in ((nc[:, 0], nc_o), (r[:, 0], r_o), (df[:, 0], df_o)):
+        assert np.abs(a - b).max() < 1e-7 * np.abs(b).max()
+    assert N == 3
+
+
+def test_adaptive_enrichment_loop():
+    """online_adaptive_lrbms.py:121-139 / online_enrichment.py:63-93.  At the reference's HEAD the corrector depends on
+    (subdomain, mu) only (the Dirichlet lift by the current solution is commented out, block_swipdg.py:250-261), so for
+    one mu every subdomain can gain exactly one vector; the loop is checked for its mechanics (Doerfler + age marking,
+    ragged growth, step limit) and its final estimate against the oracle on the very same bases."""
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    from pylrbms_amd.online_enrichment import AdaptiveEnrichment
+    from pylrbms_amd.reductor import LRBMSReductor
+    p = _problem('OS2015_academic_problem', {'num_subdomains': [4, 4], 'half_num_fine_elements_per_subdomain_and_dim': 16})
+    d, data = discretize(p)
+    o = oracle_from_problem(p)
+    reductor = LRBMSReductor(d, order=0)
+    rd = reductor.reduce()
+    mu = d.parse_parameter(0.1)
+    eta0 = rd.estimate(rd.solve(mu), mu=mu)
+    history = []
+    loop = AdaptiveEnrichment(p, d, data['block_space'], reductor, rd, target_error=1e-3, marking_doerfler_theta=0.8,
+                              marking_max_age=2)
+    U, rd2, red2 = loop.solve(mu, enrichment_steps=4, callback=lambda rd_, U_, mu_, info: history.append(dict(info)))
+    assert red2 is reductor and rd2 is loop.rd and len(history) == 5
+    assert history[0]['eta'] == pytest.approx(eta0, rel=1e-12) and history[0]['local_problem_solves'] == 0
+    for h in history:
+        assert h['global RB size'] == sum(h['local RB sizes'])
+    assert 1 <= history[1]['local_problem_solves'] < 16            # Doerfler marking picks a strict subset first
+    assert sorted(set(history[1]['local RB sizes'])) == [1, 2]     # ragged after the first round
+    assert history[-1]['local RB sizes'] == [2] * 16               # age marking reaches everyone within 3 rounds
+    # final state against the oracle on the same (device-built) bases
+    V = [reductor.bases['domain_{}'.format(ii)].tensor[0].cpu().numpy() for ii in range(o.S)]
+    oreductor = OracleReductor(o, V)
+    ored = oreductor.reduce()
+    u_o = ored.solve(0.1)
+    eta_o = ored.estimate(u_o, 0.1)
+    assert abs(history[-1]['eta'] - eta_o) < 1e-7 * eta_o
+    rec_o = np.stack(oreductor.reconstruct(u_o))
+    assert np.abs(reductor.reconstruct(U).data.reshape(o.S, o.n) - rec_o).max() < 1e-7 * np.abs(rec_o).max()

@@ -142,3 +142,20 @@ def test_oracle_reproduces_golden_fixtures(name):
         a, b = np.asarray(out[key], dtype=np.float64), ref[key]
         assert a.shape == b.shape, key
         assert np.abs(a - b).max() <= 1e-9 * max(np.abs(b).max(), 1e-300), key
+
+
+def test_local_correction_on_a_whole_domain_neighbourhood_is_the_global_solution():
+    """Pins the from-scratch neighbourhood assembly (block_swipdg.py:227-316) against the global one: for 3 x 1
+    subdomains N(1) is the whole domain, its Dirichlet boundary the physical one."""
+    from pylrbms_amd import OS2015_academic_problem
+    p = OS2015_academic_problem.init_grid_and_problem({'num_subdomains': [3, 1],
+                                                       'half_num_fine_elements_per_subdomain_and_dim': 6})
+    d = oracle_from_problem(p)
+    u = d.solve(0.3)
+    x = d.solve_for_local_correction(1, 0.3)
+    assert np.abs(u[1] - x).max() < 1e-12 * np.abs(u[1]).max()
+    # a proper neighbourhood: symmetric positive definite, and NOT the global solution (Dirichlet cut-off)
+    A, b, hood, dofs = d.local_correction_system(0, 0.3)
+    assert hood == [0, 1] and A.shape == (2 * d.n, 2 * d.n)
+    assert abs(A - A.T).max() < 1e-13 and np.linalg.eigvalsh(A.toarray()).min() > 0.0
+    assert np.abs(d.solve_for_local_correction(0, 0.3) - u[0]).max() > 1e-3 * np.abs(u[0]).max()

@@ -115,6 +115,9 @@ def test_golden_fixtures(name):
     etaU = host(eng.reduced_estimate(theta, eng.ctx.from_numpy(np.ones((S, 1))), bufU['grams']))
     for row, key in enumerate(('fom_eta_nc', 'fom_eta_r', 'fom_eta_df')):
         assert np.abs(etaU[row] - ref[key]).max() < 1e-9 * max(np.abs(ref[key]).max(), 1e-300), key
+    # online enrichment correctors (iterative on the GPU, direct in the oracle: 1e-8)
+    corr, _ = eng.local_corrections(theta, list(range(S)))
+    assert np.abs(host(corr) - ref['local_correction']).max() < 1e-8 * np.abs(ref['local_correction']).max()
 
 
 def test_full_size_properties_config2():
