@@ -107,8 +107,14 @@ def cpu_baseline(N, coarse, sample_subdomains=(16, 16), repeats=1):
             t0 = time.perf_counter()
             pool.map(_pool_reduce, chunks)
             allc = d.S / (time.perf_counter() - t0)
+        # online enrichment: the oracle's neighbourhood corrector (sparse direct solve) on a few interior subdomains
+        picks = [d.S // 2 + k for k in range(4)]
+        t0 = time.perf_counter()
+        for ii in picks:
+            d.solve_for_local_correction(ii, 0.3)
+        corr = len(picks) / (time.perf_counter() - t0)
     return {'value': allc, 'unit': 'subdomains/s', 'cores': cores, 'kind': 'port', 'value_1core': one,
-            'assemble_subdomains_per_s_1core': d.S / t_asm,
+            'assemble_subdomains_per_s_1core': d.S / t_asm, 'local_correction_solves_per_s_1core': corr,
             'sample': 'oracle.lrbms.OracleReductor.reduce() (NumPy/SciPy fp64) on {}x{} subdomains of the same synthetic '
                       'multiscale problem, N={}, k_c={}: value = target subdomains farmed over a {}-process pool '
                       '(1 BLAS thread each), value_1core = one process, one thread'
@@ -234,6 +240,23 @@ def main():
                   'solver': 'block-Jacobi PCG on the block-sparse reduced system, rtol 1e-12; estimates: '
                             'lrbms_reduced_estimate_batch (local nc / r / df terms of every subdomain)'}
 
+    enrichment = None
+    if world == 1 and not args.no_online:
+        # online enrichment: the neighbourhood corrector problems of ALL subdomains in one launch
+        # (5 * 384 = 1920 unknowns each at config 3), block-Jacobi PCG to rtol 1e-12 inside one workgroup per problem
+        th = np.array([c.evaluate(0.3) for c in lam['coefficients']])
+        marked = list(range(eng.S))
+        eng.local_corrections(th, marked[:8])                                        # warm-up (also assembles D_corr)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _, cinfo = eng.local_corrections(th, marked)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        enrichment = {'metric': 'neighbourhood corrector solves (solve_for_local_correction)', 'value': len(marked) / dt,
+                      'unit': 'local solves/s', 'problems': len(marked), 'unknowns_per_problem': 5 * t.n, 'ms': 1e3 * dt,
+                      'cg_iterations_max': int(cinfo[:, 0].max()), 'cg_iterations_mean': float(cinfo[:, 0].mean()),
+                      'relative_residual_max': float(cinfo[:, 1].max())}
+
     if rank == 0:
         Q = eng.Q
         flops = algorithmic_flops_per_subdomain(t.n, t.n_rt, t.n_T, N, Q)
@@ -273,6 +296,8 @@ def main():
                            'value': eng.S / (1e-3 * assemble_ms), 'unit': 'subdomains/s (this rank)'}
         if online is not None:
             out['online'] = online
+        if enrichment is not None:
+            out['enrichment'] = enrichment
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(N, cfg['coarse_per_subdomain'])
         print(json.dumps(out), flush=True)
