@@ -26,7 +26,9 @@ CONFIGS = {
     'cfg2': {'num_subdomains': [8, 8], 'N': 20, 'coarse_per_subdomain': 4},
     'cfg3': {'num_subdomains': [32, 32], 'N': 40, 'coarse_per_subdomain': 4},
     # diagnostics: what ONE rank of the 8-GPU run of config 3 holds (16x8 tile), without the halo exchange
-    'cfg3_tile8': {'num_subdomains': [16, 8], 'N': 40, 'coarse_per_subdomain': 4},
+    'cfg3_tile8': {'num_subdomains': [16, 8], 'N': 40, 'coarse_per_subdomain': 4},    # per-rank tiles of the 8/4/2-GPU runs
+    'cfg3_tile4': {'num_subdomains': [16, 16], 'N': 40, 'coarse_per_subdomain': 4},
+    'cfg3_tile2': {'num_subdomains': [32, 16], 'N': 40, 'coarse_per_subdomain': 4},
 }
 
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (HBM3E spec) and SURVEY.md section 8d (fp64 matrix)

@@ -982,7 +982,11 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // fork: F2 / F3, the thin kernels and the coupling projection are independent of each other and of F1 (they all read
   // only V and the two prepare kernels' outputs); on separate streams their workgroups interleave on the CUs, which
   // hides the latencies each of them exposes when it runs alone (they are latency-, not throughput-bound)
-  const bool multi = getenv("LRBMS_STREAMS") != nullptr;   // measured on MI355X / ROCm 7.2: 1.92 ms vs 1.81 ms serial -> off by default
+  // Measured on MI355X / ROCm 7.2 (config 3 tiles): S = 128: 0.32 ms forked vs 0.41 ms serial (no kernel fills 256 CUs alone);
+  // S = 256: 0.53 vs 0.51; S = 512: 0.97 vs 0.93; S = 1024: 1.92 vs 1.81 -> fork only below 192 subdomains per rank.
+  // LRBMS_STREAMS=0 / 1 overrides.
+  const char* env_streams = getenv("LRBMS_STREAMS");
+  const bool multi = env_streams ? env_streams[0] != '0' : S < 192;
   hipStream_t s_rt = multi ? ctx->aux[0] : st, s_f23 = multi ? ctx->aux[1] : st, s_nc = multi ? ctx->aux[2] : st;
   hipStream_t side = s_nc;
   if (multi) {

@@ -138,14 +138,69 @@ def test_full_size_properties_config2():
             assert float((G[:, b] - G[:, b].transpose(1, 2)).abs().max()) <= 1e-12 * float(G.abs().max())
     B_sys = buf['sys'][0]
     assert float((B_sys[:, :, 2] - B_sys[:, :, 2].transpose(2, 3)).abs().max()) <= 1e-12 * float(B_sys.abs().max())
-    ref = torch.matmul(buf['Wt'].transpose(1, 2), buf['Wt'])
-    got = eng.ctx.gemm_tn(buf['Wt'], buf['Wt'])
+    X = eng.ctx.from_numpy(np.random.default_rng(3).standard_normal((S, n, 5 * N)))
+    ref = torch.matmul(X.transpose(1, 2), X)
+    got = eng.ctx.gemm_tn(X, X)
     assert float((ref - got).abs().max()) <= 1e-12 * float(ref.abs().max())
     theta = theta_of(p, 0.35)
     rng = np.random.default_rng(5)
     u = eng.ctx.from_numpy(rng.standard_normal((S, N)))
     eta = eng.reduced_estimate(theta, u, buf['grams'])
     U = torch.einsum('snk,sk->sn', V, u)[:, :, None].contiguous()
+    bufU = eng.project_and_estimate(U, project_system=False)
+    etaU = eng.reduced_estimate(theta, eng.ctx.from_numpy(np.ones((S, 1))), bufU['grams'])
+    scale = etaU.abs().max(dim=1, keepdim=True).values
+    assert float(((eta - etaU).abs() / scale).max()) < 1e-9
+
+
+def test_full_size_properties_config3(monkeypatch):
+    """BASELINE.json config 3 at full size (32x32 subdomains, N = 40: the benchmark workload).  Size-independent
+    properties: the fused pass gives bit-identical results with its kernels serial or forked over the library's
+    streams (every reduction has a fixed order), every symmetric operator is symmetric, the energy Gram of an
+    energy-orthonormal basis is the identity, and the reduced estimate is linear in the sense of the config-2 test."""
+    import torch
+    from pylrbms_amd import multiscale_problem
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': [32, 32], 'coarse_per_subdomain': 4})
+    eng = _engine(p)
+    S, n, N = eng.S, eng.t.n, 40
+    assert eng.ctx.fused_supported(eng.Q, N)
+    V = eng.ctx.from_numpy(make_bases(S, n, N, seed=4))
+    monkeypatch.setenv('LRBMS_STREAMS', '0')
+    buf = eng.project_and_estimate(V)
+    serial = [x.clone() for x in buf['sys']] + [x.clone() for x in buf['grams']]
+    monkeypatch.setenv('LRBMS_STREAMS', '1')
+    buf = eng.project_and_estimate(V, buf)
+    forked = list(buf['sys']) + list(buf['grams'])
+    for a, b in zip(serial, forked):
+        assert torch.equal(a, b)
+    monkeypatch.delenv('LRBMS_STREAMS')
+    del serial
+    G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = buf['grams']
+    assert float((G_nc - G_nc.transpose(1, 2)).abs().max()) <= 1e-12 * float(G_nc.abs().max())
+    for G in (G_rdd, G_bb):
+        for b in (0, 5, 6, 7, 8):
+            assert float((G[:, b] - G[:, b].transpose(1, 2)).abs().max()) <= 1e-12 * float(G.abs().max())
+    B_sys, rhs_red, E_red, M_red = buf['sys']
+    assert float((B_sys[:, :, 2] - B_sys[:, :, 2].transpose(2, 3)).abs().max()) <= 1e-12 * float(B_sys.abs().max())
+    # coupling blocks: block [s, slot] is the transpose of block [nbr(s, slot), 4 - slot]
+    nbr = torch.as_tensor(eng.nbr.astype(np.int64), device=B_sys.device)
+    for slot in (0, 1):
+        s_idx = torch.nonzero(nbr[:, slot] >= 0)[:, 0]
+        other = nbr[s_idx, slot]
+        for q in range(eng.Q):
+            a = B_sys[q, s_idx, slot]
+            b = B_sys[q, other, 4 - slot].transpose(1, 2)
+            assert float((a - b).abs().max()) <= 1e-12 * float(B_sys.abs().max())
+    # energy-orthonormalise with the projected energy product, project again: E_red == I
+    Lh = np.linalg.cholesky(E_red.cpu().numpy())                  # [S, N, N]: small, on the host
+    Vo = torch.bmm(V, eng.ctx.from_numpy(np.linalg.inv(Lh).transpose(0, 2, 1))).contiguous()
+    bufo = eng.project_and_estimate(Vo, buf)
+    eye = torch.eye(N, dtype=torch.float64, device=Vo.device)[None]
+    assert float((bufo['sys'][2] - eye).abs().max()) < 1e-10
+    theta = theta_of(p, 0.35)
+    u = eng.ctx.from_numpy(np.random.default_rng(5).standard_normal((S, N)))
+    eta = eng.reduced_estimate(theta, u, bufo['grams'])
+    U = torch.einsum('snk,sk->sn', Vo, u)[:, :, None].contiguous()
     bufU = eng.project_and_estimate(U, project_system=False)
     etaU = eng.reduced_estimate(theta, eng.ctx.from_numpy(np.ones((S, 1))), bufU['grams'])
     scale = etaU.abs().max(dim=1, keepdim=True).values
