@@ -8,7 +8,8 @@ estimators.py:100-101 are its only live collectives on this path.  Here:
   its own target subdomains ``ii`` -- including the images W^{kk}|_ii, R^{kk}|_ii of its neighbours' bases -- so
   the projection needs a single halo exchange of neighbour basis rows and no second exchange (SURVEY section 8e);
 * the halo carries only the DoF rows of elements that touch the shared side (what the coupling blocks, the Oswald
-  vertex stars and the flux reconstruction read), packed into one buffer and moved by one RCCL all-gather over xGMI;
+  vertex stars and the flux reconstruction read), packed into one buffer and moved by one RCCL all-to-all with
+  per-peer splits over xGMI (point-to-point: only the owner of the neighbour receives a row);
 * the estimator norms (C2/C3) are one all-reduce of 2 doubles per estimated vector.
 
 Works with any torch.distributed backend (``nccl`` = RCCL on the GPUs, ``gloo`` in the CPU tests).
@@ -99,21 +100,56 @@ class HaloPlan:
         self.unpack_src = np.concatenate(src) if src else np.zeros(0, dtype=np.int64)
         self.unpack_dst = np.concatenate(dst) if dst else np.zeros(0, dtype=np.int64)
         self.opposite = opposite
+        # point-to-point form of the same exchange (one all_to_all with per-peer splits): every (s, side) item goes
+        # to exactly one peer, the owner of the neighbour across that side.  Send buffer ordered by (peer, s, side).
+        def dest(s, sd):
+            return owner[int(g.neighbor_slots[s, slot_of_side[sd]])]
+        self.a2a_send_splits = [0] * world_size
+        self.a2a_recv_splits = [0] * world_size
+        pidx, udst = [], []
+        for r in range(world_size):
+            if r == rank:
+                continue
+            for (s, sd) in self.send_items[rank]:
+                if dest(s, sd) == r:
+                    pidx.append(lpos[s] * t.n + rows[sd])
+                    self.a2a_send_splits[r] += self.row_counts[sd]
+            for (s, sd) in self.send_items[r]:
+                if dest(s, sd) == rank:
+                    udst.append(hpos[s] * t.n + rows[sd])
+                    self.a2a_recv_splits[r] += self.row_counts[sd]
+        self.a2a_pack_index = np.concatenate(pidx) if pidx else np.zeros(0, dtype=np.int64)
+        self.a2a_unpack_dst = np.concatenate(udst) if udst else np.zeros(0, dtype=np.int64)
 
 
 class HaloExchange:
-    """Fills the halo slabs V[S:] from the neighbours' owners with one all-gather."""
+    """Fills the halo slabs V[S:] from the neighbours' owners with ONE collective per pass.
 
-    def __init__(self, plan, N, device, dtype=None, group=None):
+    ``mode='alltoall'`` (default): ``all_to_all_single`` with per-peer row splits -- every rank sends each packed row
+    only to the one peer that reads it (point-to-point over xGMI, no traffic to non-neighbours; at the 8-GPU tile of
+    config 3 this is 1.3 MB per rank instead of the 10 MB an all-gather delivers to everyone).
+    ``mode='allgather'`` (or env ``LRBMS_HALO=allgather``): the same rows through one ``all_gather_into_tensor``."""
+
+    def __init__(self, plan, N, device, dtype=None, group=None, mode=None):
+        import os
         import torch
         self.torch, self.plan, self.group = torch, plan, group
+        self.mode = mode or os.environ.get('LRBMS_HALO', 'alltoall')
+        if self.mode not in ('alltoall', 'allgather'):
+            raise ValueError('halo mode must be alltoall or allgather')
         dtype = dtype or torch.float64
-        self.send = torch.zeros(max(plan.max_rows, 1), N, dtype=dtype, device=device)
-        self.recv = torch.zeros(plan.world_size * max(plan.max_rows, 1), N, dtype=dtype, device=device)
-        self.pack_index = torch.from_numpy(plan.pack_index).to(device)
-        self.unpack_src = torch.from_numpy(plan.unpack_src).to(device)
-        self.unpack_dst = torch.from_numpy(plan.unpack_dst).to(device)
-        self.count = len(plan.pack_index)
+        if self.mode == 'allgather':
+            self.send = torch.zeros(max(plan.max_rows, 1), N, dtype=dtype, device=device)
+            self.recv = torch.zeros(plan.world_size * max(plan.max_rows, 1), N, dtype=dtype, device=device)
+            self.pack_index = torch.from_numpy(plan.pack_index).to(device)
+            self.unpack_src = torch.from_numpy(plan.unpack_src).to(device)
+            self.unpack_dst = torch.from_numpy(plan.unpack_dst).to(device)
+        else:
+            self.send = torch.zeros(len(plan.a2a_pack_index), N, dtype=dtype, device=device)
+            self.recv = torch.zeros(len(plan.a2a_unpack_dst), N, dtype=dtype, device=device)
+            self.pack_index = torch.from_numpy(plan.a2a_pack_index).to(device)
+            self.unpack_dst = torch.from_numpy(plan.a2a_unpack_dst).to(device)
+        self.count = len(self.pack_index)
 
     def __call__(self, V):
         """V [S_ext, n, N] contiguous; rows of the halo slabs that the kernels read are overwritten in place."""
@@ -124,9 +160,15 @@ class HaloExchange:
         flat = V.view(-1, V.shape[2])
         if self.count:
             torch.index_select(flat, 0, self.pack_index, out=self.send[:self.count])
-        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-        if len(self.unpack_src):
-            flat.index_copy_(0, self.unpack_dst, self.recv.index_select(0, self.unpack_src))
+        if self.mode == 'allgather':
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            if len(self.unpack_src):
+                flat.index_copy_(0, self.unpack_dst, self.recv.index_select(0, self.unpack_src))
+        else:
+            dist.all_to_all_single(self.recv, self.send, output_split_sizes=self.plan.a2a_recv_splits,
+                                   input_split_sizes=self.plan.a2a_send_splits, group=self.group)
+            if len(self.unpack_dst):
+                flat.index_copy_(0, self.unpack_dst, self.recv)
         return V
 
 

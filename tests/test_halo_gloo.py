@@ -19,7 +19,7 @@ def _global_V(grid):
     return rng.standard_normal((grid.num_subdomains, grid.template.n, N))
 
 
-def _worker(rank, world, port, results):
+def _worker(rank, world, port, results, mode):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -32,7 +32,7 @@ def _worker(rank, world, port, results):
         halo = sorted({j for s in local for j in grid.neighboring_subdomains(s)} - set(local))
         V = torch.zeros(len(local) + len(halo), grid.template.n, N, dtype=torch.float64)
         V[:len(local)] = torch.from_numpy(Vg[local])
-        HaloExchange(plan, N, V.device)(V)
+        HaloExchange(plan, N, V.device, mode=mode)(V)
         rows = side_rows(grid.template)
         ok = True
         checked = 0
@@ -55,12 +55,12 @@ def _worker(rank, world, port, results):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 4])
-def test_halo_exchange_gloo(world):
-    port = 29500 + (os.getpid() % 2000) + world
+@pytest.mark.parametrize('world,mode', [(2, 'alltoall'), (4, 'alltoall'), (2, 'allgather'), (4, 'allgather')])
+def test_halo_exchange_gloo(world, mode):
+    port = 29500 + (os.getpid() % 2000) + world + (10 if mode == 'allgather' else 0)
     mgr = mp.Manager()
     results = mgr.dict()
-    mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, results, mode), nprocs=world, join=True)
     assert len(results) == world
     for r in range(world):
         ok, checked = results[r]
@@ -84,3 +84,18 @@ def test_side_rows_cover_what_the_kernels_read():
             if on:
                 need |= set(int(i) for i in t.vdof_idx[t.vdof_ptr[v]:t.vdof_ptr[v + 1]])   # Oswald vertex stars
         assert need <= set(int(r) for r in rows[osd])
+
+
+def test_alltoall_plan_is_consistent_across_ranks():
+    """What rank a sends to rank b is, row for row, what rank b expects from rank a (no handshake at run time)."""
+    world = 8
+    mk = lambda r: DDSubdomainsGrid([0, 0], [1, 1], (32, 32), (8, 8), rank=r, world_size=world)  # noqa: E731
+    plans = [HaloPlan(mk, world, r) for r in range(world)]
+    for a in range(world):
+        assert plans[a].a2a_send_splits[a] == 0 and plans[a].a2a_recv_splits[a] == 0
+        assert sum(plans[a].a2a_send_splits) == len(plans[a].a2a_pack_index)
+        assert sum(plans[a].a2a_recv_splits) == len(plans[a].a2a_unpack_dst)
+        for b in range(world):
+            assert plans[a].a2a_send_splits[b] == plans[b].a2a_recv_splits[a]
+        # point-to-point volume is far below the all-gather volume
+        assert sum(plans[a].a2a_recv_splits) < plans[a].max_rows * (world - 1)
