@@ -74,7 +74,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get('LRBMS_HIP_LIB') or LIB_PATH     # LRBMS_HIP_LIB: A/B builds of tools/build_variant.sh
     # torch bundles its own libamdhip64: import it FIRST so that our NEEDED libamdhip64.so.7 resolves to the copy
     # torch uses (two HIP runtimes in one process do not share devices, streams or allocations)
     import torch  # noqa: F401

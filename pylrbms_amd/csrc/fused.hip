@@ -34,6 +34,9 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+#ifndef F1_SCALAR_LOADS
+#define F1_SCALAR_LOADS 0
+#endif
 constexpr int EC = 4;               // elements per K-chunk (12 DG rows = 3 MFMA k-steps) = staging waves
 constexpr int F1_NTY = 7;           // Y column tiles per wave in k_f1
 constexpr int F1_YW = 4 * F1_NTY * 16;   // 448 columns
@@ -43,6 +46,30 @@ constexpr int F1_MAXG = 12;
 __host__ __device__ constexpr int padded_ld(int tiles) { return (tiles * 16) % 32 == 16 ? tiles * 16 : tiles * 16 + 16; }
 
 __device__ inline int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// Wave-uniform data through the scalar unit: a pointer cast to the constant address space makes every load with a
+// uniform address an s_load (scalar cache, SGPR result usable directly as the scalar operand of v_fma_f64).
+typedef const __attribute__((address_space(4))) int* cint_p;
+typedef const __attribute__((address_space(4))) double* cdbl_p;
+
+// A global load the compiler does not track.  The producers of k_f1 prefetch the rows of the NEXT chunk while they stage
+// the current one; that only works if the wait before the staging is `s_waitcnt vmcnt(<loads just issued>)`.  With
+// ordinary loads hipcc (ROCm 7.2) emits vmcnt(0) there -- its wait-count bookkeeping gives up across the unrolled
+// ping-pong loop -- which also waits for the loads just issued, i.e. exposes one full memory latency per chunk.  So the
+// prefetch loads are inline asm (invisible to that pass) and are completed by an explicit wait that names every
+// destination register as an in/out operand (so no use can be scheduled above it).
+__device__ inline double gload_f64(const double* p) {
+  double v;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// Broadcast lane `l` of a per-lane double to the whole wave as an SGPR pair (two v_readlane_b32, no LDS round trip).
+__device__ inline double bcast_d(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. it waits for every
 // global load in flight -- which would serialise the register prefetch of the next chunk behind each barrier.
@@ -190,7 +217,6 @@ struct F1Args {
   const double *V, *A_diag, *P_diag, *caa, *Aab, *Rself, *b;
   double* rhs_red;   // may be null (written only by the launch that carries it)
   int Q, N, S;
-  int dbg;           // timing experiments only (LRBMS_F1_DBG): 1 = skip the group loop, 2 = skip the MFMAs, 4 = skip prefetch
 };
 
 // Producer / consumer workgroup of 8 waves (one workgroup per CU):
@@ -245,9 +271,6 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
 
   if (wave < EC) {
     // ================================================= producers
-    bool want_ab = false;
-    for (int g = 0; g < ng; ++g) want_ab |= (grp[g].kind == G_AB);
-    const bool has_ab = uniform(want_ab ? 1 : 0) != 0;
     const bool do_rhs = a.rhs_red != nullptr && blockIdx.y == 0;
     // element-block fetch of this wave's element: lane item o = lane + 64 k; (pointer, per-element stride) fixed
     const double* fsrc[PRE];
@@ -255,8 +278,8 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
       const int o = lane + 64 * k;
-      fsrc[k] = nullptr;
-      fstr[k] = 0;
+      fsrc[k] = a.A_diag + (long)s * t.nT * 36;   // lanes beyond the record re-read its first entry: every prefetch load is
+      fstr[k] = 36;                               // unconditional, so the compiler can count them (s_waitcnt vmcnt(n), see step)
       if (o < ESTR) {
         if (o < oP) {
           const int q = o / 36;
@@ -280,27 +303,60 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     const double* Rs = a.Rself + (long)s * t.nrt * QN;
     const int j = lane;
     const bool colj = j < N;
+    const int jc = colj ? j : N - 1;   // lanes beyond the basis width load (and never use) the last column: no exec masking
+    // QP > 0 (chosen by the launcher only when all groups fit in one slice): canonical group order
+    // [SYS q][ENERGY][MASS][AA q<=q'][AB q q'] with compile-time Q -> straight-line staging, asm-managed prefetch
+    constexpr bool straight = QP > 0;
+    constexpr int PREU = straight ? (45 * QP + 36 + QP * QP + 63) / 64 : PRE;   // prefetch registers that hold record items
+    constexpr int NLOADS = PREU + 12 + 3 * QP;                                  // loads per prefetch set (straight path)
+    static_assert(QP <= 2, "k_f1: the asm-managed prefetch is written out for Q <= 2");
     double pre[PRE], vb[4][3], rv[3][QR], nvb[4][3], nrv[3][QR];
+    auto ld = [&](const double* p) { return straight ? gload_f64(p) : *p; };
     auto fetch = [&](int T, double (&pr)[PRE]) {
 #pragma unroll
-      for (int k = 0; k < PRE; ++k) pr[k] = fsrc[k] ? fsrc[k][(long)T * fstr[k]] : 0.0;
+      for (int k = 0; k < PREU; ++k) pr[k] = ld(fsrc[k] + (long)T * fstr[k]);
     };
+    // completes one prefetch set: everything older than the NLOADS loads issued since is done
+    auto wait_set = [&](double (&pr)[PRE], double (&vbx)[4][3], double (&rvx)[3][QR]) {
+      if constexpr (QP == 2) {
+        asm volatile("s_waitcnt vmcnt(%21)"
+                     : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(vbx[0][0]), "+v"(vbx[0][1]), "+v"(vbx[0][2]), "+v"(vbx[1][0]),
+                       "+v"(vbx[1][1]), "+v"(vbx[1][2]), "+v"(vbx[2][0]), "+v"(vbx[2][1]), "+v"(vbx[2][2]), "+v"(vbx[3][0]),
+                       "+v"(vbx[3][1]), "+v"(vbx[3][2]), "+v"(rvx[0][0]), "+v"(rvx[0][1]), "+v"(rvx[1][0]), "+v"(rvx[1][1]),
+                       "+v"(rvx[2][0]), "+v"(rvx[2][1])
+                     : "n"(NLOADS));
+      } else if constexpr (QP == 1) {
+        asm volatile("s_waitcnt vmcnt(%17)"
+                     : "+v"(pr[0]), "+v"(pr[1]), "+v"(vbx[0][0]), "+v"(vbx[0][1]), "+v"(vbx[0][2]), "+v"(vbx[1][0]), "+v"(vbx[1][1]),
+                       "+v"(vbx[1][2]), "+v"(vbx[2][0]), "+v"(vbx[2][1]), "+v"(vbx[2][2]), "+v"(vbx[3][0]), "+v"(vbx[3][1]),
+                       "+v"(vbx[3][2]), "+v"(rvx[0][0]), "+v"(rvx[1][0]), "+v"(rvx[2][0])
+                     : "n"(NLOADS));
+      }
+    };
+    // Template adjacency of the (wave-uniform) element through the scalar cache.  A face without an in-subdomain
+    // neighbour has an all-zero block in A_diag / P_diag (its coupling lives in A_cpl), so its rows may be any finite
+    // values: the element's own rows are loaded instead, which keeps the twelve row loads branch-free.
+    const cint_p nbc = (cint_p)t.nb_elem;
+    const cint_p rtc = (cint_p)t.elem_rt;
     auto load_rows = [&](int T, double (&vbx)[4][3], double (&rvx)[3][QR]) {
-      if (colj) {
+      int nbT[3], rtT[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) vbx[0][i] = Vs[(long)(3 * T + i) * N + j];
+      for (int f = 0; f < 3; ++f) {
+        const int nb = nbc[T * 3 + f];
+        nbT[f] = nb >= 0 ? nb : T;
+        rtT[f] = rtc[T * 3 + f];
+      }
 #pragma unroll
-        for (int f = 0; f < 3; ++f) {
-          const int nb = nbl[T * 3 + f];
+      for (int i = 0; i < 3; ++i) vbx[0][i] = ld(Vs + (long)(3 * T + i) * N + jc);
 #pragma unroll
-          for (int i = 0; i < 3; ++i) vbx[1 + f][i] = nb >= 0 ? Vs[(long)(3 * nb + i) * N + j] : 0.0;
-        }
-        if (QP > 0 && has_ab) {
+      for (int f = 0; f < 3; ++f)
 #pragma unroll
-          for (int f = 0; f < 3; ++f)
+        for (int i = 0; i < 3; ++i) vbx[1 + f][i] = ld(Vs + (long)(3 * nbT[f] + i) * N + jc);
+      if (QP > 0) {   // QP > 0: Q == QP, the flux rows are always fetched (used by the G_AB groups)
 #pragma unroll
-            for (int q2 = 0; q2 < QR; ++q2) rvx[f][q2] = q2 < Q ? Rs[(long)rtl[T * 3 + f] * QN + q2 * N + j] : 0.0;
-        }
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+          for (int q2 = 0; q2 < QR; ++q2) rvx[f][q2] = ld(Rs + (long)rtT[f] * QN + q2 * N + jc);
       }
     };
 #pragma unroll
@@ -316,53 +372,84 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     load_rows(wave, vb, rv);
     double rhs_part = 0.0;
     // one pipeline step over (current, next) register sets; the sets alternate (loop unrolled by two, no copies)
-    auto step = [&](int c, const double (&pre)[PRE], const double (&vb)[4][3], const double (&rv)[3][QR],
+    auto step = [&](int c, double (&pre)[PRE], double (&vb)[4][3], double (&rv)[3][QR],
                     double (&npre)[PRE], double (&nvb)[4][3], double (&nrv)[3][QR]) {
       const int T = c * EC + wave;                 // wave-uniform element
       double* Xb = &Xs[c & 1][0];
       double* Yb = &Ys[c & 1][0];
+      if constexpr (!straight) {
 #pragma unroll
-      for (int k = 0; k < PRE; ++k)                // this wave's element blocks -> its private LDS record
-        if (fsrc[k]) Ee[lane + 64 * k] = pre[k];
-      if (c + 1 < nchunks) {                       // next chunk's loads: in flight during this staging AND the barrier
-        fetch(T + EC, npre);
-        load_rows(T + EC, nvb, nrv);
+        for (int k = 0; k < PRE; ++k)              // this wave's element blocks -> its private LDS record
+          if (lane + 64 * k < ESTR) Ee[lane + 64 * k] = pre[k];
+      }
+      {
+        // Next chunk's loads, in flight during this staging AND the barrier.  They are issued UNCONDITIONALLY (last
+        // chunk: the current element again; idle lanes: clamped addresses): s_waitcnt vmcnt is an in-order counter,
+        // and with any branch around a load the compiler can no longer tell how many younger loads may be pending
+        // when the staging below needs the current rows -- it then emits vmcnt(0), which also waits for the loads
+        // just issued, i.e. exposes one full memory latency per chunk (this cost 170 us of 670 at config 3).
+        const int Tn = c + 1 < nchunks ? T + EC : T;
+        fetch(Tn, npre);
+        load_rows(Tn, nvb, nrv);
+        if constexpr (straight) wait_set(pre, vb, rv);   // current set complete; the NLOADS loads above stay in flight
       }
       if (colj) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) Xb[(3 * wave + i) * LDX + j] = vb[0][i];
-        if (do_rhs) {
-          const double* be = a.b + (long)s * t.n + 3 * T;
+        if (do_rhs) {   // b_T through the scalar unit (lgkmcnt): a vector load here would force a vmcnt(0) on the prefetch
+          const cdbl_p be = (cdbl_p)(a.b + (long)s * t.n + 3 * T);
           rhs_part += be[0] * vb[0][0] + be[1] * vb[0][1] + be[2] * vb[0][2];
         }
         double kv[3];
         const double* K = Kl + T * 9;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) kv[i] = K[i * 3] * vb[0][0] + K[i * 3 + 1] * vb[0][1] + K[i * 3 + 2] * vb[0][2];
-        if (QP > 0 && ng == QP + 2 + (QP * (QP + 1)) / 2 + QP * QP) {
-          // ---- straight-line staging for the canonical group order [SYS q][ENERGY][MASS][AA q<=q'][AB q q'] with
-          // compile-time Q: no group-table reads or branches, every LDS operand address is an immediate, so the
-          // compiler batches the ds_reads of the whole element and one LDS latency is exposed instead of ~11
+        for (int i = 0; i < 3; ++i)
+          kv[i] = __builtin_fma(K[i * 3 + 2], vb[0][2], __builtin_fma(K[i * 3 + 1], vb[0][1], K[i * 3] * vb[0][0]));
+        if constexpr (straight) {
+          // ---- straight-line staging: no group-table reads or branches.  The element's record sits lane-distributed
+          // in the prefetch registers (item o in lane o & 63 of pre[o >> 6], loaded one chunk ahead); every entry is
+          // broadcast with v_readlane into an SGPR pair and used as the scalar operand of v_fma_f64.  Measured
+          // alternatives for this broadcast (k_f1 at config 3): LDS round trip 683 us (64 lanes x 16 B of LDS return
+          // bandwidth per broadcast ds_read_b128: the LDS pipe saturates), v_readlane 647 us, s_load from the
+          // constant address space 738 us (F1_SCALAR_LOADS=1: zero VALU cost, but ~5 dependent scalar-cache-miss
+          // round trips per element that nothing hides: VALU and f64-MFMA issue serialise per SIMD on this chip,
+          // so a stalled producer is not overlapped by its SIMD's consumer).
+          // F1_BLK(off): entry `off` of the element record [A_q blocks | P block | A_ab^q blocks | c^{qq'}], wave-uniform
+#if F1_SCALAR_LOADS
+          asm volatile("" ::"v"(pre[0]), "v"(pre[1]), "v"(pre[2]), "v"(pre[3]));   // keep the L2 warm-up loads
+          const long eT = (long)s * t.nT + T;
+          const long qstr = (long)S * t.nT;
+#define F1_BLK(off)                                                                                                  \
+  ((off) < 36 * QP ? ((cdbl_p)a.A_diag)[(((off) / 36) * qstr + eT) * 36 + (off) % 36]                                 \
+   : (off) < 36 * QP + 36 ? ((cdbl_p)a.P_diag)[eT * 36 + (off) - 36 * QP]                                             \
+   : (off) < 36 * QP + 36 + 9 * QP ? ((cdbl_p)a.Aab)[((((off) - 36 * QP - 36) / 9) * qstr + eT) * 9 + ((off) - 36 * QP - 36) % 9] \
+                                   : ((cdbl_p)a.caa)[((off) - 36 * QP - 36 - 9 * QP) * qstr + eT])
+#else
+#define F1_BLK(off) bcast_d(pre[(off) >> 6], (off) & 63)
+#endif
           int g = 0;
           auto put = [&](const double (&y)[3]) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) Yb[(3 * wave + i) * LDY + g * N + j] = y[i];
             ++g;
           };
-          auto apply = [&](const double* blk) {
+          auto apply = [&](int base) {
             double y[3] = {0, 0, 0};
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-              for (int i = 0; i < 3; ++i)
-                y[i] += blk[bb * 9 + i * 3] * vb[bb][0] + blk[bb * 9 + i * 3 + 1] * vb[bb][1] + blk[bb * 9 + i * 3 + 2] * vb[bb][2];
+              for (int i = 0; i < 3; ++i) {
+                y[i] = __builtin_fma(F1_BLK(base + bb * 9 + i * 3), vb[bb][0], y[i]);
+                y[i] = __builtin_fma(F1_BLK(base + bb * 9 + i * 3 + 1), vb[bb][1], y[i]);
+                y[i] = __builtin_fma(F1_BLK(base + bb * 9 + i * 3 + 2), vb[bb][2], y[i]);
+              }
             put(y);
           };
 #pragma unroll
-          for (int q = 0; q < QP; ++q) apply(Ee + 36 * q);
-          apply(Ee + 36 * QP);
+          for (int q = 0; q < QP; ++q) apply(36 * q);
+          apply(36 * QP);
           {
-            const double m = t.area[T] / 12.0, sum = vb[0][0] + vb[0][1] + vb[0][2];
+            const double m = ((cdbl_p)t.area)[T] * (1.0 / 12.0), sum = vb[0][0] + vb[0][1] + vb[0][2];
             const double y[3] = {m * (sum + vb[0][0]), m * (sum + vb[0][1]), m * (sum + vb[0][2])};
             put(y);
           }
@@ -370,21 +457,25 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
           for (int q = 0; q < QP; ++q)
 #pragma unroll
             for (int q2 = q; q2 < QP; ++q2) {
-              const double cc = Ee[36 * QP + 36 + 9 * QP + q * QP + q2];
+              const double cc = F1_BLK(36 * QP + 36 + 9 * QP + q * QP + q2);
               const double y[3] = {cc * kv[0], cc * kv[1], cc * kv[2]};
               put(y);
             }
 #pragma unroll
           for (int q = 0; q < QP; ++q) {
-            const double* A = Ee + 36 * QP + 36 + 9 * q;
+            double A[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) A[i] = F1_BLK(36 * QP + 36 + 9 * q + i);
 #pragma unroll
             for (int q2 = 0; q2 < QP; ++q2) {
-              const double y[3] = {A[0] * rv[0][q2] + A[1] * rv[1][q2] + A[2] * rv[2][q2],
-                                   A[3] * rv[0][q2] + A[4] * rv[1][q2] + A[5] * rv[2][q2],
-                                   A[6] * rv[0][q2] + A[7] * rv[1][q2] + A[8] * rv[2][q2]};
+              double y[3];
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+                y[i] = __builtin_fma(A[i * 3 + 2], rv[2][q2], __builtin_fma(A[i * 3 + 1], rv[1][q2], A[i * 3] * rv[0][q2]));
               put(y);
             }
           }
+#undef F1_BLK
         } else
         for (int g = 0; g < ng; ++g) {
           const int kind = uniform(grp[g].kind), q = uniform(grp[g].q), q2 = uniform(grp[g].q2);
@@ -433,6 +524,7 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
       step(c + 1, npre, nvb, nrv, pre, vb, rv);
     }
     lds_barrier();                                 // final barrier (matches the consumers' count)
+    if constexpr (straight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (unused) prefetch set
     if (do_rhs) red[wave * 64 + lane] = rhs_part;
   } else {
     // ================================================= consumers
@@ -1010,6 +1102,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     constexpr int NTY = 7;                                   // 4 consumer waves x 7 column tiles = 448 columns per slice
     const int per = std::min(F1_MAXG, (4 * NTY * 16) / N);
     const int ntx = (N + 15) / 16;
+    const bool one_slice = groups.size() <= (size_t)per;   // the straight-line (compile-time Q) producer needs every group
     const size_t ldsf1 = sizeof(int) * 6 * t.nT + sizeof(double) * 9 * t.nT;   // 6 nT ints: 8-byte aligned (nT % 8 == 0)
     for (size_t g0 = 0; g0 < groups.size(); g0 += 3 * (size_t)per) {   // up to three slices per launch (grid.y)
       GrpTable gt[3];
@@ -1022,13 +1115,12 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
         for (int i = 0; i < gt[sl].n; ++i) gt[sl].g[i] = groups[b0 + i];
         nsl = sl + 1;
       }
-      const char* dbg_env = getenv("LRBMS_F1_DBG");
-      F1Args a{V, A_diag, P_diag, caa, Aab, Rself, b, g0 == 0 ? rhs_red : nullptr, Q, N, S, dbg_env ? atoi(dbg_env) : 0};
+      F1Args a{V, A_diag, P_diag, caa, Aab, Rself, b, g0 == 0 ? rhs_red : nullptr, Q, N, S};
       const dim3 grid(S, nsl);
 #define LRBMS_F1(NTXV)                                                                                              \
   do {                                                                                                              \
-    if (Q == 1) hipLaunchKernelGGL((k_f1<NTXV, NTY, 1>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);      \
-    else if (Q == 2) hipLaunchKernelGGL((k_f1<NTXV, NTY, 2>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]); \
+    if (Q == 1 && one_slice) hipLaunchKernelGGL((k_f1<NTXV, NTY, 1>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);      \
+    else if (Q == 2 && one_slice) hipLaunchKernelGGL((k_f1<NTXV, NTY, 2>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]); \
     else hipLaunchKernelGGL((k_f1<NTXV, NTY, 0>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);             \
   } while (0)
       switch (ntx) {
