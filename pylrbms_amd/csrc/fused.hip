@@ -596,17 +596,19 @@ struct F2Args {
 };
 
 // Same producer / consumer structure as k_f1: waves 0-3 stage the face rows R~_T, B_T R~_T, d_T, |T| d_T of element
-// 4 c + w into LDS buffer c & 1 (global loads of chunk c + 1 in flight), waves 4 .. 4 + NR - 1 own one column tile each
-// of the (Q N)-wide self blocks of G_bb and G_rdd (NR row tiles).  One barrier per chunk.
+// 4 c + w into LDS buffer c & 1 (global loads of chunk c + 1 in flight), waves 4 .. 7 share the
+// upper-triangular tiles of the (Q N)-wide self blocks of G_bb and G_rdd.  One barrier per chunk.
+constexpr int F2_NCW = 4;   // consumer waves of k_f2
+
 template <int NR>
-__global__ __launch_bounds__(64 * (NR + EC)) void k_f2(Tmpl t, F2Args a) {
+__global__ __launch_bounds__(64 * (F2_NCW + EC)) void k_f2(Tmpl t, F2Args a) {
   constexpr int LD = padded_ld(NR);
   extern __shared__ double dyn[];             // per-element scalars cached once: coef [nT][3], bsum [nT], rt [nT][3] (int)
   __shared__ double Xb[2][3 * EC * LD], Yb[2][3 * EC * LD], Xd[2][EC * LD], Yd[2][EC * LD];
   __shared__ double red[EC * 128];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
-  const int nthreads = 64 * (NR + EC);
+  const int nthreads = 64 * (F2_NCW + EC);
   const int QN = a.Q * a.N, C = 5 * QN;
   double* coefs = dyn;
   double* bsums = dyn + 3 * t.nT;
@@ -630,38 +632,44 @@ __global__ __launch_bounds__(64 * (NR + EC)) void k_f2(Tmpl t, F2Args a) {
 
   if (wave < EC) {
     // ================================================= producers
-    double rv[2][3], nrv[2][3], Bv[9], nBv[9];
-    auto load = [&](int T, double (&r)[2][3], double (&B)[9]) {
+    // Prefetch set of one element: its 3 face rows of R~ in two column halves (6 loads; idle lanes re-read the last
+    // column) and its B_T block, item i in lane i (1 load).  All seven are asm loads completed by an explicit
+    // s_waitcnt vmcnt(7) (see gload_f64): everything else the staging needs comes from LDS or the scalar unit, because
+    // ANY compiler-visible vector load in this loop ends in a vmcnt(0) that also waits for the prefetch just issued.
+    double rv[2][3], nrv[2][3], Bl, nBl;
+    const int cc0 = lane < QN ? lane : QN - 1, cc1 = lane + 64 < QN ? lane + 64 : QN - 1;
+    const int bi = lane < 9 ? lane : 8;
+    auto load = [&](int T, double (&r)[2][3], double& B) {
       const int r0 = rts[3 * T], r1 = rts[3 * T + 1], r2 = rts[3 * T + 2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int c = lane + 64 * k;
-        if (c < QN) {
-          r[k][0] = Rs[(long)r0 * QN + c];
-          r[k][1] = Rs[(long)r1 * QN + c];
-          r[k][2] = Rs[(long)r2 * QN + c];
-        } else {
-          r[k][0] = r[k][1] = r[k][2] = 0.0;
-        }
-      }
-      const double* Bp = a.Bbb + ((long)s * t.nT + T) * 9;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) B[i] = Bp[i];
+      r[0][0] = gload_f64(Rs + (long)r0 * QN + cc0);
+      r[0][1] = gload_f64(Rs + (long)r1 * QN + cc0);
+      r[0][2] = gload_f64(Rs + (long)r2 * QN + cc0);
+      r[1][0] = gload_f64(Rs + (long)r0 * QN + cc1);
+      r[1][1] = gload_f64(Rs + (long)r1 * QN + cc1);
+      r[1][2] = gload_f64(Rs + (long)r2 * QN + cc1);
+      B = gload_f64(a.Bbb + ((long)s * t.nT + T) * 9 + bi);
     };
-    load(wave, rv, Bv);
+    auto wait_set = [&](double (&r)[2][3], double& B) {
+      asm volatile("s_waitcnt vmcnt(7)"
+                   : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]), "+v"(B));
+    };
+    load(wave, rv, Bl);
     double rfd_part[2] = {0.0, 0.0};   // columns lane and lane + 64 (QN <= 128)
     // One pipeline step: issue the loads of chunk c + 1 into the OTHER register set, stage chunk c from this one.
-    // The two sets alternate (loop unrolled by two, no register copies), so the wait for a load lands at its first
-    // use one step later and the L2 / HBM latency hides behind a full staging step plus the barrier.
-    auto step = [&](int c, const double (&cr)[2][3], const double (&cB)[9], double (&nr)[2][3], double (&nB)[9]) {
+    // The two sets alternate (loop unrolled by two, no register copies).
+    auto step = [&](int c, double (&cr)[2][3], double& cBl, double (&nr)[2][3], double& nB) {
       const int T = c * EC + wave, el = wave;
-      if (c + 1 < nchunks) load(T + EC, nr, nB);
+      load(c + 1 < nchunks ? T + EC : T, nr, nB);   // unconditional: the wait below counts on exactly 7 younger loads
+      wait_set(cr, cBl);
+      double cB[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) cB[i] = bcast_d(cBl, i);
       double* xb = &Xb[c & 1][0];
       double* yb = &Yb[c & 1][0];
       double* xd = &Xd[c & 1][0];
       double* yd = &Yd[c & 1][0];
       const double c0f = coefs[3 * T], c1f = coefs[3 * T + 1], c2f = coefs[3 * T + 2];
-      const double bsum = bsums[T], area = t.area[T];
+      const double bsum = bsums[T], area = ((cdbl_p)t.area)[T];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int cc = lane + 64 * k;
@@ -682,18 +690,38 @@ __global__ __launch_bounds__(64 * (NR + EC)) void k_f2(Tmpl t, F2Args a) {
       lds_barrier();                               // barrier c: buffer c & 1 complete (loads stay in flight)
     };
     for (int c = 0; c < nchunks; c += 2) {         // nT is a multiple of 8, so nchunks is even
-      step(c, rv, Bv, nrv, nBv);
-      step(c + 1, nrv, nBv, rv, Bv);
+      step(c, rv, Bl, nrv, nBl);
+      step(c + 1, nrv, nBl, rv, Bl);
     }
     lds_barrier();                                 // final barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (unused) prefetch set
     red[wave * 128 + lane] = rfd_part[0];
     red[wave * 128 + 64 + lane] = rfd_part[1];
   } else {
     // ================================================= consumers
-    const int ct = wave - EC;                      // this wave's column tile
-    d4 accb[NR], accd[NR];
+    // G_bb[self,self] = R~^T B R~ and G_rdd[self,self] = d^T |T| d are symmetric: only the NR (NR + 1) / 2 tiles on and
+    // above the diagonal are computed, dealt round-robin over the consumer waves (static accumulator index k, the
+    // tile coordinates of (wave, k) are wave-uniform scalars); the epilogue mirrors the off-diagonal tiles.
+    constexpr int NTRI = NR * (NR + 1) / 2;
+    constexpr int NCW = F2_NCW;                                // consumer waves (one per SIMD)
+    constexpr int TPW = (NTRI + NCW - 1) / NCW;                // tiles per wave
+    const int cw = wave - EC;
+    int ti[TPW], tj[TPW];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) accb[i] = accd[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < TPW; ++k) {
+      int idx = cw + k * NCW, i = 0;                           // idx-th upper-triangular tile, row-major
+      if (idx >= NTRI) idx = -1;
+      int rem = idx;
+      while (rem >= NR - i && idx >= 0) {
+        rem -= NR - i;
+        ++i;
+      }
+      ti[k] = idx >= 0 ? i : -1;
+      tj[k] = idx >= 0 ? i + rem : 0;
+    }
+    d4 accb[TPW], accd[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) accb[k] = accd[k] = (d4){0.0, 0.0, 0.0, 0.0};
     for (int c = 0; c < nchunks; ++c) {
       lds_barrier();                               // barrier c
       const double* xb = &Xb[c & 1][0];
@@ -701,30 +729,33 @@ __global__ __launch_bounds__(64 * (NR + EC)) void k_f2(Tmpl t, F2Args a) {
       const double* xd = &Xd[c & 1][0];
       const double* yd = &Yd[c & 1][0];
 #pragma unroll
-      for (int kk = 0; kk < 3 * EC; kk += 4) {
-        const double bv = yb[(kk + lk) * LD + ct * 16 + li];
+      for (int k = 0; k < TPW; ++k) {
+        if (ti[k] < 0) continue;                   // wave-uniform
+        const int xo = ti[k] * 16 + li, yo = tj[k] * 16 + li;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) accb[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[(kk + lk) * LD + i * 16 + li], bv, accb[i], 0, 0, 0);
-      }
-      {
-        const double bv = yd[lk * LD + ct * 16 + li];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) accd[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[lk * LD + i * 16 + li], bv, accd[i], 0, 0, 0);
+        for (int kk = 0; kk < 3 * EC; kk += 4)
+          accb[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[(kk + lk) * LD + xo], yb[(kk + lk) * LD + yo], accb[k], 0, 0, 0);
+        accd[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[lk * LD + xo], yd[lk * LD + yo], accd[k], 0, 0, 0);
       }
     }
     lds_barrier();                                 // final barrier
-    const int col = ct * 16 + li;
-    double* gb = a.G_bb + (long)s * 9 * QN * QN + col;      // block 0 = [self, self] of the block-compact layout
-    double* gd = a.G_rdd + (long)s * 9 * QN * QN + col;
+    double* gb = a.G_bb + (long)s * 9 * QN * QN;            // block 0 = [self, self] of the block-compact layout
+    double* gd = a.G_rdd + (long)s * 9 * QN * QN;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
+    for (int k = 0; k < TPW; ++k) {
+      if (ti[k] < 0) continue;
+      const int col = tj[k] * 16 + li;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = i * 16 + lk + 4 * r;
-        const double vb = accb[i][r], vd = accd[i][r];
+        const int row = ti[k] * 16 + lk + 4 * r;
+        const double vb = accb[k][r], vd = accd[k][r];
         if (col < QN && row < QN) {
-          gb[(long)row * QN] = vb;
-          gd[(long)row * QN] = vd;
+          gb[(long)row * QN + col] = vb;
+          gd[(long)row * QN + col] = vd;
+          if (ti[k] != tj[k]) {                    // mirror: the stored operator is exactly symmetric
+            gb[(long)col * QN + row] = vb;
+            gd[(long)col * QN + row] = vd;
+          }
         }
       }
     }
@@ -1156,14 +1187,14 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     const int nr = (QN + 15) / 16;
     const size_t ldsf2 = sizeof(double) * 4 * t.nT + sizeof(int) * 3 * t.nT;
     switch (nr) {
-      case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(320), ldsf2, s_f23, t, a); break;
-      case 2: hipLaunchKernelGGL(k_f2<2>, dim3(S), dim3(384), ldsf2, s_f23, t, a); break;
-      case 3: hipLaunchKernelGGL(k_f2<3>, dim3(S), dim3(448), ldsf2, s_f23, t, a); break;
-      case 4: hipLaunchKernelGGL(k_f2<4>, dim3(S), dim3(512), ldsf2, s_f23, t, a); break;
-      case 5: hipLaunchKernelGGL(k_f2<5>, dim3(S), dim3(576), ldsf2, s_f23, t, a); break;
-      case 6: hipLaunchKernelGGL(k_f2<6>, dim3(S), dim3(640), ldsf2, s_f23, t, a); break;
-      case 7: hipLaunchKernelGGL(k_f2<7>, dim3(S), dim3(704), ldsf2, s_f23, t, a); break;
-      default: hipLaunchKernelGGL(k_f2<8>, dim3(S), dim3(768), ldsf2, s_f23, t, a); break;
+      case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
+      case 2: hipLaunchKernelGGL(k_f2<2>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
+      case 3: hipLaunchKernelGGL(k_f2<3>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
+      case 4: hipLaunchKernelGGL(k_f2<4>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
+      case 5: hipLaunchKernelGGL(k_f2<5>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
+      case 6: hipLaunchKernelGGL(k_f2<6>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
+      case 7: hipLaunchKernelGGL(k_f2<7>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
+      default: hipLaunchKernelGGL(k_f2<8>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
