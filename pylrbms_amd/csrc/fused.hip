@@ -858,32 +858,57 @@ __global__ __launch_bounds__(512) void k_thin_nc(Tmpl t, int S, const int* __res
   const int KP = (3 * t.ntouch + 3) & ~3;
   double* Wa = lds;
   double* Yc = lds + KP * LDA;
+  // per touching element p (built once, so that the staging below has no dependent index chains or integer divisions):
+  //   Ksc[p][9]       ebar_T * K_T
+  //   vtab[p][i]      lattice vertex of local DoF i;   ptab[p][i][sd]  its position along side sd, or -1 if not on it
+  double* Ksc = Yc + KP * LDB;
+  int* vtab = reinterpret_cast<int*>(Ksc + 9 * t.ntouch);
+  int* ptab = vtab + 3 * t.ntouch;
+  int* ttab = ptab + 12 * t.ntouch;
   __shared__ int side_mask[256];                // per touching element: which sides its vertices lie on
   for (int i = tid; i < KP * LDA; i += 512) Wa[i] = 0.0;
   for (int i = tid; i < KP * LDB; i += 512) Yc[i] = 0.0;
   for (int p = tid; p < ne && p < 256; p += 512) {
     const int T = t.touch_elem[side * t.ntouch + p];
+    ttab[p] = T;
     int m = 0;
     for (int i = 0; i < 3; ++i) {
       const int v = t.dof_vertex[3 * T + i], lx = v % t.nvx, ly = v / t.nvx;
       m |= (ly == 0 ? 1 : 0) | (lx == 0 ? 2 : 0) | (lx == t.nvx - 1 ? 4 : 0) | (ly == t.nvy - 1 ? 8 : 0);
+      vtab[3 * p + i] = v;
+      ptab[(3 * p + i) * 4 + 0] = ly == 0 ? lx : -1;
+      ptab[(3 * p + i) * 4 + 1] = lx == 0 ? ly : -1;
+      ptab[(3 * p + i) * 4 + 2] = lx == t.nvx - 1 ? ly : -1;
+      ptab[(3 * p + i) * 4 + 3] = ly == t.nvy - 1 ? lx : -1;
     }
     side_mask[p] = m;
+    double K[9];
+    stiffness3(t, T, K);
+    const double eb = ebar[(long)s * t.nT + T];
+    for (int i = 0; i < 9; ++i) Ksc[9 * p + i] = eb * K[i];
   }
   __syncthreads();
+  const int nvs = nvs_of(t);
+  const double* Vs = V + (long)s * t.n * N;
+  const double* As = AvgSelf + (long)s * t.nv * N;
+  const double* Aa = AvgSide + ((long)s * 4 + side) * nvs * N;
   // phase 1: rows of the touching elements: Wa (neighbour image), and E applied to the own / neighbour image
   for (int it = tid; it < ne * N; it += 512) {
     const int p = it / N, j = it - p * N;
-    const int T = t.touch_elem[side * t.ntouch + p];
-    double wa[3], ws[3], K[9];
-    oswald_rows(t, s, T, slot, N, j, V, AvgSelf, AvgSide, wa);
-    oswald_rows(t, s, T, 2, N, j, V, AvgSelf, AvgSide, ws);
-    stiffness3(t, T, K);
-    const double eb = ebar[(long)s * t.nT + T];
+    const int T = ttab[p];
+    double wa[3], ws[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int pos = ptab[(3 * p + i) * 4 + side];
+      ws[i] = Vs[(long)(3 * T + i) * N + j] - As[(long)vtab[3 * p + i] * N + j];
+      wa[i] = pos >= 0 ? -Aa[(long)pos * N + j] : 0.0;
+    }
+    const double* K = Ksc + 9 * p;
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
       Wa[(3 * p + k) * LDA + j] = wa[k];
-      Yc[(3 * p + k) * LDB + j] = eb * (K[k * 3] * ws[0] + K[k * 3 + 1] * ws[1] + K[k * 3 + 2] * ws[2]);
-      Yc[(3 * p + k) * LDB + NMAX + j] = eb * (K[k * 3] * wa[0] + K[k * 3 + 1] * wa[1] + K[k * 3 + 2] * wa[2]);
+      Yc[(3 * p + k) * LDB + j] = K[k * 3] * ws[0] + K[k * 3 + 1] * ws[1] + K[k * 3 + 2] * ws[2];
+      Yc[(3 * p + k) * LDB + NMAX + j] = K[k * 3] * wa[0] + K[k * 3 + 1] * wa[1] + K[k * 3 + 2] * wa[2];
     }
   }
   __syncthreads();
@@ -918,41 +943,46 @@ __global__ __launch_bounds__(512) void k_thin_nc(Tmpl t, int S, const int* __res
       }
     }
   }
-  // phase 3: blocks [a, b] towards the other sides b (only elements touching both sides contribute; usually zero)
-  for (int c = tid; c < 3 * N; c += 512) {
-    const int which = c / N, j = c - which * N;       // which-th slot of {0, 1, 3, 4} without `slot`
-    int slot2 = -1, seen = 0;
+  // phase 3: blocks [a, b] towards the other sides b: only elements touching both sides contribute (the corner ones;
+  // none for the opposite side).  Work item = (other slot, column j, chunk of NMAX / 4 rows), all 8 waves busy.
+  constexpr int RPC = NMAX / 4;
+  for (int it = tid; it < 3 * N * 4; it += 512) {
+    const int which = it / (4 * N), rem = it - which * 4 * N, rc = rem / N, j = rem - rc * N;
+    int slot2 = -1, seen = 0;                     // which-th slot of {0, 1, 3, 4} without `slot`
 #pragma unroll
     for (int sl = 0; sl < 5; ++sl) {
       if (sl == 2 || sl == slot) continue;
       if (seen == which) slot2 = sl;
       ++seen;
     }
-    double accv[NMAX];
+    double accv[RPC];
 #pragma unroll
-    for (int i = 0; i < NMAX; ++i) accv[i] = 0.0;
+    for (int i = 0; i < RPC; ++i) accv[i] = 0.0;
     const int sx = nbr[s * 5 + slot2];
     if (sx >= 0) {
-      const int bit2 = 1 << slot_to_side(slot2);
+      const int sd2 = slot_to_side(slot2), bit2 = 1 << sd2;
+      const double* Ab = AvgSide + ((long)s * 4 + sd2) * nvs * N;
       for (int p = 0; p < ne; ++p) {
-        if (!(side_mask[p] & bit2)) continue;      // only elements that also touch side b contribute
-        const int T = t.touch_elem[side * t.ntouch + p];
+        if (!(side_mask[p] & bit2)) continue;
         double w[3];
-        oswald_rows(t, s, T, slot2, N, j, V, AvgSelf, AvgSide, w);
-        double K[9];
-        stiffness3(t, T, K);
-        const double eb = ebar[(long)s * t.nT + T];
-        for (int k = 0; k < 3; ++k) {
-          const double y = eb * (K[k * 3] * w[0] + K[k * 3 + 1] * w[1] + K[k * 3 + 2] * w[2]);
-          const double* wa = Wa + (3 * p + k) * LDA;
 #pragma unroll
-          for (int i = 0; i < NMAX; ++i) accv[i] += wa[i] * y;
+        for (int i = 0; i < 3; ++i) {
+          const int pos = ptab[(3 * p + i) * 4 + sd2];
+          w[i] = pos >= 0 ? -Ab[(long)pos * N + j] : 0.0;
+        }
+        const double* K = Ksc + 9 * p;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double y = K[k * 3] * w[0] + K[k * 3 + 1] * w[1] + K[k * 3 + 2] * w[2];
+          const double* wa = Wa + (3 * p + k) * LDA + rc * RPC;
+#pragma unroll
+          for (int i = 0; i < RPC; ++i) accv[i] += wa[i] * y;
         }
       }
     }
 #pragma unroll
-    for (int i = 0; i < NMAX; ++i)
-      if (i < N) G[(long)(slot * N + i) * W + slot2 * N + j] = accv[i];
+    for (int i = 0; i < RPC; ++i)
+      if (rc * RPC + i < N) G[(long)(slot * N + rc * RPC + i) * W + slot2 * N + j] = accv[i];
   }
 }
 
@@ -1072,12 +1102,17 @@ int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N) {
   return (long)ctx->S * t.nrt * Q * N + (long)ctx->S * 4 * t.ncf * Q * N + (long)ctx->S * t.nv * N + (long)ctx->S * 4 * nvs * N;
 }
 
+static size_t thin_nc_lds_bytes(const Tmpl& t, int ntx) {   // Wa, Yc, Ksc, vtab / ptab / ttab of k_thin_nc
+  const size_t kp = (size_t)((3 * t.ntouch + 3) & ~3);
+  return sizeof(double) * (kp * (padded_ld(ntx) + padded_ld(2 * ntx)) + 9 * (size_t)t.ntouch) + sizeof(int) * 16 * (size_t)t.ntouch;
+}
+
 bool fused_supported(lrbms_ctx* ctx, int Q, int N) {
   const Tmpl& t = ctx->t;
   if (N > 64 || Q > 4 || Q * N > 128 || t.nT % 8 != 0 || t.nT > 1024 || t.ntouch > 256) return false;
   {
     const int ntx = (N + 15) / 16;
-    if ((size_t)((3 * t.ntouch + 3) & ~3) * (padded_ld(ntx) + padded_ld(2 * ntx)) * sizeof(double) > 64 * 1024) return false;
+    if (thin_nc_lds_bytes(t, ntx) > 64 * 1024) return false;
   }
   if ((size_t)(3 * t.ncf * Q * N + Q * t.ncf * N + 3 * t.ncf) * sizeof(double) > 64 * 1024) return false;
   if ((size_t)2 * 3 * t.ncf * N * sizeof(double) > 64 * 1024) return false;
@@ -1168,7 +1203,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   {
     const int ntx = (N + 15) / 16;
     const int kp = (3 * t.ntouch + 3) & ~3;
-    const size_t lds = sizeof(double) * (size_t)kp * (padded_ld(ntx) + padded_ld(2 * ntx));
+    const size_t lds = thin_nc_lds_bytes(t, ntx);
     switch (ntx) {
       case 1: hipLaunchKernelGGL(k_thin_nc<1>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
       case 2: hipLaunchKernelGGL(k_thin_nc<2>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
