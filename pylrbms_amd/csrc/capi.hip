@@ -163,6 +163,7 @@ int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* d, int32_t S, int32
   ctx->nbr = const_cast<int*>(nbr_dev);
   ctx->S = S;
   ctx->S_ext = S_ext;
+  if ((rc = build_template_tables(ctx))) return rc;
   ctx->has_mesh = true;
   return LRBMS_OK;
 }

@@ -257,11 +257,7 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     nbl[i] = t.nb_elem[i];
     rtl[i] = t.elem_rt[i];
   }
-  for (int T = tid; T < t.nT; T += 512) {
-    double K[9];
-    stiffness3(t, T, K);
-    for (int i = 0; i < 9; ++i) Kl[T * 9 + i] = K[i];
-  }
+  for (int i = tid; i < 9 * t.nT; i += 512) Kl[i] = t.stiff[i];
   for (int i = tid; i < 2 * 3 * EC * LDX; i += 512) (&Xs[0][0])[i] = 0.0;
   for (int i = tid; i < 2 * 3 * EC * LDY; i += 512) (&Ys[0][0])[i] = 0.0;
   __syncthreads();
@@ -777,51 +773,95 @@ struct F3Args {
   int N, S;
 };
 
+constexpr int F3_EW = 4;   // elements staged per wave and chunk: 16 elements (48 K-rows) per barrier pair
+
 template <int NTX>
 __global__ __launch_bounds__(256) void k_f3(Tmpl t, F3Args a) {
   constexpr int LD = padded_ld(NTX);
-  constexpr int NT = (NTX * NTX + 3) / 4;
-  __shared__ double Xs[3 * EC * LD], Ys[3 * EC * LD];
+  constexpr int ECH = 4 * F3_EW;                 // elements per chunk
+  constexpr int NTRI = NTX * (NTX + 1) / 2;      // G_nc[self,self] = W^T E W is symmetric: tiles on / above the diagonal
+  constexpr int NT = (NTRI + 3) / 4;
+  __shared__ double Xs[3 * ECH * LD], Ys[3 * ECH * LD];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
   const int N = a.N, W = 5 * N;
-  for (int i = tid; i < 3 * EC * LD; i += 256) Xs[i] = Ys[i] = 0.0;
+  for (int i = tid; i < 3 * ECH * LD; i += 256) Xs[i] = Ys[i] = 0.0;
+  int ti[NT], tj[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {                 // (wave + 4 k)-th upper-triangular tile, row-major
+    int idx = wave + 4 * k, i = 0;
+    if (idx >= NTRI) idx = -1;
+    int rem = idx;
+    while (idx >= 0 && rem >= NTX - i) {
+      rem -= NTX - i;
+      ++i;
+    }
+    ti[k] = idx >= 0 ? i : -1;
+    tj[k] = idx >= 0 ? i + rem : 0;
+  }
   __syncthreads();
   d4 acc[NT];
+#pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int c0 = 0; c0 < t.nT; c0 += EC) {
-    const int T = c0 + wave;
-    if (lane < N) {
-      double w[3], K[9];
-      oswald_rows(t, s, T, 2, N, lane, a.V, a.AvgSelf, a.AvgSide, w);
-      stiffness3(t, T, K);
-      const double eb = a.ebar[(long)s * t.nT + T];
+  const double* Vs = a.V + (long)s * t.n * N;
+  const double* As = a.AvgSelf + (long)s * t.nv * N;
+  const double* ebs = a.ebar + (long)s * t.nT;
+  const int jc = lane < N ? lane : N - 1;
+  for (int c0 = 0; c0 < t.nT; c0 += ECH) {
+    // each wave stages F3_EW elements: all their loads are issued before the first use (one exposed latency per chunk)
+    double v[F3_EW][3], av[F3_EW][3];
+#pragma unroll
+    for (int e = 0; e < F3_EW; ++e) {
+      const int T = c0 + wave * F3_EW + e;
+      const bool ok = T < t.nT;
+#pragma unroll
       for (int i = 0; i < 3; ++i) {
-        Xs[(3 * wave + i) * LD + lane] = w[i];
-        Ys[(3 * wave + i) * LD + lane] = eb * (K[i * 3] * w[0] + K[i * 3 + 1] * w[1] + K[i * 3 + 2] * w[2]);
+        const int r = ok ? 3 * T + i : 0;
+        v[e][i] = Vs[(long)r * N + jc];
+        av[e][i] = As[(long)t.dof_vertex[r] * N + jc];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < F3_EW; ++e) {
+      const int T = c0 + wave * F3_EW + e;
+      const bool ok = T < t.nT;
+      const double* K = t.stiff + 9 * (ok ? T : 0);
+      const double eb = ok ? ebs[T] : 0.0;
+      double w[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) w[i] = ok ? v[e][i] - av[e][i] : 0.0;
+      if (lane < N) {
+        const int row = 3 * (wave * F3_EW + e);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          Xs[(row + i) * LD + lane] = w[i];
+          Ys[(row + i) * LD + lane] = eb * (K[i * 3] * w[0] + K[i * 3 + 1] * w[1] + K[i * 3 + 2] * w[2]);
+        }
       }
     }
     __syncthreads();
-    for (int kk = 0; kk < 3 * EC; kk += 4)
-      for (int k = 0; k < NT; ++k) {
-        const int tile = wave + 4 * k;
-        if (tile < NTX * NTX) {
-          const int ti = tile / NTX, tj = tile - ti * NTX;
-          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(kk + lk) * LD + ti * 16 + li], Ys[(kk + lk) * LD + tj * 16 + li], acc[k], 0, 0, 0);
-        }
-      }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      if (ti[k] < 0) continue;                   // wave-uniform
+      const int xo = ti[k] * 16 + li, yo = tj[k] * 16 + li;
+#pragma unroll
+      for (int kk = 0; kk < 3 * ECH; kk += 4)
+        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(kk + lk) * LD + xo], Ys[(kk + lk) * LD + yo], acc[k], 0, 0, 0);
+    }
     __syncthreads();
   }
+  double* g = a.G_nc + (long)s * W * W + (long)(2 * N) * W + 2 * N;
+#pragma unroll
   for (int k = 0; k < NT; ++k) {
-    const int tile = wave + 4 * k;
-    if (tile >= NTX * NTX) continue;
-    const int ti = tile / NTX, tj = tile - ti * NTX;
-    const int col = tj * 16 + li;
-    if (col >= N) continue;
-    double* g = a.G_nc + (long)s * W * W + (long)(2 * N) * W + 2 * N + col;
+    if (ti[k] < 0) continue;
+    const int col = tj[k] * 16 + li;
+#pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = ti * 16 + lk + 4 * r;
-      if (row < N) g[(long)row * W] = acc[k][r];
+      const int row = ti[k] * 16 + lk + 4 * r;
+      if (col < N && row < N) {
+        g[(long)row * W + col] = acc[k][r];
+        if (ti[k] != tj[k]) g[(long)col * W + row] = acc[k][r];   // mirror: the stored operator is exactly symmetric
+      }
     }
   }
 }
@@ -858,34 +898,26 @@ __global__ __launch_bounds__(512) void k_thin_nc(Tmpl t, int S, const int* __res
   const int KP = (3 * t.ntouch + 3) & ~3;
   double* Wa = lds;
   double* Yc = lds + KP * LDA;
-  // per touching element p (built once, so that the staging below has no dependent index chains or integer divisions):
-  //   Ksc[p][9]       ebar_T * K_T
-  //   vtab[p][i]      lattice vertex of local DoF i;   ptab[p][i][sd]  its position along side sd, or -1 if not on it
-  double* Ksc = Yc + KP * LDB;
-  int* vtab = reinterpret_cast<int*>(Ksc + 9 * t.ntouch);
-  int* ptab = vtab + 3 * t.ntouch;
-  int* ttab = ptab + 12 * t.ntouch;
-  __shared__ int side_mask[256];                // per touching element: which sides its vertices lie on
+  // Per touching element everything but ebar is template data built once at mesh upload (t.stiff, t.touch_vtx,
+  // t.touch_pos, t.touch_mask): no dependent index chains or integer divisions in the staging.
+  // They are copied to LDS by all threads (coalesced), with ebar folded into the stiffness blocks.
+  double* Ksc = Yc + KP * LDB;                                    // [ne][9]  ebar_T K_T
+  int* ttab = reinterpret_cast<int*>(Ksc + 9 * t.ntouch);        // [ne]
+  int* vtab = ttab + t.ntouch;                                    // [ne][3]
+  int* ptab = vtab + 3 * t.ntouch;                                // [ne][3][4]
+  int* side_mask = ptab + 12 * t.ntouch;                          // [ne]
+  const double* ebs = ebar + (long)s * t.nT;
   for (int i = tid; i < KP * LDA; i += 512) Wa[i] = 0.0;
   for (int i = tid; i < KP * LDB; i += 512) Yc[i] = 0.0;
-  for (int p = tid; p < ne && p < 256; p += 512) {
-    const int T = t.touch_elem[side * t.ntouch + p];
-    ttab[p] = T;
-    int m = 0;
-    for (int i = 0; i < 3; ++i) {
-      const int v = t.dof_vertex[3 * T + i], lx = v % t.nvx, ly = v / t.nvx;
-      m |= (ly == 0 ? 1 : 0) | (lx == 0 ? 2 : 0) | (lx == t.nvx - 1 ? 4 : 0) | (ly == t.nvy - 1 ? 8 : 0);
-      vtab[3 * p + i] = v;
-      ptab[(3 * p + i) * 4 + 0] = ly == 0 ? lx : -1;
-      ptab[(3 * p + i) * 4 + 1] = lx == 0 ? ly : -1;
-      ptab[(3 * p + i) * 4 + 2] = lx == t.nvx - 1 ? ly : -1;
-      ptab[(3 * p + i) * 4 + 3] = ly == t.nvy - 1 ? lx : -1;
-    }
-    side_mask[p] = m;
-    double K[9];
-    stiffness3(t, T, K);
-    const double eb = ebar[(long)s * t.nT + T];
-    for (int i = 0; i < 9; ++i) Ksc[9 * p + i] = eb * K[i];
+  for (int i = tid; i < ne; i += 512) {
+    ttab[i] = t.touch_elem[side * t.ntouch + i];
+    side_mask[i] = t.touch_mask[side * t.ntouch + i];
+  }
+  for (int i = tid; i < 3 * ne; i += 512) vtab[i] = t.touch_vtx[side * t.ntouch * 3 + i];
+  for (int i = tid; i < 12 * ne; i += 512) ptab[i] = t.touch_pos[side * t.ntouch * 12 + i];
+  for (int i = tid; i < 9 * ne; i += 512) {
+    const int T = t.touch_elem[side * t.ntouch + i / 9];
+    Ksc[i] = ebs[T] * t.stiff[9 * T + i % 9];
   }
   __syncthreads();
   const int nvs = nvs_of(t);
@@ -1102,9 +1134,66 @@ int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N) {
   return (long)ctx->S * t.nrt * Q * N + (long)ctx->S * 4 * t.ncf * Q * N + (long)ctx->S * t.nv * N + (long)ctx->S * 4 * nvs * N;
 }
 
-static size_t thin_nc_lds_bytes(const Tmpl& t, int ntx) {   // Wa, Yc, Ksc, vtab / ptab / ttab of k_thin_nc
+namespace {
+__global__ __launch_bounds__(256) void k_build_tables(Tmpl t, double* __restrict__ stiff, int* __restrict__ tvtx,
+                                                      int* __restrict__ tpos, int* __restrict__ tmask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < t.nT) {
+    double K[9];
+    stiffness3(t, i, K);
+    for (int k = 0; k < 9; ++k) stiff[i * 9 + k] = K[k];
+  }
+  if (i < 4 * t.ntouch) {
+    const int sd = i / t.ntouch, p = i - sd * t.ntouch;
+    int m = 0;
+    if (p < t.touch_count[sd]) {
+      const int T = t.touch_elem[i];
+      for (int d = 0; d < 3; ++d) {
+        const int v = t.dof_vertex[3 * T + d], lx = v % t.nvx, ly = v / t.nvx;
+        m |= (ly == 0 ? 1 : 0) | (lx == 0 ? 2 : 0) | (lx == t.nvx - 1 ? 4 : 0) | (ly == t.nvy - 1 ? 8 : 0);
+        tvtx[i * 3 + d] = v;
+        tpos[(i * 3 + d) * 4 + 0] = ly == 0 ? lx : -1;
+        tpos[(i * 3 + d) * 4 + 1] = lx == 0 ? ly : -1;
+        tpos[(i * 3 + d) * 4 + 2] = lx == t.nvx - 1 ? ly : -1;
+        tpos[(i * 3 + d) * 4 + 3] = ly == t.nvy - 1 ? lx : -1;
+      }
+    } else {
+      for (int d = 0; d < 3; ++d) {
+        tvtx[i * 3 + d] = 0;
+        for (int q = 0; q < 4; ++q) tpos[(i * 3 + d) * 4 + q] = -1;
+      }
+    }
+    tmask[i] = m;
+  }
+}
+}  // namespace
+
+int build_template_tables(lrbms_ctx* ctx) {
+  Tmpl& t = ctx->t;
+  double* stiff = nullptr;
+  int *tvtx = nullptr, *tpos = nullptr, *tmask = nullptr;
+  LRBMS_HIP_CHECK(ctx, hipMalloc(&stiff, sizeof(double) * 9 * (size_t)t.nT));
+  ctx->owned.push_back(stiff);
+  LRBMS_HIP_CHECK(ctx, hipMalloc(&tvtx, sizeof(int) * 12 * (size_t)t.ntouch));
+  ctx->owned.push_back(tvtx);
+  LRBMS_HIP_CHECK(ctx, hipMalloc(&tpos, sizeof(int) * 48 * (size_t)t.ntouch));
+  ctx->owned.push_back(tpos);
+  LRBMS_HIP_CHECK(ctx, hipMalloc(&tmask, sizeof(int) * 4 * (size_t)t.ntouch));
+  ctx->owned.push_back(tmask);
+  const int total = t.nT > 4 * t.ntouch ? t.nT : 4 * t.ntouch;
+  hipLaunchKernelGGL(k_build_tables, dim3((total + 255) / 256), dim3(256), 0, nullptr, t, stiff, tvtx, tpos, tmask);
+  LRBMS_LAUNCH_CHECK(ctx);
+  LRBMS_HIP_CHECK(ctx, hipDeviceSynchronize());
+  t.stiff = stiff;
+  t.touch_vtx = tvtx;
+  t.touch_pos = tpos;
+  t.touch_mask = tmask;
+  return LRBMS_OK;
+}
+
+static size_t thin_nc_lds_bytes(const Tmpl& t, int ntx) {   // Wa, Yc, Ksc, ttab / vtab / ptab / side_mask of k_thin_nc
   const size_t kp = (size_t)((3 * t.ntouch + 3) & ~3);
-  return sizeof(double) * (kp * (padded_ld(ntx) + padded_ld(2 * ntx)) + 9 * (size_t)t.ntouch) + sizeof(int) * 16 * (size_t)t.ntouch;
+  return sizeof(double) * (kp * (padded_ld(ntx) + padded_ld(2 * ntx)) + 9 * (size_t)t.ntouch) + sizeof(int) * 17 * (size_t)t.ntouch;
 }
 
 bool fused_supported(lrbms_ctx* ctx, int Q, int N) {

@@ -19,6 +19,11 @@ struct Tmpl {
   int ntouch;
   const int *touch_elem, *touch_count;
   const double *grad, *area, *normal, *face_len, *points;
+  // derived on the device at mesh upload (build_template_tables, fused.hip): template data every subdomain shares
+  const double* stiff;       // [nT][9]            K_T[i][j] = grad phi_i . kappa grad phi_j
+  const int* touch_vtx;      // [4][ntouch][3]     lattice vertex of local DoF i of the p-th element touching side sd
+  const int* touch_pos;      // [4][ntouch][3][4]  its position along side sd', or -1 if it is not on that side
+  const int* touch_mask;     // [4][ntouch]        bit sd' set if the element has a vertex on side sd'
 };
 
 struct lrbms_ctx {
@@ -78,6 +83,8 @@ static inline int lrbms_fail(lrbms_ctx* ctx, int code, const std::string& msg) {
   } while (0)
 
 #define LRBMS_LAUNCH_CHECK(ctx) LRBMS_HIP_CHECK(ctx, hipGetLastError())
+
+int build_template_tables(lrbms_ctx* ctx);   // fused.hip; called at the end of lrbms_mesh_upload
 
 // launchers implemented in the other translation units
 int launch_assemble_swipdg(lrbms_ctx*, int Q, const double* lam, double* A_diag, double* A_cpl, hipStream_t);
