@@ -1088,28 +1088,56 @@ __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
     Xab[it] = x;
   }
   __syncthreads();
-  // the two non-zero blocks of block-row a: [a, a] (rank-np with the side-face scalars) and [a, self]
-  for (int it = tid; it < QN * QN; it += 256) {
-    const int row = it / QN, cc = it - row * QN;
-    double vb = 0.0, vd = 0.0, wb = 0.0, wd = 0.0;
-    for (int p = 0; p < np; ++p) {
-      const double ra = Ra[p * QN + row];
-      const double rr = ra * Ra[p * QN + cc];
-      vb += sc[p * 3] * rr;
-      vd += sc[p * 3 + 1] * rr;
-      wb += ra * Yb[p * QN + cc];
-      wd += ra * Dp[p * QN + cc];
+  // the two non-zero blocks of block-row a: [a, a] (rank-np with the side-face scalars) and [a, self].
+  // Register tiles of 4 rows x 1 column, lanes over consecutive columns: per side face 4 broadcast + 3 lane reads from
+  // LDS feed 16 outputs (one output per thread needed 5 reads for 4 outputs, and the LDS pipe competed with the HBM
+  // writes that bound this kernel); every store instruction still writes consecutive doubles across the lanes.
+  {
+    constexpr int RT = 4;
+    const int trows = (QN + RT - 1) / RT;
+    for (int it = tid; it < trows * QN; it += 256) {
+      const int tr = it / QN, cc = it - tr * QN, r0 = RT * tr;
+      double vb[RT], vd[RT], wb[RT], wd[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) vb[i] = vd[i] = wb[i] = wd[i] = 0.0;
+      for (int p = 0; p < np; ++p) {
+        const double rc = Ra[p * QN + cc], yc = Yb[p * QN + cc], dc = Dp[p * QN + cc];
+        const double s0 = sc[p * 3] * rc, s1 = sc[p * 3 + 1] * rc;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const double ra = Ra[p * QN + (r0 + i < QN ? r0 + i : QN - 1)];
+          vb[i] += ra * s0;
+          vd[i] += ra * s1;
+          wb[i] += ra * yc;
+          wd[i] += ra * dc;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        if (r0 + i < QN) {
+          const long o = (long)(r0 + i) * QN + cc;
+          Gb_aa[o] = vb[i];
+          Gd_aa[o] = vd[i];
+          Gb_as[o] = wb[i];
+          Gd_as[o] = wd[i];
+        }
+      }
     }
-    Gb_aa[it] = vb;
-    Gd_aa[it] = vd;
-    Gb_as[it] = wb;
-    Gd_as[it] = wd;
-  }
-  for (int it = tid; it < Q * N * QN; it += 256) {
-    const int q = it / (N * QN), rem = it - q * N * QN, i = rem / QN, cc = rem - i * QN;
-    double v = 0.0;
-    for (int p = 0; p < np; ++p) v += Xab[(q * np + p) * N + i] * Ra[p * QN + cc];
-    a.G_ab[(((long)q * S + s) * N + i) * C + slot * QN + cc] = v;
+    const int irows = (N + RT - 1) / RT;
+    for (int it = tid; it < Q * irows * QN; it += 256) {
+      const int q = it / (irows * QN), rem = it - q * irows * QN, ir = rem / QN, cc = rem - ir * QN, i0 = RT * ir;
+      double v[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) v[i] = 0.0;
+      for (int p = 0; p < np; ++p) {
+        const double rc = Ra[p * QN + cc];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) v[i] += Xab[(q * np + p) * N + (i0 + i < N ? i0 + i : N - 1)] * rc;
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+        if (i0 + i < N) a.G_ab[(((long)q * S + s) * N + i0 + i) * C + slot * QN + cc] = v[i];
+    }
   }
   for (int c = tid; c < QN; c += 256) {
     double v = 0.0;
