@@ -34,6 +34,9 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+#ifndef F1_PF
+#define F1_PF 1     // prefetch distance of the k_f1 producers in chunks (1 or 2; measured at config 3: 550 us vs 566 us)
+#endif
 #ifndef F1_SCALAR_LOADS
 #define F1_SCALAR_LOADS 0
 #endif
@@ -267,6 +270,211 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
 
   if (wave < EC) {
     // ================================================= producers
+#ifdef F1_PRODUCER_PRIO
+    __builtin_amdgcn_s_setprio(F1_PRODUCER_PRIO);
+#endif
+   if constexpr (QP > 0) {
+    // ---- straight-line producer (compile-time Q, all groups in this slice; canonical group order
+    // [SYS q][ENERGY][MASS][AA q<=q'][AB q q']).  Per element:
+    //  * the QP + 1 four-block applies (A_q V, P V: 108 of the ~170 multiply-adds of an element) are ONE small MFMA
+    //    product: rows = the 3 (QP + 1) stacked output rows, K = 12 = (block, local column), columns = basis columns.
+    //    Both operands come straight from global memory in the MFMA lane layout, so the element blocks need no
+    //    broadcast at all (on the VALU they cost two v_readlane per entry, or an LDS round trip that saturated the
+    //    LDS pipe), and VALU / f64-MFMA issue serialise per SIMD on this chip, so 9 MFMAs replace ~330 VALU issues;
+    //  * everything else (X rows, rhs, mass, c^{qq'} K V, A_ab R) stays on the VALU with lanes = basis columns; the
+    //    A_ab^q / c^{qq'} entries sit one per lane in a prefetch register and are broadcast with v_readlane;
+    //  * all loads of an element are a prefetch set issued one chunk ahead as asm loads and completed by an explicit
+    //    s_waitcnt vmcnt(NLOADS) (see gload_f64).
+    constexpr int R = 3 * (QP + 1);
+    constexpr int NLOADS = 3 + 3 * NTX + 3 + 3 * QP + 1;
+    struct Set {
+      double A[3], B[3][NTX], v0[3], rv[3][QP], ab;
+    };
+    const bool do_rhs = a.rhs_red != nullptr && blockIdx.y == 0;
+    const double* Vs = a.V + (long)s * t.n * N;
+    const double* Rs = a.Rself + (long)s * t.nrt * QN;
+    const int j = lane;
+    const bool colj = j < N;
+    const int jc = colj ? j : N - 1;   // idle lanes load (and never use) the last column: no exec masking around loads
+    const int r16 = lane & 15, kq = lane >> 4;
+    const double* asrc[3];
+    int bbk[3], ck[3], colB[NTX], yoff[3];
+    {
+      const int g = r16 / 3 < QP + 1 ? r16 / 3 : QP, i = r16 % 3;   // rows >= R repeat a valid row; they are never stored
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const int k = 4 * ks + kq, bb = k / 3, c = k - 3 * bb;
+        asrc[ks] = (g < QP ? a.A_diag + ((long)g * S + s) * t.nT * 36 : a.P_diag + (long)s * t.nT * 36) + bb * 9 + i * 3 + c;
+        bbk[ks] = bb;
+        ck[ks] = c;
+      }
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) colB[ct] = 16 * ct + r16 < N ? 16 * ct + r16 : N - 1;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {           // LDS offset of output row kq + 4 rr (group r / 3, local row r % 3), or -1
+        const int r = kq + 4 * rr;
+        yoff[rr] = r < R ? (3 * wave + r % 3) * LDY + (r / 3) * N : -1;
+      }
+    }
+    const double* absrc = a.Aab + (long)s * t.nT * 9;   // lanes beyond the record re-read its first entry
+    int abstr = 9;
+    if (lane < 9 * QP) {
+      absrc = a.Aab + ((long)(lane / 9) * S + s) * t.nT * 9 + lane % 9;
+    } else if (lane < 9 * QP + QP * QP) {
+      absrc = a.caa + ((long)(lane - 9 * QP) * S + s) * t.nT;
+      abstr = 1;
+    }
+    const cint_p nbc = (cint_p)t.nb_elem;     // template adjacency of the (wave-uniform) element through the scalar cache
+    const cint_p rtc = (cint_p)t.elem_rt;
+    auto load_set = [&](int T, Set& x) {
+      // A face without an in-subdomain neighbour has an all-zero block in A_diag / P_diag (its coupling lives in
+      // A_cpl), so its rows may be any finite values: the element's own rows, which keeps every load unconditional.
+      int nbT[4], rtT[3];
+      nbT[0] = T;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const int nb = nbc[T * 3 + f];
+        nbT[1 + f] = nb >= 0 ? nb : T;
+        rtT[f] = rtc[T * 3 + f];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) x.A[ks] = gload_f64(asrc[ks] + (long)T * 36);
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const int e = bbk[ks] == 0 ? nbT[0] : bbk[ks] == 1 ? nbT[1] : bbk[ks] == 2 ? nbT[2] : nbT[3];
+        const double* rowp = Vs + (long)(3 * e + ck[ks]) * N;
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) x.B[ks][ct] = gload_f64(rowp + colB[ct]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) x.v0[i] = gload_f64(Vs + (long)(3 * T + i) * N + jc);
+#pragma unroll
+      for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int q2 = 0; q2 < QP; ++q2) x.rv[f][q2] = gload_f64(Rs + (long)rtT[f] * QN + q2 * N + jc);
+      x.ab = gload_f64(absrc + (long)T * abstr);
+    };
+    auto tie = [](double& v) { asm volatile("" : "+v"(v)); };
+    auto tie_set = [&](Set& x) {
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        tie(x.A[ks]);
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) tie(x.B[ks][ct]);
+        tie(x.v0[ks]);
+#pragma unroll
+        for (int q2 = 0; q2 < QP; ++q2) tie(x.rv[ks][q2]);
+      }
+      tie(x.ab);
+    };
+    auto wait_set = [&](Set& x) {   // everything older than the F1_PF younger prefetch sets is complete
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F1_PF * NLOADS));
+      tie_set(x);
+    };
+    // Prefetch distance F1_PF chunks (F1_PF + 1 register sets in rotation).  Measured per chunk at config 3: loads +
+    // barriers alone 0.87 us, consumer MFMAs alone 1.36 us, both together 2.2 us -- on this chip the load stream, the
+    // producers' VALU work and the consumers' f64 MFMAs of one SIMD add up instead of overlapping, with distance 1 or
+    // 2 alike, so the kernel time is about base + loads + staging + MFMA and each term has to be cut on its own.
+    Set s0, s1, s2;
+    load_set(wave, s0);
+    if (F1_PF == 2) load_set(EC + wave, s1);       // nT >= 8, so chunk 1 exists
+    double rhs_part = 0.0;
+    auto step = [&](int c, Set& cur, Set& nxt) {
+      const int T = c * EC + wave;                 // wave-uniform element
+      double* Xb = &Xs[c & 1][0];
+      double* Yb = &Ys[c & 1][0];
+      load_set(c + F1_PF < nchunks ? T + F1_PF * EC : T, nxt);   // unconditional (tail: this element again): the wait counts loads
+      wait_set(cur);
+#ifndef F1_NO_STAGE   // timing experiments (tools/build_variant.sh): producers only load and synchronise
+      // ---- the stacked four-block applies on the matrix pipe
+      d4 D[NTX];
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) D[ct] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) D[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.A[ks], cur.B[ks][ct], D[ct], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+          if (yoff[rr] >= 0 && 16 * ct + r16 < N) Yb[yoff[rr] + 16 * ct + r16] = D[ct][rr];
+      // ---- the rest on the VALU, lanes = basis columns
+      if (colj) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Xb[(3 * wave + i) * LDX + j] = cur.v0[i];
+        if (do_rhs) {   // b_T through the scalar unit (lgkmcnt)
+          const cdbl_p be = (cdbl_p)(a.b + (long)s * t.n + 3 * T);
+          rhs_part += be[0] * cur.v0[0] + be[1] * cur.v0[1] + be[2] * cur.v0[2];
+        }
+        double kv[3];
+        const double* K = Kl + T * 9;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          kv[i] = __builtin_fma(K[i * 3 + 2], cur.v0[2], __builtin_fma(K[i * 3 + 1], cur.v0[1], K[i * 3] * cur.v0[0]));
+        int g = QP + 1;
+        auto put = [&](const double (&y)[3]) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) Yb[(3 * wave + i) * LDY + g * N + j] = y[i];
+          ++g;
+        };
+        {
+          const double m = ((cdbl_p)t.area)[T] * (1.0 / 12.0), sum = cur.v0[0] + cur.v0[1] + cur.v0[2];
+          const double y[3] = {m * (sum + cur.v0[0]), m * (sum + cur.v0[1]), m * (sum + cur.v0[2])};
+          put(y);
+        }
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+#pragma unroll
+          for (int q2 = q; q2 < QP; ++q2) {
+            const double cc = bcast_d(cur.ab, 9 * QP + q * QP + q2);
+            const double y[3] = {cc * kv[0], cc * kv[1], cc * kv[2]};
+            put(y);
+          }
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+          double A[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) A[i] = bcast_d(cur.ab, 9 * q + i);
+#pragma unroll
+          for (int q2 = 0; q2 < QP; ++q2) {
+            double y[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              y[i] = __builtin_fma(A[i * 3 + 2], cur.rv[2][q2], __builtin_fma(A[i * 3 + 1], cur.rv[1][q2], A[i * 3] * cur.rv[0][q2]));
+            put(y);
+          }
+        }
+      }
+#endif
+      lds_barrier();                               // barrier c: buffer c & 1 is complete (global loads stay in flight)
+    };
+    int c = 0;
+    if (F1_PF == 2) {
+      for (; c + 3 <= nchunks; c += 3) {           // static register-set rotation: (cur, target of the new loads)
+        step(c, s0, s2);
+        step(c + 1, s1, s0);
+        step(c + 2, s2, s1);
+      }
+      if (c < nchunks) step(c++, s0, s2);
+      if (c < nchunks) step(c++, s1, s0);
+    } else {
+      for (; c < nchunks; c += 2) {                // nT is a multiple of 8, so nchunks is even
+        step(c, s0, s1);
+        step(c + 1, s1, s0);
+      }
+    }
+    lds_barrier();                                 // final barrier (matches the consumers' count)
+    // The sets loaded by the tail steps are never consumed.  They must still count as live until their loads have
+    // landed: a destination the compiler considers dead is handed to other values while the load is in flight, and
+    // the late write then corrupts them (seen as a GPU abort with prefetch distance 2).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie_set(s0);
+    tie_set(s1);
+    if (F1_PF == 2) tie_set(s2);
+    if (do_rhs) red[wave * 64 + lane] = rhs_part;
+   } else {
+    // ---- generic producer (runtime Q, or the groups do not fit in one slice): group table, element record through LDS
     const bool do_rhs = a.rhs_red != nullptr && blockIdx.y == 0;
     // element-block fetch of this wave's element: lane item o = lane + 64 k; (pointer, per-element stride) fixed
     const double* fsrc[PRE];
@@ -522,6 +730,7 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     lds_barrier();                                 // final barrier (matches the consumers' count)
     if constexpr (straight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (unused) prefetch set
     if (do_rhs) red[wave * 64 + lane] = rhs_part;
+   }
   } else {
     // ================================================= consumers
     const int cw = wave - EC;
@@ -534,6 +743,7 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
       lds_barrier();                               // barrier c
       const double* Xb = &Xs[c & 1][0];
       const double* Yb = &Ys[c & 1][0];
+#ifndef F1_NO_MFMA    // timing experiments: consumers only synchronise
 #pragma unroll
       for (int kk = 0; kk < 3 * EC; kk += 4) {
         double av[NTX];
@@ -546,6 +756,7 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
           for (int i = 0; i < NTX; ++i) acc[i][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[i][jt], 0, 0, 0);
         }
       }
+#endif
     }
     lds_barrier();                                 // final barrier
     // ---- epilogue: scatter the tiles to their destination arrays (static accumulator indices only)
@@ -649,6 +860,9 @@ __global__ __launch_bounds__(64 * (F2_NCW + EC)) void k_f2(Tmpl t, F2Args a) {
       asm volatile("s_waitcnt vmcnt(7)"
                    : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]), "+v"(B));
     };
+    auto wait_set_tie = [&](double (&r)[2][3], double& B) {
+      asm volatile("" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]), "+v"(B));
+    };
     load(wave, rv, Bl);
     double rfd_part[2] = {0.0, 0.0};   // columns lane and lane + 64 (QN <= 128)
     // One pipeline step: issue the loads of chunk c + 1 into the OTHER register set, stage chunk c from this one.
@@ -690,7 +904,9 @@ __global__ __launch_bounds__(64 * (F2_NCW + EC)) void k_f2(Tmpl t, F2Args a) {
       step(c + 1, nrv, nBl, rv, Bl);
     }
     lds_barrier();                                 // final barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (unused) prefetch set
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last prefetch set is never consumed, but it has to stay
+    wait_set_tie(rv, Bl);                              // live until its loads have landed (see k_f1)
+    wait_set_tie(nrv, nBl);
     red[wave * 128 + lane] = rfd_part[0];
     red[wave * 128 + 64 + lane] = rfd_part[1];
   } else {
