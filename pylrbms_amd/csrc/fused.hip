@@ -34,16 +34,15 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+#ifndef F1_SPLIT_SIMD
+#define F1_SPLIT_SIMD 0
+#endif
 #ifndef F1_PF
 #define F1_PF 1     // prefetch distance of the k_f1 producers in chunks (1 or 2; measured at config 3: 550 us vs 566 us)
-#endif
-#ifndef F1_SCALAR_LOADS
-#define F1_SCALAR_LOADS 0
 #endif
 constexpr int EC = 4;               // elements per K-chunk (12 DG rows = 3 MFMA k-steps) = staging waves
 constexpr int F1_NTY = 7;           // Y column tiles per wave in k_f1
 constexpr int F1_YW = 4 * F1_NTY * 16;   // 448 columns
-constexpr int F1_LDY = F1_YW + 16;  // row stride == 16 (mod 32) doubles: the 4 k-rows of a fragment hit disjoint banks
 constexpr int F1_MAXG = 12;
 
 __host__ __device__ constexpr int padded_ld(int tiles) { return (tiles * 16) % 32 == 16 ? tiles * 16 : tiles * 16 + 16; }
@@ -235,7 +234,6 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
   constexpr int LDX = padded_ld(NTX);
   constexpr int LDY = 4 * NTY * 16 + 16;
   constexpr int PRE = 4;                       // per-lane prefetch registers for the element blocks (ESTR <= 256)
-  constexpr int QR = QP > 0 ? QP : 1;
   extern __shared__ int idx[];                 // template adjacency cached once: nb_elem [nT][3], elem_rt [nT][3]
   __shared__ double Xs[2][3 * EC * LDX];
   __shared__ double Ys[2][3 * EC * LDY];
@@ -244,7 +242,12 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
   __shared__ Grp grp[F1_MAXG];
   __shared__ int grp_n;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+#if F1_SPLIT_SIMD   // experiment: producers on SIMDs 0 / 2, consumers on SIMDs 1 / 3 (hardware wave w runs on SIMD w % 4)
+  const int hw_wave = uniform(tid >> 6);
+  const int wave = (hw_wave & 1) ? EC + (hw_wave >> 1) : (hw_wave >> 1);
+#else
   const int wave = uniform(tid >> 6);
+#endif
   const int N = a.N, Q = a.Q, S = a.S, QN = Q * N;
   const int oP = 36 * Q, oAb = oP + 36, oC = oAb + 9 * Q, ESTR = oC + Q * Q;    // <= 256 for Q <= 4
   // select this slice's group table with static indices only (a runtime index into a kernel-argument array would
@@ -261,8 +264,11 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     rtl[i] = t.elem_rt[i];
   }
   for (int i = tid; i < 9 * t.nT; i += 512) Kl[i] = t.stiff[i];
-  for (int i = tid; i < 2 * 3 * EC * LDX; i += 512) (&Xs[0][0])[i] = 0.0;
-  for (int i = tid; i < 2 * 3 * EC * LDY; i += 512) (&Ys[0][0])[i] = 0.0;
+#ifndef F1_LDS_FILL
+#define F1_LDS_FILL 0.0   // timing experiments: non-zero operands for the consumers when the producers do not stage
+#endif
+  for (int i = tid; i < 2 * 3 * EC * LDX; i += 512) (&Xs[0][0])[i] = F1_LDS_FILL * (1 + (i % 7));
+  for (int i = tid; i < 2 * 3 * EC * LDY; i += 512) (&Ys[0][0])[i] = F1_LDS_FILL * (1 + (i % 5));
   __syncthreads();
   const int ng = uniform(grp_n);
   const int ncols = ng * N;
@@ -386,6 +392,7 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
       load_set(c + F1_PF < nchunks ? T + F1_PF * EC : T, nxt);   // unconditional (tail: this element again): the wait counts loads
       wait_set(cur);
 #ifndef F1_NO_STAGE   // timing experiments (tools/build_variant.sh): producers only load and synchronise
+#ifndef F1_NO_APPLY
       // ---- the stacked four-block applies on the matrix pipe
       d4 D[NTX];
 #pragma unroll
@@ -399,8 +406,13 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
           if (yoff[rr] >= 0 && 16 * ct + r16 < N) Yb[yoff[rr] + 16 * ct + r16] = D[ct][rr];
+#endif
       // ---- the rest on the VALU, lanes = basis columns
+#ifdef F1_NO_VALU_STAGE
+      if (false) {
+#else
       if (colj) {
+#endif
 #pragma unroll
         for (int i = 0; i < 3; ++i) Xb[(3 * wave + i) * LDX + j] = cur.v0[i];
         if (do_rhs) {   // b_T through the scalar unit (lgkmcnt)
@@ -474,32 +486,29 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     if (F1_PF == 2) tie_set(s2);
     if (do_rhs) red[wave * 64 + lane] = rhs_part;
    } else {
-    // ---- generic producer (runtime Q, or the groups do not fit in one slice): group table, element record through LDS
+    // ---- generic producer (runtime Q, or the groups do not fit in one slice): group table, the element record goes
+    // through a per-wave LDS record, compiler-managed loads (the slow path: small templates, N > 40, Q > 2).
     const bool do_rhs = a.rhs_red != nullptr && blockIdx.y == 0;
-    // element-block fetch of this wave's element: lane item o = lane + 64 k; (pointer, per-element stride) fixed
+    // element-record fetch of this wave's element: lane item o = lane + 64 k; (pointer, per-element stride) fixed
     const double* fsrc[PRE];
     int fstr[PRE];
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
       const int o = lane + 64 * k;
-      fsrc[k] = a.A_diag + (long)s * t.nT * 36;   // lanes beyond the record re-read its first entry: every prefetch load is
-      fstr[k] = 36;                               // unconditional, so the compiler can count them (s_waitcnt vmcnt(n), see step)
-      if (o < ESTR) {
-        if (o < oP) {
-          const int q = o / 36;
-          fsrc[k] = a.A_diag + ((long)q * S + s) * t.nT * 36 + (o - 36 * q);
-          fstr[k] = 36;
-        } else if (o < oAb) {
-          fsrc[k] = a.P_diag + (long)s * t.nT * 36 + (o - oP);
-          fstr[k] = 36;
-        } else if (o < oC) {
-          const int q = (o - oAb) / 9;
-          fsrc[k] = a.Aab + ((long)q * S + s) * t.nT * 9 + (o - oAb - 9 * q);
-          fstr[k] = 9;
-        } else {
-          fsrc[k] = a.caa + ((long)(o - oC) * S + s) * t.nT;
-          fstr[k] = 1;
-        }
+      fsrc[k] = a.A_diag + (long)s * t.nT * 36;   // lanes beyond the record re-read its first entry
+      fstr[k] = 36;
+      if (o < oP) {
+        const int q = o / 36;
+        fsrc[k] = a.A_diag + ((long)q * S + s) * t.nT * 36 + (o - 36 * q);
+      } else if (o < oAb) {
+        fsrc[k] = a.P_diag + (long)s * t.nT * 36 + (o - oP);
+      } else if (o < oC) {
+        const int q = (o - oAb) / 9;
+        fsrc[k] = a.Aab + ((long)q * S + s) * t.nT * 9 + (o - oAb - 9 * q);
+        fstr[k] = 9;
+      } else if (o < ESTR) {
+        fsrc[k] = a.caa + ((long)(o - oC) * S + s) * t.nT;
+        fstr[k] = 1;
       }
     }
     double* Ee = Eb + wave * 256;
@@ -507,180 +516,42 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     const double* Rs = a.Rself + (long)s * t.nrt * QN;
     const int j = lane;
     const bool colj = j < N;
-    const int jc = colj ? j : N - 1;   // lanes beyond the basis width load (and never use) the last column: no exec masking
-    // QP > 0 (chosen by the launcher only when all groups fit in one slice): canonical group order
-    // [SYS q][ENERGY][MASS][AA q<=q'][AB q q'] with compile-time Q -> straight-line staging, asm-managed prefetch
-    constexpr bool straight = QP > 0;
-    constexpr int PREU = straight ? (45 * QP + 36 + QP * QP + 63) / 64 : PRE;   // prefetch registers that hold record items
-    constexpr int NLOADS = PREU + 12 + 3 * QP;                                  // loads per prefetch set (straight path)
-    static_assert(QP <= 2, "k_f1: the asm-managed prefetch is written out for Q <= 2");
-    double pre[PRE], vb[4][3], rv[3][QR], nvb[4][3], nrv[3][QR];
-    auto ld = [&](const double* p) { return straight ? gload_f64(p) : *p; };
-    auto fetch = [&](int T, double (&pr)[PRE]) {
+    const int jc = colj ? j : N - 1;
+    double pre[PRE], npre[PRE], vb[4][3], nvb[4][3];
+    auto fetch = [&](int T, double (&pr)[PRE], double (&vbx)[4][3]) {
 #pragma unroll
-      for (int k = 0; k < PREU; ++k) pr[k] = ld(fsrc[k] + (long)T * fstr[k]);
-    };
-    // completes one prefetch set: everything older than the NLOADS loads issued since is done
-    auto wait_set = [&](double (&pr)[PRE], double (&vbx)[4][3], double (&rvx)[3][QR]) {
-      if constexpr (QP == 2) {
-        asm volatile("s_waitcnt vmcnt(%21)"
-                     : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(vbx[0][0]), "+v"(vbx[0][1]), "+v"(vbx[0][2]), "+v"(vbx[1][0]),
-                       "+v"(vbx[1][1]), "+v"(vbx[1][2]), "+v"(vbx[2][0]), "+v"(vbx[2][1]), "+v"(vbx[2][2]), "+v"(vbx[3][0]),
-                       "+v"(vbx[3][1]), "+v"(vbx[3][2]), "+v"(rvx[0][0]), "+v"(rvx[0][1]), "+v"(rvx[1][0]), "+v"(rvx[1][1]),
-                       "+v"(rvx[2][0]), "+v"(rvx[2][1])
-                     : "n"(NLOADS));
-      } else if constexpr (QP == 1) {
-        asm volatile("s_waitcnt vmcnt(%17)"
-                     : "+v"(pr[0]), "+v"(pr[1]), "+v"(vbx[0][0]), "+v"(vbx[0][1]), "+v"(vbx[0][2]), "+v"(vbx[1][0]), "+v"(vbx[1][1]),
-                       "+v"(vbx[1][2]), "+v"(vbx[2][0]), "+v"(vbx[2][1]), "+v"(vbx[2][2]), "+v"(vbx[3][0]), "+v"(vbx[3][1]),
-                       "+v"(vbx[3][2]), "+v"(rvx[0][0]), "+v"(rvx[1][0]), "+v"(rvx[2][0])
-                     : "n"(NLOADS));
-      }
-    };
-    // Template adjacency of the (wave-uniform) element through the scalar cache.  A face without an in-subdomain
-    // neighbour has an all-zero block in A_diag / P_diag (its coupling lives in A_cpl), so its rows may be any finite
-    // values: the element's own rows are loaded instead, which keeps the twelve row loads branch-free.
-    const cint_p nbc = (cint_p)t.nb_elem;
-    const cint_p rtc = (cint_p)t.elem_rt;
-    auto load_rows = [&](int T, double (&vbx)[4][3], double (&rvx)[3][QR]) {
-      int nbT[3], rtT[3];
+      for (int k = 0; k < PRE; ++k) pr[k] = fsrc[k][(long)T * fstr[k]];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) vbx[0][i] = Vs[(long)(3 * T + i) * N + jc];
 #pragma unroll
       for (int f = 0; f < 3; ++f) {
-        const int nb = nbc[T * 3 + f];
-        nbT[f] = nb >= 0 ? nb : T;
-        rtT[f] = rtc[T * 3 + f];
-      }
+        const int nb = nbl[T * 3 + f];
+        const int e = nb >= 0 ? nb : T;            // no in-subdomain neighbour: the block is zero, any finite rows do
 #pragma unroll
-      for (int i = 0; i < 3; ++i) vbx[0][i] = ld(Vs + (long)(3 * T + i) * N + jc);
-#pragma unroll
-      for (int f = 0; f < 3; ++f)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) vbx[1 + f][i] = ld(Vs + (long)(3 * nbT[f] + i) * N + jc);
-      if (QP > 0) {   // QP > 0: Q == QP, the flux rows are always fetched (used by the G_AB groups)
-#pragma unroll
-        for (int f = 0; f < 3; ++f)
-#pragma unroll
-          for (int q2 = 0; q2 < QR; ++q2) rvx[f][q2] = ld(Rs + (long)rtT[f] * QN + q2 * N + jc);
+        for (int i = 0; i < 3; ++i) vbx[1 + f][i] = Vs[(long)(3 * e + i) * N + jc];
       }
     };
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) vb[bb][i] = nvb[bb][i] = 0.0;
-#pragma unroll
-    for (int f = 0; f < 3; ++f)
-#pragma unroll
-      for (int q2 = 0; q2 < QR; ++q2) rv[f][q2] = nrv[f][q2] = 0.0;
-    double npre[PRE];
-    fetch(wave, pre);
-    load_rows(wave, vb, rv);
+    fetch(wave, pre, vb);
     double rhs_part = 0.0;
-    // one pipeline step over (current, next) register sets; the sets alternate (loop unrolled by two, no copies)
-    auto step = [&](int c, double (&pre)[PRE], double (&vb)[4][3], double (&rv)[3][QR],
-                    double (&npre)[PRE], double (&nvb)[4][3], double (&nrv)[3][QR]) {
+    auto step = [&](int c, const double (&pre)[PRE], const double (&vb)[4][3], double (&npre)[PRE], double (&nvb)[4][3]) {
       const int T = c * EC + wave;                 // wave-uniform element
       double* Xb = &Xs[c & 1][0];
       double* Yb = &Ys[c & 1][0];
-      if constexpr (!straight) {
 #pragma unroll
-        for (int k = 0; k < PRE; ++k)              // this wave's element blocks -> its private LDS record
-          if (lane + 64 * k < ESTR) Ee[lane + 64 * k] = pre[k];
-      }
-      {
-        // Next chunk's loads, in flight during this staging AND the barrier.  They are issued UNCONDITIONALLY (last
-        // chunk: the current element again; idle lanes: clamped addresses): s_waitcnt vmcnt is an in-order counter,
-        // and with any branch around a load the compiler can no longer tell how many younger loads may be pending
-        // when the staging below needs the current rows -- it then emits vmcnt(0), which also waits for the loads
-        // just issued, i.e. exposes one full memory latency per chunk (this cost 170 us of 670 at config 3).
-        const int Tn = c + 1 < nchunks ? T + EC : T;
-        fetch(Tn, npre);
-        load_rows(Tn, nvb, nrv);
-        if constexpr (straight) wait_set(pre, vb, rv);   // current set complete; the NLOADS loads above stay in flight
-      }
+      for (int k = 0; k < PRE; ++k)                // this wave's element record -> its private LDS copy
+        if (lane + 64 * k < ESTR) Ee[lane + 64 * k] = pre[k];
+      fetch(c + 1 < nchunks ? T + EC : T, npre, nvb);
       if (colj) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) Xb[(3 * wave + i) * LDX + j] = vb[0][i];
-        if (do_rhs) {   // b_T through the scalar unit (lgkmcnt): a vector load here would force a vmcnt(0) on the prefetch
-          const cdbl_p be = (cdbl_p)(a.b + (long)s * t.n + 3 * T);
+        if (do_rhs) {
+          const double* be = a.b + (long)s * t.n + 3 * T;
           rhs_part += be[0] * vb[0][0] + be[1] * vb[0][1] + be[2] * vb[0][2];
         }
         double kv[3];
         const double* K = Kl + T * 9;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-          kv[i] = __builtin_fma(K[i * 3 + 2], vb[0][2], __builtin_fma(K[i * 3 + 1], vb[0][1], K[i * 3] * vb[0][0]));
-        if constexpr (straight) {
-          // ---- straight-line staging: no group-table reads or branches.  The element's record sits lane-distributed
-          // in the prefetch registers (item o in lane o & 63 of pre[o >> 6], loaded one chunk ahead); every entry is
-          // broadcast with v_readlane into an SGPR pair and used as the scalar operand of v_fma_f64.  Measured
-          // alternatives for this broadcast (k_f1 at config 3): LDS round trip 683 us (64 lanes x 16 B of LDS return
-          // bandwidth per broadcast ds_read_b128: the LDS pipe saturates), v_readlane 647 us, s_load from the
-          // constant address space 738 us (F1_SCALAR_LOADS=1: zero VALU cost, but ~5 dependent scalar-cache-miss
-          // round trips per element that nothing hides: VALU and f64-MFMA issue serialise per SIMD on this chip,
-          // so a stalled producer is not overlapped by its SIMD's consumer).
-          // F1_BLK(off): entry `off` of the element record [A_q blocks | P block | A_ab^q blocks | c^{qq'}], wave-uniform
-#if F1_SCALAR_LOADS
-          asm volatile("" ::"v"(pre[0]), "v"(pre[1]), "v"(pre[2]), "v"(pre[3]));   // keep the L2 warm-up loads
-          const long eT = (long)s * t.nT + T;
-          const long qstr = (long)S * t.nT;
-#define F1_BLK(off)                                                                                                  \
-  ((off) < 36 * QP ? ((cdbl_p)a.A_diag)[(((off) / 36) * qstr + eT) * 36 + (off) % 36]                                 \
-   : (off) < 36 * QP + 36 ? ((cdbl_p)a.P_diag)[eT * 36 + (off) - 36 * QP]                                             \
-   : (off) < 36 * QP + 36 + 9 * QP ? ((cdbl_p)a.Aab)[((((off) - 36 * QP - 36) / 9) * qstr + eT) * 9 + ((off) - 36 * QP - 36) % 9] \
-                                   : ((cdbl_p)a.caa)[((off) - 36 * QP - 36 - 9 * QP) * qstr + eT])
-#else
-#define F1_BLK(off) bcast_d(pre[(off) >> 6], (off) & 63)
-#endif
-          int g = 0;
-          auto put = [&](const double (&y)[3]) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) Yb[(3 * wave + i) * LDY + g * N + j] = y[i];
-            ++g;
-          };
-          auto apply = [&](int base) {
-            double y[3] = {0, 0, 0};
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-              for (int i = 0; i < 3; ++i) {
-                y[i] = __builtin_fma(F1_BLK(base + bb * 9 + i * 3), vb[bb][0], y[i]);
-                y[i] = __builtin_fma(F1_BLK(base + bb * 9 + i * 3 + 1), vb[bb][1], y[i]);
-                y[i] = __builtin_fma(F1_BLK(base + bb * 9 + i * 3 + 2), vb[bb][2], y[i]);
-              }
-            put(y);
-          };
-#pragma unroll
-          for (int q = 0; q < QP; ++q) apply(36 * q);
-          apply(36 * QP);
-          {
-            const double m = ((cdbl_p)t.area)[T] * (1.0 / 12.0), sum = vb[0][0] + vb[0][1] + vb[0][2];
-            const double y[3] = {m * (sum + vb[0][0]), m * (sum + vb[0][1]), m * (sum + vb[0][2])};
-            put(y);
-          }
-#pragma unroll
-          for (int q = 0; q < QP; ++q)
-#pragma unroll
-            for (int q2 = q; q2 < QP; ++q2) {
-              const double cc = F1_BLK(36 * QP + 36 + 9 * QP + q * QP + q2);
-              const double y[3] = {cc * kv[0], cc * kv[1], cc * kv[2]};
-              put(y);
-            }
-#pragma unroll
-          for (int q = 0; q < QP; ++q) {
-            double A[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) A[i] = F1_BLK(36 * QP + 36 + 9 * q + i);
-#pragma unroll
-            for (int q2 = 0; q2 < QP; ++q2) {
-              double y[3];
-#pragma unroll
-              for (int i = 0; i < 3; ++i)
-                y[i] = __builtin_fma(A[i * 3 + 2], rv[2][q2], __builtin_fma(A[i * 3 + 1], rv[1][q2], A[i * 3] * rv[0][q2]));
-              put(y);
-            }
-          }
-#undef F1_BLK
-        } else
+        for (int i = 0; i < 3; ++i) kv[i] = K[i * 3] * vb[0][0] + K[i * 3 + 1] * vb[0][1] + K[i * 3 + 2] * vb[0][2];
         for (int g = 0; g < ng; ++g) {
           const int kind = uniform(grp[g].kind), q = uniform(grp[g].q), q2 = uniform(grp[g].q2);
           double y[3] = {0, 0, 0};
@@ -702,18 +573,8 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
           } else {  // G_AB: A_ab^q restricted to the self part of the flux image
             const double* A = Ee + oAb + 9 * q;
             double r3[3];
-            if (QP > 0) {
 #pragma unroll
-              for (int f = 0; f < 3; ++f) {
-                r3[f] = rv[f][0];
-#pragma unroll
-                for (int qq = 1; qq < QR; ++qq)
-                  if (q2 == qq) r3[f] = rv[f][qq];
-              }
-            } else {
-#pragma unroll
-              for (int f = 0; f < 3; ++f) r3[f] = Rs[(long)rtl[T * 3 + f] * QN + q2 * N + j];
-            }
+            for (int f = 0; f < 3; ++f) r3[f] = Rs[(long)rtl[T * 3 + f] * QN + q2 * N + j];
 #pragma unroll
             for (int i = 0; i < 3; ++i) y[i] = A[i * 3] * r3[0] + A[i * 3 + 1] * r3[1] + A[i * 3 + 2] * r3[2];
           }
@@ -721,14 +582,13 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
           for (int i = 0; i < 3; ++i) Yb[(3 * wave + i) * LDY + g * N + j] = y[i];
         }
       }
-      lds_barrier();                               // barrier c: buffer c & 1 is complete (global loads stay in flight)
+      lds_barrier();                               // barrier c: buffer c & 1 is complete
     };
     for (int c = 0; c < nchunks; c += 2) {         // nT is a multiple of 8, so nchunks is even
-      step(c, pre, vb, rv, npre, nvb, nrv);
-      step(c + 1, npre, nvb, nrv, pre, vb, rv);
+      step(c, pre, vb, npre, nvb);
+      step(c + 1, npre, nvb, pre, vb);
     }
     lds_barrier();                                 // final barrier (matches the consumers' count)
-    if constexpr (straight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (unused) prefetch set
     if (do_rhs) red[wave * 64 + lane] = rhs_part;
    }
   } else {
@@ -1535,7 +1395,6 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // ---- thin parts
   {
     const int ntx = (N + 15) / 16;
-    const int kp = (3 * t.ntouch + 3) & ~3;
     const size_t lds = thin_nc_lds_bytes(t, ntx);
     switch (ntx) {
       case 1: hipLaunchKernelGGL(k_thin_nc<1>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
