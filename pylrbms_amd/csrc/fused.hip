@@ -24,7 +24,7 @@
 //   k_f3<NTX>        X = W_self: G_nc[self,self]                                        (MFMA)
 //   k_thin_nc        grid (4 sides, S): block-row `a` and block [self,a] of G_nc        (VALU, write-bound)
 //   k_thin_rt        grid (4 sides, S): block-rows (a,q) / blocks [self,(a,q)] of G_bb, G_rdd, G_ab[:, a], r_fd[a]
-//   k_project_coupling (apply.hip): off-diagonal blocks of B_sys
+//   k_coupling       grid (4 sides, S): off-diagonal blocks of B_sys                    (MFMA, small)
 // Every output element is written exactly once (zeros included); all reductions have a fixed order.
 #include <cstdlib>
 
@@ -1222,6 +1222,67 @@ __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Off-diagonal blocks of the projected system: B_q[s][slot a] = V_s|side^T (C_q V_nbr|side), K = 3 * (faces on the
+// side).  One workgroup per (side, subdomain) handles every q: the rows of V_s at the side are staged once, C_q V_nbr per
+// q, and the N x N product is a handful of MFMAs (the VALU version re-read two LDS operands per multiply-add and was
+// bound by the LDS pipe: 76 us at config 3 for 105 MB of output).
+template <int NTX>
+__global__ __launch_bounds__(256) void k_coupling(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
+                                                  const double* __restrict__ V, const double* __restrict__ A_cpl,
+                                                  double* __restrict__ B_sys) {
+  constexpr int LD = padded_ld(NTX);
+  constexpr int NT = (NTX * NTX + 3) / 4;
+  extern __shared__ double lds[];
+  const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
+  const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = uniform(tid >> 6);
+  const int s2 = nbr[s * 5 + slot];
+  const int cnt = t.side_count[side];
+  if (s2 < 0 || cnt == 0) {
+    for (int q = 0; q < Q; ++q) {
+      double* out = B_sys + ((((long)q * S + s) * 5 + slot) * N) * N;
+      for (int i = tid; i < N * N; i += 256) out[i] = 0.0;
+    }
+    return;
+  }
+  const int K = 3 * cnt, KP = (K + 3) & ~3;
+  double* Xin = lds;             // [KP][LD]  rows of V_s at the side
+  double* Tm = lds + KP * LD;    // [KP][LD]  C_q * rows of V_nbr
+  for (int i = tid; i < 2 * KP * LD; i += 256) lds[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < K * N; i += 256) {
+    const int row = i / N, col = i - row * N, pos = row / 3, ii = row - 3 * pos;
+    Xin[row * LD + col] = V[((long)s * t.n + 3 * t.side_elem[side * t.ncf + pos] + ii) * N + col];
+  }
+  for (int q = 0; q < Q; ++q) {
+    for (int i = tid; i < K * N; i += 256) {
+      const int row = i / N, col = i - row * N, pos = row / 3, ii = row - 3 * pos;
+      const double* C = A_cpl + ((((long)q * S + s) * 4 + side) * t.ncf + pos) * 9 + ii * 3;
+      const double* v2 = V + ((long)s2 * t.n + 3 * t.side_elem_out[side * t.ncf + pos]) * N + col;
+      Tm[row * LD + col] = C[0] * v2[0] + C[1] * v2[N] + C[2] * v2[2 * N];
+    }
+    __syncthreads();
+    double* out = B_sys + ((((long)q * S + s) * 5 + slot) * N) * N;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const int tile = wave + 4 * k;
+      if (tile >= NTX * NTX) continue;           // wave-uniform
+      const int ti = tile / NTX, tj = tile - ti * NTX;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int kk = 0; kk < KP; kk += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xin[(kk + lk) * LD + ti * 16 + li], Tm[(kk + lk) * LD + tj * 16 + li], acc, 0, 0, 0);
+      const int col = tj * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + lk + 4 * r;
+        if (row < N && col < N) out[(long)row * N + col] = acc[r];
+      }
+    }
+    __syncthreads();                             // Tm is restaged for the next q
+  }
+}
+
 inline unsigned grid_for(long total) {
   long g = (total + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -1229,8 +1290,6 @@ inline unsigned grid_for(long total) {
 
 }  // namespace
 
-// defined in apply.hip
-int launch_project_coupling(lrbms_ctx* ctx, int Q, int N, const double* V, const double* A_cpl, double* B_sys, hipStream_t st);
 
 int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N) {
   const Tmpl& t = ctx->t;
@@ -1437,9 +1496,16 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
-  {
-    const int rc = launch_project_coupling(ctx, Q, N, V, A_cpl, B_sys, s_nc);
-    if (rc) return rc;
+  {   // off-diagonal blocks of B_sys
+    const int ntx = (N + 15) / 16;
+    const size_t ldsc = sizeof(double) * 2 * (size_t)((3 * t.ncf + 3) & ~3) * padded_ld(ntx);
+    switch (ntx) {
+      case 1: hipLaunchKernelGGL(k_coupling<1>, dim3(4, S), dim3(256), ldsc, s_nc, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
+      case 2: hipLaunchKernelGGL(k_coupling<2>, dim3(4, S), dim3(256), ldsc, s_nc, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
+      case 3: hipLaunchKernelGGL(k_coupling<3>, dim3(4, S), dim3(256), ldsc, s_nc, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
+      default: hipLaunchKernelGGL(k_coupling<4>, dim3(4, S), dim3(256), ldsc, s_nc, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
+    }
+    LRBMS_LAUNCH_CHECK(ctx);
   }
   if (multi) {
     for (int i = 0; i < 3; ++i) {
