@@ -182,9 +182,8 @@ def main():
     buf = eng.alloc_reduce_buffers(N)
 
     def step():
-        if halo is not None:
-            halo(V)
-        eng.project_and_estimate(V, buf)
+        # sharded: the halo exchange runs on the communication stream under the halo-independent half of the pass
+        eng.project_and_estimate(V, buf, halo=halo)
 
     def fence():
         if world > 1:

@@ -164,6 +164,18 @@ int lrbms_project_estimate_fused(lrbms_ctx* ctx, int32_t Q, int32_t N, const dou
                                  double* G_nc, double* r_fd, double* G_rdd, double* G_bb, double* G_ab, double* G_aa,
                                  void* stream);
 
+/* The same pass in two halves for a sharded run that overlaps its halo exchange with compute (one exchange step per
+ * pass): phase 1 reads only the first S (rank-local) slabs of V -- compact flux image and vertex
+ * averages of the own basis, the dense self blocks: B_sys diagonal, E_red, M_red, G_aa, G_ab[:, self], rhs_red,
+ * G_bb / G_rdd [self, self], r_fd[self], G_nc[self, self]; phase 2 needs the halo slabs and writes every block that
+ * involves a neighbour.  phase 0 == lrbms_project_estimate_fused; 1 followed by 2 is bit-identical to 0.  Same
+ * buffers (including `work`) must be passed to both halves. */
+int lrbms_project_estimate_fused_phase(lrbms_ctx* ctx, int32_t phase, int32_t Q, int32_t N, const double* V, const double* F,
+                                       const double* A_diag, const double* A_cpl, const double* P_diag, const double* b,
+                                       const double* ebar, const double* caa, const double* Aab, const double* Bbb, double* work,
+                                       double* B_sys, double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd,
+                                       double* G_rdd, double* G_bb, double* G_ab, double* G_aa, void* stream);
+
 /* -- online --------------------------------------------------------------------------------------------- */
 /* E1: EstimatorBase._estimate_elliptic on reduced coefficients (estimators.py:45-112), per-subdomain part.
  *   theta [Q] host; u [S_ext][N]; f2, ceps [S]; hdiam scalar

@@ -45,6 +45,7 @@ SIGNATURES = {
     'lrbms_fused_supported': (ctypes.c_int, [c_vp, c_i32, c_i32]),
     'lrbms_fused_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_project_estimate_fused': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 22),
+    'lrbms_project_estimate_fused_phase': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32] + [c_vp] * 22),
     'lrbms_reduced_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 9 + [c_dbl, c_vp, c_vp]),
     'lrbms_reduced_estimate_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL] + [c_vp] * 9 + [c_dbl, c_vp, c_vp]),
     'lrbms_reduced_solve_work_size': (c_i64, [c_vp, c_i32]),
@@ -299,15 +300,16 @@ class NativeContext:
             raise NativeError('lrbms_fused_work_size failed')
         return int(sz)
 
-    def project_estimate_fused(self, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, sys_out, gram_out):
+    def project_estimate_fused(self, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, sys_out, gram_out, phase=0):
+        """phase 0: the whole pass; 1 / 2: its halo-independent / halo-dependent halves (lrbms_project_estimate_fused_phase)."""
         Q, N, S = A_diag.shape[0], V.shape[2], self.S
         W, C = 5 * N, 5 * Q * N
         if work.numel() < self.fused_work_size(Q, N):
             raise NativeError('project_estimate_fused: work too small')
         B_sys, rhs_red, E_red, M_red = sys_out
         G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = gram_out
-        rc = self.lib.lrbms_project_estimate_fused(
-            self.handle, Q, N, self._ptr(V, (self.S_ext, self.n, N), 'V'), self._ptr(F, (Q, S, self.n_rt, 6), 'F'),
+        rc = self.lib.lrbms_project_estimate_fused_phase(
+            self.handle, int(phase), Q, N, self._ptr(V, (self.S_ext, self.n, N), 'V'), self._ptr(F, (Q, S, self.n_rt, 6), 'F'),
             self._ptr(A_diag, (Q, S, self.n_T, 4, 9), 'A_diag'), self._ptr(A_cpl, (Q, S, 4, self.ncf, 9), 'A_cpl'),
             self._ptr(P_diag, (S, self.n_T, 4, 9), 'P_diag'), self._ptr(b, (S, self.n), 'b'),
             self._ptr(ebar, (S, self.n_T), 'ebar'), self._ptr(caa, (Q, Q, S, self.n_T), 'caa'),
@@ -317,7 +319,7 @@ class NativeContext:
             self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, Q * N, Q * N), 'G_rdd'),
             self._ptr(G_bb, (S, 9, Q * N, Q * N), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
             self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._stream())
-        self._check(rc, 'lrbms_project_estimate_fused')
+        self._check(rc, 'lrbms_project_estimate_fused_phase')
 
     # ------------------------------------------------------------------ online
     def reduced_estimate(self, theta, u, grams, f2, ceps, hdiam):

@@ -25,7 +25,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
                                   const double* A_cpl, const double* P_diag, const double* b, const double* ebar,
                                   const double* caa, const double* Aab, const double* Bbb, double* work, double* B_sys,
                                   double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd, double* G_rdd,
-                                  double* G_bb, double* G_ab, double* G_aa, hipStream_t st);
+                                  double* G_bb, double* G_ab, double* G_aa, int phase, hipStream_t st);
 
 namespace {
 
@@ -257,7 +257,20 @@ int lrbms_project_estimate_fused(lrbms_ctx* ctx, int32_t Q, int32_t N, const dou
   CHECK_PTR(ctx, work); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red); CHECK_PTR(ctx, E_red); CHECK_PTR(ctx, M_red);
   CHECK_PTR(ctx, G_nc); CHECK_PTR(ctx, r_fd); CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa);
   return launch_project_estimate_fused(ctx, Q, N, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, B_sys, rhs_red, E_red,
-                                       M_red, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, (hipStream_t)stream);
+                                       M_red, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, 0, (hipStream_t)stream);
+}
+
+int lrbms_project_estimate_fused_phase(lrbms_ctx* ctx, int32_t phase, int32_t Q, int32_t N, const double* V, const double* F,
+                                       const double* A_diag, const double* A_cpl, const double* P_diag, const double* b,
+                                       const double* ebar, const double* caa, const double* Aab, const double* Bbb, double* work,
+                                       double* B_sys, double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd,
+                                       double* G_rdd, double* G_bb, double* G_ab, double* G_aa, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, V); CHECK_PTR(ctx, F); CHECK_PTR(ctx, A_diag); CHECK_PTR(ctx, A_cpl);
+  CHECK_PTR(ctx, P_diag); CHECK_PTR(ctx, b); CHECK_PTR(ctx, ebar); CHECK_PTR(ctx, caa); CHECK_PTR(ctx, Aab); CHECK_PTR(ctx, Bbb);
+  CHECK_PTR(ctx, work); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red); CHECK_PTR(ctx, E_red); CHECK_PTR(ctx, M_red);
+  CHECK_PTR(ctx, G_nc); CHECK_PTR(ctx, r_fd); CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa);
+  return launch_project_estimate_fused(ctx, Q, N, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, B_sys, rhs_red, E_red,
+                                       M_red, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, phase, (hipStream_t)stream);
 }
 
 int lrbms_reduced_estimate(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u, const double* G_nc,

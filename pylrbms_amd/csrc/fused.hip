@@ -126,10 +126,11 @@ __device__ inline int face_sign_at(const Tmpl& t, const int* nbr_s, int e, int f
 __device__ inline int nvs_of(const Tmpl& t) { return t.nvx > t.nvy ? t.nvx : t.nvy; }
 
 // ---------------------------------------------------------------------------------------------------------
-// compact flux reconstruction
+// compact flux reconstruction.  write_side = 0: only R_self (needs no neighbour data: the halo-independent phase of a
+// sharded pass); write_side = 1: R_self and R_side in one sweep.
 __global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
                                                       const double* __restrict__ F, const double* __restrict__ V,
-                                                      double* __restrict__ Rself, double* __restrict__ Rside) {
+                                                      double* __restrict__ Rself, double* __restrict__ Rside, int write_side) {
   const long total = (long)S * t.nrt * N;
   const int QN = Q * N;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* 
     const long sr = idx / N;
     const int r = (int)(sr % t.nrt), s = (int)(sr / t.nrt);
     const int e0 = t.rt_e0[r], e1 = t.rt_e1[r], side = t.rt_side[r];
-    const int s2 = side >= 0 ? nbr[s * 5 + side_to_slot(side)] : -1;
+    const int s2 = (side >= 0 && write_side) ? nbr[s * 5 + side_to_slot(side)] : -1;
     double v0[3], v1[3] = {0, 0, 0};
     for (int i = 0; i < 3; ++i) v0[i] = V[((long)s * t.n + 3 * e0 + i) * N + j];
     if (side < 0)
@@ -149,8 +150,38 @@ __global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* 
       const double self = f[0] * v0[0] + f[1] * v0[1] + f[2] * v0[2];
       const double other = f[3] * v1[0] + f[4] * v1[1] + f[5] * v1[2];
       Rself[((long)s * t.nrt + r) * QN + q * N + j] = side < 0 ? self + other : self;
-      if (side >= 0)
+      if (side >= 0 && write_side)
         Rside[(((long)s * 4 + side) * t.ncf + t.elem_side_pos[e0 * 3 + t.rt_f0[r]]) * QN + q * N + j] = s2 >= 0 ? other : 0.0;
+    }
+  }
+}
+
+// R_side alone (the halo-dependent phase of a sharded pass): one item per (subdomain, side, side face, column).
+__global__ __launch_bounds__(256) void k_flux_side(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
+                                                   const double* __restrict__ F, const double* __restrict__ V,
+                                                   double* __restrict__ Rside) {
+  const long total = (long)S * 4 * t.ncf * N;
+  const int QN = Q * N;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % N);
+    long rem = idx / N;
+    const int pos = (int)(rem % t.ncf);
+    rem /= t.ncf;
+    const int side = (int)(rem % 4), s = (int)(rem / 4);
+    if (pos >= t.side_count[side]) continue;
+    const int e0 = t.side_elem[side * t.ncf + pos], e1 = t.side_elem_out[side * t.ncf + pos];
+    int f0 = 0;
+    for (int f = 0; f < 3; ++f)
+      if (t.nb_elem[e0 * 3 + f] == -(1 + side)) f0 = f;
+    const int r = t.elem_rt[e0 * 3 + f0];
+    const int s2 = nbr[s * 5 + side_to_slot(side)];
+    double v1[3] = {0, 0, 0};
+    if (s2 >= 0)
+      for (int i = 0; i < 3; ++i) v1[i] = V[((long)s2 * t.n + 3 * e1 + i) * N + j];
+    for (int q = 0; q < Q; ++q) {
+      const double* f = F + (((long)q * S + s) * t.nrt + r) * 6;
+      const double other = f[3] * v1[0] + f[4] * v1[1] + f[5] * v1[2];
+      Rside[(((long)s * 4 + side) * t.ncf + pos) * QN + q * N + j] = s2 >= 0 ? other : 0.0;
     }
   }
 }
@@ -159,7 +190,7 @@ __global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* 
 // the star of the matching vertex in the neighbour across side sd (0 if there is none).
 __global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __restrict__ nbr, int N,
                                                     const double* __restrict__ V, double* __restrict__ AvgSelf,
-                                                    double* __restrict__ AvgSide) {
+                                                    double* __restrict__ AvgSide, int write_side) {
   const long total = (long)S * t.nv * N;
   const int nvs = nvs_of(t);
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -170,6 +201,7 @@ __global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __
     double acc = 0.0;
     for (int p = t.vdof_ptr[v]; p < t.vdof_ptr[v + 1]; ++p) acc += V[((long)s * t.n + t.vdof_idx[p]) * N + j];
     AvgSelf[idx] = o.inv * acc;
+    if (!write_side) continue;                     // Avg_self needs no neighbour data (only the patch sizes)
     for (int sd = 0; sd < 4; ++sd) {
       if (o.vside[sd] < 0) continue;
       const int s2 = nbr[s * 5 + side_to_slot(sd)];
@@ -181,6 +213,31 @@ __global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __
       }
       AvgSide[(((long)s * 4 + sd) * nvs + o.pos[sd]) * N + j] = a2;
     }
+  }
+}
+
+// Avg_side alone (the halo-dependent phase of a sharded pass): one item per (subdomain, side, side vertex, column).
+__global__ __launch_bounds__(256) void k_vertex_side(Tmpl t, int S, const int* __restrict__ nbr, int N,
+                                                     const double* __restrict__ V, double* __restrict__ AvgSide) {
+  const int nvs = nvs_of(t);
+  const long total = (long)S * 4 * nvs * N;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % N);
+    long rem = idx / N;
+    const int pos = (int)(rem % nvs);
+    rem /= nvs;
+    const int sd = (int)(rem % 4), s = (int)(rem / 4);
+    if (pos >= ((sd == 0 || sd == 3) ? t.nvx : t.nvy)) continue;
+    const int v = sd == 0 ? pos : sd == 1 ? pos * t.nvx : sd == 2 ? pos * t.nvx + t.nvx - 1 : (t.nvy - 1) * t.nvx + pos;
+    const OsInfo o = oswald_vertex(t, nbr + s * 5, v);
+    const int s2 = nbr[s * 5 + side_to_slot(sd)];
+    double a2 = 0.0;
+    if (s2 >= 0 && o.inv != 0.0) {
+      const int v2 = o.vside[sd];
+      for (int p = t.vdof_ptr[v2]; p < t.vdof_ptr[v2 + 1]; ++p) a2 += V[((long)s2 * t.n + t.vdof_idx[p]) * N + j];
+      a2 *= o.inv;
+    }
+    AvgSide[idx] = a2;
   }
 }
 
@@ -1375,8 +1432,14 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
                                   const double* A_cpl, const double* P_diag, const double* b, const double* ebar,
                                   const double* caa, const double* Aab, const double* Bbb, double* work, double* B_sys,
                                   double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd, double* G_rdd,
-                                  double* G_bb, double* G_ab, double* G_aa, hipStream_t st) {
+                                  double* G_bb, double* G_ab, double* G_aa, int phase, hipStream_t st) {
+  // phase 0: the whole pass.  phase 1 / 2: its halo-independent / halo-dependent halves, for a sharded run that overlaps
+  // the halo exchange with phase 1 (everything that reads only the rank's own basis slabs: R_self, Avg_self, k_f1,
+  // k_f2, k_f3 -- more than half of the pass); phase 2 then needs the halo slabs of V (R_side, Avg_side, the thin
+  // kernels, the coupling blocks).  1 followed by 2 gives bit-identical results to 0.
   if (!fused_supported(ctx, Q, N)) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: unsupported N / Q / template size");
+  if (phase < 0 || phase > 2) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: phase must be 0, 1 or 2");
+  const bool do_a = phase != 2, do_b = phase != 1;
   const Tmpl& t = ctx->t;
   const int S = ctx->S, QN = Q * N, C = 5 * QN;
   const long nvs = t.nvx > t.nvy ? t.nvx : t.nvy;
@@ -1384,11 +1447,16 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   double* Rside = Rself + (long)S * t.nrt * QN;
   double* AvgSelf = Rside + (long)S * 4 * t.ncf * QN;
   double* AvgSide = AvgSelf + (long)S * t.nv * N;
-  hipLaunchKernelGGL(k_flux_compact, dim3(grid_for((long)S * t.nrt * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside);
+  if (do_a) {
+    hipLaunchKernelGGL(k_flux_compact, dim3(grid_for((long)S * t.nrt * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
+                       phase == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_vertex_avg, dim3(grid_for((long)S * t.nv * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
+                       phase == 0 ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)S * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
+    hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)S * 4 * nvs * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSide);
+  }
   LRBMS_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(k_vertex_avg, dim3(grid_for((long)S * t.nv * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide);
-  LRBMS_LAUNCH_CHECK(ctx);
-  (void)nvs;
   // fork: F2 / F3, the thin kernels and the coupling projection are independent of each other and of F1 (they all read
   // only V and the two prepare kernels' outputs); on separate streams their workgroups interleave on the CUs, which
   // hides the latencies each of them exposes when it runs alone (they are latency-, not throughput-bound)
@@ -1406,6 +1474,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
 
   // ---- F1: build the column-group list and launch in slices of at most F1_YW / N groups
   std::vector<Grp> groups;
+  if (do_a) {
   for (int q = 0; q < Q; ++q) groups.push_back({G_SYS, q, 0, N, B_sys + ((long)q * S * 5 + 2) * N * N, nullptr, (long)5 * N * N});
   groups.push_back({G_ENERGY, 0, 0, N, E_red, nullptr, (long)N * N});
   groups.push_back({G_MASS, 0, 0, N, M_red, nullptr, (long)N * N});
@@ -1451,8 +1520,9 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       LRBMS_LAUNCH_CHECK(ctx);
     }
   }
+  }
   // ---- thin parts
-  {
+  if (do_b) {
     const int ntx = (N + 15) / 16;
     const size_t lds = thin_nc_lds_bytes(t, ntx);
     switch (ntx) {
@@ -1468,7 +1538,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     LRBMS_LAUNCH_CHECK(ctx);
   }
   // ---- F2
-  {
+  if (do_a) {
     F2Args a{Rself, Bbb, b, ctx->nbr, G_bb, G_rdd, r_fd, Q, N, S};
     const int nr = (QN + 15) / 16;
     const size_t ldsf2 = sizeof(double) * 4 * t.nT + sizeof(int) * 3 * t.nT;
@@ -1485,7 +1555,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     LRBMS_LAUNCH_CHECK(ctx);
   }
   // ---- F3
-  {
+  if (do_a) {
     F3Args a{V, ebar, AvgSelf, AvgSide, G_nc, N, S};
     const int ntx = (N + 15) / 16;
     switch (ntx) {
@@ -1496,7 +1566,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
-  {   // off-diagonal blocks of B_sys
+  if (do_b) {   // off-diagonal blocks of B_sys
     const int ntx = (N + 15) / 16;
     const size_t ldsc = sizeof(double) * 2 * (size_t)((3 * t.ncf + 3) & ~3) * padded_ld(ntx);
     switch (ntx) {

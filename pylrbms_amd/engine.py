@@ -115,8 +115,11 @@ class Engine:
                       c.empty(Q, Q, S, N, N)),
         }
 
-    def project_and_estimate(self, V, buffers=None, project_system=True, fused=None):
-        """One pass of the hot path over all local subdomains.  ``V`` [S_ext, n, N] must already hold the halo.
+    def project_and_estimate(self, V, buffers=None, project_system=True, fused=None, halo=None):
+        """One pass of the hot path over all local subdomains.  ``V`` [S_ext, n, N] must already hold the halo -- or
+        ``halo`` (a ``pylrbms_amd.parallel.HaloExchange``) is given and fills it: with the fused pass the exchange then
+        runs on the communication stream while the halo-independent half of the pass (more than half of its time) is
+        computed, and only the half that reads neighbour rows waits for it.
         ``fused=None`` picks the fused pass (csrc/fused.hip) whenever the library supports (Q, N) and falls back to the
         unfused HIP kernels otherwise (both are GPU paths; the unfused one also materialises the image bases Wt, Rt)."""
         if not self.assembled:
@@ -129,9 +132,18 @@ class Engine:
         if fused is None:
             fused = c.fused_supported(self.Q, N)
         if fused:
-            c.project_estimate_fused(V, self.F, self.A_diag, self.A_cpl, self.P_diag, self.b, self.ebar, self.caa, self.Aab,
-                                     self.Bbb, buf['work'], buf['sys'], buf['grams'])
+            args = (V, self.F, self.A_diag, self.A_cpl, self.P_diag, self.b, self.ebar, self.caa, self.Aab, self.Bbb,
+                    buf['work'], buf['sys'], buf['grams'])
+            if halo is None:
+                c.project_estimate_fused(*args)
+            else:
+                finish = halo.start(V)                      # pack + asynchronous collective
+                c.project_estimate_fused(*args, phase=1)    # reads local slabs only
+                finish()                                    # current stream waits for the collective, unpack
+                c.project_estimate_fused(*args, phase=2)
             return buf
+        if halo is not None:
+            halo(V)
         c.oswald_apply(V, out=buf['Wt'])
         c.flux_reconstruct(self.F, V, out=buf['Rt'])
         if project_system:

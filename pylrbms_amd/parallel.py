@@ -151,25 +151,36 @@ class HaloExchange:
             self.unpack_dst = torch.from_numpy(plan.a2a_unpack_dst).to(device)
         self.count = len(self.pack_index)
 
-    def __call__(self, V):
-        """V [S_ext, n, N] contiguous; rows of the halo slabs that the kernels read are overwritten in place."""
+    def start(self, V):
+        """Pack and launch the collective asynchronously; returns ``finish()``, which makes the current stream wait for
+        it and unpacks into the halo slabs of V.  Kernels enqueued between the two calls overlap with the exchange and
+        may read the LOCAL slabs of V only (the halo slabs are written by ``finish``)."""
         import torch.distributed as dist
         torch = self.torch
         if self.plan.world_size == 1:
-            return V
+            return lambda: V
         flat = V.view(-1, V.shape[2])
         if self.count:
             torch.index_select(flat, 0, self.pack_index, out=self.send[:self.count])
         if self.mode == 'allgather':
-            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-            if len(self.unpack_src):
-                flat.index_copy_(0, self.unpack_dst, self.recv.index_select(0, self.unpack_src))
+            work = dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=True)
         else:
-            dist.all_to_all_single(self.recv, self.send, output_split_sizes=self.plan.a2a_recv_splits,
-                                   input_split_sizes=self.plan.a2a_send_splits, group=self.group)
-            if len(self.unpack_dst):
+            work = dist.all_to_all_single(self.recv, self.send, output_split_sizes=self.plan.a2a_recv_splits,
+                                          input_split_sizes=self.plan.a2a_send_splits, group=self.group, async_op=True)
+
+        def finish():
+            work.wait()          # device-side wait on the current stream for RCCL; blocking for gloo
+            if self.mode == 'allgather':
+                if len(self.unpack_src):
+                    flat.index_copy_(0, self.unpack_dst, self.recv.index_select(0, self.unpack_src))
+            elif len(self.unpack_dst):
                 flat.index_copy_(0, self.unpack_dst, self.recv)
-        return V
+            return V
+        return finish
+
+    def __call__(self, V):
+        """V [S_ext, n, N] contiguous; rows of the halo slabs that the kernels read are overwritten in place."""
+        return self.start(V)()
 
 
 def global_norms(local_eta_nc, local_eta_r_plus_df, group=None):

@@ -53,8 +53,21 @@ def _worker(rank, world, port, ref_path, results):
         ref = np.load(ref_path)
         ok = True
         worst = 0.0
-        for fused in (False, True):
-            buf = eng.project_and_estimate(V, eng.alloc_reduce_buffers(N), fused=fused)
+        for fused in (False, True, 'phased'):
+            if fused == 'phased':
+                # the overlapped form: phase 1 must not touch the halo slabs (poisoned with NaN while it runs), phase 2
+                # runs after the exchange has filled them
+                buf = eng.alloc_reduce_buffers(N)
+                Vp = V.clone()
+                Vp[eng.S:] = float('nan')
+                args = (Vp, eng.F, eng.A_diag, eng.A_cpl, eng.P_diag, eng.b, eng.ebar, eng.caa, eng.Aab, eng.Bbb, buf['work'],
+                        buf['sys'], buf['grams'])
+                eng.ctx.project_estimate_fused(*args, phase=1)
+                torch.cuda.synchronize()
+                Vp[eng.S:] = V[eng.S:]
+                eng.ctx.project_estimate_fused(*args, phase=2)
+            else:
+                buf = eng.project_and_estimate(V, eng.alloc_reduce_buffers(N), fused=fused)
             names = ('B_sys', 'rhs_red', 'E_red', 'M_red', 'G_nc', 'r_fd', 'G_rdd', 'G_bb', 'G_ab', 'G_aa')
             for name, arr in zip(names, list(buf['sys']) + list(buf['grams'])):
                 a = arr.cpu().numpy()
