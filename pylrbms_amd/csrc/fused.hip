@@ -131,12 +131,10 @@ __device__ inline int nvs_of(const Tmpl& t) { return t.nvx > t.nvy ? t.nvx : t.n
 __global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
                                                       const double* __restrict__ F, const double* __restrict__ V,
                                                       double* __restrict__ Rself, double* __restrict__ Rside, int write_side) {
-  const long total = (long)S * t.nrt * N;
   const int QN = Q * N;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(idx % N);
-    const long sr = idx / N;
-    const int r = (int)(sr % t.nrt), s = (int)(sr / t.nrt);
+  const int s = blockIdx.x;                        // grid (S, chunks of n_rt * N): 32-bit index arithmetic only
+  for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < t.nrt * N; it += gridDim.y * blockDim.x) {
+    const int r = it / N, j = it - r * N;
     const int e0 = t.rt_e0[r], e1 = t.rt_e1[r], side = t.rt_side[r];
     const int s2 = (side >= 0 && write_side) ? nbr[s * 5 + side_to_slot(side)] : -1;
     double v0[3], v1[3] = {0, 0, 0};
@@ -191,16 +189,14 @@ __global__ __launch_bounds__(256) void k_flux_side(Tmpl t, int S, const int* __r
 __global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __restrict__ nbr, int N,
                                                     const double* __restrict__ V, double* __restrict__ AvgSelf,
                                                     double* __restrict__ AvgSide, int write_side) {
-  const long total = (long)S * t.nv * N;
   const int nvs = nvs_of(t);
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(idx % N);
-    const long sv = idx / N;
-    const int v = (int)(sv % t.nv), s = (int)(sv / t.nv);
+  const int s = blockIdx.x;                        // grid (S, chunks of n_v * N)
+  for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < t.nv * N; it += gridDim.y * blockDim.x) {
+    const int v = it / N, j = it - v * N;
     const OsInfo o = oswald_vertex(t, nbr + s * 5, v);
     double acc = 0.0;
     for (int p = t.vdof_ptr[v]; p < t.vdof_ptr[v + 1]; ++p) acc += V[((long)s * t.n + t.vdof_idx[p]) * N + j];
-    AvgSelf[idx] = o.inv * acc;
+    AvgSelf[((long)s * t.nv + v) * N + j] = o.inv * acc;
     if (!write_side) continue;                     // Avg_self needs no neighbour data (only the patch sizes)
     for (int sd = 0; sd < 4; ++sd) {
       if (o.vside[sd] < 0) continue;
@@ -1448,9 +1444,9 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   double* AvgSelf = Rside + (long)S * 4 * t.ncf * QN;
   double* AvgSide = AvgSelf + (long)S * t.nv * N;
   if (do_a) {
-    hipLaunchKernelGGL(k_flux_compact, dim3(grid_for((long)S * t.nrt * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
+    hipLaunchKernelGGL(k_flux_compact, dim3(S, (t.nrt * N + 255) / 256), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
                        phase == 0 ? 1 : 0);
-    hipLaunchKernelGGL(k_vertex_avg, dim3(grid_for((long)S * t.nv * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
+    hipLaunchKernelGGL(k_vertex_avg, dim3(S, (t.nv * N + 255) / 256), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
                        phase == 0 ? 1 : 0);
   } else {
     hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)S * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
