@@ -276,11 +276,11 @@ def main():
         # profiles/r01_final_pmc_traffic.txt), only known for the profiled configuration.
         traffic = None
         if args.config == 'cfg3' and world == 1:
-            traffic = (2 * 745.7 + 1869.2) * 1024 * 1024
+            traffic = (2 * 677.4 + 1869.1) * 1024 * 1024
         roofline = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': ach_gbs / PEAK_HBM_GBS, 'traffic': traffic,
                     'kernel': 'fused project+estimate pass: k_flux_compact, k_vertex_avg, k_f1, k_f2, k_f3, k_thin_nc, '
-                              'k_thin_rt, k_project_coupling (HIP events around the pass on the launch stream)',
+                              'k_thin_rt, k_coupling (HIP events around the pass on the launch stream)',
                     'bytes_per_subdomain': byts, 'flops_per_subdomain': flops,
                     'canonical_mfma_TFLOPs': ach_tflops, 'canonical_mfma_frac_of_fp64_peak': ach_tflops / PEAK_FP64_MFMA_TFLOPS,
                     'device_ms_per_step': 1e3 * dev_s_per_step}
