@@ -1420,7 +1420,7 @@ bool fused_supported(lrbms_ctx* ctx, int Q, int N) {
     if (thin_nc_lds_bytes(t, ntx) > 64 * 1024) return false;
   }
   if ((size_t)(3 * t.ncf * Q * N + Q * t.ncf * N + 3 * t.ncf) * sizeof(double) > 64 * 1024) return false;
-  if ((size_t)2 * 3 * t.ncf * N * sizeof(double) > 64 * 1024) return false;
+  if ((size_t)2 * ((3 * t.ncf + 3) & ~3) * padded_ld((N + 15) / 16) * sizeof(double) > 64 * 1024) return false;   // k_coupling
   return true;
 }
 
