@@ -141,10 +141,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node {} for --gpus {}'.format(args.gpus, args.gpus))
+    # LRBMS_BENCH_BACKEND=gloo LRBMS_BENCH_DEVICE=0: rehearsal of the multi-rank path with all ranks on one GPU (the halo
+    # rows are then staged through host memory); the driver's runs use RCCL, one rank per GPU
+    backend = os.environ.get('LRBMS_BENCH_BACKEND', 'nccl')
+    local_rank = int(os.environ.get('LRBMS_BENCH_DEVICE', local_rank))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from pylrbms_amd import multiscale_problem
     from pylrbms_amd.engine import Engine
@@ -186,6 +193,7 @@ def main():
         eng.project_and_estimate(V, buf, halo=halo)
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -299,7 +307,7 @@ def main():
             out['online'] = online
         if enrichment is not None:
             out['enrichment'] = enrichment
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
             out['cpu_baseline'] = cpu_baseline(N, cfg['coarse_per_subdomain'])
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -162,14 +162,19 @@ class HaloExchange:
         flat = V.view(-1, V.shape[2])
         if self.count:
             torch.index_select(flat, 0, self.pack_index, out=self.send[:self.count])
+        # gloo has no device collectives: stage through host memory (CPU rehearsals of the multi-rank path on one GPU)
+        staged = self.send.is_cuda and dist.get_backend(self.group) == 'gloo'
+        send, recv = (self.send.cpu(), torch.empty_like(self.recv, device='cpu')) if staged else (self.send, self.recv)
         if self.mode == 'allgather':
-            work = dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=True)
+            work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
         else:
-            work = dist.all_to_all_single(self.recv, self.send, output_split_sizes=self.plan.a2a_recv_splits,
+            work = dist.all_to_all_single(recv, send, output_split_sizes=self.plan.a2a_recv_splits,
                                           input_split_sizes=self.plan.a2a_send_splits, group=self.group, async_op=True)
 
         def finish():
             work.wait()          # device-side wait on the current stream for RCCL; blocking for gloo
+            if staged:
+                self.recv.copy_(recv)
             if self.mode == 'allgather':
                 if len(self.unpack_src):
                     flat.index_copy_(0, self.unpack_dst, self.recv.index_select(0, self.unpack_src))

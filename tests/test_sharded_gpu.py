@@ -116,3 +116,23 @@ def test_sharded_projection_matches_single_rank(world, tmp_path):
         ok, worst, S, S_ext = results[r]
         assert ok, (r, worst)
         assert S_ext > S
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's N > 1 code path (sharded engine, asynchronous halo exchange under phase 1, max-over-ranks timing) with
+    two ranks sharing cuda:0 over gloo (halo rows staged through host memory); the driver's runs use RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LRBMS_BENCH_BACKEND='gloo', LRBMS_BENCH_DEVICE='0')
+    port = 29900 + (os.getpid() % 90)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--config', 'cfg2']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['scaling'] == 'strong' and 'cpu_baseline' not in out
