@@ -325,7 +325,12 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
   __syncthreads();
   const int ng = uniform(grp_n);
   const int ncols = ng * N;
-  const int nchunks = t.nT / EC;
+  // K-split (grid.z = 2, only when a rank has so few subdomains that half the CUs would idle): each half of the
+  // elements is a workgroup of its own and the two partial results meet in zeroed outputs by atomic add -- with
+  // exactly two contributions, 0 + a + b is the same double in either order.
+  const int ksplit = gridDim.z;
+  const int nchunks = t.nT / EC / ksplit;
+  const int T0 = blockIdx.z * nchunks * EC;        // first element of this workgroup's share
 
   if (wave < EC) {
     // ================================================= producers
@@ -435,11 +440,11 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     // producers' VALU work and the consumers' f64 MFMAs of one SIMD add up instead of overlapping, with distance 1 or
     // 2 alike, so the kernel time is about base + loads + staging + MFMA and each term has to be cut on its own.
     Set s0, s1, s2;
-    load_set(wave, s0);
-    if (F1_PF == 2) load_set(EC + wave, s1);       // nT >= 8, so chunk 1 exists
+    load_set(T0 + wave, s0);
+    if (F1_PF == 2) load_set(T0 + EC + wave, s1);  // every share has at least two chunks
     double rhs_part = 0.0;
     auto step = [&](int c, Set& cur, Set& nxt) {
-      const int T = c * EC + wave;                 // wave-uniform element
+      const int T = T0 + c * EC + wave;            // wave-uniform element
       double* Xb = &Xs[c & 1][0];
       double* Yb = &Ys[c & 1][0];
       load_set(c + F1_PF < nchunks ? T + F1_PF * EC : T, nxt);   // unconditional (tail: this element again): the wait counts loads
@@ -584,10 +589,10 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
         for (int i = 0; i < 3; ++i) vbx[1 + f][i] = Vs[(long)(3 * e + i) * N + jc];
       }
     };
-    fetch(wave, pre, vb);
+    fetch(T0 + wave, pre, vb);
     double rhs_part = 0.0;
     auto step = [&](int c, const double (&pre)[PRE], const double (&vb)[4][3], double (&npre)[PRE], double (&nvb)[4][3]) {
-      const int T = c * EC + wave;                 // wave-uniform element
+      const int T = T0 + c * EC + wave;            // wave-uniform element
       double* Xb = &Xs[c & 1][0];
       double* Yb = &Ys[c & 1][0];
 #pragma unroll
@@ -688,8 +693,13 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
           const int row = i * 16 + lk + 4 * r;
           const double val = acc[i][jt][r];
           if (live && row < N) {
-            dst[(long)row * ld] = val;
-            if (dst_t) dst_t[row] = val;
+            if (ksplit == 1) {
+              dst[(long)row * ld] = val;
+              if (dst_t) dst_t[row] = val;
+            } else {
+              unsafeAtomicAdd(dst + (long)row * ld, val);
+              if (dst_t) unsafeAtomicAdd(dst_t + row, val);
+            }
           }
         }
       }
@@ -700,9 +710,28 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     if (tid < N) {
       double sum = 0.0;
       for (int w = 0; w < EC; ++w) sum += red[w * 64 + tid];
-      a.rhs_red[(long)s * N + tid] = sum;
+      if (ksplit == 1)
+        a.rhs_red[(long)s * N + tid] = sum;
+      else
+        unsafeAtomicAdd(a.rhs_red + (long)s * N + tid, sum);
     }
   }
+}
+
+// Zeroes every output of k_f1 (the destination blocks of its column groups and rhs_red) before a K-split launch.
+__global__ __launch_bounds__(256) void k_f1_zero(GrpTable gt, int S, int N, double* __restrict__ rhs_red) {
+  const int s = blockIdx.x;
+  for (int g = 0; g < gt.n; ++g) {
+    double* dst = gt.g[g].dst + (long)s * gt.g[g].sstride;
+    double* dst_t = gt.g[g].dst_t ? gt.g[g].dst_t + (long)s * gt.g[g].sstride : nullptr;
+    const int ld = gt.g[g].ld;
+    for (int i = threadIdx.x; i < N * N; i += 256) {
+      dst[(long)(i / N) * ld + i % N] = 0.0;
+      if (dst_t) dst_t[(long)(i / N) * ld + i % N] = 0.0;
+    }
+  }
+  if (rhs_red)
+    for (int i = threadIdx.x; i < N; i += 256) rhs_red[(long)s * N + i] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1499,7 +1528,18 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
         nsl = sl + 1;
       }
       F1Args a{V, A_diag, P_diag, caa, Aab, Rself, b, g0 == 0 ? rhs_red : nullptr, Q, N, S};
-      const dim3 grid(S, nsl);
+      // K-split in two when even the split launch leaves half of the CUs to the kernels forked beside k_f1 (a k_f1
+      // workgroup owns its CU's whole register file) and both halves keep an even number of chunks (the producers'
+      // loops are unrolled by two).  Measured: 64 subdomains (config 2) 0.160 -> 0.145 ms per pass; at 128 subdomains
+      // the split launch fills all 256 CUs, the forked kernels queue behind it and the pass gets slower (0.22 -> 0.26).
+      const char* env_ks = getenv("LRBMS_F1_KSPLIT");
+      const bool split_ok = (t.nT / EC) % 4 == 0;
+      const int ksplit = split_ok && (env_ks ? env_ks[0] == '2' : 4 * S * nsl <= 256) ? 2 : 1;
+      if (ksplit > 1) {
+        for (int sl = 0; sl < nsl; ++sl)
+          hipLaunchKernelGGL(k_f1_zero, dim3(S), dim3(256), 0, st, gt[sl], S, N, sl == 0 ? a.rhs_red : nullptr);
+      }
+      const dim3 grid(S, nsl, ksplit);
 #define LRBMS_F1(NTXV)                                                                                              \
   do {                                                                                                              \
     if (Q == 1 && one_slice) hipLaunchKernelGGL((k_f1<NTXV, NTY, 1>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);      \
