@@ -196,3 +196,30 @@ def global_norms(local_eta_nc, local_eta_r_plus_df, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(sq, group=group)
     return torch.sqrt(sq)
+
+
+def gather_subdomain_rows(t_local, owned, total, group=None):
+    """All-gather per-subdomain rows into global subdomain order.
+
+    ``t_local`` [S_loc, ...] holds the rows of the subdomains ``owned[rank]`` (every rank passes the same ``owned``:
+    one list of global subdomain indices per rank).  Returns [total, ...] on every rank.  Ranks may own different
+    numbers of subdomains (rows are padded to the largest share for the collective)."""
+    import torch
+    import torch.distributed as dist
+    world = len(owned)
+    if world == 1:
+        return t_local
+    smax = max(len(o) for o in owned)
+    pad = torch.zeros((smax,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
+    pad[:t_local.shape[0]] = t_local
+    staged = pad.is_cuda and dist.get_backend(group) == 'gloo'     # gloo has no device all-gather
+    src = pad.cpu() if staged else pad
+    out = torch.empty((world * smax,) + tuple(pad.shape[1:]), dtype=pad.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src.contiguous(), group=group)
+    if staged:
+        out = out.to(pad.device)
+    res = torch.empty((total,) + tuple(pad.shape[1:]), dtype=pad.dtype, device=pad.device)
+    for r, ids in enumerate(owned):
+        if len(ids):
+            res[torch.as_tensor(list(ids), device=res.device)] = out[r * smax:r * smax + len(ids)]
+    return res

@@ -53,10 +53,36 @@ class ReducedDiscretization:
         dense LU of the unblocked matrix; here block-Jacobi PCG on the block-sparse system (``lrbms_reduced_solve``)."""
         eng = self.d.engine
         if eng.S_ext != eng.S:
-            raise NotImplementedError('reduced solve on a sharded discretization: gather B_sys / rhs_red first')
+            ctx, B_all, rhs_all = self._global_online()
+            u, info = ctx.reduced_solve(self.d.theta(mu), B_all, rhs_all)
+            self.last_solve_info = info
+            u = u[self._torch.as_tensor(eng.local, device=u.device)]
+            return ReducedVectorArray(u.reshape(eng.S, self.N, 1))
         u, info = eng.reduced_solve(self.d.theta(mu), self.B_sys, self.rhs_red)
         self.last_solve_info = info
         return ReducedVectorArray(u.reshape(eng.S, self.N, 1))
+
+    def _global_online(self):
+        """Sharded discretization: the reduced system is small (S x 5 blocks of N x N per affine component), so every rank
+        gathers all of it once (one all-gather each for B_sys and rhs_red) and solves redundantly on its own GPU through
+        a second library context that holds the GLOBAL neighbour table.  Returns (context, B_sys, rhs_red) in global order."""
+        if getattr(self, '_online', None) is None:
+            from pylrbms_amd._native import NativeContext
+            from pylrbms_amd.grid import DDSubdomainsGrid
+            from pylrbms_amd.parallel import gather_subdomain_rows
+            eng = self.d.engine
+            g = eng.grid
+            group = getattr(self.d.mpi_comm, 'group', None)
+            owned = [list(DDSubdomainsGrid(g.lower_left, g.upper_right, g.K, g.P, rank=r, world_size=g.world_size).subdomains_on_rank)
+                     for r in range(g.world_size)]
+            total = g.num_subdomains
+            B = gather_subdomain_rows(self.B_sys.permute(1, 0, 2, 3, 4).contiguous(), owned, total, group)
+            rhs = gather_subdomain_rows(self.rhs_red, owned, total, group)
+            ctx = NativeContext(eng.ctx.device.index)
+            nbr = np.asarray(g.neighbor_slots, dtype=np.int32).reshape(total, 5)
+            ctx.mesh_upload(eng.t, eng.kappa, nbr, total, total)
+            self._online = (ctx, B.permute(1, 0, 2, 3, 4).contiguous(), rhs.contiguous())
+        return self._online
 
     def _local_estimates(self, U, mu):
         torch = self._torch

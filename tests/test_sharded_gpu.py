@@ -87,7 +87,18 @@ def _worker(rank, world, port, ref_path, results):
         u = eng.ctx.from_numpy(u_g[eng.ext])
         eta = eng.reduced_estimate(theta, u, buf['grams']).cpu().numpy()
         ok &= bool(np.abs(eta - ref['eta'][:, eng.local]).max() < 1e-10 * np.abs(ref['eta']).max())
-        results[rank] = (ok, worst, eng.S, eng.S_ext)
+        # API level: sharded discretize -> reductor with the same bases -> reduce (halo exchange inside) -> rd.solve, which
+        # gathers the reduced system on every rank and solves it through a second context with the global neighbour table
+        from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+        from pylrbms_amd.reductor import LRBMSReductor
+        del eng, buf, V
+        d, _ = discretize(_problem(Communicator(rank, world)), mpi_comm=Communicator(rank, world))
+        red = LRBMSReductor(d, bases={'domain_{}'.format(ii): Vg[ii].T for ii in d.engine.local})
+        rd = red.reduce()
+        u_loc = rd.solve(0.4).tensor[:, :, 0].cpu().numpy()
+        err_u = np.abs(u_loc - ref['u_solve'][d.engine.local]).max() / np.abs(ref['u_solve']).max()
+        ok &= bool(err_u < 1e-9)
+        results[rank] = (ok, max(worst, err_u), d.engine.S, d.engine.S_ext)
     finally:
         dist.destroy_process_group()
 
@@ -103,6 +114,7 @@ def test_sharded_projection_matches_single_rank(world, tmp_path):
     out = {k: v.cpu().numpy() for k, v in zip(names, list(buf['sys']) + list(buf['grams']))}
     u_g = np.random.default_rng(5).standard_normal((grid.num_subdomains, N))
     out['eta'] = eng.reduced_estimate(np.array([1.0, 0.4]), eng.ctx.from_numpy(u_g), buf['grams']).cpu().numpy()
+    out['u_solve'] = eng.reduced_solve(np.array([1.0, 0.4]), buf['sys'][0], buf['sys'][1])[0].cpu().numpy()
     ref_path = str(tmp_path / 'ref.npz')
     np.savez(ref_path, **out)
     del eng, buf, V
