@@ -1036,11 +1036,11 @@ __global__ __launch_bounds__(512) void k_thin_nc(Tmpl t, int S, const int* __res
                                                  double* __restrict__ G_nc) {
   constexpr int NMAX = 16 * NTX;
   constexpr int LDA = padded_ld(NTX);
-  constexpr int NT2 = 2 * NTX;                  // column tiles of [self | a] (each block padded to NTX tiles)
-  constexpr int LDB = padded_ld(NT2);
+  constexpr int LDB = LDA;                      // one Y buffer, used twice: E W_self (block [a, self]), then E W_a ([a, a])
   constexpr int NW = 8;                         // waves per workgroup
-  constexpr int NACC = (NTX * NT2 + NW - 1) / NW;
-  extern __shared__ double lds[];               // Wa [KP][LDA], Yc [KP][LDB]
+  constexpr int NACC = (NTX * NTX + NW - 1) / NW;
+  constexpr int ITM = 3;                        // staging items per thread (ne * N <= 3 * 512, checked by the launcher)
+  extern __shared__ double lds[];               // Wa [KP][LDA], Yc [KP][LDB]: 40 KB at config 3 -> 4 workgroups per CU
   const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
   const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
@@ -1082,54 +1082,76 @@ __global__ __launch_bounds__(512) void k_thin_nc(Tmpl t, int S, const int* __res
   const double* Vs = V + (long)s * t.n * N;
   const double* As = AvgSelf + (long)s * t.nv * N;
   const double* Aa = AvgSide + ((long)s * 4 + side) * nvs * N;
-  // phase 1: rows of the touching elements: Wa (neighbour image), and E applied to the own / neighbour image
-  for (int it = tid; it < ne * N; it += 512) {
-    const int p = it / N, j = it - p * N;
-    const int T = ttab[p];
-    double wa[3], ws[3];
+  // phase 1: rows of the touching elements: Wa (neighbour image) and Y = E W_self; E W_a stays in registers for pass 2
+  double ya[ITM][3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int pos = ptab[(3 * p + i) * 4 + side];
-      ws[i] = Vs[(long)(3 * T + i) * N + j] - As[(long)vtab[3 * p + i] * N + j];
-      wa[i] = pos >= 0 ? -Aa[(long)pos * N + j] : 0.0;
-    }
-    const double* K = Ksc + 9 * p;
+  for (int u = 0; u < ITM; ++u) {
+    const int it = tid + 512 * u;
+    ya[u][0] = ya[u][1] = ya[u][2] = 0.0;
+    if (it < ne * N) {
+      const int p = it / N, j = it - p * N;
+      const int T = ttab[p];
+      double wa[3], ws[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      Wa[(3 * p + k) * LDA + j] = wa[k];
-      Yc[(3 * p + k) * LDB + j] = K[k * 3] * ws[0] + K[k * 3 + 1] * ws[1] + K[k * 3 + 2] * ws[2];
-      Yc[(3 * p + k) * LDB + NMAX + j] = K[k * 3] * wa[0] + K[k * 3 + 1] * wa[1] + K[k * 3 + 2] * wa[2];
-    }
-  }
-  __syncthreads();
-  // phase 2: MFMA, tiles dealt round-robin to the 8 waves
-  d4 acc[NACC];
+      for (int i = 0; i < 3; ++i) {
+        const int pos = ptab[(3 * p + i) * 4 + side];
+        ws[i] = Vs[(long)(3 * T + i) * N + j] - As[(long)vtab[3 * p + i] * N + j];
+        wa[i] = pos >= 0 ? -Aa[(long)pos * N + j] : 0.0;
+      }
+      const double* K = Ksc + 9 * p;
 #pragma unroll
-  for (int k = 0; k < NACC; ++k) acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int kk = 0; kk < KP; kk += 4) {
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-      const int tile = wave + NW * k;
-      if (tile < NTX * NT2) {
-        const int ti = tile / NT2, tj = tile - ti * NT2;
-        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wa[(kk + lk) * LDA + ti * 16 + li], Yc[(kk + lk) * LDB + tj * 16 + li], acc[k], 0, 0, 0);
+      for (int k = 0; k < 3; ++k) {
+        Wa[(3 * p + k) * LDA + j] = wa[k];
+        Yc[(3 * p + k) * LDB + j] = K[k * 3] * ws[0] + K[k * 3 + 1] * ws[1] + K[k * 3 + 2] * ws[2];
+        ya[u][k] = K[k * 3] * wa[0] + K[k * 3 + 1] * wa[1] + K[k * 3 + 2] * wa[2];
       }
     }
   }
+  __syncthreads();
+  // phase 2: two MFMA passes over the same Wa, tiles dealt round-robin to the 8 waves:
+  //   pass 0: Wa^T (E W_self) = block [a, self] (and its transpose [self, a]);  pass 1: Wa^T (E W_a) = block [a, a]
 #pragma unroll
-  for (int k = 0; k < NACC; ++k) {
-    const int tile = wave + NW * k;
-    const int ti = tile / NT2, tj = tile - ti * NT2;
-    const int col = tj * 16 + li;                       // < NMAX: block [a, self]; >= NMAX: block [a, a]
-    const int jj = col < NMAX ? col : col - NMAX;
-    const int cslot = col < NMAX ? 2 : slot;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {
+      __syncthreads();                          // every wave is done reading Y = E W_self
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = ti * 16 + lk + 4 * r;
-      const double val = acc[k][r];
-      if (tile < NTX * NT2 && jj < N && row < N) {
-        G[(long)(slot * N + row) * W + cslot * N + jj] = val;
-        if (cslot == 2) G[(long)(2 * N + jj) * W + slot * N + row] = val;   // [self, a] = [a, self]^T
+      for (int u = 0; u < ITM; ++u) {
+        const int it = tid + 512 * u;
+        if (it < ne * N) {
+          const int p = it / N, j = it - p * N;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) Yc[(3 * p + k) * LDB + j] = ya[u][k];
+        }
+      }
+      __syncthreads();
+    }
+    d4 acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < KP; kk += 4) {
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) {
+        const int tile = wave + NW * k;
+        if (tile < NTX * NTX) {
+          const int ti = tile / NTX, tj = tile - ti * NTX;
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wa[(kk + lk) * LDA + ti * 16 + li], Yc[(kk + lk) * LDB + tj * 16 + li], acc[k], 0, 0, 0);
+        }
+      }
+    }
+    const int cslot = pass == 0 ? 2 : slot;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+      const int tile = wave + NW * k;
+      const int ti = tile / NTX, tj = tile - ti * NTX;
+      const int jj = tj * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + lk + 4 * r;
+        const double val = acc[k][r];
+        if (tile < NTX * NTX && jj < N && row < N) {
+          G[(long)(slot * N + row) * W + cslot * N + jj] = val;
+          if (pass == 0) G[(long)(2 * N + jj) * W + slot * N + row] = val;   // [self, a] = [a, self]^T
+        }
       }
     }
   }
@@ -1438,7 +1460,7 @@ int build_template_tables(lrbms_ctx* ctx) {
 
 static size_t thin_nc_lds_bytes(const Tmpl& t, int ntx) {   // Wa, Yc, Ksc, ttab / vtab / ptab / side_mask of k_thin_nc
   const size_t kp = (size_t)((3 * t.ntouch + 3) & ~3);
-  return sizeof(double) * (kp * (padded_ld(ntx) + padded_ld(2 * ntx)) + 9 * (size_t)t.ntouch) + sizeof(int) * 17 * (size_t)t.ntouch;
+  return sizeof(double) * (kp * 2 * padded_ld(ntx) + 9 * (size_t)t.ntouch) + sizeof(int) * 17 * (size_t)t.ntouch;
 }
 
 bool fused_supported(lrbms_ctx* ctx, int Q, int N) {
@@ -1446,7 +1468,7 @@ bool fused_supported(lrbms_ctx* ctx, int Q, int N) {
   if (N > 64 || Q > 4 || Q * N > 128 || t.nT % 8 != 0 || t.nT > 1024 || t.ntouch > 256) return false;
   {
     const int ntx = (N + 15) / 16;
-    if (thin_nc_lds_bytes(t, ntx) > 64 * 1024) return false;
+    if (thin_nc_lds_bytes(t, ntx) > 64 * 1024 || t.ntouch * N > 3 * 512) return false;   // k_thin_nc: LDS, items per thread
   }
   if ((size_t)(3 * t.ncf * Q * N + Q * t.ncf * N + 3 * t.ncf) * sizeof(double) > 64 * 1024) return false;
   if ((size_t)2 * ((3 * t.ncf + 3) & ~3) * padded_ld((N + 15) / 16) * sizeof(double) > 64 * 1024) return false;   // k_coupling
