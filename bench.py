@@ -228,7 +228,9 @@ def main():
         mus = np.random.default_rng(7).uniform(0.1, 1.0, size=256)
         coeffs = lam['coefficients']
         thetas = np.array([[c.evaluate(float(m)) for c in coeffs] for m in mus])
-        nb = 16 if N * 16 <= 768 else max(1, 768 // N)
+        nb = min(16, 1280 // N)            # lrbms_reduced_solve_batch takes N * nmu <= 1280; measured at config 3: batches of
+                                           # 16 give 760 mu-solves/s, batches of 32 only 577 (the panel matvec turns VALU-bound)
+        ne = min(16, nb)                                                     # lrbms_reduced_estimate_batch: <= 16 per call
         eng.ctx.reduced_solve_batch(thetas[:nb], bufo['sys'][0], bufo['sys'][1])      # warm-up
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -239,7 +241,9 @@ def main():
             iters, worst = max(iters, info['iterations']), max(worst, info['relative_residual'])
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            eng.ctx.reduced_estimate_batch(thetas[b0:b0 + nb], ub, bufo['grams'], eng.f2, eng.ceps, eng.hdiam)   # E1
+            for e0 in range(0, ub.shape[2], ne):                              # E1, in sub-batches of <= 16 parameters
+                eng.ctx.reduced_estimate_batch(thetas[b0 + e0:b0 + e0 + ne], ub[:, :, e0:e0 + ne].contiguous(), bufo['grams'],
+                                               eng.f2, eng.ceps, eng.hdiam)
             torch.cuda.synchronize()
             t_est += time.perf_counter() - t2
         dt = time.perf_counter() - t1

@@ -201,7 +201,7 @@ int lrbms_reduced_solve(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* thet
                         const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
                         void* stream);
 
-/* O1, throughput form: nmu <= 32 parameters at once (N * nmu <= 768).  theta [nmu][Q] host; u [S][N][nmu] (mu fastest).
+/* O1, throughput form: nmu <= 32 parameters at once (N * nmu <= 1280).  theta [nmu][Q] host; u [S][N][nmu] (mu fastest).
  * Every projected block is read once per CG iteration for the whole batch; one block-Jacobi preconditioner at the
  * batch-mean theta.  info[0] = iterations, info[1] = worst relative residual. */
 int64_t lrbms_reduced_solve_batch_work_size(lrbms_ctx* ctx, int32_t N, int32_t nmu);

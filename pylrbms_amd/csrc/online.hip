@@ -349,6 +349,7 @@ int launch_reduced_solve(lrbms_ctx* ctx, int Q, int N, const double* theta, cons
 namespace {
 
 constexpr int BMAX = 32;   // max parameters per batch
+constexpr int BCG_K = 5;   // outputs per thread of the batched matvec: N * nmu <= 256 * BCG_K = 1280
 
 struct ThetaBatch { double v[BMAX * 8]; };   // theta[m][q], q < 8
 
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void k_bcg_matvec(int S, const int* __restrict
     }
     Pt[i] = v;
   }
-  double acc[3] = {0.0, 0.0, 0.0};   // outputs it = tid + 256 k < N nmu  (N nmu <= 768)
+  double acc[BCG_K] = {0.0, 0.0, 0.0, 0.0, 0.0};   // outputs it = tid + 256 k < N nmu  (N nmu <= 256 BCG_K)
   for (int slot = 0; slot < 5; ++slot) {
     if (nbr[s * 5 + slot] < 0) continue;
     for (int q = 0; q < Q; ++q) {
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256) void k_bcg_matvec(int S, const int* __restrict
       for (int i = tid; i < N * N; i += 256) Bs[i] = B[i];
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < BCG_K; ++k) {
         const int it = tid + 256 * k;
         if (it < NM) {
           const int r = it / nmu, m = it - r * nmu;
@@ -401,14 +402,14 @@ __global__ __launch_bounds__(256) void k_bcg_matvec(int S, const int* __restrict
   double* Ys = Bs;   // reuse (N * nmu <= N * N is not guaranteed): use red-free region of Pt slot 0 instead
   (void)Ys;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < BCG_K; ++k) {
     const int it = tid + 256 * k;
     if (it < NM) y[(long)s * NM + it] = acc[k];
   }
   // partial[s][m] = sum_r p_new[s][r][m] * y[s][r][m]: stage products in LDS slot 0 of Pt, then sum over r per m
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < BCG_K; ++k) {
     const int it = tid + 256 * k;
     if (it < NM) Pt[it] = acc[k] * Pt[2 * NM + it];
   }
@@ -509,8 +510,8 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
                                const double* rhs_red, double* work, double* u, double rtol, int max_iter, double* info,
                                hipStream_t st) {
   if (ctx->S_ext != ctx->S) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve_batch needs all subdomains on one rank");
-  if (N > 64 || nmu < 1 || nmu > BMAX || N * nmu > 768)
-    return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve_batch: need N <= 64, nmu <= 32, N * nmu <= 768");
+  if (N > 64 || nmu < 1 || nmu > BMAX || N * nmu > 256 * BCG_K)
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve_batch: need N <= 64, nmu <= 32, N * nmu <= 1280");
   const int S = ctx->S;
   const long NM = (long)N * nmu, vec = (long)S * NM;
   ThetaBatch th;
@@ -541,6 +542,8 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   LRBMS_LAUNCH_CHECK(ctx);
   const size_t lds_upd = sizeof(double) * 3 * NM;
   const size_t lds_mv = sizeof(double) * (5 * NM + (size_t)N * N + 256);
+  if (lds_mv > 64 * 1024)
+    LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mv));
   hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, st, N, nmu, Dinv, scal, 1, u, r, p0, y, z, partial, partial2);
   hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, st, S, nmu, partial, partial2, scal, 0);
   LRBMS_LAUNCH_CHECK(ctx);
