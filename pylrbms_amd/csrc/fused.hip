@@ -10,22 +10,28 @@
 //   * blocks between two different neighbour slots are zero (or corner-element-only) and are only zero-filled.
 // What remains dense is the self x self part: V^T{A_q V, P V, M V, c K V, A_ab R}, W^T E W, R^T B R, D^T |T| D,
 // all with K = n (or n_T) -- these run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), with the "L_T Y_T"
-// operand built on the fly from L2-resident rows into LDS while another workgroup of the same CU issues MFMAs.
+// operand built on the fly from L2-resident rows into LDS by producer waves while consumer waves issue the MFMAs.
 //
-// Staging is wave-uniform: wave w of a workgroup builds the three rows of element c0 + w, lanes run over basis
-// columns.  Everything that depends only on the element (3x3 blocks, stiffness, coefficients, adjacency) is then
-// wave-uniform and comes through the scalar cache (s_load), leaving the vector memory pipe to the basis rows.
+// Staging is wave-uniform: producer wave w of a workgroup builds the rows of element c0 + w.  What depends only on the
+// element (adjacency, areas, rhs) comes through the scalar cache (constant-address-space loads); the element's blocks
+// reach the math without any broadcast: the four-block applies are a small MFMA whose operands are loaded in lane
+// layout, the few remaining entries sit one per lane and are read with v_readlane.  All vector loads of the producers
+// are asm-managed prefetch sets (gload_f64 / s_waitcnt vmcnt(n)), see k_f1.
 //
-// Launches (grid = one workgroup per subdomain unless noted):
-//   k_flux_compact   R_self [S][n_rt][QN], R_side [S][4][ncf][QN]                      (HBM-bound, small)
-//   k_vertex_avg     Oswald vertex averages Avg_self [S][nv][N], Avg_side [S][4][nvs][N] (HBM-bound, small)
-//   k_f1<NTX>        X = V:  B_sys diag, E_red, M_red, G_aa, G_ab[:, self], rhs_red     (MFMA)
-//   k_f2<NR>         X = R~: G_bb[self,self], G_rdd[self,self], r_fd[self]              (MFMA)
-//   k_f3<NTX>        X = W_self: G_nc[self,self]                                        (MFMA)
-//   k_thin_nc        grid (4 sides, S): block-row `a` and block [self,a] of G_nc        (VALU, write-bound)
-//   k_thin_rt        grid (4 sides, S): block-rows (a,q) / blocks [self,(a,q)] of G_bb, G_rdd, G_ab[:, a], r_fd[a]
-//   k_coupling       grid (4 sides, S): off-diagonal blocks of B_sys                    (MFMA, small)
-// Every output element is written exactly once (zeros included); all reductions have a fixed order.
+// Launches (grid = one workgroup per subdomain unless noted); "A" = reads only the rank's own basis slabs (phase 1 of a
+// sharded pass, overlapped with the halo exchange), "B" = needs the neighbours' rows (phase 2):
+//   k_flux_compact   A(+B)  R_self [S][n_rt][QN], R_side [S][4][ncf][QN]                 (HBM-bound, small)
+//   k_vertex_avg     A(+B)  Oswald vertex averages Avg_self [S][nv][N], Avg_side [S][4][nvs][N]
+//   k_flux_side, k_vertex_side   B   R_side / Avg_side alone (phase 2 of a sharded pass)
+//   k_f1<NTX,7,Q>    A   X = V:  B_sys diag, E_red, M_red, G_aa, G_ab[:, self], rhs_red  (MFMA; grid.z = 2: K-split)
+//   k_f2<NR>         A   X = R~: G_bb[self,self], G_rdd[self,self], r_fd[self]           (MFMA, symmetric tiles)
+//   k_f3<NTX>        A   X = W_self: G_nc[self,self]                                     (MFMA, symmetric tiles)
+//   k_thin_nc        B   grid (4 sides, S): block-row `a` and block [self,a] of G_nc     (MFMA + VALU, latency-bound)
+//   k_thin_rt        B   grid (4 sides, S): blocks [a,self], [a,a] of G_bb, G_rdd; G_ab[:, a], r_fd[a]  (write-bound)
+//   k_coupling       B   grid (4 sides, S): off-diagonal blocks of B_sys                 (MFMA, small)
+// Below 192 subdomains per rank the independent kernels are forked over the library's streams.  Every output element is
+// written exactly once (zeros included); all reductions have a fixed order (the 2-way K-split meets by atomic add, which
+// is order-independent for two contributions).
 #include <cstdlib>
 
 #include "lrbms_dev.h"
