@@ -209,6 +209,16 @@ int lrbms_reduced_solve_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu,
                               const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
                               void* stream);
 
+/* -- snapshot generation (SURVEY.md section 8f "next" #2) -------------------------------------------------- */
+/* DuneDiscretization._solve (block_swipdg.py:219-225; ISTL bicgstab.ilut in the reference driver,
+ * online_adaptive_lrbms.py:71): A(mu) x = b for the full-order block operator, never assembled: matvec on the block-ELL
+ * data (A_diag, A_cpl), CG with the 3x3 element blocks as block-Jacobi preconditioner (the operator is SPD).
+ *   theta [Q] host; b, x [S][n]; work: lrbms_fom_solve_work_size doubles (device); info (host, may be NULL):
+ *   iterations, final relative residual.  LRBMS_E_NOT_CONVERGED above rtol after max_iter.  Needs S_ext == S. */
+int64_t lrbms_fom_solve_work_size(lrbms_ctx* ctx);
+int lrbms_fom_solve(lrbms_ctx* ctx, int32_t Q, const double* theta, const double* A_diag, const double* A_cpl, const double* b,
+                    double* work, double* x, double rtol, int32_t max_iter, double* info, void* stream);
+
 /* -- online enrichment (SURVEY.md section 8f "next" #1) ---------------------------------------------------- */
 /* Dirichlet correction blocks of the neighbourhood problems: on every coupling face of subdomain s, the boundary-form
  * diagonal block minus the inner-face block already contained in A_diag

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'liblrbms_hip.so')
-SOURCES = ['capi.hip', 'assemble.hip', 'apply.hip', 'gemm.hip', 'fused.hip', 'online.hip', 'enrich.hip']
+SOURCES = ['capi.hip', 'assemble.hip', 'apply.hip', 'gemm.hip', 'fused.hip', 'online.hip', 'enrich.hip', 'fom.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 

@@ -53,6 +53,8 @@ SIGNATURES = {
     'lrbms_reduced_solve_batch_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_reduced_solve_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL,
                                                  c_vp]),
+    'lrbms_fom_solve_work_size': (c_i64, [c_vp]),
+    'lrbms_fom_solve': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms_assemble_dirichlet_correction': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     'lrbms_local_correction_work_size': (c_i64, [c_vp, c_i32]),
     'lrbms_local_correction_solve': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_i32, _P_I32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl,
@@ -390,6 +392,22 @@ class NativeContext:
                                                 c_vp(u.data_ptr()), float(rtol), int(max_iter), _dblp(info), self._stream())
         self._check(rc, 'lrbms_reduced_solve_batch')
         return u, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
+
+    # ------------------------------------------------------------------ snapshot generation
+    def fom_solve(self, theta, A_diag, A_cpl, b, rtol=1e-12, max_iter=100000):
+        """A(mu) x = b for the full-order block operator -> (x [S, n], info)."""
+        Q, S = A_diag.shape[0], self.S
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        assert th.shape == (Q,)
+        work = self.empty(int(self.lib.lrbms_fom_solve_work_size(self.handle)))
+        x = self.empty(S, self.n)
+        info = np.zeros(2)
+        rc = self.lib.lrbms_fom_solve(self.handle, Q, _dblp(th), self._ptr(A_diag, (Q, S, self.n_T, 4, 9), 'A_diag'),
+                                      self._ptr(A_cpl, (Q, S, 4, self.ncf, 9), 'A_cpl'), self._ptr(b, (S, self.n), 'b'),
+                                      c_vp(work.data_ptr()), c_vp(x.data_ptr()), float(rtol), int(max_iter), _dblp(info),
+                                      self._stream())
+        self._check(rc, 'lrbms_fom_solve')
+        return x, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
 
     # ------------------------------------------------------------------ online enrichment
     def assemble_dirichlet_correction(self, lam):

@@ -19,6 +19,9 @@ int64_t local_correction_work_size(lrbms_ctx* ctx, int nmark);
 int launch_local_correction(lrbms_ctx* ctx, int Q, const double* theta, int nmark, const int32_t* marked, const double* A_diag,
                             const double* A_cpl, const double* D_corr, const double* b, double* work, double* corr, double rtol,
                             int max_iter, double* info, hipStream_t st);
+int64_t fom_solve_work_size(lrbms_ctx* ctx);
+int launch_fom_solve(lrbms_ctx* ctx, int Q, const double* theta, const double* A_diag, const double* A_cpl, const double* b,
+                     double* work, double* x, double rtol, int max_iter, double* info, hipStream_t st);
 int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N);
 bool fused_supported(lrbms_ctx* ctx, int Q, int N);
 int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V, const double* F, const double* A_diag,
@@ -319,6 +322,18 @@ int lrbms_reduced_solve_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu,
   LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red);
   CHECK_PTR(ctx, work); CHECK_PTR(ctx, u);
   return launch_reduced_solve_batch(ctx, Q, N, nmu, theta, B_sys, rhs_red, work, u, rtol, max_iter, info, (hipStream_t)stream);
+}
+
+int64_t lrbms_fom_solve_work_size(lrbms_ctx* ctx) {
+  if (!ctx || !ctx->has_mesh) return -1;
+  return fom_solve_work_size(ctx);
+}
+
+int lrbms_fom_solve(lrbms_ctx* ctx, int32_t Q, const double* theta, const double* A_diag, const double* A_cpl, const double* b,
+                    double* work, double* x, double rtol, int32_t max_iter, double* info, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, 1); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, A_diag); CHECK_PTR(ctx, A_cpl);
+  CHECK_PTR(ctx, b); CHECK_PTR(ctx, work); CHECK_PTR(ctx, x);
+  return launch_fom_solve(ctx, Q, theta, A_diag, A_cpl, b, work, x, rtol, max_iter, info, (hipStream_t)stream);
 }
 
 int lrbms_assemble_dirichlet_correction(lrbms_ctx* ctx, int32_t Q, const double* lam, double* D_corr, void* stream) {

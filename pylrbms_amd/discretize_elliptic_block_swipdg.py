@@ -122,8 +122,10 @@ class DuneDiscretization:
 
     def solve(self, mu, inverse_options=None):
         """``DuneDiscretization._solve`` (block_swipdg.py:219-225).  The reference hands the global matrix to ISTL
-        (bicgstab.ilut); here: Jacobi-preconditioned CG on the SPD block operator, matvec = ``lrbms_fom_apply``.
-        (Snapshot generation is not on the hot path: SURVEY.md section 8f #2.)"""
+        (bicgstab.ilut); here: preconditioned CG on the SPD block operator, never assembled.  One rank: the native
+        ``lrbms_fom_solve`` (element-block Jacobi, four launches per iteration, no host round trips).  Sharded: the same
+        iteration driven from here with ``lrbms_fom_apply`` as matvec, a halo exchange per iteration and all-reduced dot
+        products.  (Snapshot generation is the step before the hot path: SURVEY.md section 8f #2.)"""
         import torch
         import torch.distributed as dist
         eng = self.engine
@@ -135,6 +137,10 @@ class DuneDiscretization:
         max_iter = max(max_iter, 20000)
         group = getattr(self.mpi_comm, 'group', None)
         sharded = eng.S_ext != eng.S
+        if not sharded:
+            x, info = eng.ctx.fom_solve(theta, eng.A_diag, eng.A_cpl, eng.b, rtol=rtol, max_iter=max_iter)
+            self.last_solve_info = info
+            return BlockVectorArray(x.reshape(eng.S, eng.t.n, 1), self.solution_space)
 
         def dot(a, b):
             v = (a * b).sum()

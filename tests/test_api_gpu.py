@@ -106,3 +106,21 @@ def test_fom_apply_matches_the_oracle_operator():
     A = o.assemble_global(0.37)
     ref = (A @ x.reshape(o.ndof, 3)).reshape(o.S, o.n, 3)
     assert np.abs(y - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+def test_native_fom_solve_matches_the_oracle_and_reports_non_convergence():
+    """lrbms_fom_solve (DuneDiscretization._solve, block_swipdg.py:219-225): CG on the never-assembled block operator
+    against the oracle's sparse direct solve; rtol 1e-12 on the residual gives <= 1e-8 on the solution here."""
+    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd._native import NativeError
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': [3, 4], 'coarse_per_subdomain': 2})
+    d, _ = discretize(p)
+    o = oracle_from_problem(p)
+    eng = d.engine
+    x, info = eng.ctx.fom_solve(d.theta(0.37), eng.A_diag, eng.A_cpl, eng.b)
+    ref = o.solve(0.37)
+    assert info['iterations'] > 0 and info['relative_residual'] <= 1e-12
+    assert np.abs(x.cpu().numpy() - ref).max() < 1e-8 * np.abs(ref).max()
+    with pytest.raises(NativeError, match='did not reach rtol'):
+        eng.ctx.fom_solve(d.theta(0.37), eng.A_diag, eng.A_cpl, eng.b, max_iter=3)
