@@ -169,7 +169,13 @@ int lrbms_project_estimate_fused(lrbms_ctx* ctx, int32_t Q, int32_t N, const dou
  * averages of the own basis, the dense self blocks: B_sys diagonal, E_red, M_red, G_aa, G_ab[:, self], rhs_red,
  * G_bb / G_rdd [self, self], r_fd[self], G_nc[self, self]; phase 2 needs the halo slabs and writes every block that
  * involves a neighbour.  phase 0 == lrbms_project_estimate_fused; 1 followed by 2 is bit-identical to 0.  Same
- * buffers (including `work`) must be passed to both halves. */
+ * buffers (including `work`) must be passed to both halves.  phase 3 / 4 split phase 1 into its preparation kernels and
+ * its dense kernels: phase 2 depends on 3 and on the halo only, so it may run on another stream beside 4. */
+/* The i-th (0..2) library-owned HIP stream of the context (a hipStream_t).  A host that overlaps its halo exchange with
+ * the pass runs the halo-dependent phase on stream 0 (HIP multiplexes streams onto few hardware queues: a further host
+ * stream may land on the queue of the caller's stream and serialise behind the dense kernels). */
+void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
+
 int lrbms_project_estimate_fused_phase(lrbms_ctx* ctx, int32_t phase, int32_t Q, int32_t N, const double* V, const double* F,
                                        const double* A_diag, const double* A_cpl, const double* P_diag, const double* b,
                                        const double* ebar, const double* caa, const double* Aab, const double* Bbb, double* work,

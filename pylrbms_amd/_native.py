@@ -32,6 +32,7 @@ SIGNATURES = {
     'lrbms_ctx_create': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_vp)]),
     'lrbms_ctx_destroy': (ctypes.c_int, [c_vp]),
     'lrbms_last_error': (ctypes.c_char_p, [c_vp]),
+    'lrbms_ctx_aux_stream': (c_vp, [c_vp, c_i32]),
     'lrbms_mesh_upload': (ctypes.c_int, [c_vp, ctypes.POINTER(MeshDesc), c_i32, c_i32, _P_I32]),
     'lrbms_assemble_swipdg': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'lrbms_assemble_rhs': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -392,6 +393,16 @@ class NativeContext:
                                                 c_vp(u.data_ptr()), float(rtol), int(max_iter), _dblp(info), self._stream())
         self._check(rc, 'lrbms_reduced_solve_batch')
         return u, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
+
+    def aux_stream(self, i=0):
+        """The i-th library-owned stream as a ``torch.cuda.ExternalStream`` (cached)."""
+        cache = self.__dict__.setdefault('_aux_streams', {})
+        if i not in cache:
+            ptr = self.lib.lrbms_ctx_aux_stream(self.handle, int(i))
+            if not ptr:
+                raise NativeError('lrbms_ctx_aux_stream({}) returned NULL'.format(i))
+            cache[i] = self.torch.cuda.ExternalStream(int(ptr), device=self.device)
+        return cache[i]
 
     # ------------------------------------------------------------------ snapshot generation
     def fom_solve(self, theta, A_diag, A_cpl, b, rtol=1e-12, max_iter=100000):

@@ -90,6 +90,8 @@ int lrbms_ctx_destroy(lrbms_ctx* ctx) {
   return LRBMS_OK;
 }
 
+void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i) { return (ctx && i >= 0 && i < 3) ? (void*)ctx->aux[i] : nullptr; }
+
 const char* lrbms_last_error(lrbms_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* d, int32_t S, int32_t S_ext, const int32_t* nbr) {

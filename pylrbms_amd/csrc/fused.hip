@@ -1491,8 +1491,13 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // k_f2, k_f3 -- more than half of the pass); phase 2 then needs the halo slabs of V (R_side, Avg_side, the thin
   // kernels, the coupling blocks).  1 followed by 2 gives bit-identical results to 0.
   if (!fused_supported(ctx, Q, N)) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: unsupported N / Q / template size");
-  if (phase < 0 || phase > 2) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: phase must be 0, 1 or 2");
-  const bool do_a = phase != 2, do_b = phase != 1;
+  // phase 3 / 4: phase 1 split once more into its preparation (R_self, Avg_self) and its dense kernels (k_f1, k_f2,
+  // k_f3), so that a host can record an event between them and start phase 2 on another stream as soon as the halo has
+  // arrived, while the dense kernels are still running (Engine.project_and_estimate with `halo=`).
+  if (phase < 0 || phase > 4) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: phase must be 0 .. 4");
+  const bool do_prep = phase == 0 || phase == 1 || phase == 3;
+  const bool do_a = phase == 0 || phase == 1 || phase == 4;      // the dense, halo-independent kernels
+  const bool do_b = phase == 0 || phase == 2;
   const Tmpl& t = ctx->t;
   const int S = ctx->S, QN = Q * N, C = 5 * QN;
   const long nvs = t.nvx > t.nvy ? t.nvx : t.nvy;
@@ -1500,12 +1505,12 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   double* Rside = Rself + (long)S * t.nrt * QN;
   double* AvgSelf = Rside + (long)S * 4 * t.ncf * QN;
   double* AvgSide = AvgSelf + (long)S * t.nv * N;
-  if (do_a) {
+  if (do_prep) {
     hipLaunchKernelGGL(k_flux_compact, dim3(S, (t.nrt * N + 255) / 256), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
                        phase == 0 ? 1 : 0);
     hipLaunchKernelGGL(k_vertex_avg, dim3(S, (t.nv * N + 255) / 256), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
                        phase == 0 ? 1 : 0);
-  } else {
+  } else if (do_b) {
     hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)S * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
     hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)S * 4 * nvs * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSide);
   }
@@ -1517,7 +1522,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // S = 256: 0.53 vs 0.51; S = 512: 0.97 vs 0.93; S = 1024: 1.92 vs 1.81 -> fork only below 192 subdomains per rank.
   // LRBMS_STREAMS=0 / 1 overrides.
   const char* env_streams = getenv("LRBMS_STREAMS");
-  const bool multi = env_streams ? env_streams[0] != '0' : S < 192;
+  const bool multi = (do_a || do_b) && (env_streams ? env_streams[0] != '0' : S < 192);
   hipStream_t s_rt = multi ? ctx->aux[0] : st, s_f23 = multi ? ctx->aux[1] : st, s_nc = multi ? ctx->aux[2] : st;
   hipStream_t side = s_nc;
   if (multi) {

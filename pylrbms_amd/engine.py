@@ -118,8 +118,8 @@ class Engine:
     def project_and_estimate(self, V, buffers=None, project_system=True, fused=None, halo=None):
         """One pass of the hot path over all local subdomains.  ``V`` [S_ext, n, N] must already hold the halo -- or
         ``halo`` (a ``pylrbms_amd.parallel.HaloExchange``) is given and fills it: with the fused pass the exchange then
-        runs on the communication stream while the halo-independent half of the pass (more than half of its time) is
-        computed, and only the half that reads neighbour rows waits for it.
+        runs on the communication stream while the halo-independent kernels (more than half of the pass) are computed on
+        the main stream; the kernels that read neighbour rows start on a side stream as soon as the halo has arrived.
         ``fused=None`` picks the fused pass (csrc/fused.hip) whenever the library supports (Q, N) and falls back to the
         unfused HIP kernels otherwise (both are GPU paths; the unfused one also materialises the image bases Wt, Rt)."""
         if not self.assembled:
@@ -137,10 +137,19 @@ class Engine:
             if halo is None:
                 c.project_estimate_fused(*args)
             else:
-                finish = halo.start(V)                      # pack + asynchronous collective
-                c.project_estimate_fused(*args, phase=1)    # reads local slabs only
-                finish()                                    # current stream waits for the collective, unpack
-                c.project_estimate_fused(*args, phase=2)
+                torch = c.torch
+                main = torch.cuda.current_stream()
+                side = c.aux_stream(0)     # a library stream, not a fresh one: HIP maps streams onto few hardware queues
+                finish = halo.start(V)                      # pack on the main stream + asynchronous collective
+                c.project_estimate_fused(*args, phase=3)    # R_self, Avg_self (local slabs only)
+                prepared = torch.cuda.Event()
+                prepared.record(main)
+                c.project_estimate_fused(*args, phase=4)    # k_f1, k_f2, k_f3 on the main stream (local slabs only)
+                with torch.cuda.stream(side):               # beside them, as soon as the halo is there:
+                    side.wait_event(prepared)
+                    finish()                                # side stream waits for the collective, unpacks into V[S:]
+                    c.project_estimate_fused(*args, phase=2)    # R_side, Avg_side, thin kernels, coupling blocks
+                main.wait_stream(side)
             return buf
         if halo is not None:
             halo(V)

@@ -53,8 +53,16 @@ def _worker(rank, world, port, ref_path, results):
         ref = np.load(ref_path)
         ok = True
         worst = 0.0
-        for fused in (False, True, 'phased'):
-            if fused == 'phased':
+        for fused in (False, True, 'phased', 'overlap'):
+            if fused == 'overlap':
+                # the production form of a sharded pass: Engine drives the exchange (gloo here: staged through the host)
+                # and the stream choreography -- dense kernels on the main stream, halo-dependent ones on a side stream
+                Vo = torch.zeros_like(V)
+                Vo[:eng.S] = V[:eng.S]
+                Vo[eng.S:] = float('nan')
+                buf = eng.project_and_estimate(Vo, eng.alloc_reduce_buffers(N), halo=HaloExchange(plan, N, Vo.device))
+                torch.cuda.synchronize()
+            elif fused == 'phased':
                 # the overlapped form: phase 1 must not touch the halo slabs (poisoned with NaN while it runs), phase 2
                 # runs after the exchange has filled them
                 buf = eng.alloc_reduce_buffers(N)

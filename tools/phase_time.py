@@ -1,0 +1,41 @@
+"""Times the fused pass whole vs in two phases on a bench config.  usage: phase_time.py CONFIG"""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np, torch
+import bench
+from pylrbms_amd import multiscale_problem
+from pylrbms_amd.engine import Engine
+cfg = bench.CONFIGS[sys.argv[1]]
+p = multiscale_problem.init_grid_and_problem({'num_subdomains': cfg['num_subdomains'], 'coarse_per_subdomain': cfg['coarse_per_subdomain']})
+lam = p['lambda']
+tb = np.array([c.evaluate(p['mu_bar']) for c in lam['coefficients']])
+eng = Engine(p['grid'], lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], tb).assemble()
+N = cfg['N']
+V = eng.ctx.from_numpy(bench.make_bases_host(eng.local, eng.t.n, N))
+buf = eng.alloc_reduce_buffers(N)
+args = (V, eng.F, eng.A_diag, eng.A_cpl, eng.P_diag, eng.b, eng.ebar, eng.caa, eng.Aab, eng.Bbb, buf['work'], buf['sys'], buf['grams'])
+def run(fn, n=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return 1e3 * (time.perf_counter() - t0) / n
+print('whole   ms', round(run(lambda: eng.ctx.project_estimate_fused(*args)), 4))
+print('phased  ms', round(run(lambda: (eng.ctx.project_estimate_fused(*args, phase=1), eng.ctx.project_estimate_fused(*args, phase=2))), 4))
+print('phase 1 ms', round(run(lambda: eng.ctx.project_estimate_fused(*args, phase=1)), 4))
+print('phase 2 ms', round(run(lambda: eng.ctx.project_estimate_fused(*args, phase=2)), 4))
+
+
+class _NoHalo:
+    def start(self, V):
+        return lambda: V
+
+
+print('overlap ms', round(run(lambda: eng.project_and_estimate(V, buf, halo=_NoHalo())), 4), '(stream choreography of a sharded pass, no exchange)')
+
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(200):
+    eng.ctx.project_estimate_fused(*args, phase=3)
+host = (time.perf_counter() - t0) / 200
+torch.cuda.synchronize()
+print('host time of one library call through NativeContext (phase 3, enqueue only): %.1f us' % (1e6 * host))
