@@ -1523,6 +1523,8 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // LRBMS_STREAMS=0 / 1 overrides.
   const char* env_streams = getenv("LRBMS_STREAMS");
   const bool multi = (do_a || do_b) && (env_streams ? env_streams[0] != '0' : S < 192);
+  // forked: caller's stream k_f1 | aux0 k_thin_rt, k_coupling | aux1 k_f2 | aux2 k_thin_nc, k_f3 (balanced from a kernel
+  // trace at 128 subdomains: every side chain ends before k_f1 does)
   hipStream_t s_rt = multi ? ctx->aux[0] : st, s_f23 = multi ? ctx->aux[1] : st, s_nc = multi ? ctx->aux[2] : st;
   hipStream_t side = s_nc;
   if (multi) {
@@ -1628,10 +1630,10 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     F3Args a{V, ebar, AvgSelf, AvgSide, G_nc, N, S};
     const int ntx = (N + 15) / 16;
     switch (ntx) {
-      case 1: hipLaunchKernelGGL(k_f3<1>, dim3(S), dim3(256), 0, s_f23, t, a); break;
-      case 2: hipLaunchKernelGGL(k_f3<2>, dim3(S), dim3(256), 0, s_f23, t, a); break;
-      case 3: hipLaunchKernelGGL(k_f3<3>, dim3(S), dim3(256), 0, s_f23, t, a); break;
-      default: hipLaunchKernelGGL(k_f3<4>, dim3(S), dim3(256), 0, s_f23, t, a); break;
+      case 1: hipLaunchKernelGGL(k_f3<1>, dim3(S), dim3(256), 0, s_nc, t, a); break;
+      case 2: hipLaunchKernelGGL(k_f3<2>, dim3(S), dim3(256), 0, s_nc, t, a); break;
+      case 3: hipLaunchKernelGGL(k_f3<3>, dim3(S), dim3(256), 0, s_nc, t, a); break;
+      default: hipLaunchKernelGGL(k_f3<4>, dim3(S), dim3(256), 0, s_nc, t, a); break;
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
@@ -1639,10 +1641,10 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     const int ntx = (N + 15) / 16;
     const size_t ldsc = sizeof(double) * 2 * (size_t)((3 * t.ncf + 3) & ~3) * padded_ld(ntx);
     switch (ntx) {
-      case 1: hipLaunchKernelGGL(k_coupling<1>, dim3(4, S), dim3(256), ldsc, s_nc, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
-      case 2: hipLaunchKernelGGL(k_coupling<2>, dim3(4, S), dim3(256), ldsc, s_nc, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
-      case 3: hipLaunchKernelGGL(k_coupling<3>, dim3(4, S), dim3(256), ldsc, s_nc, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
-      default: hipLaunchKernelGGL(k_coupling<4>, dim3(4, S), dim3(256), ldsc, s_nc, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
+      case 1: hipLaunchKernelGGL(k_coupling<1>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
+      case 2: hipLaunchKernelGGL(k_coupling<2>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
+      case 3: hipLaunchKernelGGL(k_coupling<3>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
+      default: hipLaunchKernelGGL(k_coupling<4>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
