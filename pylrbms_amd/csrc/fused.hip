@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
       for (int i = 0; i < RT; ++i) {
         if (r0 + i < QN) {
           const long o = (long)(r0 + i) * QN + cc;
-          Gb_aa[o] = vb[i];
+          Gb_aa[o] = vb[i];   // (non-temporal stores measured: no difference)
           Gd_aa[o] = vd[i];
           Gb_as[o] = wb[i];
           Gd_as[o] = wd[i];
