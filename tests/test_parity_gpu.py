@@ -44,6 +44,9 @@ def _problems():
         # BASELINE.json config 2 geometry (k_c = 4, N = 20) on a smaller subdomain grid
         'multiscale_4x3_kc4_N20': (lambda: multiscale_problem.init_grid_and_problem(
             {'num_subdomains': [4, 3], 'coarse_per_subdomain': 4}), 20, 0.7),
+        # the widest supported basis (N = 64, QN = 128): k_f1 needs two column slices -> its generic (runtime-Q) producer
+        'multiscale_2x2_kc4_N64': (lambda: multiscale_problem.init_grid_and_problem(
+            {'num_subdomains': [2, 2], 'coarse_per_subdomain': 4}), 64, 0.8),
         # a larger template (n = 864, 24 touching elements per side) through the same fused kernels
         'multiscale_2x2_kc6_N24': (lambda: multiscale_problem.init_grid_and_problem(
             {'num_subdomains': [2, 2], 'coarse_per_subdomain': 6}), 24, 0.45),
