@@ -5,6 +5,8 @@
 // block-Jacobi preconditioned CG; the matrix (S x 5 blocks of N x N) is assembled once per mu and then lives in
 // the Infinity Cache for the iteration.  All reductions are fixed-order trees (no fp64 atomics) so that results are
 // bitwise reproducible run to run.
+#include <cstdlib>
+
 #include "lrbms_dev.h"
 
 struct QVec { double v[8]; };
@@ -425,6 +427,104 @@ __global__ __launch_bounds__(256) void k_bcg_matvec(int S, const int* __restrict
   (void)red;
 }
 
+// The same step on the fp64 matrix cores, for batches of at most 16 parameters (the panel is padded to 16 columns):
+// y_s (N x 16) = sum_{slot, q} B_q[s][slot] (N x N) * (P_slot diag(theta_q)) (N x 16).  Wave w owns row tile w.  Each
+// block is staged once into LDS with coalesced loads (the next block's loads are issued before the MFMAs of the current
+// one), and read from there as MFMA A operand: 1 LDS read per MFMA, where the VALU form above reads two LDS operands
+// per multiply-add and is bound by the LDS pipe (78 us per iteration at config 3 for 131 MB of blocks; this form:
+// 766 -> 968 mu-solves/s).  (Folding the two single-workgroup reductions of an iteration into the producing kernels
+// with a "last workgroup reduces" ticket was measured too: the device-scope fences it needs cost far more on this
+// multi-XCD part than the two launches they save: 348 mu-solves/s.)
+typedef double d4m __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_bcg_matvec_mfma(int S, const int* __restrict__ nbr, int Q, int N, int nmu, ThetaBatch th,
+                                                         const double* __restrict__ B_sys, const double* __restrict__ z,
+                                                         const double* __restrict__ p_old, const double* __restrict__ beta,
+                                                         int first, double* __restrict__ p_out, double* __restrict__ y,
+                                                         double* __restrict__ partial) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = tid >> 6;
+  const int NM = N * nmu;
+  const int KP = (N + 3) & ~3;                         // K padded to a multiple of 4 (zero rows / columns)
+  const int LDB = N + ((4 - N % 8) + 8) % 8;           // row stride == 4 (mod 8) doubles: conflict-free A-operand reads
+  const int NR = (N + 15) & ~15;                       // rows padded to whole tiles (zero rows)
+  double* Pt = lds;                                    // [5][KP][16]
+  double* Bs = Pt + 5 * KP * 16;                       // [NR][LDB]
+  double* prod = Bs + NR * LDB;                        // [N][16]
+  for (int i = tid; i < 5 * KP * 16; i += 256) {
+    const int slot = i / (KP * 16), rem = i - slot * KP * 16, c = rem >> 4, m = rem & 15;
+    const int s2 = nbr[s * 5 + slot];
+    double v = 0.0;
+    if (s2 >= 0 && c < N && m < nmu) {
+      const long g = (long)s2 * NM + c * nmu + m;
+      v = first ? z[g] : z[g] + beta[m] * p_old[g];
+      if (slot == 2) p_out[g] = v;
+    }
+    Pt[i] = v;
+  }
+  for (int i = tid; i < NR * LDB; i += 256) Bs[i] = 0.0;
+  double thq[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) thq[q] = li < nmu ? th.v[li * 8 + q] : 0.0;
+  // block list of this subdomain: (slot, q) for every existing neighbour slot; register prefetch of the next block
+  constexpr int PF = 16;                               // N * N <= 4096 = 256 threads x 16
+  double pf[PF];
+  auto load_block = [&](int slot, int q) {
+    const double* B = B_sys + ((((long)q * S + s) * 5 + slot) * N) * N;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int i = tid + 256 * k;
+      pf[k] = i < N * N ? B[i] : 0.0;
+    }
+  };
+  int slots[5], ns = 0;
+  for (int slot = 0; slot < 5; ++slot)
+    if (nbr[s * 5 + slot] >= 0) slots[ns++] = slot;
+  const int nblk = ns * Q;
+  d4m acc = (d4m){0.0, 0.0, 0.0, 0.0};
+  const bool active = wave * 16 < N;                   // this wave's row tile exists
+  if (nblk > 0) load_block(slots[0], 0);
+  for (int b = 0; b < nblk; ++b) {
+    const int slot = slots[b / Q], q = b - (b / Q) * Q;
+    __syncthreads();                                   // previous block's MFMAs are done reading Bs (and Pt is complete)
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int i = tid + 256 * k;
+      if (i < N * N) Bs[(i / N) * LDB + i % N] = pf[k];
+    }
+    if (b + 1 < nblk) load_block(slots[(b + 1) / Q], (b + 1) - ((b + 1) / Q) * Q);
+    __syncthreads();
+    if (active) {
+      const double* pslot = Pt + slot * KP * 16;
+      double thv = thq[0];
+#pragma unroll
+      for (int qq = 1; qq < 8; ++qq)
+        if (q == qq) thv = thq[qq];
+      for (int kk = 0; kk < KP; kk += 4) {
+        const double a = Bs[(wave * 16 + li) * LDB + kk + lk];
+        const double bv = thv * pslot[(kk + lk) * 16 + li];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  // D layout: lane holds rows lk + 4 r of its tile, column li
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = wave * 16 + lk + 4 * r;
+    if (active && row < N && li < nmu) {
+      y[(long)s * NM + row * nmu + li] = acc[r];
+      prod[row * 16 + li] = acc[r] * Pt[2 * KP * 16 + row * 16 + li];
+    }
+  }
+  __syncthreads();
+  if (tid < nmu) {
+    double sum = 0.0;
+    for (int r = 0; r < N; ++r) sum += prod[r * 16 + tid];
+    partial[(long)s * nmu + tid] = sum;
+  }
+}
+
 // out[m] = sum_s partial[s][m]; mode 1: pAp -> alpha = rz / pAp; mode 2: rz_new -> beta = rz_new / rz, rz = rz_new;
 // mode 0: rz (initial).  scal layout: rz [BMAX], alpha [BMAX], beta [BMAX], rr [BMAX]
 __global__ __launch_bounds__(1024) void k_bcg_reduce(int S, int nmu, const double* __restrict__ partial,
@@ -544,6 +644,12 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
                      rhs_red, u, r);
   LRBMS_LAUNCH_CHECK(ctx);
   const size_t lds_upd = sizeof(double) * 3 * NM;
+  // matrix-core form for batches of at most 16 parameters (LRBMS_BCG_VALU=1 forces the VALU form)
+  const int kp = (N + 3) & ~3, ldb = N + ((4 - N % 8) + 8) % 8, nrp = (N + 15) & ~15;
+  const size_t lds_mfma = sizeof(double) * ((size_t)5 * kp * 16 + (size_t)nrp * ldb + (size_t)N * 16);
+  const bool use_mfma = nmu <= 16 && getenv("LRBMS_BCG_VALU") == nullptr;
+  if (use_mfma && lds_mfma > 64 * 1024)
+    LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
   const size_t lds_mv = sizeof(double) * (5 * NM + (size_t)N * N + 256);
   if (lds_mv > 64 * 1024)
     LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec<BCG_KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mv));
@@ -570,7 +676,10 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   double* pout = p1;
   while (it < max_iter) {
     for (int k = 0; k < check_every && it < max_iter; ++k, ++it) {
-      if (NM <= 768)   // three outputs per thread: fewer registers, measurably faster for the usual batch of 16
+      if (use_mfma)
+        hipLaunchKernelGGL(k_bcg_matvec_mfma, dim3(S), dim3(256), lds_mfma, st, S, ctx->nbr, Q, N, nmu, th, B_sys, z, pin,
+                           scal + 2 * BMAX, it == 0 ? 1 : 0, pout, y, partial);
+      else if (NM <= 768)   // three outputs per thread: fewer registers, measurably faster for the usual batch of 16
         hipLaunchKernelGGL(k_bcg_matvec<3>, dim3(S), dim3(256), lds_mv, st, S, ctx->nbr, Q, N, nmu, th, B_sys, z, pin,
                            scal + 2 * BMAX, it == 0 ? 1 : 0, pout, y, partial);
       else
