@@ -1,5 +1,5 @@
 """Sum FETCH_SIZE / WRITE_SIZE (rocprofv3 --pmc, KiB units) over the kernels of the passes of bench.py.
-usage: pmc_traffic.py NUM_PASSES DIR [DIR...]"""
+usage: pmc_traffic.py NUM_PASSES DIR [DIR...]   (NUM_PASSES is ignored: per-call averages are summed)"""
 import collections
 import csv
 import glob
@@ -19,13 +19,14 @@ for d in sys.argv[2:]:
             calls[(k, r['Counter_Name'])] += 1
 print('{:24s} {:>6s} {:>18s} {:>18s}'.format('kernel', 'calls', 'FETCH_SIZE MiB/call', 'WRITE_SIZE MiB/call'))
 sf = sw = 0.0
+PASS_KERNELS = ('k_flux_compact', 'k_vertex_avg', 'k_f1', 'k_f2', 'k_f3', 'k_thin_nc', 'k_thin_rt', 'k_coupling', 'k_project_coupling')
 for k, v in sorted(tot.items()):
     nf, nw = calls[(k, 'FETCH_SIZE')], calls[(k, 'WRITE_SIZE')]
     f = v.get('FETCH_SIZE', 0.0) / nf / 1024 if nf else 0.0
     w = v.get('WRITE_SIZE', 0.0) / nw / 1024 if nw else 0.0
     print('{:24s} {:6d} {:18.1f} {:18.1f}'.format(k, max(nf, nw), f, w))
-    if k.startswith('k_') and not k.startswith('k_assemble'):
-        sf += v.get('FETCH_SIZE', 0.0) / 1024 / passes
-        sw += v.get('WRITE_SIZE', 0.0) / 1024 / passes
+    if k in PASS_KERNELS:        # one call of each per pass: sum the per-call averages (bench.py also times phase 4 alone)
+        sf += f
+        sw += w
 print('per pass (hot-path kernels): FETCH_SIZE {:.1f} MiB (x2 correction for wide coalesced reads on gfx950: {:.1f} MiB), '
       'WRITE_SIZE {:.1f} MiB'.format(sf, 2 * sf, sw))
