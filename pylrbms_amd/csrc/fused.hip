@@ -356,9 +356,9 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     //  * all loads of an element are a prefetch set issued one chunk ahead as asm loads and completed by an explicit
     //    s_waitcnt vmcnt(NLOADS) (see gload_f64).
     constexpr int R = 3 * (QP + 1);
-    constexpr int NLOADS = 3 + 3 * NTX + 3 + 3 * QP + 1;
+    constexpr int NLOADS = 3 + 3 * NTX + 3 * QP + 1;
     struct Set {
-      double A[3], B[3][NTX], v0[3], rv[3][QP], ab;
+      double A[3], B[3][NTX], rv[3][QP], ab;   // the element's own rows are B[0][.] of the lanes kq < 3
     };
     const bool do_rhs = a.rhs_red != nullptr && blockIdx.y == 0;
     const double* Vs = a.V + (long)s * t.n * N;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
     const int jc = colj ? j : N - 1;   // idle lanes load (and never use) the last column: no exec masking around loads
     const int r16 = lane & 15, kq = lane >> 4;
     const double* asrc[3];
-    int bbk[3], ck[3], colB[NTX], yoff[3];
+    int bbk[3], ck[3], colB[NTX], doff[3][NTX];
     {
       const int g = r16 / 3 < QP + 1 ? r16 / 3 : QP, i = r16 % 3;   // rows >= R repeat a valid row; they are never stored
 #pragma unroll
@@ -381,9 +381,12 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
 #pragma unroll
       for (int ct = 0; ct < NTX; ++ct) colB[ct] = 16 * ct + r16 < N ? 16 * ct + r16 : N - 1;
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr) {           // LDS offset of output row kq + 4 rr (group r / 3, local row r % 3), or -1
-        const int r = kq + 4 * rr;
-        yoff[rr] = r < R ? (3 * wave + r % 3) * LDY + (r / 3) * N : -1;
+      for (int rr = 0; rr < 3; ++rr) {           // LDS offset of output (row kq + 4 rr, column 16 ct + r16): group r / 3,
+        const int r = kq + 4 * rr;               // local row r % 3 -- or a dump slot in the row padding (columns >= 448 are
+#pragma unroll                                   // never read), so that the stores need no exec masking
+        for (int ct = 0; ct < NTX; ++ct)
+          doff[rr][ct] = (r < R && 16 * ct + r16 < N) ? (3 * wave + r % 3) * LDY + (r / 3) * N + 16 * ct + r16
+                                                       : (3 * wave) * LDY + 4 * NTY * 16 + r16;
       }
     }
     const double* absrc = a.Aab + (long)s * t.nT * 9;   // lanes beyond the record re-read its first entry
@@ -417,8 +420,6 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
         for (int ct = 0; ct < NTX; ++ct) x.B[ks][ct] = gload_f64(rowp + colB[ct]);
       }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) x.v0[i] = gload_f64(Vs + (long)(3 * T + i) * N + jc);
-#pragma unroll
       for (int f = 0; f < 3; ++f)
 #pragma unroll
         for (int q2 = 0; q2 < QP; ++q2) x.rv[f][q2] = gload_f64(Rs + (long)rtT[f] * QN + q2 * N + jc);
@@ -431,7 +432,6 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
         tie(x.A[ks]);
 #pragma unroll
         for (int ct = 0; ct < NTX; ++ct) tie(x.B[ks][ct]);
-        tie(x.v0[ks]);
 #pragma unroll
         for (int q2 = 0; q2 < QP; ++q2) tie(x.rv[ks][q2]);
       }
@@ -469,25 +469,32 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
       for (int ct = 0; ct < NTX; ++ct)
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
-          if (yoff[rr] >= 0 && 16 * ct + r16 < N) Yb[yoff[rr] + 16 * ct + r16] = D[ct][rr];
+          Yb[doff[rr][ct]] = D[ct][rr];
 #endif
-      // ---- the rest on the VALU, lanes = basis columns
+      // ---- X rows: the own rows sit in the B operand of k-step 0 (lanes kq < 3 hold row kq); the padding columns
+      // N .. 16 NTX - 1 get the clamped last column: they only reach output rows >= N, which are never stored
+      if (kq < 3) {
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) Xb[(3 * wave + kq) * LDX + 16 * ct + r16] = cur.B[0][ct];
+      }
+      // ---- the rest on the VALU, lanes = basis columns (own rows re-read from LDS in that layout)
 #ifdef F1_NO_VALU_STAGE
       if (false) {
 #else
       if (colj) {
 #endif
+        double v0[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) Xb[(3 * wave + i) * LDX + j] = cur.v0[i];
+        for (int i = 0; i < 3; ++i) v0[i] = Xb[(3 * wave + i) * LDX + j];
         if (do_rhs) {   // b_T through the scalar unit (lgkmcnt)
           const cdbl_p be = (cdbl_p)(a.b + (long)s * t.n + 3 * T);
-          rhs_part += be[0] * cur.v0[0] + be[1] * cur.v0[1] + be[2] * cur.v0[2];
+          rhs_part += be[0] * v0[0] + be[1] * v0[1] + be[2] * v0[2];
         }
         double kv[3];
         const double* K = Kl + T * 9;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-          kv[i] = __builtin_fma(K[i * 3 + 2], cur.v0[2], __builtin_fma(K[i * 3 + 1], cur.v0[1], K[i * 3] * cur.v0[0]));
+          kv[i] = __builtin_fma(K[i * 3 + 2], v0[2], __builtin_fma(K[i * 3 + 1], v0[1], K[i * 3] * v0[0]));
         int g = QP + 1;
         auto put = [&](const double (&y)[3]) {
 #pragma unroll
@@ -495,8 +502,8 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
           ++g;
         };
         {
-          const double m = ((cdbl_p)t.area)[T] * (1.0 / 12.0), sum = cur.v0[0] + cur.v0[1] + cur.v0[2];
-          const double y[3] = {m * (sum + cur.v0[0]), m * (sum + cur.v0[1]), m * (sum + cur.v0[2])};
+          const double m = ((cdbl_p)t.area)[T] * (1.0 / 12.0), sum = v0[0] + v0[1] + v0[2];
+          const double y[3] = {m * (sum + v0[0]), m * (sum + v0[1]), m * (sum + v0[2])};
           put(y);
         }
 #pragma unroll
