@@ -318,9 +318,11 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
   int* nbl = idx;
   int* rtl = idx + 3 * t.nT;
   double* Kl = reinterpret_cast<double*>(idx + 6 * t.nT);   // template stiffness K_T [nT][9] (same for all subdomains)
-  for (int i = tid; i < 3 * t.nT; i += 512) {
-    nbl[i] = t.nb_elem[i];
-    rtl[i] = t.elem_rt[i];
+  if (QP == 0) {   // the straight-line producer reads the adjacency through the scalar cache instead
+    for (int i = tid; i < 3 * t.nT; i += 512) {
+      nbl[i] = t.nb_elem[i];
+      rtl[i] = t.elem_rt[i];
+    }
   }
   for (int i = tid; i < 9 * t.nT; i += 512) Kl[i] = t.stiff[i];
 #ifndef F1_LDS_FILL
