@@ -820,6 +820,126 @@ __global__ __launch_bounds__(256) void k_reduced_estimate_batch(int S, const int
   }
 }
 
+// The same estimates on the fp64 matrix cores.  For every block G (R x C) of a projected operator the batch of quadratic
+// forms  x_m^T G y_m  is  sum_r x[r][m] (G Y)[r][m]:  T = G Y is a 16-column MFMA product whose A operand is loaded from
+// global memory directly in lane layout (row = lane & 15, k = lane >> 4: every entry of G is read exactly once, 8 bytes
+// per lane, four k-steps consume one 128-byte line per row), Y comes from LDS with the per-parameter weights folded in,
+// and each lane finishes with four multiply-adds against X.  The VALU form above needs 16 LDS operands per loaded entry
+// and runs at 15 % of the HBM rate this kernel is bound by.
+__device__ inline void quad_mfma(const double* __restrict__ G, int ld, int R, int C, const double* X, const double* Y, double wl,
+                                 double& acc) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, wave = threadIdx.x >> 6;
+  const int ntile = (R + 15) >> 4;
+  for (int tile = wave; tile < ntile; tile += 4) {
+    const int ra = tile * 16 + li < R ? tile * 16 + li : R - 1;           // rows >= R repeat the last row (their X is 0)
+    const double* grow = G + (long)ra * ld;
+    d4m T = (d4m){0.0, 0.0, 0.0, 0.0};
+    int kk = 0;
+    for (; kk + 32 <= C; kk += 32) {                                      // 8 loads in flight per lane
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = grow[kk + 4 * u + lk];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], wl * Y[(kk + 4 * u + lk) * 16 + li], T, 0, 0, 0);
+    }
+    for (; kk < C; kk += 4) {
+      const bool in = kk + lk < C;                                        // columns >= C contribute nothing
+      T = __builtin_amdgcn_mfma_f64_16x16x4f64(grow[in ? kk + lk : C - 1], in ? wl * Y[(kk + lk) * 16 + li] : 0.0, T, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = tile * 16 + lk + 4 * rr;
+      if (row < R) acc += X[row * 16 + li] * T[rr];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_reduced_estimate_batch_mfma(int S, const int* __restrict__ nbr, int Q, int N, int nmu,
+                                                                     ThetaBatch th, const double* __restrict__ u,
+                                                                     const double* __restrict__ G_nc, const double* __restrict__ r_fd,
+                                                                     const double* __restrict__ G_rdd, const double* __restrict__ G_bb,
+                                                                     const double* __restrict__ G_ab, const double* __restrict__ G_aa,
+                                                                     const double* __restrict__ f2, const double* __restrict__ ceps,
+                                                                     double hdiam, double* __restrict__ eta_loc) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, wave = tid >> 6;
+  const int W = 5 * N, QN = Q * N, C = 5 * QN;
+  const int Wp = (W + 3) & ~3, Cp = (C + 3) & ~3;
+  double* uo = lds;                 // [Wp][16]  coefficients of the own + neighbour bases (columns >= nmu and pad rows zero)
+  double* ur = uo + Wp * 16;        // [Cp][16]  theta_q(mu_m) * coefficient, row order (slot, q, j)
+  double* red = ur + Cp * 16;       // [4][3][16]
+  for (int i = tid; i < (Wp + Cp) * 16; i += 256) lds[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < W * nmu; i += 256) {
+    const int row = i / nmu, m = i - row * nmu, slot = row / N, j = row - slot * N;
+    const int s2 = nbr[s * 5 + slot];
+    const double val = s2 >= 0 ? u[((long)s2 * N + j) * nmu + m] : 0.0;
+    uo[row * 16 + m] = val;
+    for (int q = 0; q < Q; ++q) ur[((slot * Q + q) * N + j) * 16 + m] = th.v[m * 8 + q] * val;
+  }
+  __syncthreads();
+  double thl[8];                    // theta_q of this lane's parameter
+#pragma unroll
+  for (int q = 0; q < 8; ++q) thl[q] = li < nmu ? th.v[li * 8 + q] : 0.0;
+  double a_nc = 0.0, a_r = 0.0, a_df = 0.0;
+  const double* ui = uo + 2 * N * 16;
+  const double* zs = ur + 2 * QN * 16;
+  quad_mfma(G_nc + (long)s * W * W, W, W, W, uo, uo, 1.0, a_nc);
+  const double* Gd = G_rdd + (long)s * 9 * QN * QN;
+  const double* Gb = G_bb + (long)s * 9 * QN * QN;
+  quad_mfma(Gd, QN, QN, QN, zs, zs, 1.0, a_r);
+  quad_mfma(Gb, QN, QN, QN, zs, zs, 1.0, a_df);
+  for (int side = 0; side < 4; ++side) {
+    const double* za = ur + (side < 2 ? side : side + 1) * QN * 16;
+    quad_mfma(Gd + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, 2.0, a_r);
+    quad_mfma(Gd + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, 1.0, a_r);
+    quad_mfma(Gb + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, 2.0, a_df);
+    quad_mfma(Gb + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, 1.0, a_df);
+  }
+  // - 2 r_fd . ur: lanes over (16 rows of c) x parameter
+  for (int c = wave * 4 + (lane >> 4); c < C; c += 16) a_r -= 2.0 * r_fd[(long)s * C + c] * ur[c * 16 + li];
+  for (int q = 0; q < Q; ++q) {
+    double tq = thl[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+      if (q == k) tq = thl[k];
+    quad_mfma(G_ab + ((long)q * S + s) * N * C, C, N, C, ui, ur, 2.0 * tq, a_df);
+    for (int q2 = 0; q2 < Q; ++q2) {
+      double tq2 = thl[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k)
+        if (q2 == k) tq2 = thl[k];
+      quad_mfma(G_aa + (((long)q * Q + q2) * S + s) * N * N, N, N, N, ui, ui, tq * tq2, a_df);
+    }
+  }
+  // fixed-order reductions: the four k-groups of a wave by shuffles (lanes li, li + 16, li + 32, li + 48 share a
+  // parameter), then the 4 waves through LDS
+  for (int off = 32; off >= 16; off >>= 1) {
+    a_nc += __shfl_down(a_nc, off, 64);
+    a_r += __shfl_down(a_r, off, 64);
+    a_df += __shfl_down(a_df, off, 64);
+  }
+  if (lane < 16) {
+    red[(wave * 3 + 0) * 16 + lane] = a_nc;
+    red[(wave * 3 + 1) * 16 + lane] = a_r;
+    red[(wave * 3 + 2) * 16 + lane] = a_df;
+  }
+  __syncthreads();
+  if (tid < nmu) {
+    const double pi = 3.14159265358979323846;
+    double nc = 0.0, rr = 0.0, df = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      nc += red[(w * 3 + 0) * 16 + tid];
+      rr += red[(w * 3 + 1) * 16 + tid];
+      df += red[(w * 3 + 2) * 16 + tid];
+    }
+    eta_loc[((long)0 * S + s) * nmu + tid] = nc;
+    eta_loc[((long)1 * S + s) * nmu + tid] = (f2[s] + rr) * ((1.0 / (pi * pi)) / ceps[s]) * hdiam * hdiam;   // estimators.py:88-91
+    eta_loc[((long)2 * S + s) * nmu + tid] = df;
+  }
+}
+
 }  // namespace
 
 int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const double* theta, const double* u, const double* G_nc,
@@ -832,6 +952,17 @@ int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const d
   ThetaBatch th;
   for (int m = 0; m < BMAX; ++m)
     for (int q = 0; q < 8; ++q) th.v[m * 8 + q] = (m < nmu && q < Q) ? theta[m * Q + q] : 0.0;
+  if (getenv("LRBMS_EST_VALU") == nullptr) {   // matrix-core form (default)
+    const size_t ldm = sizeof(double) * ((size_t)(((5 * N + 3) & ~3) + ((5 * Q * N + 3) & ~3)) * 16 + 4 * 3 * 16);
+    if (ldm > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
+    if (ldm > 64 * 1024)
+      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)ldm));
+    hipLaunchKernelGGL(k_reduced_estimate_batch_mfma, dim3(ctx->S), dim3(256), ldm, st, ctx->S, ctx->nbr, Q, N, nmu, th, u, G_nc, r_fd,
+                       G_rdd, G_bb, G_ab, G_aa, f2, ceps, hdiam, eta_loc);
+    LRBMS_LAUNCH_CHECK(ctx);
+    return LRBMS_OK;
+  }
   if (lds > 64 * 1024)
     LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_reduced_estimate_batch, dim3(ctx->S), dim3(256), lds, st, ctx->S, ctx->nbr, Q, N, nmu, th, u, G_nc, r_fd, G_rdd,
