@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_bcg_matvec(int S, const int* __restrict
   if (tid < nmu) {
     double sum = 0.0;
     for (int r = 0; r < N; ++r) sum += Pt[r * nmu + tid];
-    partial[(long)s * nmu + tid] = sum;
+    partial[(long)tid * gridDim.x + s] = sum;          // [m][S]: the reduce reads contiguous runs
   }
   (void)red;
 }
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void k_bcg_matvec_mfma(int S, const int* __res
   if (tid < nmu) {
     double sum = 0.0;
     for (int r = 0; r < N; ++r) sum += prod[r * 16 + tid];
-    partial[(long)s * nmu + tid] = sum;
+    partial[(long)tid * gridDim.x + s] = sum;          // [m][S]: the reduce reads contiguous runs
   }
 }
 
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(1024) void k_bcg_reduce(int S, int nmu, const doubl
   for (int m = threadIdx.x >> 6; m < nmu; m += nw) {       // wave m sums parameter m: lane-strided, then a fixed shuffle tree
     double a = 0.0, b = 0.0;
     for (int i = lane; i < S; i += 64) {
-      a += partial[(long)i * nmu + m];
-      if (partial2) b += partial2[(long)i * nmu + m];
+      a += partial[(long)m * S + i];
+      if (partial2) b += partial2[(long)m * S + i];
     }
     for (int off = 32; off > 0; off >>= 1) {
       a += __shfl_down(a, off, 64);
@@ -589,8 +589,8 @@ __global__ __launch_bounds__(256) void k_bcg_update(int N, int nmu, const double
       a += prod[row * nmu + tid];
       b += prod[NM + row * nmu + tid];
     }
-    partial[(long)s * nmu + tid] = a;
-    partial2[(long)s * nmu + tid] = b;
+    partial[(long)tid * gridDim.x + s] = a;            // [m][S]
+    partial2[(long)tid * gridDim.x + s] = b;
   }
 }
 
