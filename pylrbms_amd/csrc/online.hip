@@ -594,6 +594,61 @@ __global__ __launch_bounds__(256) void k_bcg_update(int N, int nmu, const double
   }
 }
 
+// The same update with z = Dinv r as a 16-column MFMA product (batches of at most 16 parameters): wave w owns row tile w,
+// the inverse diagonal block is the A operand straight from global memory, r (padded to 16 columns) the B operand in LDS.
+__global__ __launch_bounds__(256) void k_bcg_update_mfma(int N, int nmu, const double* __restrict__ Dinv, const double* __restrict__ scal,
+                                                         int first, double* __restrict__ x, double* __restrict__ r,
+                                                         const double* __restrict__ p, const double* __restrict__ y,
+                                                         double* __restrict__ z, double* __restrict__ partial,
+                                                         double* __restrict__ partial2) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4, wave = tid >> 6;
+  const int NM = N * nmu, KP = (N + 3) & ~3;
+  double* rs = lds;              // [KP][16]  (columns >= nmu and rows >= N zero)
+  double* prod = rs + KP * 16;   // [2][N][16]
+  for (int i = tid; i < KP * 16; i += 256) rs[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < NM; i += 256) {
+    const long g = (long)s * NM + i;
+    const int row = i / nmu, m = i - row * nmu;
+    const double alpha = first ? 0.0 : scal[BMAX + m];
+    if (!first) x[g] += alpha * p[g];
+    const double rv = first ? r[g] : r[g] - alpha * y[g];
+    r[g] = rv;
+    rs[row * 16 + m] = rv;
+  }
+  __syncthreads();
+  if (wave * 16 < N) {
+    const int ra = wave * 16 + li < N ? wave * 16 + li : N - 1;
+    const double* D = Dinv + ((long)s * N + ra) * N;
+    d4m T = (d4m){0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < KP; kk += 4) {
+      const bool in = kk + lk < N;
+      T = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? D[kk + lk] : 0.0, rs[(kk + lk) * 16 + li], T, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = wave * 16 + lk + 4 * rr;
+      if (row < N) {
+        const double rv = rs[row * 16 + li];
+        if (li < nmu) z[(long)s * NM + row * nmu + li] = T[rr];
+        prod[row * 16 + li] = T[rr] * rv;
+        prod[(N + row) * 16 + li] = rv * rv;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < nmu) {
+    double a = 0.0, b = 0.0;
+    for (int row = 0; row < N; ++row) {
+      a += prod[row * 16 + tid];
+      b += prod[(N + row) * 16 + tid];
+    }
+    partial[(long)tid * gridDim.x + s] = a;
+    partial2[(long)tid * gridDim.x + s] = b;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_bcg_init(long total, int nmu, const double* __restrict__ rhs, double* __restrict__ x,
                                                   double* __restrict__ r) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -653,7 +708,11 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   const size_t lds_mv = sizeof(double) * (5 * NM + (size_t)N * N + 256);
   if (lds_mv > 64 * 1024)
     LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec<BCG_KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mv));
-  hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, st, N, nmu, Dinv, scal, 1, u, r, p0, y, z, partial, partial2);
+  const size_t lds_upd_mfma = sizeof(double) * ((size_t)kp * 16 + (size_t)2 * N * 16);
+  if (use_mfma)
+    hipLaunchKernelGGL(k_bcg_update_mfma, dim3(S), dim3(256), lds_upd_mfma, st, N, nmu, Dinv, scal, 1, u, r, p0, y, z, partial, partial2);
+  else
+    hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, st, N, nmu, Dinv, scal, 1, u, r, p0, y, z, partial, partial2);
   hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, st, S, nmu, partial, partial2, scal, 0);
   LRBMS_LAUNCH_CHECK(ctx);
   double host[4 * BMAX];
@@ -686,7 +745,11 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
         hipLaunchKernelGGL(k_bcg_matvec<BCG_KMAX>, dim3(S), dim3(256), lds_mv, st, S, ctx->nbr, Q, N, nmu, th, B_sys, z, pin,
                            scal + 2 * BMAX, it == 0 ? 1 : 0, pout, y, partial);
       hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, st, S, nmu, partial, (const double*)nullptr, scal, 1);
-      hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, st, N, nmu, Dinv, scal, 0, u, r, pout, y, z, partial, partial2);
+      if (use_mfma)
+        hipLaunchKernelGGL(k_bcg_update_mfma, dim3(S), dim3(256), lds_upd_mfma, st, N, nmu, Dinv, scal, 0, u, r, pout, y, z, partial,
+                           partial2);
+      else
+        hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, st, N, nmu, Dinv, scal, 0, u, r, pout, y, z, partial, partial2);
       hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, st, S, nmu, partial, partial2, scal, 2);
       double* tmp = pin; pin = pout; pout = tmp;
     }
