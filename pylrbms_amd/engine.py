@@ -104,16 +104,27 @@ class Engine:
         return self
 
     # ------------------------------------------------------------------ timed region: K7 + K8 + P1 + P2
-    def alloc_reduce_buffers(self, N):
-        c, S, Q, n, n_rt = self.ctx, self.S, self.Q, self.t.n, self.t.n_rt
+    def alloc_outputs(self, N):
+        """The projected system and the projected estimator operators of one pass (3.3 GB at config 3)."""
+        c, S, Q = self.ctx, self.S, self.Q
         W, C = 5 * N, 5 * Q * N
-        work = c.empty(max(c.estimator_work_size(Q, N), Q * S * n * N, c.fused_work_size(Q, N)))
         return {
-            'N': N, 'Wt': c.empty(S, n, W), 'Rt': c.empty(S, n_rt, C), 'work': work,
             'sys': (c.empty(Q, S, 5, N, N), c.empty(S, N), c.empty(S, N, N), c.empty(S, N, N)),
             'grams': (c.empty(S, W, W), c.empty(S, C), c.empty(S, 9, Q * N, Q * N), c.empty(S, 9, Q * N, Q * N), c.empty(Q, S, N, C),
                       c.empty(Q, Q, S, N, N)),
         }
+
+    def alloc_reduce_buffers(self, N, images=None):
+        """Outputs + scratch of ``project_and_estimate``.  The padded image bases ``Wt`` / ``Rt`` (1.3 GB at config 3) are
+        only materialised by the unfused kernels: ``images=None`` allocates them iff the fused pass cannot run."""
+        c, S, Q, n, n_rt = self.ctx, self.S, self.Q, self.t.n, self.t.n_rt
+        W, C = 5 * N, 5 * Q * N
+        if images is None:
+            images = not c.fused_supported(Q, N)
+        work = c.empty(max(c.estimator_work_size(Q, N), Q * S * n * N, c.fused_work_size(Q, N)))
+        buf = {'N': N, 'Wt': c.empty(S, n, W) if images else None, 'Rt': c.empty(S, n_rt, C) if images else None, 'work': work}
+        buf.update(self.alloc_outputs(N))
+        return buf
 
     def project_and_estimate(self, V, buffers=None, project_system=True, fused=None, halo=None):
         """One pass of the hot path over all local subdomains.  ``V`` [S_ext, n, N] must already hold the halo -- or
@@ -153,6 +164,9 @@ class Engine:
             return buf
         if halo is not None:
             halo(V)
+        if buf.get('Wt') is None:      # the unfused kernels materialise the image bases
+            buf['Wt'] = c.empty(self.S, self.t.n, 5 * N)
+            buf['Rt'] = c.empty(self.S, self.t.n_rt, 5 * self.Q * N)
         c.oswald_apply(V, out=buf['Wt'])
         c.flux_reconstruct(self.F, V, out=buf['Rt'])
         if project_system:

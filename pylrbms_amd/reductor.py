@@ -31,8 +31,8 @@ class ReducedDiscretization:
         import torch
         self.reductor, self.d, self.N = reductor, reductor.d, N
         eng = self.d.engine
-        self.B_sys, self.rhs_red, self.E_red, self.M_red = (x.clone() for x in buffers['sys'])
-        self.grams = tuple(x.clone() for x in buffers['grams'])
+        self.B_sys, self.rhs_red, self.E_red, self.M_red = buffers['sys']      # owned by this reduced model (no copies:
+        self.grams = tuple(buffers['grams'])                                    # the reductor allocates fresh outputs)
         self.estimator = self.d.estimator
         self.parameter_space = self.d.parameter_space
 
@@ -267,10 +267,24 @@ class LRBMSReductor:
         N = self.basis_size()
         V = d._with_halo(self._V)
         if getattr(self, '_buffers', None) is None or self._buffers['N'] != N:
-            self._buffers = eng.alloc_reduce_buffers(N)
-        buf = eng.project_and_estimate(V, self._buffers)
-        self._image_bases = {'OI': buf['Wt'], 'RT': buf['Rt']}          # target-major image bases (device tensors)
+            self._buffers = eng.alloc_reduce_buffers(N)                   # scratch (and image bases if unfused): reused
+        buf = dict(self._buffers)
+        buf.update(eng.alloc_outputs(N))                                  # outputs: fresh, handed over to the reduced model
+        buf = eng.project_and_estimate(V, buf)
+        self._buffers['Wt'], self._buffers['Rt'] = buf['Wt'], buf['Rt']
+        if buf['Wt'] is not None:                                         # only the unfused kernels materialise them
+            self._image_bases = {'OI': buf['Wt'], 'RT': buf['Rt']}      # target-major image bases (device tensors)
         return ReducedDiscretization(self, buf, N)
+
+    def image_bases(self):
+        """The image bases the reference keeps as ``bases['OI_i']`` / ``bases['RT_i']`` (reductor.py:40-60), target-major:
+        ``Wt`` [S, n, 5 N], ``Rt`` [S, n_rt, 5 Q N].  The fused pass never forms them; this applies K7 / K8 on demand."""
+        eng = self.d.engine
+        V = self.d._with_halo(self._V)
+        Wt = eng.ctx.oswald_apply(V)
+        Rt = eng.ctx.flux_reconstruct(eng.F, V)
+        self._image_bases = {'OI': Wt, 'RT': Rt}
+        return self._image_bases
 
     def reconstruct(self, u):
         import torch

@@ -47,6 +47,10 @@ def _run(problem_module, config, mus, mu_test):
     assert N == 1 + len(mus)
     rd = reductor.reduce()
     assert rd.solution_space.dim == o.S * N
+    # the image bases of reductor.py:40-60 are not formed by the fused pass; they are available on demand
+    ib = reductor.image_bases()
+    assert tuple(ib['OI'].shape) == (o.S, o.n, 5 * N) and tuple(ib['RT'].shape)[0] == o.S and 'OI' in reductor.bases
+    assert bool(ib['OI'].isfinite().all()) and bool(ib['RT'].isfinite().all())
 
     # local bases are energy-orthonormal
     E = rd.E_red.cpu().numpy()
