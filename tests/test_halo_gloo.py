@@ -50,6 +50,13 @@ def _worker(rank, world, port, results, mode):
         norms = global_norms(a, 2 * a)
         want = np.sqrt(sum(s * s for s in range(grid.num_subdomains)))
         ok &= abs(float(norms[0]) - want) < 1e-12 and abs(float(norms[1]) - 2 * want) < 1e-12
+        # gather of per-subdomain rows into global order (the reduced system of a sharded run, rd.solve)
+        from pylrbms_amd.parallel import gather_subdomain_rows
+        owned = [list(mk(r).subdomains_on_rank) for r in range(world)]
+        rows = torch.tensor([[float(s), 10.0 * s] for s in local], dtype=torch.float64)
+        allrows = gather_subdomain_rows(rows, owned, grid.num_subdomains)
+        want_rows = np.array([[float(s), 10.0 * s] for s in range(grid.num_subdomains)])
+        ok &= bool(np.array_equal(allrows.numpy(), want_rows))
         results[rank] = (ok, checked)
     finally:
         dist.destroy_process_group()
