@@ -1514,10 +1514,20 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   double* Rside = Rself + (long)S * t.nrt * QN;
   double* AvgSelf = Rside + (long)S * 4 * t.ncf * QN;
   double* AvgSide = AvgSelf + (long)S * t.nv * N;
+  // Small per-rank counts (forked mode): the vertex averages are not needed by k_f1 / k_f2, only by the kernels of the
+  // library's stream 2 (k_thin_nc, k_f3) -- they run at the head of that stream, beside k_f1, instead of in front of it.
+  const char* env_streams0 = getenv("LRBMS_STREAMS");
+  const bool forked = env_streams0 ? env_streams0[0] != '0' : S < 192;
   if (do_prep) {
     hipLaunchKernelGGL(k_flux_compact, dim3(S, (t.nrt * N + 255) / 256), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
                        phase == 0 ? 1 : 0);
-    hipLaunchKernelGGL(k_vertex_avg, dim3(S, (t.nv * N + 255) / 256), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
+    hipStream_t sv = st;
+    if (forked) {
+      sv = ctx->aux[2];
+      LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
+      LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(sv, ctx->ev_fork, 0));
+    }
+    hipLaunchKernelGGL(k_vertex_avg, dim3(S, (t.nv * N + 255) / 256), dim3(256), 0, sv, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
                        phase == 0 ? 1 : 0);
   } else if (do_b) {
     hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)S * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
