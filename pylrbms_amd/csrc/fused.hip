@@ -1531,7 +1531,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
                        phase == 0 ? 1 : 0);
   } else if (do_b) {
     hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)S * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
-    hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)S * 4 * nvs * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSide);
+    // Avg_side is read by k_thin_nc only: k_vertex_side is launched on that kernel's stream, right in front of it
   }
   LRBMS_LAUNCH_CHECK(ctx);
   // fork: F2 / F3, the thin kernels and the coupling projection are independent of each other and of F1 (they all read
@@ -1613,6 +1613,8 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   }
   // ---- thin parts
   if (do_b) {
+    if (!do_prep)
+      hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)S * 4 * nvs * N)), dim3(256), 0, side, t, S, ctx->nbr, N, V, AvgSide);
     const int ntx = (N + 15) / 16;
     const size_t lds = thin_nc_lds_bytes(t, ntx);
     switch (ntx) {
