@@ -225,6 +225,37 @@ int64_t lrbms_fom_solve_work_size(lrbms_ctx* ctx);
 int lrbms_fom_solve(lrbms_ctx* ctx, int32_t Q, const double* theta, const double* A_diag, const double* A_cpl, const double* b,
                     double* work, double* x, double rtol, int32_t max_iter, double* info, void* stream);
 
+/* -- parabolic LRBMS (SURVEY.md section 8f "next" #3) --------------------------------------------------------- */
+/* InstationaryDuneDiscretization._solve (discretize_parabolic_block_swipdg.py:28-40) with pyMOR's
+ * ImplicitEulerTimeStepper(nt) (:87), mass = block L2 product (:49-59):
+ *   (M + dt A(mu)) u_{k+1} = M u_k + dt b,  k = 0 .. nt-1,  all nt steps in one call (the step operator is combined once,
+ *   every step is a warm-started CG with the kernels of lrbms_fom_solve).
+ *   theta [Q] host; U [nt+1][S][n]: U[0] = initial value (input; zero in the reference, :82), U[1..nt] written;
+ *   work: lrbms_fom_solve_work_size doubles; info (host, may be NULL): CG iterations over all steps, worst final residual
+ *   relative to |M u_k + dt b|.  LRBMS_E_NOT_CONVERGED if a step misses rtol within max_iter.  Needs S_ext == S. */
+int lrbms_fom_implicit_euler(lrbms_ctx* ctx, int32_t Q, const double* theta, double dt, int32_t nt, const double* A_diag,
+                             const double* A_cpl, const double* b, double* work, double* U, double rtol, int32_t max_iter,
+                             double* info, void* stream);
+
+/* d.l2_product.apply_inverse(Y).pairwise_dot(Y) per subdomain (time-stepping residual of ParabolicEstimator.estimate,
+ * estimators.py:146-148; r_l2_i of discretize_parabolic_block_swipdg.py:72-74 applied to M^-1 Y):
+ *   Y [S][n][L];  out [S][L] = y^T M_s^-1 y  (the P1 mass matrix is inverted element by element in closed form). */
+int lrbms_mass_inverse_norm2(lrbms_ctx* ctx, int32_t L, const double* Y, double* out, void* stream);
+
+/* The reduced counterpart of lrbms_fom_implicit_euler on the projected operators:
+ *   (M_red + dt sum_q theta_q B_sys_q) u_{k+1} = M_red u_k + dt rhs_red.
+ *   B_sys [Q][S][5][N][N], M_red [S][N][N], rhs_red [S][N] as written by the projection; U [nt+1][S][N] (U[0] input);
+ *   work: lrbms_reduced_solve_work_size doubles.  N <= 64, S_ext == S. */
+int lrbms_reduced_implicit_euler(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, double dt, int32_t nt,
+                                 const double* B_sys, const double* M_red, const double* rhs_red, double* work, double* U,
+                                 double rtol, int32_t max_iter, double* info, void* stream);
+
+/* Time-stepping residual with d = rd (estimators.py:146-148): out [L][S] = y^T M_red[s]^-1 y,
+ * y = (sum_q theta_q B_sys_q dU_l)_s, for L vectors dU [L][S][N]. */
+int64_t lrbms_reduced_time_residual_work_size(lrbms_ctx* ctx, int32_t N);
+int lrbms_reduced_time_residual(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t L, const double* theta, const double* B_sys,
+                                const double* M_red, const double* dU, double* work, double* out, void* stream);
+
 /* -- online enrichment (SURVEY.md section 8f "next" #1) ---------------------------------------------------- */
 /* Dirichlet correction blocks of the neighbourhood problems: on every coupling face of subdomain s, the boundary-form
  * diagonal block minus the inner-face block already contained in A_diag

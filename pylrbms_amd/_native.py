@@ -56,6 +56,13 @@ SIGNATURES = {
                                                  c_vp]),
     'lrbms_fom_solve_work_size': (c_i64, [c_vp]),
     'lrbms_fom_solve': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
+    'lrbms_fom_implicit_euler': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_dbl, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL,
+                                                c_vp]),
+    'lrbms_mass_inverse_norm2': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'lrbms_reduced_implicit_euler': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_dbl, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl,
+                                                    c_i32, _P_DBL, c_vp]),
+    'lrbms_reduced_time_residual_work_size': (c_i64, [c_vp, c_i32]),
+    'lrbms_reduced_time_residual': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'lrbms_assemble_dirichlet_correction': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     'lrbms_local_correction_work_size': (c_i64, [c_vp, c_i32]),
     'lrbms_local_correction_solve': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_i32, _P_I32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl,
@@ -419,6 +426,64 @@ class NativeContext:
                                       self._stream())
         self._check(rc, 'lrbms_fom_solve')
         return x, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
+
+    # ------------------------------------------------------------------ parabolic path
+    def fom_implicit_euler(self, theta, dt, nt, A_diag, A_cpl, b, U0=None, rtol=1e-12, max_iter=100000):
+        """(M + dt A(mu)) u_{k+1} = M u_k + dt b, nt steps -> (U [nt + 1, S, n], info); U0 [S, n] (default 0)."""
+        Q, S = A_diag.shape[0], self.S
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        assert th.shape == (Q,)
+        work = self.empty(int(self.lib.lrbms_fom_solve_work_size(self.handle)))
+        U = self.zeros(int(nt) + 1, S, self.n)
+        if U0 is not None:
+            U[0] = U0.reshape(S, self.n)
+        info = np.zeros(2)
+        rc = self.lib.lrbms_fom_implicit_euler(self.handle, Q, _dblp(th), float(dt), int(nt),
+                                               self._ptr(A_diag, (Q, S, self.n_T, 4, 9), 'A_diag'),
+                                               self._ptr(A_cpl, (Q, S, 4, self.ncf, 9), 'A_cpl'), self._ptr(b, (S, self.n), 'b'),
+                                               c_vp(work.data_ptr()), c_vp(U.data_ptr()), float(rtol), int(max_iter), _dblp(info),
+                                               self._stream())
+        self._check(rc, 'lrbms_fom_implicit_euler')
+        return U, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
+
+    def mass_inverse_norm2(self, Y):
+        """Y [S, n, L] -> [S, L]: y^T M^-1 y per subdomain and column."""
+        S, L = self.S, Y.shape[2]
+        out = self.empty(S, L)
+        rc = self.lib.lrbms_mass_inverse_norm2(self.handle, L, self._ptr(Y, (S, self.n, L), 'Y'), c_vp(out.data_ptr()),
+                                               self._stream())
+        self._check(rc, 'lrbms_mass_inverse_norm2')
+        return out
+
+    def reduced_implicit_euler(self, theta, dt, nt, B_sys, M_red, rhs_red, U0=None, rtol=1e-13, max_iter=20000):
+        """(M_red + dt A_red(mu)) u_{k+1} = M_red u_k + dt rhs_red -> (U [nt + 1, S, N], info)."""
+        Q, S, N = B_sys.shape[0], self.S, B_sys.shape[3]
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        assert th.shape == (Q,)
+        work = self.empty(int(self.lib.lrbms_reduced_solve_work_size(self.handle, N)))
+        U = self.zeros(int(nt) + 1, S, N)
+        if U0 is not None:
+            U[0] = U0.reshape(S, N)
+        info = np.zeros(2)
+        rc = self.lib.lrbms_reduced_implicit_euler(self.handle, Q, N, _dblp(th), float(dt), int(nt),
+                                                   self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'), self._ptr(M_red, (S, N, N), 'M_red'),
+                                                   self._ptr(rhs_red, (S, N), 'rhs_red'), c_vp(work.data_ptr()),
+                                                   c_vp(U.data_ptr()), float(rtol), int(max_iter), _dblp(info), self._stream())
+        self._check(rc, 'lrbms_reduced_implicit_euler')
+        return U, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
+
+    def reduced_time_residual(self, theta, B_sys, M_red, dU):
+        """dU [L, S, N] -> [L, S]: y^T M_red^-1 y with y = A_red(mu) dU_l."""
+        Q, S, N, L = B_sys.shape[0], self.S, B_sys.shape[3], dU.shape[0]
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        assert th.shape == (Q,)
+        work = self.empty(int(self.lib.lrbms_reduced_time_residual_work_size(self.handle, N)))
+        out = self.empty(L, S)
+        rc = self.lib.lrbms_reduced_time_residual(self.handle, Q, N, L, _dblp(th), self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'),
+                                                  self._ptr(M_red, (S, N, N), 'M_red'), self._ptr(dU, (L, S, N), 'dU'),
+                                                  c_vp(work.data_ptr()), c_vp(out.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_reduced_time_residual')
+        return out
 
     # ------------------------------------------------------------------ online enrichment
     def assemble_dirichlet_correction(self, lam):

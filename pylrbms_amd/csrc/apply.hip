@@ -193,6 +193,24 @@ __global__ __launch_bounds__(256) void k_elemdiag_apply(Tmpl t, int S, int M, in
   }
 }
 
+// out[s][c] = y_s^T M_s^{-1} y_s for column c of Y [S][n][C]: the P1 mass matrix is block diagonal with the element
+// blocks |T|/12 (I + J), whose inverse is 12/|T| (I - J/4)   (l2_product.apply_inverse(...).pairwise_dot(...),
+// estimators.py:148)
+__global__ __launch_bounds__(256) void k_mass_inv_norm2(Tmpl t, int S, int C, const double* __restrict__ Y, double* __restrict__ out) {
+  const long total = (long)S * C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C), s = (int)(idx / C);
+    double acc = 0.0;
+    for (int e = 0; e < t.nT; ++e) {
+      const double* yr = Y + ((long)s * t.n + 3 * e) * C + c;
+      const double y0 = yr[0], y1 = yr[C], y2 = yr[2 * (long)C];
+      const double sum = y0 + y1 + y2;
+      acc += 12.0 / t.area[e] * (y0 * y0 + y1 * y1 + y2 * y2 - 0.25 * sum * sum);
+    }
+    out[idx] = acc;
+  }
+}
+
 // D[s][e][c] = sum_f sign_f |e_f| / |T| Rt[s][rt(e,f)][c]   (div of the RT0 function, one value per element)
 __global__ __launch_bounds__(256) void k_div_apply(Tmpl t, int S, const int* __restrict__ nbr, int C,
                                                    const double* __restrict__ Rt, double* __restrict__ D) {
@@ -350,6 +368,14 @@ int launch_oswald(lrbms_ctx* ctx, int N, const double* V, double* Wt, hipStream_
 int launch_flux(lrbms_ctx* ctx, int Q, int N, const double* F, const double* V, double* Rt, hipStream_t st) {
   const Tmpl& t = ctx->t;
   hipLaunchKernelGGL(k_flux, dim3(grid_for((long)ctx->S * t.nrt * N)), dim3(256), 0, st, t, ctx->S, ctx->nbr, Q, N, F, V, Rt);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
+}
+
+int launch_mass_inverse_norm2(lrbms_ctx* ctx, int C, const double* Y, double* out, hipStream_t st) {
+  if (C < 1) return lrbms_fail(ctx, LRBMS_E_INVALID, "mass_inverse_norm2: C < 1");
+  const long total = (long)ctx->S * C;
+  hipLaunchKernelGGL(k_mass_inv_norm2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->t, ctx->S, C, Y, out);
   LRBMS_LAUNCH_CHECK(ctx);
   return LRBMS_OK;
 }

@@ -22,6 +22,14 @@ int launch_local_correction(lrbms_ctx* ctx, int Q, const double* theta, int nmar
 int64_t fom_solve_work_size(lrbms_ctx* ctx);
 int launch_fom_solve(lrbms_ctx* ctx, int Q, const double* theta, const double* A_diag, const double* A_cpl, const double* b,
                      double* work, double* x, double rtol, int max_iter, double* info, hipStream_t st);
+int launch_fom_implicit_euler(lrbms_ctx* ctx, int Q, const double* theta, double dt, int nt, const double* A_diag, const double* A_cpl,
+                              const double* b, double* work, double* U, double rtol, int max_iter, double* info, hipStream_t st);
+int launch_mass_inverse_norm2(lrbms_ctx* ctx, int C, const double* Y, double* out, hipStream_t st);
+int launch_reduced_implicit_euler(lrbms_ctx* ctx, int Q, int N, const double* theta, double dt, int nt, const double* B_sys,
+                                  const double* M_red, const double* rhs_red, double* work, double* U, double rtol,
+                                  int max_iter, double* info, hipStream_t st);
+int launch_reduced_time_residual(lrbms_ctx* ctx, int Q, int N, int L, const double* theta, const double* B_sys, const double* M_red,
+                                 const double* dU, double* work, double* out, hipStream_t st);
 int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N);
 bool fused_supported(lrbms_ctx* ctx, int Q, int N);
 int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V, const double* F, const double* A_diag,
@@ -336,6 +344,40 @@ int lrbms_fom_solve(lrbms_ctx* ctx, int32_t Q, const double* theta, const double
   LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, 1); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, A_diag); CHECK_PTR(ctx, A_cpl);
   CHECK_PTR(ctx, b); CHECK_PTR(ctx, work); CHECK_PTR(ctx, x);
   return launch_fom_solve(ctx, Q, theta, A_diag, A_cpl, b, work, x, rtol, max_iter, info, (hipStream_t)stream);
+}
+
+int lrbms_fom_implicit_euler(lrbms_ctx* ctx, int32_t Q, const double* theta, double dt, int32_t nt, const double* A_diag,
+                             const double* A_cpl, const double* b, double* work, double* U, double rtol, int32_t max_iter,
+                             double* info, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, 1); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, A_diag); CHECK_PTR(ctx, A_cpl);
+  CHECK_PTR(ctx, b); CHECK_PTR(ctx, work); CHECK_PTR(ctx, U);
+  return launch_fom_implicit_euler(ctx, Q, theta, dt, nt, A_diag, A_cpl, b, work, U, rtol, max_iter, info, (hipStream_t)stream);
+}
+
+int lrbms_mass_inverse_norm2(lrbms_ctx* ctx, int32_t L, const double* Y, double* out, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_PTR(ctx, Y); CHECK_PTR(ctx, out);
+  return launch_mass_inverse_norm2(ctx, L, Y, out, (hipStream_t)stream);
+}
+
+int lrbms_reduced_implicit_euler(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, double dt, int32_t nt,
+                                 const double* B_sys, const double* M_red, const double* rhs_red, double* work, double* U,
+                                 double rtol, int32_t max_iter, double* info, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, M_red);
+  CHECK_PTR(ctx, rhs_red); CHECK_PTR(ctx, work); CHECK_PTR(ctx, U);
+  return launch_reduced_implicit_euler(ctx, Q, N, theta, dt, nt, B_sys, M_red, rhs_red, work, U, rtol, max_iter, info,
+                                       (hipStream_t)stream);
+}
+
+int64_t lrbms_reduced_time_residual_work_size(lrbms_ctx* ctx, int32_t N) {
+  if (!ctx || !ctx->has_mesh || N < 1) return -1;
+  return (int64_t)ctx->S * (6 * (int64_t)N * N + N + 1);
+}
+
+int lrbms_reduced_time_residual(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t L, const double* theta, const double* B_sys,
+                                const double* M_red, const double* dU, double* work, double* out, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, M_red);
+  CHECK_PTR(ctx, dU); CHECK_PTR(ctx, work); CHECK_PTR(ctx, out);
+  return launch_reduced_time_residual(ctx, Q, N, L, theta, B_sys, M_red, dU, work, out, (hipStream_t)stream);
 }
 
 int lrbms_assemble_dirichlet_correction(lrbms_ctx* ctx, int32_t Q, const double* lam, double* D_corr, void* stream) {

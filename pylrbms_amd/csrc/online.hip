@@ -116,12 +116,13 @@ __global__ __launch_bounds__(256) void k_assemble_mu(long per_q, int Q, QVec the
 }
 
 // Dinv[s] = inverse of the SPD diagonal block Amu[s][2] by Gauss-Jordan without pivoting in LDS (N <= 64)
-__global__ __launch_bounds__(64) void k_block_inverse(int N, const double* __restrict__ Amu, double* __restrict__ Dinv) {
+__global__ __launch_bounds__(64) void k_block_inverse(int N, const double* __restrict__ Amu, double* __restrict__ Dinv,
+                                                      int blocks_per_s, int block_off) {
   extern __shared__ double lds[];
   const int s = blockIdx.x;
   double* A = lds;           // [N][N]
   double* I = lds + N * N;   // [N][N]
-  const double* src = Amu + ((long)s * 5 + 2) * N * N;
+  const double* src = Amu + ((long)s * blocks_per_s + block_off) * N * N;
   for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
     const bool diag = i / N == i % N;
     const double a = src[i];
@@ -179,81 +180,224 @@ __global__ __launch_bounds__(64) void k_cg_matvec(const int* __restrict__ nbr, i
   if (threadIdx.x == 0) partial[s] = dot;
 }
 
-// scal[dst] = sum_s partial[s] (fixed-order tree); optionally alpha = scal[num] / scal[dst] etc. handled by `mode`:
-//   mode 0: scal[0] = sum (rz_old at start), scal[3] = sum (|r0|^2 proxy)
-//   mode 1: scal[1] = pAp = sum; scal[2] = alpha = scal[0] / pAp
-//   mode 2: rz_new = sum; scal[4] = beta = rz_new / scal[0]; scal[0] = rz_new
-__global__ __launch_bounds__(1024) void k_cg_reduce(int S, const double* __restrict__ partial, double* __restrict__ scal,
-                                                    int mode) {
-  __shared__ double red[1024];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < S; i += blockDim.x) acc += partial[i];
-  const double sum = block_reduce_sum(acc, red);
-  if (threadIdx.x == 0) {
-    if (mode == 0) {
-      scal[0] = sum;
-      scal[3] = sum;
-    } else if (mode == 1) {
-      scal[1] = sum;
-      scal[2] = scal[0] / sum;
+// ---- two-kernel CG iteration -------------------------------------------------------------------------------
+// A dependent kernel costs ~6 us on this part whatever it does (measured: 6 kernels per iteration = 35 us, graph replay
+// or not), so the scalar reductions are not kernels of their own: every workgroup sums the per-subdomain partials of the
+// previous kernel itself (S doubles from L2, the same fixed order in every workgroup, so all of them get the same bits).
+// Sums of a[0..n) and b[0..n) by one wave: lane-strided partial sums, then a butterfly.  All loads of a 1024-entry
+// chunk are issued before the first add (a plain `acc += a[i]` loop waits one L2 round trip per entry: 16 x ~0.7 us).
+__device__ inline void wave_sum_arrays(const double* __restrict__ a, const double* __restrict__ b, int n, double& sa, double& sb) {
+  const int lane = threadIdx.x & 63;
+  double acc_a = 0.0, acc_b = 0.0;
+  for (int base = 0; base < n; base += 1024) {
+    double va[16], vb[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = base + lane + 64 * k;
+      va[k] = i < n ? a[i] : 0.0;
+      vb[k] = i < n ? b[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      acc_a += va[k];
+      acc_b += vb[k];
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    acc_a += __shfl_xor(acc_a, off, 64);
+    acc_b += __shfl_xor(acc_b, off, 64);
+  }
+  sa = acc_a;
+  sb = acc_b;
+}
+
+// p_new = z + beta p_old (beta = rz_new / rz_old from the partials; own + neighbour rows on the fly, own rows stored),
+// y_s = sum_slot Amu[s][slot] p_new[nbr(s, slot)],  ppap[s] = p_s . y_s.   One 256-thread workgroup per subdomain: the
+// 5 N rows of the subdomain's blocks are dealt to groups of 4 lanes, each lane takes every 4th pair of doubles of its
+// rows (16-byte loads, the 4 lanes cover 64 contiguous bytes per step).  The matrix (65 MB at config 3) does not fit
+// the L2s and streams from the Infinity Cache: 17 us = 3.8 TB/s.  (Measured alternatives: one wave per subdomain with a
+// row per lane: the same 17 us; all 40 row loads of a lane hoisted in front of the reduction: 41 us per iteration
+// instead of 28 -- the few loads everything waits for then queue behind the bulk of every workgroup on the CU.)
+template <bool EVEN>
+__global__ __launch_bounds__(256) void k_cg2_matvec(const int* __restrict__ nbr, int S, int N, const double* __restrict__ Amu,
+                                                   const double* __restrict__ z, const double* __restrict__ p_old,
+                                                   const double* __restrict__ prz_new, const double* __restrict__ prz_old,
+                                                   int first, double* __restrict__ p_new, double* __restrict__ y,
+                                                   double* __restrict__ ppap) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  double beta = 0.0;
+  if (!first) {
+    double rz_new, rz_old;
+    wave_sum_arrays(prz_new, prz_old, S, rz_new, rz_old);
+    beta = rz_old != 0.0 ? rz_new / rz_old : 0.0;
+  }
+  double* ps = lds;            // [5][N]   direction on the neighbourhood
+  double* ya = lds + 5 * N;    // [5][N]   per-slot row sums
+  int slot_mask = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) slot_mask |= (nbr[s * 5 + k] >= 0) << k;
+  for (int i = tid; i < 5 * N; i += 256) {
+    const int s2 = nbr[s * 5 + i / N];
+    double v = 0.0;
+    if (s2 >= 0) {
+      const long g = (long)s2 * N + i % N;
+      v = first ? z[g] : z[g] + beta * p_old[g];
+      if (i / N == 2) p_new[g] = v;
+    }
+    ps[i] = v;
+  }
+  __syncthreads();
+  const int q4 = tid & 3;
+  const double* base = Amu + (long)s * 5 * N * N;
+  for (int pair = tid >> 2; pair < 5 * N; pair += 64) {      // pair = slot * N + row
+    const int slot = pair / N;
+    const double* row = base + (long)pair * N;
+    const double* pv = ps + slot * N;
+    double acc = 0.0;
+    if ((slot_mask >> slot) & 1) {
+      if (EVEN) {
+        for (int c = 2 * q4; c < N; c += 8) {
+          const double2 a = *reinterpret_cast<const double2*>(row + c);
+          acc += a.x * pv[c] + a.y * pv[c + 1];
+        }
+      } else {
+        for (int c = q4; c < N; c += 4) acc += row[c] * pv[c];
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (q4 == 0) ya[pair] = acc;
+  }
+  __syncthreads();
+  double dot = 0.0;
+  if (tid < N) {
+    const double v = ya[tid] + ya[N + tid] + ya[2 * N + tid] + ya[3 * N + tid] + ya[4 * N + tid];
+    y[(long)s * N + tid] = v;
+    dot = v * ps[2 * N + tid];
+  }
+  if (tid < 64) {                                            // N <= 64: the first wave holds every row
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_down(dot, off, 64);
+    if (tid == 0) ppap[s] = dot;
+  }
+}
+
+// alpha = rz / pAp from the partials;  x += alpha p;  r -= alpha y;  z = Dinv r;  prz_out[s] = r_s . z_s;  prr[s] = r_s . r_s.
+// first: alpha = 0 (only z and the partials of the start residual are formed).  256 threads per subdomain, 4 lanes per row.
+template <bool EVEN>
+__global__ __launch_bounds__(256) void k_cg2_update(int S, int N, const double* __restrict__ Dinv, const double* __restrict__ prz_in,
+                                                   const double* __restrict__ ppap, int first, double* __restrict__ x,
+                                                   double* __restrict__ r, const double* __restrict__ p,
+                                                   const double* __restrict__ y, double* __restrict__ z,
+                                                   double* __restrict__ prz_out, double* __restrict__ prr) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  double alpha = 0.0;
+  if (!first) {
+    double rz, pap;
+    wave_sum_arrays(prz_in, ppap, S, rz, pap);
+    alpha = pap != 0.0 ? rz / pap : 0.0;
+  }
+  double* rs = lds;        // [N]
+  double* zs = lds + N;    // [N]
+  if (tid < N) {
+    const long g = (long)s * N + tid;
+    double rv = r[g];
+    if (!first) {
+      x[g] += alpha * p[g];
+      rv -= alpha * y[g];
+      r[g] = rv;
+    }
+    rs[tid] = rv;
+  }
+  __syncthreads();
+  const int q4 = tid & 3, row_i = tid >> 2;
+  if (row_i < N) {
+    const double* row = Dinv + ((long)s * N + row_i) * N;
+    double acc = 0.0;
+    if (EVEN) {
+      for (int c = 2 * q4; c < N; c += 8) {
+        const double2 a = *reinterpret_cast<const double2*>(row + c);
+        acc += a.x * rs[c] + a.y * rs[c + 1];
+      }
     } else {
-      scal[4] = sum / scal[0];
-      scal[0] = sum;
+      for (int c = q4; c < N; c += 4) acc += row[c] * rs[c];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (q4 == 0) {
+      zs[row_i] = acc;
+      z[(long)s * N + row_i] = acc;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    double dot = 0.0, rr = 0.0;
+    if (tid < N) {
+      dot = zs[tid] * rs[tid];
+      rr = rs[tid] * rs[tid];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      dot += __shfl_down(dot, off, 64);
+      rr += __shfl_down(rr, off, 64);
+    }
+    if (tid == 0) {
+      prz_out[s] = dot;
+      prr[s] = rr;
     }
   }
 }
 
-// x += alpha p; r -= alpha y; z = Dinv r; partial[s] = r_s . z_s; partial2[s] = r_s . r_s.  One wave per subdomain.
-__global__ __launch_bounds__(64) void k_cg_update(int N, const double* __restrict__ Dinv, const double* __restrict__ scal,
-                                                  int first, double* __restrict__ x, double* __restrict__ r,
-                                                  const double* __restrict__ p, const double* __restrict__ y,
-                                                  double* __restrict__ z, double* __restrict__ partial,
-                                                  double* __restrict__ partial2) {
+// Amu[s][slot] = sum_q theta_q B_sys[q][s][slot] (+ M_red[s] on the self slot): the operator of a reduced implicit Euler step
+__global__ __launch_bounds__(256) void k_assemble_mu_mass(long per_q, int Q, int N, QVec theta, const double* __restrict__ B_sys,
+                                                          const double* __restrict__ M_red, double* __restrict__ Amu) {
+  const long nn = (long)N * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_q; i += (long)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int q = 0; q < Q; ++q) acc += theta.v[q] * B_sys[(long)q * per_q + i];
+    const long blk = i / nn;
+    if (blk % 5 == 2) acc += M_red[(blk / 5) * nn + i % nn];
+    Amu[i] = acc;
+  }
+}
+
+// warm-started step: r_s = M_red[s] u_s + dt b_s - y_s  (y = (M + dt A) u_k);  partial[s] = |M_red[s] u_s + dt b_s|^2
+__global__ __launch_bounds__(64) void k_red_step_residual(int N, double dt, const double* __restrict__ M_red,
+                                                          const double* __restrict__ uk, const double* __restrict__ b,
+                                                          const double* __restrict__ y, double* __restrict__ r,
+                                                          double* __restrict__ partial) {
   extern __shared__ double lds[];
   const int s = blockIdx.x;
-  double* rs = lds;  // [N]
-  const double alpha = first ? 0.0 : scal[2];
-  for (int i = threadIdx.x; i < N; i += 64) {
-    const long g = (long)s * N + i;
-    if (!first) x[g] += alpha * p[g];
-    const double rv = r[g] - alpha * (first ? 0.0 : y[g]);
-    r[g] = rv;
-    rs[i] = rv;
-  }
+  for (int i = threadIdx.x; i < N; i += 64) lds[i] = uk[(long)s * N + i];
   __syncthreads();
-  double dot = 0.0, rr = 0.0;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < N; i += 64) {
+    const double* row = M_red + ((long)s * N + i) * N;
+    double rhs = dt * b[(long)s * N + i];
+    for (int c = 0; c < N; ++c) rhs += row[c] * lds[c];
+    r[(long)s * N + i] = rhs - y[(long)s * N + i];
+    acc += rhs * rhs;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (threadIdx.x == 0) partial[s] = acc;
+}
+
+// out[s] = y_s^T Dinv[s] y_s  (one wave per subdomain)
+__global__ __launch_bounds__(64) void k_red_inv_norm2(int N, const double* __restrict__ Dinv, const double* __restrict__ y,
+                                                      double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x;
+  for (int i = threadIdx.x; i < N; i += 64) lds[i] = y[(long)s * N + i];
+  __syncthreads();
+  double acc = 0.0;
   for (int i = threadIdx.x; i < N; i += 64) {
     const double* row = Dinv + ((long)s * N + i) * N;
-    double acc = 0.0;
-    for (int c = 0; c < N; ++c) acc += row[c] * rs[c];
-    z[(long)s * N + i] = acc;
-    dot += acc * rs[i];
-    rr += rs[i] * rs[i];
+    double z = 0.0;
+    for (int c = 0; c < N; ++c) z += row[c] * lds[c];
+    acc += z * lds[i];
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    dot += __shfl_down(dot, off, 64);
-    rr += __shfl_down(rr, off, 64);
-  }
-  if (threadIdx.x == 0) {
-    partial[s] = dot;
-    partial2[s] = rr;
-  }
-}
-
-// p = z + beta p
-__global__ __launch_bounds__(256) void k_cg_direction(long total, const double* __restrict__ scal, int first,
-                                                      const double* __restrict__ z, double* __restrict__ p) {
-  const double beta = first ? 0.0 : scal[4];
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
-    p[i] = z[i] + beta * p[i];
-}
-
-__global__ __launch_bounds__(1024) void k_sum_to(int S, const double* __restrict__ partial, double* __restrict__ dst) {
-  __shared__ double red[1024];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < S; i += blockDim.x) acc += partial[i];
-  const double sum = block_reduce_sum(acc, red);
-  if (threadIdx.x == 0) *dst = sum;
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (threadIdx.x == 0) out[s] = acc;
 }
 
 }  // namespace
@@ -273,8 +417,94 @@ int launch_reduced_estimate(lrbms_ctx* ctx, int Q, int N, const double* theta, c
 
 int64_t reduced_solve_work_size(lrbms_ctx* ctx, int N) {
   const long S = ctx->S;
-  return S * 5 * N * N + S * N * N + 4 * S * N + 2 * S + 16;
+  return S * 5 * N * N + S * N * N + 5 * S * N + 4 * S + 16;
 }
+
+namespace {
+
+struct RedCg {
+  double *Amu, *Dinv, *r, *z, *p[2], *y, *prz[2], *ppap, *prr;
+  void carve(double* work, long S, int N) {
+    Amu = work;
+    Dinv = Amu + S * 5 * N * N;
+    r = Dinv + S * N * N;
+    z = r + S * N;
+    p[0] = z + S * N;
+    p[1] = p[0] + S * N;
+    y = p[1] + S * N;
+    prz[0] = y + S * N;
+    prz[1] = prz[0] + S;
+    ppap = prz[1] + S;
+    prr = ppap + S;
+  }
+};
+
+// sum of a device array of S doubles on the host (fixed order); synchronises `st`
+int host_sum(lrbms_ctx* ctx, const double* dev, std::vector<double>& host, double* out, hipStream_t st) {
+  LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(host.data(), dev, sizeof(double) * host.size(), hipMemcpyDeviceToHost, st));
+  LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  double acc = 0.0;
+  for (double v : host) acc += v;
+  *out = acc;
+  return LRBMS_OK;
+}
+
+// Block-Jacobi PCG on Amu x = rhs: on entry x holds the start value and b.r the start residual; iterates until
+// |r| <= rtol * sqrt(ref2) (ref2 < 0: relative to the start residual).  Two kernels per iteration (see k_cg2_*); the
+// convergence check (8 KB to the host) is placed where the observed rate predicts convergence, at most 40 iterations apart.
+int red_cg_run(lrbms_ctx* ctx, int N, RedCg& b, double* x, double ref2, double rtol, int max_iter, int* its, double* rel_out,
+               hipStream_t st) {
+  const int S = ctx->S;
+  std::vector<double> host(S);
+  const size_t lds_mv = sizeof(double) * 10 * N, lds_up = sizeof(double) * 2 * N;
+  if (N % 2 == 0)
+    hipLaunchKernelGGL(k_cg2_update<true>, dim3(S), dim3(256), lds_up, st, S, N, b.Dinv, b.prz[0], b.ppap, 1, x, b.r, b.p[0], b.y, b.z,
+                       b.prz[0], b.prr);
+  else
+    hipLaunchKernelGGL(k_cg2_update<false>, dim3(S), dim3(256), lds_up, st, S, N, b.Dinv, b.prz[0], b.ppap, 1, x, b.r, b.p[0], b.y, b.z,
+                       b.prz[0], b.prr);
+  LRBMS_LAUNCH_CHECK(ctx);
+  double rr = 0.0;
+  if (int rc = host_sum(ctx, b.prr, host, &rr, st)) return rc;
+  if (ref2 < 0.0) ref2 = rr;
+  *its = 0;
+  *rel_out = 0.0;
+  if (rr == 0.0 || ref2 == 0.0) return LRBMS_OK;
+  double rel = sqrt(rr / ref2);
+  int it = 0, block = 10;
+  while (rel > rtol && it < max_iter) {
+    if (block > max_iter - it) block = max_iter - it;
+    for (int k = 0; k < block; ++k, ++it) {
+      const int c = it & 1, o = c ^ 1;
+      if (N % 2 == 0) {
+        hipLaunchKernelGGL(k_cg2_matvec<true>, dim3(S), dim3(256), lds_mv, st, ctx->nbr, S, N, b.Amu, b.z, b.p[o], b.prz[c], b.prz[o],
+                           it == 0 ? 1 : 0, b.p[c], b.y, b.ppap);
+        hipLaunchKernelGGL(k_cg2_update<true>, dim3(S), dim3(256), lds_up, st, S, N, b.Dinv, b.prz[c], b.ppap, 0, x, b.r, b.p[c], b.y,
+                           b.z, b.prz[o], b.prr);
+      } else {
+        hipLaunchKernelGGL(k_cg2_matvec<false>, dim3(S), dim3(256), lds_mv, st, ctx->nbr, S, N, b.Amu, b.z, b.p[o], b.prz[c], b.prz[o],
+                           it == 0 ? 1 : 0, b.p[c], b.y, b.ppap);
+        hipLaunchKernelGGL(k_cg2_update<false>, dim3(S), dim3(256), lds_up, st, S, N, b.Dinv, b.prz[c], b.ppap, 0, x, b.r, b.p[c], b.y,
+                           b.z, b.prz[o], b.prr);
+      }
+    }
+    LRBMS_LAUNCH_CHECK(ctx);
+    if (int rc = host_sum(ctx, b.prr, host, &rr, st)) return rc;
+    rel = sqrt(rr / ref2);
+    if (!(rel == rel)) return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced CG: NaN residual (system not SPD?)");
+    const double rate = log(rel) / it;                 // log-residual per iteration so far (relative to ref2)
+    block = 10;
+    if (rel > rtol && rate < 0.0) {
+      const double need = (log(rtol) - log(rel)) / rate;
+      block = need < 2.0 ? 2 : need > 40.0 ? 40 : (int)need + 1;
+    }
+  }
+  *its = it;
+  *rel_out = rel;
+  return LRBMS_OK;
+}
+
+}  // namespace
 
 int launch_reduced_solve(lrbms_ctx* ctx, int Q, int N, const double* theta, const double* B_sys, const double* rhs_red,
                          double* work, double* u, double rtol, int max_iter, double* info, hipStream_t st) {
@@ -283,60 +513,106 @@ int launch_reduced_solve(lrbms_ctx* ctx, int Q, int N, const double* theta, cons
   const int S = ctx->S;
   QVec th;
   for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
-  double* Amu = work;
-  double* Dinv = Amu + (long)S * 5 * N * N;
-  double* r = Dinv + (long)S * N * N;
-  double* z = r + (long)S * N;
-  double* p = z + (long)S * N;
-  double* y = p + (long)S * N;
-  double* partial = y + (long)S * N;
-  double* partial2 = partial + S;
-  double* scal = partial2 + S;   // [0] rz, [1] pAp, [2] alpha, [3] rz0, [4] beta, [5] rr
+  RedCg b;
+  b.carve(work, S, N);
   const long per_q = (long)S * 5 * N * N;
   const long vec = (long)S * N;
   hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256),
-                     0, st, per_q, Q, th, B_sys, Amu);
+                     0, st, per_q, Q, th, B_sys, b.Amu);
   LRBMS_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, Amu, Dinv);
+  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, b.Amu, b.Dinv, 5, 2);
   LRBMS_LAUNCH_CHECK(ctx);
   // x0 = 0, r0 = b
   LRBMS_HIP_CHECK(ctx, hipMemsetAsync(u, 0, sizeof(double) * vec, st));
-  LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(r, rhs_red, sizeof(double) * vec, hipMemcpyDeviceToDevice, st));
-  hipLaunchKernelGGL(k_cg_update, dim3(S), dim3(64), sizeof(double) * N, st, N, Dinv, scal, 1, u, r, p, y, z, partial, partial2);
-  LRBMS_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(k_cg_reduce, dim3(1), dim3(1024), 0, st, S, partial, scal, 0);
-  hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(1024), 0, st, S, partial2, scal + 5);
-  hipLaunchKernelGGL(k_cg_direction, dim3((unsigned)((vec + 255) / 256)), dim3(256), 0, st, vec, scal, 1, z, p);
-  LRBMS_LAUNCH_CHECK(ctx);
-  double host_scal[8];
-  LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, scal, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
-  LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  const double rr0 = host_scal[5];
-  double rel = 1.0;
+  LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(b.r, rhs_red, sizeof(double) * vec, hipMemcpyDeviceToDevice, st));
   int it = 0;
-  if (rr0 == 0.0) {
-    if (info) { info[0] = 0; info[1] = 0.0; }
-    return LRBMS_OK;
-  }
-  const int check_every = 10;
-  while (it < max_iter) {
-    for (int k = 0; k < check_every && it < max_iter; ++k, ++it) {
-      hipLaunchKernelGGL(k_cg_matvec, dim3(S), dim3(64), sizeof(double) * 5 * N, st, ctx->nbr, N, Amu, p, y, partial);
-      hipLaunchKernelGGL(k_cg_reduce, dim3(1), dim3(1024), 0, st, S, partial, scal, 1);
-      hipLaunchKernelGGL(k_cg_update, dim3(S), dim3(64), sizeof(double) * N, st, N, Dinv, scal, 0, u, r, p, y, z, partial, partial2);
-      hipLaunchKernelGGL(k_cg_reduce, dim3(1), dim3(1024), 0, st, S, partial, scal, 2);
-      hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(1024), 0, st, S, partial2, scal + 5);
-      hipLaunchKernelGGL(k_cg_direction, dim3((unsigned)((vec + 255) / 256)), dim3(256), 0, st, vec, scal, 0, z, p);
-    }
-    LRBMS_LAUNCH_CHECK(ctx);
-    LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(host_scal, scal, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
-    LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    rel = sqrt(host_scal[5] / rr0);
-    if (!(rel == rel)) return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve: NaN residual (system not SPD?)");
-    if (rel <= rtol) break;
-  }
+  double rel = 0.0;
+  if (int rc = red_cg_run(ctx, N, b, u, -1.0, rtol, max_iter, &it, &rel, st)) return rc;
   if (info) { info[0] = it; info[1] = rel; }
   if (rel > rtol) return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve: CG did not reach rtol");
+  return LRBMS_OK;
+}
+
+// Reduced implicit Euler (the reduced counterpart of InstationaryDuneDiscretization._solve,
+// discretize_parabolic_block_swipdg.py:28-40):  (M_red + dt sum_q theta_q B_q) u_{k+1} = M_red u_k + dt rhs_red.
+// The step operator and its block-Jacobi preconditioner are built once, every step is a warm-started PCG with the
+// kernels of lrbms_reduced_solve.  U [nt+1][S][N]: U[0] initial value (input), U[1..nt] written.
+int launch_reduced_implicit_euler(lrbms_ctx* ctx, int Q, int N, const double* theta, double dt, int nt, const double* B_sys,
+                                  const double* M_red, const double* rhs_red, double* work, double* U, double rtol,
+                                  int max_iter, double* info, hipStream_t st) {
+  if (ctx->S_ext != ctx->S) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_implicit_euler needs all subdomains on one rank");
+  if (N > 64 || N < 1) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_implicit_euler: N > 64 not supported by the block inverse");
+  if (Q < 1 || Q > 8 || nt < 1 || !(dt > 0.0) || !(rtol > 0.0) || max_iter < 1)
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_implicit_euler: bad Q / nt / dt / rtol / max_iter");
+  const int S = ctx->S;
+  QVec th;
+  for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? dt * theta[q] : 0.0;
+  RedCg b;
+  b.carve(work, S, N);
+  const long per_q = (long)S * 5 * N * N;
+  const long vec = (long)S * N;
+  hipLaunchKernelGGL(k_assemble_mu_mass, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256),
+                     0, st, per_q, Q, N, th, B_sys, M_red, b.Amu);
+  LRBMS_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, b.Amu, b.Dinv, 5, 2);
+  LRBMS_LAUNCH_CHECK(ctx);
+  std::vector<double> host(S);
+  long total_it = 0;
+  double worst = 0.0;
+  for (int step = 0; step < nt; ++step) {
+    const double* uk = U + (long)step * vec;
+    double* u = U + (long)(step + 1) * vec;
+    LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(u, uk, sizeof(double) * vec, hipMemcpyDeviceToDevice, st));
+    // warm start: r = M_red u_k + dt b - (M_red + dt A) u_k; the matvec kernel with first = 1 takes its direction from `z`
+    if (N % 2 == 0)
+      hipLaunchKernelGGL(k_cg2_matvec<true>, dim3(S), dim3(256), sizeof(double) * 10 * N, st, ctx->nbr, S, N, b.Amu, uk, b.p[1], b.prz[0],
+                         b.prz[1], 1, b.p[0], b.y, b.ppap);
+    else
+      hipLaunchKernelGGL(k_cg2_matvec<false>, dim3(S), dim3(256), sizeof(double) * 10 * N, st, ctx->nbr, S, N, b.Amu, uk, b.p[1], b.prz[0],
+                         b.prz[1], 1, b.p[0], b.y, b.ppap);
+    hipLaunchKernelGGL(k_red_step_residual, dim3(S), dim3(64), sizeof(double) * N, st, N, dt, M_red, uk, rhs_red, b.y, b.r, b.ppap);
+    LRBMS_LAUNCH_CHECK(ctx);
+    double ref2 = 0.0;
+    if (int rc = host_sum(ctx, b.ppap, host, &ref2, st)) return rc;
+    if (ref2 == 0.0) continue;                           // zero right-hand side: u_{k+1} = u_k = 0
+    int it = 0;
+    double rel = 0.0;
+    if (int rc = red_cg_run(ctx, N, b, u, ref2, rtol, max_iter, &it, &rel, st)) return rc;
+    total_it += it;
+    if (rel > worst) worst = rel;
+    if (rel > rtol) {
+      if (info) { info[0] = (double)total_it; info[1] = worst; }
+      return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced_implicit_euler: CG did not reach rtol");
+    }
+  }
+  if (info) { info[0] = (double)total_it; info[1] = worst; }
+  return LRBMS_OK;
+}
+
+// Time-stepping residual of the reduced model (ParabolicEstimator.estimate, estimators.py:146-148, with d = rd):
+// out[l][s] = y^T M_red[s]^{-1} y,  y = (sum_q theta_q B_q dU_l)_s, for L difference vectors dU [L][S][N].
+// work: S*5*N*N + S*N*N + S*N + S doubles.
+int launch_reduced_time_residual(lrbms_ctx* ctx, int Q, int N, int L, const double* theta, const double* B_sys, const double* M_red,
+                                 const double* dU, double* work, double* out, hipStream_t st) {
+  if (ctx->S_ext != ctx->S) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_time_residual needs all subdomains on one rank");
+  if (N > 64 || N < 1 || L < 1 || Q < 1 || Q > 8) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_time_residual: bad N / L / Q");
+  const int S = ctx->S;
+  QVec th;
+  for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
+  double* Amu = work;
+  double* Minv = Amu + (long)S * 5 * N * N;
+  double* y = Minv + (long)S * N * N;
+  double* partial = y + (long)S * N;
+  const long per_q = (long)S * 5 * N * N;
+  hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256),
+                     0, st, per_q, Q, th, B_sys, Amu);
+  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, M_red, Minv, 1, 0);
+  LRBMS_LAUNCH_CHECK(ctx);
+  for (int l = 0; l < L; ++l) {
+    hipLaunchKernelGGL(k_cg_matvec, dim3(S), dim3(64), sizeof(double) * 5 * N, st, ctx->nbr, N, Amu, dU + (long)l * S * N, y, partial);
+    hipLaunchKernelGGL(k_red_inv_norm2, dim3(S), dim3(64), sizeof(double) * N, st, N, Minv, y, out + (long)l * S);
+  }
+  LRBMS_LAUNCH_CHECK(ctx);
   return LRBMS_OK;
 }
 
@@ -532,9 +808,21 @@ __global__ __launch_bounds__(1024) void k_bcg_reduce(int S, int nmu, const doubl
   const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   for (int m = threadIdx.x >> 6; m < nmu; m += nw) {       // wave m sums parameter m: lane-strided, then a fixed shuffle tree
     double a = 0.0, b = 0.0;
-    for (int i = lane; i < S; i += 64) {
-      a += partial[(long)m * S + i];
-      if (partial2) b += partial2[(long)m * S + i];
+    // all loads of a 1024-entry chunk are issued before the first add (an `a += partial[i]` loop waits one L2 round
+    // trip per entry: this single-workgroup kernel took 7.6 us, 19 % of an iteration of the batched solve)
+    for (int base = 0; base < S; base += 1024) {
+      double va[16], vb[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int i = base + lane + 64 * k;
+        va[k] = i < S ? partial[(long)m * S + i] : 0.0;
+        vb[k] = (partial2 && i < S) ? partial2[(long)m * S + i] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        a += va[k];
+        b += vb[k];
+      }
     }
     for (int off = 32; off > 0; off >>= 1) {
       a += __shfl_down(a, off, 64);
@@ -694,7 +982,7 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   const long per_q = (long)S * 5 * N * N;
   hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256), 0, st,
                      per_q, Q, mean, B_sys, Amu);
-  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, Amu, Dinv);
+  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, Amu, Dinv, 5, 2);
   hipLaunchKernelGGL(k_bcg_init, dim3((unsigned)((vec + 255) / 256 > 4096 ? 4096 : (vec + 255) / 256)), dim3(256), 0, st, vec, nmu,
                      rhs_red, u, r);
   LRBMS_LAUNCH_CHECK(ctx);

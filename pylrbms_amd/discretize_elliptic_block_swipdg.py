@@ -179,20 +179,25 @@ class DuneDiscretization:
         return BlockVectorArray(x, self.solution_space)
 
     def _local_estimates(self, U, mu):
-        """Per-subdomain nc / r / df for every vector of a full-order array: the vectors become a ``len(U)``-column
-        basis pushed through K7 / K8 / P2, and the k-th unit coefficient vector selects the k-th pairwise form."""
+        """Per-subdomain nc / r / df for every vector of a full-order array: the vectors become a basis of ``len(U)``
+        columns (in chunks of 16) pushed through K7 / K8 / P2, and the k-th unit coefficient vector selects the k-th
+        pairwise form -- one batched estimate launch per chunk."""
         import torch
         eng = self.engine
         theta = self.theta(mu)
-        V = self._with_halo(U.tensor)
-        L = V.shape[2]
-        buf = eng.project_and_estimate(V, project_system=False)
+        Vall = self._with_halo(U.tensor)
         out = []
-        for k in range(L):
-            u = eng.ctx.zeros(eng.S_ext, L)
-            u[:, k] = 1.0
-            out.append(eng.reduced_estimate(theta, u, buf['grams']))
-        eta = torch.stack(out, dim=2)                                      # [3, S, L]
+        for c0 in range(0, Vall.shape[2], 16):
+            V = Vall[:, :, c0:c0 + 16].contiguous()
+            L = V.shape[2]
+            buf = eng.project_and_estimate(V, project_system=False)
+            if L == 1:
+                u = eng.ctx.zeros(eng.S_ext, 1) + 1.0
+                out.append(eng.reduced_estimate(theta, u, buf['grams'])[:, :, None])
+                continue
+            u = torch.eye(L, dtype=V.dtype, device=V.device).expand(eng.S_ext, L, L).contiguous()
+            out.append(eng.ctx.reduced_estimate_batch(np.tile(theta, (L, 1)), u, buf['grams'], eng.f2, eng.ceps, eng.hdiam))
+        eta = torch.cat(out, dim=2)                                        # [3, S, len(U)]
         return eta[0], eta[1], eta[2]
 
     def estimate(self, U, mu=None, decompose=False):

@@ -1,7 +1,7 @@
-"""Localized a-posteriori error estimator (reference python/dune/pylrbms/estimators.py:28-136).
+"""Localized a-posteriori error estimator (reference python/dune/pylrbms/estimators.py:28-168).
 
 Same class names, constructor arguments and return values as the reference's ``EstimatorBase`` /
-``EllipticEstimator``.  The per-subdomain loop of ``_estimate_elliptic`` (estimators.py:70-91: six
+``EllipticEstimator`` / ``ParabolicEstimator``.  The per-subdomain loop of ``_estimate_elliptic`` (estimators.py:70-91: six
 ``pairwise_apply2`` / ``apply`` calls per subdomain) is ONE launch of the HIP kernel behind
 ``lrbms_reduced_estimate`` on the projected operators; full-order vectors take the same route after being pushed
 through the Oswald / flux-reconstruction kernels as a ``len(U)``-column basis.
@@ -96,3 +96,43 @@ class EllipticEstimator(EstimatorBase):
 
     def estimate(self, U, mu, d, decompose=False):
         return self._estimate_elliptic(U, mu, d, False, decompose)
+
+
+class ParabolicEstimator(EstimatorBase):
+    """Reference estimators.py:139-168.  ``d`` is the instationary discretization (full order or reduced): it provides
+    ``T``, ``time_stepper.nt``, ``_local_estimates`` and ``_time_residual_norm2`` (the
+    ``l2_product.apply_inverse(operator.apply(dU)).pairwise_dot(operator.apply(dU))`` of :146-148 as one kernel chain).
+
+    At HEAD this estimator cannot run: it asks ``_estimate_elliptic`` for the elliptic reconstruction (:143), whose
+    branch starts with ``assert False`` (:64).  ``elliptic_reconstruction=False`` (default) evaluates the code as written
+    without that branch; ``True`` keeps the reference's behaviour (AssertionError).  One eta per time step (see
+    oracle/parabolic.py on ``mpi_norm``)."""
+
+    def __init__(self, *args, elliptic_reconstruction=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.elliptic_reconstruction = elliptic_reconstruction
+
+    def estimate(self, U, mu, d, decompose=False):
+        dt = d.T / d.time_stepper.nt
+        eta, (local_eta_nc, local_eta_r, local_eta_df), elliptic_local_indicators = \
+            self._estimate_elliptic(U, mu, d, self.elliptic_reconstruction, True)
+        eta = np.atleast_1d(np.asarray(eta, dtype=np.float64))
+
+        dU = U[1:] - U[:-1]
+        time_residual = d._time_residual_norm2(dU, mu)                     # :146-148
+        time_residual = time_residual * (dt / 3)
+        time_residual = np.sqrt(time_residual)
+
+        # elliptic error
+        eta = eta * (2 * np.sqrt(dt / 3))
+        local_eta_nc = local_eta_nc * (2 * np.sqrt(dt / 3))
+        local_eta_r = local_eta_r * (2 * np.sqrt(dt / 3))
+        local_eta_df = local_eta_df * (2 * np.sqrt(dt / 3))
+
+        # nc_ii(U_o[k+1] - U_o[k]): the Oswald interpolation error is linear, so this is the nc form of dU  (:158-162)
+        time_deriv_nc = d._local_estimates(dU, mu)[0].cpu().numpy()
+        time_deriv_nc = time_deriv_nc * (1 / dt)
+        time_deriv_nc = np.sqrt(np.maximum(time_deriv_nc, 0.0))
+
+        est = np.linalg.norm(eta) + np.linalg.norm(time_residual) + np.linalg.norm(time_deriv_nc)
+        return est, (local_eta_nc, local_eta_r, local_eta_df, time_residual, time_deriv_nc)

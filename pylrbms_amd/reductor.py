@@ -88,19 +88,24 @@ class ReducedDiscretization:
         torch = self._torch
         eng = self.d.engine
         theta = self.d.theta(mu)
+        u_all = U.tensor                                                   # [S, N, len(U)]
+        if eng.S_ext != eng.S:
+            # halo coefficients: every rank contributes its rows to a global [S_total, N, len] table (one all-reduce),
+            # then picks the rows of its ext ordering
+            import torch.distributed as dist
+            table = torch.zeros(eng.grid.num_subdomains, self.N, u_all.shape[2], dtype=u_all.dtype, device=u_all.device)
+            table[torch.as_tensor(eng.local, device=u_all.device)] = u_all
+            dist.all_reduce(table, group=getattr(self.d.mpi_comm, 'group', None))
+            u_all = table[torch.as_tensor(eng.ext, device=u_all.device)]
         cols = []
-        for k in range(len(U)):
-            u = U.tensor[:, :, k].contiguous()
-            if eng.S_ext != eng.S:
-                # halo coefficients: every rank contributes its rows to a global [S_total, N] table (one all-reduce
-                # of S_total * N doubles), then picks the rows of its ext ordering
-                import torch.distributed as dist
-                table = torch.zeros(eng.grid.num_subdomains, self.N, dtype=u.dtype, device=u.device)
-                table[torch.as_tensor(eng.local, device=u.device)] = u
-                dist.all_reduce(table, group=getattr(self.d.mpi_comm, 'group', None))
-                u = table[torch.as_tensor(eng.ext, device=u.device)].contiguous()
-            cols.append(eng.reduced_estimate(theta, u, self.grams))
-        eta = torch.stack(cols, dim=2)
+        for c0 in range(0, u_all.shape[2], 16):                            # the batched estimate takes <= 16 vectors
+            u = u_all[:, :, c0:c0 + 16].contiguous()
+            L = u.shape[2]
+            if L == 1:
+                cols.append(eng.reduced_estimate(theta, u[:, :, 0].contiguous(), self.grams)[:, :, None])
+            else:
+                cols.append(eng.ctx.reduced_estimate_batch(np.tile(theta, (L, 1)), u, self.grams, eng.f2, eng.ceps, eng.hdiam))
+        eta = torch.cat(cols, dim=2)
         return eta[0], eta[1], eta[2]
 
     def estimate(self, U, mu=None, decompose=False):
@@ -323,3 +328,58 @@ class ParallelLRBMSReductor(LRBMSReductor):
     def __init__(self, d, bases=None, products=None, order=None, solver_options=None, mpi_comm=None):
         super().__init__(d, bases=bases, products=products, solver_options=solver_options, num_cpus=1, order=order)
         self.mpi_comm = mpi_comm
+
+
+class InstationaryReducedDiscretization(ReducedDiscretization):
+    """The reduced instationary model of the parabolic path: reduced implicit Euler (``lrbms_reduced_implicit_euler``, the
+    whole trajectory in one native call) and the same ``ParabolicEstimator`` with the projected operators."""
+
+    def __init__(self, reductor, buffers, N):
+        super().__init__(reductor, buffers, N)
+        self.T, self.time_stepper = self.d.T, self.d.time_stepper
+        self.mass = self.M_red
+
+    def solve(self, mu, inverse_options=None):
+        eng = self.d.engine
+        if eng.S_ext != eng.S:
+            raise NotImplementedError('the reduced parabolic solve needs all subdomains on one rank')
+        dt = self.T / self.time_stepper.nt
+        U, info = eng.ctx.reduced_implicit_euler(self.d.theta(mu), dt, self.time_stepper.nt, self.B_sys, self.M_red,
+                                                 self.rhs_red)
+        self.last_solve_info = info
+        return ReducedVectorArray(U.permute(1, 2, 0))
+
+    def _time_residual_norm2(self, dU, mu):
+        eng = self.d.engine
+        if eng.S_ext != eng.S:
+            raise NotImplementedError('the reduced parabolic estimate needs all subdomains on one rank')
+        out = eng.ctx.reduced_time_residual(self.d.theta(mu), self.B_sys, self.M_red, dU.tensor.permute(2, 0, 1).contiguous())
+        return out.sum(dim=1).cpu().numpy()
+
+
+class ParabolicLRBMSReductor(LRBMSReductor):
+    """The reductor python/scripts/parabolic.py:9,42-45 asks for (imported there from ``dune.pylrbms.estimators``, where
+    it does not exist at HEAD).  Same bases and projection as ``LRBMSReductor``; ``extend_basis`` takes a trajectory:
+    its vectors are Gram-Schmidt-ed into the local bases one after the other, vectors that are numerically in the span
+    of a local basis are skipped for that subdomain (pyMOR ``gram_schmidt`` semantics), ``ExtensionError`` if nothing
+    was added anywhere; ``reduce()`` returns the instationary reduced model."""
+
+    def extend_basis(self, U, max_vectors=None):
+        eng = self.d.engine
+        t = U.tensor
+        added = 0
+        for k in range(t.shape[2]):
+            if max_vectors is not None and self.basis_size() >= max_vectors:
+                break
+            if self._V is None:
+                self._V = eng.ctx.zeros(eng.S, eng.t.n, 0)
+                self._nloc = np.zeros(eng.S, dtype=np.int64)
+            v, ok = self._orthonormalize_against_basis(t[:, :, k:k + 1])
+            added += int(self._append_columns(v, ok).sum())
+        if added == 0:
+            raise ExtensionError('no snapshot block extends its local basis')
+
+    def _reduce(self):
+        rd = super()._reduce()
+        return InstationaryReducedDiscretization(self, {'sys': (rd.B_sys, rd.rhs_red, rd.E_red, rd.M_red), 'grams': rd.grams},
+                                                 rd.N)

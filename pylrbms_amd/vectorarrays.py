@@ -88,6 +88,10 @@ class BlockVectorArray:
     def sup_norm(self):
         return self._t.abs().amax(dim=(0, 1)).cpu().numpy()
 
+    def l2_norm(self):
+        """Euclidean norm of the coefficient vectors (pyMOR ``l2_norm``; python/scripts/parabolic.py:71)."""
+        return (self._t ** 2).sum(dim=(0, 1)).sqrt().cpu().numpy()
+
 
 class ReducedVectorArray:
     """Reduced coefficient vectors ``[num_blocks, N, len]`` (what ``rd.solve`` returns)."""
@@ -110,3 +114,13 @@ class ReducedVectorArray:
     def append(self, other):
         import torch
         self._t = torch.cat([self._t, other._t], dim=2).contiguous()
+
+    def __getitem__(self, idx):
+        idx = [idx] if np.isscalar(idx) else list(range(len(self)))[idx] if isinstance(idx, slice) else list(idx)
+        return ReducedVectorArray(self._t[:, :, idx])
+
+    def __sub__(self, other):
+        return ReducedVectorArray(self._t - other._t)
+
+    def __add__(self, other):
+        return ReducedVectorArray(self._t + other._t)

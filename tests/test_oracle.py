@@ -159,3 +159,46 @@ def test_local_correction_on_a_whole_domain_neighbourhood_is_the_global_solution
     assert hood == [0, 1] and A.shape == (2 * d.n, 2 * d.n)
     assert abs(A - A.T).max() < 1e-13 and np.linalg.eigvalsh(A.toarray()).min() > 0.0
     assert np.abs(d.solve_for_local_correction(0, 0.3) - u[0]).max() > 1e-3 * np.abs(u[0]).max()
+
+
+def test_parabolic_oracle_invariants():
+    """oracle/parabolic.py (parity unpinned: the reference's parabolic path does not run at HEAD): the implicit Euler
+    trajectory tends to the stationary solution; the reduced estimate equals the full-order estimate of the
+    reconstruction in every part that does not involve the inverse mass; the elliptic-reconstruction terms of
+    estimators.py:80-83 add up to ||M^-1 A u - div r||^2 - ||Pi f||^2 (checked against an independent evaluation)."""
+    import scipy.sparse.linalg as spla
+    from oracle.parabolic import OracleParabolic, OracleParabolicReduced
+    d, _ = _os2015([2, 2], [2, 2])
+    mu = 0.5
+    U_inf = OracleParabolic(d, 200.0, 20).solve(mu)[-1]
+    Ust = d.solve(mu)
+    assert np.abs(U_inf - Ust).max() < 1e-10 * np.abs(Ust).max()
+
+    par = OracleParabolic(d, 1.0, 6)
+    U = par.solve(mu)
+    assert np.abs(U[0]).max() == 0.0 and U.shape == (7, d.S, d.n)
+    rng = np.random.default_rng(0)
+    N = 4
+    bases = [np.linalg.qr(np.hstack([U[1:, ii].T, rng.standard_normal((d.n, 1))]))[0][:, :N] for ii in range(d.S)]
+    red = OracleReductor(d, bases)
+    pr = OracleParabolicReduced(red, red.reduce(), 1.0, 6)
+    u = pr.solve(mu)
+    off = np.arange(d.S + 1) * N
+    Urec = np.stack([np.stack([bases[ii] @ u[k, off[ii]:off[ii + 1]] for ii in range(d.S)]) for k in range(u.shape[0])])
+    for rec in (False, True):
+        _, parts_r = pr.estimate(u, mu, elliptic_reconstruction=rec)
+        _, parts_f = par.estimate(Urec, mu, elliptic_reconstruction=rec)
+        for i in ((0, 2, 4) if rec else (0, 1, 2, 4)):      # with the reconstruction, r involves M_red^-1 as well
+            assert np.abs(parts_r[i] - parts_f[i]).max() < 1e-9 * np.abs(parts_f[i]).max()
+
+    _, r1, _ = par._elliptic_local(U, mu, True)
+    A, Minv, th, k = d.assemble_global(mu), spla.splu(d.l2_product.tocsc()), d.theta(mu), 3
+    BU_R, F_R = Minv.solve(A @ U[k].reshape(-1)), Minv.solve(d.b)
+    _, RT = OracleReductor(d, [U[k, ii][:, None] for ii in range(d.S)]).image_bases()
+    for ii in range(d.S):
+        ur = sum(RT[kk][d.mesh.neighborhood_of(kk).index(ii)] @ th for kk in d.mesh.neighborhood_of(ii))
+        M, sl = d.block(d.l2_product, ii, ii), slice(ii * d.n, (ii + 1) * d.n)
+        w = BU_R[sl] - d.Div[ii] @ ur
+        val = w @ (M @ w) + d.local_eta_rf_squared[ii] - F_R[sl] @ (M @ F_R[sl])
+        val *= (1.0 / np.pi ** 2) / d.min_diffusion_evs[ii] * d.subdomain_diameters[ii] ** 2
+        assert abs(val - r1[ii, k]) < 1e-10 * abs(val)
