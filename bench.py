@@ -127,8 +127,14 @@ def cpu_baseline(N, coarse, sample_subdomains=(16, 16), repeats=1):
         for ii in picks:
             d.solve_for_local_correction(ii, 0.3)
         corr = len(picks) / (time.perf_counter() - t0)
+        # parabolic path: the oracle's implicit Euler (one sparse LU, then a solve per step) on the sample
+        from oracle.parabolic import OracleParabolic
+        t0 = time.perf_counter()
+        OracleParabolic(d, 0.05, 10).solve(0.5)
+        par = 10 / (time.perf_counter() - t0)
     return {'value': allc, 'unit': 'subdomains/s', 'cores': cores, 'kind': 'port', 'value_1core': one,
             'assemble_subdomains_per_s_1core': d.S / t_asm, 'local_correction_solves_per_s_1core': corr,
+            'implicit_euler_steps_per_s_1core': par,
             'sample': 'oracle.lrbms.OracleReductor.reduce() (NumPy/SciPy fp64) on {}x{} subdomains of the same synthetic '
                       'multiscale problem, N={}, k_c={}: value = target subdomains farmed over a {}-process pool '
                       '(1 BLAS thread each), value_1core = one process, one thread'
@@ -298,6 +304,27 @@ def main():
                       'cg_iterations_max': int(cinfo[:, 0].max()), 'cg_iterations_mean': float(cinfo[:, 0].mean()),
                       'relative_residual_max': float(cinfo[:, 1].max())}
 
+    parabolic = None
+    if world == 1 and not args.no_online:
+        # parabolic LRBMS: implicit Euler trajectories, full order and reduced, each ONE native call
+        # (T = 0.05, 10 steps, mu = 0.5, zero initial data; the reduced model is the online one built above)
+        th = np.array([c.evaluate(0.5) for c in lam['coefficients']])
+        nt_p, T_p = 10, 0.05
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _, finfo = eng.ctx.fom_implicit_euler(th, T_p / nt_p, nt_p, eng.A_diag, eng.A_cpl, eng.b)
+        torch.cuda.synchronize()
+        t_f = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        _, rinfo = eng.ctx.reduced_implicit_euler(th, T_p / nt_p, nt_p, bufo['sys'][0], bufo['sys'][3], bufo['sys'][1])
+        torch.cuda.synchronize()
+        t_r = time.perf_counter() - t1
+        parabolic = {'metric': 'implicit Euler time steps', 'unit': 'steps/s', 'steps': nt_p, 'T': T_p,
+                     'full_order_steps_per_s': nt_p / t_f, 'full_order_dofs': S_total * t.n,
+                     'full_order_cg_iterations': finfo['iterations'], 'reduced_steps_per_s': nt_p / t_r,
+                     'reduced_dim': S_total * N, 'reduced_cg_iterations': rinfo['iterations'],
+                     'relative_residual_max': max(finfo['relative_residual'], rinfo['relative_residual'])}
+
     if rank == 0:
         Q = eng.Q
         flops = algorithmic_flops_per_subdomain(t.n, t.n_rt, t.n_T, N, Q)
@@ -346,6 +373,8 @@ def main():
             out['online'] = online
         if enrichment is not None:
             out['enrichment'] = enrichment
+        if parabolic is not None:
+            out['parabolic'] = parabolic
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
             out['cpu_baseline'] = cpu_baseline(N, cfg['coarse_per_subdomain'])
         print(json.dumps(out), flush=True)

@@ -1,0 +1,247 @@
+"""Convergence / verification harness (reference python/dune/pylrbms/EOC.py:24-324; SURVEY.md section 8f "next" #4).
+
+``EocStudy.run`` walks the refinement levels, solves, measures the error against a reference solution, evaluates the
+estimator and prints one table row per level with the experimental orders of convergence and the efficiency index
+``error / estimate`` (EOC.py:52-216: same columns -- discretization, norms, indicators, estimates -- laid out plainly).
+``StationaryEocStudy`` is the study of python/scripts/OS2015_convergence_study.py (OS2015 tables 1-3).
+
+Differences to the reference, which cannot run without dune-gdt:
+* the reference solution is the block SWIPDG P1 solution on a uniformly refined copy of the finest level (the
+  reference takes SWIPDG with ``p_ref = 2`` on the finest grid, EOC.py:290-298; P2 is out of scope here);
+* ``prolong`` (dune.gdt.prolong, EOC.py:300-314) is the nested-mesh P1 interpolation below: the cube grid with two
+  conforming bisections is nested under doubling the coarse squares, so a coarse P1-DG function is reproduced exactly.
+
+All solves and estimates run through the HIP path of the discretization handed in; the error norms are a few torch
+reductions on the device (verification harness, not on the hot path).
+"""
+import sys
+
+import numpy as np
+
+from pylrbms_amd.grid import RING
+
+
+def prolongation_map(grid_c, grid_f):
+    """Index / weight arrays of the P1-DG prolongation from ``grid_c`` to the nested finer ``grid_f``:
+    ``U_f[dof] = sum_i w[dof, i] * U_c[idx[dof, i]]`` with global DoF numbers ``3 * (subdomain * n_T + element) + vertex``."""
+    tc, tf = grid_c.template, grid_f.template
+    Sf = grid_f.num_subdomains
+    org_f = np.stack([grid_f.subdomain_origin(jj) for jj in range(Sf)])             # [Sf, 2]
+    x = org_f[:, None, None, :] + tf.points[None]                                   # [Sf, nT_f, 3, 2]
+    cen = x.mean(axis=2)
+    ll = grid_c.lower_left
+    hc = np.array([grid_c.hx, grid_c.hy])
+    rel = (cen - ll) / (2.0 * hc)
+    sq = np.minimum(np.floor(rel).astype(np.int64), np.array(grid_c.K) - 1)         # global coarse square
+    loc = (cen - ll) / hc - 2.0 * sq                                                # in [0, 2]^2, lattice units
+    # which of the 8 ring triangles (centre, RING[t], RING[t+1]) holds the centroid
+    a = np.array([1.0, 1.0])
+    best, best_val = np.zeros(loc.shape[:-1], dtype=np.int64), np.full(loc.shape[:-1], -np.inf)
+    for t in range(8):
+        b, c = RING[t].astype(np.float64), RING[(t + 1) % 8].astype(np.float64)
+        det = (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])
+        l1 = ((loc[..., 0] - a[0]) * (c[1] - a[1]) - (loc[..., 1] - a[1]) * (c[0] - a[0])) / det
+        l2 = ((b[0] - a[0]) * (loc[..., 1] - a[1]) - (b[1] - a[1]) * (loc[..., 0] - a[0])) / det
+        val = np.minimum(np.minimum(l1, l2), 1.0 - l1 - l2)
+        take = val > best_val
+        best, best_val = np.where(take, t, best), np.where(take, val, best_val)
+    assert best_val.min() > -1e-9, 'grids are not nested'
+    Pxc = grid_c.P[0]
+    sub_c = (sq[..., 0] // tc.kx) + Pxc * (sq[..., 1] // tc.ky)
+    e_c = ((sq[..., 0] % tc.kx) + tc.kx * (sq[..., 1] % tc.ky)) * 8 + best           # [Sf, nT_f]
+    org_c = np.stack([grid_c.subdomain_origin(ii) for ii in range(grid_c.num_subdomains)])
+    p0 = org_c[sub_c] + tc.points[e_c, 0]                                           # vertex 0 of the parent
+    g = tc.grad[e_c]                                                                # [Sf, nT_f, 3(i), 2]
+    dx = x - p0[:, :, None, :]                                                      # [Sf, nT_f, 3(v), 2]
+    w = np.einsum('seia,seva->sevi', g, dx)
+    w[..., 0] += 1.0                                                                # lambda_i(p_0) = delta_{i0}
+    base = 3 * (sub_c * tc.n_T + e_c)
+    idx = base[:, :, None, None] + np.arange(3)[None, None, None, :] + np.zeros((1, 1, 3, 1), dtype=np.int64)
+    return idx.reshape(-1, 3), w.reshape(-1, 3)
+
+
+def prolong(U, grid_c, grid_f, ctx, _cache={}):
+    """``U`` [S_c, n_c, L] device tensor on ``grid_c`` -> [S_f, n_f, L] on ``grid_f``."""
+    import torch
+    key = (tuple(grid_c.K), tuple(grid_c.P), tuple(grid_f.K), tuple(grid_f.P))
+    if key not in _cache:
+        idx, w = prolongation_map(grid_c, grid_f)
+        _cache[key] = (torch.from_numpy(idx).to(U.device), ctx.from_numpy(w))
+    idx, w = _cache[key]
+    flat = U.reshape(-1, U.shape[2])
+    out = (flat[idx.reshape(-1)].reshape(idx.shape[0], 3, -1) * w[:, :, None]).sum(dim=1)
+    return out.reshape(grid_f.num_subdomains, grid_f.template.n, U.shape[2])
+
+
+def error_norms(diff, d):
+    """L2 and broken ``elliptic_mu_bar`` norm (EOC.py:263-270) of the block tensor ``diff`` [S, n, L] on the grid of
+    ``d``: element mass |T|/12 (1 + delta_ij) and int lambda_bar times the P1 stiffness template."""
+    import torch
+    eng = d.engine
+    t = eng.t
+    u = diff.reshape(eng.S, t.n_T, 3, -1)
+    area = eng.ctx.from_numpy(np.asarray(t.area))
+    s = u.sum(dim=2)
+    l2 = (area[None, :, None] / 12.0 * ((u * u).sum(dim=2) + s * s)).sum(dim=(0, 1))
+    kap = np.asarray(eng.kappa, dtype=np.float64).reshape(2, 2)
+    K = eng.ctx.from_numpy(np.einsum('eia,ab,ejb->eij', t.grad, kap, t.grad))
+    en = (eng.ebar[:, :, None] * torch.einsum('seil,eij,sejl->sel', u, K, u)).sum(dim=(0, 1))
+    return {'L2': torch.sqrt(l2).cpu().numpy(), 'elliptic_mu_bar': torch.sqrt(en).cpu().numpy()}
+
+
+class EocStudy:
+    """EOC.py:24-216.  Subclasses provide ``solve``, ``level_info``, ``accuracy``, ``compute_norm``,
+    ``compute_indicator``, ``compute_estimate``; ``run`` fills ``self.data[level]`` and prints the table."""
+
+    level_info_title = None
+    accuracies = norms = indicators = estimates = None
+    max_levels = None
+    data = None
+
+    def run(self, only_these=None, file=None):
+        file = file or sys.stdout
+        sel = (lambda ids: tuple(i for i in (ids or ()) if not only_these or i in only_these))
+        accs, norms, inds = sel(self.accuracies), sel(self.norms), sel(self.indicators)
+        ests = tuple(e for e in (self.estimates or ()) if not only_these or e[0] in only_these)
+        cols = [self.level_info_title] + list(accs)
+        for q in list(norms) + list(inds):
+            cols += [q] + ['EOC({})'.format(a) for a in accs]
+        for e, _ in ests:
+            cols += [e, 'eff.'] + ['EOC({})'.format(a) for a in accs]
+        width = max(12, max(len(c) for c in cols) + 1)
+        print(' | '.join(c.rjust(width) for c in cols), file=file)
+        print('-+-'.join('-' * width for _ in cols), file=file)
+
+        def eoc(kind, q, level, a):
+            if level == 0:
+                return '----'
+            old, new = self.data[level - 1][kind][q], self.data[level][kind][q]
+            if np.allclose(old, 0):
+                return 'inf'                                                     # EOC.py:84-85
+            acc_old, acc_new = self.data[level - 1]['accuracy'][a], self.data[level]['accuracy'][a]
+            if acc_old == acc_new:
+                return '----'
+            return '{:.2f}'.format(np.log(new / old) / np.log(acc_new / acc_old))
+
+        for level in range(self.max_levels + 1):
+            self.data.setdefault(level, {})
+            self.solve(level)
+            row = [self.level_info(level)]
+            dl = self.data[level]
+            for k in ('accuracy', 'norm', 'indicator', 'estimate'):
+                dl.setdefault(k, {})
+            for a in self.accuracies:
+                dl['accuracy'][a] = self.accuracy(level, a)
+            row += ['{:.2e}'.format(dl['accuracy'][a]) for a in accs]
+            for q in norms:
+                dl['norm'][q] = self.compute_norm(level, q)
+                row += ['{:.2e}'.format(dl['norm'][q])] + [eoc('norm', q, level, a) for a in accs]
+            for q in inds:
+                dl['indicator'][q] = self.compute_indicator(level, q)
+                row += ['{:.2e}'.format(dl['indicator'][q])] + [eoc('indicator', q, level, a) for a in accs]
+            for e, norm_id in ests:
+                dl['estimate'][e] = self.compute_estimate(level, e)
+                if norm_id not in dl['norm']:
+                    dl['norm'][norm_id] = self.compute_norm(level, norm_id)
+                row += ['{:.2e}'.format(dl['estimate'][e]), '{:.2f}'.format(dl['norm'][norm_id] / dl['estimate'][e])]
+                row += [eoc('estimate', e, level, a) for a in accs]
+            print(' | '.join(c.rjust(width) for c in row), file=file)
+        return self.data
+
+
+def refine_uniformly(cfg):
+    """Twice as many coarse squares per direction on the same subdomains (the reference level of the studies here)."""
+    out = dict(cfg)
+    for key in ('half_num_fine_elements_per_subdomain_and_dim', 'coarse_per_subdomain'):
+        if key in out:
+            out[key] = 2 * out[key]
+            return out
+    raise KeyError('config has no grid resolution key')
+
+
+class StationaryEocStudy(EocStudy):
+    """EOC.py:219-324."""
+
+    level_info_title = '|grid|/|Grid|'
+    accuracies = ('h', 'H')
+    norms = ('L2', 'elliptic_mu_bar')
+    indicators = ('eta_nc', 'eta_r', 'eta_df')
+    estimates = (('eta', 'elliptic_mu_bar'), )
+    max_levels = 2
+
+    def __init__(self, gp_initializer, disc, base_cfg, refine, mu, reference_cfg=None, max_levels=None):
+        self.data = {}
+        (self._grid_and_problem_data, self._d, self._d_data, self._solution, self._solution_as_reference, self._config,
+         self._cache) = {}, {}, {}, {}, {}, {}, {}
+        self._grid_and_problem_initializer = gp_initializer
+        self._discretizer = disc
+        self.mu = mu
+        if max_levels is not None:
+            self.max_levels = max_levels
+        self._config[0] = dict(base_cfg)
+        for level in range(1, self.max_levels + 1):
+            self._config[level] = refine(self._config[level - 1])
+        self._config[-1] = dict(reference_cfg) if reference_cfg is not None else refine_uniformly(self._config[self.max_levels])
+
+    def solve(self, level):
+        assert level <= self.max_levels
+        if level in self._solution:
+            return
+        self._grid_and_problem_data[level] = self._grid_and_problem_initializer(self._config[level])
+        self._d[level], self._d_data[level] = self._discretizer(self._grid_and_problem_data[level])
+        mu = self._d[level].parse_parameter(self.mu)
+        self._solution[level] = self._d[level].solve(mu)
+
+    def level_info(self, level):
+        grid = self._grid_and_problem_data[level]['grid']
+        return str(grid.num_elements) + '/' + str(grid.num_subdomains)
+
+    def accuracy(self, level, id):
+        grid = self._grid_and_problem_data[level]['grid']
+        if id == 'h':
+            return grid.max_entity_diameter()
+        if id == 'H':
+            return max(grid.subdomain_diameter(ss) for ss in range(grid.num_subdomains))
+        assert False
+
+    def _compute_reference_solution(self):
+        if -1 in self._solution:
+            return
+        self._grid_and_problem_data[-1] = self._grid_and_problem_initializer(self._config[-1])
+        self._d[-1], self._d_data[-1] = self._discretizer(self._grid_and_problem_data[-1])
+        self._solution[-1] = self._d[-1].solve(self._d[-1].parse_parameter(self.mu))
+
+    def _reconstructed(self, level):
+        if 'reductor' in self._d_data[level]:                                 # EOC.py:303-304
+            return self._d_data[level]['reductor'].reconstruct(self._solution[level])
+        return self._solution[level]
+
+    def _prolong_onto_reference(self, level):
+        if level in self._solution_as_reference:
+            return
+        U = self._reconstructed(level)
+        self._solution_as_reference[level] = prolong(U.tensor, self._grid_and_problem_data[level]['grid'],
+                                                     self._grid_and_problem_data[-1]['grid'], self._d[-1].engine.ctx)
+
+    def compute_norm(self, level, id):
+        self._compute_reference_solution()
+        self._prolong_onto_reference(level)
+        if ('norms', level) not in self._cache:
+            diff = self._solution[-1].tensor - self._solution_as_reference[level]
+            self._cache[('norms', level)] = error_norms(diff, self._d[-1])
+        return float(self._cache[('norms', level)][id][0])
+
+    def _compute_estimates(self, level):
+        if level not in self._cache:
+            mu = self._d[level].parse_parameter(self.mu)
+            eta, (eta_ncs, eta_rs, eta_dfs), _ = self._d[level].estimate(self._solution[level], mu=mu, decompose=True)
+            self._cache[level] = {'eta_nc': np.linalg.norm(eta_ncs), 'eta_df': np.linalg.norm(eta_dfs),
+                                  'eta_r': np.linalg.norm(eta_rs), 'eta': float(np.ravel(eta)[0])}   # EOC.py:316-324
+
+    def compute_indicator(self, level, id):
+        self._compute_estimates(level)
+        return self._cache[level][id]
+
+    def compute_estimate(self, level, id):
+        self._compute_estimates(level)
+        return self._cache[level][id]

@@ -7,7 +7,6 @@ the hot path: ``solve``, ``estimate``, ``operators[...]``, ``products['l2']``, `
 ``flux_reconstruction`` / ``oswald_interpolation_error``.  All arithmetic is done by the HIP kernels through
 ``pylrbms_amd.engine.Engine``; nothing here computes on the CPU besides coefficient sampling and index bookkeeping.
 
-Out of scope: ``visualize``.
 """
 import numpy as np
 
@@ -109,8 +108,10 @@ class DuneDiscretization:
     def unblock(self, U):
         return U.data                                                     # block-mapper ordering == global ordering
 
-    def visualize(self, U, *args, **kwargs):
-        return None
+    def visualize(self, U, filename='solution', name='u', **kwargs):
+        """``DuneGDTVisualizer`` (block_swipdg.py:802): writes this rank's subdomains as legacy VTK files."""
+        from pylrbms_amd.visualize import visualize_block_array
+        return visualize_block_array(U, self.grid, self.engine.local, filename, name=name)
 
     def shape_functions(self, subdomain, order=0):
         """block_swipdg.py:187-200: only ``order=0`` (the constant) works in the reference (App. B-4)."""

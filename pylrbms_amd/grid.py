@@ -261,8 +261,10 @@ class DDSubdomainsGrid:
         key[:, :, 1] += ((s // Px) * t.ky)[:, None]
         return key
 
-    def visualize(self, name, with_coupling=False):   # API stub (VTK output is out of scope)
-        return None
+    def visualize(self, name, with_coupling=False):
+        """grid.py:35 ``grid.visualize('grid', False)``: the mesh with the subdomain index as cell data (legacy VTK)."""
+        from pylrbms_amd.visualize import write_vtk
+        return write_vtk(name, self, range(self.num_subdomains))
 
 
 def tile_grid(world_size, Px, Py):

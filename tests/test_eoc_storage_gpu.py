@@ -1,0 +1,98 @@
+"""SURVEY.md section 8f "next" #4 on the GPU: the stationary convergence study (reference EOC.py:219-324 /
+python/scripts/OS2015_convergence_study.py), VTK output and the on-disk format of bases and reduced models."""
+import numpy as np
+import pytest
+
+from common import oracle_from_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stationary_eoc_study_os2015(capsys):
+    """OS2015 academic problem, mu = 1 (all coefficients equal: the setting of OS2015 table 1): P1 block SWIPDG converges
+    with order 1 in the broken energy norm and 2 in L2; the estimator (paper variant: local indicators under a square
+    root) is an upper bound of the energy error with an efficiency that stays bounded; the error norms of the harness
+    agree with the oracle's mass / energy matrices."""
+    from pylrbms_amd import OS2015_academic_problem
+    from pylrbms_amd.EOC import StationaryEocStudy, error_norms, prolong
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize as discretize_block
+
+    def discretize(gp):
+        d, data = discretize_block(gp)
+        d.estimator = d.estimator.with_(sqrt_local=True)
+        return d, {'block_space': data['block_space'], 'unblock': d.unblock}
+
+    def refine(cfg):
+        out = dict(cfg)
+        out['half_num_fine_elements_per_subdomain_and_dim'] *= 2
+        out['num_subdomains'] = [2 * s for s in cfg['num_subdomains']]
+        return out
+
+    base = {'num_subdomains': [1, 1], 'half_num_fine_elements_per_subdomain_and_dim': 4}
+    study = StationaryEocStudy(OS2015_academic_problem.init_grid_and_problem, discretize, base, refine, mu=1)
+    data = study.run()
+    out = capsys.readouterr().out
+    assert out.count('\n') == 2 + 3
+    import os
+    if os.path.isdir('gpurun_out'):
+        open('gpurun_out/eoc_table.txt', 'w').write(out)
+    h = [data[l]['accuracy']['h'] for l in range(3)]
+    en = [data[l]['norm']['elliptic_mu_bar'] for l in range(3)]
+    l2 = [data[l]['norm']['L2'] for l in range(3)]
+    eta = [data[l]['estimate']['eta'] for l in range(3)]
+    assert h[0] == 2 * h[1] == 4 * h[2]
+    # the reference solution is only one refinement finer, so the last level's measured error is ~13 % (energy) /
+    # ~25 % (L2) short of the true one: rates between the first two levels
+    assert 0.85 < np.log2(en[0] / en[1]) < 1.25
+    assert 1.7 < np.log2(l2[0] / l2[1]) < 2.4
+    # eta_r carries the subdomain diameter H, which is halved as well: the estimate falls faster than h at first
+    assert 0.8 < np.log2(eta[0] / eta[1]) < 1.8 and 0.8 < np.log2(eta[1] / eta[2]) < 1.8
+    for l in range(3):
+        assert 0.05 < en[l] / eta[l] <= 1.0                                   # efficiency index: eta is an upper bound
+        for q in ('eta_nc', 'eta_r', 'eta_df'):
+            assert data[l]['indicator'][q] > 0
+    # the harness' norms against the oracle's matrices on the reference grid (level 1 prolonged onto level 2's grid)
+    g1, g2 = study._grid_and_problem_data[1]['grid'], study._grid_and_problem_data[2]['grid']
+    d2 = study._d[2]
+    diff = study._solution[2].tensor - prolong(study._solution[1].tensor, g1, g2, d2.engine.ctx)
+    nrm = error_norms(diff, d2)
+    o = oracle_from_problem(study._grid_and_problem_data[2])
+    v = diff.cpu().numpy().reshape(-1)
+    assert abs(nrm['L2'][0] - np.sqrt(v @ (o.l2_product @ v))) < 1e-10 * nrm['L2'][0]
+    assert abs(nrm['elliptic_mu_bar'][0] - np.sqrt(v @ (o.elliptic_bar @ v))) < 1e-10 * nrm['elliptic_mu_bar'][0]
+
+
+def test_bases_and_reduced_model_round_trip_through_disk(tmp_path):
+    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    from pylrbms_amd.reductor import LRBMSReductor
+    from pylrbms_amd.storage import load_bases, load_reduced, save_bases, save_reduced
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': [3, 2], 'coarse_per_subdomain': 2})
+    d, _ = discretize(p)
+    reductor = LRBMSReductor(d, order=0)
+    for mu in (0.2, 0.9):
+        reductor.extend_basis(d.solve(mu))
+    reductor.enrich_local_batch([1, 4], None, mu=0.5)                        # ragged local sizes
+    rd = reductor.reduce()
+    fb, fr = str(tmp_path / 'bases.safetensors'), str(tmp_path / 'rd.safetensors')
+    save_bases(reductor, fb)
+    save_reduced(rd, fr)
+
+    reductor2 = LRBMSReductor(d, bases=load_bases(d, fb))
+    assert reductor2.local_sizes() == reductor.local_sizes() == [3, 4, 3, 3, 4, 3]
+    assert bool((reductor2._V == reductor._V).all())
+    rd2 = load_reduced(reductor2, fr)
+    mu = d.parse_parameter(0.6)
+    u, u2 = rd.solve(mu), rd2.solve(mu)
+    assert bool((u.tensor == u2.tensor).all())                               # same bits: same tensors, same kernels
+    assert rd.estimate(u, mu=mu) == rd2.estimate(u2, mu=mu)
+    rd3 = reductor2.reduce()                                                  # and the stored blocks are what a fresh pass gives
+    assert bool((rd3.B_sys == rd2.B_sys).all()) and all(bool((a == b).all()) for a, b in zip(rd3.grams, rd2.grams))
+    # a file is refused by a discretization it does not belong to
+    p_other = multiscale_problem.init_grid_and_problem({'num_subdomains': [2, 3], 'coarse_per_subdomain': 2})
+    d_other, _ = discretize(p_other)
+    with pytest.raises(ValueError):
+        load_bases(d_other, fb)
+    # VTK output of the reconstruction (one file per vector)
+    files = d.visualize(reductor.reconstruct(u), filename=str(tmp_path / 'u_red'))
+    assert len(files) == 1 and open(files[0]).readline().startswith('# vtk DataFile')

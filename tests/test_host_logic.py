@@ -59,3 +59,87 @@ def test_parameters():
     assert all(0.1 <= m['diffusion'][0] <= 1.0 for m in space.sample_randomly(5, seed=1))
     with pytest.raises(AssertionError):
         parse_parameter((1, 2), pt)
+
+
+def _dof_points(g):
+    t = g.template
+    org = np.stack([g.subdomain_origin(i) for i in range(g.num_subdomains)])
+    return (org[:, None, None, :] + t.points[None]).reshape(-1, 2)
+
+
+@pytest.mark.parametrize('pc,kc,pf,kf', [([2, 3], 2, [2, 3], 4), ([2, 3], 2, [4, 6], 2), ([1, 1], 3, [3, 3], 4)])
+def test_prolongation_reproduces_p1_functions_on_nested_grids(pc, kc, pf, kf):
+    """EOC harness (reference EOC.py:300-314 ``prolong``): convex weights, exact for globally linear functions, and an
+    arbitrary P1-DG function is reproduced at the fine vertices (checked by evaluating the parent's local P1 function)."""
+    from pylrbms_amd.EOC import prolongation_map
+    from pylrbms_amd.grid import make_multiscale_grid
+    gc, gf = make_multiscale_grid(pc, kc), make_multiscale_grid(pf, kf)
+    idx, w = prolongation_map(gc, gf)
+    assert idx.shape == (3 * gf.num_elements, 3) and np.abs(w.sum(axis=1) - 1).max() < 1e-14 and w.min() > -1e-14
+    assert (idx // 3 == idx[:, :1] // 3).all()                     # all three parents are DoFs of ONE coarse element
+    lin = lambda x: 0.3 + 1.7 * x[:, 0] - 2.2 * x[:, 1]  # noqa: E731
+    assert np.abs((lin(_dof_points(gc))[idx] * w).sum(axis=1) - lin(_dof_points(gf))).max() < 1e-13
+    # a discontinuous coarse function: one random P1 function per coarse element
+    rng = np.random.default_rng(3)
+    coef = rng.standard_normal((gc.num_elements, 3))               # a + b x + c y per coarse element
+    xc, xf = _dof_points(gc), _dof_points(gf)
+    Uc = coef[np.arange(3 * gc.num_elements) // 3, 0] + (coef[np.arange(3 * gc.num_elements) // 3, 1:] * xc).sum(axis=1)
+    par = idx[:, 0] // 3
+    Uf = coef[par, 0] + (coef[par, 1:] * xf).sum(axis=1)
+    assert np.abs((Uc[idx] * w).sum(axis=1) - Uf).max() < 1e-12
+
+
+def test_eoc_table_logic(capsys):
+    """``EocStudy.run``: rates from consecutive levels, efficiency = norm / estimate, 'inf' for a vanishing quantity."""
+    from pylrbms_amd.EOC import EocStudy
+
+    class Fake(EocStudy):
+        level_info_title, accuracies, norms, indicators = 'lvl', ('h',), ('err',), ('zero',)
+        estimates, max_levels = (('eta', 'err'),), 2
+
+        def __init__(self):
+            self.data = {}
+
+        def solve(self, level):
+            pass
+
+        def level_info(self, level):
+            return str(level)
+
+        def accuracy(self, level, id):
+            return 0.5 ** level
+
+        def compute_norm(self, level, id):
+            return 3.0 * (0.5 ** level) ** 2
+
+        def compute_indicator(self, level, id):
+            return 0.0
+
+        def compute_estimate(self, level, id):
+            return 6.0 * (0.5 ** level)
+
+    data = Fake().run()
+    out = capsys.readouterr().out.splitlines()
+    assert len(out) == 5 and out[2].split('|')[3].strip() == '----'
+    cells = [c.strip() for c in out[4].split('|')]
+    assert cells[3] == '2.00' and cells[5] == 'inf' and cells[8] == '1.00'     # EOC(err), EOC(zero), EOC(eta)
+    assert abs(float(cells[7]) - data[2]['norm']['err'] / data[2]['estimate']['eta']) < 0.01
+    only = Fake()
+    only.run(only_these=('h', 'err'))
+    assert 'eta' not in capsys.readouterr().out
+
+
+def test_vtk_writer(tmp_path):
+    from pylrbms_amd.grid import make_multiscale_grid
+    from pylrbms_amd.visualize import write_vtk
+    g = make_multiscale_grid([2, 2], 2)
+    t = g.template
+    vals = np.arange(4 * t.n, dtype=np.float64).reshape(4, t.n)
+    fn = write_vtk(str(tmp_path / 'u'), g, range(4), {'u': vals})
+    lines = open(fn).read().splitlines()
+    assert lines[0].startswith('# vtk DataFile') and lines[3] == 'DATASET UNSTRUCTURED_GRID'
+    npts = 4 * t.n
+    assert 'POINTS {} double'.format(npts) in lines and 'CELLS {} {}'.format(npts // 3, 4 * npts // 3) in lines
+    i = lines.index('SCALARS u double 1')
+    assert np.allclose(np.array(lines[i + 2:i + 2 + npts], dtype=float), vals.reshape(-1))
+    assert g.visualize(str(tmp_path / 'grid')).endswith('grid.vtk')
