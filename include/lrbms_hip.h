@@ -199,7 +199,8 @@ int lrbms_reduced_estimate_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t n
                                  double* eta_loc, void* stream);
 
 /* O1: rd.solve(mu): (sum_q theta_q B_sys_q) u = rhs_red by block-Jacobi preconditioned CG on the block-sparse
- * reduced system (single rank: S_ext == S).  work >= lrbms_reduced_solve_work_size doubles.
+ * reduced system (single rank: S_ext == S), two-level preconditioner (see lrbms_reduced_precond_build).
+ * work >= lrbms_reduced_solve_work_size doubles.
  * Returns LRBMS_E_NOT_CONVERGED if the relative residual is above rtol after max_iter.  info[0] = iterations,
  * info[1] = final relative residual (host pointers, may be NULL). */
 int64_t lrbms_reduced_solve_work_size(lrbms_ctx* ctx, int32_t N);
@@ -214,6 +215,20 @@ int64_t lrbms_reduced_solve_batch_work_size(lrbms_ctx* ctx, int32_t N, int32_t n
 int lrbms_reduced_solve_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* B_sys,
                               const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
                               void* stream);
+
+/* Preconditioner of the reduced solves, built once per reduced model.  Both reduced solvers precondition with the
+ * inverse diagonal blocks plus a coarse level on the first local basis vector of every subdomain (the constant the
+ * reference starts every basis with, reductor.py:29-31); without the calls below they build it per call at (the batch
+ * mean of) theta, which costs about as much as a batched solve (a dense S x S factorisation).  Any SPD preconditioner is
+ * admissible, so one built at a reference parameter serves a whole parameter range:
+ *   lrbms_reduced_precond_build   theta [Q] host (reference parameter); work >= lrbms_reduced_solve_work_size doubles;
+ *                                 pc: lrbms_reduced_precond_size doubles, caller-owned, filled
+ *   lrbms_reduced_precond_use     subsequent lrbms_reduced_solve / _batch calls on this context with basis size N use pc
+ *                                 (pc must stay alive; NULL: back to per-call preconditioners) */
+int64_t lrbms_reduced_precond_size(lrbms_ctx* ctx, int32_t N);
+int lrbms_reduced_precond_build(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* B_sys, double* work,
+                                double* pc, void* stream);
+int lrbms_reduced_precond_use(lrbms_ctx* ctx, int32_t N, const double* pc);
 
 /* -- snapshot generation (SURVEY.md section 8f "next" #2) -------------------------------------------------- */
 /* DuneDiscretization._solve (block_swipdg.py:219-225; ISTL bicgstab.ilut in the reference driver,

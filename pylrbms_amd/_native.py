@@ -54,6 +54,9 @@ SIGNATURES = {
     'lrbms_reduced_solve_batch_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_reduced_solve_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL,
                                                  c_vp]),
+    'lrbms_reduced_precond_size': (c_i64, [c_vp, c_i32]),
+    'lrbms_reduced_precond_build': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp]),
+    'lrbms_reduced_precond_use': (ctypes.c_int, [c_vp, c_i32, c_vp]),
     'lrbms_fom_solve_work_size': (c_i64, [c_vp]),
     'lrbms_fom_solve': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms_fom_implicit_euler': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_dbl, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL,
@@ -400,6 +403,26 @@ class NativeContext:
                                                 c_vp(u.data_ptr()), float(rtol), int(max_iter), _dblp(info), self._stream())
         self._check(rc, 'lrbms_reduced_solve_batch')
         return u, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
+
+    def reduced_precond_build(self, theta, B_sys):
+        """Two-level preconditioner of the reduced solves at the reference parameter ``theta`` -> device buffer."""
+        Q, S, N = B_sys.shape[0], self.S, B_sys.shape[3]
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        assert th.shape == (Q,)
+        work = self.empty(int(self.lib.lrbms_reduced_solve_work_size(self.handle, N)))
+        pc = self.empty(int(self.lib.lrbms_reduced_precond_size(self.handle, N)))
+        rc = self.lib.lrbms_reduced_precond_build(self.handle, Q, N, _dblp(th), self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'),
+                                                  c_vp(work.data_ptr()), c_vp(pc.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_reduced_precond_build')
+        pc._lrbms_N = N
+        return pc
+
+    def reduced_precond_use(self, pc):
+        """Subsequent reduced solves use ``pc`` (``None``: per-call preconditioners).  The context keeps a reference."""
+        self._pc_in_use = pc
+        rc = self.lib.lrbms_reduced_precond_use(self.handle, int(pc._lrbms_N) if pc is not None else 0,
+                                                c_vp(pc.data_ptr()) if pc is not None else None)
+        self._check(rc, 'lrbms_reduced_precond_use')
 
     def aux_stream(self, i=0):
         """The i-th library-owned stream as a ``torch.cuda.ExternalStream`` (cached)."""

@@ -30,6 +30,10 @@ int launch_reduced_implicit_euler(lrbms_ctx* ctx, int Q, int N, const double* th
                                   int max_iter, double* info, hipStream_t st);
 int launch_reduced_time_residual(lrbms_ctx* ctx, int Q, int N, int L, const double* theta, const double* B_sys, const double* M_red,
                                  const double* dU, double* work, double* out, hipStream_t st);
+void coarse_release(lrbms_ctx* ctx);   // online.hip
+int64_t reduced_precond_size(lrbms_ctx* ctx, int N);
+int launch_reduced_precond_build(lrbms_ctx* ctx, int Q, int N, const double* theta, const double* B_sys, double* work, double* pc,
+                                 hipStream_t st);
 int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N);
 bool fused_supported(lrbms_ctx* ctx, int Q, int N);
 int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V, const double* F, const double* A_diag,
@@ -88,6 +92,7 @@ int lrbms_ctx_create(int device, lrbms_ctx** out) {
 int lrbms_ctx_destroy(lrbms_ctx* ctx) {
   if (!ctx) return LRBMS_E_INVALID;
   (void)hipSetDevice(ctx->device);
+  coarse_release(ctx);
   free_owned(ctx);
   for (int i = 0; i < 3; ++i) {
     if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
@@ -332,6 +337,24 @@ int lrbms_reduced_solve_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu,
   LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red);
   CHECK_PTR(ctx, work); CHECK_PTR(ctx, u);
   return launch_reduced_solve_batch(ctx, Q, N, nmu, theta, B_sys, rhs_red, work, u, rtol, max_iter, info, (hipStream_t)stream);
+}
+
+int64_t lrbms_reduced_precond_size(lrbms_ctx* ctx, int32_t N) {
+  if (!ctx || !ctx->has_mesh || N < 1 || N > 64) return -1;
+  return reduced_precond_size(ctx, N);
+}
+
+int lrbms_reduced_precond_build(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* B_sys, double* work,
+                                double* pc, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, work); CHECK_PTR(ctx, pc);
+  return launch_reduced_precond_build(ctx, Q, N, theta, B_sys, work, pc, (hipStream_t)stream);
+}
+
+int lrbms_reduced_precond_use(lrbms_ctx* ctx, int32_t N, const double* pc) {
+  LRBMS_REQUIRE_MESH(ctx);
+  ctx->user_pc = pc;
+  ctx->user_pc_N = pc ? N : 0;
+  return LRBMS_OK;
 }
 
 int64_t lrbms_fom_solve_work_size(lrbms_ctx* ctx) {

@@ -35,6 +35,12 @@ struct lrbms_ctx {
   std::vector<void*> owned;       // device allocations to free
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // library-owned streams: independent small kernels run concurrently
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  // coarse level of the reduced solvers' preconditioner (online.hip): rocBLAS handle and S x S scratch, created on first use
+  void* blas = nullptr;
+  double* coarse = nullptr;       // [2][S][S] + info
+  long coarse_cap = 0;
+  const double* user_pc = nullptr;   // prebuilt preconditioner the reduced solves use (lrbms_reduced_precond_use), caller-owned
+  int user_pc_N = 0;
   std::string err;
 };
 

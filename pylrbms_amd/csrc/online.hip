@@ -7,6 +7,8 @@
 // bitwise reproducible run to run.
 #include <cstdlib>
 
+#include <rocsolver/rocsolver.h>
+
 #include "lrbms_dev.h"
 
 struct QVec { double v[8]; };
@@ -415,6 +417,174 @@ int launch_reduced_estimate(lrbms_ctx* ctx, int Q, int N, const double* theta, c
   return LRBMS_OK;
 }
 
+// =========================================================================================================
+// Coarse level of the reduced solvers' preconditioner.
+// Block-Jacobi alone has no global coupling: its iteration count doubles with the number of subdomains per direction
+// (36 / 75 / 170 iterations at 8x8 / 16x16 / 32x32 subdomains).  Adding the Galerkin coarse problem on the span of the
+// FIRST local basis vector of every subdomain (the constant shape function the reference starts every basis with,
+// reductor.py:29-31) -- M^-1 = blockdiag(A_ss)^-1 + R0^T (R0 A R0^T)^-1 R0, additive, symmetric positive definite --
+// makes it independent of the subdomain count (~27 iterations).  The coarse matrix is the 5-point S x S matrix of the
+// (0, 0) entries of the combined blocks; it is factorised and inverted once per solve by rocSOLVER (dpotrf + dpotrs on
+// the identity: a plain library factorisation of an S x S matrix, 8 MB at config 3; 2.9 + 0.6 ms) and applied as a dense
+// product per iteration (k_coarse_apply).  If the factorisation fails (a zero first basis vector) the solvers run with
+// block-Jacobi alone.  LRBMS_NO_COARSE=1 switches the coarse level off.  Because the factorisation costs about as much
+// as a whole batched solve, a preconditioner can be built once for a reduced model at a reference parameter
+// (lrbms_reduced_precond_build) and handed to every solve (lrbms_reduced_precond_use): any symmetric positive definite
+// preconditioner is admissible, and one built at the middle of the parameter range serves the whole range.
+namespace {
+
+__global__ __launch_bounds__(256) void k_coarse_init(long S, double* __restrict__ A0, double* __restrict__ A0inv) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < S * S; i += (long)gridDim.x * blockDim.x) {
+    A0[i] = 0.0;
+    A0inv[i] = (i / S == i % S) ? 1.0 : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_coarse_entries(int S, int N, const int* __restrict__ nbr, const double* __restrict__ Amu,
+                                                        double* __restrict__ A0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * 5) return;
+  const int s = i / 5, slot = i - s * 5, t = nbr[i];
+  if (t >= 0) A0[(long)s * S + t] = Amu[((long)s * 5 + slot) * N * N];      // entry (0, 0) of block [s][slot]
+}
+
+// c = A0inv R0 r for nmu <= 16 columns on the fp64 matrix cores:  z[s][0][m] += c[s][m],
+// prz[m][s] += r[s][0][m] c[s][m]  (the coarse part of r . z, added to the partial the update kernel has just written).
+// One workgroup per 16 subdomains (rows of A0inv), 16 waves splitting K = S: every MFMA step takes its A operand from
+// A0inv[k][row] (= A0inv[row][k], the matrix is symmetric: 16 contiguous doubles per k) and its B operand from
+// r[k][0][m]; a wave issues the loads of 16 steps (32 per lane) before its first MFMA; the 16 partial tiles meet in LDS.
+// (A VALU form with a thread per (m, row, k-part) was bound by its load instructions -- 4 useful addresses each: 17.6 us.)
+typedef double d4c __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void k_coarse_apply(int S, int N, int nmu, const double* __restrict__ A0inv,
+                                                       const double* __restrict__ r, double* __restrict__ z,
+                                                       double* __restrict__ prz) {
+  __shared__ double red[16 * 4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4, wave = tid >> 6;
+  const int row0 = blockIdx.x * 16;
+  const long NM = (long)N * nmu;
+  const int nsteps = (S + 3) / 4;
+  const int row = row0 + li;
+  d4c acc = (d4c){0.0, 0.0, 0.0, 0.0};
+  for (int i0 = 0; wave + 16 * i0 < nsteps; i0 += 16) {
+    double a[16], b[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = 4 * (wave + 16 * (i0 + u)) + lk;
+      const bool in = k < S;
+      a[u] = (in && row < S) ? A0inv[(long)k * S + row] : 0.0;
+      b[u] = (in && li < nmu) ? r[(long)k * NM + li] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[(wave * 4 + q) * 64 + lane] = acc[q];
+  __syncthreads();
+  if (tid < 256) {
+    const int q = tid >> 6;                              // D layout: lane holds rows lk + 4 q of the tile, column li
+    double c = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) c += red[(w * 4 + q) * 64 + lane];
+    const int s = row0 + lk + 4 * q;
+    if (s < S && li < nmu) {
+      const long g = (long)s * NM + li;
+      z[g] += c;
+      prz[(long)li * S + s] += r[g] * c;
+    }
+  }
+}
+
+}  // namespace
+
+void coarse_release(lrbms_ctx* ctx) {
+  if (ctx->blas) (void)rocblas_destroy_handle((rocblas_handle)ctx->blas);
+  if (ctx->coarse) (void)hipFree(ctx->coarse);
+  ctx->blas = nullptr;
+  ctx->coarse = nullptr;
+  ctx->coarse_cap = 0;
+}
+
+// Builds A0inv for the combined blocks Amu; *A0inv_out = nullptr if the coarse level is not available (switched off,
+// S too large for a dense S x S inverse, factorisation failed).  Synchronises `st`.
+static int coarse_setup(lrbms_ctx* ctx, int N, const double* Amu, const double** A0inv_out, hipStream_t st) {
+  *A0inv_out = nullptr;
+  const long S = ctx->S;
+  if (getenv("LRBMS_NO_COARSE") != nullptr || S < 4 || S > 4096) return LRBMS_OK;
+  const long need = 2 * S * S + 16;
+  if (ctx->coarse_cap < need) {
+    if (ctx->coarse) (void)hipFree(ctx->coarse);
+    ctx->coarse = nullptr;
+    ctx->coarse_cap = 0;
+    LRBMS_HIP_CHECK(ctx, hipMalloc((void**)&ctx->coarse, sizeof(double) * need));
+    ctx->coarse_cap = need;
+  }
+  if (!ctx->blas) {
+    rocblas_handle h = nullptr;
+    if (rocblas_create_handle(&h) != rocblas_status_success) return lrbms_fail(ctx, LRBMS_E_HIP, "rocblas_create_handle failed");
+    ctx->blas = h;
+  }
+  rocblas_handle h = (rocblas_handle)ctx->blas;
+  if (rocblas_set_stream(h, st) != rocblas_status_success) return lrbms_fail(ctx, LRBMS_E_HIP, "rocblas_set_stream failed");
+  double* A0 = ctx->coarse;
+  double* A0inv = A0 + S * S;
+  rocblas_int* info = (rocblas_int*)(A0inv + S * S);
+  hipLaunchKernelGGL(k_coarse_init, dim3(2048), dim3(256), 0, st, S, A0, A0inv);
+  hipLaunchKernelGGL(k_coarse_entries, dim3((unsigned)((S * 5 + 255) / 256)), dim3(256), 0, st, (int)S, N, ctx->nbr, Amu, A0);
+  LRBMS_LAUNCH_CHECK(ctx);
+  if (rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)S, A0, (rocblas_int)S, info) != rocblas_status_success)
+    return lrbms_fail(ctx, LRBMS_E_HIP, "rocsolver_dpotrf failed");
+  rocblas_int hinfo = 0;
+  LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(&hinfo, info, sizeof(rocblas_int), hipMemcpyDeviceToHost, st));
+  LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (hinfo != 0) return LRBMS_OK;                       // not positive definite (zero first basis vector): no coarse level
+  if (rocsolver_dpotrs(h, rocblas_fill_lower, (rocblas_int)S, (rocblas_int)S, A0, (rocblas_int)S, A0inv, (rocblas_int)S) !=
+      rocblas_status_success)
+    return lrbms_fail(ctx, LRBMS_E_HIP, "rocsolver_dpotrs failed");
+  *A0inv_out = A0inv;
+  return LRBMS_OK;
+}
+
+// Prebuilt preconditioner, caller-owned: pc[0] = 1 if the coarse inverse is present, pc[1] = N, then Dinv [S][N][N], A0inv [S][S]
+int64_t reduced_precond_size(lrbms_ctx* ctx, int N) { return 2 + (int64_t)ctx->S * N * N + (int64_t)ctx->S * ctx->S; }
+
+int launch_reduced_precond_build(lrbms_ctx* ctx, int Q, int N, const double* theta, const double* B_sys, double* work, double* pc,
+                                 hipStream_t st) {
+  if (ctx->S_ext != ctx->S) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_precond_build needs all subdomains on one rank");
+  if (N > 64 || N < 1 || Q < 1 || Q > 8) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_precond_build: bad N / Q");
+  const long S = ctx->S;
+  QVec th;
+  for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
+  double* Amu = work;                                   // lrbms_reduced_solve_work_size doubles are enough
+  double* Dinv = pc + 2;
+  double* A0inv = Dinv + S * N * N;
+  const long per_q = S * 5 * N * N;
+  hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256), 0, st,
+                     per_q, Q, th, B_sys, Amu);
+  hipLaunchKernelGGL(k_block_inverse, dim3((unsigned)S), dim3(64), sizeof(double) * 2 * N * N, st, N, Amu, Dinv, 5, 2);
+  LRBMS_LAUNCH_CHECK(ctx);
+  const double* built = nullptr;
+  if (int rc = coarse_setup(ctx, N, Amu, &built, st)) return rc;
+  const double head[2] = {built ? 1.0 : 0.0, (double)N};
+  LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(pc, head, sizeof(head), hipMemcpyHostToDevice, st));
+  if (built) LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(A0inv, built, sizeof(double) * S * S, hipMemcpyDeviceToDevice, st));
+  LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  return LRBMS_OK;
+}
+
+// Dinv / A0inv of the preconditioner in use (ctx->user_pc) for basis size N, or nullptrs
+static int user_precond(lrbms_ctx* ctx, int N, const double** Dinv, const double** A0inv, hipStream_t st) {
+  *Dinv = nullptr;
+  *A0inv = nullptr;
+  if (!ctx->user_pc || ctx->user_pc_N != N) return LRBMS_OK;
+  double head[2];
+  LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(head, ctx->user_pc, sizeof(head), hipMemcpyDeviceToHost, st));
+  LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if ((int)head[1] != N) return lrbms_fail(ctx, LRBMS_E_INVALID, "the preconditioner in use was built for another basis size");
+  *Dinv = ctx->user_pc + 2;
+  if (head[0] != 0.0 && getenv("LRBMS_NO_COARSE") == nullptr) *A0inv = *Dinv + (long)ctx->S * N * N;
+  return LRBMS_OK;
+}
+
 int64_t reduced_solve_work_size(lrbms_ctx* ctx, int N) {
   const long S = ctx->S;
   return S * 5 * N * N + S * N * N + 5 * S * N + 4 * S + 16;
@@ -424,6 +594,7 @@ namespace {
 
 struct RedCg {
   double *Amu, *Dinv, *r, *z, *p[2], *y, *prz[2], *ppap, *prr;
+  const double* A0inv = nullptr;      // coarse level (coarse_setup), or nullptr
   void carve(double* work, long S, int N) {
     Amu = work;
     Dinv = Amu + S * 5 * N * N;
@@ -463,6 +634,7 @@ int red_cg_run(lrbms_ctx* ctx, int N, RedCg& b, double* x, double ref2, double r
   else
     hipLaunchKernelGGL(k_cg2_update<false>, dim3(S), dim3(256), lds_up, st, S, N, b.Dinv, b.prz[0], b.ppap, 1, x, b.r, b.p[0], b.y, b.z,
                        b.prz[0], b.prr);
+  if (b.A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16), dim3(1024), 0, st, S, N, 1, b.A0inv, b.r, b.z, b.prz[0]);
   LRBMS_LAUNCH_CHECK(ctx);
   double rr = 0.0;
   if (int rc = host_sum(ctx, b.prr, host, &rr, st)) return rc;
@@ -487,6 +659,7 @@ int red_cg_run(lrbms_ctx* ctx, int N, RedCg& b, double* x, double ref2, double r
         hipLaunchKernelGGL(k_cg2_update<false>, dim3(S), dim3(256), lds_up, st, S, N, b.Dinv, b.prz[c], b.ppap, 0, x, b.r, b.p[c], b.y,
                            b.z, b.prz[o], b.prr);
       }
+      if (b.A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16), dim3(1024), 0, st, S, N, 1, b.A0inv, b.r, b.z, b.prz[o]);
     }
     LRBMS_LAUNCH_CHECK(ctx);
     if (int rc = host_sum(ctx, b.prr, host, &rr, st)) return rc;
@@ -494,9 +667,9 @@ int red_cg_run(lrbms_ctx* ctx, int N, RedCg& b, double* x, double ref2, double r
     if (!(rel == rel)) return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced CG: NaN residual (system not SPD?)");
     const double rate = log(rel) / it;                 // log-residual per iteration so far (relative to ref2)
     block = 10;
-    if (rel > rtol && rate < 0.0) {
-      const double need = (log(rtol) - log(rel)) / rate;
-      block = need < 2.0 ? 2 : need > 40.0 ? 40 : (int)need + 1;
+    if (rel > rtol && rate < 0.0) {                    // aim a little short: CG converges superlinearly
+      const double need = 0.8 * (log(rtol) - log(rel)) / rate;
+      block = need < 2.0 ? 2 : need > 40.0 ? 40 : (int)need;
     }
   }
   *its = it;
@@ -520,8 +693,16 @@ int launch_reduced_solve(lrbms_ctx* ctx, int Q, int N, const double* theta, cons
   hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256),
                      0, st, per_q, Q, th, B_sys, b.Amu);
   LRBMS_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, b.Amu, b.Dinv, 5, 2);
   LRBMS_LAUNCH_CHECK(ctx);
+  const double* pcD = nullptr;
+  if (int rc = user_precond(ctx, N, &pcD, &b.A0inv, st)) return rc;
+  if (pcD) {
+    b.Dinv = const_cast<double*>(pcD);                   // read only below
+  } else {
+    hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, b.Amu, b.Dinv, 5, 2);
+    LRBMS_LAUNCH_CHECK(ctx);
+    if (int rc = coarse_setup(ctx, N, b.Amu, &b.A0inv, st)) return rc;
+  }
   // x0 = 0, r0 = b
   LRBMS_HIP_CHECK(ctx, hipMemsetAsync(u, 0, sizeof(double) * vec, st));
   LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(b.r, rhs_red, sizeof(double) * vec, hipMemcpyDeviceToDevice, st));
@@ -556,6 +737,7 @@ int launch_reduced_implicit_euler(lrbms_ctx* ctx, int Q, int N, const double* th
   LRBMS_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, b.Amu, b.Dinv, 5, 2);
   LRBMS_LAUNCH_CHECK(ctx);
+  if (int rc = coarse_setup(ctx, N, b.Amu, &b.A0inv, st)) return rc;
   std::vector<double> host(S);
   long total_it = 0;
   double worst = 0.0;
@@ -710,7 +892,10 @@ __global__ __launch_bounds__(256) void k_bcg_matvec(int S, const int* __restrict
 // per multiply-add and is bound by the LDS pipe (78 us per iteration at config 3 for 131 MB of blocks; this form:
 // 766 -> 968 mu-solves/s).  (Folding the two single-workgroup reductions of an iteration into the producing kernels
 // with a "last workgroup reduces" ticket was measured too: the device-scope fences it needs cost far more on this
-// multi-XCD part than the two launches they save: 348 mu-solves/s.)
+// multi-XCD part than the two launches they save: 348 mu-solves/s.  All 10 block loads of a subdomain in flight at once
+// (inline-asm loads, 70 per lane, consumed block by block behind exact s_waitcnt vmcnt(n)): 1 030 vs 1 190 mu-solves/s --
+// 176 VGPRs leave two workgroups per CU instead of three, and the kernel is not short of loads in flight but of
+// bandwidth: 131 MB per launch stream at 2.5 TB/s here, 3.8 TB/s is the most any kernel of this library reaches.)
 typedef double d4m __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_bcg_matvec_mfma(int S, const int* __restrict__ nbr, int Q, int N, int nmu, ThetaBatch th,
                                                          const double* __restrict__ B_sys, const double* __restrict__ z,
@@ -980,12 +1165,22 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   double* partial2 = partial + (long)S * nmu;
   double* scal = partial2 + (long)S * nmu;              // rz, alpha, beta, rr (BMAX each)
   const long per_q = (long)S * 5 * N * N;
-  hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256), 0, st,
-                     per_q, Q, mean, B_sys, Amu);
-  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, Amu, Dinv, 5, 2);
   hipLaunchKernelGGL(k_bcg_init, dim3((unsigned)((vec + 255) / 256 > 4096 ? 4096 : (vec + 255) / 256)), dim3(256), 0, st, vec, nmu,
                      rhs_red, u, r);
   LRBMS_LAUNCH_CHECK(ctx);
+  const double* A0inv = nullptr;
+  const double* pcD = nullptr;
+  if (int rc = user_precond(ctx, N, &pcD, &A0inv, st)) return rc;
+  if (pcD) {
+    Dinv = const_cast<double*>(pcD);                     // prebuilt (lrbms_reduced_precond_build / _use): read only below
+  } else {                                               // block inverses and coarse level at the batch-mean theta
+    hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256), 0, st,
+                       per_q, Q, mean, B_sys, Amu);
+    hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, Amu, Dinv, 5, 2);
+    LRBMS_LAUNCH_CHECK(ctx);
+    if (int rc = coarse_setup(ctx, N, Amu, &A0inv, st)) return rc;
+  }
+  if (nmu > 16) A0inv = nullptr;                         // k_coarse_apply handles at most 16 columns
   const size_t lds_upd = sizeof(double) * 3 * NM;
   // matrix-core form for batches of at most 16 parameters (LRBMS_BCG_VALU=1 forces the VALU form)
   const int kp = (N + 3) & ~3, ldb = N + ((4 - N % 8) + 8) % 8, nrp = (N + 15) & ~15;
@@ -1001,6 +1196,7 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
     hipLaunchKernelGGL(k_bcg_update_mfma, dim3(S), dim3(256), lds_upd_mfma, st, N, nmu, Dinv, scal, 1, u, r, p0, y, z, partial, partial2);
   else
     hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, st, N, nmu, Dinv, scal, 1, u, r, p0, y, z, partial, partial2);
+  if (A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16), dim3(1024), 0, st, S, N, nmu, A0inv, r, z, partial);
   hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, st, S, nmu, partial, partial2, scal, 0);
   LRBMS_LAUNCH_CHECK(ctx);
   double host[4 * BMAX];
@@ -1018,11 +1214,11 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   }
   double rel = 1.0;
   int it = 0;
-  const int check_every = 10;
+  int block = 10;                                        // iterations until the next look at the residuals (see red_cg_run)
   double* pin = p0;
   double* pout = p1;
   while (it < max_iter) {
-    for (int k = 0; k < check_every && it < max_iter; ++k, ++it) {
+    for (int k = 0; k < block && it < max_iter; ++k, ++it) {
       if (use_mfma)
         hipLaunchKernelGGL(k_bcg_matvec_mfma, dim3(S), dim3(256), lds_mfma, st, S, ctx->nbr, Q, N, nmu, th, B_sys, z, pin,
                            scal + 2 * BMAX, it == 0 ? 1 : 0, pout, y, partial);
@@ -1038,6 +1234,7 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
                            partial2);
       else
         hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, st, N, nmu, Dinv, scal, 0, u, r, pout, y, z, partial, partial2);
+      if (A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16), dim3(1024), 0, st, S, N, nmu, A0inv, r, z, partial);
       hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, st, S, nmu, partial, partial2, scal, 2);
       double* tmp = pin; pin = pout; pout = tmp;
     }
@@ -1051,6 +1248,14 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
       rel = rm > rel ? rm : rel;
     }
     if (rel <= rtol) break;
+    // CG converges superlinearly, so the average rate so far overestimates what is left: aim a little short (a further
+    // look costs one host round trip, a wasted iteration three to four kernels)
+    const double rate = log(rel) / it;
+    block = 10;
+    if (rate < 0.0) {
+      const double need = 0.8 * (log(rtol) - log(rel)) / rate;
+      block = need < 2.0 ? 2 : need > 40.0 ? 40 : (int)need;
+    }
   }
   if (info) { info[0] = it; info[1] = rel; }
   if (rel > rtol) return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve_batch: CG did not reach rtol");

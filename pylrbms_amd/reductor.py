@@ -48,19 +48,53 @@ class ReducedDiscretization:
     def parse_parameter(self, mu):
         return self.d.parse_parameter(mu)
 
+    def _reference_theta(self):
+        """theta at the middle of the parameter range (the reference parameter of the prebuilt preconditioner)."""
+        ps = self.parameter_space
+        mid = 0.5 * (ps.minimum + ps.maximum)
+        mu = {k: np.full(shape, mid) for k, shape in ps.parameter_type.items()}
+        return self.d.theta(mu)
+
+    def _solve_with_preconditioner(self, ctx, B_sys, fn):
+        """Run ``fn()`` (reduced solves on ``ctx``) with this model's two-level preconditioner, built once at the middle
+        of the parameter range (``lrbms_reduced_precond_build``; any SPD preconditioner is admissible)."""
+        cache = self.__dict__.setdefault('_pc', {})
+        if id(ctx) not in cache:
+            cache[id(ctx)] = ctx.reduced_precond_build(self._reference_theta(), B_sys)
+        ctx.reduced_precond_use(cache[id(ctx)])
+        try:
+            return fn()
+        finally:
+            ctx.reduced_precond_use(None)
+
     def solve(self, mu, inverse_options=None):
         """``rd.solve(mu)`` (online_adaptive_lrbms.py:141): (sum_q theta_q A_q^red) u = b^red.  The reference does a
-        dense LU of the unblocked matrix; here block-Jacobi PCG on the block-sparse system (``lrbms_reduced_solve``)."""
+        dense LU of the unblocked matrix; here PCG on the block-sparse system (``lrbms_reduced_solve``) with the inverse
+        diagonal blocks plus a coarse level on the first local basis vectors as preconditioner."""
         eng = self.d.engine
+        theta = self.d.theta(mu)
         if eng.S_ext != eng.S:
             ctx, B_all, rhs_all = self._global_online()
-            u, info = ctx.reduced_solve(self.d.theta(mu), B_all, rhs_all)
+            u, info = self._solve_with_preconditioner(ctx, B_all, lambda: ctx.reduced_solve(theta, B_all, rhs_all))
             self.last_solve_info = info
             u = u[self._torch.as_tensor(eng.local, device=u.device)]
             return ReducedVectorArray(u.reshape(eng.S, self.N, 1))
-        u, info = eng.reduced_solve(self.d.theta(mu), self.B_sys, self.rhs_red)
+        u, info = self._solve_with_preconditioner(eng.ctx, self.B_sys, lambda: eng.reduced_solve(theta, self.B_sys, self.rhs_red))
         self.last_solve_info = info
         return ReducedVectorArray(u.reshape(eng.S, self.N, 1))
+
+    def solve_batch(self, mus):
+        """Parameter sweep: ``len(mus)`` reduced solutions (batches of <= 16 through ``lrbms_reduced_solve_batch``);
+        returns one ``ReducedVectorArray`` with ``len(mus)`` vectors."""
+        eng = self.d.engine
+        if eng.S_ext != eng.S:
+            raise NotImplementedError('solve_batch on a sharded discretization')
+        thetas = np.array([self.d.theta(mu) for mu in mus])
+        nb = max(1, min(16, 1280 // self.N))
+
+        def run():
+            return [eng.ctx.reduced_solve_batch(thetas[b0:b0 + nb], self.B_sys, self.rhs_red)[0] for b0 in range(0, len(thetas), nb)]
+        return ReducedVectorArray(self._torch.cat(self._solve_with_preconditioner(eng.ctx, self.B_sys, run), dim=2))
 
     def _global_online(self):
         """Sharded discretization: the reduced system is small (S x 5 blocks of N x N per affine component), so every rank

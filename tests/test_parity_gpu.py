@@ -268,3 +268,49 @@ def test_batched_reduced_solve_matches_single_and_oracle():
             scale = max(np.abs(ref_row).max(), 1e-300)
             assert np.abs(eta_b[row, :, m] - ref_row).max() < 1e-9 * scale
             assert np.abs(eta_s[row] - ref_row).max() < 1e-9 * scale
+
+
+def test_two_level_preconditioner_and_prebuilt_form(monkeypatch):
+    """The coarse level of the reduced solvers: same solutions as the oracle's dense solves with it, without it
+    (LRBMS_NO_COARSE) and with a preconditioner prebuilt at ANOTHER parameter (lrbms_reduced_precond_build / _use);
+    fewer iterations with it; basis size mismatch of a prebuilt preconditioner falls back to per-call ones."""
+    from pylrbms_amd import multiscale_problem
+    from oracle.lrbms import OracleReductor
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': [8, 8], 'coarse_per_subdomain': 2})
+    eng = _engine(p)
+    d = oracle_from_problem(p)
+    N = 5
+    V = energy_orthonormalize(make_bases(d.S, d.n, N, seed=4), d)
+    buf = eng.project_and_estimate(eng.ctx.from_numpy(V))
+    B, rhs = buf['sys'][0], buf['sys'][1]
+    rd = OracleReductor(d, [V[ii] for ii in range(d.S)]).reduce()
+    mus = [0.1, 0.37, 1.0]
+    thetas = np.stack([theta_of(p, mu) for mu in mus])
+    refs = [np.stack(rd.solve(mu)) for mu in mus]
+
+    def check(tag):
+        ub, info_b = eng.ctx.reduced_solve_batch(thetas, B, rhs)
+        its = [info_b['iterations']]
+        for m in range(len(mus)):
+            us, info = eng.reduced_solve(thetas[m], B, rhs)
+            its.append(info['iterations'])
+            assert np.linalg.norm(us.cpu().numpy() - refs[m]) < 1e-10 * np.linalg.norm(refs[m]), tag
+            assert np.linalg.norm(ub[:, :, m].cpu().numpy() - refs[m]) < 1e-10 * np.linalg.norm(refs[m]), tag
+        return its
+
+    with_coarse = check('per-call two-level')
+    monkeypatch.setenv('LRBMS_NO_COARSE', '1')
+    jacobi_only = check('block-Jacobi only')
+    monkeypatch.delenv('LRBMS_NO_COARSE')
+    assert max(with_coarse) < min(jacobi_only)
+    pc = eng.ctx.reduced_precond_build(theta_of(p, 0.55), B)
+    eng.ctx.reduced_precond_use(pc)
+    prebuilt = check('prebuilt at mu = 0.55')
+    assert max(prebuilt) < min(jacobi_only)
+    # a preconditioner for another basis size is ignored (the context keys it on N)
+    buf3 = eng.project_and_estimate(eng.ctx.from_numpy(np.ascontiguousarray(V[:, :, :3])))
+    u3, _ = eng.reduced_solve(thetas[0], buf3['sys'][0], buf3['sys'][1])
+    rd3 = OracleReductor(d, [V[ii][:, :3] for ii in range(d.S)]).reduce()
+    ref3 = np.stack(rd3.solve(mus[0]))
+    assert np.linalg.norm(u3.cpu().numpy() - ref3) < 1e-10 * np.linalg.norm(ref3)
+    eng.ctx.reduced_precond_use(None)
