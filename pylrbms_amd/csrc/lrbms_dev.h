@@ -90,7 +90,11 @@ static inline int lrbms_fail(lrbms_ctx* ctx, int code, const std::string& msg) {
 
 #define LRBMS_LAUNCH_CHECK(ctx) LRBMS_HIP_CHECK(ctx, hipGetLastError())
 
-int build_template_tables(lrbms_ctx* ctx);   // fused.hip; called at the end of lrbms_mesh_upload
+int build_template_tables(lrbms_ctx* ctx);
+// dense coarse level of the Krylov preconditioners (online.hip)
+int coarse_begin(lrbms_ctx* ctx, double** A0_out, hipStream_t st);
+int coarse_finish(lrbms_ctx* ctx, const double** A0inv_out, hipStream_t st);
+int launch_coarse_apply(lrbms_ctx* ctx, int N, int nmu, const double* A0inv, const double* r, double* z, double* prz, hipStream_t st);   // fused.hip; called at the end of lrbms_mesh_upload
 
 // launchers implemented in the other translation units
 int launch_assemble_swipdg(lrbms_ctx*, int Q, const double* lam, double* A_diag, double* A_cpl, hipStream_t);

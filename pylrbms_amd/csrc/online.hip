@@ -504,10 +504,12 @@ void coarse_release(lrbms_ctx* ctx) {
   ctx->coarse_cap = 0;
 }
 
-// Builds A0inv for the combined blocks Amu; *A0inv_out = nullptr if the coarse level is not available (switched off,
-// S too large for a dense S x S inverse, factorisation failed).  Synchronises `st`.
-static int coarse_setup(lrbms_ctx* ctx, int N, const double* Amu, const double** A0inv_out, hipStream_t st) {
-  *A0inv_out = nullptr;
+// The dense coarse machinery, shared with the full-order solver (fom.hip):
+//   coarse_begin   scratch A0 (zeroed) for the caller to fill with the S x S coarse matrix (either triangle, column major);
+//                  *A0 = nullptr if the coarse level is not available (switched off, S too small or too large)
+//   coarse_finish  factorises A0 and forms its inverse; *A0inv_out = nullptr if A0 is not positive definite.  Synchronises.
+int coarse_begin(lrbms_ctx* ctx, double** A0_out, hipStream_t st) {
+  *A0_out = nullptr;
   const long S = ctx->S;
   if (getenv("LRBMS_NO_COARSE") != nullptr || S < 4 || S > 4096) return LRBMS_OK;
   const long need = 2 * S * S + 16;
@@ -518,6 +520,15 @@ static int coarse_setup(lrbms_ctx* ctx, int N, const double* Amu, const double**
     LRBMS_HIP_CHECK(ctx, hipMalloc((void**)&ctx->coarse, sizeof(double) * need));
     ctx->coarse_cap = need;
   }
+  hipLaunchKernelGGL(k_coarse_init, dim3(2048), dim3(256), 0, st, S, ctx->coarse, ctx->coarse + S * S);
+  LRBMS_LAUNCH_CHECK(ctx);
+  *A0_out = ctx->coarse;
+  return LRBMS_OK;
+}
+
+int coarse_finish(lrbms_ctx* ctx, const double** A0inv_out, hipStream_t st) {
+  *A0inv_out = nullptr;
+  const long S = ctx->S;
   if (!ctx->blas) {
     rocblas_handle h = nullptr;
     if (rocblas_create_handle(&h) != rocblas_status_success) return lrbms_fail(ctx, LRBMS_E_HIP, "rocblas_create_handle failed");
@@ -528,9 +539,6 @@ static int coarse_setup(lrbms_ctx* ctx, int N, const double* Amu, const double**
   double* A0 = ctx->coarse;
   double* A0inv = A0 + S * S;
   rocblas_int* info = (rocblas_int*)(A0inv + S * S);
-  hipLaunchKernelGGL(k_coarse_init, dim3(2048), dim3(256), 0, st, S, A0, A0inv);
-  hipLaunchKernelGGL(k_coarse_entries, dim3((unsigned)((S * 5 + 255) / 256)), dim3(256), 0, st, (int)S, N, ctx->nbr, Amu, A0);
-  LRBMS_LAUNCH_CHECK(ctx);
   if (rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)S, A0, (rocblas_int)S, info) != rocblas_status_success)
     return lrbms_fail(ctx, LRBMS_E_HIP, "rocsolver_dpotrf failed");
   rocblas_int hinfo = 0;
@@ -542,6 +550,24 @@ static int coarse_setup(lrbms_ctx* ctx, int N, const double* Amu, const double**
     return lrbms_fail(ctx, LRBMS_E_HIP, "rocsolver_dpotrs failed");
   *A0inv_out = A0inv;
   return LRBMS_OK;
+}
+
+int launch_coarse_apply(lrbms_ctx* ctx, int N, int nmu, const double* A0inv, const double* r, double* z, double* prz, hipStream_t st) {
+  hipLaunchKernelGGL(k_coarse_apply, dim3((ctx->S + 15) / 16), dim3(1024), 0, st, ctx->S, N, nmu, A0inv, r, z, prz);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
+}
+
+// Coarse inverse for the combined reduced blocks Amu (nullptr if not available).  Synchronises `st`.
+static int coarse_setup(lrbms_ctx* ctx, int N, const double* Amu, const double** A0inv_out, hipStream_t st) {
+  *A0inv_out = nullptr;
+  double* A0 = nullptr;
+  if (int rc = coarse_begin(ctx, &A0, st)) return rc;
+  if (!A0) return LRBMS_OK;
+  const long S = ctx->S;
+  hipLaunchKernelGGL(k_coarse_entries, dim3((unsigned)((S * 5 + 255) / 256)), dim3(256), 0, st, (int)S, N, ctx->nbr, Amu, A0);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return coarse_finish(ctx, A0inv_out, st);
 }
 
 // Prebuilt preconditioner, caller-owned: pc[0] = 1 if the coarse inverse is present, pc[1] = N, then Dinv [S][N][N], A0inv [S][S]
