@@ -494,6 +494,33 @@ __global__ __launch_bounds__(1024) void k_coarse_apply(int S, int N, int nmu, co
   }
 }
 
+// The same for ONE column (single-parameter reduced solve, full-order solve): one wave per coarse row, every lane holds
+// 16 entries of the row and of the coarse residual (32 loads in flight, one round trip), then a butterfly.
+__global__ __launch_bounds__(256) void k_coarse_apply1(int S, long NM, const double* __restrict__ A0inv, const double* __restrict__ r,
+                                                       double* __restrict__ z, double* __restrict__ prz) {
+  const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= S) return;
+  const double* row = A0inv + (long)s * S;
+  double acc = 0.0;
+  for (int base = 0; base < S; base += 1024) {
+    double a[16], b[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = base + lane + 64 * k;
+      a[k] = i < S ? row[i] : 0.0;
+      b[k] = i < S ? r[(long)i * NM] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += a[k] * b[k];
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) {
+    const long g = (long)s * NM;
+    z[g] += acc;
+    prz[s] += r[g] * acc;
+  }
+}
+
 }  // namespace
 
 void coarse_release(lrbms_ctx* ctx) {
@@ -553,7 +580,10 @@ int coarse_finish(lrbms_ctx* ctx, const double** A0inv_out, hipStream_t st) {
 }
 
 int launch_coarse_apply(lrbms_ctx* ctx, int N, int nmu, const double* A0inv, const double* r, double* z, double* prz, hipStream_t st) {
-  hipLaunchKernelGGL(k_coarse_apply, dim3((ctx->S + 15) / 16), dim3(1024), 0, st, ctx->S, N, nmu, A0inv, r, z, prz);
+  if (nmu == 1)
+    hipLaunchKernelGGL(k_coarse_apply1, dim3((ctx->S + 3) / 4), dim3(256), 0, st, ctx->S, (long)N, A0inv, r, z, prz);
+  else
+    hipLaunchKernelGGL(k_coarse_apply, dim3((ctx->S + 15) / 16), dim3(1024), 0, st, ctx->S, N, nmu, A0inv, r, z, prz);
   LRBMS_LAUNCH_CHECK(ctx);
   return LRBMS_OK;
 }
@@ -660,7 +690,8 @@ int red_cg_run(lrbms_ctx* ctx, int N, RedCg& b, double* x, double ref2, double r
   else
     hipLaunchKernelGGL(k_cg2_update<false>, dim3(S), dim3(256), lds_up, st, S, N, b.Dinv, b.prz[0], b.ppap, 1, x, b.r, b.p[0], b.y, b.z,
                        b.prz[0], b.prr);
-  if (b.A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16), dim3(1024), 0, st, S, N, 1, b.A0inv, b.r, b.z, b.prz[0]);
+  if (b.A0inv)
+    if (int rc = launch_coarse_apply(ctx, N, 1, b.A0inv, b.r, b.z, b.prz[0], st)) return rc;
   LRBMS_LAUNCH_CHECK(ctx);
   double rr = 0.0;
   if (int rc = host_sum(ctx, b.prr, host, &rr, st)) return rc;
@@ -685,7 +716,8 @@ int red_cg_run(lrbms_ctx* ctx, int N, RedCg& b, double* x, double ref2, double r
         hipLaunchKernelGGL(k_cg2_update<false>, dim3(S), dim3(256), lds_up, st, S, N, b.Dinv, b.prz[c], b.ppap, 0, x, b.r, b.p[c], b.y,
                            b.z, b.prz[o], b.prr);
       }
-      if (b.A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16), dim3(1024), 0, st, S, N, 1, b.A0inv, b.r, b.z, b.prz[o]);
+      if (b.A0inv)
+        if (int rc = launch_coarse_apply(ctx, N, 1, b.A0inv, b.r, b.z, b.prz[o], st)) return rc;
     }
     LRBMS_LAUNCH_CHECK(ctx);
     if (int rc = host_sum(ctx, b.prr, host, &rr, st)) return rc;
