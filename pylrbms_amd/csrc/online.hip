@@ -966,10 +966,11 @@ __global__ __launch_bounds__(256) void k_bcg_matvec_mfma(int S, const int* __res
   const int NM = N * nmu;
   const int KP = (N + 3) & ~3;                         // K padded to a multiple of 4 (zero rows / columns)
   const int LDB = N + ((4 - N % 8) + 8) % 8;           // row stride == 4 (mod 8) doubles: conflict-free A-operand reads
-  const int NR = (N + 15) & ~15;                       // rows padded to whole tiles (zero rows)
+  // LDS: 40 032 B at N = 40, so that FOUR workgroups fit a CU and all 1 024 of config 3 are resident at once (with the
+  // 47.6 KB of a tile-padded block and a separate product buffer only three fit: a second, third-full round of workgroups)
   double* Pt = lds;                                    // [5][KP][16]
-  double* Bs = Pt + 5 * KP * 16;                       // [NR][LDB]
-  double* prod = Bs + NR * LDB;                        // [N][16]
+  double* Bs = Pt + 5 * KP * 16;                       // [N + 1][LDB]: the block, row N stays zero (rows of a partial tile)
+  double* prod = Bs;                                   // [N][16], after the last block has been multiplied
   for (int i = tid; i < 5 * KP * 16; i += 256) {
     const int slot = i / (KP * 16), rem = i - slot * KP * 16, c = rem >> 4, m = rem & 15;
     const int s2 = nbr[s * 5 + slot];
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(256) void k_bcg_matvec_mfma(int S, const int* __res
     }
     Pt[i] = v;
   }
-  for (int i = tid; i < NR * LDB; i += 256) Bs[i] = 0.0;
+  for (int i = tid; i < (N + 1) * LDB; i += 256) Bs[i] = 0.0;
   double thq[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) thq[q] = li < nmu ? th.v[li * 8 + q] : 0.0;
@@ -1019,14 +1020,15 @@ __global__ __launch_bounds__(256) void k_bcg_matvec_mfma(int S, const int* __res
 #pragma unroll
       for (int qq = 1; qq < 8; ++qq)
         if (q == qq) thv = thq[qq];
+      const int ra = wave * 16 + li < N ? wave * 16 + li : N;
       for (int kk = 0; kk < KP; kk += 4) {
-        const double a = Bs[(wave * 16 + li) * LDB + kk + lk];
+        const double a = Bs[ra * LDB + kk + lk];
         const double bv = thv * pslot[(kk + lk) * 16 + li];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
       }
     }
   }
-  __syncthreads();
+  __syncthreads();                                     // all reads of Bs are done: it becomes the product buffer
   // D layout: lane holds rows lk + 4 r of its tile, column li
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1241,8 +1243,9 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   if (nmu > 16) A0inv = nullptr;                         // k_coarse_apply handles at most 16 columns
   const size_t lds_upd = sizeof(double) * 3 * NM;
   // matrix-core form for batches of at most 16 parameters (LRBMS_BCG_VALU=1 forces the VALU form)
-  const int kp = (N + 3) & ~3, ldb = N + ((4 - N % 8) + 8) % 8, nrp = (N + 15) & ~15;
-  const size_t lds_mfma = sizeof(double) * ((size_t)5 * kp * 16 + (size_t)nrp * ldb + (size_t)N * 16);
+  const int kp = (N + 3) & ~3, ldb = N + ((4 - N % 8) + 8) % 8;
+  const size_t bs_lds = (size_t)(N + 1) * ldb > (size_t)N * 16 ? (size_t)(N + 1) * ldb : (size_t)N * 16;   // block, later the products
+  const size_t lds_mfma = sizeof(double) * ((size_t)5 * kp * 16 + bs_lds);
   const bool use_mfma = nmu <= 16 && getenv("LRBMS_BCG_VALU") == nullptr;
   if (use_mfma && lds_mfma > 64 * 1024)
     LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
