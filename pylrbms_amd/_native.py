@@ -334,6 +334,35 @@ class NativeContext:
             self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._stream())
         self._check(rc, 'lrbms_project_estimate_fused_phase')
 
+    def bind_project_estimate_fused(self, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, sys_out, gram_out):
+        """The same call with the argument checks and the pointer marshalling done ONCE: returns ``run(phase=0)``.  A
+        sharded step makes three library calls on ~0.2 ms of device work; checking 23 tensors per call made the host
+        the slower side.  The closure keeps the tensors alive; it must not outlive a change of their storage."""
+        Q, N, S = A_diag.shape[0], V.shape[2], self.S
+        W, C = 5 * N, 5 * Q * N
+        if work.numel() < self.fused_work_size(Q, N):
+            raise NativeError('project_estimate_fused: work too small')
+        B_sys, rhs_red, E_red, M_red = sys_out
+        G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = gram_out
+        ptrs = (self._ptr(V, (self.S_ext, self.n, N), 'V'), self._ptr(F, (Q, S, self.n_rt, 6), 'F'),
+                self._ptr(A_diag, (Q, S, self.n_T, 4, 9), 'A_diag'), self._ptr(A_cpl, (Q, S, 4, self.ncf, 9), 'A_cpl'),
+                self._ptr(P_diag, (S, self.n_T, 4, 9), 'P_diag'), self._ptr(b, (S, self.n), 'b'),
+                self._ptr(ebar, (S, self.n_T), 'ebar'), self._ptr(caa, (Q, Q, S, self.n_T), 'caa'),
+                self._ptr(Aab, (Q, S, self.n_T, 3, 3), 'Aab'), self._ptr(Bbb, (S, self.n_T, 3, 3), 'Bbb'),
+                c_vp(work.data_ptr()), self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'), self._ptr(rhs_red, (S, N), 'rhs_red'),
+                self._ptr(E_red, (S, N, N), 'E_red'), self._ptr(M_red, (S, N, N), 'M_red'),
+                self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, Q * N, Q * N), 'G_rdd'),
+                self._ptr(G_bb, (S, 9, Q * N, Q * N), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
+                self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'))
+        keep = (V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, sys_out, gram_out)
+        fn, handle, cur, dev = self.lib.lrbms_project_estimate_fused_phase, self.handle, self.torch.cuda.current_stream, self.device
+
+        def run(phase=0, _keep=keep):
+            rc = fn(handle, phase, Q, N, *ptrs, c_vp(cur(dev).cuda_stream))
+            if rc != 0:
+                self._check(rc, 'lrbms_project_estimate_fused_phase')
+        return run
+
     # ------------------------------------------------------------------ online
     def reduced_estimate(self, theta, u, grams, f2, ceps, hdiam):
         G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = grams

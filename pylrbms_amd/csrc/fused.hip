@@ -1548,9 +1548,18 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // trace at 128 subdomains: every side chain ends before k_f1 does)
   hipStream_t s_rt = multi ? ctx->aux[0] : st, s_f23 = multi ? ctx->aux[1] : st, s_nc = multi ? ctx->aux[2] : st;
   hipStream_t side = s_nc;
-  if (multi) {
+  // only the library streams that get work in this call are forked and joined (an event operation costs 4 - 5 us of host
+  // time on this runtime, and a sharded step makes three calls on ~0.2 ms of device work: with all three streams forked
+  // and joined in every call the host was the slower side, 232 us per step at 128 subdomains against 202 us now); a
+  // library stream that IS the caller's stream (the sharded choreography runs phase 2 on stream 0) needs neither.
+  // (Replaying the phases as captured hipGraphs instead was measured too: one graph launch costs ~35 us of host time and
+  // the replay loses the overlap between the branches, 272 us per step.)
+  const bool use_aux[3] = {multi && do_b && ctx->aux[0] != st, multi && do_a && ctx->aux[1] != st,
+                           multi && (do_a || do_b) && ctx->aux[2] != st};
+  if (use_aux[0] || use_aux[1] || use_aux[2]) {
     LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
-    for (int i = 0; i < 3; ++i) LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+    for (int i = 0; i < 3; ++i)
+      if (use_aux[i]) LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
   }
 
   // ---- F1: build the column-group list and launch in slices of at most F1_YW / N groups
@@ -1671,11 +1680,10 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
-  if (multi) {
-    for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 3; ++i)
+    if (use_aux[i]) {
       LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
       LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_join[i], 0));
     }
-  }
   return LRBMS_OK;
 }

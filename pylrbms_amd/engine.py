@@ -141,26 +141,43 @@ class Engine:
             raise NativeError('buffers were allocated for N={}'.format(buf['N']))
         c = self.ctx
         if fused is None:
-            fused = c.fused_supported(self.Q, N)
+            cache = self.__dict__.setdefault('_fused_ok', {})
+            if N not in cache:
+                cache[N] = c.fused_supported(self.Q, N)
+            fused = cache[N]
         if fused:
             args = (V, self.F, self.A_diag, self.A_cpl, self.P_diag, self.b, self.ebar, self.caa, self.Aab, self.Bbb,
                     buf['work'], buf['sys'], buf['grams'])
+            # argument checks / pointer marshalling once per (V, buffers) pair: a sharded step makes three library calls on
+            # ~0.2 ms of device work, so the host side of a step matters (tools/phase_time.py)
+            key = (V.data_ptr(), buf['work'].data_ptr(), buf['grams'][0].data_ptr(), buf['sys'][0].data_ptr())
+            bound = self.__dict__.get('_bound_pass')
+            if bound is None or bound[0] != key:
+                bound = (key, c.bind_project_estimate_fused(*args))
+                self._bound_pass = bound
+            run = bound[1]
             if halo is None:
-                c.project_estimate_fused(*args)
+                run(0)
             else:
                 torch = c.torch
                 main = torch.cuda.current_stream()
                 side = c.aux_stream(0)     # a library stream, not a fresh one: HIP maps streams onto few hardware queues
+                if '_step_events' not in self.__dict__:
+                    self._step_events = (torch.cuda.Event(), torch.cuda.Event())
+                prepared, done = self._step_events
                 finish = halo.start(V)                      # pack on the main stream + asynchronous collective
-                c.project_estimate_fused(*args, phase=3)    # R_self, Avg_self (local slabs only)
-                prepared = torch.cuda.Event()
+                run(3)                                      # R_self, Avg_self (local slabs only)
                 prepared.record(main)
-                c.project_estimate_fused(*args, phase=4)    # k_f1, k_f2, k_f3 on the main stream (local slabs only)
-                with torch.cuda.stream(side):               # beside them, as soon as the halo is there:
+                run(4)                                      # k_f1, k_f2, k_f3 on the main stream (local slabs only)
+                torch.cuda.set_stream(side)                 # beside them, as soon as the halo is there (set_stream pair and
+                try:                                        # persistent events: the context manager + wait_stream cost 20 us)
                     side.wait_event(prepared)
                     finish()                                # side stream waits for the collective, unpacks into V[S:]
-                    c.project_estimate_fused(*args, phase=2)    # R_side, Avg_side, thin kernels, coupling blocks
-                main.wait_stream(side)
+                    run(2)                                  # R_side, Avg_side, thin kernels, coupling blocks
+                    done.record(side)
+                finally:
+                    torch.cuda.set_stream(main)
+                main.wait_event(done)
             return buf
         if halo is not None:
             halo(V)

@@ -39,3 +39,28 @@ for _ in range(200):
 host = (time.perf_counter() - t0) / 200
 torch.cuda.synchronize()
 print('host time of one library call through NativeContext (phase 3, enqueue only): %.1f us' % (1e6 * host))
+
+# host side of one sharded step (pack + phases 3 / 4 / 2 + stream choreography, exchange replaced by two torch index ops of
+# the same size): enqueue-only time per step.  If it exceeds the device time per step the multi-GPU run is launch-bound.
+idx = torch.arange(0, min(eng.S * eng.t.n, 4096), device=V.device)
+flat = V.view(-1, N)
+send = torch.empty(len(idx), N, dtype=V.dtype, device=V.device)
+
+
+class _PackOnly:
+    def start(self, V):
+        torch.index_select(flat, 0, idx, out=send)
+        return lambda: flat.index_copy_(0, idx, send)
+
+
+h = _PackOnly()
+for _ in range(5):
+    eng.project_and_estimate(V, buf, halo=h)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(200):
+    eng.project_and_estimate(V, buf, halo=h)
+host = (time.perf_counter() - t0) / 200
+torch.cuda.synchronize()
+total = (time.perf_counter() - t0) / 200
+print('sharded step: host enqueue %.1f us per step, device-paced total %.1f us per step' % (1e6 * host, 1e6 * total))
