@@ -1224,7 +1224,10 @@ struct ThinRtArgs {
   int Q, N, S;
 };
 
-__global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
+// at least 6 waves per SIMD (80 VGPRs, 28 bytes of scratch in the prologue): the kernel is bound by its 1 GB of writes,
+// but with 5 waves per SIMD the stores were held up by LDS and FMA latency (a chunked fill with 32 dependent FMAs per store
+// reaches 5.2 TB/s, tools/ubench/write_pattern.hip; this kernel 3.9 -> 4.2 TB/s; 8 waves spill in the loop: 375 us)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_thin_rt(Tmpl t, ThinRtArgs a) {
   extern __shared__ double lds[];
   const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
   const int Q = a.Q, N = a.N, QN = Q * N, C = 5 * QN, S = a.S;
@@ -1286,9 +1289,66 @@ __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
   }
   __syncthreads();
   // the two non-zero blocks of block-row a: [a, a] (rank-np with the side-face scalars) and [a, self].
-  // Register tiles of 4 rows x 1 column, lanes over consecutive columns: per side face 4 broadcast + 3 lane reads from
-  // LDS feed 16 outputs (one output per thread needed 5 reads for 4 outputs, and the LDS pipe competed with the HBM
-  // writes that bound this kernel); every store instruction still writes consecutive doubles across the lanes.
+  if ((QN & 1) == 0) {
+    // Register tiles of 2 rows x 2 columns, lanes over consecutive column PAIRS: every store is 16 bytes per lane and a
+    // wave's store instruction covers whole 128-byte lines (rows are 8 QN bytes = whole lines apart, 40 lanes per row at
+    // QN = 80) -- the kernel is bound by its 1 GB of writes, and 8-byte stores that start and end inside lines reached
+    // 3.7 TB/s where a plain fill reaches 6.5 (tools/ubench/write_bw.py).  Per side face 3 lane reads (16 bytes) and 2
+    // broadcast reads from LDS feed 16 outputs.
+    const int hp = QN / 2, trows = (QN + 1) / 2;
+    for (int it = tid; it < trows * hp; it += 256) {
+      const int tr = it / hp, cc = 2 * (it - tr * hp), r0 = 2 * tr, r1 = r0 + 1 < QN ? r0 + 1 : QN - 1;
+      double2 vb[2], vd[2], wb[2], wd[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) vb[i] = vd[i] = wb[i] = wd[i] = make_double2(0.0, 0.0);
+      for (int p = 0; p < np; ++p) {
+        const double2 rc = *reinterpret_cast<const double2*>(Ra + p * QN + cc);
+        const double2 yc = *reinterpret_cast<const double2*>(Yb + p * QN + cc);
+        const double2 dc = *reinterpret_cast<const double2*>(Dp + p * QN + cc);
+        const double k0 = sc[p * 3], k1 = sc[p * 3 + 1];
+        const double ra[2] = {Ra[p * QN + r0], Ra[p * QN + r1]};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          vb[i].x += ra[i] * (k0 * rc.x); vb[i].y += ra[i] * (k0 * rc.y);
+          vd[i].x += ra[i] * (k1 * rc.x); vd[i].y += ra[i] * (k1 * rc.y);
+          wb[i].x += ra[i] * yc.x;        wb[i].y += ra[i] * yc.y;
+          wd[i].x += ra[i] * dc.x;        wd[i].y += ra[i] * dc.y;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (r0 + i < QN) {
+          const long o = (long)(r0 + i) * QN + cc;
+          *reinterpret_cast<double2*>(Gb_aa + o) = vb[i];
+          *reinterpret_cast<double2*>(Gd_aa + o) = vd[i];
+          *reinterpret_cast<double2*>(Gb_as + o) = wb[i];
+          *reinterpret_cast<double2*>(Gd_as + o) = wd[i];
+        }
+      }
+    }
+    constexpr int RT = 4;
+    const int irows = (N + RT - 1) / RT;
+    for (int it = tid; it < Q * irows * hp; it += 256) {
+      const int q = it / (irows * hp), rem = it - q * irows * hp, ir = rem / hp, cc = 2 * (rem - ir * hp), i0 = RT * ir;
+      double2 v[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) v[i] = make_double2(0.0, 0.0);
+      for (int p = 0; p < np; ++p) {
+        const double2 rc = *reinterpret_cast<const double2*>(Ra + p * QN + cc);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const double x = Xab[(q * np + p) * N + (i0 + i < N ? i0 + i : N - 1)];
+          v[i].x += x * rc.x;
+          v[i].y += x * rc.y;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+        if (i0 + i < N)
+          *reinterpret_cast<double2*>(a.G_ab + (((long)q * S + s) * N + i0 + i) * C + slot * QN + cc) = v[i];
+    }
+  } else {
+    // odd QN: register tiles of 4 rows x 1 column, lanes over consecutive columns (8-byte stores)
   {
     constexpr int RT = 4;
     const int trows = (QN + RT - 1) / RT;
@@ -1335,6 +1395,7 @@ __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
       for (int i = 0; i < RT; ++i)
         if (i0 + i < N) a.G_ab[(((long)q * S + s) * N + i0 + i) * C + slot * QN + cc] = v[i];
     }
+  }
   }
   for (int c = tid; c < QN; c += 256) {
     double v = 0.0;
