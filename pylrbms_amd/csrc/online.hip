@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void k_coarse_entries(int S, int N, const int*
 // prz[m][s] += r[s][0][m] c[s][m]  (the coarse part of r . z, added to the partial the update kernel has just written).
 // One workgroup per 16 subdomains (rows of A0inv), 16 waves splitting K = S: every MFMA step takes its A operand from
 // A0inv[k][row] (= A0inv[row][k], the matrix is symmetric: 16 contiguous doubles per k) and its B operand from
-// r[k][0][m]; a wave issues the loads of 16 steps (32 per lane) before its first MFMA; the 16 partial tiles meet in LDS.
+// r[k][0][m]; a wave issues the loads of 8 steps (16 per lane) before its first MFMA; the 16 partial tiles meet in LDS.
 // (A VALU form with a thread per (m, row, k-part) was bound by its load instructions -- 4 useful addresses each: 17.6 us.)
 typedef double d4c __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(1024) void k_coarse_apply(int S, int N, int nmu, const double* __restrict__ A0inv,
@@ -465,17 +465,17 @@ __global__ __launch_bounds__(1024) void k_coarse_apply(int S, int N, int nmu, co
   const int nsteps = (S + 3) / 4;
   const int row = row0 + li;
   d4c acc = (d4c){0.0, 0.0, 0.0, 0.0};
-  for (int i0 = 0; wave + 16 * i0 < nsteps; i0 += 16) {
-    double a[16], b[16];
+  for (int i0 = 0; wave + 16 * i0 < nsteps; i0 += 8) {   // 8 steps = 16 loads per lane in flight (16 steps spill at 1024 threads)
+    double a[8], b[8];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int k = 4 * (wave + 16 * (i0 + u)) + lk;
       const bool in = k < S;
       a[u] = (in && row < S) ? A0inv[(long)k * S + row] : 0.0;
       b[u] = (in && li < nmu) ? r[(long)k * NM + li] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) red[(wave * 4 + q) * 64 + lane] = acc[q];
