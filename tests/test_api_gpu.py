@@ -128,3 +128,37 @@ def test_native_fom_solve_matches_the_oracle_and_reports_non_convergence():
     assert np.abs(x.cpu().numpy() - ref).max() < 1e-8 * np.abs(ref).max()
     with pytest.raises(NativeError, match='did not reach rtol'):
         eng.ctx.fom_solve(d.theta(0.37), eng.A_diag, eng.A_cpl, eng.b, max_iter=3)
+
+
+def test_reduced_model_parameter_sweep_and_preconditioner_reuse():
+    """``rd.solve_batch(mus)`` (batched PCG, one prebuilt two-level preconditioner per reduced model) returns the same
+    solutions as ``rd.solve(mu)`` one by one and as the oracle's dense solves; the preconditioner is built once."""
+    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    from pylrbms_amd.reductor import LRBMSReductor
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': [4, 4], 'coarse_per_subdomain': 2})
+    d, _ = discretize(p)
+    o = oracle_from_problem(p)
+    reductor = LRBMSReductor(d, order=0)
+    snaps = []
+    for mu in (0.15, 0.5, 0.95):
+        U = d.solve(mu)
+        snaps.append(U.data.reshape(o.S, o.n))
+        reductor.extend_basis(U)
+    rd = reductor.reduce()
+    mus = [0.1 + 0.045 * k for k in range(19)]                       # two batches (16 + 3)
+    ub = rd.solve_batch(mus)
+    assert len(ub) == len(mus) and len(rd._pc) == 1
+    pc_before = next(iter(rd._pc.values()))
+    bases = [np.stack([np.ones(o.n)] + [s[ii] for s in snaps], axis=1) for ii in range(o.S)]
+    ored = OracleReductor(o, bases)
+    ord_ = ored.reduce()
+    rec_b = reductor.reconstruct(ub).data.reshape(len(mus), o.S, o.n)
+    for k in (0, 7, 18):
+        u1 = rd.solve(mus[k])
+        assert rd.last_solve_info['relative_residual'] <= 1e-12
+        rec_1 = reductor.reconstruct(u1).data.reshape(o.S, o.n)
+        ref = np.stack(ored.reconstruct(ord_.solve(mus[k])))
+        assert np.abs(rec_1 - ref).max() < 1e-8 * np.abs(ref).max()
+        assert np.abs(rec_b[k] - ref).max() < 1e-8 * np.abs(ref).max()
+    assert next(iter(rd._pc.values())) is pc_before                   # reused, not rebuilt
