@@ -1252,36 +1252,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   double* sc = Xab + Q * np * N;    // [np][3]    B[f,f], |T| c^2, bsum * c
   const int* nbr_s = a.nbr + s * 5;
   const double* Rs = a.Rself + (long)s * t.nrt * QN;
-  for (int it = tid; it < np * QN; it += 256) {
-    const int p = it / QN, c = it - p * QN;
-    const int T = t.side_elem[side * t.ncf + p];
+  // per side face p: element, its face on the side, its three RT0 rows and divergence coefficients -- resolved ONCE by
+  // np threads into LDS (the index chains side_elem -> nb_elem -> elem_rt / face_len / area are three dependent round
+  // trips; chased by every item of the loops below they made the prologue ~10 round trips long)
+  double* fco = sc + 3 * np;                       // [np][4]: sign |e_g| / |T| (g = 0..2), |T|
+  int* fidx = reinterpret_cast<int*>(fco + 4 * np);   // [np][5]: T, fp, rt row of face 0..2
+  if (tid < np) {
+    const int p = tid, T = t.side_elem[side * t.ncf + p];
     int fp = 0;
     for (int f = 0; f < 3; ++f)
       if (t.nb_elem[T * 3 + f] == -(1 + side)) fp = f;
+    fidx[p * 5] = T;
+    fidx[p * 5 + 1] = fp;
+    const double area = t.area[T];
+    for (int g = 0; g < 3; ++g) {
+      fidx[p * 5 + 2 + g] = t.elem_rt[T * 3 + g];
+      fco[p * 4 + g] = face_sign_at(t, nbr_s, T, g) * t.face_len[T * 3 + g] / area;
+    }
+    fco[p * 4 + 3] = area;
+  }
+  __syncthreads();
+  for (int it = tid; it < np * QN; it += 256) {
+    const int p = it / QN, c = it - p * QN;
+    const int T = fidx[p * 5], fp = fidx[p * 5 + 1];
     Ra[it] = a.Rside[(((long)s * 4 + side) * t.ncf + p) * QN + c];
     const double* B = a.Bbb + ((long)s * t.nT + T) * 9 + fp * 3;
+    const double area = fco[p * 4 + 3];
     double yb = 0.0, d = 0.0;
     for (int g = 0; g < 3; ++g) {
-      const double rv = Rs[(long)t.elem_rt[T * 3 + g] * QN + c];
+      const double rv = Rs[(long)fidx[p * 5 + 2 + g] * QN + c];
       yb += B[g] * rv;
-      d += face_sign_at(t, nbr_s, T, g) * t.face_len[T * 3 + g] / t.area[T] * rv;
+      d += fco[p * 4 + g] * rv;
     }
-    const double cp = face_sign_at(t, nbr_s, T, fp) * t.face_len[T * 3 + fp] / t.area[T];
+    const double cp = fco[p * 4 + fp];
     Yb[it] = yb;
-    Dp[it] = t.area[T] * cp * d;
+    Dp[it] = area * cp * d;
     if (c == 0) {
       const double* be = a.b + (long)s * t.n + 3 * T;
       sc[p * 3] = B[fp];
-      sc[p * 3 + 1] = t.area[T] * cp * cp;
+      sc[p * 3 + 1] = area * cp * cp;
       sc[p * 3 + 2] = (be[0] + be[1] + be[2]) * cp;
     }
   }
   for (int it = tid; it < Q * np * N; it += 256) {
     const int q = it / (np * N), rem = it - q * np * N, p = rem / N, i = rem - p * N;
-    const int T = t.side_elem[side * t.ncf + p];
-    int fp = 0;
-    for (int f = 0; f < 3; ++f)
-      if (t.nb_elem[T * 3 + f] == -(1 + side)) fp = f;
+    const int T = fidx[p * 5], fp = fidx[p * 5 + 1];
     const double* A = a.Aab + (((long)q * S + s) * t.nT + T) * 9;
     double x = 0.0;
     for (int k = 0; k < 3; ++k) x += a.V[((long)s * t.n + 3 * T + k) * N + i] * A[k * 3 + fp];
@@ -1301,7 +1316,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       double2 vb[2], vd[2], wb[2], wd[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) vb[i] = vd[i] = wb[i] = wd[i] = make_double2(0.0, 0.0);
+#ifdef THIN_RT_NOCOMPUTE
+      for (int p = 0; p < (a.N < 0 ? np : 0); ++p) {
+#else
       for (int p = 0; p < np; ++p) {
+#endif
         const double2 rc = *reinterpret_cast<const double2*>(Ra + p * QN + cc);
         const double2 yc = *reinterpret_cast<const double2*>(Yb + p * QN + cc);
         const double2 dc = *reinterpret_cast<const double2*>(Dp + p * QN + cc);
@@ -1317,7 +1336,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
+#ifdef THIN_RT_NOSTORE
+        if (r0 + i < QN && vb[i].x == 1.2345e300) {
+#else
         if (r0 + i < QN) {
+#endif
           const long o = (long)(r0 + i) * QN + cc;
           *reinterpret_cast<double2*>(Gb_aa + o) = vb[i];
           *reinterpret_cast<double2*>(Gd_aa + o) = vd[i];
@@ -1697,7 +1720,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     }
     LRBMS_LAUNCH_CHECK(ctx);
     ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, G_bb, G_rdd, G_ab, r_fd, Q, N, S};
-    const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf);
+    const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf + 4 * t.ncf + 3 * t.ncf);   // + fco [ncf][4], fidx [ncf][5] ints
     hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, s_rt, t, a);
     LRBMS_LAUNCH_CHECK(ctx);
   }

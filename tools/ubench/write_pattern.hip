@@ -22,6 +22,20 @@ __global__ __launch_bounds__(256) void k_chunk_work(double2* out, long chunk2, d
     o[i] = make_double2(a, v);
   }
 }
+// k_thin_rt's pattern: workgroup (side, s) writes blocks 1 + side and 5 + side (51 200 B each) of subdomain s in TWO arrays
+// [S][9][6400] doubles; interleaved = one 16-byte store into each of the four blocks per item, sequential = block after block
+__global__ __launch_bounds__(256) void k_thin(double2* A, double2* B, int interleaved, double v) {
+  const int side = blockIdx.x, s = blockIdx.y;
+  double2* dst[4] = {A + ((long)s * 9 + 5 + side) * 3200, B + ((long)s * 9 + 5 + side) * 3200, A + ((long)s * 9 + 1 + side) * 3200,
+                     B + ((long)s * 9 + 1 + side) * 3200};
+  if (interleaved) {
+    for (int i = threadIdx.x; i < 3200; i += 256)
+      for (int k = 0; k < 4; ++k) dst[k][i] = make_double2(v, v);
+  } else {
+    for (int k = 0; k < 4; ++k)
+      for (int i = threadIdx.x; i < 3200; i += 256) dst[k][i] = make_double2(v, v);
+  }
+}
 int main() {
   const long bytes = 1L << 30;
   double2* d;
@@ -50,5 +64,22 @@ int main() {
   for (int work : {8, 32, 128})
     time(("chunk 256 KB + " + std::to_string(work) + " dependent FMAs per store").c_str(),
          [&] { hipLaunchKernelGGL(k_chunk_work, dim3(bytes / (256L << 10)), dim3(256), 0, 0, d, (256L << 10) / 16, 1.5, work); });
+  {
+    double2 *A, *B;
+    const long per = 1024L * 9 * 3200 * 16;
+    hipMalloc(&A, per);
+    hipMalloc(&B, per);
+    const double gb = 4096.0 * 4 * 51200;
+    for (int mode : {1, 0}) {
+      for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_thin, dim3(4, 1024), dim3(256), 0, 0, A, B, mode, 1.5);
+      hipEventRecord(e0);
+      for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(k_thin, dim3(4, 1024), dim3(256), 0, 0, A, B, mode, 1.5);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      printf("k_thin_rt pattern (4 blocks / workgroup), %-12s %7.3f ms  %5.2f TB/s\n", mode ? "interleaved" : "sequential", ms / 10, gb / (ms / 10) / 1e9);
+    }
+  }
   return 0;
 }
