@@ -200,8 +200,18 @@ __global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __
   for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < t.nv * N; it += gridDim.y * blockDim.x) {
     const int v = it / N, j = it - v * N;
     const OsInfo o = oswald_vertex(t, nbr + s * 5, v);
+    // the (at most 8) values at the vertex are loaded together and summed in the same order (an `acc += V[...]` loop
+    // waits one memory round trip per value)
     double acc = 0.0;
-    for (int p = t.vdof_ptr[v]; p < t.vdof_ptr[v + 1]; ++p) acc += V[((long)s * t.n + t.vdof_idx[p]) * N + j];
+    const int p0 = t.vdof_ptr[v], p1 = t.vdof_ptr[v + 1];
+    for (int pb = p0; pb < p1; pb += 8) {
+      double val[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) val[k] = pb + k < p1 ? V[((long)s * t.n + t.vdof_idx[pb + k]) * N + j] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (pb + k < p1) acc += val[k];
+    }
     AvgSelf[((long)s * t.nv + v) * N + j] = o.inv * acc;
     if (!write_side) continue;                     // Avg_self needs no neighbour data (only the patch sizes)
     for (int sd = 0; sd < 4; ++sd) {
@@ -210,7 +220,15 @@ __global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __
       double a2 = 0.0;
       if (s2 >= 0 && o.inv != 0.0) {
         const int v2 = o.vside[sd];
-        for (int p = t.vdof_ptr[v2]; p < t.vdof_ptr[v2 + 1]; ++p) a2 += V[((long)s2 * t.n + t.vdof_idx[p]) * N + j];
+        const int q0 = t.vdof_ptr[v2], q1 = t.vdof_ptr[v2 + 1];
+        for (int pb = q0; pb < q1; pb += 8) {
+          double val[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) val[k] = pb + k < q1 ? V[((long)s2 * t.n + t.vdof_idx[pb + k]) * N + j] : 0.0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (pb + k < q1) a2 += val[k];
+        }
         a2 *= o.inv;
       }
       AvgSide[(((long)s * 4 + sd) * nvs + o.pos[sd]) * N + j] = a2;
