@@ -1443,11 +1443,15 @@ __global__ __launch_bounds__(256) void k_reduced_estimate_batch(int S, const int
 // per lane, four k-steps consume one 128-byte line per row), Y comes from LDS with the per-parameter weights folded in,
 // and each lane finishes with four multiply-adds against X.  The VALU form above needs 16 LDS operands per loaded entry
 // and runs at 15 % of the HBM rate this kernel is bound by.
+// waves per workgroup of the batched estimate: its coefficient panels take 77 KB of LDS at config 3 (two workgroups per
+// CU), and every wave works through its tiles in batches of 8 loads, one round trip each -- eight waves instead of four
+// double the loads in flight per CU at the same LDS footprint
+constexpr int EST_NW = 8;
 __device__ inline void quad_mfma(const double* __restrict__ G, int ld, int R, int C, const double* X, const double* Y, double wl,
                                  double& acc) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, wave = threadIdx.x >> 6;
   const int ntile = (R + 15) >> 4;
-  for (int tile = wave; tile < ntile; tile += 4) {
+  for (int tile = wave; tile < ntile; tile += EST_NW) {
     const int ra = tile * 16 + li < R ? tile * 16 + li : R - 1;           // rows >= R repeat the last row (their X is 0)
     const double* grow = G + (long)ra * ld;
     d4m T = (d4m){0.0, 0.0, 0.0, 0.0};
@@ -1472,7 +1476,7 @@ __device__ inline void quad_mfma(const double* __restrict__ G, int ld, int R, in
   }
 }
 
-__global__ __launch_bounds__(256) void k_reduced_estimate_batch_mfma(int S, const int* __restrict__ nbr, int Q, int N, int nmu,
+__global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int S, const int* __restrict__ nbr, int Q, int N, int nmu,
                                                                      ThetaBatch th, const double* __restrict__ u,
                                                                      const double* __restrict__ G_nc, const double* __restrict__ r_fd,
                                                                      const double* __restrict__ G_rdd, const double* __restrict__ G_bb,
@@ -1485,10 +1489,10 @@ __global__ __launch_bounds__(256) void k_reduced_estimate_batch_mfma(int S, cons
   const int Wp = (W + 3) & ~3, Cp = (C + 3) & ~3;
   double* uo = lds;                 // [Wp][16]  coefficients of the own + neighbour bases (columns >= nmu and pad rows zero)
   double* ur = uo + Wp * 16;        // [Cp][16]  theta_q(mu_m) * coefficient, row order (slot, q, j)
-  double* red = ur + Cp * 16;       // [4][3][16]
-  for (int i = tid; i < (Wp + Cp) * 16; i += 256) lds[i] = 0.0;
+  double* red = ur + Cp * 16;       // [EST_NW][3][16]
+  for (int i = tid; i < (Wp + Cp) * 16; i += 64 * EST_NW) lds[i] = 0.0;
   __syncthreads();
-  for (int i = tid; i < W * nmu; i += 256) {
+  for (int i = tid; i < W * nmu; i += 64 * EST_NW) {
     const int row = i / nmu, m = i - row * nmu, slot = row / N, j = row - slot * N;
     const int s2 = nbr[s * 5 + slot];
     const double val = s2 >= 0 ? u[((long)s2 * N + j) * nmu + m] : 0.0;
@@ -1515,7 +1519,7 @@ __global__ __launch_bounds__(256) void k_reduced_estimate_batch_mfma(int S, cons
     quad_mfma(Gb + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, 1.0, a_df);
   }
   // - 2 r_fd . ur: lanes over (16 rows of c) x parameter
-  for (int c = wave * 4 + (lane >> 4); c < C; c += 16) a_r -= 2.0 * r_fd[(long)s * C + c] * ur[c * 16 + li];
+  for (int c = wave * 4 + (lane >> 4); c < C; c += 4 * EST_NW) a_r -= 2.0 * r_fd[(long)s * C + c] * ur[c * 16 + li];
   for (int q = 0; q < Q; ++q) {
     double tq = thl[0];
 #pragma unroll
@@ -1531,7 +1535,7 @@ __global__ __launch_bounds__(256) void k_reduced_estimate_batch_mfma(int S, cons
     }
   }
   // fixed-order reductions: the four k-groups of a wave by shuffles (lanes li, li + 16, li + 32, li + 48 share a
-  // parameter), then the 4 waves through LDS
+  // parameter), then the waves through LDS
   for (int off = 32; off >= 16; off >>= 1) {
     a_nc += __shfl_down(a_nc, off, 64);
     a_r += __shfl_down(a_r, off, 64);
@@ -1546,7 +1550,7 @@ __global__ __launch_bounds__(256) void k_reduced_estimate_batch_mfma(int S, cons
   if (tid < nmu) {
     const double pi = 3.14159265358979323846;
     double nc = 0.0, rr = 0.0, df = 0.0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < EST_NW; ++w) {
       nc += red[(w * 3 + 0) * 16 + tid];
       rr += red[(w * 3 + 1) * 16 + tid];
       df += red[(w * 3 + 2) * 16 + tid];
@@ -1570,12 +1574,12 @@ int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const d
   for (int m = 0; m < BMAX; ++m)
     for (int q = 0; q < 8; ++q) th.v[m * 8 + q] = (m < nmu && q < Q) ? theta[m * Q + q] : 0.0;
   if (getenv("LRBMS_EST_VALU") == nullptr) {   // matrix-core form (default)
-    const size_t ldm = sizeof(double) * ((size_t)(((5 * N + 3) & ~3) + ((5 * Q * N + 3) & ~3)) * 16 + 4 * 3 * 16);
+    const size_t ldm = sizeof(double) * ((size_t)(((5 * N + 3) & ~3) + ((5 * Q * N + 3) & ~3)) * 16 + EST_NW * 3 * 16);
     if (ldm > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
     if (ldm > 64 * 1024)
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)ldm));
-    hipLaunchKernelGGL(k_reduced_estimate_batch_mfma, dim3(ctx->S), dim3(256), ldm, st, ctx->S, ctx->nbr, Q, N, nmu, th, u, G_nc, r_fd,
+    hipLaunchKernelGGL(k_reduced_estimate_batch_mfma, dim3(ctx->S), dim3(64 * EST_NW), ldm, st, ctx->S, ctx->nbr, Q, N, nmu, th, u, G_nc, r_fd,
                        G_rdd, G_bb, G_ab, G_aa, f2, ceps, hdiam, eta_loc);
     LRBMS_LAUNCH_CHECK(ctx);
     return LRBMS_OK;
