@@ -245,3 +245,109 @@ class StationaryEocStudy(EocStudy):
     def compute_estimate(self, level, id):
         self._compute_estimates(level)
         return self._cache[level][id]
+
+
+class InstationaryEocStudy(EocStudy):
+    """EOC.py:326-505: the study of python/scripts/parabolic_convergence_study.py.  Levels refine the grid and the time
+    step (``cfg['dt']``, ``nt = int(T / dt) + 1`` as at :351-354); the reference solution is the parabolic block SWIPDG
+    P1 solution of ``reference_cfg`` (the reference uses the non-block SWIPDG solver with ``p_ref = 2``, :444-449); level
+    solutions are prolonged onto it in space (``prolong``) and in time (P1 in time, :473-489); the ``L2`` time norm is
+    the one-point (midpoint) rule per reference time interval of the P1-in-time interpolant (:393-426)."""
+
+    level_info_title = '|grid|/|Grid|/nt'
+    accuracies = ('h', 'H', 'dt')
+    norms = ('L_oo - L2', 'L_oo - elliptic_mu_bar', 'L2 - L2', 'L2 - elliptic_mu_bar')
+    indicators = ('eta_nc', 'eta_r', 'eta_df', 'R_T', 'partial_t_nc')
+    estimates = (('eta', 'L2 - elliptic_mu_bar'), )
+    max_levels = 2
+
+    def __init__(self, gp_initializer, disc, base_cfg, refine, reference_cfg, mu, max_levels=None):
+        self.data = {}
+        (self._grid_and_problem_data, self._d, self._d_data, self._solution, self._solution_as_reference, self._config,
+         self._cache) = {}, {}, {}, {}, {}, {}, {}
+        self._grid_and_problem_initializer = gp_initializer
+        self._discretizer = disc
+        self.mu = mu
+        if max_levels is not None:
+            self.max_levels = max_levels
+        self._config[0] = dict(base_cfg)
+        for level in range(1, self.max_levels + 1):
+            self._config[level] = refine(self._config[level - 1])
+        self._config[-1] = dict(reference_cfg)
+        self._T = self._config[0]['T']
+
+    def _discretize(self, level):
+        cfg = self._config[level]
+        self._grid_and_problem_data[level] = self._grid_and_problem_initializer(cfg)
+        self._d[level], self._d_data[level] = self._discretizer(self._grid_and_problem_data[level], self._T,
+                                                                int(self._T / cfg['dt']) + 1)
+        self._solution[level] = self._d[level].solve(self._d[level].parse_parameter(self.mu))
+
+    def solve(self, level):
+        assert level <= self.max_levels
+        if level not in self._solution:
+            self._discretize(level)
+
+    def level_info(self, level):
+        grid = self._grid_and_problem_data[level]['grid']
+        return '{}/{}/{}'.format(grid.num_elements, grid.num_subdomains, len(self._solution[level]) - 1)
+
+    def accuracy(self, level, id):
+        grid = self._grid_and_problem_data[level]['grid']
+        if id == 'h':
+            return grid.max_entity_diameter()
+        if id == 'H':
+            return max(grid.subdomain_diameter(ss) for ss in range(grid.num_subdomains))
+        if id == 'dt':
+            return self._config[level]['dt']
+        assert False
+
+    def _prolong_onto_reference(self, level):
+        if level in self._solution_as_reference:
+            return
+        if -1 not in self._solution:
+            self._discretize(-1)
+        if 'reductor' in self._d_data[level]:
+            assert False                                                      # not yet implemented (EOC.py:457)
+        import torch
+        ctx = self._d[-1].engine.ctx
+        Uc = prolong(self._solution[level].tensor, self._grid_and_problem_data[level]['grid'],
+                     self._grid_and_problem_data[-1]['grid'], ctx)            # fine in space, coarse in time
+        nc, nf = Uc.shape[2] - 1, len(self._solution[-1]) - 1
+        t_f = np.linspace(0.0, self._T, nf + 1)
+        ent = np.minimum((t_f * nc / self._T).astype(np.int64), nc - 1)      # coarse interval of every reference time
+        a, b = ent * self._T / nc, (ent + 1) * self._T / nc
+        w_b = ctx.from_numpy((t_f - a) / (b - a))
+        e = torch.from_numpy(ent).to(Uc.device)
+        self._solution_as_reference[level] = Uc[:, :, e] * (1.0 - w_b)[None, None, :] + Uc[:, :, e + 1] * w_b[None, None, :]
+
+    def compute_norm(self, level, id):
+        self._prolong_onto_reference(level)
+        if ('norms', level) not in self._cache:
+            diff = self._solution[-1].tensor - self._solution_as_reference[level]
+            mid = 0.5 * (diff[:, :, 1:] + diff[:, :, :-1])                    # P1 in time at the interval midpoints
+            self._cache[('norms', level)] = (error_norms(diff, self._d[-1]), error_norms(mid, self._d[-1]))
+        nodes, mids = self._cache[('norms', level)]
+        time_norm_id, space_norm_id = (x.strip() for x in id.split('-'))
+        if time_norm_id == 'L_oo':
+            return float(np.max(nodes[space_norm_id]))
+        if time_norm_id == 'L2':
+            dt_ref = self._T / (len(self._solution[-1]) - 1)
+            return float(np.sqrt(dt_ref * np.sum(mids[space_norm_id] ** 2)))
+        assert False
+
+    def _compute_estimates(self, level):
+        if level not in self._cache:
+            mu = self._d[level].parse_parameter(self.mu)
+            eta, (eta_ncs, eta_rs, eta_dfs, time_residuals, time_derivs_nc) = self._d[level].estimate(self._solution[level], mu)
+            self._cache[level] = {'eta_nc': np.linalg.norm(eta_ncs), 'eta_df': np.linalg.norm(eta_dfs),
+                                  'eta_r': np.linalg.norm(eta_rs), 'R_T': np.linalg.norm(time_residuals),
+                                  'partial_t_nc': np.linalg.norm(time_derivs_nc), 'eta': float(eta)}    # EOC.py:495-505
+
+    def compute_indicator(self, level, id):
+        self._compute_estimates(level)
+        return self._cache[level][id]
+
+    def compute_estimate(self, level, id):
+        self._compute_estimates(level)
+        return self._cache[level][id]

@@ -96,3 +96,52 @@ def test_bases_and_reduced_model_round_trip_through_disk(tmp_path):
     # VTK output of the reconstruction (one file per vector)
     files = d.visualize(reductor.reconstruct(u), filename=str(tmp_path / 'u_red'))
     assert len(files) == 1 and open(files[0]).readline().startswith('# vtk DataFile')
+
+
+def test_instationary_eoc_study(capsys):
+    """The parabolic study of python/scripts/parabolic_convergence_study.py (thermal block, dt = 0.1 h, refinement in
+    space and time): runs through all levels, the errors against the space-time reference fall, every indicator is
+    positive, and the prolongation in time reproduces a trajectory that is linear in time."""
+    from pylrbms_amd import thermalblock_problem
+    from pylrbms_amd.EOC import InstationaryEocStudy
+    from pylrbms_amd.discretize_parabolic_block_swipdg import discretize as discretize_parabolic
+
+    def discretize(gp, T, nt):
+        d, data = discretize_parabolic(gp, T, nt)
+        return d, {'block_space': data['block_space'], 'unblock': d.unblock}
+
+    def with_dt(cfg):
+        cfg = dict(cfg)
+        cfg['dt'] = 0.1 * thermalblock_problem.init_grid_and_problem(cfg)['grid'].max_entity_diameter()
+        return cfg
+
+    def refine(cfg):
+        out = dict(cfg)
+        out['half_num_fine_elements_per_subdomain_and_dim'] *= 2
+        out['num_subdomains'] = [2 * s for s in cfg['num_subdomains']]
+        return with_dt(out)
+
+    base = with_dt({'num_subdomains': [1, 1], 'half_num_fine_elements_per_subdomain_and_dim': 4, 'T': 0.5})
+    reference = refine(refine(base))
+    study = InstationaryEocStudy(thermalblock_problem.init_grid_and_problem, discretize, base, refine, reference,
+                                 mu=(1, 1, 1, 1), max_levels=1)
+    data = study.run(('h', 'dt', 'L2 - elliptic_mu_bar', 'L_oo - L2', 'eta_nc', 'R_T', 'partial_t_nc', 'eta'))
+    out = capsys.readouterr().out
+    assert out.count('\n') == 2 + 2 and '/' in out.splitlines()[2].split('|')[0]
+    for q in ('L2 - elliptic_mu_bar', 'L_oo - L2'):
+        assert 0.0 < data[1]['norm'][q] < data[0]['norm'][q]
+    for q in ('eta_nc', 'R_T', 'partial_t_nc'):
+        assert data[1]['indicator'][q] > 0
+    assert data[1]['estimate']['eta'] < data[0]['estimate']['eta']
+    nt0, ntr = len(study._solution[0]) - 1, len(study._solution[-1]) - 1
+    assert (nt0, ntr) == (int(0.5 / base['dt']) + 1, int(0.5 / reference['dt']) + 1)
+    # prolongation in time: replace the level-0 trajectory by t * U_T (linear in time) -> exact at every reference time
+    import torch
+    U0 = study._solution[0].tensor
+    lin = U0[:, :, -1:] * torch.linspace(0, 1, nt0 + 1, dtype=U0.dtype, device=U0.device)[None, None, :]
+    study._solution[0]._t = lin.contiguous()
+    del study._solution_as_reference[0]
+    study._prolong_onto_reference(0)
+    got = study._solution_as_reference[0]
+    want = got[:, :, -1:] * torch.linspace(0, 1, ntr + 1, dtype=U0.dtype, device=U0.device)[None, None, :]
+    assert float((got - want).abs().max()) < 1e-12 * float(want.abs().max())
