@@ -257,6 +257,23 @@ int lrbms_fom_implicit_euler(lrbms_ctx* ctx, int32_t Q, const double* theta, dou
  *   Y [S][n][L];  out [S][L] = y^T M_s^-1 y  (the P1 mass matrix is inverted element by element in closed form). */
 int lrbms_mass_inverse_norm2(lrbms_ctx* ctx, int32_t L, const double* Y, double* out, void* stream);
 
+/* Elliptic-reconstruction terms of the parabolic estimator (estimators.py:65-68, :80-83; operators r_ud_i / r_l2_i of
+ * discretize_parabolic_block_swipdg.py:65-74).  The reference never evaluates them (the branch starts with `assert False`,
+ * estimators.py:64); they are provided for `ParabolicEstimator(elliptic_reconstruction=True)`.
+ *   lrbms_div_apply      Rt [S][n_rt][C] -> mode 0: D [S][n_T][C], the divergence of the RT0 columns (one value per element);
+ *                        mode 1: M_s Div_s Rt_s [S][n][C] (the operator inside r_ud_s)
+ *   lrbms_div_pairing    full order: out [S][L] = g^T Div U_r with U_r = sum_{slot,q} theta_q Rt[:, (slot, q, l)]
+ *                        (D from mode 0, C = 5 Q L; G [S][n][L]); r_ud_s(M^-1 g, U_r), the mass matrices cancel
+ *   lrbms_reduced_reconstruction_terms   reduced: out [L][S] = y^T M_red^-1 y - b^T M_red^-1 b - 2 (M_red^-1 (y - b))^T G_ud ur
+ *                        with y = (A_red(mu) u_l)_s, b = rhs_red[s], G_ud [S][N][5 Q N] the projected r_ud_s, U [L][S][N];
+ *                        work: lrbms_reduced_time_residual_work_size doubles */
+int lrbms_div_apply(lrbms_ctx* ctx, int32_t C, int32_t mode, const double* Rt, double* out, void* stream);
+int lrbms_div_pairing(lrbms_ctx* ctx, int32_t Q, int32_t L, const double* theta, const double* D, const double* G, double* out,
+                      void* stream);
+int lrbms_reduced_reconstruction_terms(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t L, const double* theta, const double* B_sys,
+                                       const double* M_red, const double* rhs_red, const double* G_ud, const double* U,
+                                       double* work, double* out, void* stream);
+
 /* The reduced counterpart of lrbms_fom_implicit_euler on the projected operators:
  *   (M_red + dt sum_q theta_q B_sys_q) u_{k+1} = M_red u_k + dt rhs_red.
  *   B_sys [Q][S][5][N][N], M_red [S][N][N], rhs_red [S][N] as written by the projection; U [nt+1][S][N] (U[0] input);

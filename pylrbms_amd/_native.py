@@ -62,6 +62,9 @@ SIGNATURES = {
     'lrbms_fom_implicit_euler': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_dbl, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL,
                                                 c_vp]),
     'lrbms_mass_inverse_norm2': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'lrbms_div_apply': (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    'lrbms_div_pairing': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp]),
+    'lrbms_reduced_reconstruction_terms': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL] + [c_vp] * 8),
     'lrbms_reduced_implicit_euler': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_dbl, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl,
                                                     c_i32, _P_DBL, c_vp]),
     'lrbms_reduced_time_residual_work_size': (c_i64, [c_vp, c_i32]),
@@ -505,6 +508,38 @@ class NativeContext:
         rc = self.lib.lrbms_mass_inverse_norm2(self.handle, L, self._ptr(Y, (S, self.n, L), 'Y'), c_vp(out.data_ptr()),
                                                self._stream())
         self._check(rc, 'lrbms_mass_inverse_norm2')
+        return out
+
+    def div_apply(self, Rt, mode=0):
+        """Rt [S, n_rt, C] -> mode 0: div per element [S, n_T, C]; mode 1: M Div Rt [S, n, C]."""
+        S, C = self.S, Rt.shape[2]
+        out = self.empty(S, self.n_T if mode == 0 else self.n, C)
+        rc = self.lib.lrbms_div_apply(self.handle, C, int(mode), self._ptr(Rt, (S, self.n_rt, C), 'Rt'), c_vp(out.data_ptr()),
+                                      self._stream())
+        self._check(rc, 'lrbms_div_apply')
+        return out
+
+    def div_pairing(self, theta, D, G):
+        """D [S, n_T, 5 Q L] (div_apply mode 0), G [S, n, L] -> [S, L]: g^T Div U_r."""
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        Q, S, L = len(th), self.S, G.shape[2]
+        out = self.empty(S, L)
+        rc = self.lib.lrbms_div_pairing(self.handle, Q, L, _dblp(th), self._ptr(D, (S, self.n_T, 5 * Q * L), 'D'),
+                                        self._ptr(G, (S, self.n, L), 'G'), c_vp(out.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_div_pairing')
+        return out
+
+    def reduced_reconstruction_terms(self, theta, B_sys, M_red, rhs_red, G_ud, U):
+        """U [L, S, N] -> [L, S]: the elliptic-reconstruction terms of the reduced estimate."""
+        Q, S, N, L = B_sys.shape[0], self.S, B_sys.shape[3], U.shape[0]
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        work = self.empty(int(self.lib.lrbms_reduced_time_residual_work_size(self.handle, N)))
+        out = self.empty(L, S)
+        rc = self.lib.lrbms_reduced_reconstruction_terms(
+            self.handle, Q, N, L, _dblp(th), self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'), self._ptr(M_red, (S, N, N), 'M_red'),
+            self._ptr(rhs_red, (S, N), 'rhs_red'), self._ptr(G_ud, (S, N, 5 * Q * N), 'G_ud'), self._ptr(U, (L, S, N), 'U'),
+            c_vp(work.data_ptr()), c_vp(out.data_ptr()), self._stream())
+        self._check(rc, 'lrbms_reduced_reconstruction_terms')
         return out
 
     def reduced_implicit_euler(self, theta, dt, nt, B_sys, M_red, rhs_red, U0=None, rtol=1e-13, max_iter=20000):

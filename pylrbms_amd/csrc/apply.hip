@@ -380,6 +380,73 @@ int launch_mass_inverse_norm2(lrbms_ctx* ctx, int C, const double* Y, double* ou
   return LRBMS_OK;
 }
 
+// out[s][3e+i][c] = (M_s Div_s Rt_s)[3e+i][c] = |T|/3 * div_T(c)   (the mass matrix applied to the constant (d, d, d))
+__global__ __launch_bounds__(256) void k_mass_div_apply(Tmpl t, int S, const int* __restrict__ nbr, int C,
+                                                        const double* __restrict__ Rt, double* __restrict__ MD) {
+  const long total = (long)S * t.nT * C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const long se = idx / C;
+    const int e = (int)(se % t.nT), s = (int)(se / t.nT);
+    double acc = 0.0;
+    for (int f = 0; f < 3; ++f) {
+      int sign = t.face_sign[e * 3 + f];
+      const int nb = t.nb_elem[e * 3 + f];
+      if (nb < 0 && nbr[s * 5 + side_to_slot(-1 - nb)] < 0) sign = 1;
+      acc += sign * t.face_len[e * 3 + f] * Rt[((long)s * t.nrt + t.elem_rt[e * 3 + f]) * C + c];
+    }
+    const double v = acc / 3.0;
+    double* o = MD + ((long)s * t.n + 3 * e) * C + c;
+    o[0] = v;
+    o[C] = v;
+    o[2 * (long)C] = v;
+  }
+}
+
+// out[s][l] = sum_T (g_{3T} + g_{3T+1} + g_{3T+2})[l] * sum_{slot, q} theta_q D[s][T][(slot Q + q) L + l]:
+// r_ud_s(M^-1 g, U_r) of estimators.py:83 for full-order vectors (the mass matrix and its inverse cancel; D = Div Rt)
+__global__ __launch_bounds__(256) void k_div_pairing(Tmpl t, int S, int Q, int L, QVecA theta, const double* __restrict__ D,
+                                                     const double* __restrict__ G, double* __restrict__ out) {
+  const long total = (long)S * L;
+  const int C = 5 * Q * L;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(idx % L), s = (int)(idx / L);
+    double acc = 0.0;
+    for (int e = 0; e < t.nT; ++e) {
+      const double* g = G + ((long)s * t.n + 3 * e) * L + l;
+      const double gs = g[0] + g[L] + g[2 * (long)L];
+      const double* d = D + ((long)s * t.nT + e) * C + l;
+      double div = 0.0;
+      for (int slot = 0; slot < 5; ++slot)
+        for (int q = 0; q < Q; ++q) div += theta.v[q] * d[(long)(slot * Q + q) * L];
+      acc += gs * div;
+    }
+    out[idx] = acc;
+  }
+}
+
+int launch_div_apply(lrbms_ctx* ctx, int C, int mode, const double* Rt, double* out, hipStream_t st) {
+  if (C < 1 || mode < 0 || mode > 1) return lrbms_fail(ctx, LRBMS_E_INVALID, "div_apply: bad C / mode");
+  const long total = (long)ctx->S * ctx->t.nT * C;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256);
+  if (mode == 0)
+    hipLaunchKernelGGL(k_div_apply, dim3(grid), dim3(256), 0, st, ctx->t, ctx->S, ctx->nbr, C, Rt, out);
+  else
+    hipLaunchKernelGGL(k_mass_div_apply, dim3(grid), dim3(256), 0, st, ctx->t, ctx->S, ctx->nbr, C, Rt, out);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
+}
+
+int launch_div_pairing(lrbms_ctx* ctx, int Q, int L, const double* theta, const double* D, const double* G, double* out, hipStream_t st) {
+  if (Q < 1 || Q > 8 || L < 1) return lrbms_fail(ctx, LRBMS_E_INVALID, "div_pairing: bad Q / L");
+  QVecA th;
+  for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
+  const long total = (long)ctx->S * L;
+  hipLaunchKernelGGL(k_div_pairing, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->t, ctx->S, Q, L, th, D, G, out);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
+}
+
 int launch_blockell_apply(lrbms_ctx* ctx, int S, int M, const double* A, long sA, const double* x, double* y,
                           hipStream_t st) {
   const Tmpl& t = ctx->t;

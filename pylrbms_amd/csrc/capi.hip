@@ -25,6 +25,11 @@ int launch_fom_solve(lrbms_ctx* ctx, int Q, const double* theta, const double* A
 int launch_fom_implicit_euler(lrbms_ctx* ctx, int Q, const double* theta, double dt, int nt, const double* A_diag, const double* A_cpl,
                               const double* b, double* work, double* U, double rtol, int max_iter, double* info, hipStream_t st);
 int launch_mass_inverse_norm2(lrbms_ctx* ctx, int C, const double* Y, double* out, hipStream_t st);
+int launch_div_apply(lrbms_ctx* ctx, int C, int mode, const double* Rt, double* out, hipStream_t st);
+int launch_div_pairing(lrbms_ctx* ctx, int Q, int L, const double* theta, const double* D, const double* G, double* out, hipStream_t st);
+int launch_reduced_reconstruction_terms(lrbms_ctx* ctx, int Q, int N, int L, const double* theta, const double* B_sys,
+                                        const double* M_red, const double* rhs_red, const double* G_ud, const double* U,
+                                        double* work, double* out, hipStream_t st);
 int launch_reduced_implicit_euler(lrbms_ctx* ctx, int Q, int N, const double* theta, double dt, int nt, const double* B_sys,
                                   const double* M_red, const double* rhs_red, double* work, double* U, double rtol,
                                   int max_iter, double* info, hipStream_t st);
@@ -380,6 +385,25 @@ int lrbms_fom_implicit_euler(lrbms_ctx* ctx, int32_t Q, const double* theta, dou
 int lrbms_mass_inverse_norm2(lrbms_ctx* ctx, int32_t L, const double* Y, double* out, void* stream) {
   LRBMS_REQUIRE_MESH(ctx); CHECK_PTR(ctx, Y); CHECK_PTR(ctx, out);
   return launch_mass_inverse_norm2(ctx, L, Y, out, (hipStream_t)stream);
+}
+
+int lrbms_div_apply(lrbms_ctx* ctx, int32_t C, int32_t mode, const double* Rt, double* out, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_PTR(ctx, Rt); CHECK_PTR(ctx, out);
+  return launch_div_apply(ctx, C, mode, Rt, out, (hipStream_t)stream);
+}
+
+int lrbms_div_pairing(lrbms_ctx* ctx, int32_t Q, int32_t L, const double* theta, const double* D, const double* G, double* out,
+                      void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, D); CHECK_PTR(ctx, G); CHECK_PTR(ctx, out);
+  return launch_div_pairing(ctx, Q, L, theta, D, G, out, (hipStream_t)stream);
+}
+
+int lrbms_reduced_reconstruction_terms(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t L, const double* theta, const double* B_sys,
+                                       const double* M_red, const double* rhs_red, const double* G_ud, const double* U,
+                                       double* work, double* out, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, M_red);
+  CHECK_PTR(ctx, rhs_red); CHECK_PTR(ctx, G_ud); CHECK_PTR(ctx, U); CHECK_PTR(ctx, work); CHECK_PTR(ctx, out);
+  return launch_reduced_reconstruction_terms(ctx, Q, N, L, theta, B_sys, M_red, rhs_red, G_ud, U, work, out, (hipStream_t)stream);
 }
 
 int lrbms_reduced_implicit_euler(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, double dt, int32_t nt,

@@ -856,6 +856,77 @@ int launch_reduced_time_residual(lrbms_ctx* ctx, int Q, int N, int L, const doub
   return LRBMS_OK;
 }
 
+// Elliptic-reconstruction terms of _estimate_elliptic with d = rd (estimators.py:65-68, :80-83), per subdomain:
+//   out = y^T Minv y - b^T Minv b - 2 (Minv (y - b))^T G_ud ur,   y = (A_red(mu) u)_s, b = rhs_red[s], Minv = M_red[s]^-1,
+//   ur = theta_q u_nbr(slot)[j] in column order (slot, q, j), G_ud [S][N][5 Q N] = V^T M Div Rt (projected r_ud_s).
+// One wave per subdomain.
+__global__ __launch_bounds__(64) void k_red_recon_terms(const int* __restrict__ nbr, int Q, int N, QVec theta,
+                                                        const double* __restrict__ Minv, const double* __restrict__ y,
+                                                        const double* __restrict__ b, const double* __restrict__ G_ud,
+                                                        const double* __restrict__ u, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x, lane = threadIdx.x, C = 5 * Q * N;
+  double* ys = lds;            // [N]  y
+  double* ds = ys + N;         // [N]  y - b
+  double* bs = ds + N;         // [N]  b
+  double* ur = bs + N;         // [C]
+  for (int i = lane; i < N; i += 64) {
+    const double yv = y[(long)s * N + i], bv = b[(long)s * N + i];
+    ys[i] = yv;
+    bs[i] = bv;
+    ds[i] = yv - bv;
+  }
+  for (int c = lane; c < C; c += 64) {
+    const int slot = c / (Q * N), rem = c - slot * Q * N, q = rem / N, j = rem - q * N;
+    const int s2 = nbr[s * 5 + slot];
+    ur[c] = s2 >= 0 ? theta.v[q] * u[(long)s2 * N + j] : 0.0;
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (int r = lane; r < N; r += 64) {
+    const double* row = Minv + ((long)s * N + r) * N;
+    double zy = 0.0, zb = 0.0, w = 0.0;
+    for (int c = 0; c < N; ++c) {
+      zy += row[c] * ys[c];
+      zb += row[c] * bs[c];
+      w += row[c] * ds[c];
+    }
+    const double* g = G_ud + ((long)s * N + r) * C;
+    double gu = 0.0;
+    for (int c = 0; c < C; ++c) gu += g[c] * ur[c];
+    acc += zy * ys[r] - zb * bs[r] - 2.0 * w * gu;      // Minv is symmetric: (Minv d)_r (G_ud ur)_r summed over r
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) out[s] = acc;
+}
+
+int launch_reduced_reconstruction_terms(lrbms_ctx* ctx, int Q, int N, int L, const double* theta, const double* B_sys,
+                                        const double* M_red, const double* rhs_red, const double* G_ud, const double* U,
+                                        double* work, double* out, hipStream_t st) {
+  if (ctx->S_ext != ctx->S) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_reconstruction_terms needs all subdomains on one rank");
+  if (N > 64 || N < 1 || L < 1 || Q < 1 || Q > 8) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_reconstruction_terms: bad N / L / Q");
+  const int S = ctx->S;
+  QVec th;
+  for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
+  double* Amu = work;                                  // lrbms_reduced_time_residual_work_size doubles
+  double* Minv = Amu + (long)S * 5 * N * N;
+  double* y = Minv + (long)S * N * N;
+  double* partial = y + (long)S * N;
+  const long per_q = (long)S * 5 * N * N;
+  hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256),
+                     0, st, per_q, Q, th, B_sys, Amu);
+  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, M_red, Minv, 1, 0);
+  LRBMS_LAUNCH_CHECK(ctx);
+  for (int l = 0; l < L; ++l) {
+    const double* ul = U + (long)l * S * N;
+    hipLaunchKernelGGL(k_cg_matvec, dim3(S), dim3(64), sizeof(double) * 5 * N, st, ctx->nbr, N, Amu, ul, y, partial);
+    hipLaunchKernelGGL(k_red_recon_terms, dim3(S), dim3(64), sizeof(double) * (3 * N + 5 * Q * N), st, ctx->nbr, Q, N, th, Minv, y,
+                       rhs_red, G_ud, ul, out + (long)l * S);
+  }
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
+}
+
 // =========================================================================================================
 // Batched reduced solve: nmu parameters at once.  The affine structure A(mu) = sum_q theta_q(mu) B_q means the
 // block-sparse matvec of ALL parameters reads each projected block B_q[s][slot] exactly once per iteration

@@ -61,6 +61,28 @@ class InstationaryDuneDiscretization(DuneDiscretization):
         R = eng.ctx.fom_apply(self.theta(mu), eng.A_diag, eng.A_cpl, dU.tensor.contiguous())
         return eng.ctx.mass_inverse_norm2(R).sum(dim=0).cpu().numpy()
 
+    def _reconstruction_terms(self, U, mu):
+        """``r_l2(BU_R, BU_R) - r_l2(F_R, F_R) - 2 r_ud(BUF_R, U_r)`` per subdomain and vector (estimators.py:65-68,
+        :80-83) -> [S, len(U)]:  BU = A(mu) U (``lrbms_fom_apply``), the ``r_l2`` terms are ``M^-1`` norms
+        (``lrbms_mass_inverse_norm2``), and in ``r_ud(M^-1 (BU - f), U_r)`` the mass matrices cancel:
+        ``(BU - f)^T Div U_r`` (``lrbms_flux_reconstruct`` -> ``lrbms_div_apply`` -> ``lrbms_div_pairing``)."""
+        import torch
+        eng = self.engine
+        if eng.S_ext != eng.S:
+            raise NotImplementedError('the parabolic estimate needs all subdomains on one rank')
+        theta = self.theta(mu)
+        c = eng.ctx
+        t2 = c.mass_inverse_norm2(eng.b.reshape(eng.S, eng.t.n, 1).contiguous())            # [S, 1]
+        out = []
+        for c0 in range(0, len(U), 16):
+            V = U.tensor[:, :, c0:c0 + 16].contiguous()
+            BU = c.fom_apply(theta, eng.A_diag, eng.A_cpl, V)
+            t1 = c.mass_inverse_norm2(BU)
+            D = c.div_apply(c.flux_reconstruct(eng.F, V), mode=0)
+            t3 = c.div_pairing(theta, D, (BU - eng.b.reshape(eng.S, eng.t.n, 1)).contiguous())
+            out.append(t1 - t2 - 2.0 * t3)
+        return torch.cat(out, dim=1)
+
 
 def discretize(grid_and_problem_data, T, nt, solver_options=None, mpi_comm=None, device_index=None,
                elliptic_reconstruction=False):

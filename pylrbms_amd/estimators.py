@@ -48,12 +48,20 @@ class EstimatorBase:
         return d._local_estimates(U, mu)
 
     def _estimate_elliptic(self, U, mu, d, elliptic_reconstruction=False, decompose=False):
-        if elliptic_reconstruction:
-            assert False                                                   # estimators.py:63-64
         alpha_mu_mu_bar = self.alpha(self.lambda_coeffs, mu, self.mu_bar)
         gamma_mu_mu_bar = self.gamma(self.lambda_coeffs, mu, self.mu_bar)
         alpha_mu_mu_hat = self.alpha(self.lambda_coeffs, mu, self.mu_hat)
         local_eta_nc, local_eta_r, local_eta_df = self._local_indicators(U, mu, d)
+        if elliptic_reconstruction:
+            # estimators.py:63-68, :80-83.  The reference stops here with `assert False`; the terms behind it are
+            #   + r_l2(BU_R, BU_R) - r_l2(F_R, F_R) - 2 r_ud(BUF_R, U_r)   with BU_R = M^-1 A(mu) U, F_R = M^-1 f,
+            # added to local_eta_r before its Poincare scaling (:88-91) -- evaluated natively by the discretization
+            import torch
+            scale = (1.0 / np.pi ** 2) / np.asarray(self.min_diffusion_evs.cpu() if hasattr(self.min_diffusion_evs, 'cpu')
+                                                    else self.min_diffusion_evs, dtype=np.float64) \
+                * np.asarray(self.subdomain_diameters, dtype=np.float64) ** 2
+            add = d._reconstruction_terms(U, mu)                           # [num_subdomains, len(U)] device tensor
+            local_eta_r = local_eta_r + add * torch.as_tensor(scale, dtype=add.dtype, device=add.device)[:, None]
         if self.sqrt_local:
             local_eta_nc, local_eta_r, local_eta_df = (x.abs().sqrt() for x in (local_eta_nc, local_eta_r, local_eta_df))
         group = getattr(self.mpi_comm, 'group', None)
@@ -105,8 +113,9 @@ class ParabolicEstimator(EstimatorBase):
 
     At HEAD this estimator cannot run: it asks ``_estimate_elliptic`` for the elliptic reconstruction (:143), whose
     branch starts with ``assert False`` (:64).  ``elliptic_reconstruction=False`` (default) evaluates the code as written
-    without that branch; ``True`` keeps the reference's behaviour (AssertionError).  One eta per time step (see
-    oracle/parabolic.py on ``mpi_norm``)."""
+    without that branch; ``True`` evaluates the terms behind the ``assert False`` as well (operators ``r_ud_i`` /
+    ``r_l2_i``, discretize_parabolic_block_swipdg.py:65-74).  One eta per time step (see oracle/parabolic.py on
+    ``mpi_norm``)."""
 
     def __init__(self, *args, elliptic_reconstruction=False, **kwargs):
         super().__init__(*args, **kwargs)

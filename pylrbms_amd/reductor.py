@@ -390,6 +390,25 @@ class InstationaryReducedDiscretization(ReducedDiscretization):
         out = eng.ctx.reduced_time_residual(self.d.theta(mu), self.B_sys, self.M_red, dU.tensor.permute(2, 0, 1).contiguous())
         return out.sum(dim=1).cpu().numpy()
 
+    def _projected_r_ud(self):
+        """``V_s^T M_s Div_s Rt_s`` [S, N, 5 Q N]: the projection of ``r_ud_s`` (discretize_parabolic_block_swipdg.py:65-70)
+        onto the local basis and the RT image basis, built on first use from K8, ``lrbms_div_apply`` and ``lrbms_gemm_tn``."""
+        if getattr(self, '_G_ud', None) is None:
+            eng = self.d.engine
+            V = self.reductor._V.contiguous()
+            MD = eng.ctx.div_apply(eng.ctx.flux_reconstruct(eng.F, V), mode=1)               # [S, n, 5 Q N]
+            self._G_ud = eng.ctx.gemm_tn(V, MD)
+        return self._G_ud
+
+    def _reconstruction_terms(self, U, mu):
+        """The elliptic-reconstruction terms with the projected operators (``lrbms_reduced_reconstruction_terms``) -> [S, len(U)]."""
+        eng = self.d.engine
+        if eng.S_ext != eng.S:
+            raise NotImplementedError('the reduced parabolic estimate needs all subdomains on one rank')
+        out = eng.ctx.reduced_reconstruction_terms(self.d.theta(mu), self.B_sys, self.M_red, self.rhs_red, self._projected_r_ud(),
+                                                   U.tensor.permute(2, 0, 1).contiguous())
+        return out.t().contiguous()
+
 
 class ParabolicLRBMSReductor(LRBMSReductor):
     """The reductor python/scripts/parabolic.py:9,42-45 asks for (imported there from ``dune.pylrbms.estimators``, where
