@@ -184,6 +184,7 @@ int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* d, int32_t S, int32
   const int* nbr_dev = nullptr;
   if ((rc = upload(ctx, nbr, (size_t)S * 5, &nbr_dev))) return rc;
   ctx->nbr = const_cast<int*>(nbr_dev);
+  ctx->nbr_host.assign(nbr, nbr + (size_t)S * 5);
   ctx->S = S;
   ctx->S_ext = S_ext;
   if ((rc = build_template_tables(ctx))) return rc;

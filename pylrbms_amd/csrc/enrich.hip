@@ -312,12 +312,16 @@ int64_t local_correction_work_size(lrbms_ctx* ctx, int nmark) {
 int launch_local_correction(lrbms_ctx* ctx, int Q, const double* theta, int nmark, const int32_t* marked, const double* A_diag,
                             const double* A_cpl, const double* D_corr, const double* b, double* work, double* corr, double rtol,
                             int max_iter, double* info, hipStream_t st) {
-  if (ctx->S_ext != ctx->S)
-    return lrbms_fail(ctx, LRBMS_E_INVALID, "local_correction_solve needs all subdomains on one rank");
   if (nmark < 1 || Q < 1 || Q > 8 || max_iter < 1 || !(rtol > 0.0))
     return lrbms_fail(ctx, LRBMS_E_INVALID, "local_correction_solve: bad nmark / Q / max_iter / rtol");
-  for (int m = 0; m < nmark; ++m)
+  for (int m = 0; m < nmark; ++m) {
     if (marked[m] < 0 || marked[m] >= ctx->S) return lrbms_fail(ctx, LRBMS_E_INVALID, "local_correction_solve: marked index out of range");
+    // the operator blocks of the WHOLE neighbourhood must be on this rank (a sharded discretization runs its corrector
+    // problems on a context whose local set is its local + halo subdomains)
+    for (int slot = 0; slot < 5; ++slot)
+      if (ctx->nbr_host[(size_t)marked[m] * 5 + slot] >= ctx->S)
+        return lrbms_fail(ctx, LRBMS_E_INVALID, "local_correction_solve: the neighbourhood of a marked subdomain is not assembled on this rank");
+  }
   const int nel = 5 * ctx->t.nT;
   if ((size_t)5 * ctx->t.n * sizeof(double) + 1024 > 160 * 1024)
     return lrbms_fail(ctx, LRBMS_E_INVALID, "local_correction_solve: neighbourhood does not fit in LDS");

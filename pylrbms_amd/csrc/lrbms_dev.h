@@ -32,6 +32,7 @@ struct lrbms_ctx {
   Tmpl t{};
   int S = 0, S_ext = 0;
   int* nbr = nullptr;             // [S][5] device
+  std::vector<int32_t> nbr_host;  // the same on the host (argument checks)
   std::vector<void*> owned;       // device allocations to free
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // library-owned streams: independent small kernels run concurrently
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};

@@ -214,8 +214,6 @@ class DuneDiscretization:
         """All corrector problems of one enrichment round in one launch (``lrbms_local_correction_solve``); returns
         one single-vector array per subdomain, on the subdomain's local space."""
         eng = self.engine
-        if eng.S_ext != eng.S:
-            raise NotImplementedError('local corrector solves on a sharded discretization')
         opts = inverse_options if isinstance(inverse_options, dict) else {}
         rtol = min(float(opts.get('precision', 1e-12)), 1e-10)
         marked = [eng.local.index(int(ii)) for ii in subdomains]

@@ -56,6 +56,7 @@ class Engine:
     """All device state of one rank for one discretization."""
 
     def __init__(self, grid, lambda_funcs, kappa, f, lambda_bar, lambda_hat, theta_bar, device_index=0):
+        self._init_args = (lambda_funcs, kappa, f, lambda_bar, lambda_hat, theta_bar, device_index)
         self.grid = grid
         t = grid.template
         self.t = t
@@ -204,6 +205,19 @@ class Engine:
         """Neighbourhood corrector solves for the subdomains ``marked`` (local indices): [len(marked), n] + info."""
         if not self.assembled:
             raise NativeError('assemble() must run before local_corrections()')
+        if self.S_ext != self.S and not getattr(self, '_is_hood', False):
+            # sharded: the neighbourhood of a local subdomain reaches into the halo, whose operator blocks this engine does
+            # not hold.  The corrector problems run on a second engine whose LOCAL set is this rank's local + halo
+            # subdomains (same leading order, so local indices agree); its coefficients are sampled and its blocks assembled
+            # here, without communication (assembly needs coefficient samples only).
+            if getattr(self, '_hood_engine', None) is None:
+                import copy
+                g2 = copy.copy(self.grid)
+                g2._on_rank = list(self.ext)
+                self._hood_engine = Engine(g2, *self._init_args).assemble()
+                self._hood_engine._is_hood = True
+            corr, info = self._hood_engine.local_corrections(theta, marked, rtol=rtol, max_iter=max_iter)
+            return corr, info
         if getattr(self, 'D_corr', None) is None:
             self.D_corr = self.ctx.assemble_dirichlet_correction(self.lam)
         return self.ctx.local_correction_solve(theta, marked, self.A_diag, self.A_cpl, self.D_corr, self.b, rtol=rtol,

@@ -36,14 +36,31 @@ class AdaptiveEnrichment:
         self.marking_doerfler_theta = marking_doerfler_theta
         self.marking_max_age = marking_max_age
 
+    def _global_indicators(self, indicators):
+        """Sharded discretization: the marking is global, so every rank needs the indicators of all subdomains (one
+        all-gather of a double per subdomain); unsharded: the array as it is."""
+        eng = self.discretization.engine
+        if eng.S_ext == eng.S:
+            return np.asarray(indicators)
+        from pylrbms_amd.grid import DDSubdomainsGrid
+        from pylrbms_amd.parallel import gather_subdomain_rows
+        g = eng.grid
+        owned = [list(DDSubdomainsGrid(g.lower_left, g.upper_right, g.K, g.P, rank=r, world_size=g.world_size).subdomains_on_rank)
+                 for r in range(g.world_size)]
+        loc = eng.ctx.from_numpy(np.asarray(indicators, dtype=np.float64).reshape(-1, 1))
+        glob = gather_subdomain_rows(loc, owned, g.num_subdomains, getattr(self.discretization.mpi_comm, 'group', None))
+        return glob[:, 0].cpu().numpy()
+
     def _enrich_once(self, U, mu, indicators, age_count):
+        indicators = self._global_indicators(indicators)
         marked_subdomains = set(doerfler_marking(indicators, self.marking_doerfler_theta))
         for ii in np.where(age_count > self.marking_max_age)[0]:
             marked_subdomains.add(ii)
+        mine = sorted(ii for ii in marked_subdomains if ii in set(self.discretization.engine.local))   # this rank's share
         if hasattr(self.reductor, 'enrich_local_batch'):
-            self.reductor.enrich_local_batch(sorted(marked_subdomains), U, mu)
+            self.reductor.enrich_local_batch(mine, U, mu)
         else:
-            for ii in marked_subdomains:
+            for ii in mine:
                 self.reductor.enrich_local(ii, U, mu)
         self.rd = self.reductor.reduce()
         for ii in range(self.block_space.num_blocks):

@@ -304,6 +304,20 @@ class LRBMSReductor:
         if self._V is None:
             raise RuntimeError('no basis')
         N = self.basis_size()
+        if eng.S_ext != eng.S:
+            # sharded: after an enrichment round the widest local basis may live on another rank; the basis slabs
+            # travel through the halo exchange, so every rank pads to the global width (one max all-reduce)
+            import torch
+            import torch.distributed as dist
+            if dist.is_initialized():
+                width = torch.tensor([N], dtype=torch.int64, device=self._V.device)
+                staged = dist.get_backend(getattr(d.mpi_comm, 'group', None)) == 'gloo'
+                if staged:
+                    width = width.cpu()
+                dist.all_reduce(width, op=dist.ReduceOp.MAX, group=getattr(d.mpi_comm, 'group', None))
+                N = int(width.item())
+            if N > self._V.shape[2]:
+                self._V = torch.nn.functional.pad(self._V, (0, N - self._V.shape[2])).contiguous()
         V = d._with_halo(self._V)
         if getattr(self, '_buffers', None) is None or self._buffers['N'] != N:
             self._buffers = eng.alloc_reduce_buffers(N)                   # scratch (and image bases if unfused): reused

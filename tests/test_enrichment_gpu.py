@@ -167,3 +167,35 @@ def test_adaptive_enrichment_loop():
     assert abs(history[-1]['eta'] - eta_o) < 1e-7 * eta_o
     rec_o = np.stack(oreductor.reconstruct(u_o))
     assert np.abs(reductor.reconstruct(U).data.reshape(o.S, o.n) - rec_o).max() < 1e-7 * np.abs(rec_o).max()
+
+
+def test_corrector_solves_on_a_sharded_discretization_match_the_single_rank_ones():
+    """A rank of a sharded discretization solves the neighbourhood problems of ITS subdomains on a second engine whose
+    local set is local + halo (assembled on the rank, no communication): same correctors as the single-rank run."""
+    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd.engine import Engine
+    from pylrbms_amd.parallel import Communicator
+    cfg = {'num_subdomains': [4, 3], 'coarse_per_subdomain': 2}
+
+    def engine(comm):
+        p = multiscale_problem.init_grid_and_problem(cfg, mpi_comm=comm)
+        lam = p['lambda']
+        tb = np.array([c.evaluate(p['mu_bar']) for c in lam['coefficients']])
+        return p, Engine(p['grid'], lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], tb).assemble()
+
+    p, whole = engine(None)
+    theta = np.array([c.evaluate(0.37) for c in p['lambda']['coefficients']])
+    ref, _ = whole.local_corrections(theta, list(range(whole.S)))
+    ref = ref.cpu().numpy()
+    seen = []
+    for world in (2, 4):
+        for rank in range(world):
+            _, eng = engine(Communicator(rank, world))
+            assert eng.S_ext > eng.S
+            corr, info = eng.local_corrections(theta, list(range(eng.S)))
+            assert float(info[:, 1].max()) <= 1e-12
+            got = corr.cpu().numpy()
+            for i, g in enumerate(eng.local):
+                assert np.abs(got[i] - ref[g]).max() < 1e-9 * np.abs(ref[g]).max()
+                seen.append(g)
+    assert sorted(set(seen)) == list(range(whole.S))
