@@ -123,12 +123,11 @@ class DuneDiscretization:
 
     def solve(self, mu, inverse_options=None):
         """``DuneDiscretization._solve`` (block_swipdg.py:219-225).  The reference hands the global matrix to ISTL
-        (bicgstab.ilut); here: preconditioned CG on the SPD block operator, never assembled.  One rank: the native
-        ``lrbms_fom_solve`` (element-block Jacobi, four launches per iteration, no host round trips).  Sharded: the same
-        iteration driven from here with ``lrbms_fom_apply`` as matvec, a halo exchange per iteration and all-reduced dot
-        products.  (Snapshot generation is the step before the hot path: SURVEY.md section 8f #2.)"""
+        (bicgstab.ilut); here: preconditioned CG on the SPD block operator, never assembled, by the native
+        ``lrbms_fom_solve`` (element-block Jacobi + coarse level on the subdomain indicator functions, two to four launches
+        per iteration, no host round trips).  Sharded: every rank gathers the block operator once and solves redundantly.
+        (Snapshot generation is the step before the hot path: SURVEY.md section 8f #2.)"""
         import torch
-        import torch.distributed as dist
         eng = self.engine
         theta = self.theta(mu)
         opts = inverse_options or {}
@@ -136,48 +135,41 @@ class DuneDiscretization:
         rtol = min(rtol, 1e-10)
         max_iter = int(opts.get('max_iter', 20000)) if isinstance(opts, dict) else 20000
         max_iter = max(max_iter, 20000)
-        group = getattr(self.mpi_comm, 'group', None)
         sharded = eng.S_ext != eng.S
         if not sharded:
             x, info = eng.ctx.fom_solve(theta, eng.A_diag, eng.A_cpl, eng.b, rtol=rtol, max_iter=max_iter)
             self.last_solve_info = info
             return BlockVectorArray(x.reshape(eng.S, eng.t.n, 1), self.solution_space)
 
-        def dot(a, b):
-            v = (a * b).sum()
-            if sharded:
-                dist.all_reduce(v, group=group)
-            return v
+        # sharded: the block operator of the whole domain is small next to 288 GB of HBM (75 MB of diagonal blocks at config
+        # 3), so every rank gathers it once (one all-gather each for A_diag, A_cpl, b) and solves redundantly with the native
+        # solver through a second library context that holds the GLOBAL neighbour table; it keeps its own rows.
+        ctx, A_diag_all, A_cpl_all, b_all = self._global_fom()
+        x, info = ctx.fom_solve(theta, A_diag_all, A_cpl_all, b_all, rtol=rtol, max_iter=max_iter)
+        self.last_solve_info = info
+        x = x[torch.as_tensor(eng.local, device=x.device)]
+        return BlockVectorArray(x.reshape(eng.S, eng.t.n, 1), self.solution_space)
 
-        def apply(x):
-            return eng.ctx.fom_apply(theta, eng.A_diag, eng.A_cpl, self._with_halo(x))
-
-        # diagonal of A(mu): diagonal 3x3 blocks of the block-ELL storage
-        diag = sum(float(theta[q]) * eng.A_diag[q][:, :, 0].reshape(eng.S, eng.t.n_T, 3, 3).diagonal(dim1=2, dim2=3)
-                   for q in range(eng.Q)).reshape(eng.S, eng.t.n, 1)
-        b = eng.b.reshape(eng.S, eng.t.n, 1)
-        x = torch.zeros_like(b)
-        r = b.clone()
-        z = r / diag
-        p = z.clone()
-        rz = dot(r, z)
-        bb = float(dot(b, b))
-        if bb == 0.0:
-            return BlockVectorArray(x, self.solution_space)
-        for it in range(max_iter):
-            Ap = apply(p)
-            alpha = rz / dot(p, Ap)
-            x += alpha * p
-            r -= alpha * Ap
-            if it % 25 == 24 and float(dot(r, r)) <= (rtol ** 2) * bb:
-                break
-            z = r / diag
-            rz_new = dot(r, z)
-            p = z + (rz_new / rz) * p
-            rz = rz_new
-        else:
-            raise RuntimeError('FOM CG did not converge')
-        return BlockVectorArray(x, self.solution_space)
+    def _global_fom(self):
+        """(context, A_diag [Q, S_total, n_T, 4, 9], A_cpl [Q, S_total, 4, ncf, 9], b [S_total, n]) in global order."""
+        if getattr(self, '_fom_global', None) is None:
+            from pylrbms_amd._native import NativeContext
+            from pylrbms_amd.grid import DDSubdomainsGrid
+            from pylrbms_amd.parallel import gather_subdomain_rows
+            eng = self.engine
+            g = eng.grid
+            group = getattr(self.mpi_comm, 'group', None)
+            owned = [list(DDSubdomainsGrid(g.lower_left, g.upper_right, g.K, g.P, rank=r, world_size=g.world_size).subdomains_on_rank)
+                     for r in range(g.world_size)]
+            total = g.num_subdomains
+            A_d = gather_subdomain_rows(eng.A_diag.permute(1, 0, 2, 3, 4).contiguous(), owned, total, group)
+            A_c = gather_subdomain_rows(eng.A_cpl.permute(1, 0, 2, 3, 4).contiguous(), owned, total, group)
+            b = gather_subdomain_rows(eng.b, owned, total, group)
+            ctx = NativeContext(eng.ctx.device.index)
+            nbr = np.asarray(g.neighbor_slots, dtype=np.int32).reshape(total, 5)
+            ctx.mesh_upload(eng.t, eng.kappa, nbr, total, total)
+            self._fom_global = (ctx, A_d.permute(1, 0, 2, 3, 4).contiguous(), A_c.permute(1, 0, 2, 3, 4).contiguous(), b.contiguous())
+        return self._fom_global
 
     def _local_estimates(self, U, mu):
         """Per-subdomain nc / r / df for every vector of a full-order array: the vectors become a basis of ``len(U)``

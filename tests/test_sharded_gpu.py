@@ -165,6 +165,7 @@ def _enrichment_run(p, comm=None):
     from pylrbms_amd.reductor import LRBMSReductor
     d, data = discretize(p, mpi_comm=comm)
     reductor = LRBMSReductor(d, order=0)
+    reductor.extend_basis(d.solve(0.7))      # a snapshot: on a sharded discretization the gathered operator, solved natively
     rd = reductor.reduce()
     ae = AdaptiveEnrichment(p, d, data['block_space'], reductor, rd, target_error=1e-12, marking_doerfler_theta=0.5,
                             marking_max_age=2)
