@@ -10,7 +10,8 @@ with ``nt`` steps (:87).  The reference's version does not run at HEAD (SURVEY.m
 * the estimator's ``elliptic_reconstruction=True`` hits ``assert False`` (estimators.py:64) -> flag, default off.
 
 ``solve(mu)`` is ONE native call for the whole trajectory (``lrbms_fom_implicit_euler``): the theta-weighted block
-operator plus the mass is combined once, every step is a warm-started CG on it.  All subdomains on one rank.
+operator plus the mass is combined once, every step is a warm-started CG on it.  On a sharded discretization the solves
+run on the gathered operator; the parabolic estimate needs all subdomains on one rank.
 """
 import numpy as np
 
@@ -38,14 +39,23 @@ class InstationaryDuneDiscretization(DuneDiscretization):
 
     def solve(self, mu, inverse_options=None):
         """``_solve`` (:28-40): ``nt + 1`` vectors, the first one the (zero) initial data."""
+        import torch
         eng = self.engine
-        if eng.S_ext != eng.S:
-            raise NotImplementedError('the parabolic solve needs all subdomains on one rank')
         rtol, max_iter = self._solve_options(inverse_options)
         dt = self.T / self.time_stepper.nt
         U0 = self.initial_data.tensor[:, :, 0] if self.initial_data is not None else None
-        U, info = eng.ctx.fom_implicit_euler(self.theta(mu), dt, self.time_stepper.nt, eng.A_diag, eng.A_cpl, eng.b, U0=U0,
-                                             rtol=rtol, max_iter=max_iter)
+        if eng.S_ext != eng.S:
+            # sharded: like the stationary solve, on the gathered block operator (DuneDiscretization._global_fom); the
+            # initial data of the reference is zero (:82), a non-zero one would have to be gathered as well
+            if U0 is not None and bool((U0 != 0).any()):
+                raise NotImplementedError('non-zero initial data on a sharded discretization')
+            ctx, A_diag_all, A_cpl_all, b_all = self._global_fom()
+            U, info = ctx.fom_implicit_euler(self.theta(mu), dt, self.time_stepper.nt, A_diag_all, A_cpl_all, b_all, rtol=rtol,
+                                             max_iter=max_iter)
+            U = U[:, torch.as_tensor(eng.local, device=U.device)]
+        else:
+            U, info = eng.ctx.fom_implicit_euler(self.theta(mu), dt, self.time_stepper.nt, eng.A_diag, eng.A_cpl, eng.b, U0=U0,
+                                                 rtol=rtol, max_iter=max_iter)
         self.last_solve_info = info
         return BlockVectorArray(U.permute(1, 2, 0), self.solution_space)
 

@@ -389,11 +389,22 @@ class InstationaryReducedDiscretization(ReducedDiscretization):
 
     def solve(self, mu, inverse_options=None):
         eng = self.d.engine
-        if eng.S_ext != eng.S:
-            raise NotImplementedError('the reduced parabolic solve needs all subdomains on one rank')
         dt = self.T / self.time_stepper.nt
-        U, info = eng.ctx.reduced_implicit_euler(self.d.theta(mu), dt, self.time_stepper.nt, self.B_sys, self.M_red,
-                                                 self.rhs_red)
+        if eng.S_ext != eng.S:                                       # sharded: on the gathered reduced system, like rd.solve
+            from pylrbms_amd.parallel import gather_subdomain_rows
+            ctx, B_all, rhs_all = self._global_online()
+            if getattr(self, '_M_all', None) is None:
+                from pylrbms_amd.grid import DDSubdomainsGrid
+                g = eng.grid
+                owned = [list(DDSubdomainsGrid(g.lower_left, g.upper_right, g.K, g.P, rank=r, world_size=g.world_size).subdomains_on_rank)
+                         for r in range(g.world_size)]
+                self._M_all = gather_subdomain_rows(self.M_red, owned, g.num_subdomains,
+                                                    getattr(self.d.mpi_comm, 'group', None)).contiguous()
+            U, info = ctx.reduced_implicit_euler(self.d.theta(mu), dt, self.time_stepper.nt, B_all, self._M_all, rhs_all)
+            U = U[:, self._torch.as_tensor(eng.local, device=U.device)]
+        else:
+            U, info = eng.ctx.reduced_implicit_euler(self.d.theta(mu), dt, self.time_stepper.nt, self.B_sys, self.M_red,
+                                                     self.rhs_red)
         self.last_solve_info = info
         return ReducedVectorArray(U.permute(1, 2, 0))
 

@@ -205,3 +205,45 @@ def test_adaptive_enrichment_on_a_sharded_discretization():
         assert abs(eta - eta1) < 1e-8 * eta1 and np.allclose(log, log1, rtol=1e-8)
         sizes.update(loc)
     assert sizes == sizes1
+
+
+def _parabolic_run(p, comm=None):
+    from pylrbms_amd.discretize_parabolic_block_swipdg import discretize
+    from pylrbms_amd.reductor import ParabolicLRBMSReductor
+    d, _ = discretize(p, 0.2, 4, mpi_comm=comm)
+    U = d.solve(0.6)
+    reductor = ParabolicLRBMSReductor(d, order=0)
+    reductor.extend_basis(U[[2, 4]])
+    u = reductor.reduce().solve(0.6)
+    return dict(zip(d.engine.local, U.tensor.cpu().numpy())), dict(zip(d.engine.local, reductor.reconstruct(u).tensor.cpu().numpy()))
+
+
+def _parabolic_worker(rank, world, port, results):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pylrbms_amd.parallel import Communicator
+        results[rank] = _parabolic_run(_problem(Communicator(rank, world)), Communicator(rank, world))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_parabolic_solves_on_a_sharded_discretization():
+    """Full-order and reduced implicit Euler trajectories on two ranks (gathered operators, native solvers on every rank)
+    equal the single-rank ones."""
+    U1, R1 = _parabolic_run(_problem())
+    torch.cuda.empty_cache()
+    world = 2
+    port = 29100 + (os.getpid() % 1500)
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_parabolic_worker, args=(world, port, results), nprocs=world, join=True)
+    seen = 0
+    for r in range(world):
+        U, R = results[r]
+        for g in U:
+            assert np.abs(U[g] - U1[g]).max() < 1e-9 * np.abs(U1[g]).max()
+            assert np.abs(R[g] - R1[g]).max() < 1e-8 * np.abs(R1[g]).max()
+            seen += 1
+    assert seen == PX * PY
