@@ -64,7 +64,7 @@ def _worker(rank, world, port, results, mode):
 
 @pytest.mark.parametrize('world,mode', [(2, 'alltoall'), (4, 'alltoall'), (2, 'allgather'), (4, 'allgather')])
 def test_halo_exchange_gloo(world, mode):
-    port = 29500 + (os.getpid() % 2000) + world + (10 if mode == 'allgather' else 0)
+    port = 27500 + (os.getpid() % 1000) + world + (10 if mode == "allgather" else 0)
     mgr = mp.Manager()
     results = mgr.dict()
     mp.spawn(_worker, args=(world, port, results, mode), nprocs=world, join=True)

@@ -127,7 +127,7 @@ def test_sharded_projection_matches_single_rank(world, tmp_path):
     np.savez(ref_path, **out)
     del eng, buf, V
     torch.cuda.empty_cache()
-    port = 29700 + (os.getpid() % 1500) + world
+    port = 29500 + 2 * (os.getpid() % 100) + world        # disjoint port ranges per test of this file
     mgr = mp.Manager()
     results = mgr.dict()
     mp.spawn(_worker, args=(world, port, ref_path, results), nprocs=world, join=True)
@@ -195,7 +195,7 @@ def test_adaptive_enrichment_on_a_sharded_discretization():
     assert len(log1) == 3 and max(sizes1.values()) > min(sizes1.values())          # ragged after marking
     torch.cuda.empty_cache()
     world = 2
-    port = 29300 + (os.getpid() % 1500)
+    port = 29300 + (os.getpid() % 150)
     mgr = mp.Manager()
     results = mgr.dict()
     mp.spawn(_enrich_worker, args=(world, port, results), nprocs=world, join=True)
@@ -235,7 +235,7 @@ def test_parabolic_solves_on_a_sharded_discretization():
     U1, R1 = _parabolic_run(_problem())
     torch.cuda.empty_cache()
     world = 2
-    port = 29100 + (os.getpid() % 1500)
+    port = 29100 + (os.getpid() % 150)
     mgr = mp.Manager()
     results = mgr.dict()
     mp.spawn(_parabolic_worker, args=(world, port, results), nprocs=world, join=True)
