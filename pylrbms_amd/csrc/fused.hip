@@ -858,7 +858,11 @@ __global__ __launch_bounds__(64 * (F2_NCW + EC)) void k_f2(Tmpl t, F2Args a) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int cc = lane + 64 * k;
+#ifdef F2_NO_STAGE
+        if (cc < QN && cr[k][0] == 1.2345e300) {
+#else
         if (cc < QN) {
+#endif
           const double rv0 = cr[k][0], rv1 = cr[k][1], rv2 = cr[k][2];
           xb[(3 * el) * LD + cc] = rv0;
           xb[(3 * el + 1) * LD + cc] = rv1;
@@ -919,10 +923,14 @@ __global__ __launch_bounds__(64 * (F2_NCW + EC)) void k_f2(Tmpl t, F2Args a) {
       for (int k = 0; k < TPW; ++k) {
         if (ti[k] < 0) continue;                   // wave-uniform
         const int xo = ti[k] * 16 + li, yo = tj[k] * 16 + li;
+#ifndef F2_NO_MFMA
 #pragma unroll
         for (int kk = 0; kk < 3 * EC; kk += 4)
           accb[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[(kk + lk) * LD + xo], yb[(kk + lk) * LD + yo], accb[k], 0, 0, 0);
         accd[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[lk * LD + xo], yd[lk * LD + yo], accd[k], 0, 0, 0);
+#else
+        (void)xb; (void)yb; (void)xd; (void)yd; (void)xo; (void)yo;
+#endif
       }
     }
     lds_barrier();                                 // final barrier
