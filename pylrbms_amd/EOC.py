@@ -210,6 +210,11 @@ class StationaryEocStudy(EocStudy):
         self._grid_and_problem_data[-1] = self._grid_and_problem_initializer(self._config[-1])
         self._d[-1], self._d_data[-1] = self._discretizer(self._grid_and_problem_data[-1])
         self._solution[-1] = self._d[-1].solve(self._d[-1].parse_parameter(self.mu))
+        if 'reductor' in self._d_data[-1]:
+            # "as reduced" studies (python/scripts/OS2015_convergence_study_as_reduced.py) hand in a discretizer that
+            # returns the reduced model; the reference solution is the full-order one of the same discretization
+            self._d[-1] = self._d[-1].d
+            self._solution[-1] = self._d[-1].solve(self._d[-1].parse_parameter(self.mu))
 
     def _reconstructed(self, level):
         if 'reductor' in self._d_data[level]:                                 # EOC.py:303-304

@@ -145,3 +145,44 @@ def test_instationary_eoc_study(capsys):
     got = study._solution_as_reference[0]
     want = got[:, :, -1:] * torch.linspace(0, 1, ntr + 1, dtype=U0.dtype, device=U0.device)[None, None, :]
     assert float((got - want).abs().max()) < 1e-12 * float(want.abs().max())
+
+
+def test_stationary_eoc_study_as_reduced():
+    """python/scripts/OS2015_convergence_study_as_reduced.py: the discretizer returns the reduced model built from the
+    snapshot for mu = 1 (plus the reductor); solved at mu = 1 the reduced solution IS the snapshot, so errors and
+    estimates equal those of the full-order study."""
+    from pylrbms_amd import OS2015_academic_problem
+    from pylrbms_amd.EOC import StationaryEocStudy
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize as discretize_block
+    from pylrbms_amd.reductor import ExtensionError, LRBMSReductor
+
+    def discretize_fom(gp):
+        d, data = discretize_block(gp)
+        return d, {'block_space': data['block_space'], 'unblock': d.unblock}
+
+    def discretize_rom(gp, mus=(1,)):
+        d, data = discretize_block(gp)
+        reductor = LRBMSReductor(d, products=[d.operators['local_energy_dg_product_{}'.format(ii)]
+                                              for ii in range(data['block_space'].num_blocks)])
+        for mu in mus:
+            try:
+                reductor.extend_basis(d.solve(d.parse_parameter(mu)))
+            except ExtensionError:
+                pass
+        return reductor.reduce(), {'block_space': data['block_space'], 'unblock': d.unblock, 'reductor': reductor}
+
+    def refine(cfg):
+        out = dict(cfg)
+        out['half_num_fine_elements_per_subdomain_and_dim'] *= 2
+        out['num_subdomains'] = [2 * s for s in cfg['num_subdomains']]
+        return out
+
+    base = {'num_subdomains': [2, 2], 'half_num_fine_elements_per_subdomain_and_dim': 4}
+    import io
+    fom = StationaryEocStudy(OS2015_academic_problem.init_grid_and_problem, discretize_fom, base, refine, mu=1, max_levels=1)
+    rom = StationaryEocStudy(OS2015_academic_problem.init_grid_and_problem, discretize_rom, base, refine, mu=1, max_levels=1)
+    df, dr = fom.run(file=io.StringIO()), rom.run(file=io.StringIO())
+    for level in (0, 1):
+        for kind in ('norm', 'indicator', 'estimate'):
+            for q, v in df[level][kind].items():
+                assert abs(dr[level][kind][q] - v) < 1e-6 * abs(v), (level, kind, q)
