@@ -162,3 +162,22 @@ def test_reduced_model_parameter_sweep_and_preconditioner_reuse():
         assert np.abs(rec_1 - ref).max() < 1e-8 * np.abs(ref).max()
         assert np.abs(rec_b[k] - ref).max() < 1e-8 * np.abs(ref).max()
     assert next(iter(rd._pc.values())) is pc_before                   # reused, not rebuilt
+
+
+def test_product_reproduces_the_reference_scripts_known_answers():
+    """python/scripts/linearelliptic_block_swipdg_decomp.py:19-43 through the PRODUCT (not the oracle): OS2015, 4x4
+    subdomains, mu = 1; the script prints what its three indicators 'should be' -- 1.66e-01 / 1.45e-01 / 3.55e-01 (the sqrt
+    variant of the local indicators).  Residual and diffusive flux are reproduced to the printed digits; the nonconformity
+    value is 0.1680 with HEAD's face-neighbour neighbourhoods (1.66e-01 belongs to vertex patches over all elements,
+    tests/test_oracle.py)."""
+    from pylrbms_amd import OS2015_academic_problem
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    p = OS2015_academic_problem.init_grid_and_problem({'num_subdomains': [4, 4], 'half_num_fine_elements_per_subdomain_and_dim': 4})
+    d, _ = discretize(p)
+    d.estimator = d.estimator.with_(sqrt_local=True)
+    mu = d.parse_parameter(1.)
+    U = d.solve(mu)
+    eta, (nc, r, df), _ = d.estimate(U, mu=mu, decompose=True)
+    assert abs(np.linalg.norm(r) - 1.45e-01) < 0.5e-3
+    assert abs(np.linalg.norm(df) - 3.55e-01) < 0.5e-3
+    assert abs(np.linalg.norm(nc) - 0.1680) < 0.5e-3
