@@ -93,7 +93,7 @@ def _pool_reduce(chunk):
     return len(chunk)
 
 
-def cpu_baseline(N, coarse, sample_subdomains=(16, 16), repeats=1):
+def cpu_baseline(N, coarse, sample_subdomains=(32, 16), repeats=1):
     """The oracle (kind "port") timed on a bounded sample of the same workload: same synthetic problem family and
     basis size on a smaller subdomain grid.  Only OracleReductor.reduce() -- the same region the GPU times -- is timed."""
     from threadpoolctl import threadpool_limits
