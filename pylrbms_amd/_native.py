@@ -130,12 +130,16 @@ class NativeContext:
         if rc != 0:
             raise NativeError('lrbms_ctx_create failed with code {}'.format(rc))
         self.handle = handle
+        self._pid = os.getpid()
         self._keep = None
         self.S = self.S_ext = None
 
     def close(self):
         if getattr(self, 'handle', None):
-            self.lib.lrbms_ctx_destroy(self.handle)
+            # a fork()ed child (e.g. a multiprocessing manager started after the GPU was initialised) inherits this
+            # object but not the device context behind it: freeing the parent's allocations from there aborts the process
+            if getattr(self, '_pid', None) == os.getpid():
+                self.lib.lrbms_ctx_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

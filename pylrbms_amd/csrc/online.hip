@@ -425,7 +425,8 @@ int launch_reduced_estimate(lrbms_ctx* ctx, int Q, int N, const double* theta, c
 // reductor.py:29-31) -- M^-1 = blockdiag(A_ss)^-1 + R0^T (R0 A R0^T)^-1 R0, additive, symmetric positive definite --
 // makes it independent of the subdomain count (~27 iterations).  The coarse matrix is the 5-point S x S matrix of the
 // (0, 0) entries of the combined blocks; it is factorised and inverted once per solve by rocSOLVER (dpotrf + dpotrs on
-// the identity: a plain library factorisation of an S x S matrix, 8 MB at config 3; 2.9 + 0.6 ms) and applied as a dense
+// the identity: 2.9 + 0.6 ms at S = 1024 -- kept for subdomain numberings with a band wider than 64; the usual case is
+// the hand-written block-tridiagonal factorisation k_bt_factor / k_bt_inverse below) and applied as a dense
 // product per iteration (k_coarse_apply).  If the factorisation fails (a zero first basis vector) the solvers run with
 // block-Jacobi alone.  LRBMS_NO_COARSE=1 switches the coarse level off.  Because the factorisation costs about as much
 // as a whole batched solve, a preconditioner can be built once for a reduced model at a reference parameter
@@ -531,6 +532,169 @@ void coarse_release(lrbms_ctx* ctx) {
   ctx->coarse_cap = 0;
 }
 
+namespace {
+
+// ---- hand-written factorisation of the coarse matrix --------------------------------------------------------
+// With the subdomains numbered row by row the coarse matrix is block tridiagonal with blocks of b = (band half-width)
+// rows: D_i on the diagonal, E_i = A0[block i + 1, block i] below it.  Block Cholesky  L_ii L_ii^T = D_i - F_{i-1} F_{i-1}^T,
+// F_i = E_i L_ii^-T  in ONE workgroup with the three b x b blocks of a step in LDS; the inverses Li_i = L_ii^-1 are formed
+// on the way (every thread one column), so that the solves below are small dense products without sequential
+// substitution.  Lout [nb][2][b][b]: Li_i, F_i (row major).  flag[0] = 1 if a pivot is not positive.
+// rocSOLVER needs 3.5 ms for dpotrf + dpotrs at S = 1024 (latency-bound panel factorisations of a DENSE matrix); this
+// pair of kernels needs ~0.4 ms because it never touches the zero blocks.  Rows >= S (last block) act as identity.
+__global__ __launch_bounds__(256) void k_bt_factor(int S, int b, int nb, const double* __restrict__ A0, double* __restrict__ Lout,
+                                                   int* __restrict__ flag) {
+  extern __shared__ double lds[];
+  double* Dm = lds;              // [b][b] current diagonal block -> L (lower), later E_i
+  double* Li = Dm + b * b;       // [b][b] L^-1 (lower)
+  double* Fm = Li + b * b;       // [b][b] F_i
+  const int tid = threadIdx.x;
+  if (tid == 0) flag[0] = 0;
+  auto a0 = [&](long r, long c) -> double {            // symmetric full matrix, column major; identity beyond S
+    if (r >= S || c >= S) return r == c ? 1.0 : 0.0;
+    return A0[c * (long)S + r];
+  };
+  for (int i = tid; i < b * b; i += 256) Dm[i] = a0(i / b, i % b);
+  __syncthreads();
+  for (int blk = 0; blk < nb; ++blk) {
+    const long o = (long)blk * b;
+    // ---- Cholesky of Dm in place (lower triangle)
+    for (int k = 0; k < b; ++k) {
+      if (tid == 0) {
+        const double d = Dm[k * b + k];
+        if (!(d > 0.0)) flag[0] = 1;
+        Dm[k * b + k] = sqrt(d > 0.0 ? d : 1.0);
+      }
+      __syncthreads();
+      const double piv = Dm[k * b + k];
+      for (int r = k + 1 + tid; r < b; r += 256) Dm[r * b + k] /= piv;
+      __syncthreads();
+      const int m = b - 1 - k;                        // trailing update of the lower triangle: rows / cols k+1 .. b-1
+      for (int i = tid; i < m * m; i += 256) {
+        const int r = k + 1 + i / m, c = k + 1 + i % m;
+        if (c <= r) Dm[r * b + c] -= Dm[r * b + k] * Dm[c * b + k];
+      }
+      __syncthreads();
+    }
+    // ---- Li = L^-1, one column per thread (forward substitution)
+    for (int i = tid; i < b * b; i += 256) Li[i] = 0.0;
+    __syncthreads();
+    for (int j = tid; j < b; j += 256) {
+      Li[j * b + j] = 1.0 / Dm[j * b + j];
+      for (int r = j + 1; r < b; ++r) {
+        double acc = 0.0;
+        for (int k = j; k < r; ++k) acc += Dm[r * b + k] * Li[k * b + j];
+        Li[r * b + j] = -acc / Dm[r * b + r];
+      }
+    }
+    __syncthreads();
+    double* out = Lout + (long)blk * 2 * b * b;
+    for (int i = tid; i < b * b; i += 256) out[i] = Li[i];
+    if (blk + 1 < nb) {
+      // ---- F = E Li^T  (E = A0[block blk + 1, block blk]), then the next diagonal block D - F F^T
+      for (int i = tid; i < b * b; i += 256) Dm[i] = a0(o + b + i / b, o + i % b);
+      __syncthreads();
+      for (int i = tid; i < b * b; i += 256) {
+        const int r = i / b, c = i % b;
+        double acc = 0.0;
+        for (int k = 0; k <= c; ++k) acc += Dm[r * b + k] * Li[c * b + k];     // Li is lower triangular
+        Fm[i] = acc;
+      }
+      __syncthreads();
+      for (int i = tid; i < b * b; i += 256) {
+        out[b * b + i] = Fm[i];
+        const int r = i / b, c = i % b;
+        double acc = a0(o + b + r, o + b + c);
+        for (int k = 0; k < b; ++k) acc -= Fm[r * b + k] * Fm[c * b + k];
+        Dm[i] = acc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// A0^-1 from the block factor: every workgroup owns 16 columns of the identity.  Forward  y_i = Li_i (e_i - F_{i-1} y_{i-1}),
+// backward  x_i = Li_i^T (y_i - F_i^T x_{i+1}); the two b x b blocks of a step are staged in LDS with all loads in flight,
+// y / x travel through the output columns.  X column major [S][S] (symmetric result).
+__global__ __launch_bounds__(256) void k_bt_inverse(int S, int b, int nb, const double* __restrict__ Lf, double* __restrict__ X) {
+  extern __shared__ double lds[];
+  double* Lb = lds;              // [b][b] Li_i
+  double* Fb = Lb + b * b;       // [b][b] F block of the step
+  double* v = Fb + b * b;        // [b][16] previous block of the solution
+  double* w = v + b * 16;        // [b][16] work
+  const int tid = threadIdx.x, c0 = blockIdx.x * 16;
+  auto stage = [&](double* dst, const double* src) {
+    for (int base = 0; base < b * b; base += 2048) {
+      double t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = base + tid + 256 * k;
+        t[k] = i < b * b ? src[i] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = base + tid + 256 * k;
+        if (i < b * b) dst[i] = t[k];
+      }
+    }
+  };
+  // ---- forward
+  for (int blk = 0; blk < nb; ++blk) {
+    const double* f = Lf + (long)blk * 2 * b * b;
+    __syncthreads();
+    stage(Lb, f);
+    if (blk > 0) stage(Fb, f - b * b);                 // F_{blk-1}
+    __syncthreads();
+    for (int i = tid; i < b * 16; i += 256) {          // w = e_blk - F_{blk-1} y_{blk-1}
+      const int r = i / 16, c = i % 16;
+      double acc = ((long)blk * b + r == c0 + c) ? 1.0 : 0.0;
+      if (blk > 0)
+        for (int k = 0; k < b; ++k) acc -= Fb[r * b + k] * v[k * 16 + c];
+      w[i] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < b * 16; i += 256) {          // y = Li w (Li lower triangular)
+      const int r = i / 16, c = i % 16;
+      double acc = 0.0;
+      for (int k = 0; k <= r; ++k) acc += Lb[r * b + k] * w[k * 16 + c];
+      v[i] = acc;
+      const long row = (long)blk * b + r;
+      if (row < S && c0 + c < S) X[(long)(c0 + c) * S + row] = acc;
+    }
+  }
+  // ---- backward
+  for (int blk = nb - 1; blk >= 0; --blk) {
+    const double* f = Lf + (long)blk * 2 * b * b;
+    __syncthreads();
+    stage(Lb, f);
+    if (blk + 1 < nb) stage(Fb, f + b * b);            // F_blk
+    __syncthreads();
+    for (int i = tid; i < b * 16; i += 256) {          // w = y_blk - F_blk^T x_{blk+1}
+      const int r = i / 16, c = i % 16;
+      const long row = (long)blk * b + r;
+      double acc = (row < S && c0 + c < S) ? X[(long)(c0 + c) * S + row] : 0.0;
+      if (blk + 1 < nb)
+        for (int k = 0; k < b; ++k) acc -= Fb[k * b + r] * v[k * 16 + c];
+      w[i] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < b * 16; i += 256) {          // x = Li^T w
+      const int r = i / 16, c = i % 16;
+      double acc = 0.0;
+      for (int k = r; k < b; ++k) acc += Lb[k * b + r] * w[k * 16 + c];
+      v[i] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < b * 16; i += 256) {
+      const int r = i / 16, c = i % 16;
+      const long row = (long)blk * b + r;
+      if (row < S && c0 + c < S) X[(long)(c0 + c) * S + row] = v[i];
+    }
+  }
+}
+
+}  // namespace
+
 // The dense coarse machinery, shared with the full-order solver (fom.hip):
 //   coarse_begin   scratch A0 (zeroed) for the caller to fill with the S x S coarse matrix (either triangle, column major);
 //                  *A0 = nullptr if the coarse level is not available (switched off, S too small or too large)
@@ -539,7 +703,7 @@ int coarse_begin(lrbms_ctx* ctx, double** A0_out, hipStream_t st) {
   *A0_out = nullptr;
   const long S = ctx->S;
   if (getenv("LRBMS_NO_COARSE") != nullptr || S < 4 || S > 4096) return LRBMS_OK;
-  const long need = 2 * S * S + 16;
+  const long need = 2 * S * S + 16 + 2 * (S + 64) * 64;     // A0, A0inv, info / flag, block factor
   if (ctx->coarse_cap < need) {
     if (ctx->coarse) (void)hipFree(ctx->coarse);
     ctx->coarse = nullptr;
@@ -556,6 +720,38 @@ int coarse_begin(lrbms_ctx* ctx, double** A0_out, hipStream_t st) {
 int coarse_finish(lrbms_ctx* ctx, const double** A0inv_out, hipStream_t st) {
   *A0inv_out = nullptr;
   const long S = ctx->S;
+  {
+    // band half-width of the coarse matrix = largest distance to a neighbour in the subdomain numbering (the row length
+    // of a Cartesian subdomain grid): up to 64 the block-tridiagonal kernels do the job, beyond that rocSOLVER
+    int bw = 1;
+    for (long i = 0; i < S * 5; ++i) {
+      const int t = ctx->nbr_host[i];
+      if (t >= 0 && t < S) {
+        const int dist = t > (int)(i / 5) ? t - (int)(i / 5) : (int)(i / 5) - t;
+        bw = dist > bw ? dist : bw;
+      }
+    }
+    if (bw <= 64 && getenv("LRBMS_COARSE_ROCSOLVER") == nullptr) {
+      const int b = bw, nb = (int)((S + b - 1) / b);
+      double* A0 = ctx->coarse;
+      double* A0inv = A0 + S * S;
+      int* flag = reinterpret_cast<int*>(A0inv + S * S);
+      double* Lf = A0inv + S * S + 16;
+      const size_t lds_f = sizeof(double) * 3 * b * b, lds_i = sizeof(double) * (2 * b * b + 32 * b);
+      if (lds_f > 64 * 1024)
+        LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bt_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+      if (lds_i > 64 * 1024)
+        LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bt_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_i));
+      hipLaunchKernelGGL(k_bt_factor, dim3(1), dim3(256), lds_f, st, (int)S, b, nb, A0, Lf, flag);
+      hipLaunchKernelGGL(k_bt_inverse, dim3((unsigned)((S + 15) / 16)), dim3(256), lds_i, st, (int)S, b, nb, Lf, A0inv);
+      LRBMS_LAUNCH_CHECK(ctx);
+      int hflag = 0;
+      LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+      LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      if (hflag == 0) *A0inv_out = A0inv;              // otherwise not positive definite: no coarse level
+      return LRBMS_OK;
+    }
+  }
   if (!ctx->blas) {
     rocblas_handle h = nullptr;
     if (rocblas_create_handle(&h) != rocblas_status_success) return lrbms_fail(ctx, LRBMS_E_HIP, "rocblas_create_handle failed");

@@ -304,6 +304,24 @@ def test_two_level_preconditioner_and_prebuilt_form(monkeypatch):
     monkeypatch.delenv('LRBMS_NO_COARSE')
     assert max(with_coarse) < min(jacobi_only)
     pc = eng.ctx.reduced_precond_build(theta_of(p, 0.55), B)
+    # the hand-written block-tridiagonal coarse inverse against rocSOLVER's dense one, and against numpy on the 5-point
+    # coarse matrix itself (entries (0, 0) of the combined blocks)
+    monkeypatch.setenv('LRBMS_COARSE_ROCSOLVER', '1')
+    pc_lib = eng.ctx.reduced_precond_build(theta_of(p, 0.55), B)
+    monkeypatch.delenv('LRBMS_COARSE_ROCSOLVER')
+    S = d.S
+    A0inv, A0inv_lib = (x[2 + S * N * N:].reshape(S, S).cpu().numpy() for x in (pc, pc_lib))
+    assert float(pc[0]) == 1.0 and float(pc_lib[0]) == 1.0
+    th = theta_of(p, 0.55)
+    Bh = B.cpu().numpy()
+    A0 = np.zeros((S, S))
+    for s_ in range(S):
+        for slot, t_ in enumerate(p['grid'].neighbor_slots[s_]):
+            if t_ >= 0:
+                A0[s_, int(t_)] = sum(th[q] * Bh[q, s_, slot, 0, 0] for q in range(len(th)))
+    ref_inv = np.linalg.inv(A0)
+    assert np.abs(A0inv - ref_inv).max() < 1e-11 * np.abs(ref_inv).max()
+    assert np.abs(A0inv_lib - ref_inv).max() < 1e-11 * np.abs(ref_inv).max()
     eng.ctx.reduced_precond_use(pc)
     prebuilt = check('prebuilt at mu = 0.55')
     assert max(prebuilt) < min(jacobi_only)
