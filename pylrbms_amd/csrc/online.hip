@@ -5,6 +5,8 @@
 // block-Jacobi preconditioned CG; the matrix (S x 5 blocks of N x N) is assembled once per mu and then lives in
 // the Infinity Cache for the iteration.  All reductions are fixed-order trees (no fp64 atomics) so that results are
 // bitwise reproducible run to run.
+#include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 #include <rocsolver/rocsolver.h>
@@ -534,79 +536,188 @@ void coarse_release(lrbms_ctx* ctx) {
 
 namespace {
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {    // cross-lane move inside a row of 16 lanes without the LDS crossbar
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 // ---- hand-written factorisation of the coarse matrix --------------------------------------------------------
 // With the subdomains numbered row by row the coarse matrix is block tridiagonal with blocks of b = (band half-width)
 // rows: D_i on the diagonal, E_i = A0[block i + 1, block i] below it.  Block Cholesky  L_ii L_ii^T = D_i - F_{i-1} F_{i-1}^T,
-// F_i = E_i L_ii^-T  in ONE workgroup with the three b x b blocks of a step in LDS; the inverses Li_i = L_ii^-1 are formed
-// on the way (every thread one column), so that the solves below are small dense products without sequential
-// substitution.  Lout [nb][2][b][b]: Li_i, F_i (row major).  flag[0] = 1 if a pivot is not positive.
+// F_i = E_i L_ii^-T  in ONE workgroup with the three b x b blocks of a step in LDS; the inverses Li_i = L_ii^-1 come out of
+// the same sweep as the Cholesky factor (chol_n below), so that the solves in k_bt_inverse are small dense products without
+// sequential substitution.  Lout [nb][2][b][b | 1]: Li_i, F_i (row major, padded rows).  flag[0] = 1 if a pivot is not
+// positive.  Rows >= S (last block) act as identity.
 // rocSOLVER needs 3.5 ms for dpotrf + dpotrs at S = 1024 (latency-bound panel factorisations of a DENSE matrix); this
-// pair of kernels needs ~0.4 ms because it never touches the zero blocks.  Rows >= S (last block) act as identity.
+// kernel needs 0.62 ms (per 32 x 32 block: 13.6 us factor + inverse, 2.9 us F, 2.8 us Schur update, measured with
+// wall_clock64 laps) and k_bt_inverse 0.35 ms, because they never touch the zero blocks.
 __global__ __launch_bounds__(256) void k_bt_factor(int S, int b, int nb, const double* __restrict__ A0, double* __restrict__ Lout,
                                                    int* __restrict__ flag) {
   extern __shared__ double lds[];
-  double* Dm = lds;              // [b][b] current diagonal block -> L (lower), later E_i
-  double* Li = Dm + b * b;       // [b][b] L^-1 (lower)
-  double* Fm = Li + b * b;       // [b][b] F_i
+  // rows of the LDS blocks are ld = b | 1 doubles apart: with an even stride the column accesses below (one row per lane)
+  // all fall into the same banks, which made every phase of this kernel 3-5x slower
+  const int ld = b | 1;
+  double* Dm = lds;              // [b][ld] current diagonal block -> L (lower)
+  double* Li = Dm + b * ld;      // [b][ld] L^-1 (lower)
+  double* Fm = Li + b * ld;      // [b][ld] E_i, then F_i
   const int tid = threadIdx.x;
   if (tid == 0) flag[0] = 0;
   auto a0 = [&](long r, long c) -> double {            // symmetric full matrix, column major; identity beyond S
     if (r >= S || c >= S) return r == c ? 1.0 : 0.0;
     return A0[c * (long)S + r];
   };
-  for (int i = tid; i < b * b; i += 256) Dm[i] = a0(i / b, i % b);
+  constexpr int PT = 16;                               // b * b <= 4096 entries, 256 threads
+  // (row, column) of this thread's u-th entry of a b x b block, once: an integer division by the runtime b costs ~60
+  // instructions, and index arithmetic of that kind inside the loops below made this kernel five times slower
+  short ri[PT], ci[PT], li[PT];                        // li: position in an LDS block
+#pragma unroll
+  for (int u = 0; u < PT; ++u) {
+    const int i = tid + 256 * u;
+    ri[u] = (short)(i / b);
+    ci[u] = (short)(i - (i / b) * b);
+    li[u] = (short)(ri[u] * ld + ci[u]);
+  }
+  double en[PT], dn[PT];                               // E_blk and D_{blk+1}: loaded while block blk is factorised
+  auto fetch = [&](double (&dst)[PT], long ro, long co) {
+#pragma unroll
+    for (int u = 0; u < PT; ++u) dst[u] = tid + 256 * u < b * b ? a0(ro + ri[u], co + ci[u]) : 0.0;
+  };
+  // pacc[u] = sum_k A[ri[u]][k] B[ci[u]][k] for this thread's entries: all of them advance together over k (independent
+  // accumulators, the LDS reads of a step in flight at once); the number of live entries is uniform, so it selects an
+  // instantiation instead of predicating sixteen slots (predicated slots wait for their loads one by one)
+  short rl[PT], cl[PT];
+#pragma unroll
+  for (int u = 0; u < PT; ++u) {
+    const bool live = tid + 256 * u < b * b;
+    rl[u] = live ? (short)(ri[u] * ld) : (short)0;
+    cl[u] = live ? (short)(ci[u] * ld) : (short)0;
+  }
+  double pacc[PT];
+  auto prod_n = [&](auto nu_c, const double* A, const double* Bm) {
+    constexpr int NU = decltype(nu_c)::value;
+#pragma unroll
+    for (int u = 0; u < PT; ++u) pacc[u] = 0.0;
+#pragma unroll 2
+    for (int k = 0; k < b; ++k) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) pacc[u] += A[rl[u] + k] * Bm[cl[u] + k];
+    }
+  };
+  const int nlive = (b * b + 255) / 256;
+  auto prod = [&](const double* A, const double* Bm) {
+    if (nlive <= 2) prod_n(std::integral_constant<int, 2>{}, A, Bm);
+    else if (nlive <= 4) prod_n(std::integral_constant<int, 4>{}, A, Bm);
+    else if (nlive <= 8) prod_n(std::integral_constant<int, 8>{}, A, Bm);
+    else prod_n(std::integral_constant<int, 16>{}, A, Bm);
+  };
+  // Cholesky of the block in Dm together with Li = L^-1.  The block A and W (= identity at the start) live in REGISTERS, a
+  // 16 x 16 thread tile owning entries (tr + 16 m, tc + 16 n).  Step k: the owners publish column k of A and row k of W
+  // through a double-buffered LDS line, one barrier, then every thread applies the two rank-1 updates
+  //   A[r][c] -= A[r][k] A[c][k] / d   (r, c > k),     W[r][c] -= A[r][k] / d * W[k][c]   (r > k),
+  // and row k of Li is W[k][:] / sqrt(d).  (An LDS-resident right-looking Cholesky followed by a substitution for Li
+  // needed 3 barriers and chains of dependent LDS round trips per column: 37 us per block against ~6 us.)
+  double* cbuf = Fm + b * ld;    // [2][2][64]
+  auto chol_n = [&](auto nt_c) {
+    constexpr int NT = decltype(nt_c)::value;
+    const int tr = tid >> 4, tc = tid & 15;
+    double A[NT][NT], W[NT][NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int r = tr + 16 * m, c = tc + 16 * n;
+        A[m][n] = (r < b && c <= r) ? Dm[r * ld + c] : 0.0;
+        W[m][n] = r == c ? 1.0 : 0.0;
+      }
+    for (int k = 0; k < b; ++k) {
+      double* col = cbuf + (k & 1) * 128;
+      double* roww = col + 64;
+      const int kt = k >> 4, kl = k & 15;
+      if (tc == kl) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          if (n == kt) {
+#pragma unroll
+            for (int m = 0; m < NT; ++m) col[tr + 16 * m] = A[m][n];
+          }
+      }
+      if (tr == kl) {
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+          if (m == kt) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) roww[tc + 16 * n] = W[m][n];
+          }
+      }
+      __syncthreads();
+      // every LDS read of the step is issued before the first use (all indices stay inside the two 64-entry lines; what
+      // a read must not contribute is masked afterwards): one LDS round trip per step instead of one per operand
+      const double d = col[k];
+      const double rowme = roww[tid & 63];
+      double cr[NT], cc[NT], rw[NT];
+#pragma unroll
+      for (int m = 0; m < NT; ++m) cr[m] = col[tr + 16 * m];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        cc[n] = col[tc + 16 * n];
+        rw[n] = roww[tc + 16 * n];
+      }
+      const double rinv = rsqrt(d > 0.0 ? d : 1.0), rinv2 = rinv * rinv;
+      if (tid == 0 && !(d > 0.0)) flag[0] = 1;
+      if (tid < b) Li[k * ld + tid] = rowme * rinv;
+#pragma unroll
+      for (int m = 0; m < NT; ++m) cr[m] = tr + 16 * m > k ? cr[m] * rinv2 : 0.0;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) cc[n] = tc + 16 * n > k ? cc[n] : 0.0;
+#pragma unroll
+      for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          A[m][n] -= cr[m] * cc[n];
+          W[m][n] -= cr[m] * rw[n];
+        }
+    }
+    __syncthreads();
+  };
+  fetch(dn, 0, 0);
+#pragma unroll
+  for (int u = 0; u < PT; ++u)
+    if (tid + 256 * u < b * b) Dm[li[u]] = dn[u];
   __syncthreads();
   for (int blk = 0; blk < nb; ++blk) {
     const long o = (long)blk * b;
-    // ---- Cholesky of Dm in place (lower triangle)
-    for (int k = 0; k < b; ++k) {
-      if (tid == 0) {
-        const double d = Dm[k * b + k];
-        if (!(d > 0.0)) flag[0] = 1;
-        Dm[k * b + k] = sqrt(d > 0.0 ? d : 1.0);
-      }
-      __syncthreads();
-      const double piv = Dm[k * b + k];
-      for (int r = k + 1 + tid; r < b; r += 256) Dm[r * b + k] /= piv;
-      __syncthreads();
-      const int m = b - 1 - k;                        // trailing update of the lower triangle: rows / cols k+1 .. b-1
-      for (int i = tid; i < m * m; i += 256) {
-        const int r = k + 1 + i / m, c = k + 1 + i % m;
-        if (c <= r) Dm[r * b + c] -= Dm[r * b + k] * Dm[c * b + k];
-      }
-      __syncthreads();
+    if (blk + 1 < nb) {                                // the next blocks do not depend on this step: loads in flight below
+      fetch(en, o + b, o);
+      fetch(dn, o + b, o + b);
     }
-    // ---- Li = L^-1, one column per thread (forward substitution)
-    for (int i = tid; i < b * b; i += 256) Li[i] = 0.0;
-    __syncthreads();
-    for (int j = tid; j < b; j += 256) {
-      Li[j * b + j] = 1.0 / Dm[j * b + j];
-      for (int r = j + 1; r < b; ++r) {
-        double acc = 0.0;
-        for (int k = j; k < r; ++k) acc += Dm[r * b + k] * Li[k * b + j];
-        Li[r * b + j] = -acc / Dm[r * b + r];
-      }
-    }
-    __syncthreads();
-    double* out = Lout + (long)blk * 2 * b * b;
-    for (int i = tid; i < b * b; i += 256) out[i] = Li[i];
+    // ---- Cholesky of Dm and L^-1 in one sweep, one barrier per column (see chol_n above)
+    if (b <= 16) chol_n(std::integral_constant<int, 1>{});
+    else if (b <= 32) chol_n(std::integral_constant<int, 2>{});
+    else if (b <= 48) chol_n(std::integral_constant<int, 3>{});
+    else chol_n(std::integral_constant<int, 4>{});
+    double* out = Lout + (long)blk * 2 * b * ld;       // blocks keep the padded row stride: the consumer stages them flat
+    for (int i = tid; i < b * ld; i += 256) out[i] = Li[i];
     if (blk + 1 < nb) {
       // ---- F = E Li^T  (E = A0[block blk + 1, block blk]), then the next diagonal block D - F F^T
-      for (int i = tid; i < b * b; i += 256) Dm[i] = a0(o + b + i / b, o + i % b);
+#pragma unroll
+      for (int u = 0; u < PT; ++u)
+        if (tid + 256 * u < b * b) Dm[li[u]] = en[u];
       __syncthreads();
-      for (int i = tid; i < b * b; i += 256) {
-        const int r = i / b, c = i % b;
-        double acc = 0.0;
-        for (int k = 0; k <= c; ++k) acc += Dm[r * b + k] * Li[c * b + k];     // Li is lower triangular
-        Fm[i] = acc;
-      }
+      prod(Dm, Li);                                    // Li is zero above its diagonal: the full k range is correct
+#pragma unroll
+      for (int u = 0; u < PT; ++u)
+        if (tid + 256 * u < b * b) Fm[li[u]] = pacc[u];
       __syncthreads();
-      for (int i = tid; i < b * b; i += 256) {
-        out[b * b + i] = Fm[i];
-        const int r = i / b, c = i % b;
-        double acc = a0(o + b + r, o + b + c);
-        for (int k = 0; k < b; ++k) acc -= Fm[r * b + k] * Fm[c * b + k];
-        Dm[i] = acc;
+      prod(Fm, Fm);
+#pragma unroll
+      for (int u = 0; u < PT; ++u) {
+        if (tid + 256 * u < b * b) {
+          out[b * ld + li[u]] = Fm[li[u]];
+          Dm[li[u]] = dn[u] - pacc[u];
+        }
       }
       __syncthreads();
     }
@@ -618,45 +729,48 @@ __global__ __launch_bounds__(256) void k_bt_factor(int S, int b, int nb, const d
 // y / x travel through the output columns.  X column major [S][S] (symmetric result).
 __global__ __launch_bounds__(256) void k_bt_inverse(int S, int b, int nb, const double* __restrict__ Lf, double* __restrict__ X) {
   extern __shared__ double lds[];
-  double* Lb = lds;              // [b][b] Li_i
-  double* Fb = Lb + b * b;       // [b][b] F block of the step
-  double* v = Fb + b * b;        // [b][16] previous block of the solution
+  const int ld = b | 1;          // padded row stride of the factor blocks (as written by k_bt_factor)
+  double* Lb = lds;              // [b][ld] Li_i
+  double* Fb = Lb + b * ld;      // [b][ld] F block of the step
+  double* v = Fb + b * ld;        // [b][16] previous block of the solution
   double* w = v + b * 16;        // [b][16] work
   const int tid = threadIdx.x, c0 = blockIdx.x * 16;
   auto stage = [&](double* dst, const double* src) {
-    for (int base = 0; base < b * b; base += 2048) {
+    for (int base = 0; base < b * ld; base += 2048) {
       double t[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int i = base + tid + 256 * k;
-        t[k] = i < b * b ? src[i] : 0.0;
+        t[k] = i < b * ld ? src[i] : 0.0;
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int i = base + tid + 256 * k;
-        if (i < b * b) dst[i] = t[k];
+        if (i < b * ld) dst[i] = t[k];
       }
     }
   };
   // ---- forward
   for (int blk = 0; blk < nb; ++blk) {
-    const double* f = Lf + (long)blk * 2 * b * b;
+    const double* f = Lf + (long)blk * 2 * b * ld;
     __syncthreads();
     stage(Lb, f);
-    if (blk > 0) stage(Fb, f - b * b);                 // F_{blk-1}
+    if (blk > 0) stage(Fb, f - b * ld);                 // F_{blk-1}
     __syncthreads();
     for (int i = tid; i < b * 16; i += 256) {          // w = e_blk - F_{blk-1} y_{blk-1}
       const int r = i / 16, c = i % 16;
       double acc = ((long)blk * b + r == c0 + c) ? 1.0 : 0.0;
       if (blk > 0)
-        for (int k = 0; k < b; ++k) acc -= Fb[r * b + k] * v[k * 16 + c];
+#pragma unroll 8
+        for (int k = 0; k < b; ++k) acc -= Fb[r * ld + k] * v[k * 16 + c];
       w[i] = acc;
     }
     __syncthreads();
     for (int i = tid; i < b * 16; i += 256) {          // y = Li w (Li lower triangular)
       const int r = i / 16, c = i % 16;
       double acc = 0.0;
-      for (int k = 0; k <= r; ++k) acc += Lb[r * b + k] * w[k * 16 + c];
+#pragma unroll 8
+      for (int k = 0; k <= r; ++k) acc += Lb[r * ld + k] * w[k * 16 + c];
       v[i] = acc;
       const long row = (long)blk * b + r;
       if (row < S && c0 + c < S) X[(long)(c0 + c) * S + row] = acc;
@@ -664,24 +778,26 @@ __global__ __launch_bounds__(256) void k_bt_inverse(int S, int b, int nb, const 
   }
   // ---- backward
   for (int blk = nb - 1; blk >= 0; --blk) {
-    const double* f = Lf + (long)blk * 2 * b * b;
+    const double* f = Lf + (long)blk * 2 * b * ld;
     __syncthreads();
     stage(Lb, f);
-    if (blk + 1 < nb) stage(Fb, f + b * b);            // F_blk
+    if (blk + 1 < nb) stage(Fb, f + b * ld);            // F_blk
     __syncthreads();
     for (int i = tid; i < b * 16; i += 256) {          // w = y_blk - F_blk^T x_{blk+1}
       const int r = i / 16, c = i % 16;
       const long row = (long)blk * b + r;
       double acc = (row < S && c0 + c < S) ? X[(long)(c0 + c) * S + row] : 0.0;
       if (blk + 1 < nb)
-        for (int k = 0; k < b; ++k) acc -= Fb[k * b + r] * v[k * 16 + c];
+#pragma unroll 8
+        for (int k = 0; k < b; ++k) acc -= Fb[k * ld + r] * v[k * 16 + c];
       w[i] = acc;
     }
     __syncthreads();
     for (int i = tid; i < b * 16; i += 256) {          // x = Li^T w
       const int r = i / 16, c = i % 16;
       double acc = 0.0;
-      for (int k = r; k < b; ++k) acc += Lb[k * b + r] * w[k * 16 + c];
+#pragma unroll 8
+      for (int k = r; k < b; ++k) acc += Lb[k * ld + r] * w[k * 16 + c];
       v[i] = acc;
     }
     __syncthreads();
@@ -703,7 +819,7 @@ int coarse_begin(lrbms_ctx* ctx, double** A0_out, hipStream_t st) {
   *A0_out = nullptr;
   const long S = ctx->S;
   if (getenv("LRBMS_NO_COARSE") != nullptr || S < 4 || S > 4096) return LRBMS_OK;
-  const long need = 2 * S * S + 16 + 2 * (S + 64) * 64;     // A0, A0inv, info / flag, block factor
+  const long need = 2 * S * S + 16 + 2 * (S + 64) * 65;     // A0, A0inv, info / flag, block factor
   if (ctx->coarse_cap < need) {
     if (ctx->coarse) (void)hipFree(ctx->coarse);
     ctx->coarse = nullptr;
@@ -737,7 +853,7 @@ int coarse_finish(lrbms_ctx* ctx, const double** A0inv_out, hipStream_t st) {
       double* A0inv = A0 + S * S;
       int* flag = reinterpret_cast<int*>(A0inv + S * S);
       double* Lf = A0inv + S * S + 16;
-      const size_t lds_f = sizeof(double) * 3 * b * b, lds_i = sizeof(double) * (2 * b * b + 32 * b);
+      const size_t lds_f = sizeof(double) * (3 * b * (b | 1) + 256), lds_i = sizeof(double) * (2 * b * (b | 1) + 32 * b);
       if (lds_f > 64 * 1024)
         LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bt_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
       if (lds_i > 64 * 1024)
