@@ -12,11 +12,33 @@
 // order everywhere, so every workgroup gets the same bits; 4 launches per iteration: 31.8 us, 2 launches: see DESIGN.md).
 // The host looks at |r| where the observed convergence rate predicts the tolerance, at most 100 iterations apart.
 // The theta-weighted blocks are combined once per solve.
+#include <type_traits>
 #include "lrbms_dev.h"
 
 namespace {
 
 struct QVecF { double v[8]; };
+
+// sum over the 64 lanes of a wave, returned to every lane: DPP moves inside the rows of 16 lanes, then the four row sums
+// through scalar registers (fixed order; no LDS crossbar traffic as with __shfl_xor)
+__device__ inline double wave_sum_dpp(double v) {
+  auto dpp = [](double x, auto ctrl_c) {
+    constexpr int CTRL = decltype(ctrl_c)::value;
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  double rows[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    rows[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * k), __builtin_amdgcn_readlane(__double2loint(v), 16 * k));
+  return (rows[0] + rows[1]) + (rows[2] + rows[3]);
+}
 
 __device__ inline double block_sum_256(double v, double* red) {
   const int tid = threadIdx.x;
@@ -189,7 +211,8 @@ __global__ __launch_bounds__(256) void k_fom_cg_update(long ne, const double* __
                                                        const double* __restrict__ ppap, int npart, int npap, int first,
                                                        double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
                                                        const double* __restrict__ y, double* __restrict__ z,
-                                                       double* __restrict__ prz_out, double* __restrict__ prr) {
+                                                       double* __restrict__ prz_out, double* __restrict__ prr,
+                                                       double* __restrict__ r0w) {
   __shared__ double red[512];
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   // all loads first: none of them depends on alpha, and the reduction below synchronises
@@ -216,7 +239,7 @@ __global__ __launch_bounds__(256) void k_fom_cg_update(long ne, const double* __
     block_sum_arrays_256(prz_in, npart, ppap, npap, red, rz, pap);
     alpha = pap != 0.0 ? rz / pap : 0.0;
   }
-  double rz = 0.0, rr = 0.0;
+  double rz = 0.0, rr = 0.0, rsum = 0.0;
   if (idx < ne) {
     for (int i = 0; i < 3; ++i) {
       const long g = idx * 3 + i;
@@ -226,12 +249,19 @@ __global__ __launch_bounds__(256) void k_fom_cg_update(long ne, const double* __
         r[g] = rv[i];
       }
     }
+    rsum = rv[0] + rv[1] + rv[2];
     for (int i = 0; i < 3; ++i) {
       const double zi = M[i * 3] * rv[0] + M[i * 3 + 1] * rv[1] + M[i * 3 + 2] * rv[2];
       z[idx * 3 + i] = zi;
       rz += rv[i] * zi;
       rr += rv[i] * rv[i];
     }
+  }
+  if (r0w) {
+    // restriction to the coarse space on the way: the sum of the new residual over this wave's 64 elements (waves do not
+    // straddle subdomains when 64 divides the elements per subdomain); k_fom_coarse1 adds the waves of a subdomain
+    const double ws = wave_sum_dpp(rsum);
+    if ((threadIdx.x & 63) == 0) r0w[idx >> 6] = ws;
   }
   const double s1 = block_sum_256(rz, red);
   const double s2 = block_sum_256(rr, red);
@@ -288,6 +318,44 @@ __global__ __launch_bounds__(256) void k_fom_coarse_entries(Tmpl t, int S, const
   }
 }
 
+// Coarse part of the preconditioned residual with the restriction folded in: r0[t] = sum of the wps wave sums of
+// subdomain t (written by k_fom_cg_update), c0[s] = (A0^-1 r0)_s, prz_c[s] = r0[s] c0[s].  One wave per coarse row.
+__global__ __launch_bounds__(256) void k_fom_coarse1(int S, int wps, const double* __restrict__ A0inv, const double* __restrict__ r0w,
+                                                     double* __restrict__ c0, double* __restrict__ prz_c) {
+  const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= S) return;
+  const double* row = A0inv + (long)s * S;
+  double acc = 0.0;
+  for (int base = 0; base < S; base += 512) {
+    double a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = base + lane + 64 * k;
+      a[k] = i < S ? row[i] : 0.0;
+      b[k] = 0.0;
+    }
+    for (int w = 0; w < wps; ++w) {
+      double t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = base + lane + 64 * k;
+        t[k] = i < S ? r0w[(long)i * wps + w] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) b[k] += t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += a[k] * b[k];
+  }
+  const double sum = wave_sum_dpp(acc);
+  if (lane == 0) {
+    double own = 0.0;
+    for (int w = 0; w < wps; ++w) own += r0w[(long)s * wps + w];
+    c0[s] = sum;
+    prz_c[s] = own * sum;
+  }
+}
+
 // r0[s] = sum of the residual over subdomain s (restriction to the coarse space); zeroes the coarse solution and the
 // coarse part of the r.z partials, which k_coarse_apply accumulates into.  One workgroup per subdomain.
 __global__ __launch_bounds__(256) void k_fom_restrict(int n, const double* __restrict__ r, double* __restrict__ r0,
@@ -319,13 +387,14 @@ int64_t fom_solve_work_size(lrbms_ctx* ctx) {
   const Tmpl& t = ctx->t;
   const int64_t S = ctx->S, ne = S * t.nT;
   const int64_t nblk = (ne + 255) / 256, nmv = (ne + 63) / 64;
-  return ne * 36 + S * 4 * t.ncf * 9 + ne * 9 + 5 * ne * 3 + 3 * nblk + nmv + 4 * S + 16;
+  return ne * 36 + S * 4 * t.ncf * 9 + ne * 9 + 5 * ne * 3 + 3 * nblk + 2 * nmv + 4 * S + 16;
 }
 
 namespace {
 
 struct FomCg {
-  double *Amu_d, *Amu_c, *Minv, *r, *z, *p[2], *y, *prz[2], *ppap, *prr, *r0, *c0;
+  double *Amu_d, *Amu_c, *Minv, *r, *z, *p[2], *y, *prz[2], *ppap, *prr, *r0, *c0, *r0w;
+  int wps = 0;        // waves per subdomain of the update kernel if 64 divides the elements per subdomain (fused restriction), else 0
   const double* A0inv = nullptr;   // coarse level, or nullptr
   long ne, nv;
   int nblk, nmv;      // workgroups (= partial sums) of the update kernel (256 elements each) / the matvec kernel (64 each)
@@ -350,6 +419,8 @@ struct FomCg {
     ppap = prr + nblk;   // [nmv]
     r0 = ppap + nmv;
     c0 = r0 + S;
+    r0w = c0 + 3 * S;             // [nmv] residual sums per wave of the update kernel
+    wps = t.nT % 64 == 0 ? t.nT / 64 : 0;
   }
 };
 
@@ -368,6 +439,11 @@ int fom_host_sum(lrbms_ctx* ctx, const double* dev, std::vector<double>& host, d
 // (k_coarse_apply of online.hip with one column and one unknown per subdomain); c0 is added to z by the next matvec
 int fom_coarse_step(lrbms_ctx* ctx, FomCg& b, double* prz, hipStream_t st) {
   if (!b.A0inv) return LRBMS_OK;
+  if (b.wps) {                                           // the update kernel left the residual sums per wave
+    hipLaunchKernelGGL(k_fom_coarse1, dim3((ctx->S + 3) / 4), dim3(256), 0, st, ctx->S, b.wps, b.A0inv, b.r0w, b.c0, prz + b.nblk);
+    LRBMS_LAUNCH_CHECK(ctx);
+    return LRBMS_OK;
+  }
   hipLaunchKernelGGL(k_fom_restrict, dim3(ctx->S), dim3(256), 0, st, ctx->t.n, b.r, b.r0, b.c0, prz + b.nblk);
   LRBMS_LAUNCH_CHECK(ctx);
   return launch_coarse_apply(ctx, 1, 1, b.A0inv, b.r0, b.c0, prz + b.nblk, st);
@@ -396,7 +472,7 @@ int fom_cg_run(lrbms_ctx* ctx, FomCg& b, double* x, double ref2, double rtol, in
   const double* c0 = b.A0inv ? b.c0 : nullptr;
   std::vector<double> host(nblk);
   hipLaunchKernelGGL(k_fom_cg_update, dim3(nblk), dim3(256), 0, st, b.ne, b.Minv, b.prz[0], b.ppap, npart, b.nmv, 1, x, b.r, b.p[0], b.y, b.z,
-                     b.prz[0], b.prr);
+                     b.prz[0], b.prr, b.A0inv && b.wps ? b.r0w : nullptr);
   LRBMS_LAUNCH_CHECK(ctx);
   if (int rc = fom_coarse_step(ctx, b, b.prz[0], st)) return rc;
   double rr = 0.0;
@@ -414,7 +490,7 @@ int fom_cg_run(lrbms_ctx* ctx, FomCg& b, double* x, double ref2, double rtol, in
       hipLaunchKernelGGL(k_fom_cg_matvec, dim3(b.nmv), dim3(256), 0, st, t, S, ctx->nbr, b.Amu_d, b.Amu_c, b.z, b.p[o], b.prz[c], b.prz[o],
                          npart, it == 0 ? 1 : 0, c0, b.p[c], b.y, b.ppap);
       hipLaunchKernelGGL(k_fom_cg_update, dim3(nblk), dim3(256), 0, st, b.ne, b.Minv, b.prz[c], b.ppap, npart, b.nmv, 0, x, b.r, b.p[c], b.y, b.z,
-                         b.prz[o], b.prr);
+                         b.prz[o], b.prr, b.A0inv && b.wps ? b.r0w : nullptr);
       if (int rc = fom_coarse_step(ctx, b, b.prz[o], st)) return rc;
     }
     LRBMS_LAUNCH_CHECK(ctx);

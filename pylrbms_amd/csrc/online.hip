@@ -119,42 +119,78 @@ __global__ __launch_bounds__(256) void k_assemble_mu(long per_q, int Q, QVec the
   }
 }
 
-// Dinv[s] = inverse of the SPD diagonal block Amu[s][2] by Gauss-Jordan without pivoting in LDS (N <= 64)
-__global__ __launch_bounds__(64) void k_block_inverse(int N, const double* __restrict__ Amu, double* __restrict__ Dinv,
-                                                      int blocks_per_s, int block_off) {
+// Dinv[s] = inverse of the SPD diagonal block Amu[s][2] by Gauss-Jordan without pivoting in LDS (N <= 64).
+// Four lanes share a row (columns c = part, part + 4, ...), rows are ld = N | 1 doubles apart (with the even stride N every
+// lane of a wave hit the same two banks), and the pivot row is NOT normalised: step k subtracts (A[r][k] / A[k][k]) x row k
+// from every other row, which leaves row k alone, so one barrier per step is enough; A ends as a diagonal matrix and the
+// inverse is I[r][:] / A[r][r].  All LDS reads of a step are issued before the first write (a read-modify-write loop
+// would wait one LDS round trip per entry).  198 -> 108 us for 1024 blocks of 40 x 40; what remains is LDS bandwidth
+// (every step streams both matrices through the LDS pipe: 77 KB per block and step).
+__global__ __launch_bounds__(256) void k_block_inverse(int N, const double* __restrict__ Amu, double* __restrict__ Dinv,
+                                                       int blocks_per_s, int block_off) {
   extern __shared__ double lds[];
-  const int s = blockIdx.x;
-  double* A = lds;           // [N][N]
-  double* I = lds + N * N;   // [N][N]
+  const int s = blockIdx.x, tid = threadIdx.x, ld = N | 1;
+  double* A = lds;           // [N][ld]
+  double* I = lds + N * ld;  // [N][ld]
   const double* src = Amu + ((long)s * blocks_per_s + block_off) * N * N;
-  for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
-    const bool diag = i / N == i % N;
-    const double a = src[i];
-    // a zero-padded basis column (ragged local basis sizes after online enrichment) has an exactly zero row and
-    // column: put 1 on its diagonal so that the padded unknown decouples and stays 0
-    A[i] = (diag && a == 0.0) ? 1.0 : a;
-    I[i] = diag ? 1.0 : 0.0;
+  const int r = tid >> 2, part = tid & 3;
+  constexpr int CT = 16;     // columns per lane, N <= 64
+  if (r < N) {
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int c = part + 4 * t;
+      if (c < N) {
+        const double a = src[r * N + c];
+        // a zero-padded basis column (ragged local basis sizes after online enrichment) has an exactly zero row and
+        // column: put 1 on its diagonal so that the padded unknown decouples and stays 0
+        A[r * ld + c] = (r == c && a == 0.0) ? 1.0 : a;
+        I[r * ld + c] = r == c ? 1.0 : 0.0;
+      }
+    }
   }
   __syncthreads();
-  const int r = threadIdx.x;
+  const int rc = r < N ? r : 0;
   for (int k = 0; k < N; ++k) {
-    const double piv = 1.0 / A[k * N + k];
-    __syncthreads();
-    if (r < N) {
-      A[k * N + r] *= piv;   // thread r scales column entries of row k
-      I[k * N + r] *= piv;
+    const double f = A[rc * ld + k] / A[k * ld + k];
+    double ar[CT], ak[CT], ir[CT], ik[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int c = part + 4 * t, cc = c < N ? c : 0;
+      ar[t] = A[rc * ld + cc];
+      ak[t] = A[k * ld + cc];
+      ir[t] = I[rc * ld + cc];
+      ik[t] = I[k * ld + cc];
     }
-    __syncthreads();
     if (r < N && r != k) {
-      const double f = A[r * N + k];
-      for (int c = 0; c < N; ++c) {
-        A[r * N + c] -= f * A[k * N + c];
-        I[r * N + c] -= f * I[k * N + c];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int c = part + 4 * t;
+        if (c < N) {
+          A[r * ld + c] = ar[t] - f * ak[t];
+          I[r * ld + c] = ir[t] - f * ik[t];
+        }
       }
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < N * N; i += blockDim.x) Dinv[(long)s * N * N + i] = I[i];
+  if (r < N) {
+    const double dinv = 1.0 / A[r * ld + r];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int c = part + 4 * t;
+      if (c < N) Dinv[(long)s * N * N + r * N + c] = I[r * ld + c] * dinv;
+    }
+  }
+}
+
+// launch of k_block_inverse: src block (s, off) of bps blocks per subdomain -> dst[s]
+static int launch_block_inverse(lrbms_ctx* ctx, int S, int N, const double* src, double* dst, int bps, int off, hipStream_t st) {
+  const size_t lds = sizeof(double) * 2 * N * (N | 1);
+  if (lds > 64 * 1024)
+    LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_block_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_block_inverse, dim3((unsigned)S), dim3(256), lds, st, N, src, dst, bps, off);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
 }
 
 // y_s = sum_slot Amu[s][slot] p_{nbr(s,slot)};  partial[s] = p_s . y_s.  One wave per subdomain.
@@ -928,7 +964,7 @@ int launch_reduced_precond_build(lrbms_ctx* ctx, int Q, int N, const double* the
   const long per_q = S * 5 * N * N;
   hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256), 0, st,
                      per_q, Q, th, B_sys, Amu);
-  hipLaunchKernelGGL(k_block_inverse, dim3((unsigned)S), dim3(64), sizeof(double) * 2 * N * N, st, N, Amu, Dinv, 5, 2);
+  if (int rc = launch_block_inverse(ctx, (int)S, N, Amu, Dinv, 5, 2, st)) return rc;
   LRBMS_LAUNCH_CHECK(ctx);
   const double* built = nullptr;
   if (int rc = coarse_setup(ctx, N, Amu, &built, st)) return rc;
@@ -1069,7 +1105,7 @@ int launch_reduced_solve(lrbms_ctx* ctx, int Q, int N, const double* theta, cons
   if (pcD) {
     b.Dinv = const_cast<double*>(pcD);                   // read only below
   } else {
-    hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, b.Amu, b.Dinv, 5, 2);
+    if (int rc = launch_block_inverse(ctx, (int)S, N, b.Amu, b.Dinv, 5, 2, st)) return rc;
     LRBMS_LAUNCH_CHECK(ctx);
     if (int rc = coarse_setup(ctx, N, b.Amu, &b.A0inv, st)) return rc;
   }
@@ -1105,7 +1141,7 @@ int launch_reduced_implicit_euler(lrbms_ctx* ctx, int Q, int N, const double* th
   hipLaunchKernelGGL(k_assemble_mu_mass, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256),
                      0, st, per_q, Q, N, th, B_sys, M_red, b.Amu);
   LRBMS_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, b.Amu, b.Dinv, 5, 2);
+  if (int rc = launch_block_inverse(ctx, (int)S, N, b.Amu, b.Dinv, 5, 2, st)) return rc;
   LRBMS_LAUNCH_CHECK(ctx);
   if (int rc = coarse_setup(ctx, N, b.Amu, &b.A0inv, st)) return rc;
   std::vector<double> host(S);
@@ -1158,7 +1194,7 @@ int launch_reduced_time_residual(lrbms_ctx* ctx, int Q, int N, int L, const doub
   const long per_q = (long)S * 5 * N * N;
   hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256),
                      0, st, per_q, Q, th, B_sys, Amu);
-  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, M_red, Minv, 1, 0);
+  if (int rc = launch_block_inverse(ctx, (int)S, N, M_red, Minv, 1, 0, st)) return rc;
   LRBMS_LAUNCH_CHECK(ctx);
   for (int l = 0; l < L; ++l) {
     hipLaunchKernelGGL(k_cg_matvec, dim3(S), dim3(64), sizeof(double) * 5 * N, st, ctx->nbr, N, Amu, dU + (long)l * S * N, y, partial);
@@ -1227,7 +1263,7 @@ int launch_reduced_reconstruction_terms(lrbms_ctx* ctx, int Q, int N, int L, con
   const long per_q = (long)S * 5 * N * N;
   hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256),
                      0, st, per_q, Q, th, B_sys, Amu);
-  hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, M_red, Minv, 1, 0);
+  if (int rc = launch_block_inverse(ctx, (int)S, N, M_red, Minv, 1, 0, st)) return rc;
   LRBMS_LAUNCH_CHECK(ctx);
   for (int l = 0; l < L; ++l) {
     const double* ul = U + (long)l * S * N;
@@ -1619,7 +1655,7 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   } else {                                               // block inverses and coarse level at the batch-mean theta
     hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256), 0, st,
                        per_q, Q, mean, B_sys, Amu);
-    hipLaunchKernelGGL(k_block_inverse, dim3(S), dim3(64), sizeof(double) * 2 * N * N, st, N, Amu, Dinv, 5, 2);
+    if (int rc = launch_block_inverse(ctx, (int)S, N, Amu, Dinv, 5, 2, st)) return rc;
     LRBMS_LAUNCH_CHECK(ctx);
     if (int rc = coarse_setup(ctx, N, Amu, &A0inv, st)) return rc;
   }
