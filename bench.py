@@ -29,6 +29,9 @@ CONFIGS = {
     'cfg3_tile8': {'num_subdomains': [16, 8], 'N': 40, 'coarse_per_subdomain': 4},    # per-rank tiles of the 8/4/2-GPU runs
     'cfg3_tile4': {'num_subdomains': [16, 16], 'N': 40, 'coarse_per_subdomain': 4},
     'cfg3_tile2': {'num_subdomains': [32, 16], 'N': 40, 'coarse_per_subdomain': 4},
+    # SURVEY.md section 8d sweep k_c in {4, 8, 16}: the SAME global mesh as config 3 cut into fewer, larger subdomains
+    'cfg3_kc8': {'num_subdomains': [16, 16], 'N': 40, 'coarse_per_subdomain': 8},
+    'cfg3_kc16': {'num_subdomains': [8, 8], 'N': 40, 'coarse_per_subdomain': 16},
 }
 
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (HBM3E spec) and SURVEY.md section 8d (fp64 matrix)
@@ -370,9 +373,11 @@ def main():
         out = {'metric': 'offline project+estimate throughput', 'value': value, 'unit': 'subdomains/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-               'config': {'workload': 'BASELINE.json config {}: 2D multiscale diffusion, {}x{} subdomains, k_c={} '
+               'config': {'workload': '{}: 2D multiscale diffusion, {}x{} subdomains, k_c={} '
                                       '(n={} DG DoFs, n_rt={} RT0 DoFs per subdomain), Q={}, local basis dim {}'
-                                      .format(args.config[-1], cfg['num_subdomains'][0], cfg['num_subdomains'][1],
+                                      .format({'cfg2': 'BASELINE.json config 2', 'cfg3': 'BASELINE.json config 3'}.get(
+                                                  args.config, 'diagnostic variant {} of BASELINE.json config 3'.format(args.config)),
+                                              cfg['num_subdomains'][0], cfg['num_subdomains'][1],
                                               cfg['coarse_per_subdomain'], t.n, t.n_rt, Q, N),
                           'subdomains': S_total, 'N': N, 'Q': Q, 'parallelism': 'subdomain tiles x{}'.format(world)},
                'roofline': roofline}

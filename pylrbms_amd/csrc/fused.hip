@@ -1595,7 +1595,7 @@ bool fused_supported(lrbms_ctx* ctx, int Q, int N) {
   if (N > 64 || Q > 4 || Q * N > 128 || t.nT % 8 != 0 || t.nT > 1024 || t.ntouch > 256) return false;
   {
     const int ntx = (N + 15) / 16;
-    if (thin_nc_lds_bytes(t, ntx) > 64 * 1024 || t.ntouch * N > 3 * 512) return false;   // k_thin_nc: LDS, items per thread
+    if (thin_nc_lds_bytes(t, ntx) > 160 * 1024 || t.ntouch * N > 3 * 512) return false;   // k_thin_nc: LDS (160 KB per workgroup on gfx950), items per thread
   }
   if ((size_t)(3 * t.ncf * Q * N + Q * t.ncf * N + 3 * t.ncf) * sizeof(double) > 64 * 1024) return false;
   if ((size_t)2 * ((3 * t.ncf + 3) & ~3) * padded_ld((N + 15) / 16) * sizeof(double) > 64 * 1024) return false;   // k_coupling
@@ -1738,12 +1738,20 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)S * 4 * nvs * N)), dim3(256), 0, side, t, S, ctx->nbr, N, V, AvgSide);
     const int ntx = (N + 15) / 16;
     const size_t lds = thin_nc_lds_bytes(t, ntx);
+    // templates with more than ~24 touching elements per side (k_c = 8: 78 KB at N = 40) need the opt-in for > 64 KB of LDS
+#define LRBMS_THIN_NC(NTX)                                                                                                       \
+  do {                                                                                                                           \
+    if (lds > 64 * 1024)                                                                                                         \
+      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_thin_nc<NTX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k_thin_nc<NTX>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);    \
+  } while (0)
     switch (ntx) {
-      case 1: hipLaunchKernelGGL(k_thin_nc<1>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
-      case 2: hipLaunchKernelGGL(k_thin_nc<2>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
-      case 3: hipLaunchKernelGGL(k_thin_nc<3>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
-      default: hipLaunchKernelGGL(k_thin_nc<4>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc); break;
+      case 1: LRBMS_THIN_NC(1); break;
+      case 2: LRBMS_THIN_NC(2); break;
+      case 3: LRBMS_THIN_NC(3); break;
+      default: LRBMS_THIN_NC(4); break;
     }
+#undef LRBMS_THIN_NC
     LRBMS_LAUNCH_CHECK(ctx);
     ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, G_bb, G_rdd, G_ab, r_fd, Q, N, S};
     const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf + 4 * t.ncf + 3 * t.ncf);   // + fco [ncf][4], fidx [ncf][5] ints

@@ -50,6 +50,9 @@ def _problems():
         # a larger template (n = 864, 24 touching elements per side) through the same fused kernels
         'multiscale_2x2_kc6_N24': (lambda: multiscale_problem.init_grid_and_problem(
             {'num_subdomains': [2, 2], 'coarse_per_subdomain': 6}), 24, 0.45),
+        # SURVEY.md 8d sweep point k_c = 8 (n = 1536, 32 touching elements per side: k_thin_nc with 78 KB of LDS)
+        'multiscale_2x2_kc8_N40': (lambda: multiscale_problem.init_grid_and_problem(
+            {'num_subdomains': [2, 2], 'coarse_per_subdomain': 8}), 40, 0.6),
     }
 
 
@@ -59,6 +62,8 @@ def test_every_array_matches_the_oracle(name):
     p = mk()
     eng = _engine(p)
     d = oracle_from_problem(p)
+    if 'kc8' in name or 'kc6' in name or 'kc4' in name:
+        assert eng.ctx.fused_supported(eng.Q, N), 'these templates must run through the fused pass'
     V = energy_orthonormalize(make_bases(d.S, d.n, N, seed=3), d)
     res = compare_all(p, eng, V, mu)
     its = res.pop('cg_iterations')
