@@ -150,6 +150,15 @@ class DuneDiscretization:
         x = x[torch.as_tensor(eng.local, device=x.device)]
         return BlockVectorArray(x.reshape(eng.S, eng.t.n, 1), self.solution_space)
 
+    def _owned_subdomains(self):
+        """One list of global subdomain indices per rank (every rank computes the same lists)."""
+        if getattr(self, '_owned', None) is None:
+            from pylrbms_amd.grid import DDSubdomainsGrid
+            g = self.engine.grid
+            self._owned = [list(DDSubdomainsGrid(g.lower_left, g.upper_right, g.K, g.P, rank=r, world_size=g.world_size).subdomains_on_rank)
+                           for r in range(g.world_size)]
+        return self._owned
+
     def _global_fom(self):
         """(context, A_diag [Q, S_total, n_T, 4, 9], A_cpl [Q, S_total, 4, ncf, 9], b [S_total, n]) in global order."""
         if getattr(self, '_fom_global', None) is None:

@@ -11,7 +11,8 @@ with ``nt`` steps (:87).  The reference's version does not run at HEAD (SURVEY.m
 
 ``solve(mu)`` is ONE native call for the whole trajectory (``lrbms_fom_implicit_euler``): the theta-weighted block
 operator plus the mass is combined once, every step is a warm-started CG on it.  On a sharded discretization the solves
-run on the gathered operator; the parabolic estimate needs all subdomains on one rank.
+run on the gathered operator, and so does the time residual of the parabolic estimate (its elliptic-reconstruction
+variant needs all subdomains on one rank).
 """
 import numpy as np
 
@@ -67,7 +68,14 @@ class InstationaryDuneDiscretization(DuneDiscretization):
         """``R = operator.apply(dU, mu); l2_product.apply_inverse(R).pairwise_dot(R)`` (estimators.py:146-148): [len(dU)]."""
         eng = self.engine
         if eng.S_ext != eng.S:
-            raise NotImplementedError('the parabolic estimate needs all subdomains on one rank')
+            # sharded: the residual norm is a sum over ALL subdomains; like the solves it is taken on the gathered block
+            # operator (every rank gathers the difference vectors and evaluates the same global sum)
+            from pylrbms_amd.parallel import gather_subdomain_rows
+            ctx, A_d, A_c, _ = self._global_fom()
+            dU_all = gather_subdomain_rows(dU.tensor.contiguous(), self._owned_subdomains(), eng.grid.num_subdomains,
+                                           getattr(self.mpi_comm, 'group', None)).contiguous()
+            R = ctx.fom_apply(self.theta(mu), A_d, A_c, dU_all)
+            return ctx.mass_inverse_norm2(R).sum(dim=0).cpu().numpy()
         R = eng.ctx.fom_apply(self.theta(mu), eng.A_diag, eng.A_cpl, dU.tensor.contiguous())
         return eng.ctx.mass_inverse_norm2(R).sum(dim=0).cpu().numpy()
 
@@ -79,7 +87,7 @@ class InstationaryDuneDiscretization(DuneDiscretization):
         import torch
         eng = self.engine
         if eng.S_ext != eng.S:
-            raise NotImplementedError('the parabolic estimate needs all subdomains on one rank')
+            raise NotImplementedError('the elliptic-reconstruction terms need all subdomains on one rank')
         theta = self.theta(mu)
         c = eng.ctx
         t2 = c.mass_inverse_norm2(eng.b.reshape(eng.S, eng.t.n, 1).contiguous())            # [S, 1]

@@ -143,5 +143,15 @@ class ParabolicEstimator(EstimatorBase):
         time_deriv_nc = time_deriv_nc * (1 / dt)
         time_deriv_nc = np.sqrt(np.maximum(time_deriv_nc, 0.0))
 
-        est = np.linalg.norm(eta) + np.linalg.norm(time_residual) + np.linalg.norm(time_deriv_nc)
+        nc2 = float(np.sum(time_deriv_nc ** 2))
+        comm = getattr(d, 'mpi_comm', None) or getattr(getattr(d, 'd', None), 'mpi_comm', None)
+        if comm is not None and getattr(comm, 'size', 1) > 1:              # the rows of the other ranks' subdomains
+            import torch
+            import torch.distributed as dist
+            group = getattr(comm, 'group', None)
+            acc = torch.tensor([nc2], dtype=torch.float64,         # RCCL reduces device tensors, gloo host tensors
+                               device=U.tensor.device if dist.get_backend(group) == 'nccl' else 'cpu')
+            dist.all_reduce(acc, group=group)
+            nc2 = float(acc[0])
+        est = np.linalg.norm(eta) + np.linalg.norm(time_residual) + np.sqrt(nc2)
         return est, (local_eta_nc, local_eta_r, local_eta_df, time_residual, time_deriv_nc)

@@ -393,14 +393,7 @@ class InstationaryReducedDiscretization(ReducedDiscretization):
         if eng.S_ext != eng.S:                                       # sharded: on the gathered reduced system, like rd.solve
             from pylrbms_amd.parallel import gather_subdomain_rows
             ctx, B_all, rhs_all = self._global_online()
-            if getattr(self, '_M_all', None) is None:
-                from pylrbms_amd.grid import DDSubdomainsGrid
-                g = eng.grid
-                owned = [list(DDSubdomainsGrid(g.lower_left, g.upper_right, g.K, g.P, rank=r, world_size=g.world_size).subdomains_on_rank)
-                         for r in range(g.world_size)]
-                self._M_all = gather_subdomain_rows(self.M_red, owned, g.num_subdomains,
-                                                    getattr(self.d.mpi_comm, 'group', None)).contiguous()
-            U, info = ctx.reduced_implicit_euler(self.d.theta(mu), dt, self.time_stepper.nt, B_all, self._M_all, rhs_all)
+            U, info = ctx.reduced_implicit_euler(self.d.theta(mu), dt, self.time_stepper.nt, B_all, self._gathered_mass(), rhs_all)
             U = U[:, self._torch.as_tensor(eng.local, device=U.device)]
         else:
             U, info = eng.ctx.reduced_implicit_euler(self.d.theta(mu), dt, self.time_stepper.nt, self.B_sys, self.M_red,
@@ -408,10 +401,22 @@ class InstationaryReducedDiscretization(ReducedDiscretization):
         self.last_solve_info = info
         return ReducedVectorArray(U.permute(1, 2, 0))
 
+    def _gathered_mass(self):
+        if getattr(self, '_M_all', None) is None:
+            from pylrbms_amd.parallel import gather_subdomain_rows
+            self._M_all = gather_subdomain_rows(self.M_red, self.d._owned_subdomains(), self.d.engine.grid.num_subdomains,
+                                                getattr(self.d.mpi_comm, 'group', None)).contiguous()
+        return self._M_all
+
     def _time_residual_norm2(self, dU, mu):
         eng = self.d.engine
-        if eng.S_ext != eng.S:
-            raise NotImplementedError('the reduced parabolic estimate needs all subdomains on one rank')
+        if eng.S_ext != eng.S:                                       # sharded: a global sum, on the gathered reduced system
+            from pylrbms_amd.parallel import gather_subdomain_rows
+            ctx, B_all, _ = self._global_online()
+            dU_all = gather_subdomain_rows(dU.tensor.contiguous(), self.d._owned_subdomains(), eng.grid.num_subdomains,
+                                           getattr(self.d.mpi_comm, 'group', None))
+            out = ctx.reduced_time_residual(self.d.theta(mu), B_all, self._gathered_mass(), dU_all.permute(2, 0, 1).contiguous())
+            return out.sum(dim=1).cpu().numpy()
         out = eng.ctx.reduced_time_residual(self.d.theta(mu), self.B_sys, self.M_red, dU.tensor.permute(2, 0, 1).contiguous())
         return out.sum(dim=1).cpu().numpy()
 
@@ -429,7 +434,7 @@ class InstationaryReducedDiscretization(ReducedDiscretization):
         """The elliptic-reconstruction terms with the projected operators (``lrbms_reduced_reconstruction_terms``) -> [S, len(U)]."""
         eng = self.d.engine
         if eng.S_ext != eng.S:
-            raise NotImplementedError('the reduced parabolic estimate needs all subdomains on one rank')
+            raise NotImplementedError('the elliptic-reconstruction terms need all subdomains on one rank')
         out = eng.ctx.reduced_reconstruction_terms(self.d.theta(mu), self.B_sys, self.M_red, self.rhs_red, self._projected_r_ud(),
                                                    U.tensor.permute(2, 0, 1).contiguous())
         return out.t().contiguous()

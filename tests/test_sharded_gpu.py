@@ -214,8 +214,11 @@ def _parabolic_run(p, comm=None):
     U = d.solve(0.6)
     reductor = ParabolicLRBMSReductor(d, order=0)
     reductor.extend_basis(U[[2, 4]])
-    u = reductor.reduce().solve(0.6)
-    return dict(zip(d.engine.local, U.tensor.cpu().numpy())), dict(zip(d.engine.local, reductor.reconstruct(u).tensor.cpu().numpy()))
+    rd = reductor.reduce()
+    u = rd.solve(0.6)
+    est = (float(d.estimate(U, mu=0.6)[0]), float(rd.estimate(u, mu=0.6)[0]))
+    return (dict(zip(d.engine.local, U.tensor.cpu().numpy())), dict(zip(d.engine.local, reductor.reconstruct(u).tensor.cpu().numpy())),
+            est)
 
 
 def _parabolic_worker(rank, world, port, results):
@@ -231,8 +234,8 @@ def _parabolic_worker(rank, world, port, results):
 
 def test_parabolic_solves_on_a_sharded_discretization():
     """Full-order and reduced implicit Euler trajectories on two ranks (gathered operators, native solvers on every rank)
-    equal the single-rank ones."""
-    U1, R1 = _parabolic_run(_problem())
+    and their parabolic estimates equal the single-rank ones."""
+    U1, R1, est1 = _parabolic_run(_problem())
     torch.cuda.empty_cache()
     world = 2
     port = 29100 + (os.getpid() % 150)
@@ -241,7 +244,9 @@ def test_parabolic_solves_on_a_sharded_discretization():
     mp.spawn(_parabolic_worker, args=(world, port, results), nprocs=world, join=True)
     seen = 0
     for r in range(world):
-        U, R = results[r]
+        U, R, est = results[r]
+        # the parabolic estimates (elliptic part sharded, time residual on the gathered operators, d_t nc all-reduced)
+        assert abs(est[0] - est1[0]) < 1e-8 * est1[0] and abs(est[1] - est1[1]) < 1e-7 * est1[1], (est, est1)
         for g in U:
             assert np.abs(U[g] - U1[g]).max() < 1e-9 * np.abs(U1[g]).max()
             assert np.abs(R[g] - R1[g]).max() < 1e-8 * np.abs(R1[g]).max()
