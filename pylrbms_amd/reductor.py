@@ -87,14 +87,17 @@ class ReducedDiscretization:
         """Parameter sweep: ``len(mus)`` reduced solutions (batches of <= 16 through ``lrbms_reduced_solve_batch``);
         returns one ``ReducedVectorArray`` with ``len(mus)`` vectors."""
         eng = self.d.engine
-        if eng.S_ext != eng.S:
-            raise NotImplementedError('solve_batch on a sharded discretization')
         thetas = np.array([self.d.theta(mu) for mu in mus])
         nb = max(1, min(16, 1280 // self.N))
+        # sharded: on the gathered reduced system, like solve(); every rank keeps the rows of its own subdomains
+        ctx, B_sys, rhs = self._global_online() if eng.S_ext != eng.S else (eng.ctx, self.B_sys, self.rhs_red)
 
         def run():
-            return [eng.ctx.reduced_solve_batch(thetas[b0:b0 + nb], self.B_sys, self.rhs_red)[0] for b0 in range(0, len(thetas), nb)]
-        return ReducedVectorArray(self._torch.cat(self._solve_with_preconditioner(eng.ctx, self.B_sys, run), dim=2))
+            return [ctx.reduced_solve_batch(thetas[b0:b0 + nb], B_sys, rhs)[0] for b0 in range(0, len(thetas), nb)]
+        u = self._torch.cat(self._solve_with_preconditioner(ctx, B_sys, run), dim=2)
+        if eng.S_ext != eng.S:
+            u = u[self._torch.as_tensor(eng.local, device=u.device)]
+        return ReducedVectorArray(u)
 
     def _global_online(self):
         """Sharded discretization: the reduced system is small (S x 5 blocks of N x N per affine component), so every rank

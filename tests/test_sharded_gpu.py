@@ -106,6 +106,10 @@ def _worker(rank, world, port, ref_path, results):
         u_loc = rd.solve(0.4).tensor[:, :, 0].cpu().numpy()
         err_u = np.abs(u_loc - ref['u_solve'][d.engine.local]).max() / np.abs(ref['u_solve']).max()
         ok &= bool(err_u < 1e-9)
+        # the batched sweep on the gathered system: column 1 is the same parameter as the single solve
+        ub = rd.solve_batch([0.9, 0.4, 0.15]).tensor.cpu().numpy()
+        ok &= bool(ub.shape == (d.engine.S, Vg.shape[2], 3))
+        ok &= bool(np.abs(ub[:, :, 1] - u_loc).max() < 1e-9 * np.abs(u_loc).max())
         results[rank] = (ok, max(worst, err_u), d.engine.S, d.engine.S_ext)
     finally:
         dist.destroy_process_group()
