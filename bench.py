@@ -355,7 +355,7 @@ def main():
         # profiles/r01_final_pmc_traffic.txt), only known for the profiled configuration.
         traffic = None
         if args.config == 'cfg3' and world == 1:
-            traffic = (2 * 677.4 + 1869.1) * 1024 * 1024
+            traffic = (2 * 677.6 + 1872.5) * 1024 * 1024
         roofline = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': ach_gbs / PEAK_HBM_GBS, 'traffic': traffic,
                     'kernel': 'fused project+estimate pass: k_flux_compact, k_vertex_avg, k_f1, k_f2, k_f3, k_thin_nc, '
