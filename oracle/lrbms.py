@@ -13,7 +13,9 @@ NumPy/SciPy fp64 restatement of
 
 The integrands evaluated by the absent dune-gdt are restated from the published
 SWIPDG / OS2015 formulas; every choice the reference tree does
-not determine is fixed here and listed in DESIGN.md section 3.  PARITY UNPINNED.
+not determine is fixed here and listed in DESIGN.md section 3; each is a constructor switch (quadrature order per
+integrand ``quad``, ``oswald_patch``, ``oswald_zero_on``, ``accumulate_coupling_across_q``).  Pinned to 6.9e-5 by the
+reference's 12-digit estimate (tests/test_reference_pin.py); see oracle/__init__.py for what stays unpinned.
 
 All matrices use the block DG mapper numbering ``dof = 3 * (ii * n_T + e_local) + v``.
 """
@@ -21,7 +23,7 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-from .quadrature import TRI_BARY, TRI_W, EDGE_T, EDGE_W
+from .quadrature import QuadratureSpec, edge_rule, triangle_rule
 
 SIGMA_INNER_P1 = 8.0      # dune-gdt swipdg inner_sigma(polorder <= 1)
 SIGMA_BOUNDARY_P1 = 14.0  # dune-gdt swipdg boundary_sigma(polorder <= 1)
@@ -37,8 +39,13 @@ class OracleDiscretization:
     """Everything ``discretize`` builds (block_swipdg.py:530-811), as scipy matrices."""
 
     def __init__(self, mesh, lambda_funcs, thetas, kappa, f, lambda_bar, lambda_hat, mu_bar, mu_hat,
-                 accumulate_coupling_across_q=False, oswald_zero_on='physical'):
+                 accumulate_coupling_across_q=False, oswald_zero_on='physical', oswald_patch='neighborhood',
+                 quad=None):
         self.mesh = mesh
+        self.quad = quad if quad is not None else QuadratureSpec.uniform()
+        assert oswald_patch in ('neighborhood', 'vertex')
+        self.oswald_patch = oswald_patch
+        self._tri_cache, self._edge_cache, self._smp_cache = {}, {}, {}
         self.lambda_funcs = list(lambda_funcs)
         self.thetas = list(thetas)
         self.Q = len(self.lambda_funcs)
@@ -46,7 +53,7 @@ class OracleDiscretization:
         self.f, self.lambda_bar, self.lambda_hat = f, lambda_bar, lambda_hat
         self.mu_bar, self.mu_hat = mu_bar, mu_hat
         self.accumulate_coupling_across_q = accumulate_coupling_across_q
-        assert oswald_zero_on in ('physical', 'subdomain')
+        assert oswald_zero_on in ('physical', 'subdomain', 'none')
         self.oswald_zero_on = oswald_zero_on
         self.S = mesh.num_subdomains
         self.nT = mesh.elements_per_subdomain
@@ -64,42 +71,76 @@ class OracleDiscretization:
     # ------------------------------------------------------------------ geometry / sampling
     def _geometry(self):
         m = self.mesh
-        self.xq = np.einsum('kv,evd->ekd', TRI_BARY, m.points)         # [nE, 7, 2]
         self.kgrad = np.einsum('ab,eib->eia', self.kappa, m.grads)      # kappa grad phi_i
         self.stiff = np.einsum('eia,eja->eij', m.grads, self.kgrad)     # grad phi_i . kappa grad phi_j
-        Em, fm = m.face_minus[:, 0], m.face_minus[:, 1]
-        a = m.points[Em, (fm + 1) % 3]
-        b = m.points[Em, (fm + 2) % 3]
-        self.xf = a[:, None, :] + EDGE_T[None, :, None] * (b - a)[:, None, :]   # [nF, 3, 2]
-        nF = m.num_faces
-        phim = np.zeros((nF, 3, 3))                                     # [face, i, k]
-        ar = np.arange(nF)
-        phim[ar, (fm + 1) % 3, :] = 1.0 - EDGE_T[None, :]
-        phim[ar, (fm + 2) % 3, :] = EDGE_T[None, :]
-        self.phim = phim
+        Em = m.face_minus[:, 0]
         Ep = np.maximum(m.face_plus[:, 0], 0)
-        d = self.xf - m.points[Ep, 0][:, None, :]
-        phip = np.einsum('fia,fka->fik', m.grads[Ep], d)
-        phip[:, 0, :] += 1.0
-        phip[m.face_plus[:, 0] < 0] = 0.0
-        self.phip = phip
         n = m.face_normal
         self.delta = np.einsum('fa,ab,fb->f', n, self.kappa, n)          # n^T kappa n (kappa constant)
         self.gnm = np.einsum('fia,fa->fi', self.kgrad[Em], n)            # kappa grad phi_i^- . n
         self.gnp = np.einsum('fia,fa->fi', self.kgrad[Ep], n)
         self.gnp[m.face_plus[:, 0] < 0] = 0.0
 
-    def _vol(self, fn):
-        m = self.mesh
-        return _feval(fn, self.xq, m.elem_center, m.elem_key)           # [nE, 7]
+    def _tri(self, order):
+        """Triangle rule of a requested order with its points on every element: dict(bary, w, xq [nE, k, 2])."""
+        hit = self._tri_cache.get(order)
+        if hit is None:
+            bary, w = triangle_rule(order)
+            hit = dict(bary=bary, w=w, xq=np.einsum('kv,evd->ekd', bary, self.mesh.points))
+            self._tri_cache[order] = hit
+        return hit
 
-    def _face_sides(self, fn):
-        m = self.mesh
-        Em = m.face_minus[:, 0]
-        Ep = np.maximum(m.face_plus[:, 0], 0)
-        vm = _feval(fn, self.xf, m.elem_center[Em], m.elem_key[Em])
-        vp = _feval(fn, self.xf, m.elem_center[Ep], m.elem_key[Ep])
-        return vm, vp                                                   # [nF, 3] each
+    def _edge(self, order):
+        """Edge rule of a requested order on every face, parametrised from local vertex f+1 to f+2 of the minus
+        element: dict(t, w, xf [nF, k, 2], phim / phip [nF, i, k] basis values of the minus / plus element)."""
+        hit = self._edge_cache.get(order)
+        if hit is None:
+            m = self.mesh
+            t, w = edge_rule(order)
+            Em, fm = m.face_minus[:, 0], m.face_minus[:, 1]
+            a = m.points[Em, (fm + 1) % 3]
+            b = m.points[Em, (fm + 2) % 3]
+            xf = a[:, None, :] + t[None, :, None] * (b - a)[:, None, :]
+            nF = m.num_faces
+            phim = np.zeros((nF, 3, len(t)))
+            ar = np.arange(nF)
+            phim[ar, (fm + 1) % 3, :] = 1.0 - t[None, :]
+            phim[ar, (fm + 2) % 3, :] = t[None, :]
+            Ep = np.maximum(m.face_plus[:, 0], 0)
+            d = xf - m.points[Ep, 0][:, None, :]
+            phip = np.einsum('fia,fka->fik', m.grads[Ep], d)
+            phip[:, 0, :] += 1.0
+            phip[m.face_plus[:, 0] < 0] = 0.0
+            hit = dict(t=t, w=w, xf=xf, phim=phim, phip=phip)
+            self._edge_cache[order] = hit
+        return hit
+
+    def _vol(self, fn, order):
+        """Samples of a data function at the volume points of the rule of ``order``: [nE, k] (memoised)."""
+        key = ('v', id(fn), order)
+        hit = self._smp_cache.get(key)
+        if hit is None:
+            m = self.mesh
+            hit = _feval(fn, self._tri(order)['xq'], m.elem_center, m.elem_key)
+            self._smp_cache[key] = hit
+        return hit
+
+    def _face_sides(self, fn, order):
+        """Samples on every face seen from the minus / plus element: ([nF, k], [nF, k]) (memoised)."""
+        key = ('f', id(fn), order)
+        hit = self._smp_cache.get(key)
+        if hit is None:
+            m = self.mesh
+            xf = self._edge(order)['xf']
+            Em = m.face_minus[:, 0]
+            Ep = np.maximum(m.face_plus[:, 0], 0)
+            hit = (_feval(fn, xf, m.elem_center[Em], m.elem_key[Em]), _feval(fn, xf, m.elem_center[Ep], m.elem_key[Ep]))
+            self._smp_cache[key] = hit
+        return hit
+
+    def _vol_integral(self, fn, order):
+        """int_T fn for every element with the rule of ``order``."""
+        return (self._vol(fn, order) * self._tri(order)['w'][None, :]).sum(axis=1) * self.mesh.area
 
     def _coo(self, rows_e, cols_e, blocks):
         """Scatter 3x3 blocks [k, i, j] to (3*rows_e+i, 3*cols_e+j)."""
@@ -109,17 +150,21 @@ class OracleDiscretization:
         return sp.coo_matrix((blocks.ravel(), (r.ravel(), c.ravel())), shape=(self.ndof, self.ndof)).tocsr()
 
     # ------------------------------------------------------------------ SWIPDG system (K1-K4)
-    def _swipdg_face_blocks(self, lam_m, lam_p):
-        """The four inner-face blocks of SURVEY App. A.2 for every face, integrated with EDGE_W."""
+    def _swipdg_face_blocks(self, fn, order, faces):
+        """The four inner-face blocks of SURVEY App. A.2 on the faces ``faces``, integrated with the edge rule of
+        ``order``."""
         m = self.mesh
-        L = m.face_length
-        wq = EDGE_W[None, :] * L[:, None]                                # [nF, 3]
-        gamma = 0.5 * self.delta          # delta^+ delta^- / (delta^+ + delta^-) with constant kappa
+        ed = self._edge(order)
+        lam_m, lam_p = self._face_sides(fn, order)
+        lam_m, lam_p = lam_m[faces], lam_p[faces]
+        L = m.face_length[faces]
+        wq = ed['w'][None, :] * L[:, None]
+        gamma = 0.5 * self.delta[faces]   # delta^+ delta^- / (delta^+ + delta^-) with constant kappa
         wm = wp = 0.5
         sigma = 0.5 * (lam_m + lam_p) * SIGMA_INNER_P1 * gamma[:, None] / (L[:, None] ** BETA_2D)
-        gm = lam_m[:, None, :] * self.gnm[:, :, None]                    # [f, i, k] (D^- grad phi_i^- . n)
-        gp = lam_p[:, None, :] * self.gnp[:, :, None]
-        pm, pp = self.phim, self.phip
+        gm = lam_m[:, None, :] * self.gnm[faces][:, :, None]             # [f, i, k] (D^- grad phi_i^- . n)
+        gp = lam_p[:, None, :] * self.gnp[faces][:, :, None]
+        pm, pp = ed['phim'][faces], ed['phip'][faces]
         e = np.einsum
         # [row i (test), col j (ansatz)]
         mm = (-wm * e('fjk,fik,fk->fij', gm, pm, wq) - wm * e('fjk,fik,fk->fij', pm, gm, wq)
@@ -132,48 +177,52 @@ class OracleDiscretization:
                + e('fk,fjk,fik,fk->fij', sigma, pp, pp, wq))
         return mm, mp, pm_, pp_
 
-    def _swipdg_boundary_block(self, lam_m):
+    def _swipdg_boundary_block(self, fn, order, faces, side='minus'):
+        """Dirichlet boundary-face block seen from the minus (outward normal = face normal) or plus element."""
         m = self.mesh
-        L = m.face_length
-        wq = EDGE_W[None, :] * L[:, None]
-        sigma = lam_m * SIGMA_BOUNDARY_P1 * self.delta[:, None] / (L[:, None] ** BETA_2D)
-        g = lam_m[:, None, :] * self.gnm[:, :, None]
-        pm = self.phim
+        ed = self._edge(order)
+        lam = self._face_sides(fn, order)[0 if side == 'minus' else 1][faces]
+        L = m.face_length[faces]
+        wq = ed['w'][None, :] * L[:, None]
+        sigma = lam * SIGMA_BOUNDARY_P1 * self.delta[faces][:, None] / (L[:, None] ** BETA_2D)
+        if side == 'minus':
+            g = lam[:, None, :] * self.gnm[faces][:, :, None]
+            ph = ed['phim'][faces]
+        else:
+            g = -lam[:, None, :] * self.gnp[faces][:, :, None]
+            ph = ed['phip'][faces]
         e = np.einsum
-        return (-e('fjk,fik,fk->fij', g, pm, wq) - e('fjk,fik,fk->fij', pm, g, wq)
-                + e('fk,fjk,fik,fk->fij', sigma, pm, pm, wq))
+        return (-e('fjk,fik,fk->fij', g, ph, wq) - e('fjk,fik,fk->fij', ph, g, wq)
+                + e('fk,fjk,fik,fk->fij', sigma, ph, ph, wq))
+
+    def _inner_form(self, fn, order, faces):
+        m = self.mesh
+        Em, Ep = m.face_minus[faces, 0], m.face_plus[faces, 0]
+        mm, mp, pm_, pp_ = self._swipdg_face_blocks(fn, order, faces)
+        return (self._coo(Em, Em, mm) + self._coo(Em, Ep, mp) + self._coo(Ep, Em, pm_) + self._coo(Ep, Ep, pp_))
 
     def _assemble_system(self):
         """discretize_lhs (block_swipdg.py:381-507): local (volume + inner faces, all-Neumann, :399-406),
         coupling (:409-423) and Dirichlet boundary (:426-437) parts per affine component."""
         m = self.mesh
-        Em, Ep = m.face_minus[:, 0], m.face_plus[:, 0]
-        inner = m.face_kind == 0
-        coupl = m.face_kind == 1
-        bnd = m.face_kind == 2
+        qd = self.quad
+        Em = m.face_minus[:, 0]
+        inner = np.nonzero(m.face_kind == 0)[0]
+        coupl = np.nonzero(m.face_kind == 1)[0]
+        bnd = np.nonzero(m.face_kind == 2)[0]
         earange = np.arange(m.num_elements)
-        self.lam_vol, self.lam_face = [], []
         self.A_local, self.A_coupling, self.A_boundary, self.A = [], [], [], []
         acc = None
         for q, fn in enumerate(self.lambda_funcs):
-            lv = self._vol(fn)
-            lm, lp = self._face_sides(fn)
-            self.lam_vol.append(lv)
-            self.lam_face.append((lm, lp))
-            lam_int = (lv * TRI_W[None, :]).sum(axis=1) * m.area        # int_T lambda_q
+            lam_int = self._vol_integral(fn, qd.system_volume)           # int_T lambda_q
             A_vol = self._coo(earange, earange, lam_int[:, None, None] * self.stiff)
-            mm, mp, pm_, pp_ = self._swipdg_face_blocks(lm, lp)
-
-            def faces(mask):
-                return (self._coo(Em[mask], Em[mask], mm[mask]) + self._coo(Em[mask], Ep[mask], mp[mask]) +
-                        self._coo(Ep[mask], Em[mask], pm_[mask]) + self._coo(Ep[mask], Ep[mask], pp_[mask]))
-            A_loc = A_vol + faces(inner)
-            A_cpl = faces(coupl)
+            A_loc = A_vol + self._inner_form(fn, qd.system_inner_face, inner)
+            A_cpl = self._inner_form(fn, qd.system_coupling_face, coupl)
             if self.accumulate_coupling_across_q:      # reference quirk, SURVEY App. B-7 (:551-565 vs :581-583)
                 acc = A_cpl if acc is None else acc + A_cpl
                 A_cpl = acc.copy()
-            bb = self._swipdg_boundary_block(lm)
-            A_bnd = self._coo(Em[bnd], Em[bnd], bb[bnd])
+            bb = self._swipdg_boundary_block(fn, qd.system_boundary_face, bnd)
+            A_bnd = self._coo(Em[bnd], Em[bnd], bb)
             self.A_local.append(A_loc)
             self.A_coupling.append(A_cpl)
             self.A_boundary.append(A_bnd)
@@ -205,14 +254,14 @@ class OracleDiscretization:
     def _assemble_rhs(self):
         """discretize_rhs (block_swipdg.py:510-527) and the scalars of :776-783."""
         m = self.mesh
-        fv = self._vol(self.f)
-        self.f_vol = fv
-        b = np.einsum('ek,k,ki,e->ei', fv, TRI_W, TRI_BARY, m.area)     # [nE, 3]
+        qd = self.quad
+        tr = self._tri(qd.rhs)
+        fv = self._vol(self.f, qd.rhs)
+        b = np.einsum('ek,k,ki,e->ei', fv, tr['w'], tr['bary'], m.area)     # [nE, 3]
         self.b = b.reshape(-1)
-        f2 = (fv ** 2 * TRI_W[None, :]).sum(axis=1) * m.area
+        f2 = (self._vol(self.f, qd.f2) ** 2 * self._tri(qd.f2)['w'][None, :]).sum(axis=1) * m.area
         self.local_eta_rf_squared = f2.reshape(self.S, self.nT).sum(axis=1)
-        lh = self._vol(self.lambda_hat)
-        self.lam_hat_vol = lh
+        lh = self._vol(self.lambda_hat, qd.ceps)
         kmin = float(np.linalg.eigvalsh(0.5 * (self.kappa + self.kappa.T)).min())
         self.min_diffusion_evs = lh.reshape(self.S, -1).min(axis=1) * kmin
         self.subdomain_diameters = np.array([m.subdomain_diameter(ii) for ii in range(self.S)])
@@ -222,20 +271,21 @@ class OracleDiscretization:
         """Local energy product (elliptic + penalty at mu_bar, :651-677), L2 mass (:662,:679),
         E_ii(lambda_bar) (:685-691)."""
         m = self.mesh
+        qd = self.quad
         earange = np.arange(m.num_elements)
         Em, Ep = m.face_minus[:, 0], m.face_plus[:, 0]
         inner = m.face_kind == 0
         outer = m.face_kind != 0
         L = m.face_length
-        wq = EDGE_W[None, :] * L[:, None]
-        pm, pp = self.phim, self.phip
+        ed = self._edge(qd.energy_face)
+        wq = ed['w'][None, :] * L[:, None]
+        pm, pp = ed['phim'], ed['phip']
         e = np.einsum
         energy = None
         self.penalty = []
-        for q in range(self.Q):
-            lv = self.lam_vol[q]
-            lm, lp = self.lam_face[q]
-            lam_int = (lv * TRI_W[None, :]).sum(axis=1) * m.area
+        for q, fn in enumerate(self.lambda_funcs):
+            lm, lp = self._face_sides(fn, qd.energy_face)
+            lam_int = self._vol_integral(fn, qd.energy_volume)
             ell = self._coo(earange, earange, lam_int[:, None, None] * self.stiff)
             sig = 0.5 * (lm + lp) * SIGMA_INNER_P1 * (0.5 * self.delta)[:, None] / (L[:, None] ** BETA_2D)
             mm = e('fk,fjk,fik,fk->fij', sig, pm, pm, wq)
@@ -259,8 +309,7 @@ class OracleDiscretization:
         self.energy_product = energy.tocsr()
         mass = (1.0 + np.eye(3))[None, :, :] * (m.area / 12.0)[:, None, None]
         self.l2_product = self._coo(earange, earange, mass)
-        lb = self._vol(self.lambda_bar)
-        lb_int = (lb * TRI_W[None, :]).sum(axis=1) * m.area
+        lb_int = self._vol_integral(self.lambda_bar, qd.elliptic_bar)
         self.elliptic_bar = self._coo(earange, earange, lb_int[:, None, None] * self.stiff)
 
     # ------------------------------------------------------------------ flux reconstruction (K8)
@@ -269,19 +318,22 @@ class OracleDiscretization:
         [faces x dofs] matrix per affine component; FluxReconstructionOperator.apply
         (block_swipdg.py:148-176) is then a restriction of F_q @ v."""
         m = self.mesh
+        qd = self.quad
         Em, Ep = m.face_minus[:, 0], m.face_plus[:, 0]
         L = m.face_length
         has_p = Ep >= 0
+        ed = self._edge(qd.flux_face)
+        W, phim, phip = ed['w'], ed['phim'], ed['phip']
         self.F = []
-        for q in range(self.Q):
-            lm, lp = self.lam_face[q]
+        for q, fn in enumerate(self.lambda_funcs):
+            lm, lp = self._face_sides(fn, qd.flux_face)
             sig = 0.5 * (lm + lp) * SIGMA_INNER_P1 * (0.5 * self.delta)[:, None] / (L[:, None] ** BETA_2D)
             sigb = lm * SIGMA_BOUNDARY_P1 * self.delta[:, None] / (L[:, None] ** BETA_2D)
             # inner / coupling faces (weights w^- = w^+ = 1/2 for constant kappa)
-            cm = np.einsum('k,fk,fj->fj', EDGE_W, -0.5 * lm, self.gnm) + np.einsum('k,fk,fjk->fj', EDGE_W, sig, self.phim)
-            cp = np.einsum('k,fk,fj->fj', EDGE_W, -0.5 * lp, self.gnp) - np.einsum('k,fk,fjk->fj', EDGE_W, sig, self.phip)
+            cm = np.einsum('k,fk,fj->fj', W, -0.5 * lm, self.gnm) + np.einsum('k,fk,fjk->fj', W, sig, phim)
+            cp = np.einsum('k,fk,fj->fj', W, -0.5 * lp, self.gnp) - np.einsum('k,fk,fjk->fj', W, sig, phip)
             # Dirichlet boundary faces
-            cb = np.einsum('k,fk,fj->fj', EDGE_W, -lm, self.gnm) + np.einsum('k,fk,fjk->fj', EDGE_W, sigb, self.phim)
+            cb = np.einsum('k,fk,fj->fj', W, -lm, self.gnm) + np.einsum('k,fk,fjk->fj', W, sigb, phim)
             cm = np.where(has_p[:, None], cm, cb)
             rows = np.repeat(np.arange(m.num_faces), 3)
             colm = (3 * Em[:, None] + np.arange(3)[None, :]).ravel()
@@ -309,15 +361,21 @@ class OracleDiscretization:
         for ii in range(self.S):
             hood = m.neighborhood_of(ii)
             hood_set = set(hood)
-            rows = {kk: [] for kk in hood}
-            cols = {kk: [] for kk in hood}
-            vals = {kk: [] for kk in hood}
+            srcs = hood if self.oswald_patch == 'neighborhood' else m.vertex_neighborhood_of(ii)
+            rows = {kk: [] for kk in srcs}
+            cols = {kk: [] for kk in srcs}
+            vals = {kk: [] for kk in srcs}
             for el in range(nT):
                 E = m.elem_offset[ii] + el
                 for v in range(3):
                     g = int(m.triangles[E, v])
-                    adj = [(E2, v2) for (E2, v2) in m.vertex_adjacency[g] if int(m.elem_subdomain[E2]) in hood_set]
-                    if self.oswald_zero_on == 'physical':
+                    # 'neighborhood': elements of N(ii) = ii + face neighbours (block_swipdg.py:91-102);
+                    # 'vertex': every element at the vertex (diagonal subdomains at cross points included)
+                    adj = [(E2, v2) for (E2, v2) in m.vertex_adjacency[g]
+                           if self.oswald_patch == 'vertex' or int(m.elem_subdomain[E2]) in hood_set]
+                    if self.oswald_zero_on == 'none':
+                        dirichlet = False
+                    elif self.oswald_zero_on == 'physical':
                         dirichlet = bool(m.vertex_on_boundary[g])
                     else:  # every vertex on the boundary of the neighbourhood-restricted subdomain ii
                         dirichlet = any(int(m.elem_subdomain[E2]) != ii for (E2, _) in m.vertex_adjacency[g]) \
@@ -331,13 +389,18 @@ class OracleDiscretization:
                         cols[kk].append(3 * int(m.elem_local[E2]) + v2)
                         vals[kk].append(w)
             self.Avg.append({kk: sp.coo_matrix((vals[kk], (rows[kk], cols[kk])), shape=(n, n)).tocsr()
-                             for kk in hood})
+                             for kk in srcs})
+
+    def oi_hood(self, ii):
+        """Subdomains whose functions enter the Oswald interpolant on ``ii`` (= the ones ``ii``'s functions reach)."""
+        m = self.mesh
+        return m.neighborhood_of(ii) if self.oswald_patch == 'neighborhood' else m.vertex_neighborhood_of(ii)
 
     def oswald_interpolation_error_apply(self, s, U):
         """OswaldInterpolationErrorOperator(s).apply(U) (block_swipdg.py:83-122): one [n, k] block per
         ii in neighborhood_of(s): delta_{ii,s} U - I_os^{ii}[U extended by zero]|_{ii}."""
         out = []
-        for ii in self.mesh.neighborhood_of(s):
+        for ii in self.oi_hood(s):
             blk = -(self.Avg[ii][s] @ U)
             if ii == s:
                 blk = blk + U
@@ -348,22 +411,29 @@ class OracleDiscretization:
     def _assemble_estimator_operators(self):
         """Div_ii (:722-729), df_aa / df_ab / df_bb products (:319-378) in subdomain-local numbering."""
         m = self.mesh
+        qd = self.quad
         nT, n = self.nT, self.n
         kinv = np.linalg.inv(self.kappa)
-        lh = self.lam_hat_vol
-        wa = TRI_W[None, :] * m.area[:, None]                          # [nE, 7]
         # psi_{T,f}(x) = sign * |e| / (2|T|) * (x - p_f)
         coef = m.elem_face_sign * m.face_length[m.elem_face] / (2.0 * m.area[:, None])   # [nE, 3]
-        psi = coef[:, :, None, None] * (self.xq[:, None, :, :] - m.points[:, :, None, :])   # [nE, f, k, 2]
+
+        def rule(order):
+            tr = self._tri(order)
+            wa = tr['w'][None, :] * m.area[:, None]
+            psi = coef[:, :, None, None] * (tr['xq'][:, None, :, :] - m.points[:, :, None, :])   # [nE, f, k, 2]
+            return wa, psi, self._vol(self.lambda_hat, order)
         self.caa = [[None] * self.Q for _ in range(self.Q)]
         earange = np.arange(m.num_elements)
+        wa, _, lh = rule(qd.df_aa)
         for q in range(self.Q):
             for q2 in range(self.Q):
-                c = (self.lam_vol[q] * self.lam_vol[q2] / lh * wa).sum(axis=1)
+                c = (self._vol(self.lambda_funcs[q], qd.df_aa) * self._vol(self.lambda_funcs[q2], qd.df_aa) / lh * wa).sum(axis=1)
                 self.caa[q][q2] = self._coo(earange, earange, c[:, None, None] * self.stiff)
         # element-local blocks
-        self.ab_blocks = [np.einsum('ek,eia,efka->eif', self.lam_vol[q] / lh * wa, m.grads, psi)
+        wa, psi, lh = rule(qd.df_ab)
+        self.ab_blocks = [np.einsum('ek,eia,efka->eif', self._vol(self.lambda_funcs[q], qd.df_ab) / lh * wa, m.grads, psi)
                           for q in range(self.Q)]                      # [nE, i, f]
+        wa, psi, lh = rule(qd.df_bb)
         self.bb_blocks = np.einsum('ek,efka,ab,egkb->efg', wa / lh, psi, kinv, psi)      # [nE, f, g]
         # Div_ii maps RT0 coefficients to the DG *coefficients* of div r (piecewise constant, so all three
         # rows of an element are equal): only this reading makes r_fd = b.(Div r) = int f div r and
@@ -439,55 +509,19 @@ class OracleDiscretization:
         only_m = np.where(m_in & ~p_in)[0]
         only_p = np.where(p_in & ~m_in)[0]
         th = self.theta(mu)
-        e = np.einsum
+        qd = self.quad
         elems = np.where(inH)[0]
         A = None
         for q, fn in enumerate(self.lambda_funcs):
-            lv = self.lam_vol[q]
-            lm_all, lp_all = self.lam_face[q]
-            lam_int = (lv[elems] * TRI_W[None, :]).sum(axis=1) * m.area[elems]
+            # make_elliptic_swipdg_matrix_operator_on_neighborhood(..., over_integrate=0) (:243-247)
+            lam_int = self._vol_integral(fn, qd.energy_volume)[elems]
             Aq = self._coo(elems, elems, lam_int[:, None, None] * self.stiff[elems])
             # inner-face form on faces with both sides inside the neighbourhood
-            f = both
-            L = m.face_length[f]
-            wq = EDGE_W[None, :] * L[:, None]
-            lm, lp = lm_all[f], lp_all[f]
-            sigma = 0.5 * (lm + lp) * SIGMA_INNER_P1 * (0.5 * self.delta[f])[:, None] / (L[:, None] ** BETA_2D)
-            gm = lm[:, None, :] * self.gnm[f][:, :, None]
-            gp = lp[:, None, :] * self.gnp[f][:, :, None]
-            pm, pp = self.phim[f], self.phip[f]
-            mm = (-0.5 * e('fjk,fik,fk->fij', gm, pm, wq) - 0.5 * e('fjk,fik,fk->fij', pm, gm, wq)
-                  + e('fk,fjk,fik,fk->fij', sigma, pm, pm, wq))
-            mp = (-0.5 * e('fjk,fik,fk->fij', gp, pm, wq) + 0.5 * e('fjk,fik,fk->fij', pp, gm, wq)
-                  - e('fk,fjk,fik,fk->fij', sigma, pp, pm, wq))
-            pm_ = (0.5 * e('fjk,fik,fk->fij', gm, pp, wq) - 0.5 * e('fjk,fik,fk->fij', pm, gp, wq)
-                   - e('fk,fjk,fik,fk->fij', sigma, pm, pp, wq))
-            pp_ = (0.5 * e('fjk,fik,fk->fij', gp, pp, wq) + 0.5 * e('fjk,fik,fk->fij', pp, gp, wq)
-                   + e('fk,fjk,fik,fk->fij', sigma, pp, pp, wq))
-            Aq = Aq + (self._coo(Em[f], Em[f], mm) + self._coo(Em[f], Ep[f], mp) +
-                       self._coo(Ep[f], Em[f], pm_) + self._coo(Ep[f], Ep[f], pp_))
-            # Dirichlet form seen from the minus element (outward normal = face normal)
-            f = only_m
-            L = m.face_length[f]
-            wq = EDGE_W[None, :] * L[:, None]
-            lm = lm_all[f]
-            sigma = lm * SIGMA_BOUNDARY_P1 * self.delta[f][:, None] / (L[:, None] ** BETA_2D)
-            g = lm[:, None, :] * self.gnm[f][:, :, None]
-            pm = self.phim[f]
-            bm = (-e('fjk,fik,fk->fij', g, pm, wq) - e('fjk,fik,fk->fij', pm, g, wq)
-                  + e('fk,fjk,fik,fk->fij', sigma, pm, pm, wq))
-            Aq = Aq + self._coo(Em[f], Em[f], bm)
+            Aq = Aq + self._inner_form(fn, qd.energy_face, both)
+            # Dirichlet form seen from the minus element (outward normal = face normal) ...
+            Aq = Aq + self._coo(Em[only_m], Em[only_m], self._swipdg_boundary_block(fn, qd.energy_face, only_m, 'minus'))
             # ... and from the plus element (outward normal = - face normal)
-            f = only_p
-            L = m.face_length[f]
-            wq = EDGE_W[None, :] * L[:, None]
-            lp = lp_all[f]
-            sigma = lp * SIGMA_BOUNDARY_P1 * self.delta[f][:, None] / (L[:, None] ** BETA_2D)
-            g = -lp[:, None, :] * self.gnp[f][:, :, None]
-            pp = self.phip[f]
-            bp = (-e('fjk,fik,fk->fij', g, pp, wq) - e('fjk,fik,fk->fij', pp, g, wq)
-                  + e('fk,fjk,fik,fk->fij', sigma, pp, pp, wq))
-            Aq = Aq + self._coo(Ep[f], Ep[f], bp)
+            Aq = Aq + self._coo(Ep[only_p], Ep[only_p], self._swipdg_boundary_block(fn, qd.energy_face, only_p, 'plus'))
             A = th[q] * Aq if A is None else A + th[q] * Aq
         n = self.n
         dofs = np.concatenate([np.arange(kk * n, (kk + 1) * n) for kk in hood])
@@ -532,7 +566,7 @@ class OracleReductor:
         process pool; the returned model then only holds their entries, in that order)."""
         d, m = self.d, self.d.mesh
         targets = list(range(d.S)) if subdomains is None else list(subdomains)
-        sources = None if subdomains is None else sorted({kk for ii in targets for kk in m.neighborhood_of(ii)})
+        sources = None if subdomains is None else sorted({kk for ii in targets for kk in d.oi_hood(ii)})
         OI, RT = self.image_bases(sources)
         rd = OracleReducedModel(d, [b.shape[1] for b in self.bases])
         n = d.n
@@ -541,7 +575,7 @@ class OracleReductor:
             V = self.bases[ii]
             # local_oi_projection / local_rt_projection (block_swipdg.py:700-717): component ``ii`` of every
             # neighbour's image basis, stacked in neighbourhood order
-            Wt = np.hstack([OI[kk][m.neighborhood_of(kk).index(ii)] for kk in hood])
+            Wt = np.hstack([OI[kk][d.oi_hood(kk).index(ii)] for kk in d.oi_hood(ii)])
             Rt = np.hstack([RT[kk][m.neighborhood_of(kk).index(ii)] for kk in hood])
             E = d.block(d.elliptic_bar, ii, ii)
             M = d.block(d.l2_product, ii, ii)
@@ -604,7 +638,7 @@ class OracleReducedModel:
         eta_nc, eta_r, eta_df = np.zeros(S), np.zeros(S), np.zeros(S)
         for ii in range(S):
             hood = m.neighborhood_of(ii)
-            uo = np.concatenate([np.asarray(u[kk]) for kk in hood])
+            uo = np.concatenate([np.asarray(u[kk]) for kk in d.oi_hood(ii)])
             ur = np.concatenate([np.concatenate([th[q] * np.asarray(u[kk]) for q in range(d.Q)]) for kk in hood])
             ui = np.asarray(u[ii])
             eta_nc[ii] = uo @ self.nc[ii] @ uo

@@ -201,6 +201,15 @@ class OracleMesh:
     def neighborhood_of(self, ii):
         return sorted([ii] + self._neighbors[ii])
 
+    def vertex_neighborhood_of(self, ii):
+        """ii and every subdomain sharing at least a vertex with it (face neighbours + diagonal ones), sorted."""
+        cache = self.__dict__.setdefault('_vertex_hoods', {})
+        if ii not in cache:
+            E0 = self.elem_offset[ii]
+            verts = np.unique(self.triangles[E0:E0 + self.elements_per_subdomain])
+            cache[ii] = sorted({int(self.elem_subdomain[E]) for g in verts for (E, _) in self.vertex_adjacency[int(g)]})
+        return list(cache[ii])
+
     def boundary_subdomains(self):
         return list(self._boundary_subdomains)
 

@@ -21,8 +21,8 @@ def init_grid_and_problem(config, mu_bar=1, mu_hat=1, mpi_comm=None):
     f = make_expression_function_1x1(grid, 'x', '0.5*pi*pi*{}'.format(cos), order=2, name='f')
     mbc = '1+(1-{})*{}'.format(mu_bar, cos)
     lambda_bar = make_expression_function_1x1(grid, 'x', mbc, order=2, name='lambda_bar')
-    mhc = '1+(1-{})*{}'.format(mu_hat, cos)
-    lambda_hat = make_expression_function_1x1(grid, 'x', mhc, order=2, name='lambda_hat')
+    # as written in the reference (OS2015_academic_problem.py:48-50): lambda_hat is built from the mu_bar expression too
+    lambda_hat = make_expression_function_1x1(grid, 'x', mbc, order=2, name='lambda_hat')
     return {'grid': grid,
             'mpi_comm': mpi_comm,
             'boundary_info': all_dirichlet_boundary_info,

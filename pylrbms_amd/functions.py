@@ -40,6 +40,8 @@ class ExpressionFunction:
 
 
 class ConstantFunction:
+    order = 0
+
     def __init__(self, value, name='constant'):
         self.value, self.name = np.asarray(value, dtype=np.float64), name
 
@@ -50,6 +52,7 @@ class ConstantFunction:
 class CheckerboardFunction:
     """``make_checkerboard_function_1x1``: piecewise constant on a Cartesian ``num_elements`` checkerboard,
     ``values[ix + nx * iy]``; the cell is decided by the element centre."""
+    order = 0
 
     def __init__(self, lower_left, upper_right, num_elements, values, name='checkerboard'):
         self.ll = np.asarray(lower_left, dtype=np.float64)
@@ -71,6 +74,7 @@ class CheckerboardFunction:
 class ElementwiseFunction:
     """Piecewise constant per fine element: ``table[cy, cx, t]`` indexed by the canonical element key
     (synthetic multiscale coefficient fields)."""
+    order = 0
 
     def __init__(self, table, name='elementwise'):
         self.table, self.name = np.asarray(table, dtype=np.float64), name
@@ -84,6 +88,7 @@ class ElementwiseFunction:
 class SumFunction:
     def __init__(self, functions, coefficients, name='sum'):
         self.functions, self.coefficients, self.name = list(functions), [float(c) for c in coefficients], name
+        self.order = max(getattr(f, 'order', 2) for f in self.functions)
 
     def __call__(self, x, centers, keys):
         return sum(c * f(x, centers, keys) for f, c in zip(self.functions, self.coefficients))

@@ -26,13 +26,13 @@ def test_samples_equal_the_oracles(mk):
     Ep, fp = m.face_plus[has, 0], m.face_plus[has, 1]
     for q, fn in enumerate(p['lambda']['functions']):
         lam = sample_function(fn, x, c, k).reshape(-1, 16)
-        assert np.array_equal(lam[:, :7], d.lam_vol[q])
-        lm, lp = d.lam_face[q]
+        assert np.array_equal(lam[:, :7], d._vol(fn, 5))
+        lm, lp = d._face_sides(fn, 5)
         assert np.array_equal(lam[Em][np.arange(len(Em))[:, None], 7 + 3 * fm[:, None] + np.arange(3)[None, :]], lm)
         assert np.array_equal(lam[Ep][np.arange(len(Ep))[:, None], 7 + 3 * fp[:, None] + (2 - np.arange(3))[None, :]],
                               lp[has])
     f = sample_function(p['f'], x, c, k, volume_only=True).reshape(-1, 7)
-    assert np.array_equal(f, d.f_vol)
+    assert np.array_equal(f, d._vol(p['f'], 5))
 
 
 def test_problem_dict_keys_match_the_reference():

@@ -17,13 +17,13 @@ from pylrbms_amd import OS2015_academic_problem, multiscale_problem
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-def _os2015(K, P):
+def _os2015(K, P, **kw):
     cos = lambda x: np.cos(0.5 * np.pi * x[..., 0]) * np.cos(0.5 * np.pi * x[..., 1])  # noqa: E731
     mesh = OracleMesh([-1, -1], [1, 1], K, P)
     th = [lambda mu: 1.0, lambda mu: float(np.ravel(mu)[0])]
     one = lambda x, c, k: 1.0 + 0.0 * cos(x)  # noqa: E731
     return OracleDiscretization(mesh, [lambda x, c, k: 1 + cos(x), lambda x, c, k: -cos(x)], th, np.eye(2),
-                                lambda x, c, k: 0.5 * np.pi ** 2 * cos(x), one, one, 1.0, 1.0), cos
+                                lambda x, c, k: 0.5 * np.pi ** 2 * cos(x), one, one, 1.0, 1.0, **kw), cos
 
 
 @pytest.fixture(scope='module')
@@ -34,26 +34,22 @@ def os4():
 def test_known_answers_of_the_reference_script(os4):
     """linearelliptic_block_swipdg_decomp.py:41-43: OS2015, 4x4 subdomains, mu = 1, sqrt variant of the local
     indicators: 1.66e-01 / 1.45e-01 / 3.55e-01.  Residual and diffusive-flux values are reproduced to the printed
-    digits by the oracle as is; the nonconformity value is reproduced with the vertex patch of the Oswald
-    interpolation taken over ALL elements at a vertex (the older global estimator those numbers come from), and is
-    1.2 % higher (0.1680) with the neighbourhood structure of HEAD (face neighbours only, block_swipdg.py:78-113)."""
+    digits.  The nonconformity value is reproduced by the oracle's ``oswald_patch='vertex'`` mode (vertex patch of the
+    Oswald interpolation over ALL elements at a vertex, i.e. including the diagonal subdomain at a cross point -- the
+    older global estimator those numbers were printed for).  With the neighbourhood structure of HEAD (face neighbours
+    only, block_swipdg.py:78-113: ``grid.neighborhood_of``) it comes out 1.2 % higher: PARITY UNPINNED for that
+    convention -- no reference number exists for it, so only its distance to the printed value is bounded here."""
     d, _ = os4
     U = d.solve(1.0)
     _, (nc, r, df), _ = d.estimate(U, 1.0, decompose=True, sqrt_local=True)
     assert abs(np.linalg.norm(r) - 1.45e-01) < 0.5e-3
     assert abs(np.linalg.norm(df) - 3.55e-01) < 0.5e-3
-    assert abs(np.linalg.norm(nc) - 0.1680) < 0.5e-3
-    # global vertex patches
-    m, u = d.mesh, U.reshape(-1)
-    w = np.zeros_like(u)
-    for E in range(m.num_elements):
-        for v in range(3):
-            g = m.triangles[E, v]
-            adj = m.vertex_adjacency[g]
-            val = 0.0 if m.vertex_on_boundary[g] else sum(u[3 * E2 + v2] for E2, v2 in adj) / len(adj)
-            w[3 * E + v] = u[3 * E + v] - val
-    e = [w[ii * d.n:(ii + 1) * d.n] @ (d.block(d.elliptic_bar, ii, ii) @ w[ii * d.n:(ii + 1) * d.n]) for ii in range(d.S)]
-    assert abs(np.linalg.norm(np.sqrt(e)) - 1.66e-01) < 0.5e-3
+    assert abs(np.linalg.norm(nc) / 1.66e-01 - 1.0) < 0.02          # HEAD neighbourhoods: unpinned, 1.2 % off
+    dv, _ = _os2015([4, 4], [4, 4], oswald_patch='vertex')
+    _, (nc, r, df), _ = dv.estimate(U, 1.0, decompose=True, sqrt_local=True)
+    assert abs(np.linalg.norm(nc) - 1.66e-01) < 0.5e-3
+    assert abs(np.linalg.norm(r) - 1.45e-01) < 0.5e-3
+    assert abs(np.linalg.norm(df) - 3.55e-01) < 0.5e-3
 
 
 def test_system_is_symmetric_positive_definite_and_blocks_match_global(os4):

@@ -1,0 +1,103 @@
+"""Pin against the only 12-digit number the reference tree holds for this path.
+
+python/scripts/online_adaptive_lrbms.py:46-53 (repeated in mpi_elliptic.py:27-34) records
+
+    # OS2015_academic_problem
+    # [4, 4], 2, [2, 2], 4: 0.815510144764
+
+i.e. the estimate of the full-order solution of the OS2015 problem on ``num_subdomains=[2, 2]``,
+``half_num_fine_elements_per_subdomain_and_dim=4`` (the configuration the script still runs, :56-61) at
+``mu = parameter_range[0] = 0.1`` (its loop at :88-95), with the square-root variant of the local indicators
+ and ``alpha`` as written (estimators.py:114-121).  That value is a pin of the WHOLE full-order
+pipeline: SWIPDG assembly, solve, Oswald interpolation, RT0 flux reconstruction, the three estimator products and the
+estimator constants.
+
+Status: the oracle reproduces it to 6.9e-5 (relative) with dune-gdt's per-integrand quadrature orders, 7.9e-5 with
+the round-1 uniform rule.  tools/pin/os2015_eta.py -> profiles/r02_pin_table.txt lists every variant tried (quadrature
+order of each integrand on its own, Oswald patch / boundary conventions, coupling accumulated across q, inexact
+solves): none closes the remaining 6.9e-5 and each of them moves eta by < 1.2e-5, so the residual is not one of the
+conventions DESIGN.md section 3 leaves open (on this configuration the subdomain interfaces are symmetry lines of the
+solution, so every coupling-face convention drops out).  The other two recorded values (``[6, 6], 4, [6, 6], 4``:
+3.03372753518 for OS2015, 0.585792065793 for the local thermal block) are not reproduced by any reading
+(table section 6) -- PARITY UNPINNED for those configurations.
+"""
+import numpy as np
+import pytest
+
+from common import oracle_from_problem
+from oracle.quadrature import QuadratureSpec, edge_rule, triangle_rule
+from pylrbms_amd import OS2015_academic_problem
+
+REFERENCE_ETA = 0.815510144764          # online_adaptive_lrbms.py:49
+PIN_TOLERANCE = 1e-4                    # relative; observed 6.9e-5 (dune orders), 7.9e-5 (uniform degree 5)
+CONFIG = {'num_subdomains': [2, 2], 'half_num_fine_elements_per_subdomain_and_dim': 4}   # online_adaptive_lrbms.py:56-57
+
+
+def test_quadrature_rules_are_exact_to_their_degree():
+    import math
+    for order, degree, npts in ((1, 1, 1), (2, 2, 3), (3, 3, 4), (4, 4, 6), (5, 5, 7), (6, 7, 12), (7, 7, 12), (8, 8, 16)):
+        b, w = triangle_rule(order)
+        assert len(w) == npts and abs(w.sum() - 1.0) < 1e-15
+        for a in range(degree + 1):
+            for c in range(degree + 1 - a):
+                exact = 2.0 * math.factorial(a) * math.factorial(c) / math.factorial(a + c + 2)
+                assert abs((w * b[:, 1] ** a * b[:, 2] ** c).sum() - exact) < 1e-15
+    for order in range(0, 9):
+        t, w = edge_rule(order)
+        assert len(t) == max(1, (order + 2) // 2)
+        for k in range(order + 1):
+            assert abs((w * t ** k).sum() - 1.0 / (k + 1)) < 1e-15
+
+
+def test_dune_orders_follow_the_over_integrate_arguments_of_the_reference():
+    q = QuadratureSpec.dune(lambda_order=2, f_order=2, lambda_bar_order=2, lambda_hat_order=2)
+    # block_swipdg.py:405 (over_integrate=2), :409/:426 (coupling / boundary operators built without one), :519, :782,
+    # :655/:660 (products: 0), :327/:347/:369 (df products: 2)
+    assert (q.system_volume, q.system_inner_face, q.system_coupling_face, q.system_boundary_face) == (4, 6, 4, 4)
+    assert (q.rhs, q.f2, q.energy_volume, q.energy_face, q.elliptic_bar) == (5, 6, 2, 4, 2)
+    assert (q.df_aa, q.df_ab, q.df_bb, q.flux_face) == (8, 7, 6, 3)
+
+
+@pytest.mark.parametrize('quad, observed', [(QuadratureSpec.dune(), 0.815566053661),
+                                            (QuadratureSpec.uniform(5), 0.815574246425)])
+def test_oracle_reproduces_the_reference_estimate(quad, observed):
+    p = OS2015_academic_problem.init_grid_and_problem(CONFIG)
+    d = oracle_from_problem(p, quad=quad)
+    mu = p['parameter_range'][0]
+    eta = d.estimate(d.solve(mu), mu, sqrt_local=True)
+    assert abs(eta / REFERENCE_ETA - 1.0) < PIN_TOLERANCE
+    assert abs(eta - observed) < 1e-10                      # drift detector for the oracle itself
+    # mu = 0.1 is the maximum over the script's three parameters ("max discretization error")
+    assert all(d.estimate(d.solve(m), m, sqrt_local=True) < eta for m in (0.55, 1.0))
+    # the estimator as written at HEAD (no square root on the local indicators) is far away: the recorded value
+    # belongs to the square-root variant
+    assert abs(d.estimate(d.solve(mu), mu, sqrt_local=False) / REFERENCE_ETA - 1.0) > 0.5
+
+
+def test_pin_is_blind_to_the_coupling_conventions():
+    """On this configuration the two interfaces are symmetry lines of the solution: the conventions that only act on
+    coupling faces or at the cross point cannot be told apart by the reference value (they are exercised against each
+    other on unsymmetric problems in tests/test_oracle.py and tests/test_parity_gpu.py instead)."""
+    p = OS2015_academic_problem.init_grid_and_problem(CONFIG)
+    base = oracle_from_problem(p, quad=QuadratureSpec.dune())
+    eta0 = base.estimate(base.solve(0.1), 0.1, sqrt_local=True)
+    for kw in ({'accumulate_coupling_across_q': True}, {'oswald_patch': 'vertex'}):
+        d = oracle_from_problem(p, quad=QuadratureSpec.dune(), **kw)
+        assert abs(d.estimate(d.solve(0.1), 0.1, sqrt_local=True) - eta0) < 1e-11
+
+
+@pytest.mark.gpu
+def test_product_reproduces_the_reference_estimate():
+    """The same number through the product: init_grid_and_problem -> discretize -> d.solve -> d.estimate
+    (online_adaptive_lrbms.py:67-95), HIP kernels end to end."""
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    p = OS2015_academic_problem.init_grid_and_problem(CONFIG)
+    d, _ = discretize(p)
+    d.estimator = d.estimator.with_(sqrt_local=True)
+    mu = d.parse_parameter(p['parameter_range'][0])
+    eta = d.estimate(d.solve(mu), mu=mu)
+    assert abs(eta / REFERENCE_ETA - 1.0) < PIN_TOLERANCE
+    o = oracle_from_problem(p, quad=d.quadrature_spec_for_oracle()) if hasattr(d, 'quadrature_spec_for_oracle') \
+        else oracle_from_problem(p)
+    ref = o.estimate(o.solve(0.1), 0.1, sqrt_local=True)
+    assert abs(eta - ref) < 1e-9 * ref
