@@ -96,22 +96,44 @@ def _pool_reduce(chunk):
     return len(chunk)
 
 
-def cpu_baseline(N, coarse, sample_subdomains=(32, 16), repeats=1):
-    """The oracle (kind "port") timed on a bounded sample of the same workload: same synthetic problem family and
-    basis size on a smaller subdomain grid.  Only OracleReductor.reduce() -- the same region the GPU times -- is timed."""
+def host_cores():
+    """Cores this process may actually use: scheduler affinity, capped by the cgroup CPU quota when there is one."""
+    info = {'os_cpu_count': os.cpu_count()}
+    try:
+        info['affinity'] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        info['affinity'] = os.cpu_count() or 1
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            a, b = fh.read().split()[:2]
+            if a != 'max':
+                quota = max(1, int(float(a) / float(b)))
+    except (OSError, ValueError):
+        pass
+    info['cgroup_quota'] = quota
+    info['cores'] = max(1, min(info['affinity'], quota) if quota else info['affinity'])
+    return info
+
+
+def cpu_baseline(num_subdomains, N, coarse):
+    """The oracle (kind "port") timed on the SAME workload as the GPU (full subdomain grid, same basis size): only
+    OracleReductor.reduce() -- the region the GPU times -- is timed.  Runs BEFORE the process touches the GPU, so the
+    fork()ed worker pool never inherits HIP state.  All host cores the process may use."""
     from threadpoolctl import threadpool_limits
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from common import oracle_from_problem
     from oracle.lrbms import OracleReductor
     from pylrbms_amd import multiscale_problem
-    p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(sample_subdomains), 'coarse_per_subdomain': coarse})
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(num_subdomains), 'coarse_per_subdomain': coarse})
     t_asm = time.perf_counter()
     d = oracle_from_problem(p)
     t_asm = time.perf_counter() - t_asm
     d.precompute_blocks()
     V = make_bases_host(range(d.S), d.n, N)
     import multiprocessing as mp
-    cores = min(os.cpu_count() or 1, 16)
+    hc = host_cores()
+    cores = hc['cores']
     with threadpool_limits(limits=1):
         # (i) one core, the way the reference runs (single-threaded per rank, reductor.py:19 ignores num_cpus)
         t0 = time.perf_counter()
@@ -121,6 +143,7 @@ def cpu_baseline(N, coarse, sample_subdomains=(32, 16), repeats=1):
         _POOL_STATE['d'], _POOL_STATE['V'] = d, V
         chunks = [list(c) for c in np.array_split(np.arange(d.S), 4 * cores) if len(c)]
         with mp.get_context('fork').Pool(cores) as pool:
+            pool.map(_pool_reduce, chunks[:cores])                      # start-up of the workers is not timed
             t0 = time.perf_counter()
             pool.map(_pool_reduce, chunks)
             allc = d.S / (time.perf_counter() - t0)
@@ -130,18 +153,67 @@ def cpu_baseline(N, coarse, sample_subdomains=(32, 16), repeats=1):
         for ii in picks:
             d.solve_for_local_correction(ii, 0.3)
         corr = len(picks) / (time.perf_counter() - t0)
-        # parabolic path: the oracle's implicit Euler (one sparse LU, then a solve per step) on the sample
+        # parabolic path: the oracle's implicit Euler (one sparse LU, then a solve per step)
         from oracle.parabolic import OracleParabolic
         t0 = time.perf_counter()
         OracleParabolic(d, 0.05, 10).solve(0.5)
         par = 10 / (time.perf_counter() - t0)
-    return {'value': allc, 'unit': 'subdomains/s', 'cores': cores, 'kind': 'port', 'value_1core': one,
-            'assemble_subdomains_per_s_1core': d.S / t_asm, 'local_correction_solves_per_s_1core': corr,
-            'implicit_euler_steps_per_s_1core': par,
-            'sample': 'oracle.lrbms.OracleReductor.reduce() (NumPy/SciPy fp64) on {}x{} subdomains of the same synthetic '
-                      'multiscale problem, N={}, k_c={}: value = target subdomains farmed over a {}-process pool '
-                      '(1 BLAS thread each), value_1core = one process, one thread'
-                      .format(sample_subdomains[0], sample_subdomains[1], N, coarse, cores)}
+    _POOL_STATE.clear()
+    out = {'value': allc, 'unit': 'subdomains/s', 'cores': cores, 'kind': 'port', 'value_1core': one,
+           'assemble_subdomains_per_s_1core': d.S / t_asm, 'local_correction_solves_per_s_1core': corr,
+           'implicit_euler_steps_per_s_1core': par,
+           'sample': 'oracle.lrbms.OracleReductor.reduce() (NumPy/SciPy fp64) on the full {}x{} subdomains of the same '
+                     'synthetic multiscale problem, N={}, k_c={}: value = target subdomains farmed over a {}-process '
+                     'pool (1 BLAS thread each), value_1core = one process, one thread; timed before the GPU is touched'
+                     .format(num_subdomains[0], num_subdomains[1], N, coarse, cores)}
+    out.update({'os_cpu_count': hc['os_cpu_count'], 'affinity': hc['affinity'], 'cgroup_quota': hc['cgroup_quota']})
+    return out
+
+
+def kernel_model(t, N, Q, S):
+    """Compulsory HBM bytes (each input once, each output once) and executed fp64-MFMA flops (tile padding included)
+    of every kernel of the fused pass for S interior subdomains: {kernel: (bytes_read, bytes_written, mfma_flops)}.
+    Shared inputs are charged to every kernel that reads them (each launch must stream them once)."""
+    n, nrt, nT, nv, ncf = t.n, t.n_rt, t.n_T, t.n_vertices, t.ncf
+    QN = Q * N
+    nvs = max(2 * t.kx + 1, 2 * t.ky + 1)
+    ntx, nr = (N + 15) // 16, (QN + 15) // 16
+    chunks = nT // 4
+    d8 = 8
+    V_self = d8 * n * N
+    V_halo = d8 * 4 * (3 * t.ntouch) * N                    # rows of the neighbours' elements touching the shared side
+    R_self, R_side = d8 * nrt * QN, d8 * 4 * ncf * QN
+    A_self, A_side = d8 * nv * N, d8 * 4 * nvs * N
+    m = {
+        'k_flux_compact': (V_self + d8 * 4 * 3 * ncf * N + d8 * Q * nrt * 6, R_self + R_side, 0),
+        'k_vertex_avg': (V_self + V_halo, A_self + A_side, 0),
+        'k_f1': (V_self + d8 * nT * (36 * Q + 36 + Q * Q + 9 * Q) + R_self + d8 * n,
+                 d8 * (Q * N * N + 2 * N * N + Q * Q * N * N + Q * N * QN + N),
+                 (chunks * 3 * ntx * 28 + nT * 3 * ntx) * 2048),
+        'k_f2': (R_self + d8 * nT * 9 + d8 * n, d8 * (2 * QN * QN + QN), chunks * 4 * (nr * (nr + 1) // 2) * 2048),
+        'k_f3': (V_self + A_self + d8 * nT, d8 * N * N, (nT // 16) * 12 * (ntx * (ntx + 1) // 2) * 2048),
+        'k_thin_nc': (V_self + V_halo + A_self + A_side + d8 * nT, d8 * (25 * N * N - N * N), None),
+        'k_thin_rt': (R_self + R_side + d8 * nT * (9 + 9 * Q) + d8 * n, d8 * (2 * 8 * QN * QN + Q * N * 4 * QN + 4 * QN), 0),
+        'k_coupling': (V_self + V_halo + d8 * Q * 4 * ncf * 9, d8 * Q * 4 * N * N, None),
+    }
+    return {k: (r * S, w * S, (f * S if f is not None else None)) for k, (r, w, f) in m.items()}
+
+
+def load_pmc_traffic(config):
+    """Measured HBM traffic per kernel launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py writes
+    profiles/rNN_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950).  None when no profile of this configuration is on file."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+        try:
+            with open(path) as fh:
+                doc = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if doc.get('config') == config:
+            doc['file'] = os.path.relpath(path, ROOT)
+            return doc
+    return None
 
 
 def main():
@@ -154,11 +226,20 @@ def main():
     ap.add_argument('--no-online', action='store_true')
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    cfg = CONFIGS[args.config]
+    N = cfg['N']
+
+    # the CPU baseline runs first: its worker pool is fork()ed from a process that has not initialised the GPU
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg['num_subdomains'], N, cfg['coarse_per_subdomain'])
+
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before the HIP runtime is loaded (dmabuf IPC only)
+    import torch
+    import torch.distributed as dist
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node {} for --gpus {}'.format(args.gpus, args.gpus))
@@ -168,7 +249,6 @@ def main():
     local_rank = int(os.environ.get('LRBMS_BENCH_DEVICE', local_rank))
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
@@ -177,8 +257,6 @@ def main():
     from pylrbms_amd import multiscale_problem
     from pylrbms_amd.engine import Engine
     from pylrbms_amd.parallel import Communicator, HaloExchange, HaloPlan
-    cfg = CONFIGS[args.config]
-    N = cfg['N']
     comm = Communicator(rank, world)
     pcfg = {'num_subdomains': cfg['num_subdomains'], 'coarse_per_subdomain': cfg['coarse_per_subdomain']}
     p = multiscale_problem.init_grid_and_problem(pcfg, mpi_comm=comm)
@@ -253,6 +331,20 @@ def main():
         torch.cuda.synchronize()
         dense_ms = e0.elapsed_time(e1) / args.steps
         eng.project_and_estimate(V, buf)          # leave complete results in the buffers for the online section
+
+    # every kernel of the pass on its own: HIP event pairs on the stream each kernel is launched on (lrbms_kernel_timing),
+    # in a separate untimed loop of the same passes
+    kernel_ms = None
+    if world == 1 and eng.ctx.fused_supported(eng.Q, N):
+        eng.ctx.kernel_timing(True)
+        for _ in range(args.steps):
+            eng.project_and_estimate(V, buf)
+        rows = eng.ctx.kernel_timing_read()
+        eng.ctx.kernel_timing(False)
+        kernel_ms = {}
+        for name, ms in rows:
+            kernel_ms.setdefault(name, []).append(ms)
+        kernel_ms = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
 
     online = None
     if world == 1 and not args.no_online:
@@ -337,6 +429,21 @@ def main():
                      'reduced_dim': S_total * N, 'reduced_cg_iterations': rinfo['iterations'],
                      'relative_residual_max': max(finfo['relative_residual'], rinfo['relative_residual'])}
 
+    # what RCCL (or gloo) actually saw: world size, per-rank subdomain counts and halo bytes, gathered from every rank
+    dist_info = {'backend': backend if world > 1 else None, 'world_size': dist.get_world_size() if world > 1 else 1}
+    mine = [float(eng.S), float(len(eng.halo)), float(halo.send_bytes if halo is not None else 0),
+            float(halo.recv_bytes if halo is not None else 0)]
+    if world > 1:
+        gathered = [torch.zeros(4, dtype=torch.float64, device=V.device) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor(mine, dtype=torch.float64, device=V.device))
+        rows = [g.cpu().tolist() for g in gathered]
+    else:
+        rows = [mine]
+    dist_info['subdomains_per_rank'] = [int(r[0]) for r in rows]
+    dist_info['halo_subdomains_per_rank'] = [int(r[1]) for r in rows]
+    dist_info['halo_bytes_sent_per_rank_per_step'] = [int(r[2]) for r in rows]
+    dist_info['halo_bytes_received_per_rank_per_step'] = [int(r[3]) for r in rows]
+
     if rank == 0:
         Q = eng.Q
         flops = algorithmic_flops_per_subdomain(t.n, t.n_rt, t.n_T, N, Q)
@@ -344,25 +451,53 @@ def main():
         # device time of one pass on this rank's stream (HIP events on the launch stream)
         dev_s_per_step = 1e-3 * dev_ms / args.steps
         s_rank = eng.S
-        ach_tflops = flops * s_rank / dev_s_per_step / 1e12
-        ach_gbs = byts * s_rank / dev_s_per_step / 1e9
-        # Bound: the fused pass skips the structurally-zero part of the canonical GEMM count, so it runs
-        # FASTER than the canonical fp64-MFMA floor; what bounds it is HBM: every projected operator is written once
-        # (3.3 GB at config 3) and the basis / operators are read once.  `achieved` uses the ALGORITHMIC bytes of
-        # SURVEY 8(d) (8.74 MB per subdomain at config 3, intermediates W, R, D counted although the fused pass keeps
-        # them on chip, and the two big Gram operators counted dense although they are stored block-compact);
-        # `traffic` is the measured HBM traffic per pass (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes,
-        # profiles/r01_final_pmc_traffic.txt), only known for the profiled configuration.
-        traffic = None
-        if args.config == 'cfg3' and world == 1:
-            traffic = (2 * 677.6 + 1872.5) * 1024 * 1024
+        model = kernel_model(t, N, Q, s_rank)
+        # COMPULSORY bytes of the pass: every input once (basis slabs + the neighbour rows a subdomain reads, assembled
+        # operators) and every output once, in the layouts the pass actually writes (G_rdd / G_bb block-compact).  This is
+        # what the HBM roofline is priced against; the SURVEY 8(d) "algorithmic" count also charges the intermediates W, R,
+        # D and the dense form of the two big Gram operators, which the fused pass never moves -- reported separately below,
+        # it is NOT a utilisation figure (it exceeds what HBM can stream).
+        inputs = 8 * (t.n * N + 4 * 3 * t.ntouch * N + t.n_T * (36 * Q + 36 + 1 + Q * Q + 9 * Q + 9) + Q * 4 * t.ncf * 9 +
+                      Q * t.n_rt * 6 + t.n) * s_rank
+        outputs = sum(w for k, (r, w, f) in model.items() if k not in ('k_flux_compact', 'k_vertex_avg'))
+        compulsory = inputs + outputs
+        ach_gbs = compulsory / dev_s_per_step / 1e9
+        pmc = load_pmc_traffic(args.config) if world == 1 else None
+        traffic = pmc['per_pass_bytes'] if pmc else None
         roofline = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': ach_gbs / PEAK_HBM_GBS, 'traffic': traffic,
+                    'basis': 'compulsory bytes per pass (inputs once + outputs once, compact layouts) / device time of the pass',
+                    'compulsory_bytes': compulsory, 'compulsory_input_bytes': inputs, 'compulsory_output_bytes': outputs,
+                    'traffic_over_compulsory': (traffic / compulsory) if traffic else None,
+                    'traffic_frac_of_peak': (traffic / dev_s_per_step / 1e9 / PEAK_HBM_GBS) if traffic else None,
+                    'traffic_source': pmc['file'] if pmc else None,
                     'kernel': 'fused project+estimate pass: k_flux_compact, k_vertex_avg, k_f1, k_f2, k_f3, k_thin_nc, '
                               'k_thin_rt, k_coupling (HIP events around the pass on the launch stream)',
-                    'bytes_per_subdomain': byts, 'flops_per_subdomain': flops,
-                    'canonical_mfma_TFLOPs': ach_tflops, 'canonical_mfma_frac_of_fp64_peak': ach_tflops / PEAK_FP64_MFMA_TFLOPS,
-                    'device_ms_per_step': 1e3 * dev_s_per_step}
+                    'device_ms_per_step': 1e3 * dev_s_per_step,
+                    'survey_8d_algorithmic': {'bytes_per_subdomain': byts, 'flops_per_subdomain': flops,
+                                              'note': 'canonical counts of SURVEY 8(d); ~90 % of the flops are structural zeros the pass '
+                                                      'skips and the bytes include intermediates it keeps on chip: not executed, not moved',
+                                              'GBps': byts * s_rank / dev_s_per_step / 1e9,
+                                              'TFLOPs': flops * s_rank / dev_s_per_step / 1e12}}
+        if kernel_ms:
+            table = []
+            for name, ms in sorted(kernel_ms.items(), key=lambda kv: -kv[1]):
+                r, w, f = model.get(name, (None, None, None))
+                row = {'name': name, 'us': 1e3 * ms, 'bytes_read': r, 'bytes_written': w, 'mfma_flops': f}
+                if r is not None:
+                    row['hbm_GBps'] = (r + w) / (1e-3 * ms) / 1e9
+                    row['hbm_frac'] = row['hbm_GBps'] / PEAK_HBM_GBS
+                if f:
+                    row['mfma_TFLOPs'] = f / (1e-3 * ms) / 1e12
+                    row['mfma_frac'] = row['mfma_TFLOPs'] / PEAK_FP64_MFMA_TFLOPS
+                if pmc and name in pmc.get('per_kernel', {}):
+                    row['pmc_bytes'] = pmc['per_kernel'][name]['bytes']
+                table.append(row)
+            roofline['kernels'] = table
+            roofline['kernels_sum_us'] = sum(r['us'] for r in table)
+            dom = table[0]
+            roofline['dominant_kernel'] = dict(dom, bound='mfma' if dom.get('mfma_frac', 0) >= dom.get('hbm_frac', 0) else 'hbm',
+                                               frac=max(dom.get('mfma_frac', 0), dom.get('hbm_frac', 0)))
         if dense_ms is not None:
             mf = executed_mfma_flops_per_subdomain(t.n_T, N, Q) * s_rank
             roofline['dense_kernels'] = {'bound': 'mfma', 'achieved': mf / (1e-3 * dense_ms) / 1e12, 'peak': PEAK_FP64_MFMA_TFLOPS,
@@ -380,7 +515,7 @@ def main():
                                               cfg['num_subdomains'][0], cfg['num_subdomains'][1],
                                               cfg['coarse_per_subdomain'], t.n, t.n_rt, Q, N),
                           'subdomains': S_total, 'N': N, 'Q': Q, 'parallelism': 'subdomain tiles x{}'.format(world)},
-               'roofline': roofline}
+               'roofline': roofline, 'distributed': dist_info}
         out['assemble'] = {'metric': 'offline assembly K1-K6, K9 (+ flux coefficients)', 'ms': assemble_ms,
                            'value': eng.S / (1e-3 * assemble_ms), 'unit': 'subdomains/s (this rank)'}
         if online is not None:
@@ -389,8 +524,8 @@ def main():
             out['enrichment'] = enrichment
         if parabolic is not None:
             out['parabolic'] = parabolic
-        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
-            out['cpu_baseline'] = cpu_baseline(N, cfg['coarse_per_subdomain'])
+        if cpu is not None:                              # reported baseline: rank 0 at N = 1 only (timed before GPU init)
+            out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -176,6 +176,14 @@ int lrbms_project_estimate_fused(lrbms_ctx* ctx, int32_t Q, int32_t N, const dou
  * stream may land on the queue of the caller's stream and serialise behind the dense kernels). */
 void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
 
+/* Per-kernel device timing of the fused pass (measurement only; the reference has wall-clock prints around
+ * rd.solve / rd.estimate, python/scripts/linearelliptic_block_swipdg_decomp.py:67-75).  While enabled, every kernel of
+ * lrbms_project_estimate_fused(_phase) is bracketed by a HIP event pair on the stream it is launched on;
+ * lrbms_kernel_timing_read synchronises the device and returns the kernels of the passes since the last read:
+ * names (newline-separated, caller buffer of names_cap bytes), ms [cap], *count entries. */
+int lrbms_kernel_timing(lrbms_ctx* ctx, int32_t enable);
+int lrbms_kernel_timing_read(lrbms_ctx* ctx, char* names, int64_t names_cap, double* ms, int32_t cap, int32_t* count);
+
 int lrbms_project_estimate_fused_phase(lrbms_ctx* ctx, int32_t phase, int32_t Q, int32_t N, const double* V, const double* F,
                                        const double* A_diag, const double* A_cpl, const double* P_diag, const double* b,
                                        const double* ebar, const double* caa, const double* Aab, const double* Bbb, double* work,

@@ -26,6 +26,27 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def fused_assembly(force=False):
+    """gfx950 assembly of csrc/fused.hip as the product build compiles it (same flags, device side only), cached in
+    csrc/_obj/fused.s; input of pylrbms_amd._isa_check."""
+    objdir = os.path.join(CSRC, '_obj')
+    os.makedirs(objdir, exist_ok=True)
+    out = os.path.join(objdir, 'fused.s')
+    deps = [os.path.join(CSRC, 'fused.hip'), os.path.join(CSRC, 'lrbms_dev.h'), os.path.join(HERE, '..', 'include', 'lrbms_hip.h')]
+    if force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        cmd = [_hipcc()] + [f for f in FLAGS if f != '-fPIC'] + ['-S', '--cuda-device-only', os.path.join(CSRC, 'fused.hip'), '-o', out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc -S failed for fused.hip:\n{}'.format(r.stderr))
+    return out
+
+
+def check_isa(force=False):
+    """Guard of the compiler-invisible prefetch in k_f1 / k_f2 (see _isa_check.py); raises on a violation."""
+    from pylrbms_amd._isa_check import check_fused_isa
+    return check_fused_isa(fused_assembly(force=force))
+
+
 def build_native(force=False, verbose=False):
     """Compile every HIP translation unit and link the shared library.  Returns the library path."""
     if not force and not _stale():
@@ -46,8 +67,10 @@ def build_native(force=False, verbose=False):
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES) + 1, os.cpu_count() or 1)) as pool:
+        isa = pool.submit(check_isa, True)          # beside the compiles: the emitted ISA keeps the prefetch's assumptions
         objs = list(pool.map(compile_one, SOURCES))
+        isa.result()
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-L/opt/rocm/lib', '-lrocsolver', '-lrocblas']
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -1,0 +1,157 @@
+"""Build-time guard for the hand-scheduled prefetch of k_f1 / k_f2 (csrc/fused.hip).
+
+The producer waves of both kernels prefetch with inline-asm ``global_load_dwordx2`` that the compiler does not track
+and complete them with a hand-counted ``s_waitcnt vmcnt(n)``.  That is correct only while (i) the compiler emits no
+vector-memory instruction of its own (load, store, scratch spill) between issue and wait, (ii) it places no
+``s_waitcnt vmcnt`` of its own in the loop (it would either be redundant or, as ``vmcnt(0)``, undo the overlap), and
+(iii) the kernels neither spill VGPRs nor use scratch.  This module checks exactly that on the gfx950 assembly hipcc
+emits for the product build (``hipcc -S --cuda-device-only``), runs on the CPU box (no GPU needed) from
+``_build.build_native`` and from tests/test_capi_symbols.py.
+"""
+import re
+
+
+class IsaCheckError(RuntimeError):
+    pass
+
+
+def _functions(path):
+    cur, out = None, {}
+    with open(path) as fh:
+        for ln in fh:
+            m = re.match(r'^(_Z\w+):\s+; @', ln)
+            if m:
+                cur = m.group(1)
+                out[cur] = []
+                continue
+            if cur is not None:
+                if ln.startswith('.Lfunc_end'):
+                    cur = None
+                    continue
+                out[cur].append(ln.rstrip('\n'))
+    return out
+
+
+def _metadata(path):
+    """{kernel symbol: {private_segment_fixed_size, sgpr_spill_count, vgpr_spill_count, vgpr_count}} from amdhsa.kernels."""
+    out, cur = {}, None
+    pending = {}
+    with open(path) as fh:
+        for ln in fh:
+            m = re.match(r'^\s+\.name:\s+(_Z\w+)\s*$', ln)
+            if m:
+                cur = m.group(1)
+                out[cur] = dict(pending)
+                pending = {}
+                continue
+            m = re.match(r'^\s+(?:- )?\.(private_segment_fixed_size|sgpr_spill_count|vgpr_spill_count|vgpr_count|agpr_count):\s+(\d+)', ln)
+            if m:
+                key, val = m.group(1), int(m.group(2))
+                if cur is not None and key not in out[cur]:
+                    out[cur][key] = val
+                else:
+                    pending[key] = val          # keys sorted before .name belong to the NEXT kernel entry
+            if re.match(r'^\s+- \.', ln) and cur is not None and '.name' not in ln:
+                # a new list item starts: following keys belong to the next kernel until its .name arrives
+                cur = None
+                m2 = re.match(r'^\s+- \.(\w+):\s+(\d+)', ln)
+                pending = {m2.group(1): int(m2.group(2))} if m2 else {}
+    return out
+
+
+def _producer_loops(lines):
+    """Innermost loops (label ... back-branch) that contain an inline-asm global_load; returns (spans, in_asm flags)."""
+    in_asm, tags = False, []
+    for ln in lines:
+        s = ln.strip()
+        if s.startswith(';;#ASMSTART'):
+            in_asm = True
+        tags.append(in_asm)
+        if s.startswith(';;#ASMEND'):
+            in_asm = False
+    labels = {}
+    for i, ln in enumerate(lines):
+        m = re.match(r'^(\.LBB\d+_\d+):', ln)
+        if m:
+            labels[m.group(1)] = i
+    spans = []
+    for i, ln in enumerate(lines):
+        m = re.match(r'\s+s_c?branch\w*\s+(\.LBB\d+_\d+)', ln)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            a = labels[m.group(1)]
+            if any(tags[k] and 'global_load' in lines[k] for k in range(a, i + 1)):
+                spans.append((a, i))
+    inner = [s for s in spans if not any(o != s and o[0] >= s[0] and o[1] <= s[1] for o in spans)]
+    return inner, tags
+
+
+def check_fused_isa(asm_path):
+    """Raises IsaCheckError when the emitted code breaks an assumption of the asm-managed prefetch; returns a report."""
+    fns = _functions(asm_path)
+    meta = _metadata(asm_path)
+    report, problems = [], []
+    seen = 0
+    for name, lines in fns.items():
+        m = re.search(r'4k_f([12])I((?:Li\d+E)+)E', name)
+        if not m:
+            continue
+        kernel = 'k_f{}<{}>'.format(m.group(1), ','.join(re.findall(r'Li(\d+)E', m.group(2))))
+        md = meta.get(name, {})
+        # Spills: none are allowed in the instantiations the named configurations use (N <= 48).  The N = 49..64
+        # instantiation k_f1<4,..> keeps 28 accumulator tiles in its CONSUMER waves and spills 4 VGPRs around their MFMA
+        # loop; that is tolerated only while every scratch instruction sits in front of the first asm-managed load in
+        # layout order (i.e. in the consumer branch, where no untracked load is in flight).
+        spills = md.get('vgpr_spill_count', 0)
+        scratch_lines = [i for i, ln in enumerate(lines) if re.match(r'\s+scratch_', ln)]
+        in_asm = False
+        first_asm_load = None
+        for i, ln in enumerate(lines):
+            st = ln.strip()
+            if st.startswith(';;#ASMSTART'):
+                in_asm = True
+            elif st.startswith(';;#ASMEND'):
+                in_asm = False
+            elif in_asm and 'global_load' in ln:
+                first_asm_load = i
+                break
+        wide = m.group(1) == '1' and re.findall(r'Li(\d+)E', m.group(2))[0] == '4'
+        if (spills or scratch_lines or md.get('private_segment_fixed_size', 0)) and not wide:
+            problems.append('{}: scratch {} bytes, {} spilled VGPRs'.format(kernel, md.get('private_segment_fixed_size'), spills))
+        if spills > 8:
+            problems.append('{}: {} spilled VGPRs'.format(kernel, spills))
+        if scratch_lines and first_asm_load is not None and max(scratch_lines) >= first_asm_load:
+            problems.append('{}: scratch instruction behind the first asm-managed load (line {} >= {})'.format(
+                kernel, max(scratch_lines), first_asm_load))
+        uses_asm_prefetch = any(';;#ASMSTART' in ln for ln in lines) and \
+            any('global_load' in ln for ln in lines if True) and \
+            any(re.search(r'^\s+s_waitcnt vmcnt\((?!0\))\d+\)\s*$', ln) for ln in lines)
+        loops, tags = _producer_loops(lines)
+        if m.group(1) == '1' and kernel.endswith(',0>'):
+            # the generic-Q instantiation of k_f1 loads with ordinary (compiler-tracked) loads: nothing to guard
+            report.append('{}: compiler-managed loads, VGPRs {}'.format(kernel, md.get('vgpr_count')))
+            continue
+        if not loops or not uses_asm_prefetch:
+            problems.append('{}: no producer loop with asm-managed prefetch found'.format(kernel))
+            continue
+        seen += 1
+        for a, b in loops:
+            asm_waits = sorted({lines[k].strip() for k in range(a, b + 1) if tags[k] and 'vmcnt' in lines[k]})
+            counts = [int(x) for w in asm_waits for x in re.findall(r'vmcnt\((\d+)\)', w)]
+            own_waits = [lines[k].strip() for k in range(a, b + 1) if not tags[k] and re.search(r's_waitcnt.*vmcnt', lines[k])]
+            own_vmem = [lines[k].strip() for k in range(a, b + 1)
+                        if not tags[k] and re.match(r'\s+(global_|buffer_|scratch_|flat_)', lines[k])]
+            if not counts or min(counts) == 0:
+                problems.append('{}: producer loop waits {} (expected one vmcnt(n), n > 0)'.format(kernel, asm_waits))
+            if max(counts or [0]) > 63:
+                problems.append('{}: vmcnt({}) exceeds the 6-bit counter'.format(kernel, max(counts)))
+            if own_waits:
+                problems.append('{}: compiler-emitted vmcnt wait inside the producer loop: {}'.format(kernel, own_waits[:2]))
+            if own_vmem:
+                problems.append('{}: compiler-emitted vector-memory instruction inside the producer loop: {}'.format(kernel, own_vmem[:2]))
+            report.append('{}: producer loop [{}..{}] waits {}, VGPRs {}, scratch {}'.format(
+                kernel, a, b, asm_waits, md.get('vgpr_count'), md.get('private_segment_fixed_size')))
+    if seen == 0:
+        problems.append('no k_f1 / k_f2 instantiation with asm-managed prefetch found in {}'.format(asm_path))
+    if problems:
+        raise IsaCheckError('fused.hip ISA check failed:\n  ' + '\n  '.join(problems))
+    return report

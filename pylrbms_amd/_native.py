@@ -33,6 +33,9 @@ SIGNATURES = {
     'lrbms_ctx_destroy': (ctypes.c_int, [c_vp]),
     'lrbms_last_error': (ctypes.c_char_p, [c_vp]),
     'lrbms_ctx_aux_stream': (c_vp, [c_vp, c_i32]),
+    'lrbms_kernel_timing': (ctypes.c_int, [c_vp, c_i32]),
+    'lrbms_kernel_timing_read': (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), c_i32,
+                                                ctypes.POINTER(c_i32)]),
     'lrbms_mesh_upload': (ctypes.c_int, [c_vp, ctypes.POINTER(MeshDesc), c_i32, c_i32, _P_I32]),
     'lrbms_assemble_swipdg': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'lrbms_assemble_rhs': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -459,6 +462,20 @@ class NativeContext:
         rc = self.lib.lrbms_reduced_precond_use(self.handle, int(pc._lrbms_N) if pc is not None else 0,
                                                 c_vp(pc.data_ptr()) if pc is not None else None)
         self._check(rc, 'lrbms_reduced_precond_use')
+
+    def kernel_timing(self, enable):
+        """Bracket every kernel of the fused pass by HIP events on its own stream (measurement only)."""
+        self._check(self.lib.lrbms_kernel_timing(self.handle, 1 if enable else 0), 'lrbms_kernel_timing')
+
+    def kernel_timing_read(self):
+        """[(kernel name, milliseconds)] of the fused passes since the last read (synchronises the device)."""
+        cap = 256
+        names = ctypes.create_string_buffer(8192)
+        ms = (ctypes.c_double * cap)()
+        count = c_i32(0)
+        self._check(self.lib.lrbms_kernel_timing_read(self.handle, names, 8192, ms, cap, ctypes.byref(count)), 'lrbms_kernel_timing_read')
+        nm = names.value.decode().split('\n') if count.value else []
+        return [(nm[i], ms[i]) for i in range(count.value)]
 
     def aux_stream(self, i=0):
         """The i-th library-owned stream as a ``torch.cuda.ExternalStream`` (cached)."""

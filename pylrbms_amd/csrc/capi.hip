@@ -104,6 +104,10 @@ int lrbms_ctx_destroy(lrbms_ctx* ctx) {
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  for (auto& k : ctx->ktimers) {
+    if (k.e0) (void)hipEventDestroy(k.e0);
+    if (k.e1) (void)hipEventDestroy(k.e1);
+  }
   delete ctx;
   return LRBMS_OK;
 }
@@ -111,6 +115,36 @@ int lrbms_ctx_destroy(lrbms_ctx* ctx) {
 void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i) { return (ctx && i >= 0 && i < 3) ? (void*)ctx->aux[i] : nullptr; }
 
 const char* lrbms_last_error(lrbms_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int lrbms_kernel_timing(lrbms_ctx* ctx, int32_t enable) {
+  if (!ctx) return LRBMS_E_INVALID;
+  ctx->ktime = enable != 0;
+  ctx->ktime_n = 0;
+  for (auto& k : ctx->ktimers) k.used = false;
+  return LRBMS_OK;
+}
+
+int lrbms_kernel_timing_read(lrbms_ctx* ctx, char* names, int64_t names_cap, double* ms, int32_t cap, int32_t* count) {
+  if (!ctx || !names || !ms || !count || names_cap <= 0) return LRBMS_E_INVALID;
+  LRBMS_HIP_CHECK(ctx, hipDeviceSynchronize());
+  int n = 0;
+  std::string joined;
+  for (int i = 0; i < ctx->ktime_n && n < cap; ++i) {
+    const auto& k = ctx->ktimers[i];
+    if (!k.used) continue;
+    float t = 0.f;
+    LRBMS_HIP_CHECK(ctx, hipEventElapsedTime(&t, k.e0, k.e1));
+    ms[n++] = (double)t;
+    if (!joined.empty()) joined += '\n';
+    joined += k.name;
+  }
+  if ((int64_t)joined.size() + 1 > names_cap) return lrbms_fail(ctx, LRBMS_E_INVALID, "kernel_timing_read: names buffer too small");
+  memcpy(names, joined.c_str(), joined.size() + 1);
+  *count = n;
+  ctx->ktime_n = 0;          // the next pass records afresh
+  for (auto& k : ctx->ktimers) k.used = false;
+  return LRBMS_OK;
+}
 
 int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* d, int32_t S, int32_t S_ext, const int32_t* nbr) {
   if (!ctx || !d || !nbr) return LRBMS_E_INVALID;

@@ -40,6 +40,14 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// Experiment switches (tools/build_variant.sh builds A/B variants with them) change what the kernels compute or skip.
+// A product build must define none of them: a stray -D would silently produce wrong results.
+#if !defined(LRBMS_EXPERIMENT_BUILD) &&                                                                               \
+    (defined(F1_NO_STAGE) || defined(F1_NO_APPLY) || defined(F1_NO_VALU_STAGE) || defined(F1_NO_MFMA) ||             \
+     defined(F1_LDS_FILL) || defined(F1_PRODUCER_PRIO) || defined(F1_SPLIT_SIMD) || defined(F1_PF) ||                \
+     defined(F2_NO_STAGE) || defined(F2_NO_MFMA) || defined(THIN_RT_NOCOMPUTE) || defined(THIN_RT_NOSTORE))
+#error "experiment switch defined in a product build of fused.hip (use tools/build_variant.sh, which sets LRBMS_EXPERIMENT_BUILD)"
+#endif
 #ifndef F1_SPLIT_SIMD
 #define F1_SPLIT_SIMD 0
 #endif
@@ -1631,17 +1639,24 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   const char* env_streams0 = getenv("LRBMS_STREAMS");
   const bool forked = env_streams0 ? env_streams0[0] != '0' : S < 192;
   if (do_prep) {
-    hipLaunchKernelGGL(k_flux_compact, dim3(S, (t.nrt * N + 255) / 256), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
-                       phase == 0 ? 1 : 0);
+    {
+      KScope ks(ctx, "k_flux_compact", st);
+      hipLaunchKernelGGL(k_flux_compact, dim3(S, (t.nrt * N + 255) / 256), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
+                         phase == 0 ? 1 : 0);
+    }
     hipStream_t sv = st;
     if (forked) {
       sv = ctx->aux[2];
       LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
       LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(sv, ctx->ev_fork, 0));
     }
-    hipLaunchKernelGGL(k_vertex_avg, dim3(S, (t.nv * N + 255) / 256), dim3(256), 0, sv, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
-                       phase == 0 ? 1 : 0);
+    {
+      KScope ks(ctx, "k_vertex_avg", sv);
+      hipLaunchKernelGGL(k_vertex_avg, dim3(S, (t.nv * N + 255) / 256), dim3(256), 0, sv, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
+                         phase == 0 ? 1 : 0);
+    }
   } else if (do_b) {
+    KScope ks(ctx, "k_flux_side", st);
     hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)S * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
     // Avg_side is read by k_thin_nc only: k_vertex_side is launched on that kernel's stream, right in front of it
   }
@@ -1715,6 +1730,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
           hipLaunchKernelGGL(k_f1_zero, dim3(S), dim3(256), 0, st, gt[sl], S, N, sl == 0 ? a.rhs_red : nullptr);
       }
       const dim3 grid(S, nsl, ksplit);
+      KScope ks(ctx, "k_f1", st);
 #define LRBMS_F1(NTXV)                                                                                              \
   do {                                                                                                              \
     if (Q == 1 && one_slice) hipLaunchKernelGGL((k_f1<NTXV, NTY, 1>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);      \
@@ -1734,8 +1750,10 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   }
   // ---- thin parts
   if (do_b) {
-    if (!do_prep)
+    if (!do_prep) {
+      KScope ks(ctx, "k_vertex_side", side);
       hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)S * 4 * nvs * N)), dim3(256), 0, side, t, S, ctx->nbr, N, V, AvgSide);
+    }
     const int ntx = (N + 15) / 16;
     const size_t lds = thin_nc_lds_bytes(t, ntx);
     // templates with more than ~24 touching elements per side (k_c = 8: 78 KB at N = 40) need the opt-in for > 64 KB of LDS
@@ -1745,17 +1763,23 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_thin_nc<NTX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(k_thin_nc<NTX>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);    \
   } while (0)
+    {
+    KScope ks(ctx, "k_thin_nc", side);
     switch (ntx) {
       case 1: LRBMS_THIN_NC(1); break;
       case 2: LRBMS_THIN_NC(2); break;
       case 3: LRBMS_THIN_NC(3); break;
       default: LRBMS_THIN_NC(4); break;
     }
+    }
 #undef LRBMS_THIN_NC
     LRBMS_LAUNCH_CHECK(ctx);
     ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, G_bb, G_rdd, G_ab, r_fd, Q, N, S};
     const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf + 4 * t.ncf + 3 * t.ncf);   // + fco [ncf][4], fidx [ncf][5] ints
-    hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, s_rt, t, a);
+    {
+      KScope ks(ctx, "k_thin_rt", s_rt);
+      hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, s_rt, t, a);
+    }
     LRBMS_LAUNCH_CHECK(ctx);
   }
   // ---- F2
@@ -1763,6 +1787,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     F2Args a{Rself, Bbb, b, ctx->nbr, G_bb, G_rdd, r_fd, Q, N, S};
     const int nr = (QN + 15) / 16;
     const size_t ldsf2 = sizeof(double) * 4 * t.nT + sizeof(int) * 3 * t.nT;
+    KScope ks(ctx, "k_f2", s_f23);
     switch (nr) {
       case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
       case 2: hipLaunchKernelGGL(k_f2<2>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
@@ -1779,6 +1804,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   if (do_a) {
     F3Args a{V, ebar, AvgSelf, AvgSide, G_nc, N, S};
     const int ntx = (N + 15) / 16;
+    KScope ks(ctx, "k_f3", s_nc);
     switch (ntx) {
       case 1: hipLaunchKernelGGL(k_f3<1>, dim3(S), dim3(256), 0, s_nc, t, a); break;
       case 2: hipLaunchKernelGGL(k_f3<2>, dim3(S), dim3(256), 0, s_nc, t, a); break;
@@ -1790,6 +1816,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   if (do_b) {   // off-diagonal blocks of B_sys
     const int ntx = (N + 15) / 16;
     const size_t ldsc = sizeof(double) * 2 * (size_t)((3 * t.ncf + 3) & ~3) * padded_ld(ntx);
+    KScope ks(ctx, "k_coupling", s_rt);
     switch (ntx) {
       case 1: hipLaunchKernelGGL(k_coupling<1>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
       case 2: hipLaunchKernelGGL(k_coupling<2>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;

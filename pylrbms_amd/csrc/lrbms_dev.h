@@ -40,6 +40,11 @@ struct lrbms_ctx {
   void* blas = nullptr;
   double* coarse = nullptr;       // [2][S][S] + info
   long coarse_cap = 0;
+  // per-kernel device timing of the fused pass (lrbms_kernel_timing): HIP event pairs on the stream each kernel runs on
+  bool ktime = false;
+  struct KTimer { const char* name; hipEvent_t e0, e1; bool used; };
+  std::vector<KTimer> ktimers;
+  int ktime_n = 0;
   const double* user_pc = nullptr;   // prebuilt preconditioner the reduced solves use (lrbms_reduced_precond_use), caller-owned
   int user_pc_N = 0;
   std::string err;
@@ -90,6 +95,29 @@ static inline int lrbms_fail(lrbms_ctx* ctx, int code, const std::string& msg) {
   } while (0)
 
 #define LRBMS_LAUNCH_CHECK(ctx) LRBMS_HIP_CHECK(ctx, hipGetLastError())
+
+// RAII scope around one kernel launch: when timing is enabled (lrbms_kernel_timing) records an event pair on the
+// kernel's own stream; otherwise costs one branch.
+struct KScope {
+  lrbms_ctx* ctx;
+  hipStream_t st;
+  int idx;
+  KScope(lrbms_ctx* c, const char* name, hipStream_t s) : ctx(c), st(s), idx(-1) {
+    if (!c->ktime) return;
+    if (c->ktime_n == (int)c->ktimers.size()) {
+      lrbms_ctx::KTimer k{name, nullptr, nullptr, false};
+      if (hipEventCreate(&k.e0) != hipSuccess || hipEventCreate(&k.e1) != hipSuccess) return;
+      c->ktimers.push_back(k);
+    }
+    idx = c->ktime_n++;
+    c->ktimers[idx].name = name;
+    c->ktimers[idx].used = true;
+    (void)hipEventRecord(c->ktimers[idx].e0, st);
+  }
+  ~KScope() {
+    if (idx >= 0) (void)hipEventRecord(ctx->ktimers[idx].e1, st);
+  }
+};
 
 int build_template_tables(lrbms_ctx* ctx);
 // dense coarse level of the Krylov preconditioners (online.hip)

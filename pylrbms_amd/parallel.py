@@ -130,10 +130,14 @@ class HaloExchange:
     config 3 this is 1.3 MB per rank instead of the 10 MB an all-gather delivers to everyone).
     ``mode='allgather'`` (or env ``LRBMS_HALO=allgather``): the same rows through one ``all_gather_into_tensor``."""
 
-    def __init__(self, plan, N, device, dtype=None, group=None, mode=None):
+    def __init__(self, plan, N, device, dtype=None, group=None, mode=None, loopback=False):
+        """``loopback=True`` (alltoall mode, test use): run the collective on a one-rank process group, every packed row
+        sent to the rank itself and unpacked into its halo slabs -- exercises the asynchronous collective, its stream
+        semantics and pack / unpack on a single GPU (needs as many packed rows as halo rows: symmetric tiles)."""
         import os
         import torch
         self.torch, self.plan, self.group = torch, plan, group
+        self.loopback = bool(loopback)
         self.mode = mode or os.environ.get('LRBMS_HALO', 'alltoall')
         if self.mode not in ('alltoall', 'allgather'):
             raise ValueError('halo mode must be alltoall or allgather')
@@ -150,6 +154,17 @@ class HaloExchange:
             self.pack_index = torch.from_numpy(plan.a2a_pack_index).to(device)
             self.unpack_dst = torch.from_numpy(plan.a2a_unpack_dst).to(device)
         self.count = len(self.pack_index)
+        if self.loopback and (self.mode != 'alltoall' or self.send.shape != self.recv.shape):
+            raise ValueError('loopback needs alltoall mode and equally many packed and halo rows')
+
+    @property
+    def send_bytes(self):
+        """Bytes this rank hands to the collective per exchange."""
+        return int(self.send.numel() * self.send.element_size())
+
+    @property
+    def recv_bytes(self):
+        return int(self.recv.numel() * self.recv.element_size())
 
     def start(self, V):
         """Pack and launch the collective asynchronously; returns ``finish()``, which makes the current stream wait for
@@ -157,7 +172,7 @@ class HaloExchange:
         may read the LOCAL slabs of V only (the halo slabs are written by ``finish``)."""
         import torch.distributed as dist
         torch = self.torch
-        if self.plan.world_size == 1:
+        if self.plan.world_size == 1 and not self.loopback:
             return lambda: V
         flat = V.view(-1, V.shape[2])
         if self.count:
@@ -168,8 +183,12 @@ class HaloExchange:
         if self.mode == 'allgather':
             work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
         else:
-            work = dist.all_to_all_single(recv, send, output_split_sizes=self.plan.a2a_recv_splits,
-                                          input_split_sizes=self.plan.a2a_send_splits, group=self.group, async_op=True)
+            if self.loopback:
+                out_splits = in_splits = [int(send.shape[0])]
+            else:
+                out_splits, in_splits = self.plan.a2a_recv_splits, self.plan.a2a_send_splits
+            work = dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits,
+                                          group=self.group, async_op=True)
 
         def finish():
             work.wait()          # device-side wait on the current stream for RCCL; blocking for gloo

@@ -55,3 +55,22 @@ def test_product_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def test_emitted_isa_keeps_the_assumptions_of_the_asm_managed_prefetch():
+    """k_f1 / k_f2 prefetch with inline-asm loads the compiler does not track (csrc/fused.hip): the gfx950 assembly of the
+    product build must show, in every producer loop, the hand-counted ``s_waitcnt vmcnt(n)`` (n > 0), no vmcnt wait and no
+    vector-memory instruction of the compiler's own, and no spill in the instantiations the named configurations use
+    (pylrbms_amd/_isa_check.py; cross-compiles on the CPU box)."""
+    from pylrbms_amd._build import check_isa
+    report = check_isa()
+    assert any(r.startswith('k_f1<3,7,2>') and "vmcnt(19)" in r for r in report), report      # config 3: N = 40, Q = 2
+    assert any(r.startswith('k_f2<5>') and "vmcnt(7)" in r for r in report), report
+
+
+def test_experiment_switches_are_refused_in_a_product_build(tmp_path):
+    import subprocess
+    from pylrbms_amd._build import CSRC, FLAGS, _hipcc
+    cmd = [_hipcc()] + FLAGS + ['-DF1_NO_MFMA', '-fsyntax-only', '--cuda-host-only', os.path.join(CSRC, 'fused.hip')]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode != 0 and 'experiment switch defined in a product build' in r.stderr

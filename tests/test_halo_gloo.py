@@ -106,3 +106,51 @@ def test_alltoall_plan_is_consistent_across_ranks():
             assert plans[a].a2a_send_splits[b] == plans[b].a2a_recv_splits[a]
         # point-to-point volume is far below the all-gather volume
         assert sum(plans[a].a2a_recv_splits) < plans[a].max_rows * (world - 1)
+
+
+def _loopback_case(device, backend, port):
+    """One rank, the plan of rank 0 of a two-tile partition: every packed row goes through the asynchronous
+    all_to_all to the rank itself and lands in the halo slabs (the collective branch of HaloExchange.start / finish)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    kw = {'device_id': torch.device(device)} if backend == 'nccl' else {}
+    dist.init_process_group(backend, rank=0, world_size=1, **kw)
+    try:
+        mk = lambda r: DDSubdomainsGrid([0, 0], [1, 1], (P[0] * KC, P[1] * KC), P, rank=r, world_size=2)  # noqa: E731
+        grid = mk(0)
+        plan = HaloPlan(mk, 2, 0)
+        local = grid.subdomains_on_rank
+        halo = sorted({j for s in local for j in grid.neighboring_subdomains(s)} - set(local))
+        Vg = _global_V(grid)
+        V = torch.full((len(local) + len(halo), grid.template.n, N), float('nan'), dtype=torch.float64, device=device)
+        V[:len(local)] = torch.from_numpy(Vg[local]).to(device)
+        hx = HaloExchange(plan, N, V.device, loopback=True)
+        assert hx.send_bytes == hx.recv_bytes == 8 * N * len(plan.a2a_pack_index) > 0
+        finish = hx.start(V)
+        # work enqueued between start and finish may only touch the local slabs (it overlaps with the collective)
+        checksum = V[:len(local)].sum()
+        finish()
+        flat = V.view(-1, N)
+        sent = flat[torch.from_numpy(plan.a2a_pack_index).to(device)]
+        got = flat[torch.from_numpy(plan.a2a_unpack_dst).to(device)]
+        assert torch.equal(sent, got)                                    # every halo row the kernels read was delivered
+        assert torch.isfinite(checksum)
+        assert torch.equal(V[:len(local)].cpu(), torch.from_numpy(Vg[local]))
+        # second exchange on the same buffers (steady state of bench.py's loop)
+        V[len(local):] = float('nan')
+        hx(V)
+        assert torch.equal(flat[torch.from_numpy(plan.a2a_unpack_dst).to(device)], sent)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_branch_runs_on_one_rank_gloo():
+    _loopback_case('cpu', 'gloo', 29700 + (os.getpid() % 100))
+
+
+@pytest.mark.gpu
+def test_collective_branch_runs_on_one_rank_rccl():
+    """The same under the nccl (= RCCL) backend on one MI355X: the asynchronous all_to_all_single with split sizes, its
+    work.wait() as a device-side wait on the current stream, pack / unpack on the GPU -- the branch the 8-GPU run takes,
+    exercised once without an 8-GPU node (world_size 1: RCCL's self exchange)."""
+    _loopback_case('cuda:0', 'nccl', 29800 + (os.getpid() % 100))

@@ -31,6 +31,28 @@ def _bases(S, n):
     return rng.standard_normal((S, n, N))
 
 
+def _put(outdir, rank, value):
+    """Workers hand their results back through files: the parent has initialised the GPU, so it must not fork() a
+    manager process (mp.Manager() does); mp.spawn starts the workers with the 'spawn' method."""
+    import pickle
+    with open(os.path.join(outdir, 'result_{}.pkl'.format(rank)), 'wb') as fh:
+        pickle.dump(value, fh)
+
+
+def _spawn_and_collect(fn, args, world, tmp_path):
+    import pickle
+    outdir = str(tmp_path / 'results')
+    os.makedirs(outdir, exist_ok=True)
+    mp.spawn(fn, args=tuple(args) + (outdir,), nprocs=world, join=True)
+    out = {}
+    for r in range(world):
+        path = os.path.join(outdir, 'result_{}.pkl'.format(r))
+        if os.path.exists(path):
+            with open(path, 'rb') as fh:
+                out[r] = pickle.load(fh)
+    return out
+
+
 def _worker(rank, world, port, ref_path, results):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -110,7 +132,7 @@ def _worker(rank, world, port, ref_path, results):
         ub = rd.solve_batch([0.9, 0.4, 0.15]).tensor.cpu().numpy()
         ok &= bool(ub.shape == (d.engine.S, Vg.shape[2], 3))
         ok &= bool(np.abs(ub[:, :, 1] - u_loc).max() < 1e-9 * np.abs(u_loc).max())
-        results[rank] = (ok, max(worst, err_u), d.engine.S, d.engine.S_ext)
+        _put(results, rank, (ok, max(worst, err_u), d.engine.S, d.engine.S_ext))
     finally:
         dist.destroy_process_group()
 
@@ -132,9 +154,7 @@ def test_sharded_projection_matches_single_rank(world, tmp_path):
     del eng, buf, V
     torch.cuda.empty_cache()
     port = 29500 + 2 * (os.getpid() % 100) + world        # disjoint port ranges per test of this file
-    mgr = mp.Manager()
-    results = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ref_path, results), nprocs=world, join=True)
+    results = _spawn_and_collect(_worker, (world, port, ref_path), world, tmp_path)
     assert len(results) == world
     for r in range(world):
         ok, worst, S, S_ext = results[r]
@@ -185,12 +205,12 @@ def _enrich_worker(rank, world, port, results):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from pylrbms_amd.parallel import Communicator
-        results[rank] = _enrichment_run(_problem(Communicator(rank, world)), Communicator(rank, world))
+        _put(results, rank, _enrichment_run(_problem(Communicator(rank, world)), Communicator(rank, world)))
     finally:
         dist.destroy_process_group()
 
 
-def test_adaptive_enrichment_on_a_sharded_discretization():
+def test_adaptive_enrichment_on_a_sharded_discretization(tmp_path):
     """Online enrichment across ranks: global Doerfler / age marking from all-gathered indicators, every rank solves the
     corrector problems of its own marked subdomains (operator blocks of the halo assembled on the rank), ragged bases
     padded to the global width for the halo exchange -- same estimates and local basis sizes as the single-rank run."""
@@ -200,9 +220,7 @@ def test_adaptive_enrichment_on_a_sharded_discretization():
     torch.cuda.empty_cache()
     world = 2
     port = 29300 + (os.getpid() % 150)
-    mgr = mp.Manager()
-    results = mgr.dict()
-    mp.spawn(_enrich_worker, args=(world, port, results), nprocs=world, join=True)
+    results = _spawn_and_collect(_enrich_worker, (world, port), world, tmp_path)
     sizes = {}
     for r in range(world):
         eta, loc, log = results[r]
@@ -231,21 +249,19 @@ def _parabolic_worker(rank, world, port, results):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from pylrbms_amd.parallel import Communicator
-        results[rank] = _parabolic_run(_problem(Communicator(rank, world)), Communicator(rank, world))
+        _put(results, rank, _parabolic_run(_problem(Communicator(rank, world)), Communicator(rank, world)))
     finally:
         dist.destroy_process_group()
 
 
-def test_parabolic_solves_on_a_sharded_discretization():
+def test_parabolic_solves_on_a_sharded_discretization(tmp_path):
     """Full-order and reduced implicit Euler trajectories on two ranks (gathered operators, native solvers on every rank)
     and their parabolic estimates equal the single-rank ones."""
     U1, R1, est1 = _parabolic_run(_problem())
     torch.cuda.empty_cache()
     world = 2
     port = 29100 + (os.getpid() % 150)
-    mgr = mp.Manager()
-    results = mgr.dict()
-    mp.spawn(_parabolic_worker, args=(world, port, results), nprocs=world, join=True)
+    results = _spawn_and_collect(_parabolic_worker, (world, port), world, tmp_path)
     seen = 0
     for r in range(world):
         U, R, est = results[r]

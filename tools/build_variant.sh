@@ -6,7 +6,7 @@ NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 python3 -c "import sys; sys.path.insert(0, '$ROOT'); from pylrbms_amd._build import build_native; build_native()"
 mkdir -p $ROOT/pylrbms_amd/_variants /tmp/var_$NAME
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -I$ROOT/pylrbms_amd/csrc -c ${SRC:-$ROOT/pylrbms_amd/csrc/fused.hip} -o /tmp/var_$NAME/fused.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DLRBMS_EXPERIMENT_BUILD "$@" -I$ROOT/pylrbms_amd/csrc -c ${SRC:-$ROOT/pylrbms_amd/csrc/fused.hip} -o /tmp/var_$NAME/fused.o
 OBJS=""
 for f in capi assemble apply gemm online enrich fom; do OBJS="$OBJS $ROOT/pylrbms_amd/csrc/_obj/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/pylrbms_amd/_variants/$NAME.so $OBJS /tmp/var_$NAME/fused.o -L/opt/rocm/lib -lrocsolver -lrocblas

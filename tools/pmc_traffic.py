@@ -1,15 +1,21 @@
-"""Sum FETCH_SIZE / WRITE_SIZE (rocprofv3 --pmc, KiB units) over the kernels of the passes of bench.py.
-usage: pmc_traffic.py NUM_PASSES DIR [DIR...]   (NUM_PASSES is ignored: per-call averages are summed)"""
+"""Sum FETCH_SIZE / WRITE_SIZE (rocprofv3 --pmc, KiB units, separate passes) over the kernels of bench.py's passes.
+
+usage: pmc_traffic.py CONFIG OUT.json DIR [DIR...]
+
+Prints the per-kernel table and writes OUT.json = {config, per_kernel: {name: {fetch_bytes_raw, write_bytes, bytes}},
+per_pass_bytes}, which bench.py loads as ``roofline.traffic``.  FETCH_SIZE is doubled as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (the counter tallies 128-B requests at 64 B)."""
 import collections
 import csv
 import glob
+import json
 import re
 import sys
 
-passes = int(sys.argv[1])
+config, out_json = sys.argv[1], sys.argv[2]
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.Counter()
-for d in sys.argv[2:]:
+for d in sys.argv[3:]:
     f = glob.glob(d + '/*/*counter_collection.csv')[0]
     for r in csv.DictReader(open(f)):
         m = re.search(r'(k_[a-z0-9_]+)', r['Kernel_Name'])
@@ -20,6 +26,7 @@ for d in sys.argv[2:]:
 print('{:24s} {:>6s} {:>18s} {:>18s}'.format('kernel', 'calls', 'FETCH_SIZE MiB/call', 'WRITE_SIZE MiB/call'))
 sf = sw = 0.0
 PASS_KERNELS = ('k_flux_compact', 'k_vertex_avg', 'k_f1', 'k_f2', 'k_f3', 'k_thin_nc', 'k_thin_rt', 'k_coupling', 'k_project_coupling')
+per_kernel = {}
 for k, v in sorted(tot.items()):
     nf, nw = calls[(k, 'FETCH_SIZE')], calls[(k, 'WRITE_SIZE')]
     f = v.get('FETCH_SIZE', 0.0) / nf / 1024 if nf else 0.0
@@ -28,5 +35,11 @@ for k, v in sorted(tot.items()):
     if k in PASS_KERNELS:        # one call of each per pass: sum the per-call averages (bench.py also times phase 4 alone)
         sf += f
         sw += w
+        per_kernel[k] = {'fetch_bytes_raw': f * 2 ** 20, 'write_bytes': w * 2 ** 20, 'bytes': (2 * f + w) * 2 ** 20}
 print('per pass (hot-path kernels): FETCH_SIZE {:.1f} MiB (x2 correction for wide coalesced reads on gfx950: {:.1f} MiB), '
       'WRITE_SIZE {:.1f} MiB'.format(sf, 2 * sf, sw))
+with open(out_json, 'w') as fh:
+    json.dump({'config': config, 'per_kernel': per_kernel, 'per_pass_bytes': (2 * sf + sw) * 2 ** 20,
+               'fetch_correction': 'FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported',
+               'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py'}, fh,
+              indent=1)
