@@ -193,7 +193,8 @@ def kernel_model(t, N, Q, S):
         'k_f2': (R_self + d8 * nT * 9 + d8 * n, d8 * (2 * QN * QN + QN), chunks * 4 * (nr * (nr + 1) // 2) * 2048),
         'k_f3': (V_self + A_self + d8 * nT, d8 * N * N, (nT // 16) * 12 * (ntx * (ntx + 1) // 2) * 2048),
         'k_thin_nc': (V_self + V_halo + A_self + A_side + d8 * nT, d8 * (25 * N * N - N * N), None),
-        'k_thin_rt': (R_self + R_side + d8 * nT * (9 + 9 * Q) + d8 * n, d8 * (2 * 8 * QN * QN + Q * N * 4 * QN + 4 * QN), 0),
+        # factored layout (default): the side blocks of G_bb / G_rdd / G_ab leave the chip as their rank-<=ncf factors
+        'k_thin_rt': (R_self + R_side + d8 * nT * (9 + 9 * Q) + d8 * n, d8 * (4 * ncf * (4 * QN + 4) + 4 * QN), 0),
         'k_coupling': (V_self + V_halo + d8 * Q * 4 * ncf * 9, d8 * Q * 4 * N * N, None),
     }
     return {k: (r * S, w * S, (f * S if f is not None else None)) for k, (r, w, f) in m.items()}

@@ -190,6 +190,35 @@ int lrbms_project_estimate_fused_phase(lrbms_ctx* ctx, int32_t phase, int32_t Q,
                                        double* B_sys, double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd,
                                        double* G_rdd, double* G_bb, double* G_ab, double* G_aa, void* stream);
 
+/* FACTORED layout of the projected estimator operators (default of the Python host side).  The image of a neighbour's
+ * basis on the target subdomain lives on the <= ncf side faces only, so every block of df_bb_i, r_dd_i, df_ab_i
+ * (discretize_elliptic_block_swipdg.py:747,762-770) that involves a neighbour slot a has rank <= ncf.  Instead of the
+ * dense side blocks (205 KB per side at config 3: 1 GB of writes per pass and of reads per estimate) the pass returns
+ *   G_rdd_self, G_bb_self [S][QN][QN]   the [self, self] blocks,       G_ab_self [Q][S][N][QN]   the self columns,
+ *   F_side [S][4][ncf][4 QN + 4]         one row per side face p:  Ra | Yb | Dp | Xab (q, i) | sc0 sc1 sc2 0  with
+ *       G_bb[a, self] = Ra^T Yb    G_bb[a, a]  = Ra^T diag(sc0) Ra    G_ab^q[:, a] = Xab_q^T Ra
+ *       G_rdd[a, self] = Ra^T Dp   G_rdd[a, a] = Ra^T diag(sc1) Ra    r_fd[a] = sc2^T Ra  (r_fd itself stays dense [S][5QN])
+ * (the reference keeps such operators as BlockOperators whose missing blocks are None, block_swipdg.py:336-338: a
+ * factored block is the same idea one step further).  lrbms_fside_size: doubles of F_side.  `phase` as in
+ * lrbms_project_estimate_fused_phase (0 = whole pass).  The dense entry points above produce the same blocks from the
+ * same factors; tests compare both. */
+int64_t lrbms_fside_size(lrbms_ctx* ctx, int32_t Q, int32_t N);
+int lrbms_project_estimate_fused_factored(lrbms_ctx* ctx, int32_t phase, int32_t Q, int32_t N, const double* V, const double* F,
+                                          const double* A_diag, const double* A_cpl, const double* P_diag, const double* b,
+                                          const double* ebar, const double* caa, const double* Aab, const double* Bbb, double* work,
+                                          double* B_sys, double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd,
+                                          double* G_rdd_self, double* G_bb_self, double* G_ab_self, double* G_aa, double* F_side,
+                                          void* stream);
+/* E1 on the factored layout (same arguments otherwise as lrbms_reduced_estimate / _batch). */
+int lrbms_reduced_estimate_factored(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u, const double* G_nc,
+                                    const double* r_fd, const double* G_rdd_self, const double* G_bb_self, const double* G_ab_self,
+                                    const double* G_aa, const double* F_side, const double* f2, const double* ceps, double hdiam,
+                                    double* eta_loc, void* stream);
+int lrbms_reduced_estimate_batch_factored(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* u,
+                                          const double* G_nc, const double* r_fd, const double* G_rdd_self, const double* G_bb_self,
+                                          const double* G_ab_self, const double* G_aa, const double* F_side, const double* f2,
+                                          const double* ceps, double hdiam, double* eta_loc, void* stream);
+
 /* -- online --------------------------------------------------------------------------------------------- */
 /* E1: EstimatorBase._estimate_elliptic on reduced coefficients (estimators.py:45-112), per-subdomain part.
  *   theta [Q] host; u [S_ext][N]; f2, ceps [S]; hdiam scalar

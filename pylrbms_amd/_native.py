@@ -50,6 +50,10 @@ SIGNATURES = {
     'lrbms_fused_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_project_estimate_fused': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 22),
     'lrbms_project_estimate_fused_phase': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32] + [c_vp] * 22),
+    'lrbms_fside_size': (c_i64, [c_vp, c_i32, c_i32]),
+    'lrbms_project_estimate_fused_factored': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32] + [c_vp] * 23),
+    'lrbms_reduced_estimate_factored': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 10 + [c_dbl, c_vp, c_vp]),
+    'lrbms_reduced_estimate_batch_factored': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL] + [c_vp] * 10 + [c_dbl, c_vp, c_vp]),
     'lrbms_reduced_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 9 + [c_dbl, c_vp, c_vp]),
     'lrbms_reduced_estimate_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL] + [c_vp] * 9 + [c_dbl, c_vp, c_vp]),
     'lrbms_reduced_solve_work_size': (c_i64, [c_vp, c_i32]),
@@ -323,6 +327,24 @@ class NativeContext:
             raise NativeError('lrbms_fused_work_size failed')
         return int(sz)
 
+    def fside_ld(self, Q, N):
+        return 4 * Q * N + 4
+
+    def _gram_ptrs(self, grams, Q, N):
+        """Pointers of the projected estimator operators in either layout: 6 tensors = dense (G_rdd / G_bb block-compact
+        [S, 9, QN, QN], G_ab [Q, S, N, 5QN]); 7 tensors = factored (self parts [S, QN, QN] / [Q, S, N, QN] + F_side
+        [S, 4, ncf, 4QN + 4], include/lrbms_hip.h).  Returns (pointer list, factored flag)."""
+        S, W, C, QN = self.S, 5 * N, 5 * Q * N, Q * N
+        if len(grams) == 7:
+            G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, Fs = grams
+            return [self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, QN, QN), 'G_rdd_self'),
+                    self._ptr(G_bb, (S, QN, QN), 'G_bb_self'), self._ptr(G_ab, (Q, S, N, QN), 'G_ab_self'),
+                    self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._ptr(Fs, (S, 4, self.ncf, self.fside_ld(Q, N)), 'F_side')], True
+        G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = grams
+        return [self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, QN, QN), 'G_rdd'),
+                self._ptr(G_bb, (S, 9, QN, QN), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
+                self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa')], False
+
     def project_estimate_fused(self, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, sys_out, gram_out, phase=0):
         """phase 0: the whole pass; 1 / 2: its halo-independent / halo-dependent halves (lrbms_project_estimate_fused_phase)."""
         Q, N, S = A_diag.shape[0], V.shape[2], self.S
@@ -330,18 +352,16 @@ class NativeContext:
         if work.numel() < self.fused_work_size(Q, N):
             raise NativeError('project_estimate_fused: work too small')
         B_sys, rhs_red, E_red, M_red = sys_out
-        G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = gram_out
-        rc = self.lib.lrbms_project_estimate_fused_phase(
+        gptrs, factored = self._gram_ptrs(gram_out, Q, N)
+        fn = self.lib.lrbms_project_estimate_fused_factored if factored else self.lib.lrbms_project_estimate_fused_phase
+        rc = fn(
             self.handle, int(phase), Q, N, self._ptr(V, (self.S_ext, self.n, N), 'V'), self._ptr(F, (Q, S, self.n_rt, 6), 'F'),
             self._ptr(A_diag, (Q, S, self.n_T, 4, 9), 'A_diag'), self._ptr(A_cpl, (Q, S, 4, self.ncf, 9), 'A_cpl'),
             self._ptr(P_diag, (S, self.n_T, 4, 9), 'P_diag'), self._ptr(b, (S, self.n), 'b'),
             self._ptr(ebar, (S, self.n_T), 'ebar'), self._ptr(caa, (Q, Q, S, self.n_T), 'caa'),
             self._ptr(Aab, (Q, S, self.n_T, 3, 3), 'Aab'), self._ptr(Bbb, (S, self.n_T, 3, 3), 'Bbb'),
             c_vp(work.data_ptr()), self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'), self._ptr(rhs_red, (S, N), 'rhs_red'),
-            self._ptr(E_red, (S, N, N), 'E_red'), self._ptr(M_red, (S, N, N), 'M_red'),
-            self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, Q * N, Q * N), 'G_rdd'),
-            self._ptr(G_bb, (S, 9, Q * N, Q * N), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
-            self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._stream())
+            self._ptr(E_red, (S, N, N), 'E_red'), self._ptr(M_red, (S, N, N), 'M_red'), *gptrs, self._stream())
         self._check(rc, 'lrbms_project_estimate_fused_phase')
 
     def bind_project_estimate_fused(self, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, sys_out, gram_out):
@@ -353,19 +373,17 @@ class NativeContext:
         if work.numel() < self.fused_work_size(Q, N):
             raise NativeError('project_estimate_fused: work too small')
         B_sys, rhs_red, E_red, M_red = sys_out
-        G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = gram_out
+        gptrs, factored = self._gram_ptrs(gram_out, Q, N)
         ptrs = (self._ptr(V, (self.S_ext, self.n, N), 'V'), self._ptr(F, (Q, S, self.n_rt, 6), 'F'),
                 self._ptr(A_diag, (Q, S, self.n_T, 4, 9), 'A_diag'), self._ptr(A_cpl, (Q, S, 4, self.ncf, 9), 'A_cpl'),
                 self._ptr(P_diag, (S, self.n_T, 4, 9), 'P_diag'), self._ptr(b, (S, self.n), 'b'),
                 self._ptr(ebar, (S, self.n_T), 'ebar'), self._ptr(caa, (Q, Q, S, self.n_T), 'caa'),
                 self._ptr(Aab, (Q, S, self.n_T, 3, 3), 'Aab'), self._ptr(Bbb, (S, self.n_T, 3, 3), 'Bbb'),
                 c_vp(work.data_ptr()), self._ptr(B_sys, (Q, S, 5, N, N), 'B_sys'), self._ptr(rhs_red, (S, N), 'rhs_red'),
-                self._ptr(E_red, (S, N, N), 'E_red'), self._ptr(M_red, (S, N, N), 'M_red'),
-                self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, Q * N, Q * N), 'G_rdd'),
-                self._ptr(G_bb, (S, 9, Q * N, Q * N), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
-                self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'))
+                self._ptr(E_red, (S, N, N), 'E_red'), self._ptr(M_red, (S, N, N), 'M_red')) + tuple(gptrs)
         keep = (V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, sys_out, gram_out)
-        fn, handle, cur, dev = self.lib.lrbms_project_estimate_fused_phase, self.handle, self.torch.cuda.current_stream, self.device
+        fn = self.lib.lrbms_project_estimate_fused_factored if factored else self.lib.lrbms_project_estimate_fused_phase
+        handle, cur, dev = self.handle, self.torch.cuda.current_stream, self.device
 
         def run(phase=0, _keep=keep):
             rc = fn(handle, phase, Q, N, *ptrs, c_vp(cur(dev).cuda_stream))
@@ -375,35 +393,28 @@ class NativeContext:
 
     # ------------------------------------------------------------------ online
     def reduced_estimate(self, theta, u, grams, f2, ceps, hdiam):
-        G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = grams
-        Q, S, N = G_ab.shape[0], self.S, G_ab.shape[2]
-        W, C = 5 * N, 5 * Q * N
+        Q, S, N = grams[4].shape[0], self.S, grams[4].shape[2]
         th = np.ascontiguousarray(theta, dtype=np.float64)
         assert th.shape == (Q,)
         eta = self.empty(3, S)
-        rc = self.lib.lrbms_reduced_estimate(
-            self.handle, Q, N, _dblp(th), self._ptr(u, (self.S_ext, N), 'u'), self._ptr(G_nc, (S, W, W), 'G_nc'),
-            self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, Q * N, Q * N), 'G_rdd'), self._ptr(G_bb, (S, 9, Q * N, Q * N), 'G_bb'),
-            self._ptr(G_ab, (Q, S, N, C), 'G_ab'), self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._ptr(f2, (S,), 'f2'),
-            self._ptr(ceps, (S,), 'ceps'), float(hdiam), c_vp(eta.data_ptr()), self._stream())
+        gptrs, factored = self._gram_ptrs(grams, Q, N)
+        fn = self.lib.lrbms_reduced_estimate_factored if factored else self.lib.lrbms_reduced_estimate
+        rc = fn(self.handle, Q, N, _dblp(th), self._ptr(u, (self.S_ext, N), 'u'), *gptrs, self._ptr(f2, (S,), 'f2'),
+                self._ptr(ceps, (S,), 'ceps'), float(hdiam), c_vp(eta.data_ptr()), self._stream())
         self._check(rc, 'lrbms_reduced_estimate')
         return eta
 
     def reduced_estimate_batch(self, thetas, u, grams, f2, ceps, hdiam):
         """thetas [nmu, Q], u [S_ext, N, nmu] -> eta_loc [3, S, nmu]."""
-        G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = grams
-        Q, S, N = G_ab.shape[0], self.S, G_ab.shape[2]
-        W, C = 5 * N, 5 * Q * N
+        Q, S, N = grams[4].shape[0], self.S, grams[4].shape[2]
         th = np.ascontiguousarray(thetas, dtype=np.float64)
         nmu = th.shape[0]
         assert th.shape == (nmu, Q)
         eta = self.empty(3, S, nmu)
-        rc = self.lib.lrbms_reduced_estimate_batch(
-            self.handle, Q, N, nmu, _dblp(th), self._ptr(u, (self.S_ext, N, nmu), 'u'), self._ptr(G_nc, (S, W, W), 'G_nc'),
-            self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, Q * N, Q * N), 'G_rdd'),
-            self._ptr(G_bb, (S, 9, Q * N, Q * N), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),
-            self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._ptr(f2, (S,), 'f2'), self._ptr(ceps, (S,), 'ceps'), float(hdiam),
-            c_vp(eta.data_ptr()), self._stream())
+        gptrs, factored = self._gram_ptrs(grams, Q, N)
+        fn = self.lib.lrbms_reduced_estimate_batch_factored if factored else self.lib.lrbms_reduced_estimate_batch
+        rc = fn(self.handle, Q, N, nmu, _dblp(th), self._ptr(u, (self.S_ext, N, nmu), 'u'), *gptrs, self._ptr(f2, (S,), 'f2'),
+                self._ptr(ceps, (S,), 'ceps'), float(hdiam), c_vp(eta.data_ptr()), self._stream())
         self._check(rc, 'lrbms_reduced_estimate_batch')
         return eta
 

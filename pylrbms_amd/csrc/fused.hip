@@ -783,6 +783,7 @@ struct F2Args {
   const int* nbr;
   double *G_bb, *G_rdd, *r_fd;
   int Q, N, S;
+  long gstride;   // doubles between the self blocks of consecutive subdomains: 9 QN^2 (block-compact) or QN^2 (factored)
 };
 
 // Same producer / consumer structure as k_f1: waves 0-3 stage the face rows R~_T, B_T R~_T, d_T, |T| d_T of element
@@ -942,8 +943,8 @@ __global__ __launch_bounds__(64 * (F2_NCW + EC)) void k_f2(Tmpl t, F2Args a) {
       }
     }
     lds_barrier();                                 // final barrier
-    double* gb = a.G_bb + (long)s * 9 * QN * QN;            // block 0 = [self, self] of the block-compact layout
-    double* gd = a.G_rdd + (long)s * 9 * QN * QN;
+    double* gb = a.G_bb + (long)s * a.gstride;              // [self, self]: block 0 of the block-compact layout
+    double* gd = a.G_rdd + (long)s * a.gstride;
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
       if (ti[k] < 0) continue;
@@ -1250,47 +1251,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Thin part of G_bb / G_rdd / G_ab / r_fd for side a: rank-ncf updates from the side faces.
+// Thin part of G_bb / G_rdd / G_ab / r_fd for side a.  The image of neighbour a's basis on the target subdomain lives
+// on the np <= ncf side faces only, so every block of these operators that involves slot a is a rank-<=np product of the
+// FACTORS built here, one row per side face p (T = the element of face p, f_p its local face):
+//   Ra [p][QN]    flux image of the neighbour on face p                    (= R_side)
+//   Yb [p][QN]    (B_T R~_self)[f_p]            G_bb[a, self] = Ra^T Yb,   G_bb[a, a]  = Ra^T diag(B_T[f_p][f_p]) Ra
+//   Dp [p][QN]    |T| c_p d_T(R~_self)          G_rdd[a, self] = Ra^T Dp,  G_rdd[a, a] = Ra^T diag(|T| c_p^2) Ra
+//   Xab [p][Q][N] ((A_ab^q)^T[:, f_p] V_T)      G_ab^q[:, a] = Xab_q^T Ra
+//   sc [p][3]     B_T[f_p][f_p], |T| c_p^2, (b_T . 1) c_p                  r_fd[a] = sc2^T Ra
+// The factors ARE the output in the factored layout (lrbms_project_estimate_fused_factored: ~2 KB instead of 205 KB per
+// side at config 3, and the reduced estimate consumes them directly); the dense block-compact layout is produced from
+// them by k_thin_expand.  Row layout of F_side [S][4][ncf][LD], LD = 4 QN + 4:
+//   [0, QN) Ra | [QN, 2QN) Yb | [2QN, 3QN) Dp | [3QN, 4QN) Xab (q, i) | sc0 sc1 sc2 0
 struct ThinRtArgs {
   const double *V, *Rself, *Rside, *Bbb, *Aab, *b;
   const int* nbr;
-  double *G_bb, *G_rdd, *G_ab, *r_fd;
+  double *Fside, *r_fd;
   int Q, N, S;
 };
 
-// at least 6 waves per SIMD (80 VGPRs, 28 bytes of scratch in the prologue): the kernel is bound by its 1 GB of writes,
-// but with 5 waves per SIMD the stores were held up by LDS and FMA latency (a chunked fill with 32 dependent FMAs per store
-// reaches 5.2 TB/s, tools/ubench/write_pattern.hip; this kernel 3.9 -> 4.2 TB/s; 8 waves spill in the loop: 375 us)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_thin_rt(Tmpl t, ThinRtArgs a) {
+__host__ __device__ inline int fside_ld(int Q, int N) { return 4 * Q * N + 4; }
+
+__global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
   extern __shared__ double lds[];
   const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
-  const int Q = a.Q, N = a.N, QN = Q * N, C = 5 * QN, S = a.S;
-  // block-compact layout [S][9][QN][QN]: block 1 + side = [a, self], block 5 + side = [a, a]
-  double* Gb_as = a.G_bb + ((long)s * 9 + 1 + side) * QN * QN;
-  double* Gb_aa = a.G_bb + ((long)s * 9 + 5 + side) * QN * QN;
-  double* Gd_as = a.G_rdd + ((long)s * 9 + 1 + side) * QN * QN;
-  double* Gd_aa = a.G_rdd + ((long)s * 9 + 5 + side) * QN * QN;
+  const int Q = a.Q, N = a.N, QN = Q * N, C = 5 * QN, S = a.S, LD = fside_ld(Q, N);
+  double* Fs = a.Fside + ((long)s * 4 + side) * t.ncf * LD;
   const int s2 = a.nbr[s * 5 + slot];
-  const int np = t.side_count[side];
-  if (s2 < 0 || np == 0) {
-    for (int i = tid; i < QN * QN; i += 256) Gb_as[i] = Gb_aa[i] = Gd_as[i] = Gd_aa[i] = 0.0;
-    for (int q = 0; q < Q; ++q)
-      for (int i = tid; i < N * QN; i += 256) a.G_ab[(((long)q * S + s) * N + i / QN) * C + slot * QN + i % QN] = 0.0;
+  const int np = s2 < 0 ? 0 : t.side_count[side];
+  // rows of side faces that do not exist (no neighbour, or fewer faces than ncf on this side): zero factors
+  for (int i = tid; i < (t.ncf - np) * LD; i += 256) Fs[(long)np * LD + i] = 0.0;
+  if (np == 0) {
     for (int i = tid; i < QN; i += 256) a.r_fd[(long)s * C + slot * QN + i] = 0.0;
     return;
   }
-  double* Ra = lds;                 // [np][QN]   flux image of the neighbour on the side faces
-  double* Yb = Ra + np * QN;        // [np][QN]   (B_T R~_self)[f_p]
-  double* Dp = Yb + np * QN;        // [np][QN]   |T| c_p * d_T,self
-  double* Xab = Dp + np * QN;       // [Q][np][N] (A_ab^q)^T[:, f_p] V_T
-  double* sc = Xab + Q * np * N;    // [np][3]    B[f,f], |T| c^2, bsum * c
+  // per side face p: element, its face on the side, its three RT0 rows and divergence coefficients -- resolved ONCE by
+  // np threads into LDS (the index chains side_elem -> nb_elem -> elem_rt / face_len / area are three dependent round trips)
+  double* fco = lds;                                  // [np][4]: sign |e_g| / |T| (g = 0..2), |T|
+  double* sc2 = fco + 4 * np;                         // [np]    (b_T . 1) c_p
+  int* fidx = reinterpret_cast<int*>(sc2 + np);       // [np][5]: T, fp, rt row of face 0..2
   const int* nbr_s = a.nbr + s * 5;
   const double* Rs = a.Rself + (long)s * t.nrt * QN;
-  // per side face p: element, its face on the side, its three RT0 rows and divergence coefficients -- resolved ONCE by
-  // np threads into LDS (the index chains side_elem -> nb_elem -> elem_rt / face_len / area are three dependent round
-  // trips; chased by every item of the loops below they made the prologue ~10 round trips long)
-  double* fco = sc + 3 * np;                       // [np][4]: sign |e_g| / |T| (g = 0..2), |T|
-  int* fidx = reinterpret_cast<int*>(fco + 4 * np);   // [np][5]: T, fp, rt row of face 0..2
   if (tid < np) {
     const int p = tid, T = t.side_elem[side * t.ncf + p];
     int fp = 0;
@@ -1304,12 +1305,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       fco[p * 4 + g] = face_sign_at(t, nbr_s, T, g) * t.face_len[T * 3 + g] / area;
     }
     fco[p * 4 + 3] = area;
+    const double cp = fco[p * 4 + fp];
+    const double* be = a.b + (long)s * t.n + 3 * T;
+    const double* B = a.Bbb + ((long)s * t.nT + T) * 9 + fp * 3;
+    sc2[p] = (be[0] + be[1] + be[2]) * cp;
+    double* row = Fs + (long)p * LD + 4 * QN;
+    row[0] = B[fp];
+    row[1] = area * cp * cp;
+    row[2] = sc2[p];
+    row[3] = 0.0;
   }
   __syncthreads();
   for (int it = tid; it < np * QN; it += 256) {
     const int p = it / QN, c = it - p * QN;
     const int T = fidx[p * 5], fp = fidx[p * 5 + 1];
-    Ra[it] = a.Rside[(((long)s * 4 + side) * t.ncf + p) * QN + c];
+    const double ra = a.Rside[(((long)s * 4 + side) * t.ncf + p) * QN + c];
     const double* B = a.Bbb + ((long)s * t.nT + T) * 9 + fp * 3;
     const double area = fco[p * 4 + 3];
     double yb = 0.0, d = 0.0;
@@ -1318,48 +1328,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       yb += B[g] * rv;
       d += fco[p * 4 + g] * rv;
     }
-    const double cp = fco[p * 4 + fp];
-    Yb[it] = yb;
-    Dp[it] = area * cp * d;
-    if (c == 0) {
-      const double* be = a.b + (long)s * t.n + 3 * T;
-      sc[p * 3] = B[fp];
-      sc[p * 3 + 1] = area * cp * cp;
-      sc[p * 3 + 2] = (be[0] + be[1] + be[2]) * cp;
-    }
+    double* row = Fs + (long)p * LD;
+    row[c] = ra;
+    row[QN + c] = yb;
+    row[2 * QN + c] = area * fco[p * 4 + fp] * d;
   }
-  for (int it = tid; it < Q * np * N; it += 256) {
-    const int q = it / (np * N), rem = it - q * np * N, p = rem / N, i = rem - p * N;
+  for (int it = tid; it < np * QN; it += 256) {
+    const int p = it / QN, qi = it - p * QN, q = qi / N, i = qi - q * N;
     const int T = fidx[p * 5], fp = fidx[p * 5 + 1];
     const double* A = a.Aab + (((long)q * S + s) * t.nT + T) * 9;
     double x = 0.0;
     for (int k = 0; k < 3; ++k) x += a.V[((long)s * t.n + 3 * T + k) * N + i] * A[k * 3 + fp];
-    Xab[it] = x;
+    Fs[(long)p * LD + 3 * QN + qi] = x;
   }
+  for (int c = tid; c < QN; c += 256) {
+    double v = 0.0;
+    for (int p = 0; p < np; ++p) v += sc2[p] * a.Rside[(((long)s * 4 + side) * t.ncf + p) * QN + c];
+    a.r_fd[(long)s * C + slot * QN + c] = v;
+  }
+}
+
+// Dense block-compact form of the side blocks from the factors (callers that want the blocks themselves: the reference
+// keeps such operators as BlockOperators, block_swipdg.py:336-338): G_bb / G_rdd [S][9][QN][QN] blocks 1 + side = [a, self],
+// 5 + side = [a, a]; G_ab [Q][S][N][5QN] columns of slot a.  Bound by its writes (1 GB at config 3).
+struct ThinExpandArgs {
+  const double* Fside;
+  const int* nbr;
+  double *G_bb, *G_rdd, *G_ab;
+  int Q, N, S;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_thin_expand(Tmpl t, ThinExpandArgs a) {
+  extern __shared__ double lds[];
+  const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
+  const int Q = a.Q, N = a.N, QN = Q * N, C = 5 * QN, S = a.S, LD = fside_ld(Q, N);
+  double* Gb_as = a.G_bb + ((long)s * 9 + 1 + side) * QN * QN;
+  double* Gb_aa = a.G_bb + ((long)s * 9 + 5 + side) * QN * QN;
+  double* Gd_as = a.G_rdd + ((long)s * 9 + 1 + side) * QN * QN;
+  double* Gd_aa = a.G_rdd + ((long)s * 9 + 5 + side) * QN * QN;
+  const int s2 = a.nbr[s * 5 + slot];
+  const int np = t.side_count[side];
+  if (s2 < 0 || np == 0) {
+    for (int i = tid; i < QN * QN; i += 256) Gb_as[i] = Gb_aa[i] = Gd_as[i] = Gd_aa[i] = 0.0;
+    for (int q = 0; q < Q; ++q)
+      for (int i = tid; i < N * QN; i += 256) a.G_ab[(((long)q * S + s) * N + i / QN) * C + slot * QN + i % QN] = 0.0;
+    return;
+  }
+  double* Fl = lds;                 // [np][LD] the factor rows of this side
+  const double* Fs = a.Fside + ((long)s * 4 + side) * t.ncf * LD;
+  for (int i = tid; i < np * LD; i += 256) Fl[i] = Fs[i];
   __syncthreads();
-  // the two non-zero blocks of block-row a: [a, a] (rank-np with the side-face scalars) and [a, self].
+  const double* Ra = Fl;
+  const double* Yb = Fl + QN;
+  const double* Dp = Fl + 2 * QN;
+  const double* Xab = Fl + 3 * QN;
+  const double* sc = Fl + 4 * QN;
   if ((QN & 1) == 0) {
     // Register tiles of 2 rows x 2 columns, lanes over consecutive column PAIRS: every store is 16 bytes per lane and a
-    // wave's store instruction covers whole 128-byte lines (rows are 8 QN bytes = whole lines apart, 40 lanes per row at
-    // QN = 80) -- the kernel is bound by its 1 GB of writes, and 8-byte stores that start and end inside lines reached
-    // 3.7 TB/s where a plain fill reaches 6.5 (tools/ubench/write_bw.py).  Per side face 3 lane reads (16 bytes) and 2
-    // broadcast reads from LDS feed 16 outputs.
+    // wave's store instruction covers whole 128-byte lines.
     const int hp = QN / 2, trows = (QN + 1) / 2;
     for (int it = tid; it < trows * hp; it += 256) {
       const int tr = it / hp, cc = 2 * (it - tr * hp), r0 = 2 * tr, r1 = r0 + 1 < QN ? r0 + 1 : QN - 1;
       double2 vb[2], vd[2], wb[2], wd[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) vb[i] = vd[i] = wb[i] = wd[i] = make_double2(0.0, 0.0);
-#ifdef THIN_RT_NOCOMPUTE
-      for (int p = 0; p < (a.N < 0 ? np : 0); ++p) {
-#else
       for (int p = 0; p < np; ++p) {
-#endif
-        const double2 rc = *reinterpret_cast<const double2*>(Ra + p * QN + cc);
-        const double2 yc = *reinterpret_cast<const double2*>(Yb + p * QN + cc);
-        const double2 dc = *reinterpret_cast<const double2*>(Dp + p * QN + cc);
-        const double k0 = sc[p * 3], k1 = sc[p * 3 + 1];
-        const double ra[2] = {Ra[p * QN + r0], Ra[p * QN + r1]};
+        const double2 rc = *reinterpret_cast<const double2*>(Ra + p * LD + cc);
+        const double2 yc = *reinterpret_cast<const double2*>(Yb + p * LD + cc);
+        const double2 dc = *reinterpret_cast<const double2*>(Dp + p * LD + cc);
+        const double k0 = sc[p * LD], k1 = sc[p * LD + 1];
+        const double ra[2] = {Ra[p * LD + r0], Ra[p * LD + r1]};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           vb[i].x += ra[i] * (k0 * rc.x); vb[i].y += ra[i] * (k0 * rc.y);
@@ -1370,11 +1408,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-#ifdef THIN_RT_NOSTORE
-        if (r0 + i < QN && vb[i].x == 1.2345e300) {
-#else
         if (r0 + i < QN) {
-#endif
           const long o = (long)(r0 + i) * QN + cc;
           *reinterpret_cast<double2*>(Gb_aa + o) = vb[i];
           *reinterpret_cast<double2*>(Gd_aa + o) = vd[i];
@@ -1391,10 +1425,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #pragma unroll
       for (int i = 0; i < RT; ++i) v[i] = make_double2(0.0, 0.0);
       for (int p = 0; p < np; ++p) {
-        const double2 rc = *reinterpret_cast<const double2*>(Ra + p * QN + cc);
+        const double2 rc = *reinterpret_cast<const double2*>(Ra + p * LD + cc);
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
-          const double x = Xab[(q * np + p) * N + (i0 + i < N ? i0 + i : N - 1)];
+          const double x = Xab[p * LD + q * N + (i0 + i < N ? i0 + i : N - 1)];
           v[i].x += x * rc.x;
           v[i].y += x * rc.y;
         }
@@ -1406,7 +1440,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
   } else {
     // odd QN: register tiles of 4 rows x 1 column, lanes over consecutive columns (8-byte stores)
-  {
     constexpr int RT = 4;
     const int trows = (QN + RT - 1) / RT;
     for (int it = tid; it < trows * QN; it += 256) {
@@ -1415,11 +1448,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #pragma unroll
       for (int i = 0; i < RT; ++i) vb[i] = vd[i] = wb[i] = wd[i] = 0.0;
       for (int p = 0; p < np; ++p) {
-        const double rc = Ra[p * QN + cc], yc = Yb[p * QN + cc], dc = Dp[p * QN + cc];
-        const double s0 = sc[p * 3] * rc, s1 = sc[p * 3 + 1] * rc;
+        const double rc = Ra[p * LD + cc], yc = Yb[p * LD + cc], dc = Dp[p * LD + cc];
+        const double s0 = sc[p * LD] * rc, s1 = sc[p * LD + 1] * rc;
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
-          const double ra = Ra[p * QN + (r0 + i < QN ? r0 + i : QN - 1)];
+          const double ra = Ra[p * LD + (r0 + i < QN ? r0 + i : QN - 1)];
           vb[i] += ra * s0;
           vd[i] += ra * s1;
           wb[i] += ra * yc;
@@ -1430,7 +1463,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       for (int i = 0; i < RT; ++i) {
         if (r0 + i < QN) {
           const long o = (long)(r0 + i) * QN + cc;
-          Gb_aa[o] = vb[i];   // (non-temporal stores measured: no difference)
+          Gb_aa[o] = vb[i];
           Gd_aa[o] = vd[i];
           Gb_as[o] = wb[i];
           Gd_as[o] = wd[i];
@@ -1444,20 +1477,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #pragma unroll
       for (int i = 0; i < RT; ++i) v[i] = 0.0;
       for (int p = 0; p < np; ++p) {
-        const double rc = Ra[p * QN + cc];
+        const double rc = Ra[p * LD + cc];
 #pragma unroll
-        for (int i = 0; i < RT; ++i) v[i] += Xab[(q * np + p) * N + (i0 + i < N ? i0 + i : N - 1)] * rc;
+        for (int i = 0; i < RT; ++i) v[i] += Xab[p * LD + q * N + (i0 + i < N ? i0 + i : N - 1)] * rc;
       }
 #pragma unroll
       for (int i = 0; i < RT; ++i)
         if (i0 + i < N) a.G_ab[(((long)q * S + s) * N + i0 + i) * C + slot * QN + cc] = v[i];
     }
-  }
-  }
-  for (int c = tid; c < QN; c += 256) {
-    double v = 0.0;
-    for (int p = 0; p < np; ++p) v += sc[p * 3 + 2] * Ra[p * QN + c];
-    a.r_fd[(long)s * C + slot * QN + c] = v;
   }
 }
 
@@ -1533,8 +1560,11 @@ inline unsigned grid_for(long total) {
 int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N) {
   const Tmpl& t = ctx->t;
   const long nvs = t.nvx > t.nvy ? t.nvx : t.nvy;
-  return (long)ctx->S * t.nrt * Q * N + (long)ctx->S * 4 * t.ncf * Q * N + (long)ctx->S * t.nv * N + (long)ctx->S * 4 * nvs * N;
+  return (long)ctx->S * t.nrt * Q * N + (long)ctx->S * 4 * t.ncf * Q * N + (long)ctx->S * t.nv * N + (long)ctx->S * 4 * nvs * N +
+         (long)ctx->S * 4 * t.ncf * fside_ld(Q, N);   // side factors of the dense layout (the factored layout returns them)
 }
+
+int64_t fused_fside_size(lrbms_ctx* ctx, int Q, int N) { return (long)ctx->S * 4 * ctx->t.ncf * fside_ld(Q, N); }
 
 namespace {
 __global__ __launch_bounds__(256) void k_build_tables(Tmpl t, double* __restrict__ stiff, int* __restrict__ tvtx,
@@ -1614,7 +1644,11 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
                                   const double* A_cpl, const double* P_diag, const double* b, const double* ebar,
                                   const double* caa, const double* Aab, const double* Bbb, double* work, double* B_sys,
                                   double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd, double* G_rdd,
-                                  double* G_bb, double* G_ab, double* G_aa, int phase, hipStream_t st) {
+                                  double* G_bb, double* G_ab, double* G_aa, double* Fside, int phase, hipStream_t st) {
+  // Fside == nullptr: dense layout -- G_rdd / G_bb block-compact [S][9][QN][QN], G_ab [Q][S][N][5QN]; the side factors
+  // stay in `work` and k_thin_expand writes the side blocks from them.
+  // Fside != nullptr: factored layout -- G_rdd / G_bb [S][QN][QN] and G_ab [Q][S][N][QN] hold the self parts only, every
+  // block that involves a neighbour slot is represented by F_side [S][4][ncf][4 QN + 4] (see k_thin_rt).
   // phase 0: the whole pass.  phase 1 / 2: its halo-independent / halo-dependent halves, for a sharded run that overlaps
   // the halo exchange with phase 1 (everything that reads only the rank's own basis slabs: R_self, Avg_self, k_f1,
   // k_f2, k_f3 -- more than half of the pass); phase 2 then needs the halo slabs of V (R_side, Avg_side, the thin
@@ -1634,6 +1668,11 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   double* Rside = Rself + (long)S * t.nrt * QN;
   double* AvgSelf = Rside + (long)S * 4 * t.ncf * QN;
   double* AvgSide = AvgSelf + (long)S * t.nv * N;
+  const bool factored = Fside != nullptr;
+  if (!factored) Fside = AvgSide + (long)S * 4 * nvs * N;
+  const long gstride = factored ? (long)QN * QN : (long)9 * QN * QN;      // self blocks of G_bb / G_rdd
+  const int abld = factored ? QN : C;                                     // row length of G_ab
+  const int aboff = factored ? 0 : 2 * QN;                                // column offset of its self part
   // Small per-rank counts (forked mode): the vertex averages are not needed by k_f1 / k_f2, only by the kernels of the
   // library's stream 2 (k_thin_nc, k_f3) -- they run at the head of that stream, beside k_f1, instead of in front of it.
   const char* env_streams0 = getenv("LRBMS_STREAMS");
@@ -1699,7 +1738,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
                         q2 != q ? G_aa + ((long)q2 * Q + q) * S * N * N : nullptr, (long)N * N});
   for (int q = 0; q < Q; ++q)
     for (int q2 = 0; q2 < Q; ++q2)
-      groups.push_back({G_AB, q, q2, C, G_ab + (long)q * S * N * C + 2 * QN + q2 * N, nullptr, (long)N * C});
+      groups.push_back({G_AB, q, q2, abld, G_ab + (long)q * S * N * abld + aboff + q2 * N, nullptr, (long)N * abld});
   {
     constexpr int NTY = 7;                                   // 4 consumer waves x 7 column tiles = 448 columns per slice
     const int per = std::min(F1_MAXG, (4 * NTY * 16) / N);
@@ -1774,17 +1813,24 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     }
 #undef LRBMS_THIN_NC
     LRBMS_LAUNCH_CHECK(ctx);
-    ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, G_bb, G_rdd, G_ab, r_fd, Q, N, S};
-    const size_t lds2 = sizeof(double) * (3 * t.ncf * QN + Q * t.ncf * N + 3 * t.ncf + 4 * t.ncf + 3 * t.ncf);   // + fco [ncf][4], fidx [ncf][5] ints
+    ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, Fside, r_fd, Q, N, S};
+    const size_t lds2 = sizeof(double) * (5 * t.ncf + 3 * t.ncf);   // fco [ncf][4], sc2 [ncf], fidx [ncf][5] ints
     {
       KScope ks(ctx, "k_thin_rt", s_rt);
       hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, s_rt, t, a);
     }
     LRBMS_LAUNCH_CHECK(ctx);
+    if (!factored) {
+      ThinExpandArgs e{Fside, ctx->nbr, G_bb, G_rdd, G_ab, Q, N, S};
+      const size_t lds3 = sizeof(double) * (size_t)t.ncf * fside_ld(Q, N);
+      KScope ks(ctx, "k_thin_expand", s_rt);
+      hipLaunchKernelGGL(k_thin_expand, dim3(4, S), dim3(256), lds3, s_rt, t, e);
+      LRBMS_LAUNCH_CHECK(ctx);
+    }
   }
   // ---- F2
   if (do_a) {
-    F2Args a{Rself, Bbb, b, ctx->nbr, G_bb, G_rdd, r_fd, Q, N, S};
+    F2Args a{Rself, Bbb, b, ctx->nbr, G_bb, G_rdd, r_fd, Q, N, S, gstride};
     const int nr = (QN + 15) / 16;
     const size_t ldsf2 = sizeof(double) * 4 * t.nT + sizeof(int) * 3 * t.nT;
     KScope ks(ctx, "k_f2", s_f23);

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
                                                           const double* __restrict__ u, const double* __restrict__ G_nc,
                                                           const double* __restrict__ r_fd, const double* __restrict__ G_rdd,
                                                           const double* __restrict__ G_bb, const double* __restrict__ G_ab,
-                                                          const double* __restrict__ G_aa, const double* __restrict__ f2,
+                                                          const double* __restrict__ G_aa, const double* __restrict__ Fside,
+                                                          int ncf, const double* __restrict__ f2,
                                                           const double* __restrict__ ceps, double hdiam,
                                                           double* __restrict__ eta_loc) {
   extern __shared__ double lds[];
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
   double* uo = lds;            // [W]
   double* ur = lds + W;        // [C]
   double* red = ur + C;        // [256]
+  double* fac = red + 256;     // [4][ncf][3 + Q]  (factored layout only)
   for (int i = threadIdx.x; i < W; i += blockDim.x) {
     const int slot = i / N, j = i % N;
     const int s2 = nbr[s * 5 + slot];
@@ -71,25 +73,57 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
   __syncthreads();
   const double* ui = uo + 2 * N;
   double p_nc = quad_partial(G_nc + (long)s * W * W, W, W, W, uo, uo);
-  // block-compact G_rdd / G_bb [S][9][QN][QN]: z^T G z = z_s^T G_ss z_s + sum_a (2 z_a^T G_as z_s + z_a^T G_aa z_a)
+  // z^T G z = z_s^T G_ss z_s + sum_a (2 z_a^T G_as z_s + z_a^T G_aa z_a) for G_rdd / G_bb, either from the block-compact
+  // layout [S][9][QN][QN] or (Fside != nullptr) from the self blocks [S][QN][QN] plus the side factors (see k_thin_rt)
   const int QN = Q * N;
+  const bool factored = Fside != nullptr;
+  const long gstride = factored ? (long)QN * QN : (long)9 * QN * QN;
+  const int abld = factored ? QN : C;
   const double* zs = ur + 2 * QN;
-  const double* Gd = G_rdd + (long)s * 9 * QN * QN;
-  const double* Gb = G_bb + (long)s * 9 * QN * QN;
+  const double* Gd = G_rdd + (long)s * gstride;
+  const double* Gb = G_bb + (long)s * gstride;
   double p_rdd = quad_partial(Gd, QN, QN, QN, zs, zs);
   double p_bb = quad_partial(Gb, QN, QN, QN, zs, zs);
-  for (int side = 0; side < 4; ++side) {
-    const double* za = ur + (side < 2 ? side : side + 1) * QN;
-    p_rdd += 2.0 * quad_partial(Gd + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs) +
-             quad_partial(Gd + (long)(5 + side) * QN * QN, QN, QN, QN, za, za);
-    p_bb += 2.0 * quad_partial(Gb + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs) +
-            quad_partial(Gb + (long)(5 + side) * QN * QN, QN, QN, QN, za, za);
+  double p_ab = 0.0, p_aa = 0.0;
+  if (!factored) {
+    for (int side = 0; side < 4; ++side) {
+      const double* za = ur + (side < 2 ? side : side + 1) * QN;
+      p_rdd += 2.0 * quad_partial(Gd + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs) +
+               quad_partial(Gd + (long)(5 + side) * QN * QN, QN, QN, QN, za, za);
+      p_bb += 2.0 * quad_partial(Gb + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs) +
+              quad_partial(Gb + (long)(5 + side) * QN * QN, QN, QN, QN, za, za);
+    }
+  } else {
+    // one dot product per (side, side face p, factor k): k = 0: Ra . z_a, 1: Yb . z_s, 2: Dp . z_s, 3 + q: Xab_q . u_i
+    const int LD = 4 * QN + 4, nk = 3 + Q, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int it = wave; it < 4 * ncf * nk; it += nw) {
+      const int side = it / (ncf * nk), rem = it - side * ncf * nk, p = rem / nk, k = rem - p * nk;
+      const double* row = Fside + (((long)s * 4 + side) * ncf + p) * LD;
+      const double* x;
+      const double* y;
+      int len;
+      if (k == 0) { x = row; y = ur + (side < 2 ? side : side + 1) * QN; len = QN; }
+      else if (k < 3) { x = row + k * QN; y = zs; len = QN; }
+      else { x = row + 3 * QN + (k - 3) * N; y = ui; len = N; }
+      double d = 0.0;
+      for (int c = lane; c < len; c += 64) d += x[c] * y[c];
+      for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+      if (lane == 0) fac[it] = d;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < 4 * ncf; it += blockDim.x) {
+      const double* f = fac + it * nk;
+      const double* sc = Fside + ((long)s * 4 * ncf + it) * LD + 4 * QN;
+      const double ra = f[0];
+      p_bb += sc[0] * ra * ra + 2.0 * ra * f[1];
+      p_rdd += sc[1] * ra * ra + 2.0 * ra * f[2];
+      for (int q = 0; q < Q; ++q) p_ab += theta.v[q] * f[3 + q] * ra;
+    }
   }
   double p_rfd = 0.0;
   for (int c = threadIdx.x; c < C; c += blockDim.x) p_rfd += r_fd[(long)s * C + c] * ur[c];
-  double p_ab = 0.0, p_aa = 0.0;
   for (int q = 0; q < Q; ++q) {
-    p_ab += theta.v[q] * quad_partial(G_ab + ((long)q * S + s) * N * C, C, N, C, ui, ur);
+    p_ab += theta.v[q] * quad_partial(G_ab + ((long)q * S + s) * N * abld, abld, N, abld, ui, factored ? zs : ur);
     for (int q2 = 0; q2 < Q; ++q2)
       p_aa += theta.v[q] * theta.v[q2] * quad_partial(G_aa + (((long)q * Q + q2) * S + s) * N * N, N, N, N, ui, ui);
   }
@@ -444,13 +478,13 @@ __global__ __launch_bounds__(64) void k_red_inv_norm2(int N, const double* __res
 
 int launch_reduced_estimate(lrbms_ctx* ctx, int Q, int N, const double* theta, const double* u, const double* G_nc,
                             const double* r_fd, const double* G_rdd, const double* G_bb, const double* G_ab,
-                            const double* G_aa, const double* f2, const double* ceps, double hdiam, double* eta_loc,
-                            hipStream_t st) {
+                            const double* G_aa, const double* Fside, const double* f2, const double* ceps, double hdiam,
+                            double* eta_loc, hipStream_t st) {
   QVec th;
   for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
-  const size_t lds = sizeof(double) * (5 * N + 5 * Q * N + 256);
+  const size_t lds = sizeof(double) * (5 * N + 5 * Q * N + 256 + 4 * ctx->t.ncf * (3 + Q));
   hipLaunchKernelGGL(k_reduced_estimate, dim3(ctx->S), dim3(256), lds, st, ctx->S, ctx->nbr, Q, N, th, u, G_nc, r_fd,
-                     G_rdd, G_bb, G_ab, G_aa, f2, ceps, hdiam, eta_loc);
+                     G_rdd, G_bb, G_ab, G_aa, Fside, ctx->t.ncf, f2, ceps, hdiam, eta_loc);
   LRBMS_LAUNCH_CHECK(ctx);
   return LRBMS_OK;
 }
@@ -1895,11 +1929,68 @@ __device__ inline void quad_mfma(const double* __restrict__ G, int ld, int R, in
   }
 }
 
+// T = G_rows Y for ONE tile of 16 rows: lane (li, lk) streams row pointer `grow` (its row of G, K entries), Y [K][16] from LDS
+__device__ inline d4m tile_mfma(const double* __restrict__ grow, int K, const double* Y, double wl) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  d4m T = (d4m){0.0, 0.0, 0.0, 0.0};
+  int kk = 0;
+  for (; kk + 32 <= K; kk += 32) {
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = grow[kk + 4 * u + lk];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      T = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], wl * Y[(kk + 4 * u + lk) * 16 + li], T, 0, 0, 0);
+  }
+  for (; kk < K; kk += 4) {
+    const bool in = kk + lk < K;
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(grow[in ? kk + lk : K - 1], in ? wl * Y[(kk + lk) * 16 + li] : 0.0, T, 0, 0, 0);
+  }
+  return T;
+}
+
+// Side blocks of G_bb / G_rdd / G_ab from the factors F_side (see k_thin_rt in fused.hip): for side a with coefficient
+// panels z_a (neighbour), z_s, u_i (own) the contributions are sum_p [sc0_p ra_p^2 + 2 ra_p (Yb z_s)_p + 2 theta_q (Xab_q u_i)_p ra_p]
+// (diffusive flux) and sum_p [sc1_p ra_p^2 + 2 ra_p (Dp z_s)_p] (residual) with ra = Ra z_a -- 3 + Q thin products per side.
+__device__ inline void side_factored(const double* __restrict__ Fs, int ncf, int Q, int N, const double* za, const double* zs,
+                                     const double* ui, const double* thl, double& a_r, double& a_df) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const int QN = Q * N, LD = 4 * QN + 4;
+  for (int tile = 0; tile * 16 < ncf; ++tile) {
+    const int ra_row = tile * 16 + li < ncf ? tile * 16 + li : ncf - 1;     // rows >= ncf repeat the last row (masked below)
+    const double* grow = Fs + (long)ra_row * LD;
+    const d4m Tra = tile_mfma(grow, QN, za, 1.0);
+    const d4m Tyb = tile_mfma(grow + QN, QN, zs, 1.0);
+    const d4m Tdd = tile_mfma(grow + 2 * QN, QN, zs, 1.0);
+    d4m Tx = (d4m){0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < Q; ++q) {
+      double tq = thl[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k)
+        if (q == k) tq = thl[k];
+      const d4m Tq = tile_mfma(grow + 3 * QN + q * N, N, ui, tq);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Tx[rr] += Tq[rr];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = tile * 16 + lk + 4 * rr;
+      if (row < ncf) {
+        const double* sc = Fs + (long)row * LD + 4 * QN;
+        const double ra = Tra[rr];
+        a_df += sc[0] * ra * ra + 2.0 * ra * (Tyb[rr] + Tx[rr]);
+        a_r += sc[1] * ra * ra + 2.0 * ra * Tdd[rr];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int S, const int* __restrict__ nbr, int Q, int N, int nmu,
                                                                      ThetaBatch th, const double* __restrict__ u,
                                                                      const double* __restrict__ G_nc, const double* __restrict__ r_fd,
                                                                      const double* __restrict__ G_rdd, const double* __restrict__ G_bb,
                                                                      const double* __restrict__ G_ab, const double* __restrict__ G_aa,
+                                                                     const double* __restrict__ Fside, int ncf,
                                                                      const double* __restrict__ f2, const double* __restrict__ ceps,
                                                                      double hdiam, double* __restrict__ eta_loc) {
   extern __shared__ double lds[];
@@ -1925,17 +2016,29 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
   double a_nc = 0.0, a_r = 0.0, a_df = 0.0;
   const double* ui = uo + 2 * N * 16;
   const double* zs = ur + 2 * QN * 16;
+  const bool factored = Fside != nullptr;
+  const long gstride = factored ? (long)QN * QN : (long)9 * QN * QN;
+  const int abld = factored ? QN : C;
+  // factored layout: the four sides go to the upper waves, which get no tile of the small (N- and QN-row) operators below
+  if (factored) {
+    for (int side = EST_NW - 1 - wave; side >= 0 && side < 4; side -= EST_NW) {
+      const double* za = ur + (side < 2 ? side : side + 1) * QN * 16;
+      side_factored(Fside + ((long)s * 4 + side) * ncf * (4 * QN + 4), ncf, Q, N, za, zs, ui, thl, a_r, a_df);
+    }
+  }
   quad_mfma(G_nc + (long)s * W * W, W, W, W, uo, uo, 1.0, a_nc);
-  const double* Gd = G_rdd + (long)s * 9 * QN * QN;
-  const double* Gb = G_bb + (long)s * 9 * QN * QN;
+  const double* Gd = G_rdd + (long)s * gstride;
+  const double* Gb = G_bb + (long)s * gstride;
   quad_mfma(Gd, QN, QN, QN, zs, zs, 1.0, a_r);
   quad_mfma(Gb, QN, QN, QN, zs, zs, 1.0, a_df);
-  for (int side = 0; side < 4; ++side) {
-    const double* za = ur + (side < 2 ? side : side + 1) * QN * 16;
-    quad_mfma(Gd + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, 2.0, a_r);
-    quad_mfma(Gd + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, 1.0, a_r);
-    quad_mfma(Gb + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, 2.0, a_df);
-    quad_mfma(Gb + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, 1.0, a_df);
+  if (!factored) {
+    for (int side = 0; side < 4; ++side) {
+      const double* za = ur + (side < 2 ? side : side + 1) * QN * 16;
+      quad_mfma(Gd + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, 2.0, a_r);
+      quad_mfma(Gd + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, 1.0, a_r);
+      quad_mfma(Gb + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, 2.0, a_df);
+      quad_mfma(Gb + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, 1.0, a_df);
+    }
   }
   // - 2 r_fd . ur: lanes over (16 rows of c) x parameter
   for (int c = wave * 4 + (lane >> 4); c < C; c += 4 * EST_NW) a_r -= 2.0 * r_fd[(long)s * C + c] * ur[c * 16 + li];
@@ -1944,7 +2047,7 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
 #pragma unroll
     for (int k = 1; k < 8; ++k)
       if (q == k) tq = thl[k];
-    quad_mfma(G_ab + ((long)q * S + s) * N * C, C, N, C, ui, ur, 2.0 * tq, a_df);
+    quad_mfma(G_ab + ((long)q * S + s) * N * abld, abld, N, abld, ui, factored ? zs : ur, 2.0 * tq, a_df);
     for (int q2 = 0; q2 < Q; ++q2) {
       double tq2 = thl[0];
 #pragma unroll
@@ -1984,22 +2087,22 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
 
 int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const double* theta, const double* u, const double* G_nc,
                                   const double* r_fd, const double* G_rdd, const double* G_bb, const double* G_ab,
-                                  const double* G_aa, const double* f2, const double* ceps, double hdiam, double* eta_loc,
-                                  hipStream_t st) {
+                                  const double* G_aa, const double* Fside, const double* f2, const double* ceps, double hdiam,
+                                  double* eta_loc, hipStream_t st) {
   if (nmu < 1 || nmu > EB) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: need 1 <= nmu <= 16");
   const size_t lds = sizeof(double) * ((size_t)(5 * N + 5 * Q * N) * nmu + 8 * EB + 4 * 3 * EB);
   if (lds > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
   ThetaBatch th;
   for (int m = 0; m < BMAX; ++m)
     for (int q = 0; q < 8; ++q) th.v[m * 8 + q] = (m < nmu && q < Q) ? theta[m * Q + q] : 0.0;
-  if (getenv("LRBMS_EST_VALU") == nullptr) {   // matrix-core form (default)
+  if (Fside != nullptr || getenv("LRBMS_EST_VALU") == nullptr) {   // matrix-core form (default; the only one for the factored layout)
     const size_t ldm = sizeof(double) * ((size_t)(((5 * N + 3) & ~3) + ((5 * Q * N + 3) & ~3)) * 16 + EST_NW * 3 * 16);
     if (ldm > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
     if (ldm > 64 * 1024)
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)ldm));
     hipLaunchKernelGGL(k_reduced_estimate_batch_mfma, dim3(ctx->S), dim3(64 * EST_NW), ldm, st, ctx->S, ctx->nbr, Q, N, nmu, th, u, G_nc, r_fd,
-                       G_rdd, G_bb, G_ab, G_aa, f2, ceps, hdiam, eta_loc);
+                       G_rdd, G_bb, G_ab, G_aa, Fside, ctx->t.ncf, f2, ceps, hdiam, eta_loc);
     LRBMS_LAUNCH_CHECK(ctx);
     return LRBMS_OK;
   }

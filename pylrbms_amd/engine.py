@@ -105,17 +105,25 @@ class Engine:
         return self
 
     # ------------------------------------------------------------------ timed region: K7 + K8 + P1 + P2
-    def alloc_outputs(self, N):
-        """The projected system and the projected estimator operators of one pass (3.3 GB at config 3)."""
+    def alloc_outputs(self, N, factored=None):
+        """The projected system and the projected estimator operators of one pass.  ``factored`` (default: whenever the
+        fused pass supports (Q, N)): blocks of df_bb / r_dd / df_ab that involve a neighbour slot are returned as their
+        rank-<=ncf factors ``F_side`` (7 tensors, include/lrbms_hip.h) -- 0.9 GB of outputs at config 3 instead of 1.75 GB
+        for the dense block-compact layout (6 tensors), and the reduced estimate reads 0.6 instead of 1.5 GB."""
         c, S, Q = self.ctx, self.S, self.Q
-        W, C = 5 * N, 5 * Q * N
-        return {
-            'sys': (c.empty(Q, S, 5, N, N), c.empty(S, N), c.empty(S, N, N), c.empty(S, N, N)),
-            'grams': (c.empty(S, W, W), c.empty(S, C), c.empty(S, 9, Q * N, Q * N), c.empty(S, 9, Q * N, Q * N), c.empty(Q, S, N, C),
-                      c.empty(Q, Q, S, N, N)),
-        }
+        W, C, QN = 5 * N, 5 * Q * N, Q * N
+        if factored is None:
+            factored = c.fused_supported(Q, N)
+        sys_out = (c.empty(Q, S, 5, N, N), c.empty(S, N), c.empty(S, N, N), c.empty(S, N, N))
+        if factored:
+            grams = (c.empty(S, W, W), c.empty(S, C), c.empty(S, QN, QN), c.empty(S, QN, QN), c.empty(Q, S, N, QN),
+                     c.empty(Q, Q, S, N, N), c.empty(S, 4, self.t.ncf, c.fside_ld(Q, N)))
+        else:
+            grams = (c.empty(S, W, W), c.empty(S, C), c.empty(S, 9, QN, QN), c.empty(S, 9, QN, QN), c.empty(Q, S, N, C),
+                     c.empty(Q, Q, S, N, N))
+        return {'sys': sys_out, 'grams': grams}
 
-    def alloc_reduce_buffers(self, N, images=None):
+    def alloc_reduce_buffers(self, N, images=None, factored=None):
         """Outputs + scratch of ``project_and_estimate``.  The padded image bases ``Wt`` / ``Rt`` (1.3 GB at config 3) are
         only materialised by the unfused kernels: ``images=None`` allocates them iff the fused pass cannot run."""
         c, S, Q, n, n_rt = self.ctx, self.S, self.Q, self.t.n, self.t.n_rt
@@ -124,7 +132,7 @@ class Engine:
             images = not c.fused_supported(Q, N)
         work = c.empty(max(c.estimator_work_size(Q, N), Q * S * n * N, c.fused_work_size(Q, N)))
         buf = {'N': N, 'Wt': c.empty(S, n, W) if images else None, 'Rt': c.empty(S, n_rt, C) if images else None, 'work': work}
-        buf.update(self.alloc_outputs(N))
+        buf.update(self.alloc_outputs(N, factored=factored))
         return buf
 
     def project_and_estimate(self, V, buffers=None, project_system=True, fused=None, halo=None):
@@ -137,15 +145,17 @@ class Engine:
         if not self.assembled:
             raise NativeError('assemble() must run before project_and_estimate()')
         N = V.shape[2]
-        buf = buffers if buffers is not None else self.alloc_reduce_buffers(N)
-        if buf['N'] != N:
-            raise NativeError('buffers were allocated for N={}'.format(buf['N']))
         c = self.ctx
         if fused is None:
             cache = self.__dict__.setdefault('_fused_ok', {})
             if N not in cache:
                 cache[N] = c.fused_supported(self.Q, N)
             fused = cache[N]
+        buf = buffers if buffers is not None else self.alloc_reduce_buffers(N, factored=bool(fused))
+        if buf['N'] != N:
+            raise NativeError('buffers were allocated for N={}'.format(buf['N']))
+        if not fused and len(buf['grams']) == 7:
+            raise NativeError('the unfused kernels write the dense layout: allocate the buffers with factored=False')
         if fused:
             args = (V, self.F, self.A_diag, self.A_cpl, self.P_diag, self.b, self.ebar, self.caa, self.Aab, self.Bbb,
                     buf['work'], buf['sys'], buf['grams'])
@@ -225,6 +235,34 @@ class Engine:
 
 
 # ---------------------------------------------------------------------- layout converters (host, for API / tests)
+def expand_factored_grams(grams, ncf=None):
+    """Factored layout (7 tensors, include/lrbms_hip.h) -> dense layout (6 tensors: G_rdd / G_bb block-compact
+    [S, 9, QN, QN], G_ab [Q, S, N, 5QN]) with a few batched products on the device; a 6-tuple is returned unchanged.
+    For callers that want the blocks themselves (``rd.operators``, storage, tests) -- the estimate kernels never need it."""
+    if len(grams) == 6:
+        return tuple(grams)
+    import torch
+    G_nc, r_fd, Gd_s, Gb_s, Gab_s, G_aa, Fs = grams
+    Q, S, N, QN = Gab_s.shape[0], Gab_s.shape[1], Gab_s.shape[2], Gab_s.shape[3]
+    Ra, Yb, Dp = Fs[..., :QN], Fs[..., QN:2 * QN], Fs[..., 2 * QN:3 * QN]
+    Xab = Fs[..., 3 * QN:4 * QN].reshape(S, 4, Fs.shape[2], Q, N)
+    sc0, sc1 = Fs[..., 4 * QN], Fs[..., 4 * QN + 1]
+    G_bb = torch.empty(S, 9, QN, QN, dtype=Fs.dtype, device=Fs.device)
+    G_rdd = torch.empty_like(G_bb)
+    G_bb[:, 0], G_rdd[:, 0] = Gb_s, Gd_s
+    G_bb[:, 1:5] = torch.einsum('sapr,sapc->sarc', Ra, Yb)
+    G_rdd[:, 1:5] = torch.einsum('sapr,sapc->sarc', Ra, Dp)
+    G_bb[:, 5:9] = torch.einsum('sapr,sap,sapc->sarc', Ra, sc0, Ra)
+    G_rdd[:, 5:9] = torch.einsum('sapr,sap,sapc->sarc', Ra, sc1, Ra)
+    G_ab = torch.zeros(Q, S, N, 5 * QN, dtype=Fs.dtype, device=Fs.device)
+    G_ab[..., 2 * QN:3 * QN] = Gab_s
+    side = torch.einsum('sapqi,sapc->qsaic', Xab, Ra)
+    for a, slot in enumerate((0, 1, 3, 4)):
+        G_ab[..., slot * QN:(slot + 1) * QN] = side[:, :, a]
+    return G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa
+
+
+
 def blockell_to_dense(template, vals):
     """[n_T][4][9] block-ELL values of one subdomain -> dense [n, n] (inspection / ``.matrix()`` of the API shim)."""
     t = template

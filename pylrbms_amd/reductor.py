@@ -40,10 +40,21 @@ class ReducedDiscretization:
             dim = int(sum(reductor.local_sizes())) if eng.S == eng.grid.num_subdomains else eng.grid.num_subdomains * N
         self.solution_space = _Space
         self.operator = type('Op', (), {'source': _Space, 'range': _Space})
-        self.operators = {'nc': self.grams[0], 'r_fd': self.grams[1], 'r_dd': self.grams[2], 'df_bb': self.grams[3],
-                          'df_ab': self.grams[4], 'df_aa': self.grams[5], 'local_energy_dg_product': self.E_red}
+        self._operators = None
         self.products = {'l2': self.M_red}
         self._torch = torch
+
+    @property
+    def operators(self):
+        """The projected estimator operators as block arrays (reference: ``rd.operators``, projected at reductor.py:70).
+        The kernels keep the blocks that involve a neighbour slot in factored form (``self.grams``, 7 tensors); the dense
+        block-compact arrays are built on first access only -- the estimate never needs them."""
+        if self._operators is None:
+            from pylrbms_amd.engine import expand_factored_grams
+            g = expand_factored_grams(self.grams)
+            self._operators = {'nc': g[0], 'r_fd': g[1], 'r_dd': g[2], 'df_bb': g[3], 'df_ab': g[4], 'df_aa': g[5],
+                               'local_energy_dg_product': self.E_red}
+        return self._operators
 
     def parse_parameter(self, mu):
         return self.d.parse_parameter(mu)

@@ -166,9 +166,11 @@ def compare_all(p, engine, V, mu, do_solve=True):
     # ---- apply + projections
     Vd = eng.ctx.from_numpy(V)
     buf = eng.project_and_estimate(Vd, fused=False)
-    fbuf = None
+    fbuf = dbuf = None
     if eng.ctx.fused_supported(Q, N):
-        fbuf = eng.project_and_estimate(Vd, eng.alloc_reduce_buffers(N), fused=True)
+        fbuf = eng.project_and_estimate(Vd, eng.alloc_reduce_buffers(N), fused=True)                  # factored layout (default)
+        assert len(fbuf['grams']) == 7
+        dbuf = eng.project_and_estimate(Vd, eng.alloc_reduce_buffers(N, factored=False), fused=True)  # dense layout
     red = OracleReductor(d, [V[ii] for ii in range(S)])
     OI, RT = red.image_bases()
     mesh = d.mesh
@@ -215,11 +217,14 @@ def compare_all(p, engine, V, mu, do_solve=True):
             # the blocks the compact layout does not store are structurally zero in the ORACLE's dense operator
             errs[name] = max(errs[name], dropped / max(np.abs(dense).max(), 1e-300))
     res.update(errs)
-    if fbuf is not None:      # the fused pass must produce the same arrays as the unfused kernels (and the oracle)
+    if fbuf is not None:      # the fused pass must produce the same arrays as the unfused kernels (and the oracle), in
+        from pylrbms_amd.engine import expand_factored_grams      # both output layouts (factored blocks expanded for this)
         names = ('B_sys', 'rhs_red', 'E_red', 'M_red', 'G_nc', 'r_fd', 'G_rdd', 'G_bb', 'G_ab', 'G_aa')
-        for name, a, b in zip(names, list(fbuf['sys']) + list(fbuf['grams']), list(buf['sys']) + list(buf['grams'])):
-            a, b = host(a), host(b)
-            res['fused_' + name] = float(np.abs(a - b).max() / max(np.abs(b).max(), vscale * 1e-3))
+        for tag, xb in (('fused_', fbuf), ('fused_dense_', dbuf)):
+            for name, a, b in zip(names, list(xb['sys']) + list(expand_factored_grams(xb['grams'])),
+                                  list(buf['sys']) + list(buf['grams'])):
+                a, b = host(a), host(b)
+                res[tag + name] = float(np.abs(a - b).max() / max(np.abs(b).max(), vscale * 1e-3))
 
     # ---- online: estimate for a random coefficient vector, then solve + estimate
     theta = theta_of(p, mu)
@@ -228,6 +233,16 @@ def compare_all(p, engine, V, mu, do_solve=True):
     eta = host(eng.reduced_estimate(theta, eng.ctx.from_numpy(u), buf['grams']))
     _, (nc, r, df), _ = rd.estimate([u[ii] for ii in range(S)], mu, decompose=True)
     res['eta_nc'], res['eta_r'], res['eta_df'] = rel_err(eta[0], nc), rel_err(eta[1], r), rel_err(eta[2], df)
+    if fbuf is not None:      # the estimate on the factored layout: single-parameter kernel and the batched (MFMA) one
+        eta_f = host(eng.reduced_estimate(theta, eng.ctx.from_numpy(u), fbuf['grams']))
+        res['eta_factored'] = max(rel_err(eta_f[0], nc), rel_err(eta_f[1], r), rel_err(eta_f[2], df))
+        ub = eng.ctx.from_numpy(np.repeat(u[:, :, None], 3, axis=2) * np.array([1.0, -0.5, 2.0])[None, None, :])
+        thb = np.stack([theta, theta, theta])
+        for tag, grams in (('eta_batch_factored', fbuf['grams']), ('eta_batch_dense', dbuf['grams'])):
+            eb = host(eng.ctx.reduced_estimate_batch(thb, ub, grams, eng.f2, eng.ceps, eng.hdiam))
+            _, (nc2, r2, df2), _ = rd.estimate([-0.5 * u[ii] for ii in range(S)], mu, decompose=True)
+            res[tag] = max(rel_err(eb[0, :, 0], nc), rel_err(eb[1, :, 0], r), rel_err(eb[2, :, 0], df),
+                           rel_err(eb[0, :, 1], nc2), rel_err(eb[1, :, 1], r2), rel_err(eb[2, :, 1], df2))
     if do_solve:
         u_dev, info = eng.reduced_solve(theta, buf['sys'][0], buf['sys'][1])
         u_ref = np.stack(rd.solve(mu))

@@ -142,7 +142,8 @@ def test_full_size_properties_config2():
     S, n, N = eng.S, eng.t.n, 20
     V = eng.ctx.from_numpy(make_bases(S, n, N, seed=2))
     buf = eng.project_and_estimate(V)
-    G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = buf['grams']
+    from pylrbms_amd.engine import expand_factored_grams
+    G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = expand_factored_grams(buf['grams'])
     assert float((G_nc - G_nc.transpose(1, 2)).abs().max()) <= 1e-12 * float(G_nc.abs().max())
     for G in (G_rdd, G_bb):                                   # block-compact: blocks 0 and 5..8 are symmetric
         for b in (0, 5, 6, 7, 8):
@@ -195,7 +196,8 @@ def test_full_size_properties_config3(monkeypatch):
     for a, b in zip(serial, list(buf['sys']) + list(buf['grams'])):
         assert torch.equal(a, b)
     del serial
-    G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = buf['grams']
+    from pylrbms_amd.engine import expand_factored_grams
+    G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = expand_factored_grams(buf['grams'])
     assert float((G_nc - G_nc.transpose(1, 2)).abs().max()) <= 1e-12 * float(G_nc.abs().max())
     for G in (G_rdd, G_bb):
         for b in (0, 5, 6, 7, 8):

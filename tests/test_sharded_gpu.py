@@ -97,9 +97,10 @@ def _worker(rank, world, port, ref_path, results):
                 Vp[eng.S:] = V[eng.S:]
                 eng.ctx.project_estimate_fused(*args, phase=2)
             else:
-                buf = eng.project_and_estimate(V, eng.alloc_reduce_buffers(N), fused=fused)
+                buf = eng.project_and_estimate(V, eng.alloc_reduce_buffers(N, factored=bool(fused)), fused=fused)
+            from pylrbms_amd.engine import expand_factored_grams
             names = ('B_sys', 'rhs_red', 'E_red', 'M_red', 'G_nc', 'r_fd', 'G_rdd', 'G_bb', 'G_ab', 'G_aa')
-            for name, arr in zip(names, list(buf['sys']) + list(buf['grams'])):
+            for name, arr in zip(names, list(buf['sys']) + list(expand_factored_grams(buf['grams']))):
                 a = arr.cpu().numpy()
                 r = ref[name]
                 if name in ('B_sys', 'G_ab'):
