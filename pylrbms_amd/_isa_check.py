@@ -60,7 +60,9 @@ def _metadata(path):
 
 
 def _producer_loops(lines):
-    """Innermost loops (label ... back-branch) that contain an inline-asm global_load; returns (spans, in_asm flags)."""
+    """Loops that contain an inline-asm global_load, from LLVM's own loop annotations (``; =>This Inner Loop Header`` on
+    the header label, ``;   in Loop: Header=BBf_n`` on every other block of the loop).  Returns ([line indices of each
+    such loop], in_asm flags)."""
     in_asm, tags = False, []
     for ln in lines:
         s = ln.strip()
@@ -69,20 +71,21 @@ def _producer_loops(lines):
         tags.append(in_asm)
         if s.startswith(';;#ASMEND'):
             in_asm = False
-    labels = {}
-    for i, ln in enumerate(lines):
-        m = re.match(r'^(\.LBB\d+_\d+):', ln)
-        if m:
-            labels[m.group(1)] = i
-    spans = []
-    for i, ln in enumerate(lines):
-        m = re.match(r'\s+s_c?branch\w*\s+(\.LBB\d+_\d+)', ln)
-        if m and m.group(1) in labels and labels[m.group(1)] < i:
-            a = labels[m.group(1)]
-            if any(tags[k] and 'global_load' in lines[k] for k in range(a, i + 1)):
-                spans.append((a, i))
-    inner = [s for s in spans if not any(o != s and o[0] >= s[0] and o[1] <= s[1] for o in spans)]
-    return inner, tags
+    # split into basic blocks: a block starts at a label line or at a '; %bb.N:' comment
+    starts = [i for i, ln in enumerate(lines) if re.match(r'^(\.LBB\d+_\d+:|; %bb\.\d+:)', ln)]
+    starts.append(len(lines))
+    loops = {}
+    for k in range(len(starts) - 1):
+        head = lines[starts[k]]
+        m = re.match(r'^\.LBB\d+_(\d+):.*Loop Header', head)
+        owner = m.group(1) if m else None
+        if owner is None:
+            m = re.search(r'in Loop: Header=BB\d+_(\d+)', head)
+            owner = m.group(1) if m else None
+        if owner is not None:
+            loops.setdefault(owner, []).extend(range(starts[k], starts[k + 1]))
+    out = [idx for idx in loops.values() if any(tags[i] and 'global_load' in lines[i] for i in idx)]
+    return out, tags
 
 
 def check_fused_isa(asm_path):
@@ -92,7 +95,7 @@ def check_fused_isa(asm_path):
     report, problems = [], []
     seen = 0
     for name, lines in fns.items():
-        m = re.search(r'4k_f([12])I((?:Li\d+E)+)E', name)
+        m = re.search(r'\dk_f(1u|1|2)I((?:Li\d+E)+)E', name)
         if not m:
             continue
         kernel = 'k_f{}<{}>'.format(m.group(1), ','.join(re.findall(r'Li(\d+)E', m.group(2))))
@@ -114,7 +117,7 @@ def check_fused_isa(asm_path):
             elif in_asm and 'global_load' in ln:
                 first_asm_load = i
                 break
-        wide = m.group(1) == '1' and re.findall(r'Li(\d+)E', m.group(2))[0] == '4'
+        wide = m.group(1) in ('1', '1u') and re.findall(r'Li(\d+)E', m.group(2))[0] == '4'
         if (spills or scratch_lines or md.get('private_segment_fixed_size', 0)) and not wide:
             problems.append('{}: scratch {} bytes, {} spilled VGPRs'.format(kernel, md.get('private_segment_fixed_size'), spills))
         if spills > 8:
@@ -134,11 +137,12 @@ def check_fused_isa(asm_path):
             problems.append('{}: no producer loop with asm-managed prefetch found'.format(kernel))
             continue
         seen += 1
-        for a, b in loops:
-            asm_waits = sorted({lines[k].strip() for k in range(a, b + 1) if tags[k] and 'vmcnt' in lines[k]})
+        for idx in loops:
+            a, b = idx[0], idx[-1]
+            asm_waits = sorted({lines[k].strip() for k in idx if tags[k] and 'vmcnt' in lines[k]})
             counts = [int(x) for w in asm_waits for x in re.findall(r'vmcnt\((\d+)\)', w)]
-            own_waits = [lines[k].strip() for k in range(a, b + 1) if not tags[k] and re.search(r's_waitcnt.*vmcnt', lines[k])]
-            own_vmem = [lines[k].strip() for k in range(a, b + 1)
+            own_waits = [lines[k].strip() for k in idx if not tags[k] and re.search(r's_waitcnt.*vmcnt', lines[k])]
+            own_vmem = [lines[k].strip() for k in idx
                         if not tags[k] and re.match(r'\s+(global_|buffer_|scratch_|flat_)', lines[k])]
             if not counts or min(counts) == 0:
                 problems.append('{}: producer loop waits {} (expected one vmcnt(n), n > 0)'.format(kernel, asm_waits))

@@ -45,7 +45,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #if !defined(LRBMS_EXPERIMENT_BUILD) &&                                                                               \
     (defined(F1_NO_STAGE) || defined(F1_NO_APPLY) || defined(F1_NO_VALU_STAGE) || defined(F1_NO_MFMA) ||             \
      defined(F1_LDS_FILL) || defined(F1_PRODUCER_PRIO) || defined(F1_SPLIT_SIMD) || defined(F1_PF) ||                \
-     defined(F2_NO_STAGE) || defined(F2_NO_MFMA) || defined(THIN_RT_NOCOMPUTE) || defined(THIN_RT_NOSTORE))
+     defined(F2_NO_STAGE) || defined(F2_NO_MFMA) || defined(F1_TRACE))
 #error "experiment switch defined in a product build of fused.hip (use tools/build_variant.sh, which sets LRBMS_EXPERIMENT_BUILD)"
 #endif
 #ifndef F1_SPLIT_SIMD
@@ -53,6 +53,19 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef F1_PF
 #define F1_PF 1     // prefetch distance of the k_f1 producers in chunks (1 or 2; measured at config 3: 550 us vs 566 us)
+#endif
+#ifdef F1_TRACE   // experiment build: cycle stamps of producer wave 0 / consumer wave 4 of workgroup 0 (tools/f1_trace.py)
+__device__ unsigned long long g_f1_trace[2][64][8];
+#define F1_STAMP(role, c, k)                                                                                   \
+  do {                                                                                                         \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0 && (c) < 64)        \
+      g_f1_trace[role][c][k] = __builtin_amdgcn_s_memtime();                                                  \
+  } while (0)
+extern "C" int lrbms_debug_f1_trace(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_f1_trace), sizeof(g_f1_trace));
+}
+#else
+#define F1_STAMP(role, c, k) do {} while (0)
 #endif
 constexpr int EC = 4;               // elements per K-chunk (12 DG rows = 3 MFMA k-steps) = staging waves
 constexpr int F1_NTY = 7;           // Y column tiles per wave in k_f1
@@ -481,8 +494,11 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
       const int T = T0 + c * EC + wave;            // wave-uniform element
       double* Xb = &Xs[c & 1][0];
       double* Yb = &Ys[c & 1][0];
+      if (wave == 0) F1_STAMP(0, c, 0);
       load_set(c + F1_PF < nchunks ? T + F1_PF * EC : T, nxt);   // unconditional (tail: this element again): the wait counts loads
+      if (wave == 0) F1_STAMP(0, c, 1);
       wait_set(cur);
+      if (wave == 0) F1_STAMP(0, c, 2);
 #ifndef F1_NO_STAGE   // timing experiments (tools/build_variant.sh): producers only load and synchronise
 #ifndef F1_NO_APPLY
       // ---- the stacked four-block applies on the matrix pipe
@@ -498,6 +514,7 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
           Yb[doff[rr][ct]] = D[ct][rr];
+      if (wave == 0) F1_STAMP(0, c, 3);
 #endif
       // ---- X rows: the own rows sit in the B operand of k-step 0 (lanes kq < 3 hold row kq); the padding columns
       // N .. 16 NTX - 1 get the clamped last column: they only reach output rows >= N, which are never stored
@@ -558,7 +575,9 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
         }
       }
 #endif
+      if (wave == 0) F1_STAMP(0, c, 4);
       lds_barrier();                               // barrier c: buffer c & 1 is complete (global loads stay in flight)
+      if (wave == 0) F1_STAMP(0, c, 5);
     };
     int c = 0;
     if (F1_PF == 2) {
@@ -699,7 +718,9 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
 #pragma unroll
       for (int jj = 0; jj < NTY; ++jj) acc[i][jj] = (d4){0.0, 0.0, 0.0, 0.0};
     for (int c = 0; c < nchunks; ++c) {
+      if (cw == 0) F1_STAMP(1, c, 0);
       lds_barrier();                               // barrier c
+      if (cw == 0) F1_STAMP(1, c, 1);
       const double* Xb = &Xs[c & 1][0];
       const double* Yb = &Ys[c & 1][0];
 #ifndef F1_NO_MFMA    // timing experiments: consumers only synchronise
@@ -716,6 +737,7 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
         }
       }
 #endif
+      if (cw == 0) F1_STAMP(1, c, 2);
     }
     lds_barrier();                                 // final barrier
     // ---- epilogue: scatter the tiles to their destination arrays (static accumulator indices only)
@@ -755,6 +777,392 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
         a.rhs_red[(long)s * N + tid] = sum;
       else
         unsafeAtomicAdd(a.rhs_red + (long)s * N + tid, sum);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F1, unified-role form (compile-time Q, every column group in one slice: the configurations of BASELINE.json).
+//
+// What the producer / consumer form above runs into on gfx950 (tools/ubench/overlap64.hip, occ64.hip, tools/f1_trace.py):
+// while a wave streams v_mfma_f64_16x16x4 (68-70 cycles each, no pipelining between them), every other wave of the same
+// SIMD is starved -- f64 FMAs, integer VALU, LDS and global-memory instructions alike; a second workgroup per CU does not
+// fill the gaps either.  So a SIMD's time is (MFMA issue) + (everything else), never the maximum of the two, and in the
+// producer / consumer form the "everything else" of a chunk was ONE latency-bound producer wave per SIMD (3 850 of the
+// 8 250 cycles per chunk) while the consumer wave sat at the barrier.
+//
+// Here all eight waves alternate between the two kinds of work, chunk by chunk:
+//   stage(c):  waves 0-3 (role A, element 4 c + w): the stacked four-block applies A_q V, P V on the matrix pipe, the X
+//              rows, b . v, the mass group; waves 4-7 (role B, element 4 c + w - 4): K_T v, the c^{qq'} K V groups and
+//              the A_ab R groups (the v_readlane-heavy part).  Two waves per SIMD share the staging of one element, so
+//              their latencies overlap; every wave's global loads are a prefetch set issued one chunk ahead (asm loads +
+//              hand-counted s_waitcnt vmcnt(n), see gload_f64) that lands during the MFMA burst in between.
+//   barrier c
+//   mfma(c):   all eight waves; wave w owns 4 (w < 4) or 3 (w >= 4) of its SIMD's 7 column tiles x NTX row tiles.
+// One barrier per chunk: a wave reaches stage(c + 1) (writes buffer (c + 1) & 1) only after its own mfma(c), and every
+// wave finished mfma(c - 1) -- the last reader of that buffer -- before it arrived at barrier c.
+template <int NTX, int QP, int ROLE>
+__device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double* __restrict__ Xs, double* __restrict__ Ys,
+                                         const double* __restrict__ Kl, double* __restrict__ red, const Grp* grp, int ng) {
+  constexpr int LDX = padded_ld(NTX);
+  constexpr int NTYS = F1_NTY;                         // column tiles per SIMD (waves w and w + 4)
+  constexpr int LDY = 4 * NTYS * 16 + 16;
+  constexpr int NT = ROLE == 0 ? (NTYS + 1) / 2 : NTYS / 2;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = uniform(tid >> 6), e = wave & 3;    // e: element of the chunk this wave stages, SIMD it runs on
+  const int tile0 = e * NTYS + (ROLE == 0 ? 0 : (NTYS + 1) / 2);
+  const int N = a.N, S = a.S, QN = QP * N;
+  const int ncols = ng * N;
+  const int ksplit = gridDim.z;
+  const int nchunks = t.nT / EC / ksplit;
+  const int T0 = blockIdx.z * nchunks * EC;
+  const double* Vs = a.V + (long)s * t.n * N;
+  const int j = lane;
+  const bool colj = j < N;
+  const int jc = colj ? j : N - 1;                     // idle lanes load (and never use) the last column: no exec masking
+  const bool do_rhs = ROLE == 0 && a.rhs_red != nullptr;
+  double rhs_part = 0.0;
+
+  d4 acc[NTX][NT];
+#pragma unroll
+  for (int i = 0; i < NTX; ++i)
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) acc[i][jt] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  auto mfma_phase = [&](int c) {
+    const double* Xb = Xs + (c & 1) * 3 * EC * LDX;
+    const double* Yb = Ys + (c & 1) * 3 * EC * LDY;
+#pragma unroll
+    for (int kk = 0; kk < 3 * EC; kk += 4) {
+      double av[NTX];
+#pragma unroll
+      for (int i = 0; i < NTX; ++i) av[i] = Xb[(kk + lk) * LDX + i * 16 + li];
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {                // tiles beyond ncols multiply zero columns (harmless, branch-free)
+        const double bv = Yb[(kk + lk) * LDY + (tile0 + jt) * 16 + li];
+#pragma unroll
+        for (int i = 0; i < NTX; ++i) acc[i][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[i][jt], 0, 0, 0);
+      }
+    }
+  };
+  auto tie = [](double& v) { asm volatile("" : "+v"(v)); };
+
+  if constexpr (ROLE == 0) {
+    // ------------------------------------------------------------- role A: applies on the matrix pipe, X rows, rhs, mass
+    constexpr int R = 3 * (QP + 1);
+    constexpr int NLOADS = 3 + 3 * NTX + 3;
+    static_assert(NLOADS <= 63, "vmcnt is a 6-bit counter");
+    struct Set {
+      double A[3], B[3][NTX], v0[3];
+    };
+    const int r16 = li, kq = lk;
+    const double* asrc[3];
+    int bbk[3], ck[3], colB[NTX], doff[3][NTX];
+    {
+      const int g = r16 / 3 < QP + 1 ? r16 / 3 : QP, i = r16 % 3;   // rows >= R repeat a valid row; they are never stored
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const int k = 4 * ks + kq, bb = k / 3, cc = k - 3 * bb;
+        asrc[ks] = (g < QP ? a.A_diag + ((long)g * S + s) * t.nT * 36 : a.P_diag + (long)s * t.nT * 36) + bb * 9 + i * 3 + cc;
+        bbk[ks] = bb;
+        ck[ks] = cc;
+      }
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) colB[ct] = 16 * ct + r16 < N ? 16 * ct + r16 : N - 1;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {           // LDS offset of output (row kq + 4 rr, column 16 ct + r16): group r / 3, local
+        const int r = kq + 4 * rr;               // row r % 3 -- or a dump slot in the row padding (never read)
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct)
+          doff[rr][ct] = (r < R && 16 * ct + r16 < N) ? (3 * e + r % 3) * LDY + (r / 3) * N + 16 * ct + r16
+                                                       : (3 * e) * LDY + 4 * NTYS * 16 + r16;
+      }
+    }
+    const cint_p nbc = (cint_p)t.nb_elem;     // template adjacency of the (wave-uniform) element through the scalar cache
+    // Wave-uniform data of an element (its three in-subdomain neighbours, b_T, |T|) comes through the scalar cache.  A
+    // scalar load issued where its value is needed exposes its whole latency (the wave has nothing else to issue), so
+    // these are fetched one stage ahead as well: `Sc` of the element staged NEXT is requested at the start of a stage
+    // and first read in the following one, after an MFMA phase.
+    struct Sc {
+      int nb[3];
+      double be[3], area;
+    };
+    auto load_sc = [&](int T, Sc& x) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) x.nb[f] = nbc[T * 3 + f];
+      const cdbl_p be = (cdbl_p)(a.b + (long)s * t.n + 3 * T);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) x.be[i] = be[i];
+      x.area = ((cdbl_p)t.area)[T];
+    };
+    auto load_set = [&](int T, const Sc& sc, Set& x) {
+      // A face without an in-subdomain neighbour has an all-zero block in A_diag / P_diag (its coupling lives in A_cpl),
+      // so its rows may be any finite values: the element's own rows, which keeps every load unconditional.
+      int nbT[4];
+      nbT[0] = T;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) nbT[1 + f] = sc.nb[f] >= 0 ? sc.nb[f] : T;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) x.A[ks] = gload_f64(asrc[ks] + (long)T * 36);
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const int el = bbk[ks] == 0 ? nbT[0] : bbk[ks] == 1 ? nbT[1] : bbk[ks] == 2 ? nbT[2] : nbT[3];
+        const double* rowp = Vs + (long)(3 * el + ck[ks]) * N;
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) x.B[ks][ct] = gload_f64(rowp + colB[ct]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) x.v0[i] = gload_f64(Vs + (long)(3 * T + i) * N + jc);
+    };
+    auto tie_set = [&](Set& x) {
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        tie(x.A[ks]);
+        tie(x.v0[ks]);
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) tie(x.B[ks][ct]);
+      }
+    };
+    // stage c: `cur` / `sc_cur` belong to element T (chunk c), `nxt` / `sc_nxt` to the element of chunk c + 1 (requested
+    // in stage c - 1), `sc_far` receives the scalars of chunk c + 2
+    auto stage = [&](int c, Set& cur, Set& nxt, const Sc& sc_cur, const Sc& sc_nxt, Sc& sc_far) {
+      const int T = T0 + c * EC + e;               // wave-uniform element
+      double* Xb = Xs + (c & 1) * 3 * EC * LDX;
+      double* Yb = Ys + (c & 1) * 3 * EC * LDY;
+      if (e == 0) F1_STAMP(0, c, 0);
+      load_sc(c + 2 < nchunks ? T + 2 * EC : T, sc_far);
+      load_set(c + 1 < nchunks ? T + EC : T, sc_nxt, nxt);   // unconditional (tail: this element again): the wait counts loads
+      if (e == 0) F1_STAMP(0, c, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS));
+      tie_set(cur);
+      if (e == 0) F1_STAMP(0, c, 2);
+      d4 D[NTX];
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) D[ct] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) D[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.A[ks], cur.B[ks][ct], D[ct], 0, 0, 0);
+      // X rows: the own rows sit in the B operand of k-step 0 (lanes kq < 3 hold row kq); the padding columns N .. 16 NTX - 1
+      // get the clamped last column: they only reach output rows >= N, which are never stored
+      if (kq < 3) {
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) Xb[(3 * e + kq) * LDX + 16 * ct + r16] = cur.B[0][ct];
+      }
+      if (colj) {
+        if (do_rhs) rhs_part += sc_cur.be[0] * cur.v0[0] + sc_cur.be[1] * cur.v0[1] + sc_cur.be[2] * cur.v0[2];
+        const double m = sc_cur.area * (1.0 / 12.0), sum = cur.v0[0] + cur.v0[1] + cur.v0[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Yb[(3 * e + i) * LDY + (QP + 1) * N + j] = m * (sum + cur.v0[i]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) Yb[doff[rr][ct]] = D[ct][rr];
+      if (e == 0) F1_STAMP(0, c, 3);
+    };
+    Set s0, s1;
+    Sc c0, c1, c2;
+    load_sc(T0 + e, c0);
+    load_sc(nchunks > 1 ? T0 + EC + e : T0 + e, c1);
+    load_set(T0 + e, c0, s0);
+    // nT is a multiple of 8, so nchunks is even; the scalar sets rotate with period 3, hence six stages per round
+    auto round = [&](int c, Set& sa, Set& sb, Sc& x0, Sc& x1, Sc& x2) {
+      stage(c, sa, sb, x0, x1, x2);
+      lds_barrier();
+      if (e == 0) F1_STAMP(0, c, 4);
+      mfma_phase(c);
+      if (e == 0) F1_STAMP(0, c, 5);
+    };
+    int c = 0;
+    for (; c + 6 <= nchunks; c += 6) {
+      round(c, s0, s1, c0, c1, c2);
+      round(c + 1, s1, s0, c1, c2, c0);
+      round(c + 2, s0, s1, c2, c0, c1);
+      round(c + 3, s1, s0, c0, c1, c2);
+      round(c + 4, s0, s1, c1, c2, c0);
+      round(c + 5, s1, s0, c2, c0, c1);
+    }
+    if (c < nchunks) { round(c, s0, s1, c0, c1, c2); ++c; }
+    if (c < nchunks) { round(c, s1, s0, c1, c2, c0); ++c; }
+    if (c < nchunks) { round(c, s0, s1, c2, c0, c1); ++c; }
+    if (c < nchunks) { round(c, s1, s0, c0, c1, c2); ++c; }
+    // the set loaded by the tail step is never consumed; it must count as live until its loads have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie_set(s0);
+    tie_set(s1);
+    if (do_rhs) red[e * 64 + lane] = rhs_part;
+  } else {
+    // ------------------------------------------------------------- role B: K_T v, c^{qq'} K V and A_ab R groups
+    constexpr int NLOADS = 3 + 3 * QP + 1;
+    struct Set {
+      double v0[3], rv[3][QP], ab;
+    };
+    const double* Rs = a.Rself + (long)s * t.nrt * QN;
+    // the element's A_ab^q blocks and c^{qq'}: one entry per lane in a prefetch register, broadcast with v_readlane
+    // (through the scalar cache into SGPRs instead they cost 44 SGPRs held across the MFMA phase: the kernel then spills
+    // SGPRs and runs 10 % slower -- measured)
+    const double* absrc = a.Aab + (long)s * t.nT * 9;   // lanes beyond the record re-read its first entry
+    int abstr = 9;
+    if (lane < 9 * QP) {
+      absrc = a.Aab + ((long)(lane / 9) * S + s) * t.nT * 9 + lane % 9;
+    } else if (lane < 9 * QP + QP * QP) {
+      absrc = a.caa + ((long)(lane - 9 * QP) * S + s) * t.nT;
+      abstr = 1;
+    }
+    const cint_p rtc = (cint_p)t.elem_rt;
+    struct Sc {       // RT0 rows of the element's three faces, fetched through the scalar cache one stage ahead (see role A)
+      int rt[3];
+    };
+    auto load_sc = [&](int T, Sc& x) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) x.rt[f] = rtc[T * 3 + f];
+    };
+    auto load_set = [&](int T, const Sc& sc, Set& x) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) x.v0[i] = gload_f64(Vs + (long)(3 * T + i) * N + jc);
+#pragma unroll
+      for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int q2 = 0; q2 < QP; ++q2) x.rv[f][q2] = gload_f64(Rs + (long)sc.rt[f] * QN + q2 * N + jc);
+      x.ab = gload_f64(absrc + (long)T * abstr);
+    };
+    auto tie_set = [&](Set& x) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        tie(x.v0[f]);
+#pragma unroll
+        for (int q2 = 0; q2 < QP; ++q2) tie(x.rv[f][q2]);
+      }
+      tie(x.ab);
+    };
+    auto stage = [&](int c, Set& cur, Set& nxt, const Sc& sc_nxt, Sc& sc_far) {
+      const int T = T0 + c * EC + e;
+      double* Yb = Ys + (c & 1) * 3 * EC * LDY;
+      if (e == 0) F1_STAMP(1, c, 0);
+      load_sc(c + 2 < nchunks ? T + 2 * EC : T, sc_far);
+      load_set(c + 1 < nchunks ? T + EC : T, sc_nxt, nxt);
+      if (e == 0) F1_STAMP(1, c, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS));
+      tie_set(cur);
+      if (e == 0) F1_STAMP(1, c, 2);
+      if (colj) {
+        double kv[3];
+        const double* K = Kl + T * 9;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          kv[i] = __builtin_fma(K[i * 3 + 2], cur.v0[2], __builtin_fma(K[i * 3 + 1], cur.v0[1], K[i * 3] * cur.v0[0]));
+        int g = QP + 2;
+        auto put = [&](const double (&y)[3]) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) Yb[(3 * e + i) * LDY + g * N + j] = y[i];
+          ++g;
+        };
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+#pragma unroll
+          for (int q2 = q; q2 < QP; ++q2) {
+            const double cc = bcast_d(cur.ab, 9 * QP + q * QP + q2);
+            const double y[3] = {cc * kv[0], cc * kv[1], cc * kv[2]};
+            put(y);
+          }
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+          double A[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) A[i] = bcast_d(cur.ab, 9 * q + i);
+#pragma unroll
+          for (int q2 = 0; q2 < QP; ++q2) {
+            double y[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              y[i] = __builtin_fma(A[i * 3 + 2], cur.rv[2][q2], __builtin_fma(A[i * 3 + 1], cur.rv[1][q2], A[i * 3] * cur.rv[0][q2]));
+            put(y);
+          }
+        }
+      }
+      if (e == 0) F1_STAMP(1, c, 3);
+    };
+    Set s0, s1;
+    Sc c0, c1;
+    load_sc(T0 + e, c0);
+    load_set(T0 + e, c0, s0);
+    load_sc(nchunks > 1 ? T0 + EC + e : T0 + e, c0);       // scalars of chunk 1 (used by stage 0), then alternating
+    auto round = [&](int c, Set& sa, Set& sb, Sc& x0, Sc& x1) {
+      stage(c, sa, sb, x0, x1);
+      lds_barrier();
+      if (e == 0) F1_STAMP(1, c, 4);
+      mfma_phase(c);
+      if (e == 0) F1_STAMP(1, c, 5);
+    };
+    for (int c = 0; c < nchunks; c += 2) {                   // nT is a multiple of 8, so nchunks is even
+      round(c, s0, s1, c0, c1);
+      round(c + 1, s1, s0, c1, c0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie_set(s0);
+    tie_set(s1);
+  }
+  // ---- epilogue: scatter the tiles to their destination arrays (static accumulator indices only)
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int col = (tile0 + jt) * 16 + li;
+    const bool live = col < ncols;
+    const int g = live ? col / N : 0, jj = col - g * N;
+    const int ld = grp[g].ld;
+    double* dst = grp[g].dst + (long)s * grp[g].sstride + jj;
+    double* dst_t = grp[g].dst_t ? grp[g].dst_t + (long)s * grp[g].sstride + (long)jj * ld : nullptr;
+#pragma unroll
+    for (int i = 0; i < NTX; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + lk + 4 * r;
+        const double val = acc[i][jt][r];
+        if (live && row < N) {
+          if (ksplit == 1) {
+            dst[(long)row * ld] = val;
+            if (dst_t) dst_t[row] = val;
+          } else {
+            unsafeAtomicAdd(dst + (long)row * ld, val);
+            if (dst_t) unsafeAtomicAdd(dst_t + row, val);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NTX, int QP>
+__global__ __launch_bounds__(512, 2) void k_f1u(Tmpl t, F1Args a, GrpTable gt) {
+  constexpr int LDX = padded_ld(NTX);
+  constexpr int LDY = 4 * F1_NTY * 16 + 16;
+  extern __shared__ double Kl[];               // template stiffness K_T [nT][9] (same for all subdomains)
+  __shared__ double Xs[2 * 3 * EC * LDX];
+  __shared__ double Ys[2 * 3 * EC * LDY];
+  __shared__ double red[EC * 64];
+  __shared__ Grp grp[F1_MAXG];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int g = 0; g < F1_MAXG; ++g)
+    if (tid == g) grp[g] = gt.g[g];
+  for (int i = tid; i < 9 * t.nT; i += 512) Kl[i] = t.stiff[i];
+  for (int i = tid; i < 2 * 3 * EC * LDX; i += 512) Xs[i] = 0.0;
+  for (int i = tid; i < 2 * 3 * EC * LDY; i += 512) Ys[i] = 0.0;
+  __syncthreads();
+  const int ng = gt.n;
+  if (uniform(tid >> 6) < EC)
+    f1u_body<NTX, QP, 0>(t, a, Xs, Ys, Kl, red, grp, ng);
+  else
+    f1u_body<NTX, QP, 1>(t, a, Xs, Ys, Kl, red, grp, ng);
+  if (a.rhs_red != nullptr) {   // fixed-order sum over the EC role-A waves
+    __syncthreads();
+    if (tid < a.N) {
+      double sum = 0.0;
+      for (int w = 0; w < EC; ++w) sum += red[w * 64 + tid];
+      if (gridDim.z == 1)
+        a.rhs_red[(long)blockIdx.x * a.N + tid] = sum;
+      else
+        unsafeAtomicAdd(a.rhs_red + (long)blockIdx.x * a.N + tid, sum);
     }
   }
 }
@@ -1770,9 +2178,13 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       }
       const dim3 grid(S, nsl, ksplit);
       KScope ks(ctx, "k_f1", st);
+      const size_t ldsf1u = sizeof(double) * 9 * t.nT;
+      const bool legacy = getenv("LRBMS_F1_LEGACY") != nullptr;   // A/B: the producer / consumer form of the same kernel
 #define LRBMS_F1(NTXV)                                                                                              \
   do {                                                                                                              \
-    if (Q == 1 && one_slice) hipLaunchKernelGGL((k_f1<NTXV, NTY, 1>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);      \
+    if (Q == 1 && one_slice && !legacy) hipLaunchKernelGGL((k_f1u<NTXV, 1>), grid, dim3(512), ldsf1u, st, t, a, gt[0]);            \
+    else if (Q == 2 && one_slice && !legacy) hipLaunchKernelGGL((k_f1u<NTXV, 2>), grid, dim3(512), ldsf1u, st, t, a, gt[0]);       \
+    else if (Q == 1 && one_slice) hipLaunchKernelGGL((k_f1<NTXV, NTY, 1>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]); \
     else if (Q == 2 && one_slice) hipLaunchKernelGGL((k_f1<NTXV, NTY, 2>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]); \
     else hipLaunchKernelGGL((k_f1<NTXV, NTY, 0>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);             \
   } while (0)
@@ -1780,7 +2192,11 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
         case 1: LRBMS_F1(1); break;
         case 2: LRBMS_F1(2); break;
         case 3: LRBMS_F1(3); break;
-        default: LRBMS_F1(4); break;
+        default:   // N = 49 .. 64: 16 accumulator tiles + two prefetch sets per wave would spill in the unified form
+          if (Q == 1 && one_slice) hipLaunchKernelGGL((k_f1<4, NTY, 1>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);
+          else if (Q == 2 && one_slice) hipLaunchKernelGGL((k_f1<4, NTY, 2>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);
+          else hipLaunchKernelGGL((k_f1<4, NTY, 0>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);
+          break;
       }
 #undef LRBMS_F1
       LRBMS_LAUNCH_CHECK(ctx);
@@ -1833,6 +2249,9 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     F2Args a{Rself, Bbb, b, ctx->nbr, G_bb, G_rdd, r_fd, Q, N, S, gstride};
     const int nr = (QN + 15) / 16;
     const size_t ldsf2 = sizeof(double) * 4 * t.nT + sizeof(int) * 3 * t.nT;
+    // (A unified-role form of this kernel as for k_f1 -- all eight waves stage, chunks of eight elements -- was measured
+    // and dropped: its 98 KB of LDS leave one workgroup per CU, 136 us against 126 us for three co-resident workgroups of
+    // this producer / consumer form; here the MFMA share is small, so other workgroups do fill the producers' latencies.)
     KScope ks(ctx, "k_f2", s_f23);
     switch (nr) {
       case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
