@@ -176,6 +176,18 @@ int lrbms_project_estimate_fused(lrbms_ctx* ctx, int32_t Q, int32_t N, const dou
  * stream may land on the queue of the caller's stream and serialise behind the dense kernels). */
 void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
 
+/* Conventions the reference tree does not determine, switchable per context so that a value pinned
+ * later against the reference can be matched without touching the kernels.  Set before lrbms_assemble_* / the passes.
+ *   LRBMS_OPT_OSWALD_ZERO_ON_SUBDOMAIN_BOUNDARY  0 (default): the Oswald interpolant vanishes on the physical boundary;
+ *       1: on the whole boundary of the subdomain -- discretize_elliptic_block_swipdg.py:108-113 passes an all-Dirichlet
+ *       boundary info on the subdomain layer to apply_oswald_interpolation_operator
+ *   LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q       0 (default): one coupling matrix per affine component; 1: component q
+ *       carries the coupling terms of all components q' <= q, as discretize_elliptic_block_swipdg.py:551-565 (matrices
+ *       allocated once) with :581-583 (assembled into for every lambda) would if the assembler does not zero them */
+#define LRBMS_OPT_OSWALD_ZERO_ON_SUBDOMAIN_BOUNDARY 1
+#define LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q 2
+int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value);
+
 /* Per-kernel device timing of the fused pass (measurement only; the reference has wall-clock prints around
  * rd.solve / rd.estimate, python/scripts/linearelliptic_block_swipdg_decomp.py:67-75).  While enabled, every kernel of
  * lrbms_project_estimate_fused(_phase) is bracketed by a HIP event pair on the stream it is launched on;

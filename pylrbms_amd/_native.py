@@ -33,6 +33,7 @@ SIGNATURES = {
     'lrbms_ctx_destroy': (ctypes.c_int, [c_vp]),
     'lrbms_last_error': (ctypes.c_char_p, [c_vp]),
     'lrbms_ctx_aux_stream': (c_vp, [c_vp, c_i32]),
+    'lrbms_ctx_set_option': (ctypes.c_int, [c_vp, c_i32, c_i32]),
     'lrbms_kernel_timing': (ctypes.c_int, [c_vp, c_i32]),
     'lrbms_kernel_timing_read': (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), c_i32,
                                                 ctypes.POINTER(c_i32)]),
@@ -473,6 +474,14 @@ class NativeContext:
         rc = self.lib.lrbms_reduced_precond_use(self.handle, int(pc._lrbms_N) if pc is not None else 0,
                                                 c_vp(pc.data_ptr()) if pc is not None else None)
         self._check(rc, 'lrbms_reduced_precond_use')
+
+    OPTIONS = {'oswald_zero_on_subdomain_boundary': 1, 'accumulate_coupling_across_q': 2}
+
+    def set_option(self, name, value):
+        """Switch one of the conventions the reference tree leaves open (include/lrbms_hip.h, LRBMS_OPT_*)."""
+        if name not in self.OPTIONS:
+            raise NativeError('unknown option {!r}; known: {}'.format(name, sorted(self.OPTIONS)))
+        self._check(self.lib.lrbms_ctx_set_option(self.handle, self.OPTIONS[name], 1 if value else 0), 'lrbms_ctx_set_option')
 
     def kernel_timing(self, enable):
         """Bracket every kernel of the fused pass by HIP events on its own stream (measurement only)."""

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_oswald(Tmpl t, int S, const int* __rest
     bool dirichlet = false;
     for (int sd = 0; sd < 4; ++sd) {
       if (vside[sd] < 0) continue;
-      if (nbr[s * 5 + side_to_slot(sd)] < 0)
+      if (nbr[s * 5 + side_to_slot(sd)] < 0 || t.opt_oswald_subdomain)
         dirichlet = true;
       else
         cnt += t.vdof_ptr[vside[sd] + 1] - t.vdof_ptr[vside[sd]];

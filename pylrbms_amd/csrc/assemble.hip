@@ -137,6 +137,17 @@ __global__ __launch_bounds__(256) void k_assemble_swipdg(Tmpl t, int S, int S_ex
         load_other_side(t, lam_q + ((long)s2 * t.nT + e2) * LRBMS_NS, e2, t.nb_face_out[e * 3 + f], nx, ny, p);
         double so[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         swipdg_inner(m, p, len, delta, blk[0], so);
+        if (t.opt_accumulate_coupling) {
+          // the reference allocates its coupling matrices once and assembles every component into them
+          // (block_swipdg.py:551-565, :581-583): component q sees the coupling terms of all components q' <= q
+          for (int q2 = 0; q2 < q; ++q2) {
+            const double* lam_q2 = lam + (long)q2 * S_ext * t.nT * LRBMS_NS;
+            FaceSide m2, p2;
+            load_self_side(t, lam_q2 + ((long)s * t.nT + e) * LRBMS_NS, e, f, nx, ny, m2);
+            load_other_side(t, lam_q2 + ((long)s2 * t.nT + e2) * LRBMS_NS, e2, t.nb_face_out[e * 3 + f], nx, ny, p2);
+            swipdg_inner(m2, p2, len, delta, blk[0], so);
+          }
+        }
         double* out = A_cpl + ((((long)q * S + s) * 4 + side) * t.ncf + t.elem_side_pos[e * 3 + f]) * 9;
         for (int i = 0; i < 9; ++i) out[i] = so[i];
       } else {

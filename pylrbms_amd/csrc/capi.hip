@@ -117,6 +117,17 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i) { return (ctx && i >= 0 &&
 
 const char* lrbms_last_error(lrbms_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value) {
+  if (!ctx) return LRBMS_E_INVALID;
+  if (value != 0 && value != 1) return lrbms_fail(ctx, LRBMS_E_INVALID, "set_option: value must be 0 or 1");
+  switch (option) {
+    case LRBMS_OPT_OSWALD_ZERO_ON_SUBDOMAIN_BOUNDARY: ctx->t.opt_oswald_subdomain = value; break;
+    case LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q: ctx->t.opt_accumulate_coupling = value; break;
+    default: return lrbms_fail(ctx, LRBMS_E_INVALID, "set_option: unknown option");
+  }
+  return LRBMS_OK;
+}
+
 int lrbms_kernel_timing(lrbms_ctx* ctx, int32_t enable) {
   if (!ctx) return LRBMS_E_INVALID;
   ctx->ktime = enable != 0;

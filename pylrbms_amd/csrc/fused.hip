@@ -135,7 +135,7 @@ __device__ inline OsInfo oswald_vertex(const Tmpl& t, const int* nbr_s, int v) {
   bool dirichlet = false;
   for (int sd = 0; sd < 4; ++sd) {
     if (o.vside[sd] < 0) continue;
-    if (nbr_s[side_to_slot(sd)] < 0)
+    if (nbr_s[side_to_slot(sd)] < 0 || t.opt_oswald_subdomain)
       dirichlet = true;
     else
       cnt += t.vdof_ptr[o.vside[sd] + 1] - t.vdof_ptr[o.vside[sd]];
@@ -810,7 +810,10 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
   constexpr int NT = ROLE == 0 ? (NTYS + 1) / 2 : NTYS / 2;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6), e = wave & 3;    // e: element of the chunk this wave stages, SIMD it runs on
-  const int tile0 = e * NTYS + (ROLE == 0 ? 0 : (NTYS + 1) / 2);
+  // column tiles are dealt round-robin over the SIMDs (tile 4 k + e belongs to SIMD e; role A takes the even k, role B the
+  // odd ones), so that basis sizes whose groups fill only part of the 4 NTYS tiles still load every SIMD evenly; tiles
+  // beyond the last column are skipped (wave-uniform branch)
+  auto tile_of = [&](int jt) { return 4 * (2 * jt + (ROLE == 0 ? 0 : 1)) + e; };
   const int N = a.N, S = a.S, QN = QP * N;
   const int ncols = ng * N;
   const int ksplit = gridDim.z;
@@ -838,8 +841,9 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
 #pragma unroll
       for (int i = 0; i < NTX; ++i) av[i] = Xb[(kk + lk) * LDX + i * 16 + li];
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {                // tiles beyond ncols multiply zero columns (harmless, branch-free)
-        const double bv = Yb[(kk + lk) * LDY + (tile0 + jt) * 16 + li];
+      for (int jt = 0; jt < NT; ++jt) {
+        if (tile_of(jt) * 16 >= ncols) continue;       // wave-uniform
+        const double bv = Yb[(kk + lk) * LDY + tile_of(jt) * 16 + li];
 #pragma unroll
         for (int i = 0; i < NTX; ++i) acc[i][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[i][jt], 0, 0, 0);
       }
@@ -1106,7 +1110,7 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
   // ---- epilogue: scatter the tiles to their destination arrays (static accumulator indices only)
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
-    const int col = (tile0 + jt) * 16 + li;
+    const int col = tile_of(jt) * 16 + li;
     const bool live = col < ncols;
     const int g = live ? col / N : 0, jj = col - g * N;
     const int ld = grp[g].ld;

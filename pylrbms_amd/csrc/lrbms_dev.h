@@ -24,6 +24,11 @@ struct Tmpl {
   const int* touch_vtx;      // [4][ntouch][3]     lattice vertex of local DoF i of the p-th element touching side sd
   const int* touch_pos;      // [4][ntouch][3][4]  its position along side sd', or -1 if it is not on that side
   const int* touch_mask;     // [4][ntouch]        bit sd' set if the element has a vertex on side sd'
+  // conventions the reference tree leaves open (lrbms_ctx_set_option; defaults = DESIGN.md section 3)
+  int opt_oswald_subdomain;      // 1: the Oswald interpolant vanishes on the WHOLE subdomain boundary (block_swipdg.py:108-113 read
+                                 //    literally: all-Dirichlet boundary info on the subdomain layer), 0: on the physical boundary only
+  int opt_accumulate_coupling;   // 1: coupling matrices accumulate across the affine components q (block_swipdg.py:551-565 vs
+                                 //    :581-583), 0: one coupling matrix per component
 };
 
 struct lrbms_ctx {

@@ -55,8 +55,9 @@ def sample_function(fn, x, centers, keys, volume_only=False):
 class Engine:
     """All device state of one rank for one discretization."""
 
-    def __init__(self, grid, lambda_funcs, kappa, f, lambda_bar, lambda_hat, theta_bar, device_index=0):
-        self._init_args = (lambda_funcs, kappa, f, lambda_bar, lambda_hat, theta_bar, device_index)
+    def __init__(self, grid, lambda_funcs, kappa, f, lambda_bar, lambda_hat, theta_bar, device_index=0, conventions=None):
+        self._init_args = (lambda_funcs, kappa, f, lambda_bar, lambda_hat, theta_bar, device_index, conventions)
+        self.conventions = dict(conventions or {})
         self.grid = grid
         t = grid.template
         self.t = t
@@ -80,6 +81,8 @@ class Engine:
         self.kappa = kap
         self.ctx = NativeContext(device_index)
         self.ctx.mesh_upload(t, kap, nbr, self.S, self.S_ext)
+        for name, value in self.conventions.items():          # conventions the reference leaves open (LRBMS_OPT_*)
+            self.ctx.set_option(name, value)
         self.hdiam = grid.subdomain_diameter(0)
 
         # ---- coefficient sampling on the host, then one H2D copy each

@@ -94,12 +94,12 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / scale)
 
 
-def compare_all(p, engine, V, mu, do_solve=True):
+def compare_all(p, engine, V, mu, do_solve=True, oracle=None):
     """Run the HIP path and the oracle on the same inputs; return {name: relative max error}."""
     from pylrbms_amd.engine import blockell_to_dense, coupling_to_dense
     grid = p['grid']
     t = grid.template
-    d = oracle_from_problem(p)
+    d = oracle if oracle is not None else oracle_from_problem(p)
     S, n, Q = d.S, d.n, d.Q
     N = V.shape[2]
     res = {}

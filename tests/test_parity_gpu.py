@@ -339,3 +339,34 @@ def test_two_level_preconditioner_and_prebuilt_form(monkeypatch):
     ref3 = np.stack(rd3.solve(mus[0]))
     assert np.linalg.norm(u3.cpu().numpy() - ref3) < 1e-10 * np.linalg.norm(ref3)
     eng.ctx.reduced_precond_use(None)
+
+
+@pytest.mark.parametrize('conv, okw', [
+    ({'accumulate_coupling_across_q': True}, {'accumulate_coupling_across_q': True}),
+    ({'oswald_zero_on_subdomain_boundary': True}, {'oswald_zero_on': 'subdomain'}),
+    ({'accumulate_coupling_across_q': True, 'oswald_zero_on_subdomain_boundary': True},
+     {'accumulate_coupling_across_q': True, 'oswald_zero_on': 'subdomain'}),
+])
+def test_open_conventions_are_switchable_in_the_kernels(conv, okw):
+    """The conventions the reference tree leaves open (coupling matrices accumulated across the affine components,
+    block_swipdg.py:551-565 vs :581-583; Oswald interpolant zero on the whole subdomain boundary, :108-113) as switches of the
+    HIP path (lrbms_ctx_set_option), against the oracle's flags on an unsymmetric problem: assembled blocks, every projected
+    array (fused in both layouts and unfused) and the estimator triple."""
+    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd.engine import Engine
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': [3, 2], 'coarse_per_subdomain': 2})
+    lam = p['lambda']
+    eng = Engine(p['grid'], lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], theta_bar_of(p),
+                 conventions=conv).assemble()
+    d = oracle_from_problem(p, **okw)
+    V = energy_orthonormalize(make_bases(d.S, d.n, 5, seed=7), d)
+    res = compare_all(p, eng, V, 0.3, oracle=d)
+    res.pop('cg_iterations')
+    bad = {k: v for k, v in res.items() if not (v < (1e-10 if k == 'u_solve' else TOL))}
+    assert not bad, bad
+    # the switches do change the result (the default conventions differ by far more than the tolerance)
+    d0 = oracle_from_problem(p)
+    if 'accumulate_coupling_across_q' in conv:
+        assert abs(d.A[1] - d0.A[1]).max() > 1e-3 * abs(d0.A[1]).max()
+    if 'oswald_zero_on_subdomain_boundary' in conv:
+        assert abs(d.Avg[0][0] - d0.Avg[0][0]).max() > 1e-3
