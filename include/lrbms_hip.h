@@ -88,31 +88,70 @@ const char* lrbms_version(void);
  * nbr[s][2] == s.  (K0; reference grid.py:8-42, block_swipdg.py:66-70,78,393,421.) */
 int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* desc, int32_t S, int32_t S_ext, const int32_t* nbr);
 
+/* -- quadrature ------------------------------------------------------------------------------------------ */
+/* One rule per integrand of the path.  dune-gdt integrates every local integrand with the rule of order
+ * (integrand order + over_integrate); the over_integrate arguments are in the reference tree
+ * (discretize_elliptic_block_swipdg.py:247,267,327,347,369,405,519,655,660,782).  The host chooses the rules
+ * (pylrbms_amd/quadrature.py: the reference's orders by default), samples the data functions at their points and hands
+ * both over; the kernels do the arithmetic.  Triangle rules in barycentric coordinates, weights summing to 1; edge rules
+ * on [0, 1] from local vertex f + 1 to f + 2 of the element, ascending and symmetric about 1/2 (the neighbour across the
+ * face sees the points in reverse order).  The o_ and _stride fields lay out the sample records per element:
+ *   lambda_q      [Q][S_ext][n_T][lam_stride]   system_volume pts | 3 faces x nfs system face pts (face f: inner rule if the
+ *                                               template has a neighbour element across it, else the coupling rule, which also
+ *                                               serves Dirichlet boundary faces) | 3 x energy_face pts | 3 x flux_face pts |
+ *                                               energy_volume pts
+ *   lambda_q (df) [Q][S][n_T][lamdf_stride]     df_aa pts | df_ab pts
+ *   lambda_hat    [S][n_T][lhat_stride]         df_aa | df_ab | df_bb | ceps pts
+ *   f             [S][n_T][f_stride]            rhs pts | f2 pts
+ *   lambda_bar    [S][n_T][lbar_stride]         elliptic_bar pts */
+#define LRBMS_MAXQV 16
+#define LRBMS_MAXQF 4
+typedef struct {
+  int32_t n, pad;
+  double w[LRBMS_MAXQV];
+  double b[LRBMS_MAXQV][3];
+} lrbms_tri_rule;
+typedef struct {
+  int32_t n, pad;
+  double w[LRBMS_MAXQF];
+  double t[LRBMS_MAXQF];
+} lrbms_edge_rule;
+typedef struct {
+  lrbms_tri_rule system_volume, energy_volume, elliptic_bar, rhs, f2, ceps, df_aa, df_ab, df_bb;
+  lrbms_edge_rule system_inner_face, system_coupling_face, energy_face, flux_face;
+  int32_t nfs, o_sysv, o_sysf, o_enf, o_flf, o_env, lam_stride;
+  int32_t o_aa, o_ab, lamdf_stride;
+  int32_t o_haa, o_hab, o_hbb, o_hceps, lhat_stride;
+  int32_t o_frhs, o_ff2, f_stride, lbar_stride, pad_;
+} lrbms_quadrature;
+/* Copied into the context (host pointer); must be called before any lrbms_assemble_* function. */
+int lrbms_set_quadrature(lrbms_ctx* ctx, const lrbms_quadrature* quad);
+
 /* -- offline assembly (not in the timed project+estimate region) ---------------------------------------- */
 /* K1-K3: SWIPDG system per affine component; replaces make_elliptic_swipdg_affine_factor_matrix_operator
  * + the coupling / boundary assemblers (block_swipdg.py:399-437) and the block axpy of :475-497.
- *   lam    [Q][S_ext][n_T][NS]  samples of lambda_q
+ *   lam    [Q][S_ext][n_T][lam_stride]  samples of lambda_q (record layout above)
  *   A_diag [Q][S][n_T][4][9]    block-ELL: block 0 = (e,e), block 1+f = (e, inner neighbour across face f)
  *   A_cpl  [Q][S][4][ncf][9]    block (ii, neighbour at side) per coupling face: rows side_elem, cols side_elem_out */
 int lrbms_assemble_swipdg(lrbms_ctx* ctx, int32_t Q, const double* lam, double* A_diag, double* A_cpl, void* stream);
 
 /* K5 + scalars: replaces make_l2_volume_vector_functional (block_swipdg.py:518-521), apply_l2_product,
  * min_diffusion_eigenvalue (:776-783).
- *   f_smp [S][n_T][7], lhat [S][n_T][7]  ->  b [S][n], f2 [S] = ||f||^2_{L2(Omega_ii)}, ceps [S] */
+ *   f_smp [S][n_T][f_stride], lhat [S][n_T][lhat_stride]  ->  b [S][n], f2 [S] = ||f||^2_{L2(Omega_ii)}, ceps [S] */
 int lrbms_assemble_rhs(lrbms_ctx* ctx, const double* f_smp, const double* lhat, double* b, double* f2, double* ceps,
                        void* stream);
 
 /* K6 + K9: local products and estimator operators (block_swipdg.py:319-378, :644-691, :722-729).
  *   theta_bar [Q]                          host pointer, theta_q(mu_bar)
- *   lbar, lhat [S][n_T][7]
+ *   lam [Q][S_ext][n_T][lam_stride], lam_df [Q][S][n_T][lamdf_stride], lbar [S][n_T][lbar_stride], lhat [S][n_T][lhat_stride]
  *   P_diag [S][n_T][4][9]                  energy product (elliptic + penalty at mu_bar), block-ELL
  *   ebar   [S][n_T]                        int_T lambda_bar         (E_ii = ebar * stiffness template)
  *   caa    [Q][Q][S][n_T]                  int_T lambda_q lambda_q' / lambda_hat
  *   Aab    [Q][S][n_T][3][3]               df_ab element blocks [i][f]
  *   Bbb    [S][n_T][3][3]                  df_bb element blocks [f][g] */
-int lrbms_assemble_products(lrbms_ctx* ctx, int32_t Q, const double* theta_bar, const double* lam, const double* lbar,
-                            const double* lhat, double* P_diag, double* ebar, double* caa, double* Aab, double* Bbb,
-                            void* stream);
+int lrbms_assemble_products(lrbms_ctx* ctx, int32_t Q, const double* theta_bar, const double* lam, const double* lam_df,
+                            const double* lbar, const double* lhat, double* P_diag, double* ebar, double* caa, double* Aab,
+                            double* Bbb, void* stream);
 
 /* K8 (assembly half): coefficient rows of the RT0 diffusive-flux reconstruction
  * (RS2017_apply_diffusive_flux_reconstruction_in_neighborhood, block_swipdg.py:165-169).

@@ -493,12 +493,18 @@ class OracleDiscretization:
         return u.reshape(self.S, self.n)
 
     # ------------------------------------------------------------------ online enrichment: local corrector problem
-    def local_correction_system(self, ii, mu):
+    def local_correction_system(self, ii, mu, rules='system'):
         """solve_for_local_correction (block_swipdg.py:227-316): the SWIPDG operator on the neighbourhood N(ii)
         (``grid.neighborhood_of``: ii and its face neighbours) with the all-Dirichlet ``local_boundary_info`` of
         :794-795 -- every face with exactly one side in N(ii) gets the boundary integrand seen from the inside
         element -- and the L2 functional of f (:263-268).  Assembled from scratch on the faces of the neighbourhood
-        (not by editing the global matrix).  Returns (A_hood csr, b_hood, hood list, dof index array)."""
+        (not by editing the global matrix).  Returns (A_hood csr, b_hood, hood list, dof index array).
+
+        ``rules='reference'``: every term with the rules of ``over_integrate=0`` (:247) -- the reference's own choice.
+        ``rules='system'`` (default): the rules of the global system on the faces / elements it shares with it (volume and
+        subdomain-inner faces with over_integrate=2, faces between subdomains and Dirichlet faces without) -- what the
+        product does, which re-uses the assembled block operator and only corrects the outer faces of the neighbourhood
+        (DESIGN.md section 5.3).  Both coincide whenever lambda is piecewise polynomial of the declared order."""
         m = self.mesh
         hood = sorted(m.neighborhood_of(ii))
         inH = np.isin(m.elem_subdomain, hood)
@@ -514,14 +520,19 @@ class OracleDiscretization:
         A = None
         for q, fn in enumerate(self.lambda_funcs):
             # make_elliptic_swipdg_matrix_operator_on_neighborhood(..., over_integrate=0) (:243-247)
-            lam_int = self._vol_integral(fn, qd.energy_volume)[elems]
+            ref = rules == 'reference'
+            lam_int = self._vol_integral(fn, qd.energy_volume if ref else qd.system_volume)[elems]
             Aq = self._coo(elems, elems, lam_int[:, None, None] * self.stiff[elems])
             # inner-face form on faces with both sides inside the neighbourhood
-            Aq = Aq + self._inner_form(fn, qd.energy_face, both)
+            both_in = both[m.face_kind[both] == 0]        # inside one subdomain
+            both_cp = both[m.face_kind[both] == 1]        # between two subdomains of the neighbourhood
+            Aq = Aq + self._inner_form(fn, qd.energy_face if ref else qd.system_inner_face, both_in)
+            Aq = Aq + self._inner_form(fn, qd.energy_face if ref else qd.system_coupling_face, both_cp)
+            o_face = qd.energy_face if ref else qd.system_boundary_face
             # Dirichlet form seen from the minus element (outward normal = face normal) ...
-            Aq = Aq + self._coo(Em[only_m], Em[only_m], self._swipdg_boundary_block(fn, qd.energy_face, only_m, 'minus'))
+            Aq = Aq + self._coo(Em[only_m], Em[only_m], self._swipdg_boundary_block(fn, o_face, only_m, 'minus'))
             # ... and from the plus element (outward normal = - face normal)
-            Aq = Aq + self._coo(Ep[only_p], Ep[only_p], self._swipdg_boundary_block(fn, qd.energy_face, only_p, 'plus'))
+            Aq = Aq + self._coo(Ep[only_p], Ep[only_p], self._swipdg_boundary_block(fn, o_face, only_p, 'plus'))
             A = th[q] * Aq if A is None else A + th[q] * Aq
         n = self.n
         dofs = np.concatenate([np.arange(kk * n, (kk + 1) * n) for kk in hood])

@@ -34,13 +34,14 @@ SIGNATURES = {
     'lrbms_last_error': (ctypes.c_char_p, [c_vp]),
     'lrbms_ctx_aux_stream': (c_vp, [c_vp, c_i32]),
     'lrbms_ctx_set_option': (ctypes.c_int, [c_vp, c_i32, c_i32]),
+    'lrbms_set_quadrature': (ctypes.c_int, [c_vp, c_vp]),
     'lrbms_kernel_timing': (ctypes.c_int, [c_vp, c_i32]),
     'lrbms_kernel_timing_read': (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), c_i32,
                                                 ctypes.POINTER(c_i32)]),
     'lrbms_mesh_upload': (ctypes.c_int, [c_vp, ctypes.POINTER(MeshDesc), c_i32, c_i32, _P_I32]),
     'lrbms_assemble_swipdg': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'lrbms_assemble_rhs': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'lrbms_assemble_products': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'lrbms_assemble_products': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'lrbms_assemble_flux': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     'lrbms_oswald_apply': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     'lrbms_flux_reconstruct': (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
@@ -212,25 +213,39 @@ class NativeContext:
         self._check(rc, 'lrbms_mesh_upload')
 
     # ------------------------------------------------------------------ assembly
+    def set_quadrature(self, spec):
+        """Upload the rules of a ``pylrbms_amd.quadrature.QuadratureSpec`` (must precede the assembly calls; after a mesh
+        upload).  Keeps the native struct: its o_* / *_stride fields are the sample record layout the host fills."""
+        from pylrbms_amd.quadrature import native_quadrature
+        self.quad = native_quadrature(spec)
+        self.quad_spec = spec
+        self._check(self.lib.lrbms_set_quadrature(self.handle, ctypes.byref(self.quad)), 'lrbms_set_quadrature')
+
+    def _quad(self):
+        if getattr(self, 'quad', None) is None:
+            raise NativeError('set_quadrature() must run before the assembly calls')
+        return self.quad
+
     def assemble_swipdg(self, lam):
-        Q = lam.shape[0]
+        Q, qd = lam.shape[0], self._quad()
         A_diag = self.empty(Q, self.S, self.n_T, 4, 9)
         A_cpl = self.empty(Q, self.S, 4, self.ncf, 9)
-        rc = self.lib.lrbms_assemble_swipdg(self.handle, Q, self._ptr(lam, (Q, self.S_ext, self.n_T, 16), 'lam'),
+        rc = self.lib.lrbms_assemble_swipdg(self.handle, Q, self._ptr(lam, (Q, self.S_ext, self.n_T, qd.lam_stride), 'lam'),
                                             c_vp(A_diag.data_ptr()), c_vp(A_cpl.data_ptr()), self._stream())
         self._check(rc, 'lrbms_assemble_swipdg')
         return A_diag, A_cpl
 
     def assemble_rhs(self, f_smp, lhat):
+        qd = self._quad()
         b, f2, ceps = self.empty(self.S, self.n), self.empty(self.S), self.empty(self.S)
-        rc = self.lib.lrbms_assemble_rhs(self.handle, self._ptr(f_smp, (self.S, self.n_T, 7), 'f_smp'),
-                                         self._ptr(lhat, (self.S, self.n_T, 7), 'lhat'), c_vp(b.data_ptr()),
+        rc = self.lib.lrbms_assemble_rhs(self.handle, self._ptr(f_smp, (self.S, self.n_T, qd.f_stride), 'f_smp'),
+                                         self._ptr(lhat, (self.S, self.n_T, qd.lhat_stride), 'lhat'), c_vp(b.data_ptr()),
                                          c_vp(f2.data_ptr()), c_vp(ceps.data_ptr()), self._stream())
         self._check(rc, 'lrbms_assemble_rhs')
         return b, f2, ceps
 
-    def assemble_products(self, theta_bar, lam, lbar, lhat):
-        Q = lam.shape[0]
+    def assemble_products(self, theta_bar, lam, lam_df, lbar, lhat):
+        Q, qd = lam.shape[0], self._quad()
         th = np.ascontiguousarray(theta_bar, dtype=np.float64)
         assert th.shape == (Q,)
         P_diag = self.empty(self.S, self.n_T, 4, 9)
@@ -239,17 +254,18 @@ class NativeContext:
         Aab = self.empty(Q, self.S, self.n_T, 3, 3)
         Bbb = self.empty(self.S, self.n_T, 3, 3)
         rc = self.lib.lrbms_assemble_products(
-            self.handle, Q, _dblp(th), self._ptr(lam, (Q, self.S_ext, self.n_T, 16), 'lam'),
-            self._ptr(lbar, (self.S, self.n_T, 7), 'lbar'), self._ptr(lhat, (self.S, self.n_T, 7), 'lhat'),
+            self.handle, Q, _dblp(th), self._ptr(lam, (Q, self.S_ext, self.n_T, qd.lam_stride), 'lam'),
+            self._ptr(lam_df, (Q, self.S, self.n_T, qd.lamdf_stride), 'lam_df'),
+            self._ptr(lbar, (self.S, self.n_T, qd.lbar_stride), 'lbar'), self._ptr(lhat, (self.S, self.n_T, qd.lhat_stride), 'lhat'),
             c_vp(P_diag.data_ptr()), c_vp(ebar.data_ptr()), c_vp(caa.data_ptr()), c_vp(Aab.data_ptr()),
             c_vp(Bbb.data_ptr()), self._stream())
         self._check(rc, 'lrbms_assemble_products')
         return P_diag, ebar, caa, Aab, Bbb
 
     def assemble_flux(self, lam):
-        Q = lam.shape[0]
+        Q, qd = lam.shape[0], self._quad()
         F = self.empty(Q, self.S, self.n_rt, 6)
-        rc = self.lib.lrbms_assemble_flux(self.handle, Q, self._ptr(lam, (Q, self.S_ext, self.n_T, 16), 'lam'),
+        rc = self.lib.lrbms_assemble_flux(self.handle, Q, self._ptr(lam, (Q, self.S_ext, self.n_T, qd.lam_stride), 'lam'),
                                           c_vp(F.data_ptr()), self._stream())
         self._check(rc, 'lrbms_assemble_flux')
         return F
@@ -617,7 +633,7 @@ class NativeContext:
     def assemble_dirichlet_correction(self, lam):
         Q = lam.shape[0]
         D = self.empty(Q, self.S, 4, self.ncf, 9)
-        rc = self.lib.lrbms_assemble_dirichlet_correction(self.handle, Q, self._ptr(lam, (Q, self.S_ext, self.n_T, 16), 'lam'),
+        rc = self.lib.lrbms_assemble_dirichlet_correction(self.handle, Q, self._ptr(lam, (Q, self.S_ext, self.n_T, self._quad().lam_stride), 'lam'),
                                                           c_vp(D.data_ptr()), self._stream())
         self._check(rc, 'lrbms_assemble_dirichlet_correction')
         return D

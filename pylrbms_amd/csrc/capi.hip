@@ -65,6 +65,7 @@ void free_owned(lrbms_ctx* ctx) {
   for (void* p : ctx->owned) (void)hipFree(p);
   ctx->owned.clear();
   ctx->nbr = nullptr;
+  ctx->qdev = nullptr;
   ctx->has_mesh = false;
 }
 
@@ -246,6 +247,37 @@ int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* d, int32_t S, int32
 #define CHECK_PTR(ctx, p) \
   do { if (!(p)) return lrbms_fail(ctx, LRBMS_E_INVALID, "null pointer: " #p); } while (0)
 
+int lrbms_set_quadrature(lrbms_ctx* ctx, const lrbms_quadrature* quad) {
+  if (!ctx || !quad) return LRBMS_E_INVALID;
+  const lrbms_tri_rule* tri[9] = {&quad->system_volume, &quad->energy_volume, &quad->elliptic_bar, &quad->rhs, &quad->f2,
+                                  &quad->ceps, &quad->df_aa, &quad->df_ab, &quad->df_bb};
+  const lrbms_edge_rule* edge[4] = {&quad->system_inner_face, &quad->system_coupling_face, &quad->energy_face, &quad->flux_face};
+  for (auto r : tri)
+    if (r->n < 1 || r->n > LRBMS_MAXQV) return lrbms_fail(ctx, LRBMS_E_INVALID, "set_quadrature: triangle rule size out of range");
+  for (auto r : edge) {
+    if (r->n < 1 || r->n > LRBMS_MAXQF) return lrbms_fail(ctx, LRBMS_E_INVALID, "set_quadrature: edge rule size out of range");
+    for (int k = 0; k < r->n; ++k)   // the neighbour across a face reads the samples in reverse order
+      if (fabs(r->t[k] + r->t[r->n - 1 - k] - 1.0) > 1e-14 || fabs(r->w[k] - r->w[r->n - 1 - k]) > 1e-14)
+        return lrbms_fail(ctx, LRBMS_E_INVALID, "set_quadrature: edge rules must be symmetric about 1/2");
+  }
+  const int nfs = quad->system_inner_face.n > quad->system_coupling_face.n ? quad->system_inner_face.n : quad->system_coupling_face.n;
+  if (quad->nfs != nfs || quad->o_sysf < quad->o_sysv + quad->system_volume.n || quad->o_enf < quad->o_sysf + 3 * nfs ||
+      quad->o_flf < quad->o_enf + 3 * quad->energy_face.n || quad->o_env < quad->o_flf + 3 * quad->flux_face.n ||
+      quad->lam_stride < quad->o_env + quad->energy_volume.n || quad->lamdf_stride < quad->o_ab + quad->df_ab.n ||
+      quad->o_ab < quad->o_aa + quad->df_aa.n || quad->o_hab < quad->o_haa + quad->df_aa.n ||
+      quad->o_hbb < quad->o_hab + quad->df_ab.n || quad->o_hceps < quad->o_hbb + quad->df_bb.n ||
+      quad->lhat_stride < quad->o_hceps + quad->ceps.n || quad->o_ff2 < quad->o_frhs + quad->rhs.n ||
+      quad->f_stride < quad->o_ff2 + quad->f2.n || quad->lbar_stride < quad->elliptic_bar.n)
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "set_quadrature: inconsistent sample record layout");
+  LRBMS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->qdev) {
+    LRBMS_HIP_CHECK(ctx, hipMalloc(&ctx->qdev, sizeof(lrbms_quadrature)));
+    ctx->owned.push_back(ctx->qdev);
+  }
+  LRBMS_HIP_CHECK(ctx, hipMemcpy(ctx->qdev, quad, sizeof(lrbms_quadrature), hipMemcpyHostToDevice));
+  return LRBMS_OK;
+}
+
 int lrbms_assemble_swipdg(lrbms_ctx* ctx, int32_t Q, const double* lam, double* A_diag, double* A_cpl, void* stream) {
   LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, 1); CHECK_PTR(ctx, lam); CHECK_PTR(ctx, A_diag); CHECK_PTR(ctx, A_cpl);
   return launch_assemble_swipdg(ctx, Q, lam, A_diag, A_cpl, (hipStream_t)stream);
@@ -257,12 +289,12 @@ int lrbms_assemble_rhs(lrbms_ctx* ctx, const double* f_smp, const double* lhat, 
   return launch_assemble_rhs(ctx, f_smp, lhat, b, f2, ceps, (hipStream_t)stream);
 }
 
-int lrbms_assemble_products(lrbms_ctx* ctx, int32_t Q, const double* theta_bar, const double* lam, const double* lbar,
-                            const double* lhat, double* P_diag, double* ebar, double* caa, double* Aab, double* Bbb,
-                            void* stream) {
-  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, 1); CHECK_PTR(ctx, theta_bar); CHECK_PTR(ctx, lam); CHECK_PTR(ctx, lbar);
+int lrbms_assemble_products(lrbms_ctx* ctx, int32_t Q, const double* theta_bar, const double* lam, const double* lam_df,
+                            const double* lbar, const double* lhat, double* P_diag, double* ebar, double* caa, double* Aab,
+                            double* Bbb, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, 1); CHECK_PTR(ctx, theta_bar); CHECK_PTR(ctx, lam); CHECK_PTR(ctx, lam_df); CHECK_PTR(ctx, lbar);
   CHECK_PTR(ctx, lhat); CHECK_PTR(ctx, P_diag); CHECK_PTR(ctx, ebar); CHECK_PTR(ctx, caa); CHECK_PTR(ctx, Aab); CHECK_PTR(ctx, Bbb);
-  return launch_assemble_products(ctx, Q, theta_bar, lam, lbar, lhat, P_diag, ebar, caa, Aab, Bbb, (hipStream_t)stream);
+  return launch_assemble_products(ctx, Q, theta_bar, lam, lam_df, lbar, lhat, P_diag, ebar, caa, Aab, Bbb, (hipStream_t)stream);
 }
 
 int lrbms_assemble_flux(lrbms_ctx* ctx, int32_t Q, const double* lam, double* F, void* stream) {

@@ -50,33 +50,15 @@ struct lrbms_ctx {
   struct KTimer { const char* name; hipEvent_t e0, e1; bool used; };
   std::vector<KTimer> ktimers;
   int ktime_n = 0;
+  lrbms_quadrature* qdev = nullptr;   // device copy of the quadrature (lrbms_set_quadrature), read by the assembly kernels
   const double* user_pc = nullptr;   // prebuilt preconditioner the reduced solves use (lrbms_reduced_precond_use), caller-owned
   int user_pc_N = 0;
   std::string err;
 };
 
-#define LRBMS_NQV 7
-#define LRBMS_NQF 3
-
 // SWIPDG constants (dune-gdt elliptic-ipdg.hh: inner_sigma / boundary_sigma for polorder <= 1), beta = 1/(d-1) = 1
 #define SIGMA_INNER 8.0
 #define SIGMA_BOUNDARY 14.0
-
-// 7-point Radon rule (degree 5) in barycentric coordinates and 3-point Gauss on [0,1];
-// same rule the oracle fixes in oracle/quadrature.py (documented in DESIGN.md section 3).
-__device__ __constant__ static const double c_tri_w[7] = {
-    0.225, 0.13239415278850618, 0.13239415278850618, 0.13239415278850618,
-    0.12593918054482715, 0.12593918054482715, 0.12593918054482715};
-__device__ __constant__ static const double c_tri_b[7][3] = {
-    {1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0},
-    {0.05971587178976982, 0.47014206410511509, 0.47014206410511509},
-    {0.47014206410511509, 0.05971587178976982, 0.47014206410511509},
-    {0.47014206410511509, 0.47014206410511509, 0.05971587178976982},
-    {0.79742698535308732, 0.10128650732345634, 0.10128650732345634},
-    {0.10128650732345634, 0.79742698535308732, 0.10128650732345634},
-    {0.10128650732345634, 0.10128650732345634, 0.79742698535308732}};
-__device__ __constant__ static const double c_edge_t[3] = {0.11270166537925831, 0.5, 0.88729833462074169};
-__device__ __constant__ static const double c_edge_w[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
 
 __host__ __device__ inline int side_to_slot(int side) { return side < 2 ? side : side + 1; }
 __host__ __device__ inline int slot_to_side(int slot) { return slot < 2 ? slot : slot - 1; }  // slot != 2
@@ -133,9 +115,9 @@ int launch_coarse_apply(lrbms_ctx* ctx, int N, int nmu, const double* A0inv, con
 // launchers implemented in the other translation units
 int launch_assemble_swipdg(lrbms_ctx*, int Q, const double* lam, double* A_diag, double* A_cpl, hipStream_t);
 int launch_assemble_rhs(lrbms_ctx*, const double* f_smp, const double* lhat, double* b, double* f2, double* ceps, hipStream_t);
-int launch_assemble_products(lrbms_ctx*, int Q, const double* theta_bar_dev, const double* lam, const double* lbar,
-                             const double* lhat, double* P_diag, double* ebar, double* caa, double* Aab, double* Bbb,
-                             hipStream_t);
+int launch_assemble_products(lrbms_ctx*, int Q, const double* theta_bar_dev, const double* lam, const double* lam_df,
+                             const double* lbar, const double* lhat, double* P_diag, double* ebar, double* caa, double* Aab,
+                             double* Bbb, hipStream_t);
 int launch_assemble_flux(lrbms_ctx*, int Q, const double* lam, double* F, hipStream_t);
 int launch_oswald(lrbms_ctx*, int N, const double* V, double* Wt, hipStream_t);
 int launch_flux(lrbms_ctx*, int Q, int N, const double* F, const double* V, double* Rt, hipStream_t);

@@ -2,7 +2,7 @@
 
 Data layout in HBM (all fp64, C-contiguous; S = local subdomains, S_ext = S + halo):
 
-    lam    [Q][S_ext][n_T][16]   coefficient samples (7 volume + 3x3 face points per element)
+    lam    [Q][S_ext][n_T][LS]   coefficient samples at the points of the quadrature rules (pylrbms_amd/quadrature.py)
     A_diag [Q][S][n_T][4][9]     SWIPDG diagonal blocks, block-ELL over the element adjacency template
     A_cpl  [Q][S][4][ncf][9]     SWIPDG coupling blocks per side face
     V      [S_ext][n][N]         local reduced bases, DoF-major (basis index contiguous)
@@ -17,47 +17,78 @@ The reference builds the same quantities as pyMOR operators in ``discretize`` / 
 import numpy as np
 
 from pylrbms_amd._native import NativeContext, NativeError
-
-_s15 = np.sqrt(15.0)
-_b1, _b2 = (6.0 + _s15) / 21.0, (6.0 - _s15) / 21.0
-TRI_BARY = np.array([[1 / 3, 1 / 3, 1 / 3],
-                     [1 - 2 * _b1, _b1, _b1], [_b1, 1 - 2 * _b1, _b1], [_b1, _b1, 1 - 2 * _b1],
-                     [1 - 2 * _b2, _b2, _b2], [_b2, 1 - 2 * _b2, _b2], [_b2, _b2, 1 - 2 * _b2]])
-EDGE_T = np.array([0.5 - 0.5 * np.sqrt(0.6), 0.5, 0.5 + 0.5 * np.sqrt(0.6)])
+from pylrbms_amd.quadrature import QuadratureSpec, edge_rule, native_quadrature, triangle_rule
 
 
-def sample_points(grid, subdomains):
-    """Quadrature points of every element of the given subdomains: x [len, n_T, 16, 2] (7 volume points, then the
-    3 Gauss points of face 0, 1, 2 running from local vertex f+1 to f+2), centres [len, n_T, 2], keys [len, n_T, 3]."""
+def element_points(grid, subdomains):
+    """Vertex coordinates of every element of the given subdomains [len, n_T, 3, 2], centres [len, n_T, 2], keys."""
     t = grid.template
     origins = np.stack([grid.subdomain_origin(int(s)) for s in subdomains])           # [len, 2]
     pts = t.points[None] + origins[:, None, None, :]                                    # [len, n_T, 3, 2]
-    vol = np.einsum('kv,sevd->sekd', TRI_BARY, pts)
-    faces = []
-    for f in range(3):
-        a, b = pts[:, :, (f + 1) % 3], pts[:, :, (f + 2) % 3]
-        faces.append(a[:, :, None, :] + EDGE_T[None, None, :, None] * (b - a)[:, :, None, :])
-    x = np.concatenate([vol] + faces, axis=2)
-    centers = pts.mean(axis=2)
-    keys = grid.element_keys(subdomains)
-    return x, centers, keys
+    return pts, pts.mean(axis=2), grid.element_keys(subdomains)
 
 
-def sample_function(fn, x, centers, keys, volume_only=False):
-    if volume_only:
-        x = x[:, :, :7]
+def volume_points(pts, order):
+    """Points of the triangle rule of a requested order on every element: [len, n_T, k, 2]."""
+    bary, _ = triangle_rule(order)
+    return np.einsum('kv,sevd->sekd', bary, pts)
+
+
+def face_points(pts, f, order):
+    """Points of the edge rule on local face f (from local vertex f + 1 to f + 2): [len, n_T, k, 2]."""
+    tt, _ = edge_rule(order)
+    a, b = pts[:, :, (f + 1) % 3], pts[:, :, (f + 2) % 3]
+    return a[:, :, None, :] + tt[None, None, :, None] * (b - a)[:, :, None, :]
+
+
+def sample_function(fn, x, centers, keys):
     c = np.broadcast_to(centers[:, :, None, :], x.shape)
     k = np.broadcast_to(keys[:, :, None, :], x.shape[:-1] + (3,))
     out = np.asarray(fn(x, c, k), dtype=np.float64)
-    return np.ascontiguousarray(np.broadcast_to(out, x.shape[:-1]))
+    return np.broadcast_to(out, x.shape[:-1])
+
+
+def lambda_record_points(grid, subdomains, spec):
+    """x [len, n_T, lam_stride, 2] of the lambda_q sample record (layout: pylrbms_amd/quadrature.py native_quadrature):
+    system volume | 3 faces x nfs system face points (inner rule on faces with an in-subdomain neighbour, coupling rule on
+    the subdomain boundary; unused slots repeat the first point) | 3 x energy face | 3 x flux face | energy volume."""
+    t = grid.template
+    qd = native_quadrature(spec)
+    pts, centers, keys = element_points(grid, subdomains)
+    x = np.empty(pts.shape[:2] + (qd.lam_stride, 2))
+    x[:, :, qd.o_sysv:qd.o_sysv + qd.system_volume.n] = volume_points(pts, spec.system_volume)
+    inner = t.nb_elem >= 0                                                              # [n_T, 3]
+    for f in range(3):
+        xi, xc = face_points(pts, f, spec.system_inner_face), face_points(pts, f, spec.system_coupling_face)
+        blk = np.repeat(xc[:, :, :1], qd.nfs, axis=2)
+        blk[:, :, :xc.shape[2]] = xc
+        blk_i = np.repeat(xi[:, :, :1], qd.nfs, axis=2)
+        blk_i[:, :, :xi.shape[2]] = xi
+        x[:, :, qd.o_sysf + f * qd.nfs:qd.o_sysf + (f + 1) * qd.nfs] = np.where(inner[None, :, f, None, None], blk_i, blk)
+        ne, nf = qd.energy_face.n, qd.flux_face.n
+        x[:, :, qd.o_enf + f * ne:qd.o_enf + (f + 1) * ne] = face_points(pts, f, spec.energy_face)
+        x[:, :, qd.o_flf + f * nf:qd.o_flf + (f + 1) * nf] = face_points(pts, f, spec.flux_face)
+    x[:, :, qd.o_env:qd.o_env + qd.energy_volume.n] = volume_points(pts, spec.energy_volume)
+    return x, centers, keys
+
+
+def volume_record_points(grid, subdomains, orders):
+    """Concatenated volume points of several rules: x [len, n_T, sum k, 2], centres, keys."""
+    pts, centers, keys = element_points(grid, subdomains)
+    return np.concatenate([volume_points(pts, o) for o in orders], axis=2), centers, keys
 
 
 class Engine:
     """All device state of one rank for one discretization."""
 
-    def __init__(self, grid, lambda_funcs, kappa, f, lambda_bar, lambda_hat, theta_bar, device_index=0, conventions=None):
-        self._init_args = (lambda_funcs, kappa, f, lambda_bar, lambda_hat, theta_bar, device_index, conventions)
+    def __init__(self, grid, lambda_funcs, kappa, f, lambda_bar, lambda_hat, theta_bar, device_index=0, conventions=None,
+                 quadrature=None):
+        """``quadrature``: a ``QuadratureSpec`` (default: the reference's orders for these data functions,
+        ``QuadratureSpec.for_problem``; ``QuadratureSpec.uniform(5)`` is the round-1 convention)."""
+        self._init_args = (lambda_funcs, kappa, f, lambda_bar, lambda_hat, theta_bar, device_index, conventions, quadrature)
         self.conventions = dict(conventions or {})
+        self.quadrature = quadrature if quadrature is not None else QuadratureSpec.for_problem(lambda_funcs, f, lambda_bar,
+                                                                                                lambda_hat)
         self.grid = grid
         t = grid.template
         self.t = t
@@ -83,16 +114,21 @@ class Engine:
         self.ctx.mesh_upload(t, kap, nbr, self.S, self.S_ext)
         for name, value in self.conventions.items():          # conventions the reference leaves open (LRBMS_OPT_*)
             self.ctx.set_option(name, value)
+        self.ctx.set_quadrature(self.quadrature)
         self.hdiam = grid.subdomain_diameter(0)
 
-        # ---- coefficient sampling on the host, then one H2D copy each
-        x, c, k = sample_points(grid, self.ext)
-        lam = np.stack([sample_function(fn, x, c, k) for fn in lambda_funcs])           # [Q, S_ext, n_T, 16]
-        xl, cl, kl = x[:self.S], c[:self.S], k[:self.S]
-        self.lam = self.ctx.from_numpy(lam)
-        self.f_smp = self.ctx.from_numpy(sample_function(f, xl, cl, kl, volume_only=True))
-        self.lbar = self.ctx.from_numpy(sample_function(lambda_bar, xl, cl, kl, volume_only=True))
-        self.lhat = self.ctx.from_numpy(sample_function(lambda_hat, xl, cl, kl, volume_only=True))
+        # ---- coefficient sampling on the host at the points of the chosen rules, one H2D copy each
+        sp = self.quadrature
+        x, c, k = lambda_record_points(grid, self.ext, sp)
+        self.lam = self.ctx.from_numpy(np.ascontiguousarray(np.stack([sample_function(fn, x, c, k) for fn in lambda_funcs])))
+        xd, cl, kl = volume_record_points(grid, self.local, (sp.df_aa, sp.df_ab))
+        self.lam_df = self.ctx.from_numpy(np.ascontiguousarray(np.stack([sample_function(fn, xd, cl, kl) for fn in lambda_funcs])))
+        xh, _, _ = volume_record_points(grid, self.local, (sp.df_aa, sp.df_ab, sp.df_bb, sp.ceps))
+        self.lhat = self.ctx.from_numpy(np.ascontiguousarray(sample_function(lambda_hat, xh, cl, kl)))
+        xf, _, _ = volume_record_points(grid, self.local, (sp.rhs, sp.f2))
+        self.f_smp = self.ctx.from_numpy(np.ascontiguousarray(sample_function(f, xf, cl, kl)))
+        xb, _, _ = volume_record_points(grid, self.local, (sp.elliptic_bar,))
+        self.lbar = self.ctx.from_numpy(np.ascontiguousarray(sample_function(lambda_bar, xb, cl, kl)))
         self.theta_bar = np.asarray(theta_bar, dtype=np.float64)
         self.assembled = False
 
@@ -101,8 +137,8 @@ class Engine:
         c = self.ctx
         self.A_diag, self.A_cpl = c.assemble_swipdg(self.lam)
         self.b, self.f2, self.ceps = c.assemble_rhs(self.f_smp, self.lhat)
-        self.P_diag, self.ebar, self.caa, self.Aab, self.Bbb = c.assemble_products(self.theta_bar, self.lam, self.lbar,
-                                                                                  self.lhat)
+        self.P_diag, self.ebar, self.caa, self.Aab, self.Bbb = c.assemble_products(self.theta_bar, self.lam, self.lam_df,
+                                                                                  self.lbar, self.lhat)
         self.F = c.assemble_flux(self.lam)
         self.assembled = True
         return self

@@ -6,10 +6,20 @@ from oracle.lrbms import OracleDiscretization, OracleReductor
 from oracle.mesh import OracleMesh
 
 
+def oracle_quadrature_of(p):
+    """The oracle's QuadratureSpec with the orders the product uses by default for this problem (the reference's orders
+    from the declared order of the data functions): both sides integrate every integrand with the same rule."""
+    from oracle.quadrature import QuadratureSpec as OracleSpec
+    from pylrbms_amd.quadrature import QuadratureSpec
+    lam = p['lambda']
+    return OracleSpec(**QuadratureSpec.for_problem(lam['functions'], p['f'], p['lambda_bar'], p['lambda_hat']).as_dict())
+
+
 def oracle_from_problem(p, **kw):
     grid = p['grid']
     mesh = OracleMesh(grid.lower_left, grid.upper_right, grid.K, grid.P)
     lam = p['lambda']
+    kw.setdefault('quad', oracle_quadrature_of(p))
     thetas = [(lambda mu, c=c: c.evaluate(mu)) for c in lam['coefficients']]
     kappa = np.asarray(getattr(p['kappa'], 'value', p['kappa']), dtype=np.float64).reshape(2, 2)
     return OracleDiscretization(mesh, lam['functions'], thetas, kappa, p['f'], p['lambda_bar'], p['lambda_hat'],

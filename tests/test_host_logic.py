@@ -4,7 +4,6 @@ import pytest
 
 from common import oracle_from_problem
 from pylrbms_amd import OS2015_academic_problem, multiscale_problem, thermalblock_problem
-from pylrbms_amd.engine import sample_function, sample_points
 from pylrbms_amd.parameters import CubicParameterSpace, ExpressionParameterFunctional, parse_parameter
 
 
@@ -16,23 +15,62 @@ from pylrbms_amd.parameters import CubicParameterSpace, ExpressionParameterFunct
     lambda: multiscale_problem.init_grid_and_problem({'num_subdomains': [3, 2], 'coarse_per_subdomain': 2}),
 ])
 def test_samples_equal_the_oracles(mk):
+    """The sample records the kernels consume (pylrbms_amd/quadrature.py native_quadrature layout) hold exactly the values
+    the oracle evaluates at the points of the same rules: volume segments, and the face segments seen from both sides."""
+    from common import oracle_quadrature_of
+    from pylrbms_amd.engine import lambda_record_points, sample_function, volume_record_points
+    from pylrbms_amd.quadrature import QuadratureSpec, native_quadrature
     p = mk()
     g = p['grid']
-    x, c, k = sample_points(g, list(range(g.num_subdomains)))
+    lam_funcs = p['lambda']['functions']
+    sp = QuadratureSpec.for_problem(lam_funcs, p['f'], p['lambda_bar'], p['lambda_hat'])
+    qd = native_quadrature(sp)
+    subs = list(range(g.num_subdomains))
+    x, c, k = lambda_record_points(g, subs, sp)
     d = oracle_from_problem(p)
+    assert d.quad.as_dict() == oracle_quadrature_of(p).as_dict() == sp.as_dict()
     m = d.mesh
     Em, fm = m.face_minus[:, 0], m.face_minus[:, 1]
     has = m.face_plus[:, 0] >= 0
     Ep, fp = m.face_plus[has, 0], m.face_plus[has, 1]
-    for q, fn in enumerate(p['lambda']['functions']):
-        lam = sample_function(fn, x, c, k).reshape(-1, 16)
-        assert np.array_equal(lam[:, :7], d._vol(fn, 5))
-        lm, lp = d._face_sides(fn, 5)
-        assert np.array_equal(lam[Em][np.arange(len(Em))[:, None], 7 + 3 * fm[:, None] + np.arange(3)[None, :]], lm)
-        assert np.array_equal(lam[Ep][np.arange(len(Ep))[:, None], 7 + 3 * fp[:, None] + (2 - np.arange(3))[None, :]],
-                              lp[has])
-    f = sample_function(p['f'], x, c, k, volume_only=True).reshape(-1, 7)
-    assert np.array_equal(f, d._vol(p['f'], 5))
+    for fn in lam_funcs:
+        lam = sample_function(fn, x, c, k).reshape(-1, qd.lam_stride)
+        assert np.array_equal(lam[:, qd.o_sysv:qd.o_sysv + qd.system_volume.n], d._vol(fn, sp.system_volume))
+        assert np.array_equal(lam[:, qd.o_env:qd.o_env + qd.energy_volume.n], d._vol(fn, sp.energy_volume))
+        for off, n, order, mask_kind in ((qd.o_enf, qd.energy_face.n, sp.energy_face, None),
+                                         (qd.o_flf, qd.flux_face.n, sp.flux_face, None),
+                                         (qd.o_sysf, qd.nfs, sp.system_inner_face, 0),
+                                         (qd.o_sysf, qd.nfs, sp.system_coupling_face, 1)):
+            lm, lp = d._face_sides(fn, order)
+            npt = lm.shape[1]
+            sel = np.ones(len(Em), dtype=bool) if mask_kind is None else (m.face_kind == 0 if mask_kind == 0 else m.face_kind != 0)
+            got_m = lam[Em][np.arange(len(Em))[:, None], off + n * fm[:, None] + np.arange(npt)[None, :]]
+            assert np.allclose(got_m[sel], lm[sel], rtol=0, atol=1e-15)
+            selp = sel[has]
+            got_p = lam[Ep][np.arange(len(Ep))[:, None], off + n * fp[:, None] + (npt - 1 - np.arange(npt))[None, :]]
+            assert np.allclose(got_p[selp], lp[has][selp], rtol=0, atol=1e-15)
+    xf, cl, kl = volume_record_points(g, subs, (sp.rhs, sp.f2))
+    f = sample_function(p['f'], xf, cl, kl).reshape(-1, qd.f_stride)
+    assert np.array_equal(f[:, :qd.rhs.n], d._vol(p['f'], sp.rhs)) and np.array_equal(f[:, qd.rhs.n:], d._vol(p['f'], sp.f2))
+
+
+def test_product_and_oracle_share_the_quadrature_tables():
+    import oracle.quadrature as oq
+    import pylrbms_amd.quadrature as pq
+    for order in range(0, 9):
+        for a, b in zip(oq.triangle_rule(order), pq.triangle_rule(order)):
+            assert np.array_equal(a, b)
+        if order <= 7:                                   # the product carries at most 4 edge points (order 7)
+            for a, b in zip(oq.edge_rule(order), pq.edge_rule(order)):
+                assert np.array_equal(a, b)
+    assert oq.QuadratureSpec.dune().as_dict() == pq.QuadratureSpec.dune().as_dict()
+    assert oq.QuadratureSpec.dune(0, 2, 0, 0).as_dict() == pq.QuadratureSpec.dune(0, 2, 0, 0).as_dict()
+    # the reference's orders for the OS2015 problem (expression functions of order 2)
+    from pylrbms_amd import OS2015_academic_problem
+    p = OS2015_academic_problem.init_grid_and_problem({'num_subdomains': [2, 2], 'half_num_fine_elements_per_subdomain_and_dim': 4})
+    sp = pq.QuadratureSpec.for_problem(p['lambda']['functions'], p['f'], p['lambda_bar'], p['lambda_hat'])
+    assert (sp.system_volume, sp.system_inner_face, sp.system_coupling_face, sp.rhs, sp.f2, sp.df_aa, sp.df_ab, sp.df_bb, sp.flux_face) == \
+        (4, 6, 4, 5, 6, 8, 7, 6, 3)
 
 
 def test_problem_dict_keys_match_the_reference():
