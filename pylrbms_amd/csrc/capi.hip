@@ -101,6 +101,8 @@ int lrbms_ctx_destroy(lrbms_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   coarse_release(ctx);
   free_owned(ctx);
+  if (ctx->ksp_part) (void)hipFree(ctx->ksp_part);
+  if (ctx->ksp_ticket) (void)hipFree(ctx->ksp_ticket);
   for (int i = 0; i < 3; ++i) {
     if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);

@@ -155,12 +155,14 @@ __device__ inline int nvs_of(const Tmpl& t) { return t.nvx > t.nvy ? t.nvx : t.n
 // ---------------------------------------------------------------------------------------------------------
 // compact flux reconstruction.  write_side = 0: only R_self (needs no neighbour data: the halo-independent phase of a
 // sharded pass); write_side = 1: R_self and R_side in one sweep.
-__global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
-                                                      const double* __restrict__ F, const double* __restrict__ V,
-                                                      double* __restrict__ Rself, double* __restrict__ Rside, int write_side) {
+// (`by` of `gy` workgroups share subdomain `s`: the bodies below are launched on their own for large subdomain counts and
+// merged into one launch -- k_prep, k_prep_side, k_thin -- for small ones, where the pass is bound by launches, not work)
+__device__ __forceinline__ void flux_compact_body(const Tmpl& t, int S, const int* __restrict__ nbr, int Q, int N,
+                                                  const double* __restrict__ F, const double* __restrict__ V,
+                                                  double* __restrict__ Rself, double* __restrict__ Rside, int write_side,
+                                                  int s, int by, int gy) {
   const int QN = Q * N;
-  const int s = blockIdx.x;                        // grid (S, chunks of n_rt * N): 32-bit index arithmetic only
-  for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < t.nrt * N; it += gridDim.y * blockDim.x) {
+  for (int it = by * 256 + threadIdx.x; it < t.nrt * N; it += gy * 256) {   // 32-bit index arithmetic only
     const int r = it / N, j = it - r * N;
     const int e0 = t.rt_e0[r], e1 = t.rt_e1[r], side = t.rt_side[r];
     const int s2 = (side >= 0 && write_side) ? nbr[s * 5 + side_to_slot(side)] : -1;
@@ -181,13 +183,19 @@ __global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* 
   }
 }
 
+__global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
+                                                      const double* __restrict__ F, const double* __restrict__ V,
+                                                      double* __restrict__ Rself, double* __restrict__ Rside, int write_side) {
+  flux_compact_body(t, S, nbr, Q, N, F, V, Rself, Rside, write_side, blockIdx.x, blockIdx.y, gridDim.y);   // grid (S, chunks of n_rt * N)
+}
+
 // R_side alone (the halo-dependent phase of a sharded pass): one item per (subdomain, side, side face, column).
-__global__ __launch_bounds__(256) void k_flux_side(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
-                                                   const double* __restrict__ F, const double* __restrict__ V,
-                                                   double* __restrict__ Rside) {
+__device__ __forceinline__ void flux_side_body(const Tmpl& t, int S, const int* __restrict__ nbr, int Q, int N,
+                                               const double* __restrict__ F, const double* __restrict__ V,
+                                               double* __restrict__ Rside, int bx, int gx) {
   const long total = (long)S * 4 * t.ncf * N;
   const int QN = Q * N;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = (long)bx * 256 + threadIdx.x; idx < total; idx += (long)gx * 256) {
     const int j = (int)(idx % N);
     long rem = idx / N;
     const int pos = (int)(rem % t.ncf);
@@ -211,14 +219,19 @@ __global__ __launch_bounds__(256) void k_flux_side(Tmpl t, int S, const int* __r
   }
 }
 
+__global__ __launch_bounds__(256) void k_flux_side(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
+                                                   const double* __restrict__ F, const double* __restrict__ V,
+                                                   double* __restrict__ Rside) {
+  flux_side_body(t, S, nbr, Q, N, F, V, Rside, blockIdx.x, gridDim.x);
+}
+
 // Oswald vertex averages: Avg_self[s][v][j] = inv(v) sum_{star_s(v)} V_s ;  Avg_side[s][sd][pos][j] = inv(v) sum over
 // the star of the matching vertex in the neighbour across side sd (0 if there is none).
-__global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __restrict__ nbr, int N,
-                                                    const double* __restrict__ V, double* __restrict__ AvgSelf,
-                                                    double* __restrict__ AvgSide, int write_side) {
+__device__ __forceinline__ void vertex_avg_body(const Tmpl& t, int S, const int* __restrict__ nbr, int N,
+                                                const double* __restrict__ V, double* __restrict__ AvgSelf,
+                                                double* __restrict__ AvgSide, int write_side, int s, int by, int gy) {
   const int nvs = nvs_of(t);
-  const int s = blockIdx.x;                        // grid (S, chunks of n_v * N)
-  for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < t.nv * N; it += gridDim.y * blockDim.x) {
+  for (int it = by * 256 + threadIdx.x; it < t.nv * N; it += gy * 256) {
     const int v = it / N, j = it - v * N;
     const OsInfo o = oswald_vertex(t, nbr + s * 5, v);
     // the (at most 8) values at the vertex are loaded together and summed in the same order (an `acc += V[...]` loop
@@ -257,12 +270,30 @@ __global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __
   }
 }
 
+__global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __restrict__ nbr, int N,
+                                                    const double* __restrict__ V, double* __restrict__ AvgSelf,
+                                                    double* __restrict__ AvgSide, int write_side) {
+  vertex_avg_body(t, S, nbr, N, V, AvgSelf, AvgSide, write_side, blockIdx.x, blockIdx.y, gridDim.y);   // grid (S, chunks of n_v * N)
+}
+
+// both preparation sweeps in one launch: grid (S, gy_flux + gy_vtx)
+__global__ __launch_bounds__(256) void k_prep(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
+                                              const double* __restrict__ F, const double* __restrict__ V,
+                                              double* __restrict__ Rself, double* __restrict__ Rside,
+                                              double* __restrict__ AvgSelf, double* __restrict__ AvgSide, int write_side,
+                                              int gy_flux) {
+  if ((int)blockIdx.y < gy_flux)
+    flux_compact_body(t, S, nbr, Q, N, F, V, Rself, Rside, write_side, blockIdx.x, blockIdx.y, gy_flux);
+  else
+    vertex_avg_body(t, S, nbr, N, V, AvgSelf, AvgSide, write_side, blockIdx.x, blockIdx.y - gy_flux, gridDim.y - gy_flux);
+}
+
 // Avg_side alone (the halo-dependent phase of a sharded pass): one item per (subdomain, side, side vertex, column).
-__global__ __launch_bounds__(256) void k_vertex_side(Tmpl t, int S, const int* __restrict__ nbr, int N,
-                                                     const double* __restrict__ V, double* __restrict__ AvgSide) {
+__device__ __forceinline__ void vertex_side_body(const Tmpl& t, int S, const int* __restrict__ nbr, int N,
+                                                 const double* __restrict__ V, double* __restrict__ AvgSide, int bx, int gx) {
   const int nvs = nvs_of(t);
   const long total = (long)S * 4 * nvs * N;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = (long)bx * 256 + threadIdx.x; idx < total; idx += (long)gx * 256) {
     const int j = (int)(idx % N);
     long rem = idx / N;
     const int pos = (int)(rem % nvs);
@@ -280,6 +311,21 @@ __global__ __launch_bounds__(256) void k_vertex_side(Tmpl t, int S, const int* _
     }
     AvgSide[idx] = a2;
   }
+}
+
+__global__ __launch_bounds__(256) void k_vertex_side(Tmpl t, int S, const int* __restrict__ nbr, int N,
+                                                     const double* __restrict__ V, double* __restrict__ AvgSide) {
+  vertex_side_body(t, S, nbr, N, V, AvgSide, blockIdx.x, gridDim.x);
+}
+
+// both halo-dependent preparation sweeps in one launch: 1-D grid, the first gx_flux workgroups take R_side
+__global__ __launch_bounds__(256) void k_prep_side(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
+                                                   const double* __restrict__ F, const double* __restrict__ V,
+                                                   double* __restrict__ Rside, double* __restrict__ AvgSide, int gx_flux) {
+  if ((int)blockIdx.x < gx_flux)
+    flux_side_body(t, S, nbr, Q, N, F, V, Rside, blockIdx.x, gx_flux);
+  else
+    vertex_side_body(t, S, nbr, N, V, AvgSide, blockIdx.x - gx_flux, gridDim.x - gx_flux);
 }
 
 // Oswald interpolation error rows of one element, one column: slot 2 = own basis, other slots = neighbour images
@@ -317,6 +363,10 @@ struct F1Args {
   const double *V, *A_diag, *P_diag, *caa, *Aab, *Rself, *b;
   double* rhs_red;   // may be null (written only by the launch that carries it)
   int Q, N, S;
+  // K-split of k_f1u (gridDim.z > 1): partial tiles [S][gridDim.z][f1u_part_size(NTX)] and one arrival counter per
+  // subdomain (zero between launches: the workgroup that arrives last resets it)
+  double* part;
+  int* ticket;
 };
 
 // Producer / consumer workgroup of 8 waves (one workgroup per CU):
@@ -781,6 +831,22 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
   }
 }
 
+// Write-through (`sc1`) stores and L1-bypassing (`sc1`) loads for data one workgroup hands to another inside a launch
+// (K-split of k_f1u).
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_sc1_b128(double* p, double x, double y) {
+  const d2v v = {x, y};
+  // s_nop 1 inside the string: the store reads its four data registers after issue, and nothing outside the string
+  // keeps the compiler's next VALU instruction from overwriting them
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_sc1_b64(double* p, double x) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_sc1_b64(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // F1, unified-role form (compile-time Q, every column group in one slice: the configurations of BASELINE.json).
 //
@@ -803,7 +869,8 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
 // wave finished mfma(c - 1) -- the last reader of that buffer -- before it arrived at barrier c.
 template <int NTX, int QP, int ROLE>
 __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double* __restrict__ Xs, double* __restrict__ Ys,
-                                         const double* __restrict__ Kl, double* __restrict__ red, const Grp* grp, int ng) {
+                                         const double* __restrict__ Kl, double* __restrict__ red, int* __restrict__ flag,
+                                         const Grp* grp, int ng) {
   constexpr int LDX = padded_ld(NTX);
   constexpr int NTYS = F1_NTY;                         // column tiles per SIMD (waves w and w + 4)
   constexpr int LDY = 4 * NTYS * 16 + 16;
@@ -1055,7 +1122,7 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
       if (e == 0) F1_STAMP(1, c, 2);
       if (colj) {
         double kv[3];
-        const double* K = Kl + T * 9;
+        const double* K = Kl + (T - T0) * 9;   // the table holds this workgroup's element range only
 #pragma unroll
         for (int i = 0; i < 3; ++i)
           kv[i] = __builtin_fma(K[i * 3 + 2], cur.v0[2], __builtin_fma(K[i * 3 + 1], cur.v0[1], K[i * 3] * cur.v0[0]));
@@ -1110,6 +1177,57 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
     tie_set(s0);
     tie_set(s1);
   }
+  // ---- K-split: every workgroup of the subdomain leaves its partial tiles in `part`; the one whose arrival is counted
+  // last sums them in the fixed order z = 0 .. ksplit - 1 (its own included, re-read from memory), so the result does not
+  // depend on the arrival order, and goes on to the epilogue.  No workgroup waits for another one.
+  // Visibility across CUs / XCDs (per-CU L1s are never refreshed, per-XCD L2s are not coherent): the partials are stored
+  // write-through (16-byte `sc1` stores), every storing wave drains its stores (s_waitcnt vmcnt(0)) before the
+  // workgroup barrier, one lane then adds to the subdomain's counter (agent-scope atomic), and the last arriver reads
+  // every partial with `sc1` loads only -- no cache-wide release / acquire, which at eight XCDs costs more than the
+  // split saves (measured: __threadfence() on both sides made the split launch slower than the unsplit one).
+  if (ksplit > 1) {
+    constexpr int PW = NTX * 4 * 4 * 64;               // doubles per wave: [i][jt < 4][r / 2][lane][r % 2]
+    const long wg = 8L * PW + 64;                      // + the partial rhs_red
+    double* mine = a.part + ((long)s * ksplit + blockIdx.z) * wg;
+    double* pw = mine + (long)wave * PW + 2 * lane;
+#pragma unroll
+    for (int i = 0; i < NTX; ++i)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) store_sc1_b128(pw + ((i * 4 + jt) * 2 + h) * 128, acc[i][jt][2 * h], acc[i][jt][2 * h + 1]);
+    __syncthreads();                                   // red[] of the role-A waves is complete
+    if (a.rhs_red != nullptr && tid < N) {
+      double sum = 0.0;
+      for (int w = 0; w < EC; ++w) sum += red[w * 64 + tid];
+      store_sc1_b64(mine + 8L * PW + tid, sum);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier in front of the arrival
+    __syncthreads();
+    if (tid == 0) *flag = __hip_atomic_fetch_add(a.ticket + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != ksplit - 1) return;                   // workgroup-uniform
+    if (tid == 0) __hip_atomic_store(a.ticket + s, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    const double* all = a.part + (long)s * ksplit * wg;
+#pragma unroll
+    for (int i = 0; i < NTX; ++i)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) acc[i][jt] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int z = 0; z < ksplit; ++z) {
+      const double* pz = all + z * wg + (long)wave * PW + 2 * lane;
+#pragma unroll
+      for (int i = 0; i < NTX; ++i)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][jt][r] += load_sc1_b64(pz + ((i * 4 + jt) * 2 + r / 2) * 128 + r % 2);
+    }
+    if (a.rhs_red != nullptr && tid < N) {
+      double sum = 0.0;
+      for (int z = 0; z < ksplit; ++z) sum += load_sc1_b64(all + z * wg + 8L * PW + tid);
+      a.rhs_red[(long)s * N + tid] = sum;
+    }
+  }
   // ---- epilogue: scatter the tiles to their destination arrays (static accumulator indices only)
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
@@ -1126,50 +1244,50 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
         const int row = i * 16 + lk + 4 * r;
         const double val = acc[i][jt][r];
         if (live && row < N) {
-          if (ksplit == 1) {
-            dst[(long)row * ld] = val;
-            if (dst_t) dst_t[row] = val;
-          } else {
-            unsafeAtomicAdd(dst + (long)row * ld, val);
-            if (dst_t) unsafeAtomicAdd(dst_t + row, val);
-          }
+          dst[(long)row * ld] = val;
+          if (dst_t) dst_t[row] = val;
         }
       }
     }
   }
 }
 
+// doubles of K-split scratch per workgroup (see the K-split block of f1u_body)
+constexpr long f1u_part_size(int ntx) { return 8L * ntx * 4 * 4 * 64 + 64; }
+
 template <int NTX, int QP>
 __global__ __launch_bounds__(512, 2) void k_f1u(Tmpl t, F1Args a, GrpTable gt) {
   constexpr int LDX = padded_ld(NTX);
   constexpr int LDY = 4 * F1_NTY * 16 + 16;
-  extern __shared__ double Kl[];               // template stiffness K_T [nT][9] (same for all subdomains)
+  extern __shared__ double Kl[];               // template stiffness K_T [nT / gridDim.z][9] of this workgroup's element range
   __shared__ double Xs[2 * 3 * EC * LDX];
   __shared__ double Ys[2 * 3 * EC * LDY];
   __shared__ double red[EC * 64];
   __shared__ Grp grp[F1_MAXG];
+  __shared__ int flag;
   const int tid = threadIdx.x;
 #pragma unroll
   for (int g = 0; g < F1_MAXG; ++g)
     if (tid == g) grp[g] = gt.g[g];
-  for (int i = tid; i < 9 * t.nT; i += 512) Kl[i] = t.stiff[i];
+  {
+    const int nel = t.nT / (int)gridDim.z;
+    const double* src = t.stiff + 9L * nel * blockIdx.z;
+    for (int i = tid; i < 9 * nel; i += 512) Kl[i] = src[i];
+  }
   for (int i = tid; i < 2 * 3 * EC * LDX; i += 512) Xs[i] = 0.0;
   for (int i = tid; i < 2 * 3 * EC * LDY; i += 512) Ys[i] = 0.0;
   __syncthreads();
   const int ng = gt.n;
   if (uniform(tid >> 6) < EC)
-    f1u_body<NTX, QP, 0>(t, a, Xs, Ys, Kl, red, grp, ng);
+    f1u_body<NTX, QP, 0>(t, a, Xs, Ys, Kl, red, &flag, grp, ng);
   else
-    f1u_body<NTX, QP, 1>(t, a, Xs, Ys, Kl, red, grp, ng);
-  if (a.rhs_red != nullptr) {   // fixed-order sum over the EC role-A waves
+    f1u_body<NTX, QP, 1>(t, a, Xs, Ys, Kl, red, &flag, grp, ng);
+  if (gridDim.z == 1 && a.rhs_red != nullptr) {   // fixed-order sum over the EC role-A waves (K-split: done in f1u_body)
     __syncthreads();
     if (tid < a.N) {
       double sum = 0.0;
       for (int w = 0; w < EC; ++w) sum += red[w * 64 + tid];
-      if (gridDim.z == 1)
-        a.rhs_red[(long)blockIdx.x * a.N + tid] = sum;
-      else
-        unsafeAtomicAdd(a.rhs_red + (long)blockIdx.x * a.N + tid, sum);
+      a.rhs_red[(long)blockIdx.x * a.N + tid] = sum;
     }
   }
 }
@@ -1495,12 +1613,10 @@ __global__ __launch_bounds__(256) void k_f3(Tmpl t, F3Args a) {
 // [a, a] are one small MFMA product  Wa^T [E Ws | E Wa]  (K = 3 ntouch, padded to a multiple of 4); the blocks
 // towards the other sides only see the corner elements and are done on the VALU.
 template <int NTX>
-// 8 waves per SIMD (<= 64 VGPRs, no spills for NTX <= 3): four 512-thread workgroups per CU instead of three (the
-// 40 KB of LDS allow four) -- 140 -> 132 us at config 3
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 8 : 6, 8))) void k_thin_nc(Tmpl t, int S, const int* __restrict__ nbr, int N,
-                                                 const double* __restrict__ V, const double* __restrict__ ebar,
-                                                 const double* __restrict__ AvgSelf, const double* __restrict__ AvgSide,
-                                                 double* __restrict__ G_nc) {
+__device__ __forceinline__ void thin_nc_body(const Tmpl& t, int S, const int* __restrict__ nbr, int N,
+                                             const double* __restrict__ V, const double* __restrict__ ebar,
+                                             const double* __restrict__ AvgSelf, const double* __restrict__ AvgSide,
+                                             double* __restrict__ G_nc, int side, int s) {
   constexpr int NMAX = 16 * NTX;
   constexpr int LDA = padded_ld(NTX);
   constexpr int LDB = LDA;                      // one Y buffer, used twice: E W_self (block [a, self]), then E W_a ([a, a])
@@ -1508,7 +1624,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 
   constexpr int NACC = (NTX * NTX + NW - 1) / NW;
   constexpr int ITM = 3;                        // staging items per thread (ne * N <= 3 * 512, checked by the launcher)
   extern __shared__ double lds[];               // Wa [KP][LDA], Yc [KP][LDB]: 40 KB at config 3 -> 4 workgroups per CU
-  const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
+  const int slot = side_to_slot(side), tid = threadIdx.x;
   const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
   const int W = 5 * N;
@@ -1665,6 +1781,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 
   }
 }
 
+template <int NTX>
+// 8 waves per SIMD (<= 64 VGPRs, no spills for NTX <= 3): four 512-thread workgroups per CU instead of three (the
+// 40 KB of LDS allow four) -- 140 -> 132 us at config 3
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 8 : 6, 8))) void k_thin_nc(Tmpl t, int S, const int* __restrict__ nbr, int N,
+                                                 const double* __restrict__ V, const double* __restrict__ ebar,
+                                                 const double* __restrict__ AvgSelf, const double* __restrict__ AvgSide,
+                                                 double* __restrict__ G_nc) {
+  thin_nc_body<NTX>(t, S, nbr, N, V, ebar, AvgSelf, AvgSide, G_nc, blockIdx.x, blockIdx.y);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Thin part of G_bb / G_rdd / G_ab / r_fd for side a.  The image of neighbour a's basis on the target subdomain lives
 // on the np <= ncf side faces only, so every block of these operators that involves slot a is a rank-<=np product of the
@@ -1687,9 +1813,9 @@ struct ThinRtArgs {
 
 __host__ __device__ inline int fside_ld(int Q, int N) { return 4 * Q * N + 4; }
 
-__global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
+__device__ __forceinline__ void thin_rt_body(const Tmpl& t, const ThinRtArgs& a, int side, int s) {
   extern __shared__ double lds[];
-  const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
+  const int slot = side_to_slot(side), tid = threadIdx.x;
   const int Q = a.Q, N = a.N, QN = Q * N, C = 5 * QN, S = a.S, LD = fside_ld(Q, N);
   double* Fs = a.Fside + ((long)s * 4 + side) * t.ncf * LD;
   const int s2 = a.nbr[s * 5 + slot];
@@ -1762,6 +1888,8 @@ __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) {
     a.r_fd[(long)s * C + slot * QN + c] = v;
   }
 }
+
+__global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) { thin_rt_body(t, a, blockIdx.x, blockIdx.y); }
 
 // Dense block-compact form of the side blocks from the factors (callers that want the blocks themselves: the reference
 // keeps such operators as BlockOperators, block_swipdg.py:336-338): G_bb / G_rdd [S][9][QN][QN] blocks 1 + side = [a, self],
@@ -1909,13 +2037,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 // q, and the N x N product is a handful of MFMAs (the VALU version re-read two LDS operands per multiply-add and was
 // bound by the LDS pipe: 76 us at config 3 for 105 MB of output).
 template <int NTX>
-__global__ __launch_bounds__(256) void k_coupling(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
-                                                  const double* __restrict__ V, const double* __restrict__ A_cpl,
-                                                  double* __restrict__ B_sys) {
+__device__ __forceinline__ void coupling_body(const Tmpl& t, int S, const int* __restrict__ nbr, int Q, int N,
+                                              const double* __restrict__ V, const double* __restrict__ A_cpl,
+                                              double* __restrict__ B_sys, int side, int s) {
   constexpr int LD = padded_ld(NTX);
   constexpr int NT = (NTX * NTX + 3) / 4;
   extern __shared__ double lds[];
-  const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
+  const int slot = side_to_slot(side), tid = threadIdx.x;
   const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
   const int s2 = nbr[s * 5 + slot];
@@ -1962,6 +2090,34 @@ __global__ __launch_bounds__(256) void k_coupling(Tmpl t, int S, const int* __re
     }
     __syncthreads();                             // Tm is restaged for the next q
   }
+}
+
+template <int NTX>
+__global__ __launch_bounds__(256) void k_coupling(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
+                                                  const double* __restrict__ V, const double* __restrict__ A_cpl,
+                                                  double* __restrict__ B_sys) {
+  coupling_body<NTX>(t, S, nbr, Q, N, V, A_cpl, B_sys, blockIdx.x, blockIdx.y);
+}
+
+// The three thin kernels of a pass in one launch, for small subdomain counts: grid (4, S, 3), z = 0 the nonconformity
+// side blocks (512 threads), z = 1 the coupling projection, z = 2 the flux side factors (256 threads each: the upper four
+// waves leave at once -- a finished wave is not waited for by s_barrier).  Long workgroups first.
+struct ThinNcArgs {
+  const double *ebar, *AvgSelf, *AvgSide, *A_cpl;
+  double *G_nc, *B_sys;
+};
+template <int NTX>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 8 : 6, 8))) void k_thin(Tmpl t, ThinRtArgs a, ThinNcArgs c) {
+  const int side = blockIdx.x, s = blockIdx.y;
+  if (blockIdx.z == 0) {
+    thin_nc_body<NTX>(t, a.S, a.nbr, a.N, a.V, c.ebar, c.AvgSelf, c.AvgSide, c.G_nc, side, s);
+    return;
+  }
+  if (threadIdx.x >= 256) return;
+  if (blockIdx.z == 1)
+    coupling_body<NTX>(t, a.S, a.nbr, a.Q, a.N, a.V, c.A_cpl, c.B_sys, side, s);
+  else
+    thin_rt_body(t, a, side, s);
 }
 
 inline unsigned grid_for(long total) {
@@ -2088,31 +2244,41 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   const long gstride = factored ? (long)QN * QN : (long)9 * QN * QN;      // self blocks of G_bb / G_rdd
   const int abld = factored ? QN : C;                                     // row length of G_ab
   const int aboff = factored ? 0 : 2 * QN;                                // column offset of its self part
-  // Small per-rank counts (forked mode): the vertex averages are not needed by k_f1 / k_f2, only by the kernels of the
-  // library's stream 2 (k_thin_nc, k_f3) -- they run at the head of that stream, beside k_f1, instead of in front of it.
+  // Small per-rank counts ("forked" mode, S < 192): no kernel fills the chip alone and the pass is bound by launches and
+  // by the longest dependency chain, not by work.  The two preparation sweeps then go out as ONE launch (k_prep /
+  // k_prep_side), the three thin kernels as ONE launch (k_thin) on a library stream, k_f2 and k_f3 on two more, k_f1 on
+  // the caller's stream: five launches and one fork / join instead of twelve launches and two forks (config 2: 86 us of
+  // host enqueue per pass for 104 us of device time before).
   const char* env_streams0 = getenv("LRBMS_STREAMS");
   const bool forked = env_streams0 ? env_streams0[0] != '0' : S < 192;
+  const int gy_flux = (t.nrt * N + 255) / 256, gy_vtx = (t.nv * N + 255) / 256;
+  // (merged launches only there: at 1 024 subdomains k_prep takes 182 us against 113 + 59 us for the two sweeps on their own)
+  const bool merge_prep = forked, merge_thin = forked;
   if (do_prep) {
-    {
-      KScope ks(ctx, "k_flux_compact", st);
-      hipLaunchKernelGGL(k_flux_compact, dim3(S, (t.nrt * N + 255) / 256), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
-                         phase == 0 ? 1 : 0);
-    }
-    hipStream_t sv = st;
-    if (forked) {
-      sv = ctx->aux[2];
-      LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
-      LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(sv, ctx->ev_fork, 0));
-    }
-    {
-      KScope ks(ctx, "k_vertex_avg", sv);
-      hipLaunchKernelGGL(k_vertex_avg, dim3(S, (t.nv * N + 255) / 256), dim3(256), 0, sv, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
+    if (merge_prep) {
+      KScope ks(ctx, "k_prep", st);
+      hipLaunchKernelGGL(k_prep, dim3(S, gy_flux + gy_vtx), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
+                         AvgSide, phase == 0 ? 1 : 0, gy_flux);
+    } else {
+      {
+        KScope ks(ctx, "k_flux_compact", st);
+        hipLaunchKernelGGL(k_flux_compact, dim3(S, gy_flux), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
+                           phase == 0 ? 1 : 0);
+      }
+      KScope ks(ctx, "k_vertex_avg", st);
+      hipLaunchKernelGGL(k_vertex_avg, dim3(S, gy_vtx), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
                          phase == 0 ? 1 : 0);
     }
   } else if (do_b) {
-    KScope ks(ctx, "k_flux_side", st);
-    hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)S * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
-    // Avg_side is read by k_thin_nc only: k_vertex_side is launched on that kernel's stream, right in front of it
+    if (merge_prep) {
+      const unsigned gxf = grid_for((long)S * 4 * t.ncf * N), gxv = grid_for((long)S * 4 * nvs * N);
+      KScope ks(ctx, "k_prep_side", st);
+      hipLaunchKernelGGL(k_prep_side, dim3(gxf + gxv), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside, AvgSide, (int)gxf);
+    } else {
+      KScope ks(ctx, "k_flux_side", st);
+      hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)S * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
+      // Avg_side is read by k_thin_nc only: k_vertex_side is launched right in front of it
+    }
   }
   LRBMS_LAUNCH_CHECK(ctx);
   // fork: F2 / F3, the thin kernels and the coupling projection are independent of each other and of F1 (they all read
@@ -2121,20 +2287,18 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // Measured on MI355X / ROCm 7.2 (config 3 tiles): S = 128: 0.32 ms forked vs 0.41 ms serial (no kernel fills 256 CUs alone);
   // S = 256: 0.53 vs 0.51; S = 512: 0.97 vs 0.93; S = 1024: 1.92 vs 1.81 -> fork only below 192 subdomains per rank.
   // LRBMS_STREAMS=0 / 1 overrides.
-  const char* env_streams = getenv("LRBMS_STREAMS");
-  const bool multi = (do_a || do_b) && (env_streams ? env_streams[0] != '0' : S < 192);
-  // forked: caller's stream k_f1 | aux0 k_thin_rt, k_coupling | aux1 k_f2 | aux2 k_thin_nc, k_f3 (balanced from a kernel
-  // trace at 128 subdomains: every side chain ends before k_f1 does)
-  hipStream_t s_rt = multi ? ctx->aux[0] : st, s_f23 = multi ? ctx->aux[1] : st, s_nc = multi ? ctx->aux[2] : st;
-  hipStream_t side = s_nc;
-  // only the library streams that get work in this call are forked and joined (an event operation costs 4 - 5 us of host
-  // time on this runtime, and a sharded step makes three calls on ~0.2 ms of device work: with all three streams forked
-  // and joined in every call the host was the slower side, 232 us per step at 128 subdomains against 202 us now); a
-  // library stream that IS the caller's stream (the sharded choreography runs phase 2 on stream 0) needs neither.
+  const bool multi = (do_a || do_b) && forked;
+  // forked: caller's stream k_f1 | aux0 k_thin (nonconformity side blocks, coupling projection, flux side factors), k_f3 |
+  // aux1 k_f2.  k_f3 goes behind k_thin on library stream 0, not on a stream of its own: one join less, and k_f2 (one long
+  // workgroup per subdomain) is not crowded out of the CUs k_f1 leaves free (128 subdomains: 171 vs 178 / 185 us per pass
+  // with k_f3 behind k_f2 / on a third stream)
+  hipStream_t s_rt = multi ? ctx->aux[0] : st, s_f23 = multi ? ctx->aux[1] : st, s_nc = multi ? ctx->aux[0] : st;
+  // only the library streams that get work in this call are forked and joined (an event operation costs host time, and
+  // a sharded step makes three calls on ~0.2 ms of device work); a library stream that IS the caller's stream (the
+  // sharded choreography runs phase 2 on stream 0) needs neither.
   // (Replaying the phases as captured hipGraphs instead was measured too: one graph launch costs ~35 us of host time and
   // the replay loses the overlap between the branches, 272 us per step.)
-  const bool use_aux[3] = {multi && do_b && ctx->aux[0] != st, multi && do_a && ctx->aux[1] != st,
-                           multi && (do_a || do_b) && ctx->aux[2] != st};
+  const bool use_aux[3] = {multi && ctx->aux[0] != st, multi && do_a && ctx->aux[1] != st, false};
   if (use_aux[0] || use_aux[1] || use_aux[2]) {
     LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
     for (int i = 0; i < 3; ++i)
@@ -2171,26 +2335,59 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
         for (int i = 0; i < gt[sl].n; ++i) gt[sl].g[i] = groups[b0 + i];
         nsl = sl + 1;
       }
-      F1Args a{V, A_diag, P_diag, caa, Aab, Rself, b, g0 == 0 ? rhs_red : nullptr, Q, N, S};
-      // K-split in two when even the split launch leaves half of the CUs to the kernels forked beside k_f1 (a k_f1
-      // workgroup owns its CU's whole register file) and both halves keep an even number of chunks (the producers'
-      // loops are unrolled by two).  Measured: 64 subdomains (config 2) 0.160 -> 0.145 ms per pass; at 128 subdomains
-      // the split launch fills all 256 CUs, the forked kernels queue behind it and the pass gets slower (0.22 -> 0.26).
-      const char* env_ks = getenv("LRBMS_F1_KSPLIT");
-      const bool split_ok = (t.nT / EC) % 4 == 0;
-      const int ksplit = split_ok && (env_ks ? env_ks[0] == '2' : 4 * S * nsl <= 256) ? 2 : 1;
-      if (ksplit > 1) {
+      F1Args a{V, A_diag, P_diag, caa, Aab, Rself, b, g0 == 0 ? rhs_red : nullptr, Q, N, S, nullptr, nullptr};
+      const bool legacy = getenv("LRBMS_F1_LEGACY") != nullptr;   // A/B: the producer / consumer form of the same kernel
+      const bool unified = (Q == 1 || Q == 2) && one_slice && ntx <= 3 && !legacy;
+      // K-split: a rank with few subdomains spreads the element range of a subdomain over up to four workgroups (k_f1u:
+      // partial tiles + "last one sums in fixed order"; the producer / consumer kernel: two halves that meet by atomic
+      // add on zeroed outputs).  Every part keeps an even number of chunks (the stage loops are unrolled by two).  A
+      // template whose stiffness table does not fit beside the staging buffers in LDS is split for that reason alone.
+      const int nch = t.nT / EC;
+      int ksplit = 1;
+      if (unified) {
+        const char* env_ks = getenv("LRBMS_F1_KSPLIT");
+        // (measured, one MI355X: 64 subdomains 98 / 102 us per pass split in 2 / 4, 110 unsplit; 128 subdomains 171 unsplit, 185 / 199 split)
+        const int want = env_ks ? atoi(env_ks) : (S <= 64 ? 2 : 1);
+        while (ksplit < want && nch % (4 * ksplit) == 0) ksplit *= 2;
+        while (72 * (size_t)(t.nT / ksplit) > 56 * 1024 && nch % (4 * ksplit) == 0) ksplit *= 2;
+        if (72 * (size_t)(t.nT / ksplit) > 56 * 1024)
+          return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: template too large for k_f1u");
+      } else {
+        const char* env_ks = getenv("LRBMS_F1_KSPLIT");
+        const bool split_ok = nch % 4 == 0;
+        ksplit = split_ok && (env_ks ? env_ks[0] == '2' : 4 * S * nsl <= 256) ? 2 : 1;
+      }
+      if (ksplit > 1 && unified) {
+        const long need = (long)S * ksplit * f1u_part_size(ntx);
+        if (ctx->ksp_part_cap < need) {
+          if (ctx->ksp_part) LRBMS_HIP_CHECK(ctx, hipFree(ctx->ksp_part));
+          ctx->ksp_part = nullptr;
+          ctx->ksp_part_cap = 0;
+          LRBMS_HIP_CHECK(ctx, hipMalloc(&ctx->ksp_part, sizeof(double) * (size_t)need));
+          ctx->ksp_part_cap = need;
+        }
+        if (ctx->ksp_ticket_cap < S) {
+          if (ctx->ksp_ticket) LRBMS_HIP_CHECK(ctx, hipFree(ctx->ksp_ticket));
+          ctx->ksp_ticket = nullptr;
+          ctx->ksp_ticket_cap = 0;
+          LRBMS_HIP_CHECK(ctx, hipMalloc(&ctx->ksp_ticket, sizeof(int) * (size_t)S));
+          LRBMS_HIP_CHECK(ctx, hipMemset(ctx->ksp_ticket, 0, sizeof(int) * (size_t)S));
+          ctx->ksp_ticket_cap = S;
+        }
+        a.part = ctx->ksp_part;
+        a.ticket = ctx->ksp_ticket;
+      }
+      if (ksplit > 1 && !unified) {
         for (int sl = 0; sl < nsl; ++sl)
           hipLaunchKernelGGL(k_f1_zero, dim3(S), dim3(256), 0, st, gt[sl], S, N, sl == 0 ? a.rhs_red : nullptr);
       }
       const dim3 grid(S, nsl, ksplit);
       KScope ks(ctx, "k_f1", st);
-      const size_t ldsf1u = sizeof(double) * 9 * t.nT;
-      const bool legacy = getenv("LRBMS_F1_LEGACY") != nullptr;   // A/B: the producer / consumer form of the same kernel
+      const size_t ldsf1u = sizeof(double) * 9 * (t.nT / ksplit);
 #define LRBMS_F1(NTXV)                                                                                              \
   do {                                                                                                              \
-    if (Q == 1 && one_slice && !legacy) hipLaunchKernelGGL((k_f1u<NTXV, 1>), grid, dim3(512), ldsf1u, st, t, a, gt[0]);            \
-    else if (Q == 2 && one_slice && !legacy) hipLaunchKernelGGL((k_f1u<NTXV, 2>), grid, dim3(512), ldsf1u, st, t, a, gt[0]);       \
+    if (Q == 1 && unified) hipLaunchKernelGGL((k_f1u<NTXV, 1>), grid, dim3(512), ldsf1u, st, t, a, gt[0]);            \
+    else if (Q == 2 && unified) hipLaunchKernelGGL((k_f1u<NTXV, 2>), grid, dim3(512), ldsf1u, st, t, a, gt[0]);       \
     else if (Q == 1 && one_slice) hipLaunchKernelGGL((k_f1<NTXV, NTY, 1>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]); \
     else if (Q == 2 && one_slice) hipLaunchKernelGGL((k_f1<NTXV, NTY, 2>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]); \
     else hipLaunchKernelGGL((k_f1<NTXV, NTY, 0>), grid, dim3(512), ldsf1, st, t, a, gt[0], gt[1], gt[2]);             \
@@ -2211,8 +2408,41 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   }
   }
   // ---- thin parts
-  if (do_b) {
-    if (!do_prep) {
+  if (do_b && merge_thin) {
+    const int ntx = (N + 15) / 16;
+    ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, Fside, r_fd, Q, N, S};
+    ThinNcArgs c{ebar, AvgSelf, AvgSide, A_cpl, G_nc, B_sys};
+    size_t lds = thin_nc_lds_bytes(t, ntx);
+    lds = std::max(lds, sizeof(double) * (5 * t.ncf + 3 * t.ncf));
+    lds = std::max(lds, sizeof(double) * 2 * (size_t)((3 * t.ncf + 3) & ~3) * padded_ld(ntx));
+#define LRBMS_THIN(NTX)                                                                                                      \
+  do {                                                                                                                       \
+    if (lds > 64 * 1024)                                                                                                     \
+      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_thin<NTX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k_thin<NTX>, dim3(4, S, 3), dim3(512), lds, s_rt, t, a, c);                                           \
+  } while (0)
+    {
+      KScope ks(ctx, "k_thin", s_rt);
+      switch (ntx) {
+        case 1: LRBMS_THIN(1); break;
+        case 2: LRBMS_THIN(2); break;
+        case 3: LRBMS_THIN(3); break;
+        default: LRBMS_THIN(4); break;
+      }
+    }
+#undef LRBMS_THIN
+    LRBMS_LAUNCH_CHECK(ctx);
+    if (!factored) {
+      ThinExpandArgs e{Fside, ctx->nbr, G_bb, G_rdd, G_ab, Q, N, S};
+      const size_t lds3 = sizeof(double) * (size_t)t.ncf * fside_ld(Q, N);
+      KScope ks(ctx, "k_thin_expand", s_rt);
+      hipLaunchKernelGGL(k_thin_expand, dim3(4, S), dim3(256), lds3, s_rt, t, e);
+      LRBMS_LAUNCH_CHECK(ctx);
+    }
+  }
+  if (do_b && !merge_thin) {
+    hipStream_t side = s_nc;
+    if (!do_prep && !merge_prep) {
       KScope ks(ctx, "k_vertex_side", side);
       hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)S * 4 * nvs * N)), dim3(256), 0, side, t, S, ctx->nbr, N, V, AvgSide);
     }
@@ -2285,7 +2515,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
-  if (do_b) {   // off-diagonal blocks of B_sys
+  if (do_b && !merge_thin) {   // off-diagonal blocks of B_sys
     const int ntx = (N + 15) / 16;
     const size_t ldsc = sizeof(double) * 2 * (size_t)((3 * t.ncf + 3) & ~3) * padded_ld(ntx);
     KScope ks(ctx, "k_coupling", s_rt);

@@ -50,6 +50,11 @@ struct lrbms_ctx {
   struct KTimer { const char* name; hipEvent_t e0, e1; bool used; };
   std::vector<KTimer> ktimers;
   int ktime_n = 0;
+  // K-split of k_f1u (fused.hip): per-workgroup partial tiles and one arrival counter per subdomain, allocated on first use
+  double* ksp_part = nullptr;
+  long ksp_part_cap = 0;
+  int* ksp_ticket = nullptr;
+  long ksp_ticket_cap = 0;
   lrbms_quadrature* qdev = nullptr;   // device copy of the quadrature (lrbms_set_quadrature), read by the assembly kernels
   const double* user_pc = nullptr;   // prebuilt preconditioner the reduced solves use (lrbms_reduced_precond_use), caller-owned
   int user_pc_N = 0;
