@@ -192,7 +192,8 @@ def kernel_model(t, N, Q, S):
                  (chunks * 3 * ntx * 28 + nT * 3 * ntx) * 2048),
         'k_f2': (R_self + d8 * nT * 9 + d8 * n, d8 * (2 * QN * QN + QN), chunks * 4 * (nr * (nr + 1) // 2) * 2048),
         'k_f3': (V_self + A_self + d8 * nT, d8 * N * N, (nT // 16) * 12 * (ntx * (ntx + 1) // 2) * 2048),
-        'k_thin_nc': (V_self + V_halo + A_self + A_side + d8 * nT, d8 * (25 * N * N - N * N), None),
+        # factored layout (default): the side blocks of G_nc leave the chip as their rank-<=nvs factors F_nc
+        'k_thin_ncf': (d8 * 4 * (3 * t.ntouch) * N + A_self + A_side + d8 * nT, d8 * 4 * nvs * (2 * N + 4 * nvs), 0),
         # factored layout (default): the side blocks of G_bb / G_rdd / G_ab leave the chip as their rank-<=ncf factors
         'k_thin_rt': (R_self + R_side + d8 * nT * (9 + 9 * Q) + d8 * n, d8 * (4 * ncf * (4 * QN + 4) + 4 * QN), 0),
         'k_coupling': (V_self + V_halo + d8 * Q * 4 * ncf * 9, d8 * Q * 4 * N * N, None),
@@ -472,7 +473,7 @@ def main():
                     'traffic_over_compulsory': (traffic / compulsory) if traffic else None,
                     'traffic_frac_of_peak': (traffic / dev_s_per_step / 1e9 / PEAK_HBM_GBS) if traffic else None,
                     'traffic_source': pmc['file'] if pmc else None,
-                    'kernel': 'fused project+estimate pass: k_flux_compact, k_vertex_avg, k_f1, k_f2, k_f3, k_thin_nc, '
+                    'kernel': 'fused project+estimate pass: k_flux_compact, k_vertex_avg, k_f1, k_f2, k_f3, k_thin_ncf, '
                               'k_thin_rt, k_coupling (HIP events around the pass on the launch stream)',
                     'device_ms_per_step': 1e3 * dev_s_per_step,
                     'survey_8d_algorithmic': {'bytes_per_subdomain': byts, 'flops_per_subdomain': flops,

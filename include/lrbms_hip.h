@@ -249,26 +249,34 @@ int lrbms_project_estimate_fused_phase(lrbms_ctx* ctx, int32_t phase, int32_t Q,
  *   F_side [S][4][ncf][4 QN + 4]         one row per side face p:  Ra | Yb | Dp | Xab (q, i) | sc0 sc1 sc2 0  with
  *       G_bb[a, self] = Ra^T Yb    G_bb[a, a]  = Ra^T diag(sc0) Ra    G_ab^q[:, a] = Xab_q^T Ra
  *       G_rdd[a, self] = Ra^T Dp   G_rdd[a, a] = Ra^T diag(sc1) Ra    r_fd[a] = sc2^T Ra  (r_fd itself stays dense [S][5QN])
+ * The same holds for the nonconformity operator nc_i (:733-745): the Oswald image of neighbour a lives on the nvs =
+ * max(nvx, nvy) vertices of side a, W_a = -P_a A_a with A_a the vertex averages, so the pass returns
+ *   G_nc_self [S][N][N]                  the [self, self] block,
+ *   F_nc [S][4][nvs][2 N + 4 nvs]        one row per side vertex:  A_a | C_a | M_a0 M_a1 M_a2 M_a3  with
+ *       G_nc[a, self] = A_a^T C_a  (= G_nc[self, a]^T)      G_nc[a, b] = A_a^T M_ab A_b
+ *   (C_a = -P_a^T E W_self, M_ab = P_a^T E P_b; 26 KB per subdomain at config 3 instead of 115 KB of side blocks).
  * (the reference keeps such operators as BlockOperators whose missing blocks are None, block_swipdg.py:336-338: a
- * factored block is the same idea one step further).  lrbms_fside_size: doubles of F_side.  `phase` as in
- * lrbms_project_estimate_fused_phase (0 = whole pass).  The dense entry points above produce the same blocks from the
- * same factors; tests compare both. */
+ * factored block is the same idea one step further).  lrbms_fside_size / lrbms_fnc_size: doubles of F_side / F_nc.
+ * `phase` as in lrbms_project_estimate_fused_phase (0 = whole pass).  The dense entry points above produce the same blocks;
+ * tests compare both. */
 int64_t lrbms_fside_size(lrbms_ctx* ctx, int32_t Q, int32_t N);
+int64_t lrbms_fnc_size(lrbms_ctx* ctx, int32_t N);
 int lrbms_project_estimate_fused_factored(lrbms_ctx* ctx, int32_t phase, int32_t Q, int32_t N, const double* V, const double* F,
                                           const double* A_diag, const double* A_cpl, const double* P_diag, const double* b,
                                           const double* ebar, const double* caa, const double* Aab, const double* Bbb, double* work,
-                                          double* B_sys, double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd,
-                                          double* G_rdd_self, double* G_bb_self, double* G_ab_self, double* G_aa, double* F_side,
-                                          void* stream);
+                                          double* B_sys, double* rhs_red, double* E_red, double* M_red, double* G_nc_self,
+                                          double* r_fd, double* G_rdd_self, double* G_bb_self, double* G_ab_self, double* G_aa,
+                                          double* F_side, double* F_nc, void* stream);
 /* E1 on the factored layout (same arguments otherwise as lrbms_reduced_estimate / _batch). */
-int lrbms_reduced_estimate_factored(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u, const double* G_nc,
-                                    const double* r_fd, const double* G_rdd_self, const double* G_bb_self, const double* G_ab_self,
-                                    const double* G_aa, const double* F_side, const double* f2, const double* ceps, double hdiam,
-                                    double* eta_loc, void* stream);
+int lrbms_reduced_estimate_factored(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u,
+                                    const double* G_nc_self, const double* r_fd, const double* G_rdd_self, const double* G_bb_self,
+                                    const double* G_ab_self, const double* G_aa, const double* F_side, const double* F_nc,
+                                    const double* f2, const double* ceps, double hdiam, double* eta_loc, void* stream);
 int lrbms_reduced_estimate_batch_factored(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* u,
-                                          const double* G_nc, const double* r_fd, const double* G_rdd_self, const double* G_bb_self,
-                                          const double* G_ab_self, const double* G_aa, const double* F_side, const double* f2,
-                                          const double* ceps, double hdiam, double* eta_loc, void* stream);
+                                          const double* G_nc_self, const double* r_fd, const double* G_rdd_self,
+                                          const double* G_bb_self, const double* G_ab_self, const double* G_aa, const double* F_side,
+                                          const double* F_nc, const double* f2, const double* ceps, double hdiam, double* eta_loc,
+                                          void* stream);
 
 /* -- online --------------------------------------------------------------------------------------------- */
 /* E1: EstimatorBase._estimate_elliptic on reduced coefficients (estimators.py:45-112), per-subdomain part.

@@ -53,9 +53,10 @@ SIGNATURES = {
     'lrbms_project_estimate_fused': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 22),
     'lrbms_project_estimate_fused_phase': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32] + [c_vp] * 22),
     'lrbms_fside_size': (c_i64, [c_vp, c_i32, c_i32]),
-    'lrbms_project_estimate_fused_factored': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32] + [c_vp] * 23),
-    'lrbms_reduced_estimate_factored': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 10 + [c_dbl, c_vp, c_vp]),
-    'lrbms_reduced_estimate_batch_factored': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL] + [c_vp] * 10 + [c_dbl, c_vp, c_vp]),
+    'lrbms_fnc_size': (c_i64, [c_vp, c_i32]),
+    'lrbms_project_estimate_fused_factored': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32] + [c_vp] * 24),
+    'lrbms_reduced_estimate_factored': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 11 + [c_dbl, c_vp, c_vp]),
+    'lrbms_reduced_estimate_batch_factored': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL] + [c_vp] * 11 + [c_dbl, c_vp, c_vp]),
     'lrbms_reduced_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 9 + [c_dbl, c_vp, c_vp]),
     'lrbms_reduced_estimate_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL] + [c_vp] * 9 + [c_dbl, c_vp, c_vp]),
     'lrbms_reduced_solve_work_size': (c_i64, [c_vp, c_i32]),
@@ -190,6 +191,7 @@ class NativeContext:
         t = template
         self.t, self.S, self.S_ext = t, int(S), int(S_ext)
         self.n_T, self.n, self.n_rt, self.ncf = t.n_T, t.n, t.n_rt, t.ncf
+        self.nvs = max(t.nvx, t.nvy)
         arrs = {}
         d = MeshDesc()
         d.kx, d.ky, d.n_T, d.n_rt, d.n_vertices, d.ncf = t.kx, t.ky, t.n_T, t.n_rt, t.n_vertices, t.ncf
@@ -347,16 +349,21 @@ class NativeContext:
     def fside_ld(self, Q, N):
         return 4 * Q * N + 4
 
+    def fnc_ld(self, N):
+        """Row length of F_nc [S, 4, nvs, .]: A_a | C_a | M_a0 .. M_a3 (include/lrbms_hip.h)."""
+        return 2 * N + 4 * self.nvs
+
     def _gram_ptrs(self, grams, Q, N):
         """Pointers of the projected estimator operators in either layout: 6 tensors = dense (G_rdd / G_bb block-compact
-        [S, 9, QN, QN], G_ab [Q, S, N, 5QN]); 7 tensors = factored (self parts [S, QN, QN] / [Q, S, N, QN] + F_side
-        [S, 4, ncf, 4QN + 4], include/lrbms_hip.h).  Returns (pointer list, factored flag)."""
+        [S, 9, QN, QN], G_ab [Q, S, N, 5QN]); 8 tensors = factored (self parts [S, N, N] / [S, QN, QN] / [Q, S, N, QN] +
+        F_side [S, 4, ncf, 4QN + 4] + F_nc [S, 4, nvs, 2N + 4nvs], include/lrbms_hip.h).  Returns (pointer list, factored flag)."""
         S, W, C, QN = self.S, 5 * N, 5 * Q * N, Q * N
-        if len(grams) == 7:
-            G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, Fs = grams
-            return [self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, QN, QN), 'G_rdd_self'),
+        if len(grams) == 8:
+            G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, Fs, Fn = grams
+            return [self._ptr(G_nc, (S, N, N), 'G_nc_self'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, QN, QN), 'G_rdd_self'),
                     self._ptr(G_bb, (S, QN, QN), 'G_bb_self'), self._ptr(G_ab, (Q, S, N, QN), 'G_ab_self'),
-                    self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._ptr(Fs, (S, 4, self.ncf, self.fside_ld(Q, N)), 'F_side')], True
+                    self._ptr(G_aa, (Q, Q, S, N, N), 'G_aa'), self._ptr(Fs, (S, 4, self.ncf, self.fside_ld(Q, N)), 'F_side'),
+                    self._ptr(Fn, (S, 4, self.nvs, self.fnc_ld(N)), 'F_nc')], True
         G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa = grams
         return [self._ptr(G_nc, (S, W, W), 'G_nc'), self._ptr(r_fd, (S, C), 'r_fd'), self._ptr(G_rdd, (S, 9, QN, QN), 'G_rdd'),
                 self._ptr(G_bb, (S, 9, QN, QN), 'G_bb'), self._ptr(G_ab, (Q, S, N, C), 'G_ab'),

@@ -8,8 +8,8 @@ int64_t estimator_work_size(lrbms_ctx* ctx, int Q, int N);
 int64_t reduced_solve_work_size(lrbms_ctx* ctx, int N);
 int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const double* theta, const double* u, const double* G_nc,
                                   const double* r_fd, const double* G_rdd, const double* G_bb, const double* G_ab,
-                                  const double* G_aa, const double* Fside, const double* f2, const double* ceps, double hdiam,
-                                  double* eta_loc, hipStream_t st);
+                                  const double* G_aa, const double* Fside, const double* Fnc, const double* f2, const double* ceps,
+                                  double hdiam, double* eta_loc, hipStream_t st);
 int64_t reduced_solve_batch_work_size(lrbms_ctx* ctx, int N, int nmu);
 int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const double* theta, const double* B_sys,
                                const double* rhs_red, double* work, double* u, double rtol, int max_iter, double* info,
@@ -41,12 +41,13 @@ int launch_reduced_precond_build(lrbms_ctx* ctx, int Q, int N, const double* the
                                  hipStream_t st);
 int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N);
 int64_t fused_fside_size(lrbms_ctx* ctx, int Q, int N);
+int64_t fused_fnc_size(lrbms_ctx* ctx, int N);
 bool fused_supported(lrbms_ctx* ctx, int Q, int N);
 int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V, const double* F, const double* A_diag,
                                   const double* A_cpl, const double* P_diag, const double* b, const double* ebar,
                                   const double* caa, const double* Aab, const double* Bbb, double* work, double* B_sys,
                                   double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd, double* G_rdd,
-                                  double* G_bb, double* G_ab, double* G_aa, double* Fside, int phase, hipStream_t st);
+                                  double* G_bb, double* G_ab, double* G_aa, double* Fside, double* Fnc, int phase, hipStream_t st);
 
 namespace {
 
@@ -361,7 +362,7 @@ int lrbms_project_estimate_fused(lrbms_ctx* ctx, int32_t Q, int32_t N, const dou
   CHECK_PTR(ctx, work); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red); CHECK_PTR(ctx, E_red); CHECK_PTR(ctx, M_red);
   CHECK_PTR(ctx, G_nc); CHECK_PTR(ctx, r_fd); CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa);
   return launch_project_estimate_fused(ctx, Q, N, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, B_sys, rhs_red, E_red,
-                                       M_red, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, nullptr, 0, (hipStream_t)stream);
+                                       M_red, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 int lrbms_project_estimate_fused_phase(lrbms_ctx* ctx, int32_t phase, int32_t Q, int32_t N, const double* V, const double* F,
@@ -374,7 +375,7 @@ int lrbms_project_estimate_fused_phase(lrbms_ctx* ctx, int32_t phase, int32_t Q,
   CHECK_PTR(ctx, work); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red); CHECK_PTR(ctx, E_red); CHECK_PTR(ctx, M_red);
   CHECK_PTR(ctx, G_nc); CHECK_PTR(ctx, r_fd); CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa);
   return launch_project_estimate_fused(ctx, Q, N, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, B_sys, rhs_red, E_red,
-                                       M_red, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, nullptr, phase, (hipStream_t)stream);
+                                       M_red, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, nullptr, nullptr, phase, (hipStream_t)stream);
 }
 
 int64_t lrbms_fside_size(lrbms_ctx* ctx, int32_t Q, int32_t N) {
@@ -382,19 +383,25 @@ int64_t lrbms_fside_size(lrbms_ctx* ctx, int32_t Q, int32_t N) {
   return fused_fside_size(ctx, Q, N);
 }
 
+int64_t lrbms_fnc_size(lrbms_ctx* ctx, int32_t N) {
+  if (!ctx || !ctx->has_mesh || N < 1) return -1;
+  return fused_fnc_size(ctx, N);
+}
+
 int lrbms_project_estimate_fused_factored(lrbms_ctx* ctx, int32_t phase, int32_t Q, int32_t N, const double* V, const double* F,
                                           const double* A_diag, const double* A_cpl, const double* P_diag, const double* b,
                                           const double* ebar, const double* caa, const double* Aab, const double* Bbb, double* work,
-                                          double* B_sys, double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd,
-                                          double* G_rdd_self, double* G_bb_self, double* G_ab_self, double* G_aa, double* F_side,
-                                          void* stream) {
+                                          double* B_sys, double* rhs_red, double* E_red, double* M_red, double* G_nc_self,
+                                          double* r_fd, double* G_rdd_self, double* G_bb_self, double* G_ab_self, double* G_aa,
+                                          double* F_side, double* F_nc, void* stream) {
   LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, V); CHECK_PTR(ctx, F); CHECK_PTR(ctx, A_diag); CHECK_PTR(ctx, A_cpl);
   CHECK_PTR(ctx, P_diag); CHECK_PTR(ctx, b); CHECK_PTR(ctx, ebar); CHECK_PTR(ctx, caa); CHECK_PTR(ctx, Aab); CHECK_PTR(ctx, Bbb);
   CHECK_PTR(ctx, work); CHECK_PTR(ctx, B_sys); CHECK_PTR(ctx, rhs_red); CHECK_PTR(ctx, E_red); CHECK_PTR(ctx, M_red);
-  CHECK_PTR(ctx, G_nc); CHECK_PTR(ctx, r_fd); CHECK_PTR(ctx, G_rdd_self); CHECK_PTR(ctx, G_bb_self); CHECK_PTR(ctx, G_ab_self);
-  CHECK_PTR(ctx, G_aa); CHECK_PTR(ctx, F_side);
+  CHECK_PTR(ctx, G_nc_self); CHECK_PTR(ctx, r_fd); CHECK_PTR(ctx, G_rdd_self); CHECK_PTR(ctx, G_bb_self); CHECK_PTR(ctx, G_ab_self);
+  CHECK_PTR(ctx, G_aa); CHECK_PTR(ctx, F_side); CHECK_PTR(ctx, F_nc);
   return launch_project_estimate_fused(ctx, Q, N, V, F, A_diag, A_cpl, P_diag, b, ebar, caa, Aab, Bbb, work, B_sys, rhs_red, E_red,
-                                       M_red, G_nc, r_fd, G_rdd_self, G_bb_self, G_ab_self, G_aa, F_side, phase, (hipStream_t)stream);
+                                       M_red, G_nc_self, r_fd, G_rdd_self, G_bb_self, G_ab_self, G_aa, F_side, F_nc, phase,
+                                       (hipStream_t)stream);
 }
 
 int lrbms_reduced_estimate(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u, const double* G_nc,
@@ -405,21 +412,22 @@ int lrbms_reduced_estimate(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* t
   CHECK_PTR(ctx, eta_loc);
   if ((size_t)(5 * N + 5 * Q * N + 256) * sizeof(double) > 64 * 1024)
     return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate: coefficient tile exceeds 64 KB of LDS");
-  return launch_reduced_estimate(ctx, Q, N, theta, u, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, nullptr, f2, ceps, hdiam, eta_loc,
+  return launch_reduced_estimate(ctx, Q, N, theta, u, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, nullptr, nullptr, f2, ceps, hdiam, eta_loc,
                                  (hipStream_t)stream);
 }
 
-int lrbms_reduced_estimate_factored(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u, const double* G_nc,
-                                    const double* r_fd, const double* G_rdd_self, const double* G_bb_self, const double* G_ab_self,
-                                    const double* G_aa, const double* F_side, const double* f2, const double* ceps, double hdiam,
-                                    double* eta_loc, void* stream) {
-  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, u); CHECK_PTR(ctx, G_nc); CHECK_PTR(ctx, r_fd);
+int lrbms_reduced_estimate_factored(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u,
+                                    const double* G_nc_self, const double* r_fd, const double* G_rdd_self, const double* G_bb_self,
+                                    const double* G_ab_self, const double* G_aa, const double* F_side, const double* F_nc,
+                                    const double* f2, const double* ceps, double hdiam, double* eta_loc, void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, u); CHECK_PTR(ctx, G_nc_self); CHECK_PTR(ctx, r_fd);
   CHECK_PTR(ctx, G_rdd_self); CHECK_PTR(ctx, G_bb_self); CHECK_PTR(ctx, G_ab_self); CHECK_PTR(ctx, G_aa); CHECK_PTR(ctx, F_side);
-  CHECK_PTR(ctx, f2); CHECK_PTR(ctx, ceps); CHECK_PTR(ctx, eta_loc);
-  if ((size_t)(5 * N + 5 * Q * N + 256 + 4 * ctx->t.ncf * (3 + Q)) * sizeof(double) > 64 * 1024)
+  CHECK_PTR(ctx, F_nc); CHECK_PTR(ctx, f2); CHECK_PTR(ctx, ceps); CHECK_PTR(ctx, eta_loc);
+  const int nvs = ctx->t.nvx > ctx->t.nvy ? ctx->t.nvx : ctx->t.nvy;
+  if ((size_t)(5 * N + 5 * Q * N + 256 + 4 * ctx->t.ncf * (3 + Q) + 8 * nvs) * sizeof(double) > 64 * 1024)
     return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate: coefficient tile exceeds 64 KB of LDS");
-  return launch_reduced_estimate(ctx, Q, N, theta, u, G_nc, r_fd, G_rdd_self, G_bb_self, G_ab_self, G_aa, F_side, f2, ceps, hdiam,
-                                 eta_loc, (hipStream_t)stream);
+  return launch_reduced_estimate(ctx, Q, N, theta, u, G_nc_self, r_fd, G_rdd_self, G_bb_self, G_ab_self, G_aa, F_side, F_nc, f2, ceps,
+                                 hdiam, eta_loc, (hipStream_t)stream);
 }
 
 int lrbms_reduced_estimate_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* u,
@@ -429,19 +437,20 @@ int lrbms_reduced_estimate_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t n
   LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, u); CHECK_PTR(ctx, G_nc); CHECK_PTR(ctx, r_fd);
   CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa); CHECK_PTR(ctx, f2); CHECK_PTR(ctx, ceps);
   CHECK_PTR(ctx, eta_loc);
-  return launch_reduced_estimate_batch(ctx, Q, N, nmu, theta, u, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, nullptr, f2, ceps, hdiam,
+  return launch_reduced_estimate_batch(ctx, Q, N, nmu, theta, u, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa, nullptr, nullptr, f2, ceps, hdiam,
                                        eta_loc, (hipStream_t)stream);
 }
 
 int lrbms_reduced_estimate_batch_factored(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* u,
-                                          const double* G_nc, const double* r_fd, const double* G_rdd_self, const double* G_bb_self,
-                                          const double* G_ab_self, const double* G_aa, const double* F_side, const double* f2,
-                                          const double* ceps, double hdiam, double* eta_loc, void* stream) {
-  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, u); CHECK_PTR(ctx, G_nc); CHECK_PTR(ctx, r_fd);
+                                          const double* G_nc_self, const double* r_fd, const double* G_rdd_self,
+                                          const double* G_bb_self, const double* G_ab_self, const double* G_aa, const double* F_side,
+                                          const double* F_nc, const double* f2, const double* ceps, double hdiam, double* eta_loc,
+                                          void* stream) {
+  LRBMS_REQUIRE_MESH(ctx); CHECK_Q_N(ctx, Q, N); CHECK_PTR(ctx, theta); CHECK_PTR(ctx, u); CHECK_PTR(ctx, G_nc_self); CHECK_PTR(ctx, r_fd);
   CHECK_PTR(ctx, G_rdd_self); CHECK_PTR(ctx, G_bb_self); CHECK_PTR(ctx, G_ab_self); CHECK_PTR(ctx, G_aa); CHECK_PTR(ctx, F_side);
-  CHECK_PTR(ctx, f2); CHECK_PTR(ctx, ceps); CHECK_PTR(ctx, eta_loc);
-  return launch_reduced_estimate_batch(ctx, Q, N, nmu, theta, u, G_nc, r_fd, G_rdd_self, G_bb_self, G_ab_self, G_aa, F_side, f2, ceps,
-                                       hdiam, eta_loc, (hipStream_t)stream);
+  CHECK_PTR(ctx, F_nc); CHECK_PTR(ctx, f2); CHECK_PTR(ctx, ceps); CHECK_PTR(ctx, eta_loc);
+  return launch_reduced_estimate_batch(ctx, Q, N, nmu, theta, u, G_nc_self, r_fd, G_rdd_self, G_bb_self, G_ab_self, G_aa, F_side, F_nc,
+                                       f2, ceps, hdiam, eta_loc, (hipStream_t)stream);
 }
 
 int64_t lrbms_reduced_solve_work_size(lrbms_ctx* ctx, int32_t N) {

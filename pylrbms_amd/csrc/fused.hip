@@ -1512,6 +1512,8 @@ struct F3Args {
   const double *V, *ebar, *AvgSelf, *AvgSide;
   double* G_nc;
   int N, S;
+  long gsub;      // doubles between the [self, self] blocks of consecutive subdomains: 25 N^2 (dense) or N^2 (factored)
+  int gld, goff;  // their row length and first entry: 5 N, 10 N^2 + 2 N (dense) or N, 0 (factored)
 };
 
 constexpr int F3_EW = 4;   // elements staged per wave and chunk: 16 elements (48 K-rows) per barrier pair
@@ -1591,7 +1593,8 @@ __global__ __launch_bounds__(256) void k_f3(Tmpl t, F3Args a) {
     }
     __syncthreads();
   }
-  double* g = a.G_nc + (long)s * W * W + (long)(2 * N) * W + 2 * N;
+  double* g = a.G_nc + (long)s * a.gsub + a.goff;
+  const int gld = a.gld;
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     if (ti[k] < 0) continue;
@@ -1600,8 +1603,8 @@ __global__ __launch_bounds__(256) void k_f3(Tmpl t, F3Args a) {
     for (int r = 0; r < 4; ++r) {
       const int row = ti[k] * 16 + lk + 4 * r;
       if (col < N && row < N) {
-        g[(long)row * W + col] = acc[k][r];
-        if (ti[k] != tj[k]) g[(long)col * W + row] = acc[k][r];   // mirror: the stored operator is exactly symmetric
+        g[(long)row * gld + col] = acc[k][r];
+        if (ti[k] != tj[k]) g[(long)col * gld + row] = acc[k][r];   // mirror: the stored operator is exactly symmetric
       }
     }
   }
@@ -1789,6 +1792,124 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 
                                                  const double* __restrict__ AvgSelf, const double* __restrict__ AvgSide,
                                                  double* __restrict__ G_nc) {
   thin_nc_body<NTX>(t, S, nbr, N, V, ebar, AvgSelf, AvgSide, G_nc, blockIdx.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Thin part of G_nc, factored.  The image of neighbour a's basis under the Oswald interpolation error lives on the
+// vertices of side a only: W_a = -P_a A_a with A_a [nvs][N] the vertex averages k_vertex_avg computes (Avg_side) and P_a
+// the 0/1 matrix that copies side vertex `pos` to every local DoF of a touching element sitting on it.  Every block of
+// G_nc that involves slot a is therefore a product of rank <= nvs:
+//   G_nc[a, self] = A_a^T C_a,   C_a = -P_a^T E W_self  [nvs][N];      G_nc[a, b] = A_a^T M_ab A_b,   M_ab = P_a^T E P_b [nvs][nvs]
+// and the factored layout stores one row per (side, side vertex):  F_nc [S][4][nvs][2 N + 4 nvs] = A_a | C_a | M_a0 .. M_a3
+// (26 KB per subdomain at config 3 instead of the 115 KB of the nine N x N blocks; the estimate kernels contract the rows
+// with the coefficient vectors directly).  Rows of vertices a side does not have, and of sides without neighbour, are zero.
+__host__ __device__ inline int fnc_ld(int nvs, int N) { return 2 * N + 4 * nvs; }
+constexpr int NCF_ROWS = 8;   // rows listed per side vertex in k_thin_ncf (4 in the 8-triangle pattern)
+
+struct ThinNcfArgs {
+  const double *V, *ebar, *AvgSelf, *AvgSide;
+  const int* nbr;
+  double* Fnc;
+  int N, S;
+};
+
+__device__ __forceinline__ void thin_ncf_body(const Tmpl& t, const ThinNcfArgs& a, int side, int s) {
+  extern __shared__ double lds[];
+  const int slot = side_to_slot(side), tid = threadIdx.x, N = a.N;
+  const int nvs = nvs_of(t), LD = fnc_ld(nvs, N);
+  double* Fs = a.Fnc + ((long)s * 4 + side) * nvs * LD;
+  const int s2 = a.nbr[s * 5 + slot];
+  if (s2 < 0) {
+    for (int i = tid; i < nvs * LD; i += 256) Fs[i] = 0.0;
+    return;
+  }
+  const int ne = t.touch_count[side];
+  double* Y = lds;                                                // [3 ne][N]  rows of E W_self of the touching elements
+  double* Ksc = Y + 3 * t.ntouch * N;                            // [ne][9]    ebar_T K_T
+  int* ttab = reinterpret_cast<int*>(Ksc + 9 * t.ntouch);        // [ne]
+  int* vtab = ttab + t.ntouch;                                    // [ne][3]
+  int* ptab = vtab + 3 * t.ntouch;                                // [ne][3][4]
+  int* side_mask = ptab + 12 * t.ntouch;                          // [ne]
+  int* rlist = side_mask + t.ntouch;                              // [nvs][NCF_ROWS + 1]: rows 3 p + k sitting on side vertex pos (count first)
+  const double* ebs = a.ebar + (long)s * t.nT;
+  for (int i = tid; i < ne; i += 256) {
+    ttab[i] = t.touch_elem[side * t.ntouch + i];
+    side_mask[i] = t.touch_mask[side * t.ntouch + i];
+  }
+  for (int i = tid; i < 3 * ne; i += 256) vtab[i] = t.touch_vtx[side * t.ntouch * 3 + i];
+  for (int i = tid; i < 12 * ne; i += 256) ptab[i] = t.touch_pos[side * t.ntouch * 12 + i];
+  for (int i = tid; i < 9 * ne; i += 256) {
+    const int T = t.touch_elem[side * t.ntouch + i / 9];
+    Ksc[i] = ebs[T] * t.stiff[9 * T + i % 9];
+  }
+  __syncthreads();
+  // the rows that meet in a side vertex, in table order (one scan per vertex instead of one per output entry); a vertex
+  // with more than NCF_ROWS rows keeps count -1 and is scanned where it is used
+  for (int pos = tid; pos < nvs; pos += 256) {
+    int cnt = 0;
+    for (int r = 0; r < 3 * ne; ++r)
+      if (ptab[r * 4 + side] == pos) {
+        if (cnt < NCF_ROWS) rlist[pos * (NCF_ROWS + 1) + 1 + cnt] = r;
+        ++cnt;
+      }
+    rlist[pos * (NCF_ROWS + 1)] = cnt <= NCF_ROWS ? cnt : -1;
+  }
+  const double* Vs = a.V + (long)s * t.n * N;
+  const double* As = a.AvgSelf + (long)s * t.nv * N;
+  for (int it = tid; it < ne * N; it += 256) {
+    const int p = it / N, j = it - p * N, T = ttab[p];
+    double ws[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ws[i] = Vs[(long)(3 * T + i) * N + j] - As[(long)vtab[3 * p + i] * N + j];
+    const double* K = Ksc + 9 * p;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Y[(3 * p + k) * N + j] = K[k * 3] * ws[0] + K[k * 3 + 1] * ws[1] + K[k * 3 + 2] * ws[2];
+  }
+  __syncthreads();
+  const int nside = (side == 0 || side == 3) ? t.nvx : t.nvy;
+  const double* Aa = a.AvgSide + ((long)s * 4 + side) * nvs * N;
+  // A_a | C_a: one item per (side vertex, column); the rows that meet in a vertex are summed in table order
+  for (int it = tid; it < nvs * N; it += 256) {
+    const int pos = it / N, j = it - pos * N;
+    double c = 0.0;
+    if (pos < nside) {
+      const int* rl = rlist + pos * (NCF_ROWS + 1);
+      if (rl[0] >= 0) {
+        for (int k = 0; k < rl[0]; ++k) c -= Y[rl[1 + k] * N + j];
+      } else {
+        for (int r = 0; r < 3 * ne; ++r)
+          if (ptab[r * 4 + side] == pos) c -= Y[r * N + j];
+      }
+    }
+    Fs[(long)pos * LD + j] = pos < nside ? Aa[(long)pos * N + j] : 0.0;
+    Fs[(long)pos * LD + N + j] = c;
+  }
+  // M_ab: one item per (side vertex, other side b, vertex of b)
+  for (int it = tid; it < nvs * 4 * nvs; it += 256) {
+    const int pos = it / (4 * nvs), rem = it - pos * 4 * nvs, sb = rem / nvs, pos2 = rem - sb * nvs;
+    double m = 0.0;
+    if (pos < nside) {
+      const int bit = 1 << sb;
+      const int* rl = rlist + pos * (NCF_ROWS + 1);
+      const int nr = rl[0] >= 0 ? rl[0] : 3 * ne;
+      for (int i = 0; i < nr; ++i) {
+        const int r = rl[0] >= 0 ? rl[1 + i] : i, p = r / 3, k = r - 3 * p;
+        if (!(side_mask[p] & bit) || ptab[r * 4 + side] != pos) continue;
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2)
+          if (ptab[(3 * p + k2) * 4 + sb] == pos2) m += Ksc[9 * p + 3 * k + k2];
+      }
+    }
+    Fs[(long)pos * LD + 2 * N + rem] = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_thin_ncf(Tmpl t, ThinNcfArgs a) { thin_ncf_body(t, a, blockIdx.x, blockIdx.y); }
+
+static size_t thin_ncf_lds_bytes(const Tmpl& t, int N) {
+  const size_t nvs = (size_t)(t.nvx > t.nvy ? t.nvx : t.nvy);
+  return sizeof(double) * (3 * (size_t)t.ntouch * N + 9 * (size_t)t.ntouch) +
+         sizeof(int) * (17 * (size_t)t.ntouch + nvs * (NCF_ROWS + 1));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2105,15 +2226,21 @@ __global__ __launch_bounds__(256) void k_coupling(Tmpl t, int S, const int* __re
 struct ThinNcArgs {
   const double *ebar, *AvgSelf, *AvgSide, *A_cpl;
   double *G_nc, *B_sys;
+  double* Fnc;   // factored layout: the side factors of G_nc instead of its side blocks
 };
 template <int NTX>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 8 : 6, 8))) void k_thin(Tmpl t, ThinRtArgs a, ThinNcArgs c) {
   const int side = blockIdx.x, s = blockIdx.y;
-  if (blockIdx.z == 0) {
+  if (blockIdx.z == 0 && c.Fnc == nullptr) {
     thin_nc_body<NTX>(t, a.S, a.nbr, a.N, a.V, c.ebar, c.AvgSelf, c.AvgSide, c.G_nc, side, s);
     return;
   }
   if (threadIdx.x >= 256) return;
+  if (blockIdx.z == 0) {
+    const ThinNcfArgs f{a.V, c.ebar, c.AvgSelf, c.AvgSide, a.nbr, c.Fnc, a.N, a.S};
+    thin_ncf_body(t, f, side, s);
+    return;
+  }
   if (blockIdx.z == 1)
     coupling_body<NTX>(t, a.S, a.nbr, a.Q, a.N, a.V, c.A_cpl, c.B_sys, side, s);
   else
@@ -2136,6 +2263,11 @@ int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N) {
 }
 
 int64_t fused_fside_size(lrbms_ctx* ctx, int Q, int N) { return (long)ctx->S * 4 * ctx->t.ncf * fside_ld(Q, N); }
+
+int64_t fused_fnc_size(lrbms_ctx* ctx, int N) {
+  const int nvs = ctx->t.nvx > ctx->t.nvy ? ctx->t.nvx : ctx->t.nvy;
+  return (long)ctx->S * 4 * nvs * fnc_ld(nvs, N);
+}
 
 namespace {
 __global__ __launch_bounds__(256) void k_build_tables(Tmpl t, double* __restrict__ stiff, int* __restrict__ tvtx,
@@ -2215,11 +2347,13 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
                                   const double* A_cpl, const double* P_diag, const double* b, const double* ebar,
                                   const double* caa, const double* Aab, const double* Bbb, double* work, double* B_sys,
                                   double* rhs_red, double* E_red, double* M_red, double* G_nc, double* r_fd, double* G_rdd,
-                                  double* G_bb, double* G_ab, double* G_aa, double* Fside, int phase, hipStream_t st) {
+                                  double* G_bb, double* G_ab, double* G_aa, double* Fside, double* Fnc, int phase,
+                                  hipStream_t st) {
   // Fside == nullptr: dense layout -- G_rdd / G_bb block-compact [S][9][QN][QN], G_ab [Q][S][N][5QN]; the side factors
   // stay in `work` and k_thin_expand writes the side blocks from them.
   // Fside != nullptr: factored layout -- G_rdd / G_bb [S][QN][QN] and G_ab [Q][S][N][QN] hold the self parts only, every
-  // block that involves a neighbour slot is represented by F_side [S][4][ncf][4 QN + 4] (see k_thin_rt).
+  // block that involves a neighbour slot is represented by F_side [S][4][ncf][4 QN + 4] (see k_thin_rt); G_nc [S][N][N] is
+  // its [self, self] block and F_nc [S][4][nvs][2 N + 4 nvs] the factors of the others (see k_thin_ncf).
   // phase 0: the whole pass.  phase 1 / 2: its halo-independent / halo-dependent halves, for a sharded run that overlaps
   // the halo exchange with phase 1 (everything that reads only the rank's own basis slabs: R_self, Avg_self, k_f1,
   // k_f2, k_f3 -- more than half of the pass); phase 2 then needs the halo slabs of V (R_side, Avg_side, the thin
@@ -2240,6 +2374,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   double* AvgSelf = Rside + (long)S * 4 * t.ncf * QN;
   double* AvgSide = AvgSelf + (long)S * t.nv * N;
   const bool factored = Fside != nullptr;
+  if (factored != (Fnc != nullptr)) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: F_side and F_nc go together");
   if (!factored) Fside = AvgSide + (long)S * 4 * nvs * N;
   const long gstride = factored ? (long)QN * QN : (long)9 * QN * QN;      // self blocks of G_bb / G_rdd
   const int abld = factored ? QN : C;                                     // row length of G_ab
@@ -2411,8 +2546,8 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   if (do_b && merge_thin) {
     const int ntx = (N + 15) / 16;
     ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, Fside, r_fd, Q, N, S};
-    ThinNcArgs c{ebar, AvgSelf, AvgSide, A_cpl, G_nc, B_sys};
-    size_t lds = thin_nc_lds_bytes(t, ntx);
+    ThinNcArgs c{ebar, AvgSelf, AvgSide, A_cpl, G_nc, B_sys, Fnc};
+    size_t lds = factored ? thin_ncf_lds_bytes(t, N) : thin_nc_lds_bytes(t, ntx);
     lds = std::max(lds, sizeof(double) * (5 * t.ncf + 3 * t.ncf));
     lds = std::max(lds, sizeof(double) * 2 * (size_t)((3 * t.ncf + 3) & ~3) * padded_ld(ntx));
 #define LRBMS_THIN(NTX)                                                                                                      \
@@ -2447,6 +2582,14 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)S * 4 * nvs * N)), dim3(256), 0, side, t, S, ctx->nbr, N, V, AvgSide);
     }
     const int ntx = (N + 15) / 16;
+    if (factored) {
+      const ThinNcfArgs f{V, ebar, AvgSelf, AvgSide, ctx->nbr, Fnc, N, S};
+      const size_t ldsf = thin_ncf_lds_bytes(t, N);
+      if (ldsf > 64 * 1024)
+        LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_thin_ncf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+      KScope ks(ctx, "k_thin_ncf", side);
+      hipLaunchKernelGGL(k_thin_ncf, dim3(4, S), dim3(256), ldsf, side, t, f);
+    } else {
     const size_t lds = thin_nc_lds_bytes(t, ntx);
     // templates with more than ~24 touching elements per side (k_c = 8: 78 KB at N = 40) need the opt-in for > 64 KB of LDS
 #define LRBMS_THIN_NC(NTX)                                                                                                       \
@@ -2465,6 +2608,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     }
     }
 #undef LRBMS_THIN_NC
+    }
     LRBMS_LAUNCH_CHECK(ctx);
     ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, Fside, r_fd, Q, N, S};
     const size_t lds2 = sizeof(double) * (5 * t.ncf + 3 * t.ncf);   // fco [ncf][4], sc2 [ncf], fidx [ncf][5] ints
@@ -2504,7 +2648,8 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   }
   // ---- F3
   if (do_a) {
-    F3Args a{V, ebar, AvgSelf, AvgSide, G_nc, N, S};
+    F3Args a{V, ebar, AvgSelf, AvgSide, G_nc, N, S, factored ? (long)N * N : 25L * N * N, factored ? N : 5 * N,
+             factored ? 0 : 10 * N * N + 2 * N};
     const int ntx = (N + 15) / 16;
     KScope ks(ctx, "k_f3", s_nc);
     switch (ntx) {

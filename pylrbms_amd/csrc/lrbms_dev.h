@@ -140,7 +140,7 @@ int launch_estimator_grams(lrbms_ctx*, int Q, int N, const double* V, const doub
                            double* G_aa, hipStream_t);
 int launch_reduced_estimate(lrbms_ctx*, int Q, int N, const double* theta_dev, const double* u, const double* G_nc,
                             const double* r_fd, const double* G_rdd, const double* G_bb, const double* G_ab,
-                            const double* G_aa, const double* Fside, const double* f2, const double* ceps, double hdiam,
-                            double* eta_loc, hipStream_t);
+                            const double* G_aa, const double* Fside, const double* Fnc, const double* f2, const double* ceps,
+                            double hdiam, double* eta_loc, hipStream_t);
 int launch_reduced_solve(lrbms_ctx*, int Q, int N, const double* theta, const double* B_sys, const double* rhs_red,
                          double* work, double* u, double rtol, int max_iter, double* info, hipStream_t);

@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
                                                           const double* __restrict__ r_fd, const double* __restrict__ G_rdd,
                                                           const double* __restrict__ G_bb, const double* __restrict__ G_ab,
                                                           const double* __restrict__ G_aa, const double* __restrict__ Fside,
-                                                          int ncf, const double* __restrict__ f2,
-                                                          const double* __restrict__ ceps, double hdiam,
-                                                          double* __restrict__ eta_loc) {
+                                                          const double* __restrict__ Fnc, int ncf, int nvs,
+                                                          const double* __restrict__ f2, const double* __restrict__ ceps,
+                                                          double hdiam, double* __restrict__ eta_loc) {
   extern __shared__ double lds[];
   const int s = blockIdx.x;
   const int W = 5 * N, C = 5 * Q * N;
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
   double* ur = lds + W;        // [C]
   double* red = ur + C;        // [256]
   double* fac = red + 256;     // [4][ncf][3 + Q]  (factored layout only)
+  double* facn = fac + 4 * ncf * (3 + Q);   // [4][nvs][2]  (factored layout only): z_a = A_a u_a, C_a u_s per side vertex
   for (int i = threadIdx.x; i < W; i += blockDim.x) {
     const int slot = i / N, j = i % N;
     const int s2 = nbr[s * 5 + slot];
@@ -72,7 +73,11 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
   }
   __syncthreads();
   const double* ui = uo + 2 * N;
-  double p_nc = quad_partial(G_nc + (long)s * W * W, W, W, W, uo, uo);
+  // nonconformity: u^T G_nc u over the five slots, either from the dense [S][5N][5N] operator or (factored layout) from
+  // its [self, self] block [S][N][N] and the side factors F_nc (k_thin_ncf in fused.hip):
+  //   u_s^T G_ss u_s + sum_a z_a^T (2 C_a u_s + sum_b M_ab z_b),   z_a = A_a u_a
+  double p_nc = Fnc == nullptr ? quad_partial(G_nc + (long)s * W * W, W, W, W, uo, uo)
+                               : quad_partial(G_nc + (long)s * N * N, N, N, N, ui, ui);
   // z^T G z = z_s^T G_ss z_s + sum_a (2 z_a^T G_as z_s + z_a^T G_aa z_a) for G_rdd / G_bb, either from the block-compact
   // layout [S][9][QN][QN] or (Fside != nullptr) from the self blocks [S][QN][QN] plus the side factors (see k_thin_rt)
   const int QN = Q * N;
@@ -110,7 +115,23 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
       for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
       if (lane == 0) fac[it] = d;
     }
+    const int LDn = 2 * N + 4 * nvs;
+    for (int it = wave; it < 4 * nvs * 2; it += nw) {
+      const int row = it >> 1, k = it & 1, side = row / nvs;
+      const double* x = Fnc + ((long)s * 4 * nvs + row) * LDn + k * N;
+      const double* y = k == 0 ? uo + (side < 2 ? side : side + 1) * N : ui;
+      double d = 0.0;
+      for (int c = lane; c < N; c += 64) d += x[c] * y[c];
+      for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+      if (lane == 0) facn[it] = d;
+    }
     __syncthreads();
+    for (int row = threadIdx.x; row < 4 * nvs; row += blockDim.x) {
+      const double* m = Fnc + ((long)s * 4 * nvs + row) * LDn + 2 * N;
+      double mz = 0.0;
+      for (int c = 0; c < 4 * nvs; ++c) mz += m[c] * facn[2 * c];
+      p_nc += facn[2 * row] * (2.0 * facn[2 * row + 1] + mz);
+    }
     for (int it = threadIdx.x; it < 4 * ncf; it += blockDim.x) {
       const double* f = fac + it * nk;
       const double* sc = Fside + ((long)s * 4 * ncf + it) * LD + 4 * QN;
@@ -478,13 +499,15 @@ __global__ __launch_bounds__(64) void k_red_inv_norm2(int N, const double* __res
 
 int launch_reduced_estimate(lrbms_ctx* ctx, int Q, int N, const double* theta, const double* u, const double* G_nc,
                             const double* r_fd, const double* G_rdd, const double* G_bb, const double* G_ab,
-                            const double* G_aa, const double* Fside, const double* f2, const double* ceps, double hdiam,
-                            double* eta_loc, hipStream_t st) {
+                            const double* G_aa, const double* Fside, const double* Fnc, const double* f2, const double* ceps,
+                            double hdiam, double* eta_loc, hipStream_t st) {
   QVec th;
   for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
-  const size_t lds = sizeof(double) * (5 * N + 5 * Q * N + 256 + 4 * ctx->t.ncf * (3 + Q));
+  if ((Fside != nullptr) != (Fnc != nullptr)) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate: F_side and F_nc go together");
+  const int nvs = ctx->t.nvx > ctx->t.nvy ? ctx->t.nvx : ctx->t.nvy;
+  const size_t lds = sizeof(double) * (5 * N + 5 * Q * N + 256 + 4 * ctx->t.ncf * (3 + Q) + 8 * nvs);
   hipLaunchKernelGGL(k_reduced_estimate, dim3(ctx->S), dim3(256), lds, st, ctx->S, ctx->nbr, Q, N, th, u, G_nc, r_fd,
-                     G_rdd, G_bb, G_ab, G_aa, Fside, ctx->t.ncf, f2, ceps, hdiam, eta_loc);
+                     G_rdd, G_bb, G_ab, G_aa, Fside, Fnc, ctx->t.ncf, nvs, f2, ceps, hdiam, eta_loc);
   LRBMS_LAUNCH_CHECK(ctx);
   return LRBMS_OK;
 }
@@ -1900,11 +1923,21 @@ __global__ __launch_bounds__(256) void k_reduced_estimate_batch(int S, const int
 // CU), and every wave works through its tiles in batches of 8 loads, one round trip each -- eight waves instead of four
 // double the loads in flight per CU at the same LDS footprint
 constexpr int EST_NW = 8;
+// Tiles are dealt to the waves through a running unit counter (`unit`, the same sequence in every wave).  Dense layout:
+// round-robin.  Factored layout: waves 0-3 each carry the side factors of one side (the longest chain of the kernel),
+// so out of every 12 tiles waves 4-7 take two and waves 0-3 one.
+__device__ inline int est_owner(int unit, bool factored) {
+  if (!factored) return unit % EST_NW;
+  const int k = unit % 12;
+  return k < 8 ? 4 + (k & 3) : k - 8;
+}
+
 __device__ inline void quad_mfma(const double* __restrict__ G, int ld, int R, int C, const double* X, const double* Y, double wl,
-                                 double& acc) {
+                                 double& acc, int& unit, bool factored) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, wave = threadIdx.x >> 6;
   const int ntile = (R + 15) >> 4;
-  for (int tile = wave; tile < ntile; tile += EST_NW) {
+  for (int tile = 0; tile < ntile; ++tile) {
+    if (est_owner(unit++, factored) != wave) continue;
     const int ra = tile * 16 + li < R ? tile * 16 + li : R - 1;           // rows >= R repeat the last row (their X is 0)
     const double* grow = G + (long)ra * ld;
     d4m T = (d4m){0.0, 0.0, 0.0, 0.0};
@@ -1952,14 +1985,24 @@ __device__ inline d4m tile_mfma(const double* __restrict__ grow, int K, const do
 // Side blocks of G_bb / G_rdd / G_ab from the factors F_side (see k_thin_rt in fused.hip): for side a with coefficient
 // panels z_a (neighbour), z_s, u_i (own) the contributions are sum_p [sc0_p ra_p^2 + 2 ra_p (Yb z_s)_p + 2 theta_q (Xab_q u_i)_p ra_p]
 // (diffusive flux) and sum_p [sc1_p ra_p^2 + 2 ra_p (Dp z_s)_p] (residual) with ra = Ra z_a -- 3 + Q thin products per side.
-__device__ inline void side_factored(const double* __restrict__ Fs, int ncf, int Q, int N, const double* za, const double* zs,
+// (`ua`: the neighbour's coefficient panel [N][16]; z_a = theta_q u_a is formed in the B operand, lane li = parameter)
+__device__ inline void side_factored(const double* __restrict__ Fs, int ncf, int Q, int N, const double* ua, const double* zs,
                                      const double* ui, const double* thl, double& a_r, double& a_df) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
   const int QN = Q * N, LD = 4 * QN + 4;
   for (int tile = 0; tile * 16 < ncf; ++tile) {
     const int ra_row = tile * 16 + li < ncf ? tile * 16 + li : ncf - 1;     // rows >= ncf repeat the last row (masked below)
     const double* grow = Fs + (long)ra_row * LD;
-    const d4m Tra = tile_mfma(grow, QN, za, 1.0);
+    d4m Tra = (d4m){0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < Q; ++q) {
+      double tq = thl[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k)
+        if (q == k) tq = thl[k];
+      const d4m Tq = tile_mfma(grow + q * N, N, ua, tq);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Tra[rr] += Tq[rr];
+    }
     const d4m Tyb = tile_mfma(grow + QN, QN, zs, 1.0);
     const d4m Tdd = tile_mfma(grow + 2 * QN, QN, zs, 1.0);
     d4m Tx = (d4m){0.0, 0.0, 0.0, 0.0};
@@ -1990,24 +2033,34 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
                                                                      const double* __restrict__ G_nc, const double* __restrict__ r_fd,
                                                                      const double* __restrict__ G_rdd, const double* __restrict__ G_bb,
                                                                      const double* __restrict__ G_ab, const double* __restrict__ G_aa,
-                                                                     const double* __restrict__ Fside, int ncf,
-                                                                     const double* __restrict__ f2, const double* __restrict__ ceps,
-                                                                     double hdiam, double* __restrict__ eta_loc) {
+                                                                     const double* __restrict__ Fside, const double* __restrict__ Fnc,
+                                                                     int ncf, int nvs, const double* __restrict__ f2,
+                                                                     const double* __restrict__ ceps, double hdiam,
+                                                                     double* __restrict__ eta_loc) {
   extern __shared__ double lds[];
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, wave = tid >> 6;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4, wave = tid >> 6;
   const int W = 5 * N, QN = Q * N, C = 5 * QN;
-  const int Wp = (W + 3) & ~3, Cp = (C + 3) & ~3;
+  const bool factored = Fside != nullptr;
+  // factored layout: only the own rows of the theta-weighted panel are kept (the neighbours' enter through the side
+  // factors, with theta folded into the MFMA operand): 40 instead of 80 KB of LDS at config 3, three workgroups per CU
+  const int Wp = (W + 3) & ~3, Cp = factored ? (QN + 3) & ~3 : (C + 3) & ~3, Zp = factored ? (4 * nvs + 3) & ~3 : 0;
   double* uo = lds;                 // [Wp][16]  coefficients of the own + neighbour bases (columns >= nmu and pad rows zero)
-  double* ur = uo + Wp * 16;        // [Cp][16]  theta_q(mu_m) * coefficient, row order (slot, q, j)
+  double* ur = uo + Wp * 16;        // [Cp][16]  theta_q(mu_m) * coefficient: row order (slot, q, j), factored: (q, j) of the own slot
   double* red = ur + Cp * 16;       // [EST_NW][3][16]
+  double* zn = red + EST_NW * 3 * 16;   // [Zp][16]  (factored layout) z_a = A_a u_a per side vertex, rows (side, vertex)
   for (int i = tid; i < (Wp + Cp) * 16; i += 64 * EST_NW) lds[i] = 0.0;
+  for (int i = tid; i < Zp * 16; i += 64 * EST_NW) zn[i] = 0.0;
   __syncthreads();
   for (int i = tid; i < W * nmu; i += 64 * EST_NW) {
     const int row = i / nmu, m = i - row * nmu, slot = row / N, j = row - slot * N;
     const int s2 = nbr[s * 5 + slot];
     const double val = s2 >= 0 ? u[((long)s2 * N + j) * nmu + m] : 0.0;
     uo[row * 16 + m] = val;
-    for (int q = 0; q < Q; ++q) ur[((slot * Q + q) * N + j) * 16 + m] = th.v[m * 8 + q] * val;
+    if (!factored) {
+      for (int q = 0; q < Q; ++q) ur[((slot * Q + q) * N + j) * 16 + m] = th.v[m * 8 + q] * val;
+    } else if (slot == 2) {
+      for (int q = 0; q < Q; ++q) ur[(q * N + j) * 16 + m] = th.v[m * 8 + q] * val;
+    }
   }
   __syncthreads();
   double thl[8];                    // theta_q of this lane's parameter
@@ -2015,45 +2068,93 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
   for (int q = 0; q < 8; ++q) thl[q] = li < nmu ? th.v[li * 8 + q] : 0.0;
   double a_nc = 0.0, a_r = 0.0, a_df = 0.0;
   const double* ui = uo + 2 * N * 16;
-  const double* zs = ur + 2 * QN * 16;
-  const bool factored = Fside != nullptr;
+  const double* zs = factored ? ur : ur + 2 * QN * 16;
   const long gstride = factored ? (long)QN * QN : (long)9 * QN * QN;
   const int abld = factored ? QN : C;
-  // factored layout: the four sides go to the upper waves, which get no tile of the small (N- and QN-row) operators below
+  // factored layout: the four sides go to waves 0-3, which get fewer tiles of the self operators below (est_owner)
+  int unit = 0;
   if (factored) {
-    for (int side = EST_NW - 1 - wave; side >= 0 && side < 4; side -= EST_NW) {
-      const double* za = ur + (side < 2 ? side : side + 1) * QN * 16;
-      side_factored(Fside + ((long)s * 4 + side) * ncf * (4 * QN + 4), ncf, Q, N, za, zs, ui, thl, a_r, a_df);
+    // nonconformity side terms from F_nc (k_thin_ncf): z_a = A_a u_a, then sum_a z_a^T (2 C_a u_s + sum_b M_ab z_b); the
+    // z panel of all four sides goes through LDS (every side needs every other side's)
+    const int LDn = 2 * N + 4 * nvs;
+    for (int side = wave; side < 4; side += EST_NW) {
+      const double* ua = uo + (side < 2 ? side : side + 1) * N * 16;
+      side_factored(Fside + ((long)s * 4 + side) * ncf * (4 * QN + 4), ncf, Q, N, ua, zs, ui, thl, a_r, a_df);
+      const double* Fn = Fnc + ((long)s * 4 + side) * nvs * LDn;
+      for (int tile = 0; tile * 16 < nvs; ++tile) {
+        const int rr0 = tile * 16 + li < nvs ? tile * 16 + li : nvs - 1;
+        const d4m Tz = tile_mfma(Fn + (long)rr0 * LDn, N, ua, 1.0);
+        const d4m Tc = tile_mfma(Fn + (long)rr0 * LDn + N, N, ui, 1.0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = tile * 16 + lk + 4 * rr;
+          if (row < nvs) {
+            zn[(side * nvs + row) * 16 + li] = Tz[rr];
+            a_nc += 2.0 * Tz[rr] * Tc[rr];
+          }
+        }
+      }
     }
+    quad_mfma(G_nc + (long)s * N * N, N, N, N, ui, ui, 1.0, a_nc, unit, factored);
+  } else {
+    quad_mfma(G_nc + (long)s * W * W, W, W, W, uo, uo, 1.0, a_nc, unit, factored);
   }
-  quad_mfma(G_nc + (long)s * W * W, W, W, W, uo, uo, 1.0, a_nc);
   const double* Gd = G_rdd + (long)s * gstride;
   const double* Gb = G_bb + (long)s * gstride;
-  quad_mfma(Gd, QN, QN, QN, zs, zs, 1.0, a_r);
-  quad_mfma(Gb, QN, QN, QN, zs, zs, 1.0, a_df);
+  quad_mfma(Gd, QN, QN, QN, zs, zs, 1.0, a_r, unit, factored);
+  quad_mfma(Gb, QN, QN, QN, zs, zs, 1.0, a_df, unit, factored);
   if (!factored) {
     for (int side = 0; side < 4; ++side) {
       const double* za = ur + (side < 2 ? side : side + 1) * QN * 16;
-      quad_mfma(Gd + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, 2.0, a_r);
-      quad_mfma(Gd + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, 1.0, a_r);
-      quad_mfma(Gb + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, 2.0, a_df);
-      quad_mfma(Gb + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, 1.0, a_df);
+      quad_mfma(Gd + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, 2.0, a_r, unit, factored);
+      quad_mfma(Gd + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, 1.0, a_r, unit, factored);
+      quad_mfma(Gb + (long)(1 + side) * QN * QN, QN, QN, QN, za, zs, 2.0, a_df, unit, factored);
+      quad_mfma(Gb + (long)(5 + side) * QN * QN, QN, QN, QN, za, za, 1.0, a_df, unit, factored);
     }
   }
   // - 2 r_fd . ur: lanes over (16 rows of c) x parameter
-  for (int c = wave * 4 + (lane >> 4); c < C; c += 4 * EST_NW) a_r -= 2.0 * r_fd[(long)s * C + c] * ur[c * 16 + li];
+  if (!factored) {
+    for (int c = wave * 4 + (lane >> 4); c < C; c += 4 * EST_NW) a_r -= 2.0 * r_fd[(long)s * C + c] * ur[c * 16 + li];
+  } else {
+    for (int c = wave * 4 + (lane >> 4); c < C; c += 4 * EST_NW) {
+      const int slot = c / QN, rem = c - slot * QN, q = rem / N, j = rem - q * N;
+      double tq = thl[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k)
+        if (q == k) tq = thl[k];
+      a_r -= 2.0 * r_fd[(long)s * C + c] * tq * uo[(slot * N + j) * 16 + li];
+    }
+  }
   for (int q = 0; q < Q; ++q) {
     double tq = thl[0];
 #pragma unroll
     for (int k = 1; k < 8; ++k)
       if (q == k) tq = thl[k];
-    quad_mfma(G_ab + ((long)q * S + s) * N * abld, abld, N, abld, ui, factored ? zs : ur, 2.0 * tq, a_df);
+    quad_mfma(G_ab + ((long)q * S + s) * N * abld, abld, N, abld, ui, factored ? zs : ur, 2.0 * tq, a_df, unit, factored);
     for (int q2 = 0; q2 < Q; ++q2) {
       double tq2 = thl[0];
 #pragma unroll
       for (int k = 1; k < 8; ++k)
         if (q2 == k) tq2 = thl[k];
-      quad_mfma(G_aa + (((long)q * Q + q2) * S + s) * N * N, N, N, N, ui, ui, tq * tq2, a_df);
+      quad_mfma(G_aa + (((long)q * Q + q2) * S + s) * N * N, N, N, N, ui, ui, tq * tq2, a_df, unit, factored);
+    }
+  }
+  if (factored) {
+    // second half of the nonconformity side terms, z_a^T M_ab z_b: needs the z panel of every side, so it comes behind a
+    // barrier -- placed here, after the tiles of the self operators, so that no wave waits for the side waves' first half
+    __syncthreads();
+    const int LDn = 2 * N + 4 * nvs;
+    for (int side = wave - 4; side >= 0 && side < 4; side += EST_NW) {
+      const double* Fn = Fnc + ((long)s * 4 + side) * nvs * LDn + 2 * N;
+      for (int tile = 0; tile * 16 < nvs; ++tile) {
+        const int rr0 = tile * 16 + li < nvs ? tile * 16 + li : nvs - 1;
+        const d4m Tm = tile_mfma(Fn + (long)rr0 * LDn, 4 * nvs, zn, 1.0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = tile * 16 + lk + 4 * rr;
+          if (row < nvs) a_nc += zn[(side * nvs + row) * 16 + li] * Tm[rr];
+        }
+      }
     }
   }
   // fixed-order reductions: the four k-groups of a wave by shuffles (lanes li, li + 16, li + 32, li + 48 share a
@@ -2087,8 +2188,10 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
 
 int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const double* theta, const double* u, const double* G_nc,
                                   const double* r_fd, const double* G_rdd, const double* G_bb, const double* G_ab,
-                                  const double* G_aa, const double* Fside, const double* f2, const double* ceps, double hdiam,
-                                  double* eta_loc, hipStream_t st) {
+                                  const double* G_aa, const double* Fside, const double* Fnc, const double* f2, const double* ceps,
+                                  double hdiam, double* eta_loc, hipStream_t st) {
+  if ((Fside != nullptr) != (Fnc != nullptr)) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: F_side and F_nc go together");
+  const int nvs = ctx->t.nvx > ctx->t.nvy ? ctx->t.nvx : ctx->t.nvy;
   if (nmu < 1 || nmu > EB) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: need 1 <= nmu <= 16");
   const size_t lds = sizeof(double) * ((size_t)(5 * N + 5 * Q * N) * nmu + 8 * EB + 4 * 3 * EB);
   if (lds > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
@@ -2096,13 +2199,14 @@ int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const d
   for (int m = 0; m < BMAX; ++m)
     for (int q = 0; q < 8; ++q) th.v[m * 8 + q] = (m < nmu && q < Q) ? theta[m * Q + q] : 0.0;
   if (Fside != nullptr || getenv("LRBMS_EST_VALU") == nullptr) {   // matrix-core form (default; the only one for the factored layout)
-    const size_t ldm = sizeof(double) * ((size_t)(((5 * N + 3) & ~3) + ((5 * Q * N + 3) & ~3)) * 16 + EST_NW * 3 * 16);
+    const size_t ldm = sizeof(double) * ((size_t)(((5 * N + 3) & ~3) + (Fside ? ((Q * N + 3) & ~3) + ((4 * nvs + 3) & ~3) : (5 * Q * N + 3) & ~3)) * 16 +
+                                         EST_NW * 3 * 16);
     if (ldm > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
     if (ldm > 64 * 1024)
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)ldm));
     hipLaunchKernelGGL(k_reduced_estimate_batch_mfma, dim3(ctx->S), dim3(64 * EST_NW), ldm, st, ctx->S, ctx->nbr, Q, N, nmu, th, u, G_nc, r_fd,
-                       G_rdd, G_bb, G_ab, G_aa, Fside, ctx->t.ncf, f2, ceps, hdiam, eta_loc);
+                       G_rdd, G_bb, G_ab, G_aa, Fside, Fnc, ctx->t.ncf, nvs, f2, ceps, hdiam, eta_loc);
     LRBMS_LAUNCH_CHECK(ctx);
     return LRBMS_OK;
   }

@@ -147,16 +147,17 @@ class Engine:
     def alloc_outputs(self, N, factored=None):
         """The projected system and the projected estimator operators of one pass.  ``factored`` (default: whenever the
         fused pass supports (Q, N)): blocks of df_bb / r_dd / df_ab that involve a neighbour slot are returned as their
-        rank-<=ncf factors ``F_side`` (7 tensors, include/lrbms_hip.h) -- 0.9 GB of outputs at config 3 instead of 1.75 GB
-        for the dense block-compact layout (6 tensors), and the reduced estimate reads 0.6 instead of 1.5 GB."""
+        rank-<=ncf factors ``F_side`` and the blocks of nc that do as their rank-<=nvs factors ``F_nc`` (8 tensors,
+        include/lrbms_hip.h) -- 0.64 GB of outputs at config 3 instead of 1.75 GB for the dense block-compact layout
+        (6 tensors), and the reduced estimate reads 0.3 instead of 1.5 GB."""
         c, S, Q = self.ctx, self.S, self.Q
         W, C, QN = 5 * N, 5 * Q * N, Q * N
         if factored is None:
             factored = c.fused_supported(Q, N)
         sys_out = (c.empty(Q, S, 5, N, N), c.empty(S, N), c.empty(S, N, N), c.empty(S, N, N))
         if factored:
-            grams = (c.empty(S, W, W), c.empty(S, C), c.empty(S, QN, QN), c.empty(S, QN, QN), c.empty(Q, S, N, QN),
-                     c.empty(Q, Q, S, N, N), c.empty(S, 4, self.t.ncf, c.fside_ld(Q, N)))
+            grams = (c.empty(S, N, N), c.empty(S, C), c.empty(S, QN, QN), c.empty(S, QN, QN), c.empty(Q, S, N, QN),
+                     c.empty(Q, Q, S, N, N), c.empty(S, 4, self.t.ncf, c.fside_ld(Q, N)), c.empty(S, 4, c.nvs, c.fnc_ld(N)))
         else:
             grams = (c.empty(S, W, W), c.empty(S, C), c.empty(S, 9, QN, QN), c.empty(S, 9, QN, QN), c.empty(Q, S, N, C),
                      c.empty(Q, Q, S, N, N))
@@ -193,7 +194,7 @@ class Engine:
         buf = buffers if buffers is not None else self.alloc_reduce_buffers(N, factored=bool(fused))
         if buf['N'] != N:
             raise NativeError('buffers were allocated for N={}'.format(buf['N']))
-        if not fused and len(buf['grams']) == 7:
+        if not fused and len(buf['grams']) == 8:
             raise NativeError('the unfused kernels write the dense layout: allocate the buffers with factored=False')
         if fused:
             args = (V, self.F, self.A_diag, self.A_cpl, self.P_diag, self.b, self.ebar, self.caa, self.Aab, self.Bbb,
@@ -275,14 +276,26 @@ class Engine:
 
 # ---------------------------------------------------------------------- layout converters (host, for API / tests)
 def expand_factored_grams(grams, ncf=None):
-    """Factored layout (7 tensors, include/lrbms_hip.h) -> dense layout (6 tensors: G_rdd / G_bb block-compact
+    """Factored layout (8 tensors, include/lrbms_hip.h) -> dense layout (6 tensors: G_rdd / G_bb block-compact
     [S, 9, QN, QN], G_ab [Q, S, N, 5QN]) with a few batched products on the device; a 6-tuple is returned unchanged.
     For callers that want the blocks themselves (``rd.operators``, storage, tests) -- the estimate kernels never need it."""
     if len(grams) == 6:
         return tuple(grams)
     import torch
-    G_nc, r_fd, Gd_s, Gb_s, Gab_s, G_aa, Fs = grams
+    Gnc_s, r_fd, Gd_s, Gb_s, Gab_s, G_aa, Fs, Fn = grams
     Q, S, N, QN = Gab_s.shape[0], Gab_s.shape[1], Gab_s.shape[2], Gab_s.shape[3]
+    nvs = Fn.shape[2]
+    A, Cn, M = Fn[..., :N], Fn[..., N:2 * N], Fn[..., 2 * N:].reshape(S, 4, nvs, 4, nvs)
+    G_nc = torch.zeros(S, 5 * N, 5 * N, dtype=Fs.dtype, device=Fs.device)
+    G_nc[:, 2 * N:3 * N, 2 * N:3 * N] = Gnc_s
+    slots = (0, 1, 3, 4)
+    a_s = torch.einsum('sapi,sapj->saij', A, Cn)                      # [a, self] blocks
+    a_b = torch.einsum('sapi,sapbr,sbrj->sabij', A, M, A)             # [a, b] blocks
+    for a, sl in enumerate(slots):
+        G_nc[:, sl * N:(sl + 1) * N, 2 * N:3 * N] = a_s[:, a]
+        G_nc[:, 2 * N:3 * N, sl * N:(sl + 1) * N] = a_s[:, a].transpose(1, 2)
+        for b, sl2 in enumerate(slots):
+            G_nc[:, sl * N:(sl + 1) * N, sl2 * N:(sl2 + 1) * N] = a_b[:, a, b]
     Ra, Yb, Dp = Fs[..., :QN], Fs[..., QN:2 * QN], Fs[..., 2 * QN:3 * QN]
     Xab = Fs[..., 3 * QN:4 * QN].reshape(S, 4, Fs.shape[2], Q, N)
     sc0, sc1 = Fs[..., 4 * QN], Fs[..., 4 * QN + 1]

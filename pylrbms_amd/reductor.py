@@ -47,7 +47,7 @@ class ReducedDiscretization:
     @property
     def operators(self):
         """The projected estimator operators as block arrays (reference: ``rd.operators``, projected at reductor.py:70).
-        The kernels keep the blocks that involve a neighbour slot in factored form (``self.grams``, 7 tensors); the dense
+        The kernels keep the blocks that involve a neighbour slot in factored form (``self.grams``, 8 tensors); the dense
         block-compact arrays are built on first access only -- the estimate never needs them."""
         if self._operators is None:
             from pylrbms_amd.engine import expand_factored_grams

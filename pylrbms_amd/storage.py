@@ -6,10 +6,11 @@ pickling -- safetensors executes nothing on load), plus a string header that pin
 shape, subdomain template, affine components, basis width) and is checked on load.
 
 * bases:   ``V`` [S, n, N_max] (zero-padded columns), ``nloc`` [S]
-* reduced: ``B_sys`` [Q, S, 5, N, N], ``rhs_red`` [S, N], ``E_red``, ``M_red`` [S, N, N], ``G_nc`` [S, 5N, 5N],
-           ``r_fd`` [S, 5QN], ``G_aa`` [Q, Q, S, N, N] and either the factored layout ``G_rdd`` / ``G_bb`` [S, QN, QN],
-           ``G_ab`` [Q, S, N, QN], ``F_side`` [S, 4, ncf, 4QN + 4] (default of the fused pass) or the dense one
-           ``G_rdd`` / ``G_bb`` [S, 9, QN, QN] (block-compact), ``G_ab`` [Q, S, N, 5QN] (include/lrbms_hip.h)
+* reduced: ``B_sys`` [Q, S, 5, N, N], ``rhs_red`` [S, N], ``E_red``, ``M_red`` [S, N, N], ``r_fd`` [S, 5QN],
+           ``G_aa`` [Q, Q, S, N, N] and either the factored layout ``G_nc`` [S, N, N], ``G_rdd`` / ``G_bb`` [S, QN, QN],
+           ``G_ab`` [Q, S, N, QN], ``F_side`` [S, 4, ncf, 4QN + 4], ``F_nc`` [S, 4, nvs, 2N + 4nvs] (default of the fused
+           pass) or the dense one ``G_nc`` [S, 5N, 5N], ``G_rdd`` / ``G_bb`` [S, 9, QN, QN] (block-compact), ``G_ab``
+           [Q, S, N, 5QN] (include/lrbms_hip.h)
 """
 import json
 
@@ -69,7 +70,7 @@ def save_reduced(rd, path):
     meta['kind'] = 'reduced'
     meta['local_sizes'] = json.dumps(rd.reductor.local_sizes())
     tensors = dict(zip(_SYS, (rd.B_sys, rd.rhs_red, rd.E_red, rd.M_red)))
-    tensors.update(dict(zip(_GRAMS + ('F_side',), rd.grams)))       # zip stops after 6 tensors for the dense layout
+    tensors.update(dict(zip(_GRAMS + ('F_side', 'F_nc'), rd.grams)))       # zip stops after 6 tensors for the dense layout
     save_file({k: v.contiguous() for k, v in tensors.items()}, path, metadata=meta)
     return path
 
@@ -82,8 +83,9 @@ def load_reduced(reductor, path, cls=None):
     with safe_open(path, framework='pt', device=str(d.engine.ctx.device)) as f:
         meta = f.metadata()
         tensors = {k: f.get_tensor(k) for k in _SYS + _GRAMS}
-        if 'F_side' in f.keys():
-            tensors['F_side'] = f.get_tensor('F_side')
+        for k in ('F_side', 'F_nc'):
+            if k in f.keys():
+                tensors[k] = f.get_tensor(k)
     N = int(meta['N'])
     want = _signature(d, N)
     want['kind'] = 'reduced'
@@ -91,5 +93,5 @@ def load_reduced(reductor, path, cls=None):
     if json.loads(meta['local_sizes']) != reductor.local_sizes():
         raise ValueError('{}: stored local basis sizes do not match the reductor'.format(path))
     buffers = {'sys': tuple(tensors[k] for k in _SYS),
-               'grams': [tensors[k] for k in _GRAMS] + ([tensors['F_side']] if 'F_side' in tensors else [])}
+               'grams': [tensors[k] for k in _GRAMS] + ([tensors['F_side'], tensors['F_nc']] if 'F_side' in tensors else [])}
     return (cls or ReducedDiscretization)(reductor, buffers, N)

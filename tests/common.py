@@ -179,7 +179,7 @@ def compare_all(p, engine, V, mu, do_solve=True, oracle=None):
     fbuf = dbuf = None
     if eng.ctx.fused_supported(Q, N):
         fbuf = eng.project_and_estimate(Vd, eng.alloc_reduce_buffers(N), fused=True)                  # factored layout (default)
-        assert len(fbuf['grams']) == 7
+        assert len(fbuf['grams']) == 8
         dbuf = eng.project_and_estimate(Vd, eng.alloc_reduce_buffers(N, factored=False), fused=True)  # dense layout
     red = OracleReductor(d, [V[ii] for ii in range(S)])
     OI, RT = red.image_bases()
