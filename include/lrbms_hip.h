@@ -192,9 +192,12 @@ int lrbms_estimator_grams(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V,
 
 /* Fused form of the whole timed region (K7 + K8 + P1 + P2) that exploits the support of the neighbour images:
  * same outputs as lrbms_oswald_apply + lrbms_flux_reconstruct + lrbms_project_system + lrbms_estimator_grams, but the
- * padded image bases Wt / Rt are never materialised.  Supported for N <= 64 and Q N <= 128
- * (lrbms_fused_supported); work >= lrbms_fused_work_size doubles. */
+ * padded image bases Wt / Rt are never materialised.  Supported for N <= 64 and Q N <= 128 on templates whose tables
+ * fit the LDS: lrbms_fused_supported answers for the dense output layout (this entry point),
+ * lrbms_fused_factored_supported for the factored one (lrbms_project_estimate_fused_factored below), which needs less
+ * LDS and also takes large templates (k_c = 16).  work >= lrbms_fused_work_size doubles. */
 int lrbms_fused_supported(lrbms_ctx* ctx, int32_t Q, int32_t N);
+int lrbms_fused_factored_supported(lrbms_ctx* ctx, int32_t Q, int32_t N);
 int64_t lrbms_fused_work_size(lrbms_ctx* ctx, int32_t Q, int32_t N);
 int lrbms_project_estimate_fused(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* F,
                                  const double* A_diag, const double* A_cpl, const double* P_diag, const double* b,

@@ -49,6 +49,7 @@ SIGNATURES = {
     'lrbms_estimator_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_estimator_grams': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 16),
     'lrbms_fused_supported': (ctypes.c_int, [c_vp, c_i32, c_i32]),
+    'lrbms_fused_factored_supported': (ctypes.c_int, [c_vp, c_i32, c_i32]),
     'lrbms_fused_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_project_estimate_fused': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 22),
     'lrbms_project_estimate_fused_phase': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32] + [c_vp] * 22),
@@ -337,8 +338,10 @@ class NativeContext:
         self._check(rc, 'lrbms_estimator_grams')
         return G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa
 
-    def fused_supported(self, Q, N):
-        return bool(self.lib.lrbms_fused_supported(self.handle, Q, N))
+    def fused_supported(self, Q, N, factored=False):
+        """Whether the fused pass runs this (template, Q, N) with the dense (default) or the factored output layout."""
+        fn = self.lib.lrbms_fused_factored_supported if factored else self.lib.lrbms_fused_supported
+        return bool(fn(self.handle, Q, N))
 
     def fused_work_size(self, Q, N):
         sz = self.lib.lrbms_fused_work_size(self.handle, Q, N)

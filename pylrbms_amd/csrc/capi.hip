@@ -42,7 +42,7 @@ int launch_reduced_precond_build(lrbms_ctx* ctx, int Q, int N, const double* the
 int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N);
 int64_t fused_fside_size(lrbms_ctx* ctx, int Q, int N);
 int64_t fused_fnc_size(lrbms_ctx* ctx, int N);
-bool fused_supported(lrbms_ctx* ctx, int Q, int N);
+bool fused_supported(lrbms_ctx* ctx, int Q, int N, bool factored);
 int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V, const double* F, const double* A_diag,
                                   const double* A_cpl, const double* P_diag, const double* b, const double* ebar,
                                   const double* caa, const double* Aab, const double* Bbb, double* work, double* B_sys,
@@ -344,7 +344,12 @@ int lrbms_estimator_grams(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V,
 
 int lrbms_fused_supported(lrbms_ctx* ctx, int32_t Q, int32_t N) {
   if (!ctx || !ctx->has_mesh || Q < 1 || Q > 8 || N < 1) return 0;
-  return fused_supported(ctx, Q, N) ? 1 : 0;
+  return fused_supported(ctx, Q, N, false) ? 1 : 0;
+}
+
+int lrbms_fused_factored_supported(lrbms_ctx* ctx, int32_t Q, int32_t N) {
+  if (!ctx || !ctx->has_mesh || Q < 1 || N < 1) return 0;
+  return fused_supported(ctx, Q, N, true) ? 1 : 0;
 }
 
 int64_t lrbms_fused_work_size(lrbms_ctx* ctx, int32_t Q, int32_t N) {

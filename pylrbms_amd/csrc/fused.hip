@@ -2220,6 +2220,19 @@ __global__ __launch_bounds__(256) void k_coupling(Tmpl t, int S, const int* __re
   coupling_body<NTX>(t, S, nbr, Q, N, V, A_cpl, B_sys, blockIdx.x, blockIdx.y);
 }
 
+// Factored layout: all three thin kernels are 256-thread workgroups -- one launch, grid (4, S, 3).
+template <int NTX>
+__global__ __launch_bounds__(256) void k_thin3(Tmpl t, ThinRtArgs a, ThinNcfArgs f, const double* __restrict__ A_cpl,
+                                               double* __restrict__ B_sys) {
+  const int side = blockIdx.x, s = blockIdx.y;
+  if (blockIdx.z == 0)
+    coupling_body<NTX>(t, a.S, a.nbr, a.Q, a.N, a.V, A_cpl, B_sys, side, s);
+  else if (blockIdx.z == 1)
+    thin_rt_body(t, a, side, s);
+  else
+    thin_ncf_body(t, f, side, s);
+}
+
 // The three thin kernels of a pass in one launch, for small subdomain counts: grid (4, S, 3), z = 0 the nonconformity
 // side blocks (512 threads), z = 1 the coupling projection, z = 2 the flux side factors (256 threads each: the upper four
 // waves leave at once -- a finished wave is not waited for by s_barrier).  Long workgroups first.
@@ -2331,15 +2344,31 @@ static size_t thin_nc_lds_bytes(const Tmpl& t, int ntx) {   // Wa, Yc, Ksc, ttab
   return sizeof(double) * (kp * 2 * padded_ld(ntx) + 9 * (size_t)t.ntouch) + sizeof(int) * 17 * (size_t)t.ntouch;
 }
 
-bool fused_supported(lrbms_ctx* ctx, int Q, int N) {
+// Which (template, Q, N) the fused pass can run, per output layout.  Everything is a question of LDS (160 KB per
+// workgroup on gfx950): the factored layout needs less of it (no N x N side blocks are formed), so large templates
+// (k_c = 16: 2 048 elements per subdomain) run fused in that layout only.
+bool fused_supported(lrbms_ctx* ctx, int Q, int N, bool factored) {
   const Tmpl& t = ctx->t;
-  if (N > 64 || Q > 4 || Q * N > 128 || t.nT % 8 != 0 || t.nT > 1024 || t.ntouch > 256) return false;
-  {
-    const int ntx = (N + 15) / 16;
-    if (thin_nc_lds_bytes(t, ntx) > 160 * 1024 || t.ntouch * N > 3 * 512) return false;   // k_thin_nc: LDS (160 KB per workgroup on gfx950), items per thread
+  constexpr size_t LDS_MAX = 160 * 1024;
+  if (N > 64 || Q > 4 || Q * N > 128 || t.nT % 8 != 0 || t.ntouch > 256) return false;
+  const int ntx = (N + 15) / 16, nr = (Q * N + 15) / 16, nch = t.nT / EC;
+  // k_f1: the unified kernel splits the element range until its stiffness table fits beside the staging buffers; the
+  // producer / consumer kernel (N > 48 or Q > 2) keeps the whole adjacency + stiffness tables (96 bytes per element)
+  const int ngroups = Q + 2 + Q * (Q + 1) / 2 + Q * Q;
+  const bool unified = (Q == 1 || Q == 2) && ntx <= 3 && ngroups <= std::min(F1_MAXG, (4 * F1_NTY * 16) / N);
+  if (unified) {
+    int ks = 1;
+    while (72 * (size_t)(t.nT / ks) > 56 * 1024 && nch % (4 * ks) == 0) ks *= 2;
+    if (72 * (size_t)(t.nT / ks) > 56 * 1024) return false;
+  } else if (96 * (size_t)t.nT > 48 * 1024) {
+    return false;
   }
-  if ((size_t)(3 * t.ncf * Q * N + Q * t.ncf * N + 3 * t.ncf) * sizeof(double) > 64 * 1024) return false;
-  if ((size_t)2 * ((3 * t.ncf + 3) & ~3) * padded_ld((N + 15) / 16) * sizeof(double) > 64 * 1024) return false;   // k_coupling
+  static const size_t f2_static[8] = {12288, 28672, 28672, 45056, 45056, 61440, 61440, 77824};   // k_f2<NR> (see the .s)
+  if (44 * (size_t)t.nT + f2_static[nr - 1] > LDS_MAX) return false;
+  if ((size_t)2 * ((3 * t.ncf + 3) & ~3) * padded_ld(ntx) * sizeof(double) > LDS_MAX) return false;   // k_coupling
+  if (factored) return thin_ncf_lds_bytes(t, N) <= LDS_MAX;
+  if (thin_nc_lds_bytes(t, ntx) > LDS_MAX || t.ntouch * N > 3 * 512) return false;   // k_thin_nc: LDS, items per thread
+  if ((size_t)t.ncf * fside_ld(Q, N) * sizeof(double) > LDS_MAX) return false;       // k_thin_expand
   return true;
 }
 
@@ -2358,7 +2387,8 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // the halo exchange with phase 1 (everything that reads only the rank's own basis slabs: R_self, Avg_self, k_f1,
   // k_f2, k_f3 -- more than half of the pass); phase 2 then needs the halo slabs of V (R_side, Avg_side, the thin
   // kernels, the coupling blocks).  1 followed by 2 gives bit-identical results to 0.
-  if (!fused_supported(ctx, Q, N)) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: unsupported N / Q / template size");
+  if (!fused_supported(ctx, Q, N, Fside != nullptr))
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: unsupported N / Q / template size for this output layout");
   // phase 3 / 4: phase 1 split once more into its preparation (R_self, Avg_self) and its dense kernels (k_f1, k_f2,
   // k_f3), so that a host can record an event between them and start phase 2 on another stream as soon as the halo has
   // arrived, while the dense kernels are still running (Engine.project_and_estimate with `halo=`).
@@ -2387,8 +2417,10 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   const char* env_streams0 = getenv("LRBMS_STREAMS");
   const bool forked = env_streams0 ? env_streams0[0] != '0' : S < 192;
   const int gy_flux = (t.nrt * N + 255) / 256, gy_vtx = (t.nv * N + 255) / 256;
-  // (merged launches only there: at 1 024 subdomains k_prep takes 182 us against 113 + 59 us for the two sweeps on their own)
-  const bool merge_prep = forked, merge_thin = forked;
+  // (k_prep only there: at 1 024 subdomains it takes 182 us against 113 + 59 us for the two sweeps on their own)
+  // factored layout: the three thin kernels are 256-thread workgroups and always share one launch (k_thin3: 141 us at
+  // 1 024 subdomains against 65 + 49 + 41 us one after the other -- they are latency-bound and fill each other's gaps)
+  const bool merge_prep = forked, merge_thin = forked || factored;
   if (do_prep) {
     if (merge_prep) {
       KScope ks(ctx, "k_prep", st);
@@ -2556,7 +2588,22 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_thin<NTX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(k_thin<NTX>, dim3(4, S, 3), dim3(512), lds, s_rt, t, a, c);                                           \
   } while (0)
-    {
+#define LRBMS_THIN3(NTX)                                                                                                     \
+  do {                                                                                                                       \
+    if (lds > 64 * 1024)                                                                                                     \
+      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_thin3<NTX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k_thin3<NTX>, dim3(4, S, 3), dim3(256), lds, s_rt, t, a, f, A_cpl, B_sys);                            \
+  } while (0)
+    if (factored) {
+      const ThinNcfArgs f{V, ebar, AvgSelf, AvgSide, ctx->nbr, Fnc, N, S};
+      KScope ks(ctx, "k_thin3", s_rt);
+      switch (ntx) {
+        case 1: LRBMS_THIN3(1); break;
+        case 2: LRBMS_THIN3(2); break;
+        case 3: LRBMS_THIN3(3); break;
+        default: LRBMS_THIN3(4); break;
+      }
+    } else {
       KScope ks(ctx, "k_thin", s_rt);
       switch (ntx) {
         case 1: LRBMS_THIN(1); break;
@@ -2565,6 +2612,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
         default: LRBMS_THIN(4); break;
       }
     }
+#undef LRBMS_THIN3
 #undef LRBMS_THIN
     LRBMS_LAUNCH_CHECK(ctx);
     if (!factored) {
@@ -2630,20 +2678,27 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     F2Args a{Rself, Bbb, b, ctx->nbr, G_bb, G_rdd, r_fd, Q, N, S, gstride};
     const int nr = (QN + 15) / 16;
     const size_t ldsf2 = sizeof(double) * 4 * t.nT + sizeof(int) * 3 * t.nT;
+#define LRBMS_F2(NRV)                                                                                                       \
+  do {                                                                                                                       \
+    if (ldsf2 > 64 * 1024)                                                                                                   \
+      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_f2<NRV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf2)); \
+    hipLaunchKernelGGL(k_f2<NRV>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a);                                    \
+  } while (0)
     // (A unified-role form of this kernel as for k_f1 -- all eight waves stage, chunks of eight elements -- was measured
     // and dropped: its 98 KB of LDS leave one workgroup per CU, 136 us against 126 us for three co-resident workgroups of
     // this producer / consumer form; here the MFMA share is small, so other workgroups do fill the producers' latencies.)
     KScope ks(ctx, "k_f2", s_f23);
     switch (nr) {
-      case 1: hipLaunchKernelGGL(k_f2<1>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
-      case 2: hipLaunchKernelGGL(k_f2<2>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
-      case 3: hipLaunchKernelGGL(k_f2<3>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
-      case 4: hipLaunchKernelGGL(k_f2<4>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
-      case 5: hipLaunchKernelGGL(k_f2<5>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
-      case 6: hipLaunchKernelGGL(k_f2<6>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
-      case 7: hipLaunchKernelGGL(k_f2<7>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
-      default: hipLaunchKernelGGL(k_f2<8>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a); break;
+      case 1: LRBMS_F2(1); break;
+      case 2: LRBMS_F2(2); break;
+      case 3: LRBMS_F2(3); break;
+      case 4: LRBMS_F2(4); break;
+      case 5: LRBMS_F2(5); break;
+      case 6: LRBMS_F2(6); break;
+      case 7: LRBMS_F2(7); break;
+      default: LRBMS_F2(8); break;
     }
+#undef LRBMS_F2
     LRBMS_LAUNCH_CHECK(ctx);
   }
   // ---- F3
@@ -2664,12 +2719,19 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     const int ntx = (N + 15) / 16;
     const size_t ldsc = sizeof(double) * 2 * (size_t)((3 * t.ncf + 3) & ~3) * padded_ld(ntx);
     KScope ks(ctx, "k_coupling", s_rt);
+#define LRBMS_CPL(NTXV)                                                                                                      \
+  do {                                                                                                                       \
+    if (ldsc > 64 * 1024)                                                                                                    \
+      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_coupling<NTXV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc)); \
+    hipLaunchKernelGGL(k_coupling<NTXV>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys);          \
+  } while (0)
     switch (ntx) {
-      case 1: hipLaunchKernelGGL(k_coupling<1>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
-      case 2: hipLaunchKernelGGL(k_coupling<2>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
-      case 3: hipLaunchKernelGGL(k_coupling<3>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
-      default: hipLaunchKernelGGL(k_coupling<4>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys); break;
+      case 1: LRBMS_CPL(1); break;
+      case 2: LRBMS_CPL(2); break;
+      case 3: LRBMS_CPL(3); break;
+      default: LRBMS_CPL(4); break;
     }
+#undef LRBMS_CPL
     LRBMS_LAUNCH_CHECK(ctx);
   }
   for (int i = 0; i < 3; ++i)

@@ -153,7 +153,7 @@ class Engine:
         c, S, Q = self.ctx, self.S, self.Q
         W, C, QN = 5 * N, 5 * Q * N, Q * N
         if factored is None:
-            factored = c.fused_supported(Q, N)
+            factored = c.fused_supported(Q, N, factored=True)
         sys_out = (c.empty(Q, S, 5, N, N), c.empty(S, N), c.empty(S, N, N), c.empty(S, N, N))
         if factored:
             grams = (c.empty(S, N, N), c.empty(S, C), c.empty(S, QN, QN), c.empty(S, QN, QN), c.empty(Q, S, N, QN),
@@ -169,7 +169,7 @@ class Engine:
         c, S, Q, n, n_rt = self.ctx, self.S, self.Q, self.t.n, self.t.n_rt
         W, C = 5 * N, 5 * Q * N
         if images is None:
-            images = not c.fused_supported(Q, N)
+            images = not c.fused_supported(Q, N, factored=True)
         work = c.empty(max(c.estimator_work_size(Q, N), Q * S * n * N, c.fused_work_size(Q, N)))
         buf = {'N': N, 'Wt': c.empty(S, n, W) if images else None, 'Rt': c.empty(S, n_rt, C) if images else None, 'work': work}
         buf.update(self.alloc_outputs(N, factored=factored))
@@ -189,7 +189,7 @@ class Engine:
         if fused is None:
             cache = self.__dict__.setdefault('_fused_ok', {})
             if N not in cache:
-                cache[N] = c.fused_supported(self.Q, N)
+                cache[N] = c.fused_supported(self.Q, N, factored=True)
             fused = cache[N]
         buf = buffers if buffers is not None else self.alloc_reduce_buffers(N, factored=bool(fused))
         if buf['N'] != N:

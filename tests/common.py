@@ -177,9 +177,10 @@ def compare_all(p, engine, V, mu, do_solve=True, oracle=None):
     Vd = eng.ctx.from_numpy(V)
     buf = eng.project_and_estimate(Vd, fused=False)
     fbuf = dbuf = None
-    if eng.ctx.fused_supported(Q, N):
+    if eng.ctx.fused_supported(Q, N, factored=True):
         fbuf = eng.project_and_estimate(Vd, eng.alloc_reduce_buffers(N), fused=True)                  # factored layout (default)
         assert len(fbuf['grams']) == 8
+    if eng.ctx.fused_supported(Q, N):
         dbuf = eng.project_and_estimate(Vd, eng.alloc_reduce_buffers(N, factored=False), fused=True)  # dense layout
     red = OracleReductor(d, [V[ii] for ii in range(S)])
     OI, RT = red.image_bases()
@@ -231,6 +232,8 @@ def compare_all(p, engine, V, mu, do_solve=True, oracle=None):
         from pylrbms_amd.engine import expand_factored_grams      # both output layouts (factored blocks expanded for this)
         names = ('B_sys', 'rhs_red', 'E_red', 'M_red', 'G_nc', 'r_fd', 'G_rdd', 'G_bb', 'G_ab', 'G_aa')
         for tag, xb in (('fused_', fbuf), ('fused_dense_', dbuf)):
+            if xb is None:      # large templates (k_c = 16) run fused in the factored layout only
+                continue
             for name, a, b in zip(names, list(xb['sys']) + list(expand_factored_grams(xb['grams'])),
                                   list(buf['sys']) + list(buf['grams'])):
                 a, b = host(a), host(b)
@@ -248,7 +251,9 @@ def compare_all(p, engine, V, mu, do_solve=True, oracle=None):
         res['eta_factored'] = max(rel_err(eta_f[0], nc), rel_err(eta_f[1], r), rel_err(eta_f[2], df))
         ub = eng.ctx.from_numpy(np.repeat(u[:, :, None], 3, axis=2) * np.array([1.0, -0.5, 2.0])[None, None, :])
         thb = np.stack([theta, theta, theta])
-        for tag, grams in (('eta_batch_factored', fbuf['grams']), ('eta_batch_dense', dbuf['grams'])):
+        for tag, grams in (('eta_batch_factored', fbuf['grams']), ('eta_batch_dense', dbuf['grams'] if dbuf else None)):
+            if grams is None:
+                continue
             eb = host(eng.ctx.reduced_estimate_batch(thb, ub, grams, eng.f2, eng.ceps, eng.hdiam))
             _, (nc2, r2, df2), _ = rd.estimate([-0.5 * u[ii] for ii in range(S)], mu, decompose=True)
             res[tag] = max(rel_err(eb[0, :, 0], nc), rel_err(eb[1, :, 0], r), rel_err(eb[2, :, 0], df),

@@ -53,6 +53,10 @@ def _problems():
         # SURVEY.md 8d sweep point k_c = 8 (n = 1536, 32 touching elements per side: k_thin_nc with 78 KB of LDS)
         'multiscale_2x2_kc8_N40': (lambda: multiscale_problem.init_grid_and_problem(
             {'num_subdomains': [2, 2], 'coarse_per_subdomain': 8}), 40, 0.6),
+        # SURVEY.md 8d sweep point k_c = 16 (n = 6144, 2 048 elements per subdomain): fused in the factored layout only --
+        # k_f1u splits the element range four ways so that its stiffness table fits the LDS
+        'multiscale_2x2_kc16_N40': (lambda: multiscale_problem.init_grid_and_problem(
+            {'num_subdomains': [2, 2], 'coarse_per_subdomain': 16}), 40, 0.35),
     }
 
 
@@ -62,7 +66,9 @@ def test_every_array_matches_the_oracle(name):
     p = mk()
     eng = _engine(p)
     d = oracle_from_problem(p)
-    if 'kc8' in name or 'kc6' in name or 'kc4' in name:
+    if 'kc16' in name:
+        assert eng.ctx.fused_supported(eng.Q, N, factored=True) and not eng.ctx.fused_supported(eng.Q, N)
+    elif 'kc8' in name or 'kc6' in name or 'kc4' in name:
         assert eng.ctx.fused_supported(eng.Q, N), 'these templates must run through the fused pass'
     V = energy_orthonormalize(make_bases(d.S, d.n, N, seed=3), d)
     res = compare_all(p, eng, V, mu)
