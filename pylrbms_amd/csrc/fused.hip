@@ -2416,7 +2416,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // host enqueue per pass for 104 us of device time before).
   const char* env_streams0 = getenv("LRBMS_STREAMS");
   const bool forked = env_streams0 ? env_streams0[0] != '0' : S < 192;
-  const int gy_flux = (t.nrt * N + 255) / 256, gy_vtx = (t.nv * N + 255) / 256;
+  const int gy_flux = (t.nrt * N + 255) / 256, gy_vtx = (t.nv * N + 255) / 256;   // (2 - 8 items per thread instead: no faster)
   // (k_prep only there: at 1 024 subdomains it takes 182 us against 113 + 59 us for the two sweeps on their own)
   // factored layout: the three thin kernels are 256-thread workgroups and always share one launch (k_thin3: 141 us at
   // 1 024 subdomains against 65 + 49 + 41 us one after the other -- they are latency-bound and fill each other's gaps)

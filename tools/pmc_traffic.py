@@ -26,7 +26,8 @@ for d in sys.argv[3:]:
             calls[(k, r['Counter_Name'])] += 1
 print('{:24s} {:>6s} {:>18s} {:>18s}'.format('kernel', 'calls', 'FETCH_SIZE MiB/call', 'WRITE_SIZE MiB/call'))
 sf = sw = 0.0
-PASS_KERNELS = ('k_flux_compact', 'k_vertex_avg', 'k_f1', 'k_f2', 'k_f3', 'k_thin_nc', 'k_thin_rt', 'k_coupling', 'k_project_coupling')
+PASS_KERNELS = ('k_flux_compact', 'k_vertex_avg', 'k_f1', 'k_f2', 'k_f3', 'k_thin_nc', 'k_thin_rt', 'k_coupling', 'k_project_coupling',
+                'k_thin3', 'k_thin_ncf', 'k_thin', 'k_prep')
 per_kernel = {}
 for k, v in sorted(tot.items()):
     nf, nw = calls[(k, 'FETCH_SIZE')], calls[(k, 'WRITE_SIZE')]
