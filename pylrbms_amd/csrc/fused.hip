@@ -2514,6 +2514,8 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       if (unified) {
         const char* env_ks = getenv("LRBMS_F1_KSPLIT");
         // (measured, one MI355X: 64 subdomains 98 / 102 us per pass split in 2 / 4, 110 unsplit; 128 subdomains 171 unsplit, 185 / 199 split)
+        // (an UNEVEN two-way split at 128 subdomains -- long parts first, short parts beside the other kernels -- was measured
+        // too: 160 - 190 us per pass for 28 .. 16 of the 32 chunks in the long part, against 150 unsplit)
         const int want = env_ks ? atoi(env_ks) : (S <= 64 ? 2 : 1);
         while (ksplit < want && nch % (4 * ksplit) == 0) ksplit *= 2;
         while (72 * (size_t)(t.nT / ksplit) > 56 * 1024 && nch % (4 * ksplit) == 0) ksplit *= 2;
