@@ -69,7 +69,6 @@ extern "C" int lrbms_debug_f1_trace(unsigned long long* host) {
 #endif
 constexpr int EC = 4;               // elements per K-chunk (12 DG rows = 3 MFMA k-steps) = staging waves
 constexpr int F1_NTY = 7;           // Y column tiles per wave in k_f1
-constexpr int F1_YW = 4 * F1_NTY * 16;   // 448 columns
 constexpr int F1_MAXG = 12;
 
 __host__ __device__ constexpr int padded_ld(int tiles) { return (tiles * 16) % 32 == 16 ? tiles * 16 : tiles * 16 + 16; }
@@ -859,12 +858,14 @@ __device__ __forceinline__ double load_sc1_b64(const double* p) {
 //
 // Here all eight waves alternate between the two kinds of work, chunk by chunk:
 //   stage(c):  waves 0-3 (role A, element 4 c + w): the stacked four-block applies A_q V, P V on the matrix pipe, the X
-//              rows, b . v, the mass group; waves 4-7 (role B, element 4 c + w - 4): K_T v, the c^{qq'} K V groups and
-//              the A_ab R groups (the v_readlane-heavy part).  Two waves per SIMD share the staging of one element, so
+//              rows, b . v, the mass group, K_T v and the c^{qq'} K V groups; waves 4-7 (role B, element 4 c + w - 4):
+//              the A_ab R groups (the v_readlane-heavy part).  (The c^{qq'} K V groups were role B's at first: its stage
+//              was then the longer one by ~1 350 cycles per chunk, which role A spent at the barrier -- 444 -> 419 us
+//              with them moved and the odd column tile given to role B instead.)  Two waves per SIMD share the staging of one element, so
 //              their latencies overlap; every wave's global loads are a prefetch set issued one chunk ahead (asm loads +
 //              hand-counted s_waitcnt vmcnt(n), see gload_f64) that lands during the MFMA burst in between.
 //   barrier c
-//   mfma(c):   all eight waves; wave w owns 4 (w < 4) or 3 (w >= 4) of its SIMD's 7 column tiles x NTX row tiles.
+//   mfma(c):   all eight waves; wave w owns 3 (w < 4) or 4 (w >= 4) of its SIMD's 7 column tiles x NTX row tiles.
 // One barrier per chunk: a wave reaches stage(c + 1) (writes buffer (c + 1) & 1) only after its own mfma(c), and every
 // wave finished mfma(c - 1) -- the last reader of that buffer -- before it arrived at barrier c.
 template <int NTX, int QP, int ROLE>
@@ -874,13 +875,13 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
   constexpr int LDX = padded_ld(NTX);
   constexpr int NTYS = F1_NTY;                         // column tiles per SIMD (waves w and w + 4)
   constexpr int LDY = 4 * NTYS * 16 + 16;
-  constexpr int NT = ROLE == 0 ? (NTYS + 1) / 2 : NTYS / 2;
+  constexpr int NT = ROLE == 0 ? NTYS / 2 : (NTYS + 1) / 2;   // role A stages more (below), so role B takes the odd tile
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6), e = wave & 3;    // e: element of the chunk this wave stages, SIMD it runs on
   // column tiles are dealt round-robin over the SIMDs (tile 4 k + e belongs to SIMD e; role A takes the even k, role B the
   // odd ones), so that basis sizes whose groups fill only part of the 4 NTYS tiles still load every SIMD evenly; tiles
   // beyond the last column are skipped (wave-uniform branch)
-  auto tile_of = [&](int jt) { return 4 * (2 * jt + (ROLE == 0 ? 0 : 1)) + e; };
+  auto tile_of = [&](int jt) { return 4 * (2 * jt + (ROLE == 0 ? 1 : 0)) + e; };
   const int N = a.N, S = a.S, QN = QP * N;
   const int ncols = ng * N;
   const int ksplit = gridDim.z;
@@ -924,10 +925,10 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
   if constexpr (ROLE == 0) {
     // ------------------------------------------------------------- role A: applies on the matrix pipe, X rows, rhs, mass
     constexpr int R = 3 * (QP + 1);
-    constexpr int NLOADS = 3 + 3 * NTX + 3;
+    constexpr int NLOADS = 3 + 3 * NTX + 3 + 1;
     static_assert(NLOADS <= 63, "vmcnt is a 6-bit counter");
     struct Set {
-      double A[3], B[3][NTX], v0[3];
+      double A[3], B[3][NTX], v0[3], c;   // c: the element's c^{qq'} (one entry per lane q QP + q', broadcast with v_readlane)
     };
     const int r16 = li, kq = lk;
     const double* asrc[3];
@@ -952,6 +953,7 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
                                                        : (3 * e) * LDY + 4 * NTYS * 16 + r16;
       }
     }
+    const double* csrc = a.caa + ((long)(lane < QP * QP ? lane : 0) * S + s) * t.nT;
     const cint_p nbc = (cint_p)t.nb_elem;     // template adjacency of the (wave-uniform) element through the scalar cache
     // Wave-uniform data of an element (its three in-subdomain neighbours, b_T, |T|) comes through the scalar cache.  A
     // scalar load issued where its value is needed exposes its whole latency (the wave has nothing else to issue), so
@@ -987,8 +989,10 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i) x.v0[i] = gload_f64(Vs + (long)(3 * T + i) * N + jc);
+      x.c = gload_f64(csrc + T);
     };
     auto tie_set = [&](Set& x) {
+      tie(x.c);
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         tie(x.A[ks]);
@@ -1028,6 +1032,23 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
         const double m = sc_cur.area * (1.0 / 12.0), sum = cur.v0[0] + cur.v0[1] + cur.v0[2];
 #pragma unroll
         for (int i = 0; i < 3; ++i) Yb[(3 * e + i) * LDY + (QP + 1) * N + j] = m * (sum + cur.v0[i]);
+        // K_T v and the c^{qq'} K V groups (moved here from role B, whose stage was the longer one: role A waited ~1 350
+        // cycles per chunk at the barrier)
+        double kv[3];
+        const double* K = Kl + (T - T0) * 9;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          kv[i] = __builtin_fma(K[i * 3 + 2], cur.v0[2], __builtin_fma(K[i * 3 + 1], cur.v0[1], K[i * 3] * cur.v0[0]));
+        int g = QP + 2;
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+#pragma unroll
+          for (int q2 = q; q2 < QP; ++q2) {
+            const double cc = bcast_d(cur.c, q * QP + q2);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Yb[(3 * e + i) * LDY + g * N + j] = cc * kv[i];
+            ++g;
+          }
       }
 #pragma unroll
       for (int ct = 0; ct < NTX; ++ct)
@@ -1068,22 +1089,17 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
     if (do_rhs) red[e * 64 + lane] = rhs_part;
   } else {
     // ------------------------------------------------------------- role B: K_T v, c^{qq'} K V and A_ab R groups
-    constexpr int NLOADS = 3 + 3 * QP + 1;
+    constexpr int NLOADS = 3 * QP + 1;
     struct Set {
-      double v0[3], rv[3][QP], ab;
+      double rv[3][QP], ab;
     };
     const double* Rs = a.Rself + (long)s * t.nrt * QN;
     // the element's A_ab^q blocks and c^{qq'}: one entry per lane in a prefetch register, broadcast with v_readlane
     // (through the scalar cache into SGPRs instead they cost 44 SGPRs held across the MFMA phase: the kernel then spills
     // SGPRs and runs 10 % slower -- measured)
     const double* absrc = a.Aab + (long)s * t.nT * 9;   // lanes beyond the record re-read its first entry
-    int abstr = 9;
-    if (lane < 9 * QP) {
-      absrc = a.Aab + ((long)(lane / 9) * S + s) * t.nT * 9 + lane % 9;
-    } else if (lane < 9 * QP + QP * QP) {
-      absrc = a.caa + ((long)(lane - 9 * QP) * S + s) * t.nT;
-      abstr = 1;
-    }
+    constexpr int abstr = 9;
+    if (lane < 9 * QP) absrc = a.Aab + ((long)(lane / 9) * S + s) * t.nT * 9 + lane % 9;
     const cint_p rtc = (cint_p)t.elem_rt;
     struct Sc {       // RT0 rows of the element's three faces, fetched through the scalar cache one stage ahead (see role A)
       int rt[3];
@@ -1094,8 +1110,6 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
     };
     auto load_set = [&](int T, const Sc& sc, Set& x) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) x.v0[i] = gload_f64(Vs + (long)(3 * T + i) * N + jc);
-#pragma unroll
       for (int f = 0; f < 3; ++f)
 #pragma unroll
         for (int q2 = 0; q2 < QP; ++q2) x.rv[f][q2] = gload_f64(Rs + (long)sc.rt[f] * QN + q2 * N + jc);
@@ -1104,7 +1118,6 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
     auto tie_set = [&](Set& x) {
 #pragma unroll
       for (int f = 0; f < 3; ++f) {
-        tie(x.v0[f]);
 #pragma unroll
         for (int q2 = 0; q2 < QP; ++q2) tie(x.rv[f][q2]);
       }
@@ -1121,25 +1134,12 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
       tie_set(cur);
       if (e == 0) F1_STAMP(1, c, 2);
       if (colj) {
-        double kv[3];
-        const double* K = Kl + (T - T0) * 9;   // the table holds this workgroup's element range only
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-          kv[i] = __builtin_fma(K[i * 3 + 2], cur.v0[2], __builtin_fma(K[i * 3 + 1], cur.v0[1], K[i * 3] * cur.v0[0]));
-        int g = QP + 2;
+        int g = QP + 2 + QP * (QP + 1) / 2;
         auto put = [&](const double (&y)[3]) {
 #pragma unroll
           for (int i = 0; i < 3; ++i) Yb[(3 * e + i) * LDY + g * N + j] = y[i];
           ++g;
         };
-#pragma unroll
-        for (int q = 0; q < QP; ++q)
-#pragma unroll
-          for (int q2 = q; q2 < QP; ++q2) {
-            const double cc = bcast_d(cur.ab, 9 * QP + q * QP + q2);
-            const double y[3] = {cc * kv[0], cc * kv[1], cc * kv[2]};
-            put(y);
-          }
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
           double A[9];
@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(256) void k_f3(Tmpl t, F3Args a) {
   __shared__ double Xs[3 * ECH * LD], Ys[3 * ECH * LD];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
-  const int N = a.N, W = 5 * N;
+  const int N = a.N;
   for (int i = tid; i < 3 * ECH * LD; i += 256) Xs[i] = Ys[i] = 0.0;
   int ti[NT], tj[NT];
 #pragma unroll
@@ -2472,7 +2472,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       if (use_aux[i]) LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
   }
 
-  // ---- F1: build the column-group list and launch in slices of at most F1_YW / N groups
+  // ---- F1: build the column-group list and launch in slices of at most 4 * F1_NTY * 16 / N groups
   std::vector<Grp> groups;
   if (do_a) {
   for (int q = 0; q < Q; ++q) groups.push_back({G_SYS, q, 0, N, B_sys + ((long)q * S * 5 + 2) * N * N, nullptr, (long)5 * N * N});

@@ -64,8 +64,8 @@ def test_emitted_isa_keeps_the_assumptions_of_the_asm_managed_prefetch():
     (pylrbms_amd/_isa_check.py; cross-compiles on the CPU box)."""
     from pylrbms_amd._build import check_isa
     report = check_isa()
-    assert any(r.startswith('k_f1u<3,2>') and "vmcnt(15)" in r for r in report), report       # config 3 (N = 40, Q = 2): role A
-    assert any(r.startswith("k_f1u<3,2>") and "vmcnt(10)" in r for r in report), report       # ... and role B
+    assert any(r.startswith('k_f1u<3,2>') and "vmcnt(16)" in r for r in report), report       # config 3 (N = 40, Q = 2): role A (3 + 9 + 3 + 1 loads)
+    assert any(r.startswith("k_f1u<3,2>") and "vmcnt(7)" in r for r in report), report        # ... and role B (6 + 1 loads)
     assert any(r.startswith('k_f1<3,7,2>') and "vmcnt(19)" in r for r in report), report      # producer / consumer form
     assert any(r.startswith('k_f2<5>') and "vmcnt(7)" in r for r in report), report
 
