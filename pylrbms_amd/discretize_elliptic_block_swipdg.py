@@ -53,6 +53,70 @@ class LinearImageOperator:
         return d.engine.ctx.flux_reconstruct(d.engine.F, V)
 
 
+class BlockProjectionOperator:
+    """``data['local_projections'][ii]``: (solution space) -> (space of subdomain ii), picks block ``ii``
+    (reference block_swipdg.py:696-697)."""
+
+    def __init__(self, discretization, subdomain):
+        self._d, self.subdomain, self.linear = discretization, subdomain, True
+        self.name = 'local_projection_{}'.format(subdomain)
+
+    def apply(self, U, mu=None):
+        d, i = self._d, self._d.engine.local.index(self.subdomain)
+        return BlockVectorArray(U.tensor[i:i + 1], BlockVectorSpace([d.solution_space.subspaces[i]]))
+
+
+class LocalImageProjection:
+    """``data['local_rt_projections'][ii]`` / ``data['local_oi_projections'][ii]`` (reference block_swipdg.py:699-718): the
+    ``BlockRowOperator`` of the projections that pick, from the image of EVERY neighbour ``kk`` of ``ii`` under the flux
+    reconstruction / the Oswald interpolation error, the component living on ``ii`` -- applied to a block array it is their
+    sum.  The kernels K7 / K8 produce the images target-major (``d.estimator.flux_reconstruction.apply(U)`` ->
+    ``[S, rows, 5 * cols]``, one column block per neighbour slot, include/lrbms_hip.h), so here ``apply`` adds the five
+    slot blocks of target ``ii``: ``[rows, cols]`` on the device."""
+
+    def __init__(self, discretization, subdomain, kind):
+        self._d, self.subdomain, self.kind, self.linear = discretization, subdomain, kind, True
+        self.name = 'local_{}_projection_{}'.format(kind, subdomain)
+
+    def apply(self, images, mu=None):
+        i = self._d.engine.local.index(self.subdomain)
+        rows, wide = images.shape[1], images.shape[2]
+        assert wide % 5 == 0, 'expected the target-major image array [S, rows, 5 * cols]'
+        return images[i].view(rows, 5, wide // 5).sum(dim=1)
+
+
+class LocalDivergenceOperator:
+    """``data['local_div_ops'][ii]`` (reference block_swipdg.py:722-729): RT0 coefficients on subdomain ``ii`` -> DG
+    coefficients of the (piecewise constant) divergence.  ``apply`` runs the native kernel (``lrbms_div_apply``, all
+    subdomains of the rank in one launch, this one returned); ``matrix()`` is the dense ``[n, n_rt]`` matrix for inspection."""
+
+    def __init__(self, discretization, subdomain):
+        self._d, self.subdomain, self.linear = discretization, subdomain, True
+        self.name = 'local_divergence_{}'.format(subdomain)
+
+    def apply(self, R, mu=None):
+        """R: ``[n_rt, L]`` device tensor of RT0 coefficients on this subdomain -> ``[n, L]``."""
+        eng, i = self._d.engine, self._d.engine.local.index(self.subdomain)
+        Rt = eng.ctx.zeros(eng.S, eng.t.n_rt, R.shape[1])
+        Rt[i] = R
+        per_element = eng.ctx.div_apply(Rt, mode=0)[i]               # [n_T, L]
+        return per_element.repeat_interleave(3, dim=0)
+
+    def matrix(self):
+        eng = self._d.engine
+        t, nbr = eng.t, eng.nbr[eng.local.index(self.subdomain)]
+        out = np.zeros((t.n, t.n_rt))
+        for e in range(t.n_T):
+            for f in range(3):
+                sign, nb = t.face_sign[e, f], t.nb_elem[e, f]
+                if nb < 0:                                   # face on side -1 - nb: outward where that side is domain boundary
+                    side = -1 - nb
+                    if nbr[side if side < 2 else side + 1] < 0:
+                        sign = 1
+                out[3 * e:3 * e + 3, t.elem_rt[e, f]] = sign * t.face_len[e, f] / t.area[e]
+        return out
+
+
 class DuneDiscretization:
     """Block-SWIPDG discretization living on one GPU (one rank's tile of subdomains)."""
 
@@ -283,7 +347,11 @@ def discretize(grid_and_problem_data, solver_options=None, mpi_comm=None, device
                     return engine.t.n
             return _Local
 
-    data = dict(grid=grid, block_space=_BlockSpace, local_projections=[], local_rt_projections=[],
-                local_oi_projections=[], local_div_ops=[], local_l2_products=d.products['l2'])
+    owned = list(engine.local)
+    data = dict(grid=grid, block_space=_BlockSpace,
+                local_projections=[BlockProjectionOperator(d, ii) for ii in owned],
+                local_rt_projections=[LocalImageProjection(d, ii, 'rt') for ii in owned],
+                local_oi_projections=[LocalImageProjection(d, ii, 'oi') for ii in owned],
+                local_div_ops=[LocalDivergenceOperator(d, ii) for ii in owned], local_l2_products=d.products['l2'])
     d.data = data
     return d, data

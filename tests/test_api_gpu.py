@@ -185,3 +185,39 @@ def test_product_reproduces_the_reference_scripts_known_answers():
     o = oracle_from_problem(p)
     _, (onc, _, _), _ = o.estimate(o.solve(1.0), 1.0, decompose=True, sqrt_local=True)
     assert abs(np.linalg.norm(nc) - np.linalg.norm(onc)) < 1e-9
+
+
+def test_data_entries_of_discretize_are_usable_operators():
+    """``data['local_projections' | 'local_rt_projections' | 'local_oi_projections' | 'local_div_ops']``
+    (reference block_swipdg.py:696-729): block picker, sums of the neighbour images on a subdomain, local divergence --
+    checked against the oracle's image bases and divergence matrices."""
+    from pylrbms_amd import OS2015_academic_problem
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    p = OS2015_academic_problem.init_grid_and_problem({'num_subdomains': [3, 2],
+                                                       'half_num_fine_elements_per_subdomain_and_dim': 6})
+    d, data = discretize(p, mpi_comm=None)
+    o = oracle_from_problem(p)
+    S, n = o.S, o.n
+    assert [len(data[k]) for k in ('local_projections', 'local_rt_projections', 'local_oi_projections', 'local_div_ops')] == [S] * 4
+    U = d.solve(d.parse_parameter(0.4))
+    Ut = U.data.reshape(S, n)
+    for ii in (0, 4):
+        assert np.array_equal(data['local_projections'][ii].apply(U).data.reshape(n), Ut[ii])
+    red = OracleReductor(o, [Ut[ii][:, None] for ii in range(S)])
+    OI, RT = red.image_bases()
+    W = d.estimator.oswald_interpolation_error.apply(U)             # [S, n, 5]
+    R = d.estimator.flux_reconstruction.apply(U)                    # [S, n_rt, 5 Q]
+    Q = o.Q
+    for ii in range(S):
+        w_ref = sum(OI[kk][o.mesh.neighborhood_of(kk).index(ii)][:, 0] for kk in o.mesh.neighborhood_of(ii))
+        w = data['local_oi_projections'][ii].apply(W).cpu().numpy()[:, 0]
+        assert np.abs(w - w_ref).max() < 1e-11 * max(np.abs(w_ref).max(), np.abs(Ut).max())
+        r_ref = sum(RT[kk][o.mesh.neighborhood_of(kk).index(ii)] for kk in o.mesh.neighborhood_of(ii))   # [n_rt, Q]
+        r = data['local_rt_projections'][ii].apply(R).cpu().numpy()
+        assert r.shape == (o.n_rt[ii], Q)
+        assert np.abs(r - r_ref).max() < 1e-11 * np.abs(r_ref).max()
+        div = data['local_div_ops'][ii]
+        Dm = o.Div[ii].toarray()
+        assert np.abs(div.matrix() - Dm).max() < 1e-12 * np.abs(Dm).max()
+        got = div.apply(d.engine.ctx.from_numpy(r_ref)).cpu().numpy()
+        assert np.abs(got - Dm @ r_ref).max() < 1e-11 * np.abs(Dm @ r_ref).max()
