@@ -902,7 +902,9 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
 
   // (Measured and dropped: skipping the 14 of 84 tiles that lie strictly below the diagonal of a symmetric group and
   // storing them from the lanes that hold the mirror entries -- the wave-uniform branch around every MFMA breaks up the
-  // compiler's operand schedule of this loop: 465 us against 443 us at config 3.)
+  // compiler's operand schedule of this loop: 465 us against 443 us at config 3.  Second form: one liveness bit mask per
+  // wave, tested once per TILE and phase, all LDS operands of the phase requested up front, the mirror entries written by
+  // the epilogue -- correct, 14 % fewer MFMAs, and slower again: 464 us against 419 us.)
   auto mfma_phase = [&](int c) {
     const double* Xb = Xs + (c & 1) * 3 * EC * LDX;
     const double* Yb = Ys + (c & 1) * 3 * EC * LDY;
