@@ -20,6 +20,10 @@ PARITY UNPINNED remains true for: coupling-face conventions and the Oswald patch
 configuration is blind to them), online enrichment, the parabolic path, and the two other recorded values
 (online_adaptive_lrbms.py:50,53), which no reading reproduces.
 
+``lrbms3d`` / ``mesh3d``: the same path for BASELINE.json config 5 (3D, P2 tetrahedra).  The reference binds the 2D P1
+operators only, so that oracle has NO reference value at all (PARITY UNPINNED); it is validated by properties
+(tests/test_oracle3d.py: polynomial reproduction, local conservation, orders of convergence, reduced == full-order).
+
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this package.  The product package (pylrbms_amd) never does.
 """
