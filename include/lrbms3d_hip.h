@@ -1,0 +1,136 @@
+/*
+ * lrbms3d_hip.h -- C ABI of the 3D / P2 hot path in liblrbms_hip.so (BASELINE.json config 5: 3D diffusion, 8x8x8
+ * subdomains, SWIPDG p = 2, local basis dim 30).
+ *
+ * The reference binds the 2D / P1 operators only (python/dune/pylrbms/discretize_elliptic_block_swipdg.py:22-23; :195 uses
+ * x[0], x[1]), so these entry points have no reference call site of their own: each one is the 3D / P2 counterpart of the
+ * 2D entry point named beside it (include/lrbms_hip.h, which cites the reference line it replaces), with the same rules:
+ * caller-allocated device buffers, plain pointers and sizes, int return codes (LRBMS_OK / LRBMS_E_*), explicit hipStream_t.
+ *
+ * Geometry: Kuhn triangulation (6 tetrahedra per cube), every subdomain a translate of one template of kx x ky x kz cubes,
+ * every element a translate of one of 6 reference tetrahedra.  All local integrals are contractions
+ *     block[e][c] = sum_k sample[e][k] * TABLE[type(e)][k][c]
+ * of coefficient samples (host-evaluated data functions at the quadrature points, as in 2D) with reference tables that the
+ * host builds once (pylrbms_amd/grid3d.py) and the context keeps on the device.
+ *
+ *   S, S_ext     local / local + halo subdomains;  n_T elements, n = 10 n_T DG DoFs, n_rt RT0 DoFs per subdomain
+ *   sides        0 = z-, 1 = y-, 2 = x-, 3 = x+, 4 = y+, 5 = z+ ; slots 0..6 = sides 0..2, self (3), sides 3..5
+ *   ncf          faces per side, nbf = 6 ncf side faces ("sf" = side * ncf + pos);  nvs nodes per side,  nb boundary nodes
+ *   Q, N, QN     affine components, local basis size, Q * N;  columns (q, j) of flux images are q-major
+ */
+#ifndef LRBMS3D_HIP_H
+#define LRBMS3D_HIP_H
+
+#include <stdint.h>
+
+#include "lrbms_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lrbms3_ctx lrbms3_ctx;
+
+typedef struct {
+  int32_t n_T, n_rt, ncf, nvs, n_nodes, nb, nbel, nsel;
+  int32_t nA, nB, nC, nFs, nFf;                   /* points of the rules: system volume, product volume, estimator volume,
+                                                     system face, flux face */
+  int32_t o_fs, o_ff, o_c, lam_stride;            /* lambda_q record: volA | 4 x Fs | 4 x Ff | volC */
+  int32_t hat_stride, f_stride;                   /* lambda_hat and f records: volB | volC;  lambda_bar record: volB */
+  double volume, kmin;                            /* |T|; smallest eigenvalue of the symmetric part of kappa */
+  const int32_t *elem_type;                       /* [n_T] 0..5 */
+  const int32_t *nb_elem, *nb_out, *face_pos, *tsign, *elem_rt;   /* [n_T][4]: inner neighbour or -(1+side); the neighbour's
+                                                     element across a side face; position on the side; RT0 orientation; RT0 DoF */
+  const int32_t *rt_e0, *rt_f0, *rt_e1, *rt_f1;   /* [n_rt] the (<= 2) own elements of an RT0 face */
+  const int32_t *side_elem, *side_face, *side_elem_out, *side_face_out;   /* [6][ncf] */
+  const int32_t *dof_node;                        /* [n] Lagrange node of a DG DoF */
+  const int32_t *node_ptr, *node_dofs;            /* CSR node -> own DoFs: [n_nodes + 1], [n] */
+  const int32_t *node_mask, *node_count;          /* [n_nodes] sides a node lies on (bit a); size of its averaging patch */
+  const int32_t *side_nodes;                      /* [6][nvs] node at position p of side a (-1 padded) */
+  const int32_t *sn_ptr, *sn_dofs;                /* CSR (side, pos) -> the NEIGHBOUR's DoFs at that node: [6 nvs + 1], [...] */
+  const int32_t *bnodes, *bnode_sides;            /* [nb] boundary nodes; [nb][3] their (side * nvs + pos) memberships, -1 padded */
+  const int32_t *bel_elem, *bel_bnode;            /* [nbel] elements with a boundary node; [nbel][10] boundary-node index per DoF or -1 */
+  const int32_t *sel_elem, *sel_sf;               /* [nsel] elements with a side face; [nsel][4] side-face index per face or -1 */
+  const double *divc;                             /* [6][4] |f| / |T| */
+  const double *TV, *TE, *TAA;                    /* [6][nA|nB|nC][100]  w |T| grad phi_i . kappa grad phi_j */
+  const double *TFo, *TFn, *TFb;                  /* [6][4][nFs][100]    inner face (own, own) / (own, neighbour); Dirichlet face */
+  const double *TC, *TCb;                         /* [6][4][nFf][10]     flux coefficients: inner / Dirichlet face */
+  const double *TPH, *TM;                         /* [6][nB][10] w |T| phi_i;  [6][100] mass */
+  const double *TB, *TAB;                         /* [6][nC][16] w |T| psi_f . kappa^-1 psi_g;  [6][nC][40] w |T| grad phi_i . psi_f */
+  const double *WB, *WC;                          /* [nB], [nC] w |T| */
+} lrbms3_mesh_desc;
+
+int lrbms3_ctx_create(int device, lrbms3_ctx** out);
+int lrbms3_ctx_destroy(lrbms3_ctx* ctx);
+const char* lrbms3_last_error(lrbms3_ctx* ctx);
+
+/* Template, tables, neighbour table nbr [S][7] (index into the S_ext ordering per slot, -1 = none, nbr[s][3] == s) and
+ * phys [S_ext] (bit a set: side a lies on the physical boundary).   2D: lrbms_mesh_upload. */
+int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* desc, int32_t S, int32_t S_ext, const int32_t* nbr,
+                       const int32_t* phys);
+
+/* -- offline assembly ------------------------------------------------------------------------------------------------- */
+/* SWIPDG system (sigma = 20 / 38, beta = 1/2).  lam [Q][S_ext][n_T][lam_stride];
+ *   A_diag [Q][S][n_T][5][100]  block-ELL: 0 = (e, e), 1 + f = (e, inner neighbour across face f)
+ *   A_cpl  [Q][S][6][ncf][100]  block (own side element, neighbour's element) per coupling face, zero on physical sides
+ * 2D: lrbms_assemble_swipdg. */
+int lrbms3_assemble_system(lrbms3_ctx* ctx, int32_t Q, const double* lam, double* A_diag, double* A_cpl, void* stream);
+/* f_smp [S][n_T][f_stride], lhat [S][n_T][hat_stride] -> b [S][n], f2 [S], ceps [S], bdiv [S][n_T] = int_T f.  2D: lrbms_assemble_rhs. */
+int lrbms3_assemble_rhs(lrbms3_ctx* ctx, const double* f_smp, const double* lhat, double* b, double* f2, double* ceps,
+                        double* bdiv, void* stream);
+/* lbar [S][n_T][nB] -> ebar [S][n_T][100] (E_ii element blocks);  Aaa [Q][Q][S][n_T][100], Aab [Q][S][n_T][10][4],
+ * Bbb [S][n_T][4][4] (RT0 orientation signs folded in).  2D: lrbms_assemble_products. */
+int lrbms3_assemble_products(lrbms3_ctx* ctx, int32_t Q, const double* lam, const double* lbar, const double* lhat, double* ebar,
+                             double* Aaa, double* Aab, double* Bbb, void* stream);
+/* Cf [Q][S_ext][n_T][4][10]: contribution of the element's own DoFs to the RT0 DoF of its face f (unsigned; the kernels
+ * apply the orientation).  2D: lrbms_assemble_flux. */
+int lrbms3_assemble_flux(lrbms3_ctx* ctx, int32_t Q, const double* lam, double* Cf, void* stream);
+
+/* -- project + estimate-offline (the timed region) ----------------------------------------------------------------------- */
+/* One pass over all local subdomains: Oswald interpolation error and RT0 flux reconstruction of the local bases, Galerkin
+ * projection of the system and of the estimator operators, in the FACTORED layout (cf. lrbms_project_estimate_fused_factored):
+ *   V [S_ext][n][N] (halo filled)
+ *   B_sys [Q][S][7][N][N], rhs_red [S][N]
+ *   G_nc [S][N][N], G_bb, G_rdd [S][QN][QN], G_ab [Q][S][N][QN], G_aa [Q][Q][S][N][N], r_fd [S][QN]      the [self, self] blocks
+ *   Rb, Yb, Dp [S][nbf][QN], Xab [Q][S][nbf][N]     per side face: neighbour's flux image; rows of B R_self, vol div div R_self,
+ *                                                   A_ab^T V at the face
+ *   As [S][6][nvs][N], Cn [S][nb][N]                per side node: neighbour's share of the vertex average; -P^T E W_self
+ * so that for coefficients u (own u_s, neighbours u_a), ur = (theta_q u)_q, zf = Rb ur_a (per side face), z = sum_a As u_a:
+ *   nc  = u_s^T G_nc u_s + 2 z^T Cn u_s + sum_e z_e^T ebar_e z_e
+ *   df  = ur^T G_bb ur + 2 zf^T Yb ur + sum_e zf_e^T Bbb_e zf_e + 2 sum_q theta_q (u_s^T G_ab_q ur + zf^T Xab_q u_s) + sum theta theta u_s^T G_aa u_s
+ *   rdd = ur^T G_rdd ur + 2 zf^T Dp ur + sum_e |T| (div zf_e)^2,   rfd = r_fd^T ur + sum_e bdiv_e div zf_e
+ * work >= lrbms3_work_size doubles (flux image R_self [S][n_rt][QN] and vertex averages [S][n_nodes][N]). */
+int64_t lrbms3_work_size(lrbms3_ctx* ctx, int32_t Q, int32_t N);
+int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* A_diag, const double* A_cpl,
+                            const double* b, const double* ebar, const double* Aaa, const double* Aab, const double* Bbb,
+                            const double* bdiv, const double* Cf, double* work, double* B_sys, double* rhs_red, double* G_nc,
+                            double* G_bb, double* G_rdd, double* G_ab, double* G_aa, double* r_fd, double* Rb, double* Yb,
+                            double* Dp, double* Xab, double* As, double* Cn, void* stream);
+
+/* Per-kernel device timing of the pass, as lrbms_kernel_timing / lrbms_kernel_timing_read. */
+int lrbms3_kernel_timing(lrbms3_ctx* ctx, int32_t enable);
+int lrbms3_kernel_timing_read(lrbms3_ctx* ctx, char* names, int64_t names_cap, double* ms, int32_t cap, int32_t* count);
+
+/* -- online ---------------------------------------------------------------------------------------------------------------- */
+/* Local estimator terms from the factored operators.  theta [Q] host; u [S_ext][N]; eta_loc [3][S]: nc, r (scaled by
+ * (1/pi^2) / c_eps h^2), df -- squared quantities.  2D: lrbms_reduced_estimate_factored. */
+int lrbms3_reduced_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u, const double* G_nc,
+                            const double* G_bb, const double* G_rdd, const double* G_ab, const double* G_aa, const double* r_fd,
+                            const double* Rb, const double* Yb, const double* Dp, const double* Xab, const double* As,
+                            const double* Cn, const double* ebar, const double* Bbb, const double* bdiv, const double* f2,
+                            const double* ceps, double hdiam, double* eta_loc, void* stream);
+
+/* (sum_q theta_q B_sys_q) u = rhs_red by block-Jacobi preconditioned CG on the 7-slot block-sparse reduced system (S_ext == S).
+ * info[0] = iterations, info[1] = final relative residual (host, may be NULL).  2D: lrbms_reduced_solve. */
+int64_t lrbms3_reduced_solve_work_size(lrbms3_ctx* ctx, int32_t N);
+int lrbms3_reduced_solve(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* B_sys, const double* rhs_red,
+                         double* work, double* u, double rtol, int32_t max_iter, double* info, void* stream);
+
+/* y [S][n][M] = sum_q theta_q (A_diag_q x_s + sum_sides A_cpl_q x_neighbour), x [S_ext][n][M].  2D: lrbms_fom_apply. */
+int lrbms3_fom_apply(lrbms3_ctx* ctx, int32_t Q, int32_t M, const double* theta, const double* A_diag, const double* A_cpl,
+                     const double* x, double* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRBMS3D_HIP_H */

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'liblrbms_hip.so')
-SOURCES = ['capi.hip', 'assemble.hip', 'apply.hip', 'gemm.hip', 'fused.hip', 'online.hip', 'enrich.hip', 'fom.hip']
+SOURCES = ['capi.hip', 'assemble.hip', 'apply.hip', 'gemm.hip', 'fused.hip', 'online.hip', 'enrich.hip', 'fom.hip', 'lrbms3d.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 
@@ -22,7 +22,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'lrbms_hip.h')]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'lrbms_hip.h'), os.path.join(HERE, '..', 'include', 'lrbms3d_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -1,0 +1,1266 @@
+// 3D / P2 hot path (BASELINE.json config 5) for gfx950: C ABI of include/lrbms3d_hip.h.
+//
+// Kuhn triangulation: every element is a translate of one of six reference tetrahedra, so every local integral is a
+// contraction of coefficient samples with a reference table (pylrbms_amd/grid3d.py builds the tables on the host, once):
+//     block[e][c] = sum_k sample[e][k] * TABLE[type(e)][k][c].
+// The pass (lrbms3_project_estimate) is built from one MFMA kernel template, k3_gram<KIND>: G = sum_rows x_row^T y_row with
+// the rows of X and Y = L X' produced on the fly from the basis slab and the element blocks (never written to HBM), fp64
+// v_mfma_f64_16x16x4_f64 accumulation, one workgroup per (subdomain, operator).  Images of a NEIGHBOUR's basis live on the
+// side faces / side nodes of the target subdomain only: they are returned as factors (Rb, Yb, Dp, Xab, As, Cn) and the
+// estimate kernel consumes the factors (header).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/lrbms3d_hip.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct T3 {
+  int S, S_ext, nT, n, nrt, ncf, nbf, nvs, nnodes, nb, nbel, nsel;
+  int nA, nB, nC, nFs, nFf, o_fs, o_ff, o_c, lam_stride, hat_stride, f_stride;
+  double volume, kmin;
+  const int *nbr, *phys;
+  const int *elem_type, *nb_elem, *nb_out, *face_pos, *tsign, *elem_rt, *rt_e0, *rt_f0, *rt_e1, *rt_f1;
+  const int *side_elem, *side_face, *side_elem_out, *side_face_out;
+  const int *dof_node, *node_ptr, *node_dofs, *node_mask, *node_count, *side_nodes, *sn_ptr, *sn_dofs;
+  const int *bnodes, *bnode_sides, *bel_elem, *bel_bnode, *sel_elem, *sel_sf;
+  const double *divc, *TV, *TE, *TAA, *TFo, *TFn, *TFb, *TC, *TCb, *TPH, *TM, *TB, *TAB, *WB, *WC;
+};
+
+}  // namespace
+
+struct lrbms3_ctx {
+  int device = 0;
+  bool has_mesh = false;
+  T3 t{};
+  std::vector<void*> owned;
+  std::vector<int32_t> nbr_host;
+  bool ktime = false;
+  struct KTimer { const char* name; hipEvent_t e0, e1; };
+  std::vector<KTimer> ktimers;
+  int ktime_n = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail3(lrbms3_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define HIP3(ctx, expr)                                                                        \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) return fail3(ctx, LRBMS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+#define REQUIRE3(ctx)                                                                \
+  do {                                                                               \
+    if (!(ctx)) return LRBMS_E_INVALID;                                              \
+    if (!(ctx)->has_mesh) return fail3(ctx, LRBMS_E_STATE, "mesh not uploaded");     \
+  } while (0)
+#define LAUNCH3(ctx) HIP3(ctx, hipGetLastError())
+
+struct KScope3 {
+  lrbms3_ctx* ctx;
+  hipStream_t st;
+  int idx;
+  KScope3(lrbms3_ctx* c, const char* name, hipStream_t s) : ctx(c), st(s), idx(-1) {
+    if (!c->ktime) return;
+    if (c->ktime_n == (int)c->ktimers.size()) {
+      lrbms3_ctx::KTimer k{name, nullptr, nullptr};
+      if (hipEventCreate(&k.e0) != hipSuccess || hipEventCreate(&k.e1) != hipSuccess) return;
+      c->ktimers.push_back(k);
+    }
+    idx = c->ktime_n++;
+    c->ktimers[idx].name = name;
+    (void)hipEventRecord(c->ktimers[idx].e0, st);
+  }
+  ~KScope3() {
+    if (idx >= 0) (void)hipEventRecord(ctx->ktimers[idx].e1, st);
+  }
+};
+
+__device__ inline int side_slot(int side) { return side < 3 ? side : side + 1; }
+
+// RT0 orientation of (element, face) in subdomain s: +1 = outward from this element
+__device__ inline int sgn3(const T3& t, int s, int e, int f) {
+  const int nb = t.nb_elem[e * 4 + f];
+  if (nb < 0 && ((t.phys[s] >> (-(nb + 1))) & 1)) return 1;
+  return t.tsign[e * 4 + f];
+}
+
+// ------------------------------------------------------------------------------------------------- offline assembly
+__device__ inline double contract(const double* __restrict__ smp, const double* __restrict__ tab, int K, int C, int c) {
+  double acc = 0.0;
+  for (int k = 0; k < K; ++k) acc += smp[k] * tab[(long)k * C + c];
+  return acc;
+}
+
+__global__ __launch_bounds__(128) void k3_assemble_system(T3 t, const double* __restrict__ lam, double* __restrict__ A_diag,
+                                                          double* __restrict__ A_cpl) {
+  const int e = blockIdx.x, s = blockIdx.y, q = blockIdx.z, c = threadIdx.x;
+  if (c >= 100) return;
+  const int ty = t.elem_type[e];
+  const double* rec = lam + (((long)q * t.S_ext + s) * t.nT + e) * t.lam_stride;
+  double* out = A_diag + ((((long)q * t.S + s) * t.nT + e) * 5) * 100;
+  double acc = contract(rec, t.TV + (long)ty * t.nA * 100, t.nA, 100, c);
+  for (int f = 0; f < 4; ++f) {
+    const int nb = t.nb_elem[e * 4 + f];
+    const double* lf = rec + t.o_fs + f * t.nFs;
+    const long toff = ((long)(ty * 4 + f) * t.nFs) * 100;
+    if (nb >= 0) {
+      acc += contract(lf, t.TFo + toff, t.nFs, 100, c);
+      out[(1 + f) * 100 + c] = contract(lf, t.TFn + toff, t.nFs, 100, c);
+    } else {
+      const int side = -(nb + 1);
+      double* cp = A_cpl + ((((long)q * t.S + s) * 6 + side) * t.ncf + t.face_pos[e * 4 + f]) * 100;
+      out[(1 + f) * 100 + c] = 0.0;
+      if ((t.phys[s] >> side) & 1) {
+        acc += contract(lf, t.TFb + toff, t.nFs, 100, c);
+        cp[c] = 0.0;
+      } else {
+        acc += contract(lf, t.TFo + toff, t.nFs, 100, c);
+        cp[c] = contract(lf, t.TFn + toff, t.nFs, 100, c);
+      }
+    }
+  }
+  out[c] = acc;
+}
+
+__global__ __launch_bounds__(64) void k3_assemble_rhs(T3 t, const double* __restrict__ f_smp, double* __restrict__ b,
+                                                      double* __restrict__ bdiv) {
+  const int e = blockIdx.x, s = blockIdx.y, i = threadIdx.x;
+  const int ty = t.elem_type[e];
+  const double* rec = f_smp + ((long)s * t.nT + e) * t.f_stride;
+  if (i < 10) b[((long)s * t.nT + e) * 10 + i] = contract(rec, t.TPH + (long)ty * t.nB * 10, t.nB, 10, i);
+  if (i == 32) {
+    double acc = 0.0;
+    for (int k = 0; k < t.nC; ++k) acc += t.WC[k] * rec[t.nB + k];
+    bdiv[(long)s * t.nT + e] = acc;
+  }
+}
+
+// f2 = ||f||^2, ceps = min lambda_hat * kmin per subdomain: one workgroup, fixed-order tree
+__global__ __launch_bounds__(256) void k3_scalars(T3 t, const double* __restrict__ f_smp, const double* __restrict__ lhat,
+                                                  double* __restrict__ f2, double* __restrict__ ceps) {
+  __shared__ double sa[256], sb[256];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  double acc = 0.0, mn = INFINITY;
+  for (int e = tid; e < t.nT; e += 256) {
+    const double* rf = f_smp + ((long)s * t.nT + e) * t.f_stride;
+    const double* rh = lhat + ((long)s * t.nT + e) * t.hat_stride;
+    for (int k = 0; k < t.nB; ++k) {
+      acc += t.WB[k] * rf[k] * rf[k];
+      mn = fmin(mn, rh[k]);
+    }
+  }
+  sa[tid] = acc;
+  sb[tid] = mn;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) {
+      sa[tid] += sa[tid + w];
+      sb[tid] = fmin(sb[tid], sb[tid + w]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    f2[s] = sa[0];
+    ceps[s] = sb[0] * t.kmin;
+  }
+}
+
+__global__ __launch_bounds__(128) void k3_assemble_products(T3 t, int Q, const double* __restrict__ lam,
+                                                            const double* __restrict__ lbar, const double* __restrict__ lhat,
+                                                            double* __restrict__ ebar, double* __restrict__ Aaa,
+                                                            double* __restrict__ Aab, double* __restrict__ Bbb) {
+  extern __shared__ double lds[];   // [Q + 1][nC]: lambda_q / lambda_hat, 1 / lambda_hat
+  const int e = blockIdx.x, s = blockIdx.y, c = threadIdx.x;
+  const int ty = t.elem_type[e], nC = t.nC;
+  const double* rh = lhat + ((long)s * t.nT + e) * t.hat_stride + t.nB;
+  for (int k = c; k < nC; k += 128) {
+    const double ih = 1.0 / rh[k];
+    lds[Q * nC + k] = ih;
+    for (int q = 0; q < Q; ++q) lds[q * nC + k] = lam[(((long)q * t.S_ext + s) * t.nT + e) * t.lam_stride + t.o_c + k] * ih;
+  }
+  __syncthreads();
+  const long se = (long)s * t.nT + e;
+  if (c < 100) {
+    ebar[se * 100 + c] = contract(lbar + se * t.nB, t.TE + (long)ty * t.nB * 100, t.nB, 100, c);
+    const double* tab = t.TAA + (long)ty * nC * 100;
+    for (int q = 0; q < Q; ++q)
+      for (int q2 = 0; q2 < Q; ++q2) {
+        // lambda_q lambda_q' / lambda_hat = (lq/lh) (lq'/lh) / (1/lh)
+        double acc = 0.0;
+        for (int k = 0; k < nC; ++k) acc += lds[q * nC + k] * lds[q2 * nC + k] / lds[Q * nC + k] * tab[(long)k * 100 + c];
+        Aaa[((((long)q * Q + q2) * t.S + s) * t.nT + e) * 100 + c] = acc;
+      }
+  }
+  if (c < 40) {
+    const int f = c & 3;
+    const double sg = (double)sgn3(t, s, e, f);
+    for (int q = 0; q < Q; ++q)
+      Aab[(((long)q * t.S + s) * t.nT + e) * 40 + c] = sg * contract(lds + q * nC, t.TAB + (long)ty * nC * 40, nC, 40, c);
+  }
+  if (c < 16) {
+    const double sg = (double)(sgn3(t, s, e, c >> 2) * sgn3(t, s, e, c & 3));
+    Bbb[se * 16 + c] = sg * contract(lds + Q * nC, t.TB + (long)ty * nC * 16, nC, 16, c);
+  }
+}
+
+__global__ __launch_bounds__(64) void k3_assemble_flux(T3 t, const double* __restrict__ lam, double* __restrict__ Cf) {
+  const int e = blockIdx.x, s = blockIdx.y, q = blockIdx.z, c = threadIdx.x;
+  if (c >= 40) return;
+  const int f = c / 10, i = c - f * 10;
+  const int ty = t.elem_type[e];
+  const int nb = t.nb_elem[e * 4 + f];
+  const bool bnd = nb < 0 && ((t.phys[s] >> (-(nb + 1))) & 1);
+  const double* lf = lam + (((long)q * t.S_ext + s) * t.nT + e) * t.lam_stride + t.o_ff + f * t.nFf;
+  const double* tab = (bnd ? t.TCb : t.TC) + ((long)(ty * 4 + f) * t.nFf) * 10;
+  Cf[(((long)q * t.S_ext + s) * t.nT + e) * 40 + c] = contract(lf, tab, t.nFf, 10, i);
+}
+
+// ------------------------------------------------------------------------------------------------- pass: preparation
+// R_self [S][n_rt][QN]: RT0 flux image of the own basis on the own faces;  Rb [S][nbf][QN]: the neighbour's share on the side faces
+__global__ __launch_bounds__(256) void k3_flux(T3 t, int Q, int N, const double* __restrict__ V, const double* __restrict__ Cf,
+                                               double* __restrict__ Rs, double* __restrict__ Rb) {
+  const int s = blockIdx.y, QN = Q * N;
+  const int c = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= QN || row >= t.nrt + t.nbf) return;
+  const int q = c / N, j = c - q * N;
+  if (row < t.nrt) {
+    double acc = 0.0;
+    for (int k = 0; k < 2; ++k) {
+      const int e = k ? t.rt_e1[row] : t.rt_e0[row], f = k ? t.rt_f1[row] : t.rt_f0[row];
+      if (e < 0) continue;
+      const double* co = Cf + (((long)q * t.S_ext + s) * t.nT + e) * 40 + f * 10;
+      const double* v = V + ((long)s * t.n + e * 10) * N + j;
+      double a = 0.0;
+      for (int i = 0; i < 10; ++i) a += co[i] * v[(long)i * N];
+      acc += sgn3(t, s, e, f) * a;
+    }
+    Rs[((long)s * t.nrt + row) * QN + c] = acc;
+  } else {
+    const int sf = row - t.nrt, side = sf / t.ncf;
+    const int t2 = t.nbr[s * 7 + side_slot(side)];
+    const int e = t.side_elem_out[sf], f = t.side_face_out[sf];
+    double acc = 0.0;
+    if (t2 >= 0 && e >= 0) {
+      const double* co = Cf + (((long)q * t.S_ext + t2) * t.nT + e) * 40 + f * 10;
+      const double* v = V + ((long)t2 * t.n + e * 10) * N + j;
+      for (int i = 0; i < 10; ++i) acc += co[i] * v[(long)i * N];
+      acc *= t.tsign[e * 4 + f];      // a coupling face of the neighbour: its template orientation
+    }
+    Rb[((long)s * t.nbf + sf) * QN + c] = acc;
+  }
+}
+
+// Avg [S][n_nodes][N]: own share of the Oswald node average (0 on the physical boundary: the interpolant vanishes there);
+// As [S][6][nvs][N]: the neighbours' shares at the side nodes
+__global__ __launch_bounds__(256) void k3_node_avg(T3 t, int N, const double* __restrict__ V, double* __restrict__ Avg,
+                                                   double* __restrict__ As) {
+  const int s = blockIdx.y;
+  const int j = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= N || row >= t.nnodes + 6 * t.nvs) return;
+  const int phys = t.phys[s];
+  if (row < t.nnodes) {
+    double acc = 0.0;
+    if (!(t.node_mask[row] & phys)) {
+      const double* v = V + (long)s * t.n * N + j;
+      for (int p = t.node_ptr[row]; p < t.node_ptr[row + 1]; ++p) acc += v[(long)t.node_dofs[p] * N];
+      acc /= (double)t.node_count[row];
+    }
+    Avg[((long)s * t.nnodes + row) * N + j] = acc;
+  } else {
+    const int sp = row - t.nnodes, side = sp / t.nvs;
+    const int node = t.side_nodes[sp];
+    const int t2 = t.nbr[s * 7 + side_slot(side)];
+    double acc = 0.0;
+    if (node >= 0 && t2 >= 0 && !(t.node_mask[node] & phys)) {
+      const double* v = V + (long)t2 * t.n * N + j;
+      for (int p = t.sn_ptr[sp]; p < t.sn_ptr[sp + 1]; ++p) acc += v[(long)t.sn_dofs[p] * N];
+      acc /= (double)t.node_count[node];
+    }
+    As[((long)s * 6 * t.nvs + sp) * N + j] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- pass: Gram kernel
+enum { G_SYS = 0, G_AAA, G_NC, G_AB, G_BB, G_RDD, G_CPL };
+
+struct GA {
+  T3 t;
+  int Q, N;
+  const double *V, *A_diag, *A_cpl, *ebar, *Aaa, *Aab, *Bbb, *Rs, *Avg;
+  double* out;
+};
+
+constexpr int BK = 16, LD = 64 + 16;
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k3_gram(GA a) {
+  __shared__ double Xs[BK][LD];
+  __shared__ double Ys[BK][LD];
+  const T3& t = a.t;
+  const int N = a.N, Q = a.Q, QN = Q * N;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1, li = lane & 15, lk = lane >> 4;
+  const int srow = tid >> 4, c0 = (tid & 15) * 4;
+
+  int s, q = 0, K, Mx, My, t2 = 0, side = 0;
+  double* out;
+  if (KIND == G_SYS) {
+    q = b / t.S; s = b - q * t.S; K = t.n; Mx = My = N;
+    out = a.out + (((long)q * t.S + s) * 7 + 3) * N * N;
+  } else if (KIND == G_CPL) {
+    side = b % 6;
+    const int qs = b / 6;
+    q = qs / t.S; s = qs - q * t.S; K = t.ncf * 10; Mx = My = N;
+    t2 = t.nbr[s * 7 + side_slot(side)];
+    out = a.out + (((long)q * t.S + s) * 7 + side_slot(side)) * N * N;
+  } else if (KIND == G_AAA) {
+    s = b % t.S; K = t.n; Mx = My = N;
+    out = a.out + (long)b * N * N;
+  } else if (KIND == G_NC) {
+    s = b; K = t.n; Mx = My = N;
+    out = a.out + (long)b * N * N;
+  } else if (KIND == G_AB) {
+    q = b / t.S; s = b - q * t.S; K = t.n; Mx = N; My = QN;
+    out = a.out + (long)b * N * QN;
+  } else if (KIND == G_BB) {
+    s = b; K = t.nT * 4; Mx = My = QN;
+    out = a.out + (long)b * QN * QN;
+  } else {
+    s = b; K = t.nT; Mx = My = QN;
+    out = a.out + (long)b * QN * QN;
+  }
+  const int ldo = My;
+
+  if (KIND == G_CPL && t2 < 0) {
+    for (int i = tid; i < Mx * My; i += 256) out[i] = 0.0;
+    return;
+  }
+
+  d4 acc[2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* Vs = a.V + (long)s * t.n * N;
+
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const int kr = k0 + srow;
+    double xv[4] = {0, 0, 0, 0}, yv[4] = {0, 0, 0, 0};
+    if (kr < K) {
+      if (KIND == G_SYS || KIND == G_AAA || KIND == G_CPL) {
+        int e, i = kr % 10;
+        const double *L, *Vy;
+        int nslot = 1;
+        if (KIND == G_CPL) {
+          const int sp = side * t.ncf + kr / 10;
+          e = t.side_elem[sp];
+          L = a.A_cpl + ((((long)q * t.S + s) * 6 + side) * t.ncf + kr / 10) * 100 + i * 10;
+          Vy = a.V + ((long)t2 * t.n + t.side_elem_out[sp] * 10) * N;
+        } else {
+          e = kr / 10;
+          if (KIND == G_SYS) {
+            L = a.A_diag + ((((long)q * t.S + s) * t.nT + e) * 5) * 100 + i * 10;
+            nslot = 5;
+          } else {
+            L = a.Aaa + ((long)b * t.nT + e) * 100 + i * 10;
+          }
+          Vy = Vs + (long)e * 10 * N;
+        }
+        if (e >= 0) {
+          const double* xp = Vs + ((long)e * 10 + i) * N;
+          for (int c = 0; c < 4; ++c)
+            if (c0 + c < N) xv[c] = xp[c0 + c];
+          for (int slot = 0; slot < nslot; ++slot) {
+            const double* vy = Vy;
+            if (KIND == G_SYS && slot > 0) {
+              const int ee = t.nb_elem[e * 4 + slot - 1];
+              if (ee < 0) continue;
+              vy = Vs + (long)ee * 10 * N;
+            }
+            const double* Ls = L + slot * 100;
+            for (int j = 0; j < 10; ++j) {
+              const double l = Ls[j];
+              for (int c = 0; c < 4; ++c)
+                if (c0 + c < N) yv[c] += l * vy[(long)j * N + c0 + c];
+            }
+          }
+        }
+      } else if (KIND == G_NC) {
+        const int e = kr / 10, i = kr - e * 10;
+        const double* L = a.ebar + ((long)s * t.nT + e) * 100 + i * 10;
+        const double* Av = a.Avg + (long)s * t.nnodes * N;
+        for (int c = 0; c < 4; ++c)
+          if (c0 + c < N) xv[c] = Vs[(long)kr * N + c0 + c] - Av[(long)t.dof_node[kr] * N + c0 + c];
+        for (int j = 0; j < 10; ++j) {
+          const double l = L[j];
+          const int d = e * 10 + j;
+          const long nd = (long)t.dof_node[d] * N;
+          for (int c = 0; c < 4; ++c)
+            if (c0 + c < N) yv[c] += l * (Vs[(long)d * N + c0 + c] - Av[nd + c0 + c]);
+        }
+      } else if (KIND == G_AB) {
+        const int e = kr / 10, i = kr - e * 10;
+        for (int c = 0; c < 4; ++c)
+          if (c0 + c < N) xv[c] = Vs[(long)kr * N + c0 + c];
+        const double* L = a.Aab + (((long)q * t.S + s) * t.nT + e) * 40 + i * 4;
+        for (int f = 0; f < 4; ++f) {
+          const double l = L[f];
+          const double* r = a.Rs + ((long)s * t.nrt + t.elem_rt[e * 4 + f]) * QN;
+          for (int c = 0; c < 4; ++c)
+            if (c0 + c < QN) yv[c] += l * r[c0 + c];
+        }
+      } else if (KIND == G_BB) {
+        const int e = kr >> 2, f = kr & 3;
+        const double* L = a.Bbb + ((long)s * t.nT + e) * 16 + f * 4;
+        const double* rx = a.Rs + ((long)s * t.nrt + t.elem_rt[kr]) * QN;
+        for (int c = 0; c < 4; ++c)
+          if (c0 + c < QN) xv[c] = rx[c0 + c];
+        for (int g = 0; g < 4; ++g) {
+          const double l = L[g];
+          const double* r = a.Rs + ((long)s * t.nrt + t.elem_rt[e * 4 + g]) * QN;
+          for (int c = 0; c < 4; ++c)
+            if (c0 + c < QN) yv[c] += l * r[c0 + c];
+        }
+      } else {   // G_RDD
+        const int e = kr, ty = t.elem_type[e];
+        for (int f = 0; f < 4; ++f) {
+          const double l = sgn3(t, s, e, f) * t.divc[ty * 4 + f];
+          const double* r = a.Rs + ((long)s * t.nrt + t.elem_rt[e * 4 + f]) * QN;
+          for (int c = 0; c < 4; ++c)
+            if (c0 + c < QN) xv[c] += l * r[c0 + c];
+        }
+        for (int c = 0; c < 4; ++c) yv[c] = t.volume * xv[c];
+      }
+    }
+    __syncthreads();
+    for (int c = 0; c < 4; ++c) {
+      Xs[srow][c0 + c] = xv[c];
+      Ys[srow][c0 + c] = yv[c];
+    }
+    __syncthreads();
+    if (wr * 32 < Mx && wc * 32 < My) {
+      for (int kk = 0; kk < BK; kk += 4) {
+        double av[2], bv[2];
+        for (int mi = 0; mi < 2; ++mi) av[mi] = Xs[kk + lk][wr * 32 + mi * 16 + li];
+        for (int ni = 0; ni < 2; ++ni) bv[ni] = Ys[kk + lk][wc * 32 + ni * 16 + li];
+        for (int mi = 0; mi < 2; ++mi)
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+  for (int mi = 0; mi < 2; ++mi)
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = wc * 32 + ni * 16 + li;
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr * 32 + mi * 16 + lk + 4 * r;
+        if (row < Mx && col < My) out[(long)row * ldo + col] = acc[mi][ni][r];
+      }
+    }
+}
+
+// rhs_red [S][N] = V^T b,  r_fd [S][QN] = sum_e bdiv_e div R_self|_e
+__global__ __launch_bounds__(256) void k3_vecs(T3 t, int Q, int N, const double* __restrict__ V, const double* __restrict__ b,
+                                               const double* __restrict__ bdiv, const double* __restrict__ Rs,
+                                               double* __restrict__ rhs_red, double* __restrict__ r_fd) {
+  __shared__ double red[4][64];
+  const int s = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6, QN = Q * N;
+  double acc = 0.0;
+  if (c < N) {
+    const double* v = V + (long)s * t.n * N + c;
+    const double* bs = b + (long)s * t.n;
+    for (int kr = g; kr < t.n; kr += 4) acc += bs[kr] * v[(long)kr * N];
+  }
+  red[g][c] = acc;
+  __syncthreads();
+  if (g == 0 && c < N) rhs_red[(long)s * N + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  __syncthreads();
+  acc = 0.0;
+  if (c < QN) {
+    for (int e = g; e < t.nT; e += 4) {
+      const int ty = t.elem_type[e];
+      double dv = 0.0;
+      for (int f = 0; f < 4; ++f)
+        dv += sgn3(t, s, e, f) * t.divc[ty * 4 + f] * Rs[((long)s * t.nrt + t.elem_rt[e * 4 + f]) * QN + c];
+      acc += bdiv[(long)s * t.nT + e] * dv;
+    }
+  }
+  red[g][c] = acc;
+  __syncthreads();
+  if (g == 0 && c < QN) r_fd[(long)s * QN + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+// per side face: Yb = row of B R_self, Dp = |T| div_f div R_self, Xab_q = A_ab_q^T V at the face
+__global__ __launch_bounds__(64) void k3_side_flux(T3 t, int Q, int N, const double* __restrict__ V, const double* __restrict__ Aab,
+                                                   const double* __restrict__ Bbb, const double* __restrict__ Rs,
+                                                   double* __restrict__ Yb, double* __restrict__ Dp, double* __restrict__ Xab) {
+  const int sf = blockIdx.x, s = blockIdx.y, c = threadIdx.x, QN = Q * N;
+  const int e = t.side_elem[sf], f = t.side_face[sf];
+  const bool on = e >= 0 && t.nbr[s * 7 + side_slot(sf / t.ncf)] >= 0;
+  if (c < QN) {
+    double yb = 0.0, dp = 0.0;
+    if (on) {
+      const int ty = t.elem_type[e];
+      double dv = 0.0;
+      for (int g = 0; g < 4; ++g) {
+        const double r = Rs[((long)s * t.nrt + t.elem_rt[e * 4 + g]) * QN + c];
+        yb += Bbb[((long)s * t.nT + e) * 16 + f * 4 + g] * r;
+        dv += sgn3(t, s, e, g) * t.divc[ty * 4 + g] * r;
+      }
+      dp = t.volume * sgn3(t, s, e, f) * t.divc[ty * 4 + f] * dv;
+    }
+    Yb[((long)s * t.nbf + sf) * QN + c] = yb;
+    Dp[((long)s * t.nbf + sf) * QN + c] = dp;
+  }
+  if (c < N) {
+    for (int q = 0; q < Q; ++q) {
+      double acc = 0.0;
+      if (on)
+        for (int i = 0; i < 10; ++i)
+          acc += Aab[(((long)q * t.S + s) * t.nT + e) * 40 + i * 4 + f] * V[((long)s * t.n + e * 10 + i) * N + c];
+      Xab[(((long)q * t.S + s) * t.nbf + sf) * N + c] = acc;
+    }
+  }
+}
+
+// Cn [S][nb][N] = -(P^T E W_self) at the boundary nodes
+__global__ __launch_bounds__(64) void k3_side_nc(T3 t, int N, const double* __restrict__ V, const double* __restrict__ ebar,
+                                                 const double* __restrict__ Avg, double* __restrict__ Cn) {
+  const int bn = blockIdx.x, s = blockIdx.y, c = threadIdx.x;
+  if (c >= N) return;
+  const int node = t.bnodes[bn];
+  const double* Vs = V + (long)s * t.n * N;
+  const double* Av = Avg + (long)s * t.nnodes * N;
+  double acc = 0.0;
+  for (int p = t.node_ptr[node]; p < t.node_ptr[node + 1]; ++p) {
+    const int d = t.node_dofs[p], e = d / 10, i = d - e * 10;
+    const double* L = ebar + ((long)s * t.nT + e) * 100 + i * 10;
+    for (int j = 0; j < 10; ++j) {
+      const int d2 = e * 10 + j;
+      acc += L[j] * (Vs[(long)d2 * N + c] - Av[(long)t.dof_node[d2] * N + c]);
+    }
+  }
+  Cn[((long)s * t.nb + bn) * N + c] = -acc;
+}
+
+// ------------------------------------------------------------------------------------------------- online: estimate
+struct QV { double v[8]; };
+
+__device__ inline double block_sum(double v, double* red) {   // fixed-order tree over 256 threads; red [256]
+  const int tid = threadIdx.x;
+  __syncthreads();
+  red[tid] = v;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  return red[0];
+}
+
+struct EA {
+  const double *u, *G_nc, *G_bb, *G_rdd, *G_ab, *G_aa, *r_fd, *Rb, *Yb, *Dp, *Xab, *As, *Cn, *ebar, *Bbb, *bdiv, *f2, *ceps;
+  double hdiam;
+  double* eta;
+};
+
+__global__ __launch_bounds__(256) void k3_estimate(T3 t, int Q, int N, QV th, EA a) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x, tid = threadIdx.x, QN = Q * N;
+  double* us = lds;                 // [7][N] coefficients on the neighbourhood (0 where no neighbour)
+  double* ur = us + 7 * N;          // [QN]   theta_q u_self
+  double* zf = ur + QN;             // [nbf]  flux of the neighbours on the side faces
+  double* z = zf + t.nbf;           // [nb]   neighbours' share of the node averages
+  double* red = z + t.nb;           // [256]
+  for (int i = tid; i < 7 * N; i += 256) {
+    const int s2 = t.nbr[s * 7 + i / N];
+    us[i] = s2 >= 0 ? a.u[(long)s2 * N + i % N] : 0.0;
+  }
+  __syncthreads();
+  const double* u0 = us + 3 * N;
+  for (int i = tid; i < QN; i += 256) ur[i] = th.v[i / N] * u0[i % N];
+  for (int sf = tid; sf < t.nbf; sf += 256) {
+    const double* ua = us + side_slot(sf / t.ncf) * N;
+    const double* r = a.Rb + ((long)s * t.nbf + sf) * QN;
+    double acc = 0.0;
+    for (int q = 0; q < Q; ++q) {
+      double aq = 0.0;
+      for (int j = 0; j < N; ++j) aq += r[q * N + j] * ua[j];
+      acc += th.v[q] * aq;
+    }
+    zf[sf] = acc;
+  }
+  for (int bn = tid; bn < t.nb; bn += 256) {
+    double acc = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      const int sp = t.bnode_sides[bn * 3 + k];
+      if (sp < 0) continue;
+      const double* ua = us + side_slot(sp / t.nvs) * N;
+      const double* r = a.As + ((long)s * 6 * t.nvs + sp) * N;
+      for (int j = 0; j < N; ++j) acc += r[j] * ua[j];
+    }
+    z[bn] = acc;
+  }
+  __syncthreads();
+  // ---- nonconformity
+  double p_nc = 0.0;
+  for (int r = tid; r < N; r += 256) {
+    const double* g = a.G_nc + ((long)s * N + r) * N;
+    double d = 0.0;
+    for (int j = 0; j < N; ++j) d += g[j] * u0[j];
+    p_nc += u0[r] * d;
+  }
+  for (int bn = tid; bn < t.nb; bn += 256) {
+    const double* g = a.Cn + ((long)s * t.nb + bn) * N;
+    double d = 0.0;
+    for (int j = 0; j < N; ++j) d += g[j] * u0[j];
+    p_nc += 2.0 * z[bn] * d;
+  }
+  for (int k = tid; k < t.nbel; k += 256) {
+    const int e = t.bel_elem[k];
+    const double* E = a.ebar + ((long)s * t.nT + e) * 100;
+    double ze[10];
+    for (int i = 0; i < 10; ++i) {
+      const int bn = t.bel_bnode[k * 10 + i];
+      ze[i] = bn >= 0 ? z[bn] : 0.0;
+    }
+    for (int i = 0; i < 10; ++i) {
+      if (ze[i] == 0.0) continue;
+      double d = 0.0;
+      for (int j = 0; j < 10; ++j) d += E[i * 10 + j] * ze[j];
+      p_nc += ze[i] * d;
+    }
+  }
+  const double nc = block_sum(p_nc, red);
+  // ---- flux terms
+  double p_bb = 0.0, p_dd = 0.0, p_fd = 0.0, p_ab = 0.0, p_aa = 0.0;
+  for (int r = tid; r < QN; r += 256) {
+    const double* gb = a.G_bb + ((long)s * QN + r) * QN;
+    const double* gd = a.G_rdd + ((long)s * QN + r) * QN;
+    double db = 0.0, dd = 0.0;
+    for (int j = 0; j < QN; ++j) {
+      db += gb[j] * ur[j];
+      dd += gd[j] * ur[j];
+    }
+    p_bb += ur[r] * db;
+    p_dd += ur[r] * dd;
+    p_fd += a.r_fd[(long)s * QN + r] * ur[r];
+  }
+  for (int r = tid; r < N; r += 256) {
+    for (int q = 0; q < Q; ++q) {
+      const double* g = a.G_ab + (((long)q * t.S + s) * N + r) * QN;
+      double d = 0.0;
+      for (int j = 0; j < QN; ++j) d += g[j] * ur[j];
+      p_ab += th.v[q] * u0[r] * d;
+      for (int q2 = 0; q2 < Q; ++q2) {
+        const double* ga = a.G_aa + ((((long)q * Q + q2) * t.S + s) * N + r) * N;
+        double da = 0.0;
+        for (int j = 0; j < N; ++j) da += ga[j] * u0[j];
+        p_aa += th.v[q] * th.v[q2] * u0[r] * da;
+      }
+    }
+  }
+  for (int sf = tid; sf < t.nbf; sf += 256) {
+    const double zz = zf[sf];
+    if (zz == 0.0) continue;
+    const double* yb = a.Yb + ((long)s * t.nbf + sf) * QN;
+    const double* dp = a.Dp + ((long)s * t.nbf + sf) * QN;
+    double db = 0.0, dd = 0.0;
+    for (int j = 0; j < QN; ++j) {
+      db += yb[j] * ur[j];
+      dd += dp[j] * ur[j];
+    }
+    p_bb += 2.0 * zz * db;
+    p_dd += 2.0 * zz * dd;
+    for (int q = 0; q < Q; ++q) {
+      const double* xa = a.Xab + (((long)q * t.S + s) * t.nbf + sf) * N;
+      double d = 0.0;
+      for (int j = 0; j < N; ++j) d += xa[j] * u0[j];
+      p_ab += th.v[q] * zz * d;
+    }
+  }
+  for (int k = tid; k < t.nsel; k += 256) {
+    const int e = t.sel_elem[k], ty = t.elem_type[e];
+    const double* B = a.Bbb + ((long)s * t.nT + e) * 16;
+    double ze[4], dv = 0.0;
+    for (int f = 0; f < 4; ++f) {
+      const int sf = t.sel_sf[k * 4 + f];
+      ze[f] = sf >= 0 ? zf[sf] : 0.0;
+      dv += sgn3(t, s, e, f) * t.divc[ty * 4 + f] * ze[f];
+    }
+    for (int f = 0; f < 4; ++f)
+      for (int g = 0; g < 4; ++g) p_bb += ze[f] * B[f * 4 + g] * ze[g];
+    p_dd += t.volume * dv * dv;
+    p_fd += a.bdiv[(long)s * t.nT + e] * dv;
+  }
+  const double bb = block_sum(p_bb, red);
+  const double dd = block_sum(p_dd, red);
+  const double fd = block_sum(p_fd, red);
+  const double ab = block_sum(p_ab, red);
+  const double aa = block_sum(p_aa, red);
+  if (tid == 0) {
+    const double pi = 3.14159265358979323846;
+    a.eta[s] = nc;
+    a.eta[t.S + s] = (a.f2[s] - 2.0 * fd + dd) * (1.0 / (pi * pi)) / a.ceps[s] * a.hdiam * a.hdiam;
+    a.eta[2 * t.S + s] = bb + 2.0 * ab + aa;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- online: reduced solve
+__global__ __launch_bounds__(256) void k3_combine(long per_q, int Q, QV th, const double* __restrict__ B, double* __restrict__ Amu) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per_q) return;
+  double acc = 0.0;
+  for (int q = 0; q < Q; ++q) acc += th.v[q] * B[q * per_q + i];
+  Amu[i] = acc;
+}
+
+// inverse of the SPD diagonal blocks by Gauss-Jordan elimination in LDS (no pivoting)
+__global__ __launch_bounds__(256) void k3_block_inverse(int N, const double* __restrict__ Amu, double* __restrict__ Dinv) {
+  extern __shared__ double lds[];   // [N][2N + 1]
+  const int s = blockIdx.x, tid = threadIdx.x, ld = 2 * N + 1;
+  const double* A = Amu + ((long)s * 7 + 3) * N * N;
+  for (int i = tid; i < N * 2 * N; i += 256) {
+    const int r = i / (2 * N), c = i - r * 2 * N;
+    lds[r * ld + c] = c < N ? A[r * N + c] : (c - N == r ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  for (int p = 0; p < N; ++p) {
+    const double ip = 1.0 / lds[p * ld + p];
+    __syncthreads();
+    for (int c = tid; c < 2 * N; c += 256) lds[p * ld + c] *= ip;
+    __syncthreads();
+    for (int i = tid; i < N * 2 * N; i += 256) {
+      const int r = i / (2 * N), c = i - r * 2 * N;
+      if (r != p && c != p) lds[r * ld + c] -= lds[r * ld + p] * lds[p * ld + c];
+    }
+    __syncthreads();
+    for (int r = tid; r < N; r += 256)
+      if (r != p) lds[r * ld + p] = 0.0;
+    __syncthreads();
+  }
+  for (int i = tid; i < N * N; i += 256) Dinv[(long)s * N * N + i] = lds[(i / N) * ld + N + i % N];
+}
+
+// scal: [0] rz_old, [1] rz_new, [2] pAp, [3] rr, [4] bb;  partial arrays [S]
+// init: x = 0, r = b, z = Dinv r, partial rz, rr
+__global__ __launch_bounds__(64) void k3_pcg_init(int N, const double* __restrict__ rhs, const double* __restrict__ Dinv,
+                                                  double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
+                                                  double* __restrict__ p, double* __restrict__ prz, double* __restrict__ prr) {
+  __shared__ double rs[64], red[64];
+  const int s = blockIdx.x, i = threadIdx.x;
+  const double ri = i < N ? rhs[(long)s * N + i] : 0.0;
+  rs[i] = ri;
+  __syncthreads();
+  double zi = 0.0;
+  if (i < N) {
+    const double* D = Dinv + ((long)s * N + i) * N;
+    for (int j = 0; j < N; ++j) zi += D[j] * rs[j];
+    x[(long)s * N + i] = 0.0;
+    r[(long)s * N + i] = ri;
+    z[(long)s * N + i] = zi;
+    p[(long)s * N + i] = 0.0;
+  }
+  red[i] = ri * zi;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (i < w) red[i] += red[i + w];
+    __syncthreads();
+  }
+  if (i == 0) prz[s] = red[0];
+  __syncthreads();
+  red[i] = ri * ri;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (i < w) red[i] += red[i + w];
+    __syncthreads();
+  }
+  if (i == 0) prr[s] = red[0];
+}
+
+__device__ inline double sum_partials(const double* __restrict__ part, int S, double* red) {   // 64 threads, fixed order
+  const int i = threadIdx.x;
+  double acc = 0.0;
+  for (int k = i; k < S; k += 64) acc += part[k];
+  __syncthreads();
+  red[i] = acc;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (i < w) red[i] += red[i + w];
+    __syncthreads();
+  }
+  const double v = red[0];
+  __syncthreads();
+  return v;
+}
+
+// direction + matvec: p_new = z + beta p_old on the neighbourhood (own part stored), Ap = sum_slot A[s][slot] p_new[slot]
+__global__ __launch_bounds__(64) void k3_pcg_matvec(T3 t, int N, int first, const double* __restrict__ Amu,
+                                                    const double* __restrict__ z, const double* __restrict__ p_old,
+                                                    double* __restrict__ p_new, double* __restrict__ Ap,
+                                                    const double* __restrict__ prz_new, const double* __restrict__ prz_old,
+                                                    double* __restrict__ ppap) {
+  extern __shared__ double lds[];   // [7][N] + 64
+  double* red = lds + 7 * N;
+  const int s = blockIdx.x, i = threadIdx.x, S = t.S;
+  double beta = 0.0;
+  if (!first) {
+    const double a = sum_partials(prz_new, S, red), b = sum_partials(prz_old, S, red);
+    beta = a / b;
+  }
+  for (int k = i; k < 7 * N; k += 64) {
+    const int s2 = t.nbr[s * 7 + k / N];
+    lds[k] = s2 >= 0 ? z[(long)s2 * N + k % N] + beta * p_old[(long)s2 * N + k % N] : 0.0;
+  }
+  __syncthreads();
+  double acc = 0.0;
+  if (i < N) {
+    p_new[(long)s * N + i] = lds[3 * N + i];
+    for (int slot = 0; slot < 7; ++slot) {
+      if (t.nbr[s * 7 + slot] < 0) continue;
+      const double* row = Amu + (((long)s * 7 + slot) * N + i) * N;
+      const double* ps = lds + slot * N;
+      for (int j = 0; j < N; ++j) acc += row[j] * ps[j];
+    }
+    Ap[(long)s * N + i] = acc;
+  }
+  __syncthreads();
+  red[i] = i < N ? acc * lds[3 * N + i] : 0.0;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (i < w) red[i] += red[i + w];
+    __syncthreads();
+  }
+  if (i == 0) ppap[s] = red[0];
+}
+
+// x += alpha p, r -= alpha Ap, z = Dinv r; partial r.z and r.r
+__global__ __launch_bounds__(64) void k3_pcg_update(int S, int N, const double* __restrict__ Dinv, const double* __restrict__ p,
+                                                    const double* __restrict__ Ap, double* __restrict__ x, double* __restrict__ r,
+                                                    double* __restrict__ z, const double* __restrict__ prz_cur,
+                                                    const double* __restrict__ ppap, double* __restrict__ prz_out,
+                                                    double* __restrict__ prr) {
+  __shared__ double rs[64], red[64];
+  const int s = blockIdx.x, i = threadIdx.x;
+  const double rz = sum_partials(prz_cur, S, red), pap = sum_partials(ppap, S, red);
+  const double alpha = rz / pap;
+  double ri = 0.0;
+  if (i < N) {
+    x[(long)s * N + i] += alpha * p[(long)s * N + i];
+    ri = r[(long)s * N + i] - alpha * Ap[(long)s * N + i];
+    r[(long)s * N + i] = ri;
+  }
+  rs[i] = ri;
+  __syncthreads();
+  double zi = 0.0;
+  if (i < N) {
+    const double* D = Dinv + ((long)s * N + i) * N;
+    for (int j = 0; j < N; ++j) zi += D[j] * rs[j];
+    z[(long)s * N + i] = zi;
+  }
+  red[i] = ri * zi;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (i < w) red[i] += red[i + w];
+    __syncthreads();
+  }
+  if (i == 0) prz_out[s] = red[0];
+  __syncthreads();
+  red[i] = ri * ri;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (i < w) red[i] += red[i + w];
+    __syncthreads();
+  }
+  if (i == 0) prr[s] = red[0];
+}
+
+__global__ __launch_bounds__(256) void k3_reduce1(int S, const double* __restrict__ part, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  double acc = 0.0;
+  for (int k = tid; k < S; k += 256) acc += part[k];
+  red[tid] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) out[0] = red[0];
+}
+
+// ------------------------------------------------------------------------------------------------- full-order apply
+__global__ __launch_bounds__(256) void k3_fom_apply(T3 t, int Q, int M, QV th, const double* __restrict__ A_diag,
+                                                    const double* __restrict__ A_cpl, const double* __restrict__ x,
+                                                    double* __restrict__ y) {
+  const int e = blockIdx.x, s = blockIdx.y;
+  for (int w = threadIdx.x; w < 10 * M; w += 256) {
+    const int i = w / M, m = w - i * M;
+    double acc = 0.0;
+    for (int q = 0; q < Q; ++q) {
+      double aq = 0.0;
+      const double* A = A_diag + ((((long)q * t.S + s) * t.nT + e) * 5) * 100 + i * 10;
+      for (int slot = 0; slot < 5; ++slot) {
+        int ee = e, ss = s;
+        const double* L = A + slot * 100;
+        if (slot > 0) {
+          ee = t.nb_elem[e * 4 + slot - 1];
+          if (ee < 0) {
+            const int side = -(ee + 1);
+            ss = t.nbr[s * 7 + side_slot(side)];
+            if (ss < 0) continue;
+            L = A_cpl + ((((long)q * t.S + s) * 6 + side) * t.ncf + t.face_pos[e * 4 + slot - 1]) * 100 + i * 10;
+            ee = t.nb_out[e * 4 + slot - 1];
+          }
+        }
+        const double* xv = x + ((long)ss * t.n + ee * 10) * M + m;
+        for (int j = 0; j < 10; ++j) aq += L[j] * xv[(long)j * M];
+      }
+      acc += th.v[q] * aq;
+    }
+    y[((long)s * t.n + e * 10 + i) * M + m] = acc;
+  }
+}
+
+template <typename T>
+int upload(lrbms3_ctx* ctx, const T* host, long count, const T** dev) {
+  void* p = nullptr;
+  if (count <= 0) count = 1;
+  HIP3(ctx, hipMalloc(&p, sizeof(T) * count));
+  ctx->owned.push_back(p);
+  if (host) HIP3(ctx, hipMemcpy(p, host, sizeof(T) * count, hipMemcpyHostToDevice));
+  *dev = (const T*)p;
+  return LRBMS_OK;
+}
+
+QV make_theta(int Q, const double* theta) {
+  QV th{};
+  for (int q = 0; q < Q && q < 8; ++q) th.v[q] = theta[q];
+  return th;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lrbms3_ctx_create(int device, lrbms3_ctx** out) {
+  if (!out) return LRBMS_E_INVALID;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return LRBMS_E_HIP;
+  if (hipSetDevice(device) != hipSuccess) return LRBMS_E_HIP;
+  lrbms3_ctx* c = new lrbms3_ctx();
+  c->device = device;
+  *out = c;
+  return LRBMS_OK;
+}
+
+int lrbms3_ctx_destroy(lrbms3_ctx* ctx) {
+  if (!ctx) return LRBMS_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  for (void* p : ctx->owned) (void)hipFree(p);
+  for (auto& k : ctx->ktimers) {
+    (void)hipEventDestroy(k.e0);
+    (void)hipEventDestroy(k.e1);
+  }
+  delete ctx;
+  return LRBMS_OK;
+}
+
+const char* lrbms3_last_error(lrbms3_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, int32_t S_ext, const int32_t* nbr,
+                       const int32_t* phys) {
+  if (!ctx || !d || !nbr || !phys) return LRBMS_E_INVALID;
+  if (ctx->has_mesh) return fail3(ctx, LRBMS_E_STATE, "mesh already uploaded (one template per context)");
+  if (S <= 0 || S_ext < S || d->n_T <= 0 || d->ncf <= 0) return fail3(ctx, LRBMS_E_INVALID, "bad sizes");
+  for (int s = 0; s < S; ++s) {
+    if (nbr[s * 7 + 3] != s) return fail3(ctx, LRBMS_E_INVALID, "nbr[s][3] must be s");
+    for (int k = 0; k < 7; ++k)
+      if (nbr[s * 7 + k] < -1 || nbr[s * 7 + k] >= S_ext) return fail3(ctx, LRBMS_E_INVALID, "nbr entry out of range");
+  }
+  HIP3(ctx, hipSetDevice(ctx->device));
+  T3& t = ctx->t;
+  t.S = S; t.S_ext = S_ext;
+  t.nT = d->n_T; t.n = 10 * d->n_T; t.nrt = d->n_rt; t.ncf = d->ncf; t.nbf = 6 * d->ncf; t.nvs = d->nvs;
+  t.nnodes = d->n_nodes; t.nb = d->nb; t.nbel = d->nbel; t.nsel = d->nsel;
+  t.nA = d->nA; t.nB = d->nB; t.nC = d->nC; t.nFs = d->nFs; t.nFf = d->nFf;
+  t.o_fs = d->o_fs; t.o_ff = d->o_ff; t.o_c = d->o_c; t.lam_stride = d->lam_stride; t.hat_stride = d->hat_stride;
+  t.f_stride = d->f_stride;
+  t.volume = d->volume; t.kmin = d->kmin;
+  const long nT = t.nT, n = t.n;
+  int rc;
+#define UP(field, count) if ((rc = upload(ctx, d->field, (long)(count), &t.field)) != LRBMS_OK) return rc
+  UP(elem_type, nT); UP(nb_elem, nT * 4); UP(nb_out, nT * 4); UP(face_pos, nT * 4); UP(tsign, nT * 4); UP(elem_rt, nT * 4);
+  UP(rt_e0, t.nrt); UP(rt_f0, t.nrt); UP(rt_e1, t.nrt); UP(rt_f1, t.nrt);
+  UP(side_elem, t.nbf); UP(side_face, t.nbf); UP(side_elem_out, t.nbf); UP(side_face_out, t.nbf);
+  UP(dof_node, n); UP(node_ptr, t.nnodes + 1); UP(node_dofs, n); UP(node_mask, t.nnodes); UP(node_count, t.nnodes);
+  UP(side_nodes, 6 * t.nvs); UP(sn_ptr, 6 * t.nvs + 1);
+  UP(sn_dofs, d->sn_ptr[6 * t.nvs]);
+  UP(bnodes, t.nb); UP(bnode_sides, t.nb * 3); UP(bel_elem, t.nbel); UP(bel_bnode, t.nbel * 10); UP(sel_elem, t.nsel);
+  UP(sel_sf, t.nsel * 4);
+  UP(divc, 24);
+  UP(TV, 6L * t.nA * 100); UP(TE, 6L * t.nB * 100); UP(TAA, 6L * t.nC * 100);
+  UP(TFo, 24L * t.nFs * 100); UP(TFn, 24L * t.nFs * 100); UP(TFb, 24L * t.nFs * 100);
+  UP(TC, 24L * t.nFf * 10); UP(TCb, 24L * t.nFf * 10);
+  UP(TPH, 6L * t.nB * 10); UP(TM, 600); UP(TB, 6L * t.nC * 16); UP(TAB, 6L * t.nC * 40); UP(WB, t.nB); UP(WC, t.nC);
+#undef UP
+  if ((rc = upload(ctx, nbr, (long)S * 7, &t.nbr)) != LRBMS_OK) return rc;
+  if ((rc = upload(ctx, phys, (long)S_ext, &t.phys)) != LRBMS_OK) return rc;
+  ctx->nbr_host.assign(nbr, nbr + (long)S * 7);
+  ctx->has_mesh = true;
+  return LRBMS_OK;
+}
+
+int lrbms3_assemble_system(lrbms3_ctx* ctx, int32_t Q, const double* lam, double* A_diag, double* A_cpl, void* stream) {
+  REQUIRE3(ctx);
+  if (Q < 1 || Q > 8 || !lam || !A_diag || !A_cpl) return fail3(ctx, LRBMS_E_INVALID, "assemble_system: bad argument");
+  const T3& t = ctx->t;
+  hipLaunchKernelGGL(k3_assemble_system, dim3(t.nT, t.S, Q), dim3(128), 0, (hipStream_t)stream, t, lam, A_diag, A_cpl);
+  LAUNCH3(ctx);
+  return LRBMS_OK;
+}
+
+int lrbms3_assemble_rhs(lrbms3_ctx* ctx, const double* f_smp, const double* lhat, double* b, double* f2, double* ceps,
+                        double* bdiv, void* stream) {
+  REQUIRE3(ctx);
+  if (!f_smp || !lhat || !b || !f2 || !ceps || !bdiv) return fail3(ctx, LRBMS_E_INVALID, "assemble_rhs: null argument");
+  const T3& t = ctx->t;
+  hipLaunchKernelGGL(k3_assemble_rhs, dim3(t.nT, t.S), dim3(64), 0, (hipStream_t)stream, t, f_smp, b, bdiv);
+  hipLaunchKernelGGL(k3_scalars, dim3(t.S), dim3(256), 0, (hipStream_t)stream, t, f_smp, lhat, f2, ceps);
+  LAUNCH3(ctx);
+  return LRBMS_OK;
+}
+
+int lrbms3_assemble_products(lrbms3_ctx* ctx, int32_t Q, const double* lam, const double* lbar, const double* lhat, double* ebar,
+                             double* Aaa, double* Aab, double* Bbb, void* stream) {
+  REQUIRE3(ctx);
+  if (Q < 1 || Q > 8 || !lam || !lbar || !lhat || !ebar || !Aaa || !Aab || !Bbb)
+    return fail3(ctx, LRBMS_E_INVALID, "assemble_products: bad argument");
+  const T3& t = ctx->t;
+  const size_t lds = sizeof(double) * (Q + 1) * t.nC;
+  if (lds > 64 * 1024) return fail3(ctx, LRBMS_E_INVALID, "assemble_products: estimator rule too large for the LDS");
+  hipLaunchKernelGGL(k3_assemble_products, dim3(t.nT, t.S), dim3(128), lds, (hipStream_t)stream, t, Q, lam, lbar, lhat, ebar, Aaa,
+                     Aab, Bbb);
+  LAUNCH3(ctx);
+  return LRBMS_OK;
+}
+
+int lrbms3_assemble_flux(lrbms3_ctx* ctx, int32_t Q, const double* lam, double* Cf, void* stream) {
+  REQUIRE3(ctx);
+  if (Q < 1 || Q > 8 || !lam || !Cf) return fail3(ctx, LRBMS_E_INVALID, "assemble_flux: bad argument");
+  const T3& t = ctx->t;
+  hipLaunchKernelGGL(k3_assemble_flux, dim3(t.nT, t.S_ext, Q), dim3(64), 0, (hipStream_t)stream, t, lam, Cf);
+  LAUNCH3(ctx);
+  return LRBMS_OK;
+}
+
+int64_t lrbms3_work_size(lrbms3_ctx* ctx, int32_t Q, int32_t N) {
+  if (!ctx || !ctx->has_mesh) return -1;
+  const T3& t = ctx->t;
+  return (int64_t)t.S * t.nrt * Q * N + (int64_t)t.S * t.nnodes * N;
+}
+
+int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* A_diag, const double* A_cpl,
+                            const double* b, const double* ebar, const double* Aaa, const double* Aab, const double* Bbb,
+                            const double* bdiv, const double* Cf, double* work, double* B_sys, double* rhs_red, double* G_nc,
+                            double* G_bb, double* G_rdd, double* G_ab, double* G_aa, double* r_fd, double* Rb, double* Yb,
+                            double* Dp, double* Xab, double* As, double* Cn, void* stream) {
+  REQUIRE3(ctx);
+  if (Q < 1 || Q > 8 || N < 1 || N > 64 || Q * N > 64)
+    return fail3(ctx, LRBMS_E_INVALID, "project_estimate: needs N <= 64 and Q N <= 64");
+  if (!V || !A_diag || !A_cpl || !b || !ebar || !Aaa || !Aab || !Bbb || !bdiv || !Cf || !work || !B_sys || !rhs_red || !G_nc ||
+      !G_bb || !G_rdd || !G_ab || !G_aa || !r_fd || !Rb || !Yb || !Dp || !Xab || !As || !Cn)
+    return fail3(ctx, LRBMS_E_INVALID, "project_estimate: null argument");
+  const T3& t = ctx->t;
+  hipStream_t st = (hipStream_t)stream;
+  ctx->ktime_n = ctx->ktime ? ctx->ktime_n : 0;
+  double* Rs = work;
+  double* Avg = work + (long)t.S * t.nrt * Q * N;
+  {
+    KScope3 k(ctx, "k3_flux", st);
+    hipLaunchKernelGGL(k3_flux, dim3((t.nrt + t.nbf + 3) / 4, t.S), dim3(256), 0, st, t, Q, N, V, Cf, Rs, Rb);
+  }
+  {
+    KScope3 k(ctx, "k3_node_avg", st);
+    hipLaunchKernelGGL(k3_node_avg, dim3((t.nnodes + 6 * t.nvs + 3) / 4, t.S), dim3(256), 0, st, t, N, V, Avg, As);
+  }
+  GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr};
+  {
+    KScope3 k(ctx, "k3_gram<SYS>", st);
+    a.out = B_sys;
+    hipLaunchKernelGGL(k3_gram<G_SYS>, dim3(Q * t.S), dim3(256), 0, st, a);
+  }
+  {
+    KScope3 k(ctx, "k3_gram<CPL>", st);
+    a.out = B_sys;
+    hipLaunchKernelGGL(k3_gram<G_CPL>, dim3(Q * t.S * 6), dim3(256), 0, st, a);
+  }
+  {
+    KScope3 k(ctx, "k3_gram<AAA>", st);
+    a.out = G_aa;
+    hipLaunchKernelGGL(k3_gram<G_AAA>, dim3(Q * Q * t.S), dim3(256), 0, st, a);
+  }
+  {
+    KScope3 k(ctx, "k3_gram<NC>", st);
+    a.out = G_nc;
+    hipLaunchKernelGGL(k3_gram<G_NC>, dim3(t.S), dim3(256), 0, st, a);
+  }
+  {
+    KScope3 k(ctx, "k3_gram<AB>", st);
+    a.out = G_ab;
+    hipLaunchKernelGGL(k3_gram<G_AB>, dim3(Q * t.S), dim3(256), 0, st, a);
+  }
+  {
+    KScope3 k(ctx, "k3_gram<BB>", st);
+    a.out = G_bb;
+    hipLaunchKernelGGL(k3_gram<G_BB>, dim3(t.S), dim3(256), 0, st, a);
+  }
+  {
+    KScope3 k(ctx, "k3_gram<RDD>", st);
+    a.out = G_rdd;
+    hipLaunchKernelGGL(k3_gram<G_RDD>, dim3(t.S), dim3(256), 0, st, a);
+  }
+  {
+    KScope3 k(ctx, "k3_vecs", st);
+    hipLaunchKernelGGL(k3_vecs, dim3(t.S), dim3(256), 0, st, t, Q, N, V, b, bdiv, Rs, rhs_red, r_fd);
+  }
+  {
+    KScope3 k(ctx, "k3_side_flux", st);
+    hipLaunchKernelGGL(k3_side_flux, dim3(t.nbf, t.S), dim3(64), 0, st, t, Q, N, V, Aab, Bbb, Rs, Yb, Dp, Xab);
+  }
+  {
+    KScope3 k(ctx, "k3_side_nc", st);
+    hipLaunchKernelGGL(k3_side_nc, dim3(t.nb, t.S), dim3(64), 0, st, t, N, V, ebar, Avg, Cn);
+  }
+  LAUNCH3(ctx);
+  return LRBMS_OK;
+}
+
+int lrbms3_kernel_timing(lrbms3_ctx* ctx, int32_t enable) {
+  if (!ctx) return LRBMS_E_INVALID;
+  ctx->ktime = enable != 0;
+  ctx->ktime_n = 0;
+  return LRBMS_OK;
+}
+
+int lrbms3_kernel_timing_read(lrbms3_ctx* ctx, char* names, int64_t names_cap, double* ms, int32_t cap, int32_t* count) {
+  if (!ctx || !names || !ms || !count) return LRBMS_E_INVALID;
+  HIP3(ctx, hipDeviceSynchronize());
+  std::string all;
+  int n = 0;
+  for (int i = 0; i < ctx->ktime_n && n < cap; ++i) {
+    float f = 0.f;
+    if (hipEventElapsedTime(&f, ctx->ktimers[i].e0, ctx->ktimers[i].e1) != hipSuccess) continue;
+    ms[n++] = f;
+    all += ctx->ktimers[i].name;
+    all += "\n";
+  }
+  if ((int64_t)all.size() + 1 > names_cap) return fail3(ctx, LRBMS_E_INVALID, "kernel_timing_read: names buffer too small");
+  memcpy(names, all.c_str(), all.size() + 1);
+  *count = n;
+  ctx->ktime_n = 0;
+  return LRBMS_OK;
+}
+
+int lrbms3_reduced_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* u, const double* G_nc,
+                            const double* G_bb, const double* G_rdd, const double* G_ab, const double* G_aa, const double* r_fd,
+                            const double* Rb, const double* Yb, const double* Dp, const double* Xab, const double* As,
+                            const double* Cn, const double* ebar, const double* Bbb, const double* bdiv, const double* f2,
+                            const double* ceps, double hdiam, double* eta_loc, void* stream) {
+  REQUIRE3(ctx);
+  if (Q < 1 || Q > 8 || N < 1 || Q * N > 64 || !theta || !u || !eta_loc)
+    return fail3(ctx, LRBMS_E_INVALID, "reduced_estimate: bad argument");
+  const T3& t = ctx->t;
+  EA a{u, G_nc, G_bb, G_rdd, G_ab, G_aa, r_fd, Rb, Yb, Dp, Xab, As, Cn, ebar, Bbb, bdiv, f2, ceps, hdiam, eta_loc};
+  const size_t lds = sizeof(double) * (7 * N + Q * N + t.nbf + t.nb + 256);
+  if (lds > 64 * 1024) return fail3(ctx, LRBMS_E_INVALID, "reduced_estimate: template too large for the LDS");
+  hipLaunchKernelGGL(k3_estimate, dim3(t.S), dim3(256), lds, (hipStream_t)stream, t, Q, N, make_theta(Q, theta), a);
+  LAUNCH3(ctx);
+  return LRBMS_OK;
+}
+
+int64_t lrbms3_reduced_solve_work_size(lrbms3_ctx* ctx, int32_t N) {
+  if (!ctx || !ctx->has_mesh) return -1;
+  const int64_t S = ctx->t.S;
+  return S * 7 * N * N + S * N * N + 6 * S * N + 5 * S + 16;
+}
+
+int lrbms3_reduced_solve(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* B_sys, const double* rhs_red,
+                         double* work, double* u, double rtol, int32_t max_iter, double* info, void* stream) {
+  REQUIRE3(ctx);
+  const T3& t = ctx->t;
+  if (t.S_ext != t.S) return fail3(ctx, LRBMS_E_INVALID, "reduced_solve: needs all subdomains on this rank");
+  if (Q < 1 || Q > 8 || N < 1 || N > 64 || !theta || !B_sys || !rhs_red || !work || !u)
+    return fail3(ctx, LRBMS_E_INVALID, "reduced_solve: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const long S = t.S, per_q = S * 7 * N * N;
+  double* Amu = work;
+  double* Dinv = Amu + per_q;
+  double* r = Dinv + S * N * N;
+  double* z = r + S * N;
+  double* p0 = z + S * N;
+  double* p1 = p0 + S * N;
+  double* Ap = p1 + S * N;
+  double* prz0 = Ap + S * N;     // partial sums, ping-pong
+  double* prz1 = prz0 + S;
+  double* ppap = prz1 + S;
+  double* prr = ppap + S;
+  double* scal = prr + S;        // [0] rr, [1] bb
+  hipLaunchKernelGGL(k3_combine, dim3((unsigned)((per_q + 255) / 256)), dim3(256), 0, st, per_q, Q, make_theta(Q, theta), B_sys, Amu);
+  hipLaunchKernelGGL(k3_block_inverse, dim3(S), dim3(256), sizeof(double) * N * (2 * N + 1), st, N, Amu, Dinv);
+  hipLaunchKernelGGL(k3_pcg_init, dim3(S), dim3(64), 0, st, N, rhs_red, Dinv, u, r, z, p0, prz0, prr);
+  hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)S, prr, scal + 1);
+  LAUNCH3(ctx);
+  double bb = 0.0;
+  HIP3(ctx, hipMemcpyAsync(&bb, scal + 1, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP3(ctx, hipStreamSynchronize(st));
+  if (info) info[0] = 0, info[1] = 0;
+  if (bb == 0.0) return LRBMS_OK;
+  const size_t lds = sizeof(double) * (7 * N + 64);
+  double *po = p0, *pn = p1, *rz_old = prz1, *rz_cur = prz0;
+  int it = 0;
+  double rel = 1.0;
+  const int check = 8;
+  while (it < max_iter) {
+    for (int k = 0; k < check && it < max_iter; ++k, ++it) {
+      hipLaunchKernelGGL(k3_pcg_matvec, dim3(S), dim3(64), lds, st, t, N, it == 0 ? 1 : 0, Amu, z, po, pn, Ap, rz_cur, rz_old, ppap);
+      hipLaunchKernelGGL(k3_pcg_update, dim3(S), dim3(64), 0, st, (int)S, N, Dinv, pn, Ap, u, r, z, rz_cur, ppap, rz_old, prr);
+      std::swap(po, pn);
+      std::swap(rz_old, rz_cur);
+    }
+    hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)S, prr, scal);
+    LAUNCH3(ctx);
+    double rr = 0.0;
+    HIP3(ctx, hipMemcpyAsync(&rr, scal, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP3(ctx, hipStreamSynchronize(st));
+    rel = sqrt(rr / bb);
+    if (!(rel == rel)) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve: NaN residual");
+    if (rel <= rtol) break;
+  }
+  if (info) info[0] = it, info[1] = rel;
+  if (rel > rtol) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve: not converged");
+  return LRBMS_OK;
+}
+
+int lrbms3_fom_apply(lrbms3_ctx* ctx, int32_t Q, int32_t M, const double* theta, const double* A_diag, const double* A_cpl,
+                     const double* x, double* y, void* stream) {
+  REQUIRE3(ctx);
+  if (Q < 1 || Q > 8 || M < 1 || !theta || !A_diag || !A_cpl || !x || !y) return fail3(ctx, LRBMS_E_INVALID, "fom_apply: bad argument");
+  const T3& t = ctx->t;
+  hipLaunchKernelGGL(k3_fom_apply, dim3(t.nT, t.S), dim3(256), 0, (hipStream_t)stream, t, Q, M, make_theta(Q, theta), A_diag, A_cpl, x, y);
+  LAUNCH3(ctx);
+  return LRBMS_OK;
+}
+
+}  // extern "C"
