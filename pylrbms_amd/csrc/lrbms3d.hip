@@ -470,6 +470,215 @@ __global__ __launch_bounds__(256) void k3_gram(GA a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------- pass: MFMA pipeline
+// G = sum_items X^T (L Y), everything on the matrix cores, operands straight from global memory (L2 / L1 resident):
+//   Z  = L Y      L [mz x ky] element block as the A operand (lane: row l&15, k l>>4), Y rows gathered as the B operand
+//   G += X^T Z    the accumulator layout of Z (lane: rows (l>>4) + 4 r, column l&15) IS the B-operand layout of k-step r,
+//                 so Z never leaves the registers; X rows as the A operand
+// One wave per item (element / side face), NW waves per workgroup = one (subdomain, operator); the waves' tiles are summed in a
+// fixed order through the LDS at the end.  RT x CT output tiles of 16 x 16 per wave.
+template <int KIND> struct PGT {};
+template <> struct PGT<G_SYS> { static constexpr int MZ = 10, KY = 50; };
+template <> struct PGT<G_AAA> { static constexpr int MZ = 10, KY = 10; };
+template <> struct PGT<G_NC> { static constexpr int MZ = 10, KY = 10; };
+template <> struct PGT<G_CPL> { static constexpr int MZ = 10, KY = 10; };
+template <> struct PGT<G_AB> { static constexpr int MZ = 10, KY = 4; };
+template <> struct PGT<G_BB> { static constexpr int MZ = 4, KY = 4; };
+
+template <int KIND, int RT, int CT>
+__global__ __launch_bounds__(256) void k3_pg(GA a) {
+  extern __shared__ double lds[];   // [RT * CT][256]
+  constexpr int MZ = PGT<KIND>::MZ, KY = PGT<KIND>::KY, KS = (KY + 3) / 4, KR = (MZ + 3) / 4;
+  const T3& t = a.t;
+  const int N = a.N, Q = a.Q, QN = Q * N;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int NW = blockDim.x >> 6;
+  int s, q = 0, Mx, My, t2 = 0, side = 0, nitems = t.nT;
+  double* out;
+  if (KIND == G_SYS) {
+    q = b / t.S; s = b - q * t.S; Mx = My = N;
+    out = a.out + (((long)q * t.S + s) * 7 + 3) * N * N;
+  } else if (KIND == G_CPL) {
+    side = b % 6;
+    const int qs = b / 6;
+    q = qs / t.S; s = qs - q * t.S; Mx = My = N; nitems = t.ncf;
+    t2 = t.nbr[s * 7 + side_slot(side)];
+    out = a.out + (((long)q * t.S + s) * 7 + side_slot(side)) * N * N;
+  } else if (KIND == G_AAA) {
+    s = b % t.S; Mx = My = N;
+    out = a.out + (long)b * N * N;
+  } else if (KIND == G_NC) {
+    s = b; Mx = My = N;
+    out = a.out + (long)b * N * N;
+  } else if (KIND == G_AB) {
+    q = b / t.S; s = b - q * t.S; Mx = N; My = QN;
+    out = a.out + (long)b * N * QN;
+  } else {
+    s = b; Mx = My = QN;
+    out = a.out + (long)b * QN * QN;
+  }
+  if (KIND == G_CPL && t2 < 0) {
+    for (int i = tid; i < Mx * My; i += blockDim.x) out[i] = 0.0;
+    return;
+  }
+  const double* Vs = a.V + (long)s * t.n * N;
+  const double* Av = a.Avg + (long)s * t.nnodes * N;
+  const double* Rss = a.Rs + (long)s * t.nrt * QN;
+
+  d4 acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  for (int item = wave; item < nitems; item += NW) {
+    int e = item;
+    const double* Lb;
+    const double* Yb = Vs;
+    if (KIND == G_SYS) Lb = a.A_diag + ((((long)q * t.S + s) * t.nT + e) * 5) * 100;
+    if (KIND == G_AAA) Lb = a.Aaa + ((long)b * t.nT + e) * 100;
+    if (KIND == G_NC) Lb = a.ebar + ((long)s * t.nT + e) * 100;
+    if (KIND == G_AB) Lb = a.Aab + (((long)q * t.S + s) * t.nT + e) * 40;
+    if (KIND == G_BB) Lb = a.Bbb + ((long)s * t.nT + e) * 16;
+    int eo = 0;
+    if (KIND == G_CPL) {
+      const int sp = side * t.ncf + item;
+      e = t.side_elem[sp];
+      if (e < 0) continue;
+      eo = t.side_elem_out[sp];
+      Lb = a.A_cpl + ((((long)q * t.S + s) * 6 + side) * t.ncf + item) * 100;
+      Yb = a.V + (long)t2 * t.n * N;
+    }
+    // ---- A operands of the apply: L[i = li][cc = 4 kk + lk]
+    double lop[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int cc = 4 * kk + lk;
+      double v = 0.0;
+      if (li < MZ && cc < KY) {
+        if (KIND == G_SYS) {
+          const int slot = cc / 10, j = cc - slot * 10;
+          v = Lb[slot * 100 + li * 10 + j];
+        } else {
+          v = Lb[li * KY + cc];
+        }
+      }
+      lop[kk] = v;
+    }
+    // ---- row of Y for this lane's k index of every k-step (same for all column tiles)
+    long yrow[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int cc = 4 * kk + lk;
+      long r = -1;
+      if (cc < KY) {
+        if (KIND == G_SYS) {
+          const int slot = cc / 10, j = cc - slot * 10;
+          const int ee = slot == 0 ? e : t.nb_elem[e * 4 + slot - 1];
+          if (ee >= 0) r = (long)ee * 10 + j;
+        } else if (KIND == G_AAA || KIND == G_NC) {
+          r = (long)e * 10 + cc;
+        } else if (KIND == G_CPL) {
+          r = (long)eo * 10 + cc;
+        } else {
+          r = t.elem_rt[e * 4 + cc];
+        }
+      }
+      yrow[kk] = r;
+    }
+    // ---- A operands of the Gram product: X[row = 4 r + lk][col = rt * 16 + li]
+    double xop[RT][KR];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < KR; ++r) {
+        const int row = 4 * r + lk, col = rt * 16 + li;
+        double v = 0.0;
+        if (row < MZ && col < Mx) {
+          if (KIND == G_BB) {
+            v = Rss[(long)t.elem_rt[e * 4 + row] * QN + col];
+          } else {
+            const long d = (long)e * 10 + row;
+            v = Vs[d * N + col];
+            if (KIND == G_NC) v -= Av[(long)t.dof_node[d] * N + col];
+          }
+        }
+        xop[rt][r] = v;
+      }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int col = ct * 16 + li;
+      d4 z = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        double v = 0.0;
+        if (yrow[kk] >= 0 && col < My) {
+          if (KIND == G_AB || KIND == G_BB) {
+            v = Rss[yrow[kk] * QN + col];
+          } else {
+            v = Yb[yrow[kk] * N + col];
+            if (KIND == G_NC) v -= Av[(long)t.dof_node[yrow[kk]] * N + col];
+          }
+        }
+        z = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[kk], v, z, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < KR; ++r) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[rt][r], z[r], acc[rt][ct], 0, 0, 0);
+    }
+  }
+  // ---- fixed-order sum over the waves: acc_0 + (acc_1 + (... + acc_{NW-1}))
+  for (int w = NW - 1; w > 0; --w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[((i * CT + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wave == w - 1) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] += lds[((i * CT + j) * 4 + r) * 64 + lane];
+    }
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const int col = j * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i * 16 + lk + 4 * r;
+          if (row < Mx && col < My) out[(long)row * My + col] = acc[i][j][r];
+        }
+      }
+  }
+}
+
+template <int KIND, int RT, int CT>
+void launch_pg(const GA& a, int batch, int nw, hipStream_t st) {
+  hipLaunchKernelGGL((k3_pg<KIND, RT, CT>), dim3(batch), dim3(64 * nw), sizeof(double) * RT * CT * 256, st, a);
+}
+
+template <int KIND>
+int dispatch_pg(const GA& a, int batch, int rt, int ct, int nw, hipStream_t st) {
+#define PGCASE(R, C) if (rt == R && ct == C) { launch_pg<KIND, R, C>(a, batch, nw, st); return 0; }
+  PGCASE(1, 1) PGCASE(2, 2) PGCASE(3, 3) PGCASE(4, 4)
+  if (KIND == G_AB) { PGCASE(1, 2) PGCASE(1, 3) PGCASE(1, 4) PGCASE(2, 3) PGCASE(2, 4) PGCASE(3, 4) }
+#undef PGCASE
+  return -1;
+}
+
 // rhs_red [S][N] = V^T b,  r_fd [S][QN] = sum_e bdiv_e div R_self|_e
 __global__ __launch_bounds__(256) void k3_vecs(T3 t, int Q, int N, const double* __restrict__ V, const double* __restrict__ b,
                                                const double* __restrict__ bdiv, const double* __restrict__ Rs,
@@ -1096,36 +1305,40 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
     hipLaunchKernelGGL(k3_node_avg, dim3((t.nnodes + 6 * t.nvs + 3) / 4, t.S), dim3(256), 0, st, t, N, V, Avg, As);
   }
   GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr};
+  const int tn = (N + 15) / 16, tq = (Q * N + 15) / 16;
+  const int nw = 4;
+  int bad = 0;
   {
-    KScope3 k(ctx, "k3_gram<SYS>", st);
+    KScope3 k(ctx, "k3_pg<SYS>", st);
     a.out = B_sys;
-    hipLaunchKernelGGL(k3_gram<G_SYS>, dim3(Q * t.S), dim3(256), 0, st, a);
+    bad |= dispatch_pg<G_SYS>(a, Q * t.S, tn, tn, nw, st);
   }
   {
-    KScope3 k(ctx, "k3_gram<CPL>", st);
+    KScope3 k(ctx, "k3_pg<CPL>", st);
     a.out = B_sys;
-    hipLaunchKernelGGL(k3_gram<G_CPL>, dim3(Q * t.S * 6), dim3(256), 0, st, a);
+    bad |= dispatch_pg<G_CPL>(a, Q * t.S * 6, tn, tn, nw, st);
   }
   {
-    KScope3 k(ctx, "k3_gram<AAA>", st);
+    KScope3 k(ctx, "k3_pg<AAA>", st);
     a.out = G_aa;
-    hipLaunchKernelGGL(k3_gram<G_AAA>, dim3(Q * Q * t.S), dim3(256), 0, st, a);
+    bad |= dispatch_pg<G_AAA>(a, Q * Q * t.S, tn, tn, nw, st);
   }
   {
-    KScope3 k(ctx, "k3_gram<NC>", st);
+    KScope3 k(ctx, "k3_pg<NC>", st);
     a.out = G_nc;
-    hipLaunchKernelGGL(k3_gram<G_NC>, dim3(t.S), dim3(256), 0, st, a);
+    bad |= dispatch_pg<G_NC>(a, t.S, tn, tn, nw, st);
   }
   {
-    KScope3 k(ctx, "k3_gram<AB>", st);
+    KScope3 k(ctx, "k3_pg<AB>", st);
     a.out = G_ab;
-    hipLaunchKernelGGL(k3_gram<G_AB>, dim3(Q * t.S), dim3(256), 0, st, a);
+    bad |= dispatch_pg<G_AB>(a, Q * t.S, tn, tq, nw, st);
   }
   {
-    KScope3 k(ctx, "k3_gram<BB>", st);
+    KScope3 k(ctx, "k3_pg<BB>", st);
     a.out = G_bb;
-    hipLaunchKernelGGL(k3_gram<G_BB>, dim3(t.S), dim3(256), 0, st, a);
+    bad |= dispatch_pg<G_BB>(a, t.S, tq, tq, nw, st);
   }
+  if (bad) return fail3(ctx, LRBMS_E_INVALID, "project_estimate: unsupported tile shape");
   {
     KScope3 k(ctx, "k3_gram<RDD>", st);
     a.out = G_rdd;
