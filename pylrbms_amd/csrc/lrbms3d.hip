@@ -32,6 +32,7 @@ struct T3 {
   const int *dof_node, *node_ptr, *node_dofs, *node_mask, *node_count, *side_nodes, *sn_ptr, *sn_dofs;
   const int *bnodes, *bnode_sides, *bel_elem, *bel_bnode, *sel_elem, *sel_sf;
   const double *divc, *TV, *TE, *TAA, *TFo, *TFn, *TFb, *TC, *TCb, *TPH, *TM, *TB, *TAB, *WB, *WC;
+  const double* zeros;   // [64] zeros: target of the loads of padding lanes
 };
 
 }  // namespace
@@ -532,8 +533,53 @@ __global__ __launch_bounds__(256) void k3_pg(GA a) {
 #pragma unroll
     for (int j = 0; j < CT; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  for (int item = wave; item < nitems; item += NW) {
-    int e = item;
+  // Software pipeline, two stages ahead: the index tables of item i + 2 (element neighbours, RT0 / node numbers) and all
+  // operands of item i + 1 are in flight while the MFMAs of item i run.  Every load is unconditional (addresses clamped into
+  // the arrays, padding lanes zeroed by selects where it matters: rows >= MZ of L and X, k >= KY of L), so the loop body is
+  // branch-free and the loads issue back to back.  Padded COLUMNS may hold finite garbage: it only reaches accumulator rows /
+  // columns that are never stored.
+  struct Idx {
+    int e, eo;
+    int nb[4];       // SYS: inner neighbour elements
+    int aux[KR];     // NC: Lagrange node of row 4 r + lk;  AB / BB: RT0 DoF of face lk
+  };
+  constexpr bool NCK = KIND == G_NC;
+  struct Ops {
+    double lop[KS];       // A operands of the apply: L[i = li][cc = 4 kk + lk]
+    double yv[CT][KS];    // B operands of the apply: Y[row cc][col = ct * 16 + li]
+    double xop[RT][KR];   // A operands of the Gram product: X[row = 4 r + lk][col = rt * 16 + li]
+    double yav[NCK ? CT : 1][NCK ? KS : 1], xav[NCK ? RT : 1][NCK ? KR : 1];   // NC: node averages, subtracted when consumed
+  };
+  const int last = nitems - 1;
+  auto load_idx = [&](int item, Idx& ix) {
+    item = item < last ? item : last;
+    ix.e = item;
+    ix.eo = 0;
+    if (KIND == G_CPL) {
+      const int sp = side * t.ncf + item;
+      ix.e = t.side_elem[sp];
+      ix.eo = t.side_elem_out[sp];
+    }
+    if (KIND == G_SYS) {
+      const int4 v = *reinterpret_cast<const int4*>(t.nb_elem + item * 4);
+      ix.nb[0] = v.x; ix.nb[1] = v.y; ix.nb[2] = v.z; ix.nb[3] = v.w;
+    }
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      ix.aux[r] = 0;
+      if (KIND == G_NC) {
+        const int row = 4 * r + lk;
+        ix.aux[r] = t.dof_node[item * 10 + (row < 10 ? row : 9)];
+      }
+    }
+    if (KIND == G_AB || KIND == G_BB) ix.aux[0] = t.elem_rt[item * 4 + lk];
+  };
+  // no arithmetic on freshly loaded values here (a select or a subtraction would make the compiler wait for the load inside
+  // this iteration): padding lanes load from t.zeros instead, chosen by ADDRESS
+  auto load_ops = [&](int item, const Idx& ix, Ops& o) {
+    item = item < last ? item : last;
+    const bool on = KIND != G_CPL || ix.e >= 0;
+    const int e = on ? ix.e : 0, eo = on ? ix.eo : 0;
     const double* Lb;
     const double* Yb = Vs;
     if (KIND == G_SYS) Lb = a.A_diag + ((((long)q * t.S + s) * t.nT + e) * 5) * 100;
@@ -541,92 +587,102 @@ __global__ __launch_bounds__(256) void k3_pg(GA a) {
     if (KIND == G_NC) Lb = a.ebar + ((long)s * t.nT + e) * 100;
     if (KIND == G_AB) Lb = a.Aab + (((long)q * t.S + s) * t.nT + e) * 40;
     if (KIND == G_BB) Lb = a.Bbb + ((long)s * t.nT + e) * 16;
-    int eo = 0;
     if (KIND == G_CPL) {
-      const int sp = side * t.ncf + item;
-      e = t.side_elem[sp];
-      if (e < 0) continue;
-      eo = t.side_elem_out[sp];
       Lb = a.A_cpl + ((((long)q * t.S + s) * 6 + side) * t.ncf + item) * 100;
       Yb = a.V + (long)t2 * t.n * N;
     }
-    // ---- A operands of the apply: L[i = li][cc = 4 kk + lk]
-    double lop[KS];
+    const double* zero = t.zeros + lane;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-      const int cc = 4 * kk + lk;
-      double v = 0.0;
-      if (li < MZ && cc < KY) {
-        if (KIND == G_SYS) {
-          const int slot = cc / 10, j = cc - slot * 10;
-          v = Lb[slot * 100 + li * 10 + j];
+      const int cc0 = 4 * kk + lk;
+      const bool kin = cc0 < KY;
+      const int cc = kin ? cc0 : KY - 1;
+      const double* lp;
+      bool lon = kin && li < MZ && on;
+      long r;
+      if (KIND == G_SYS) {
+        const int slot = cc / 10, j = cc - slot * 10;
+        lp = Lb + slot * 100 + li * 10 + j;
+        int ee = e;
+        if (slot == 1) ee = ix.nb[0];
+        if (slot == 2) ee = ix.nb[1];
+        if (slot == 3) ee = ix.nb[2];
+        if (slot == 4) ee = ix.nb[3];
+        if (ee < 0) ee = e, lon = false;        // side face: no inner neighbour (the block is zero anyway)
+        r = (long)ee * 10 + j;
+      } else {
+        lp = Lb + li * KY + cc;
+        if (KIND == G_AAA || KIND == G_NC) r = (long)e * 10 + cc;
+        else if (KIND == G_CPL) r = (long)eo * 10 + cc;
+        else r = ix.aux[0];
+      }
+      o.lop[kk] = *(lon ? lp : zero);
+      long nd = 0;
+      if (KIND == G_NC) nd = (long)ix.aux[kk] * N;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int col0 = ct * 16 + li;
+        const int col = col0 < My ? col0 : My - 1;
+        if (KIND == G_AB || KIND == G_BB) {
+          o.yv[ct][kk] = Rss[r * QN + col];
         } else {
-          v = Lb[li * KY + cc];
+          o.yv[ct][kk] = Yb[r * N + col];
+          if (NCK) o.yav[NCK ? ct : 0][NCK ? kk : 0] = Av[nd + col];
         }
       }
-      lop[kk] = v;
     }
-    // ---- row of Y for this lane's k index of every k-step (same for all column tiles)
-    long yrow[KS];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      const int cc = 4 * kk + lk;
-      long r = -1;
-      if (cc < KY) {
-        if (KIND == G_SYS) {
-          const int slot = cc / 10, j = cc - slot * 10;
-          const int ee = slot == 0 ? e : t.nb_elem[e * 4 + slot - 1];
-          if (ee >= 0) r = (long)ee * 10 + j;
-        } else if (KIND == G_AAA || KIND == G_NC) {
-          r = (long)e * 10 + cc;
-        } else if (KIND == G_CPL) {
-          r = (long)eo * 10 + cc;
-        } else {
-          r = t.elem_rt[e * 4 + cc];
-        }
+    for (int r = 0; r < KR; ++r) {
+      const int row0 = 4 * r + lk;
+      const bool rin = row0 < MZ;
+      const int row = rin ? row0 : MZ - 1;
+      long base, nd = 0;
+      if (KIND == G_BB) {
+        base = (long)ix.aux[0] * QN;        // KR == 1: row == lk
+      } else {
+        base = ((long)e * 10 + row) * N;
+        if (KIND == G_NC) nd = (long)ix.aux[r] * N;
       }
-      yrow[kk] = r;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int col0 = rt * 16 + li;
+        const int col = col0 < Mx ? col0 : Mx - 1;
+        const double* xp = (KIND == G_BB ? Rss : Vs) + base + col;
+        o.xop[rt][r] = *(rin ? xp : zero);
+        if (NCK) o.xav[NCK ? rt : 0][NCK ? r : 0] = *(rin ? Av + nd + col : zero);
+      }
     }
-    // ---- A operands of the Gram product: X[row = 4 r + lk][col = rt * 16 + li]
-    double xop[RT][KR];
+  };
+
+  Idx ix1, ix2;
+  Ops nxt;
+  load_idx(wave, ix1);
+  load_idx(wave + NW, ix2);
+  load_ops(wave, ix1, nxt);
+  for (int item = wave; item < nitems; item += NW) {
+    Ops cur = nxt;
+    load_ops(item + NW, ix2, nxt);
+    ix1 = ix2;
+    load_idx(item + 2 * NW, ix2);
+    if (NCK) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+      for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-      for (int r = 0; r < KR; ++r) {
-        const int row = 4 * r + lk, col = rt * 16 + li;
-        double v = 0.0;
-        if (row < MZ && col < Mx) {
-          if (KIND == G_BB) {
-            v = Rss[(long)t.elem_rt[e * 4 + row] * QN + col];
-          } else {
-            const long d = (long)e * 10 + row;
-            v = Vs[d * N + col];
-            if (KIND == G_NC) v -= Av[(long)t.dof_node[d] * N + col];
-          }
-        }
-        xop[rt][r] = v;
-      }
+        for (int ct = 0; ct < CT; ++ct) cur.yv[ct][kk] -= cur.yav[NCK ? ct : 0][NCK ? kk : 0];
+#pragma unroll
+      for (int r = 0; r < KR; ++r)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) cur.xop[rt][r] -= cur.xav[NCK ? rt : 0][NCK ? r : 0];
+    }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      const int col = ct * 16 + li;
       d4 z = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        double v = 0.0;
-        if (yrow[kk] >= 0 && col < My) {
-          if (KIND == G_AB || KIND == G_BB) {
-            v = Rss[yrow[kk] * QN + col];
-          } else {
-            v = Yb[yrow[kk] * N + col];
-            if (KIND == G_NC) v -= Av[(long)t.dof_node[yrow[kk]] * N + col];
-          }
-        }
-        z = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[kk], v, z, 0, 0, 0);
-      }
+      for (int kk = 0; kk < KS; ++kk) z = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.lop[kk], cur.yv[ct][kk], z, 0, 0, 0);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < KR; ++r) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[rt][r], z[r], acc[rt][ct], 0, 0, 0);
+        for (int r = 0; r < KR; ++r) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.xop[rt][r], z[r], acc[rt][ct], 0, 0, 0);
     }
   }
   // ---- fixed-order sum over the waves: acc_0 + (acc_1 + (... + acc_{NW-1}))
@@ -1226,6 +1282,10 @@ int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, in
 #undef UP
   if ((rc = upload(ctx, nbr, (long)S * 7, &t.nbr)) != LRBMS_OK) return rc;
   if ((rc = upload(ctx, phys, (long)S_ext, &t.phys)) != LRBMS_OK) return rc;
+  {
+    const double z[64] = {0.0};
+    if ((rc = upload(ctx, z, 64L, &t.zeros)) != LRBMS_OK) return rc;
+  }
   ctx->nbr_host.assign(nbr, nbr + (long)S * 7);
   ctx->has_mesh = true;
   return LRBMS_OK;
