@@ -226,7 +226,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', default='cfg3', choices=sorted(CONFIGS))
+    ap.add_argument('--config', default='cfg3', choices=sorted(CONFIGS) + ['cfg5', 'cfg5_tile8'])
+    ap.add_argument('--no-config5', action='store_true', help='skip the config-5 (3D, P2) leg of the default run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-online', action='store_true')
     args = ap.parse_args()
@@ -234,6 +235,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.config.startswith('cfg5'):
+        # BASELINE.json config 5 (3D diffusion, SWIPDG p = 2): its own line (bench3d.py); one rank holds all subdomains
+        import bench3d
+        if world > 1:
+            raise SystemExit('--config {} runs on one rank (replicas only)'.format(args.config))
+        print(json.dumps(bench3d.run(args.config, args.steps, args.warmup, device_index=local_rank, cpu=not args.no_cpu_baseline,
+                                     online=not args.no_online)), flush=True)
+        return
     cfg = CONFIGS[args.config]
     N = cfg['N']
 
@@ -241,6 +250,11 @@ def main():
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg['num_subdomains'], N, cfg['coarse_per_subdomain'])
+    cpu5 = None
+    do_cfg5 = world == 1 and rank == 0 and args.config == 'cfg3' and not args.no_config5
+    if do_cfg5 and not args.no_cpu_baseline:
+        import bench3d
+        cpu5 = bench3d.cpu_baseline3d(bench3d.CONFIGS3D['cfg5']['N'])
 
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before the HIP runtime is loaded (dmabuf IPC only)
     import torch
@@ -531,6 +545,14 @@ def main():
             out['parabolic'] = parabolic
         if cpu is not None:                              # reported baseline: rank 0 at N = 1 only (timed before GPU init)
             out['cpu_baseline'] = cpu
+        if do_cfg5:
+            # BASELINE.json config 5 (3D, P2 tetrahedra, N = 30) on the same GPU, after the config-3 buffers are released
+            import bench3d
+            del buf, V
+            torch.cuda.empty_cache()
+            out['config5'] = bench3d.run('cfg5', steps=10, warmup=2, device_index=local_rank, cpu=False, online=not args.no_online)
+            if cpu5 is not None:
+                out['config5']['cpu_baseline'] = cpu5
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,188 @@
+"""Bench leg of BASELINE.json config 5 (3D diffusion, 8 x 8 x 8 subdomains, SWIPDG p = 2, local basis dim 30) -- used by
+bench.py (`--config cfg5` prints its line; the default config-3 run carries it as the `config5` object).
+
+A step is one pass of the 3D project+estimate path (lrbms3_project_estimate) over all subdomains of this rank on synthetic
+data (pylrbms_amd/multiscale_problem3d.py, constant + seeded random basis columns resident in HBM).  One GPU holds the whole
+8 x 8 x 8 configuration (0.47 GB of bases, 2.6 GB of assembled element blocks).
+
+Roofline of the dominant kernel: executed fp64-MFMA flops (padding included, counted from the kernel's own tile shapes) over
+its HIP-event duration against 78.6 TFLOP/s; compulsory HBM bytes of the pass (inputs once + outputs once) beside it."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS3D = {
+    'cfg5': {'num_subdomains': (8, 8, 8), 'cubes_per_subdomain': 4, 'N': 30},
+    'cfg5_tile8': {'num_subdomains': (4, 4, 4), 'cubes_per_subdomain': 4, 'N': 30},   # what one rank of the 8-GPU run holds
+}
+PEAK_HBM_GBS = 8000.0
+PEAK_FP64_MFMA_TFLOPS = 78.6
+MFMA_FLOPS = 2 * 16 * 16 * 4
+
+
+def mfma_counts(n_T, ncf, N, Q):
+    """Executed v_mfma_f64_16x16x4 per subdomain and kernel of the pass (k3_pg<KIND>: per item KS * CT apply steps +
+    RT * KR * CT projection steps; csrc/lrbms3d.hip)."""
+    tn, tq = (N + 15) // 16, (Q * N + 15) // 16
+    per = {'k3_pg<SYS>': (13 * tn + tn * 3 * tn) * n_T * Q,
+           'k3_pg<CPL>': (3 * tn + tn * 3 * tn) * ncf * 6 * Q,
+           'k3_pg<AAA>': (3 * tn + tn * 3 * tn) * n_T * Q * Q,
+           'k3_pg<NC>': (3 * tn + tn * 3 * tn) * n_T,
+           'k3_pg<AB>': (1 * tq + tn * 3 * tq) * n_T * Q,
+           'k3_pg<BB>': (1 * tq + tq * 1 * tq) * n_T}
+    return per
+
+
+def compulsory_bytes(t, S, N, Q):
+    """Every input of the pass once and every output once (bytes)."""
+    QN = Q * N
+    inputs = S * 8 * (t.n * N + t.n_T * (Q * 500 + 100 + Q * Q * 100 + Q * 40 + 16 + 1 + Q * 40) + Q * 6 * t.ncf * 100 + t.n)
+    outputs = S * 8 * (Q * 7 * N * N + N + N * N + 2 * QN * QN + Q * N * QN + Q * Q * N * N + QN + 3 * t.nbf * QN + Q * t.nbf * N +
+                       6 * t.nvs * N + t.nb * N)
+    return inputs, outputs
+
+
+def cpu_baseline3d(N):
+    """The 3D oracle's Reductor3D.reduce() (NumPy / SciPy, one core) on a 2 x 2 x 2 sample of the same problem, timed before
+    the process touches the GPU."""
+    from oracle.lrbms3d import Discretization3D, Reductor3D
+    from oracle.mesh3d import KuhnMesh3D
+    from pylrbms_amd import multiscale_problem3d
+    P = (2, 2, 2)
+    p = multiscale_problem3d.init_grid_and_problem({'num_subdomains': P, 'cubes_per_subdomain': 4})
+    lam = p['lambda']
+    t0 = time.perf_counter()
+    d = Discretization3D(KuhnMesh3D(np.array(P) * 4, P), lam['functions'], lam['coefficients'], np.eye(3), p['f'], p['lambda_bar'],
+                         p['lambda_hat'], 1.0, 1.0)
+    t_asm = time.perf_counter() - t0
+    rng = np.random.default_rng(0)
+    V = [np.hstack([np.ones((d.n, 1)), rng.standard_normal((d.n, N - 1))]) for _ in range(d.S)]
+    t0 = time.perf_counter()
+    Reductor3D(d, V).reduce()
+    dt = time.perf_counter() - t0
+    return {'value': d.S / dt, 'unit': 'subdomains/s', 'cores': 1, 'kind': 'port',
+            'assemble_subdomains_per_s_1core': d.S / t_asm,
+            'sample': 'oracle.lrbms3d.Reductor3D.reduce() (NumPy/SciPy fp64, one process, one thread) on 2x2x2 subdomains of the '
+                      'same synthetic 3D problem (k_c = 4, n = 3840, N = {}); timed before the GPU is touched'.format(N),
+            'os_cpu_count': os.cpu_count()}
+
+
+def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True):
+    cfg = CONFIGS3D[config]
+    N = cfg['N']
+    base = cpu_baseline3d(N) if cpu else None
+    import torch
+    from pylrbms_amd import multiscale_problem3d
+    from pylrbms_amd.engine3d import Engine3D
+    p = multiscale_problem3d.init_grid_and_problem({'num_subdomains': cfg['num_subdomains'],
+                                                    'cubes_per_subdomain': cfg['cubes_per_subdomain']})
+    lam = p['lambda']
+    t0 = time.perf_counter()
+    eng = Engine3D(p['grid'], lam['functions'], p['f'], p['lambda_bar'], p['lambda_hat'], data_degree=p['data_degree'],
+                   device_index=device_index)
+    setup_s = time.perf_counter() - t0
+    eng.assemble()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    eng.assemble()
+    e1.record()
+    torch.cuda.synchronize()
+    assemble_ms = e0.elapsed_time(e1)
+    t, S, Q = eng.t, eng.S, eng.Q
+    g = torch.Generator(device='cuda').manual_seed(0)
+    V = torch.randn(eng.S_ext, t.n, N, dtype=torch.float64, device='cuda', generator=g)
+    V[:, :, 0] = 1.0
+    out, work = eng.alloc_outputs(N), eng.alloc_work(N)
+    for _ in range(warmup):
+        eng.project_and_estimate(V, out, work)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        eng.project_and_estimate(V, out, work)
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / steps
+    eng.ctx.kernel_timing(True)
+    for _ in range(steps):
+        eng.project_and_estimate(V, out, work)
+    rows = eng.ctx.kernel_timing_read()
+    eng.ctx.kernel_timing(False)
+    agg = {}
+    for name, v in rows:
+        agg.setdefault(name, []).append(v)
+    counts = mfma_counts(t.n_T, t.ncf, N, Q)
+    table = []
+    for name, v in sorted(agg.items(), key=lambda kv: -np.mean(kv[1])):
+        us = 1e3 * float(np.mean(v))
+        row = {'name': name, 'us': us}
+        if name in counts:
+            fl = counts[name] * S * MFMA_FLOPS
+            row.update(mfma_flops=fl, mfma_TFLOPs=fl / (us * 1e-6) / 1e12, mfma_frac=fl / (us * 1e-6) / 1e12 / PEAK_FP64_MFMA_TFLOPS)
+        table.append(row)
+    inputs, outputs = compulsory_bytes(t, S, N, Q)
+    dense_us = sum(r['us'] for r in table if 'mfma_flops' in r)
+    dense_fl = sum(r['mfma_flops'] for r in table if 'mfma_flops' in r)
+    dom = table[0]
+    roofline = {'bound': 'mfma' if 'mfma_frac' in dom else 'hbm', 'unit': 'TFLOP/s' if 'mfma_frac' in dom else 'GB/s',
+                'achieved': dom.get('mfma_TFLOPs'), 'peak': PEAK_FP64_MFMA_TFLOPS, 'frac': dom.get('mfma_frac'), 'traffic': None,
+                'kernel': dom['name'], 'kernel_us': dom['us'],
+                'basis': 'executed fp64-MFMA flops of the dominant kernel (padding included) / its HIP-event duration',
+                'dense_kernels': {'us': dense_us, 'mfma_flops': dense_fl, 'TFLOPs': dense_fl / (dense_us * 1e-6) / 1e12,
+                                  'frac': dense_fl / (dense_us * 1e-6) / 1e12 / PEAK_FP64_MFMA_TFLOPS},
+                'compulsory_bytes': inputs + outputs, 'compulsory_input_bytes': inputs, 'compulsory_output_bytes': outputs,
+                'compulsory_GBps': (inputs + outputs) / (dev_ms * 1e-3) / 1e9,
+                'compulsory_frac_of_hbm_peak': (inputs + outputs) / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                'device_ms_per_step': dev_ms, 'kernels': table, 'kernels_sum_us': sum(r['us'] for r in table)}
+    res = {'metric': 'offline project+estimate throughput', 'value': S * steps / elapsed, 'unit': 'subdomains/s', 'n_gpus': 1,
+           'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * elapsed / steps, 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': 'BASELINE.json config 5{}: 3D diffusion, {}x{}x{} subdomains, SWIPDG p=2 on Kuhn tetrahedra, k_c={} '
+                                  '(n={} DG DoFs, n_rt={} RT0 DoFs per subdomain), Q={}, local basis dim {}'.format(
+                                      '' if config == 'cfg5' else ' (per-rank tile of the 8-GPU run)', *cfg['num_subdomains'],
+                                      cfg['cubes_per_subdomain'], t.n, t.n_rt, Q, N),
+                      'subdomains': S, 'N': N, 'Q': Q, 'parallelism': 'one rank holds every subdomain'},
+           'roofline': roofline,
+           'assemble': {'ms': assemble_ms, 'value': S / (1e-3 * assemble_ms), 'unit': 'subdomains/s',
+                        'host_sampling_and_upload_s': setup_s}}
+    if online:
+        th = np.array([1.0, 0.5])
+        u, info = eng.reduced_solve(th, out, rtol=1e-12, max_iter=20000)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nrep = 8
+        for k in range(nrep):
+            u, info = eng.reduced_solve(np.array([1.0, 0.1 + 0.1 * k]), out, rtol=1e-12, max_iter=20000)
+        torch.cuda.synchronize()
+        t_solve = (time.perf_counter() - t0) / nrep
+        t0 = time.perf_counter()
+        for k in range(nrep):
+            eng.reduced_estimate(th, u, out)
+        torch.cuda.synchronize()
+        t_est = (time.perf_counter() - t0) / nrep
+        res['online'] = {'metric': 'online reduced solves (O1)', 'value': 1.0 / t_solve, 'unit': 'mu-solves/s',
+                         'estimates_per_s': 1.0 / t_est, 'reduced_dim': S * N, 'cg_iterations': info[0], 'relative_residual': info[1],
+                         'solver': 'block-Jacobi PCG on the 7-slot block-sparse reduced system, rtol 1e-12, one parameter per call'}
+    if base is not None:
+        res['cpu_baseline'] = base
+    return res
+
+
+if __name__ == '__main__':
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', default='cfg5', choices=sorted(CONFIGS3D))
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+    print(json.dumps(run(a.config, a.steps, a.warmup, cpu=not a.no_cpu_baseline)), flush=True)

@@ -735,35 +735,59 @@ int dispatch_pg(const GA& a, int batch, int rt, int ct, int nw, hipStream_t st) 
   return -1;
 }
 
-// rhs_red [S][N] = V^T b,  r_fd [S][QN] = sum_e bdiv_e div R_self|_e
+// rhs_red [S][N] = V^T b,  r_fd [S][QN] = sum_e bdiv_e div R_self|_e.  256 threads = G row groups x CW column lanes
+// (CW = 32 for <= 32 columns), four independent partial sums per thread so that the loads of four rows are in flight together.
 __global__ __launch_bounds__(256) void k3_vecs(T3 t, int Q, int N, const double* __restrict__ V, const double* __restrict__ b,
                                                const double* __restrict__ bdiv, const double* __restrict__ Rs,
                                                double* __restrict__ rhs_red, double* __restrict__ r_fd) {
-  __shared__ double red[4][64];
-  const int s = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6, QN = Q * N;
-  double acc = 0.0;
-  if (c < N) {
-    const double* v = V + (long)s * t.n * N + c;
-    const double* bs = b + (long)s * t.n;
-    for (int kr = g; kr < t.n; kr += 4) acc += bs[kr] * v[(long)kr * N];
+  __shared__ double red[256];
+  const int s = blockIdx.x, tid = threadIdx.x, QN = Q * N;
+  {
+    const int CW = N <= 32 ? 32 : 64, G = 256 / CW, c = tid % CW, g = tid / CW;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (c < N) {
+      const double* v = V + (long)s * t.n * N + c;
+      const double* bs = b + (long)s * t.n;
+      int kr = g;
+      for (; kr + 3 * G < t.n; kr += 4 * G) {
+        a0 += bs[kr] * v[(long)kr * N];
+        a1 += bs[kr + G] * v[(long)(kr + G) * N];
+        a2 += bs[kr + 2 * G] * v[(long)(kr + 2 * G) * N];
+        a3 += bs[kr + 3 * G] * v[(long)(kr + 3 * G) * N];
+      }
+      for (; kr < t.n; kr += G) a0 += bs[kr] * v[(long)kr * N];
+    }
+    red[tid] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && c < N) {
+      double acc = 0.0;
+      for (int k = 0; k < G; ++k) acc += red[k * CW + c];
+      rhs_red[(long)s * N + c] = acc;
+    }
+    __syncthreads();
   }
-  red[g][c] = acc;
-  __syncthreads();
-  if (g == 0 && c < N) rhs_red[(long)s * N + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-  __syncthreads();
-  acc = 0.0;
-  if (c < QN) {
-    for (int e = g; e < t.nT; e += 4) {
-      const int ty = t.elem_type[e];
-      double dv = 0.0;
-      for (int f = 0; f < 4; ++f)
-        dv += sgn3(t, s, e, f) * t.divc[ty * 4 + f] * Rs[((long)s * t.nrt + t.elem_rt[e * 4 + f]) * QN + c];
-      acc += bdiv[(long)s * t.nT + e] * dv;
+  {
+    const int CW = QN <= 32 ? 32 : 64, G = 256 / CW, c = tid % CW, g = tid / CW;
+    double acc = 0.0;
+    if (c < QN) {
+      const double* rs = Rs + (long)s * t.nrt * QN + c;
+      for (int e = g; e < t.nT; e += G) {
+        const int ty = t.elem_type[e];
+        const int4 rt = *reinterpret_cast<const int4*>(t.elem_rt + e * 4);
+        const double r0 = rs[(long)rt.x * QN], r1 = rs[(long)rt.y * QN], r2 = rs[(long)rt.z * QN], r3 = rs[(long)rt.w * QN];
+        const double dv = sgn3(t, s, e, 0) * t.divc[ty * 4] * r0 + sgn3(t, s, e, 1) * t.divc[ty * 4 + 1] * r1 +
+                          sgn3(t, s, e, 2) * t.divc[ty * 4 + 2] * r2 + sgn3(t, s, e, 3) * t.divc[ty * 4 + 3] * r3;
+        acc += bdiv[(long)s * t.nT + e] * dv;
+      }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (g == 0 && c < QN) {
+      double a = 0.0;
+      for (int k = 0; k < G; ++k) a += red[k * CW + c];
+      r_fd[(long)s * QN + c] = a;
     }
   }
-  red[g][c] = acc;
-  __syncthreads();
-  if (g == 0 && c < QN) r_fd[(long)s * QN + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
 // per side face: Yb = row of B R_self, Dp = |T| div_f div R_self, Xab_q = A_ab_q^T V at the face
