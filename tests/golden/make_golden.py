@@ -54,7 +54,32 @@ def build(name):
     return p, out
 
 
+def build3d(name):
+    """3D / P2 (config 5) fixture: inputs and the oracle's expected outputs for one of tests/common3d.py's problems."""
+    import common3d as c3
+    p = c3.make_problem(name)
+    d = c3.oracle_of(p)
+    V = c3.make_bases3d(d.S, d.n, p['N'], seed=3)
+    rd = c3.reduce_with_oracle(p, d, V)
+    u = np.stack(rd.solve(p['mu']))
+    rng = np.random.default_rng(5)
+    ur = rng.standard_normal((d.S, p['N']))
+    nc, r, df = rd.local_terms([ur[ii] for ii in range(d.S)], p['mu'])
+    blk = c3.oracle_dense_blocks(p, d, rd, 0)
+    return {'N': p['N'], 'mu': np.array([p['mu']]), 'V': V, 'u_random': ur, 'b': d.b, 'f2': d.f2, 'ceps': d.ceps,
+            'rhs_red': np.stack(rd.rhs), 'u': u, 'eta_nc': nc, 'eta_r': r, 'eta_df': df,
+            'G_nc_0': blk['G_nc'], 'G_bb_0': blk['G_bb'], 'G_rdd_0': blk['G_rdd'], 'r_fd_0': blk['r_fd'], 'G_ab_0': blk['G_ab'],
+            'G_aa_0': blk['G_aa'], 'B_sys_0': blk['B_sys'], 'eta': np.array([rd.estimate([u[ii] for ii in range(d.S)], p['mu'])])}
+
+
+CASES3D = ('aniso_2x2x1', 'q3_2x1x2')
+
+
 if __name__ == '__main__':
+    for name in CASES3D:
+        path = os.path.join(HERE, 'cfg5_' + name + '.npz')
+        np.savez_compressed(path, **build3d(name))
+        print('wrote', path)
     for name in CASES:
         _, out = build(name)
         path = os.path.join(HERE, name + '.npz')

@@ -33,6 +33,30 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert bound.lrbms_version().decode().startswith('lrbms_hip')
 
 
+def test_every_declared_3d_symbol_is_exported_and_bound(lib):
+    """include/lrbms3d_hip.h (config 5: 3D, P2): the same contract as the 2D header."""
+    from pylrbms_amd import _native3d
+    text = open(os.path.join(ROOT, 'include', 'lrbms3d_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    names = sorted(set(re.findall(r'\b(lrbms3_[a-z_0-9]+)\s*\(', text)))
+    assert len(names) >= 16
+    handle = ctypes.CDLL(lib)
+    for name in names:
+        assert hasattr(handle, name), name
+    assert sorted(_native3d.SIGNATURES3) == names
+    _native3d.load_library(lib)
+
+
+def test_3d_product_fails_loudly_without_a_gpu(lib):
+    import torch
+    from pylrbms_amd._native import NativeError
+    from pylrbms_amd._native3d import Native3DContext
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(NativeError):
+        Native3DContext(0)
+
+
 def test_product_fails_loudly_without_a_gpu(lib):
     import torch
     from pylrbms_amd._native import NativeContext, NativeError

@@ -150,3 +150,18 @@ def test_reduced_model_is_consistent_with_the_full_order_model():
     full = Reductor3D(d, [np.eye(d.n) for _ in range(d.S)])
     uf = full.reduce().solve(mu)
     assert np.abs(np.concatenate(uf) - d.solve(mu)).max() < 1e-10
+
+
+@pytest.mark.parametrize('name', ['aniso_2x2x1', 'q3_2x1x2'])
+def test_oracle_reproduces_the_committed_3d_fixtures(name):
+    """tests/golden/cfg5_*.npz (self-generated, tests/golden/make_golden.py: the reference has no 3D counterpart) pin the
+    oracle against silent drift; the HIP path is checked against the same files in tests/test_parity3d_gpu.py."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from make_golden import build3d
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cfg5_' + name + '.npz'))
+    out = build3d(name)
+    for k in gold.files:
+        ref = gold[k]
+        assert np.abs(np.asarray(out[k]) - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1e-300), k

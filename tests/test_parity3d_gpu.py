@@ -85,3 +85,31 @@ def test_reduced_solve_matches_the_oracle(case):
     ref = np.stack(rd.solve(p['mu']))
     assert res <= 1e-13 and it > 0
     assert c3.rel(u.cpu().numpy(), ref) < 1e-10, c3.rel(u.cpu().numpy(), ref)
+
+
+def test_product_reproduces_the_committed_3d_fixtures():
+    """The HIP path on the inputs stored in tests/golden/cfg5_*.npz against the stored expected outputs (generated with the
+    oracle by tests/golden/make_golden.py)."""
+    import os
+    from pylrbms_amd.engine3d import Engine3D, expand_factored
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ('aniso_2x2x1', 'q3_2x1x2'):
+        gold = np.load(os.path.join(here, 'golden', 'cfg5_' + name + '.npz'))
+        p = c3.make_problem(name)
+        eng = Engine3D(p['grid'], p['lambdas'], p['f'], p['lambda_bar'], p['lambda_hat']).assemble()
+        Q, N = eng.Q, int(gold['N'])
+        out = eng.project_and_estimate(eng.ctx.from_numpy(gold['V']))
+        dense = {k: v.cpu().numpy() for k, v in expand_factored(eng, out, Q, N).items()}
+        th = c3.theta_of(p, float(gold['mu'][0]))
+        assert c3.rel(eng.ops['b'].cpu().numpy().ravel(), gold['b']) < TOL
+        assert c3.rel(eng.ops['f2'].cpu().numpy(), gold['f2']) < TOL and c3.rel(eng.ops['ceps'].cpu().numpy(), gold['ceps']) < TOL
+        assert c3.rel(dense['rhs_red'], gold['rhs_red']) < TOL
+        for k in ('G_nc', 'G_bb', 'G_rdd', 'r_fd'):
+            assert c3.rel(dense[k][0], gold[k + '_0']) < TOL, k
+        assert c3.rel(dense['G_ab'][:, 0], gold['G_ab_0']) < TOL and c3.rel(dense['G_aa'][:, :, 0], gold['G_aa_0']) < TOL
+        assert c3.rel(dense['B_sys'][:, 0], gold['B_sys_0']) < TOL
+        eta = eng.reduced_estimate(th, eng.ctx.from_numpy(gold['u_random']), out).cpu().numpy()
+        for got, key in zip(eta, ('eta_nc', 'eta_r', 'eta_df')):
+            assert c3.rel(got, gold[key]) < 1e-10, key
+        u, _ = eng.reduced_solve(th, out, rtol=1e-13)
+        assert c3.rel(u.cpu().numpy(), gold['u']) < 1e-10
