@@ -32,7 +32,7 @@ extern "C" {
 typedef struct lrbms3_ctx lrbms3_ctx;
 
 typedef struct {
-  int32_t n_T, n_rt, ncf, nvs, n_nodes, nb, nbel, nsel;
+  int32_t n_T, n_rt, ncf, nvs, n_nodes, nb, nbel, nsel, nbd;
   int32_t nA, nB, nC, nFs, nFf;                   /* points of the rules: system volume, product volume, estimator volume,
                                                      system face, flux face */
   int32_t o_fs, o_ff, o_c, lam_stride;            /* lambda_q record: volA | 4 x Fs | 4 x Ff | volC */
@@ -48,6 +48,7 @@ typedef struct {
   const int32_t *node_mask, *node_count;          /* [n_nodes] sides a node lies on (bit a); size of its averaging patch */
   const int32_t *side_nodes;                      /* [6][nvs] node at position p of side a (-1 padded) */
   const int32_t *sn_ptr, *sn_dofs;                /* CSR (side, pos) -> the NEIGHBOUR's DoFs at that node: [6 nvs + 1], [...] */
+  const int32_t *dof_bslot;                       /* [n] compact index (0 .. nbd-1) of a DoF on a boundary node, else -1 */
   const int32_t *bnodes, *bnode_sides;            /* [nb] boundary nodes; [nb][3] their (side * nvs + pos) memberships, -1 padded */
   const int32_t *bel_elem, *bel_bnode;            /* [nbel] elements with a boundary node; [nbel][10] boundary-node index per DoF or -1 */
   const int32_t *sel_elem, *sel_sf;               /* [nsel] elements with a side face; [nsel][4] side-face index per face or -1 */
@@ -99,7 +100,8 @@ int lrbms3_assemble_flux(lrbms3_ctx* ctx, int32_t Q, const double* lam, double* 
  *   nc  = u_s^T G_nc u_s + 2 z^T Cn u_s + sum_e z_e^T ebar_e z_e
  *   df  = ur^T G_bb ur + 2 zf^T Yb ur + sum_e zf_e^T Bbb_e zf_e + 2 sum_q theta_q (u_s^T G_ab_q ur + zf^T Xab_q u_s) + sum theta theta u_s^T G_aa u_s
  *   rdd = ur^T G_rdd ur + 2 zf^T Dp ur + sum_e |T| (div zf_e)^2,   rfd = r_fd^T ur + sum_e bdiv_e div zf_e
- * work >= lrbms3_work_size doubles (flux image R_self [S][n_rt][QN] and vertex averages [S][n_nodes][N]). */
+ * work >= lrbms3_work_size doubles (flux image R_self [S][n_rt][QN], vertex averages [S][n_nodes][N], rows of E W_self at
+ * the boundary DoFs [S][nbd][N]). */
 int64_t lrbms3_work_size(lrbms3_ctx* ctx, int32_t Q, int32_t N);
 int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* A_diag, const double* A_cpl,
                             const double* b, const double* ebar, const double* Aaa, const double* Aab, const double* Bbb,

@@ -6,16 +6,16 @@ import numpy as np
 from pylrbms_amd import _native
 from pylrbms_amd._native import NativeError, c_dbl, c_i32, c_i64, c_vp, _P_DBL, _P_I32
 
-_INT_FIELDS = ('n_T', 'n_rt', 'ncf', 'nvs', 'n_nodes', 'nb', 'nbel', 'nsel', 'nA', 'nB', 'nC', 'nFs', 'nFf', 'o_fs', 'o_ff', 'o_c',
+_INT_FIELDS = ('n_T', 'n_rt', 'ncf', 'nvs', 'n_nodes', 'nb', 'nbel', 'nsel', 'nbd', 'nA', 'nB', 'nC', 'nFs', 'nFf', 'o_fs', 'o_ff', 'o_c',
                'lam_stride', 'hat_stride', 'f_stride')
 _I32_TABLES = ('elem_type', 'nb_elem', 'nb_out', 'face_pos', 'tsign', 'elem_rt', 'rt_e0', 'rt_f0', 'rt_e1', 'rt_f1', 'side_elem',
                'side_face', 'side_elem_out', 'side_face_out', 'dof_node', 'node_ptr', 'node_dofs', 'node_mask', 'node_count',
-               'side_nodes', 'sn_ptr', 'sn_dofs', 'bnodes', 'bnode_sides', 'bel_elem', 'bel_bnode', 'sel_elem', 'sel_sf')
+               'side_nodes', 'sn_ptr', 'sn_dofs', 'dof_bslot', 'bnodes', 'bnode_sides', 'bel_elem', 'bel_bnode', 'sel_elem', 'sel_sf')
 _DBL_TABLES = ('divc', 'TV', 'TE', 'TAA', 'TFo', 'TFn', 'TFb', 'TC', 'TCb', 'TPH', 'TM', 'TB', 'TAB', 'WB', 'WC')
 
 
 class MeshDesc3D(ctypes.Structure):
-    _fields_ = ([(k, c_i32) for k in _INT_FIELDS] + [('_pad', c_i32), ('volume', c_dbl), ('kmin', c_dbl)] +
+    _fields_ = ([(k, c_i32) for k in _INT_FIELDS] + [('volume', c_dbl), ('kmin', c_dbl)] +
                 [(k, _P_I32) for k in _I32_TABLES] + [(k, _P_DBL) for k in _DBL_TABLES])
 
 
@@ -115,7 +115,7 @@ class Native3DContext:
         self.t, self.spec, self.S, self.S_ext = t, spec, int(S), int(S_ext)
         d = MeshDesc3D()
         vals = dict(n_T=t.n_T, n_rt=t.n_rt, ncf=t.ncf, nvs=t.nvs, n_nodes=t.n_nodes, nb=t.nb, nbel=len(t.bel_elem),
-                    nsel=len(t.sel_elem), nA=spec.nA, nB=spec.nB, nC=spec.nC, nFs=spec.nFs, nFf=spec.nFf, o_fs=spec.o_fs,
+                    nsel=len(t.sel_elem), nbd=t.nbd, nA=spec.nA, nB=spec.nB, nC=spec.nC, nFs=spec.nFs, nFf=spec.nFf, o_fs=spec.o_fs,
                     o_ff=spec.o_ff, o_c=spec.o_c, lam_stride=spec.lam_stride, hat_stride=spec.hat_stride, f_stride=spec.f_stride)
         for k, v in vals.items():
             setattr(d, k, int(v))

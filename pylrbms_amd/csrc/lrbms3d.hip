@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -23,14 +24,14 @@ namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct T3 {
-  int S, S_ext, nT, n, nrt, ncf, nbf, nvs, nnodes, nb, nbel, nsel;
+  int S, S_ext, nT, n, nrt, ncf, nbf, nvs, nnodes, nb, nbel, nsel, nbd;
   int nA, nB, nC, nFs, nFf, o_fs, o_ff, o_c, lam_stride, hat_stride, f_stride;
   double volume, kmin;
   const int *nbr, *phys;
   const int *elem_type, *nb_elem, *nb_out, *face_pos, *tsign, *elem_rt, *rt_e0, *rt_f0, *rt_e1, *rt_f1;
   const int *side_elem, *side_face, *side_elem_out, *side_face_out;
   const int *dof_node, *node_ptr, *node_dofs, *node_mask, *node_count, *side_nodes, *sn_ptr, *sn_dofs;
-  const int *bnodes, *bnode_sides, *bel_elem, *bel_bnode, *sel_elem, *sel_sf;
+  const int *dof_bslot, *bnodes, *bnode_sides, *bel_elem, *bel_bnode, *sel_elem, *sel_sf;
   const double *divc, *TV, *TE, *TAA, *TFo, *TFn, *TFb, *TC, *TCb, *TPH, *TM, *TB, *TAB, *WB, *WC;
   const double* zeros;   // [64] zeros: target of the loads of padding lanes
 };
@@ -43,6 +44,8 @@ struct lrbms3_ctx {
   T3 t{};
   std::vector<void*> owned;
   std::vector<int32_t> nbr_host;
+  hipStream_t aux[2] = {nullptr, nullptr};          // library-owned streams: the flux chain and the Oswald chain of the pass
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   bool ktime = false;
   struct KTimer { const char* name; hipEvent_t e0, e1; };
   std::vector<KTimer> ktimers;
@@ -302,6 +305,7 @@ struct GA {
   int Q, N;
   const double *V, *A_diag, *A_cpl, *ebar, *Aaa, *Aab, *Bbb, *Rs, *Avg;
   double* out;
+  double* Zb;   // NC: rows of E W_self at the boundary DoFs [S][nbd][N]
 };
 
 constexpr int BK = 16, LD = 64 + 16;
@@ -486,8 +490,10 @@ template <> struct PGT<G_CPL> { static constexpr int MZ = 10, KY = 10; };
 template <> struct PGT<G_AB> { static constexpr int MZ = 10, KY = 4; };
 template <> struct PGT<G_BB> { static constexpr int MZ = 4, KY = 4; };
 
+constexpr int pg_max_threads(int tiles) { return tiles <= 4 ? 1024 : (tiles <= 8 ? 512 : 256); }   // VGPR budget 128 / 256 / 512
+
 template <int KIND, int RT, int CT>
-__global__ __launch_bounds__(256) void k3_pg(GA a) {
+__global__ __launch_bounds__(pg_max_threads(RT * CT)) void k3_pg(GA a) {
   extern __shared__ double lds[];   // [RT * CT][256]
   constexpr int MZ = PGT<KIND>::MZ, KY = PGT<KIND>::KY, KS = (KY + 3) / 4, KR = (MZ + 3) / 4;
   const T3& t = a.t;
@@ -549,6 +555,7 @@ __global__ __launch_bounds__(256) void k3_pg(GA a) {
     double yv[CT][KS];    // B operands of the apply: Y[row cc][col = ct * 16 + li]
     double xop[RT][KR];   // A operands of the Gram product: X[row = 4 r + lk][col = rt * 16 + li]
     double yav[NCK ? CT : 1][NCK ? KS : 1], xav[NCK ? RT : 1][NCK ? KR : 1];   // NC: node averages, subtracted when consumed
+    int bslot[NCK ? KR : 1];                                                    // NC: boundary-DoF slot of row 4 r + lk
   };
   const int last = nitems - 1;
   auto load_idx = [&](int item, Idx& ix) {
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(256) void k3_pg(GA a) {
       long r;
       if (KIND == G_SYS) {
         const int slot = cc / 10, j = cc - slot * 10;
-        lp = Lb + slot * 100 + li * 10 + j;
+        lp = Lb + slot * 100 + (slot == 0 ? j * 10 + li : li * 10 + j);      // the diagonal block is symmetric
         int ee = e;
         if (slot == 1) ee = ix.nb[0];
         if (slot == 2) ee = ix.nb[1];
@@ -611,7 +618,8 @@ __global__ __launch_bounds__(256) void k3_pg(GA a) {
         if (ee < 0) ee = e, lon = false;        // side face: no inner neighbour (the block is zero anyway)
         r = (long)ee * 10 + j;
       } else {
-        lp = Lb + li * KY + cc;
+        // symmetric blocks (E, A_aa, B_bb) are read transposed: 10 consecutive doubles per k index instead of a stride of 80 B
+        lp = (KIND == G_AAA || KIND == G_NC || KIND == G_BB) ? Lb + cc * KY + li : Lb + li * KY + cc;
         if (KIND == G_AAA || KIND == G_NC) r = (long)e * 10 + cc;
         else if (KIND == G_CPL) r = (long)eo * 10 + cc;
         else r = ix.aux[0];
@@ -643,6 +651,7 @@ __global__ __launch_bounds__(256) void k3_pg(GA a) {
         base = ((long)e * 10 + row) * N;
         if (KIND == G_NC) nd = (long)ix.aux[r] * N;
       }
+      if (NCK) o.bslot[NCK ? r : 0] = t.dof_bslot[e * 10 + row];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const int col0 = rt * 16 + li;
@@ -654,16 +663,16 @@ __global__ __launch_bounds__(256) void k3_pg(GA a) {
     }
   };
 
+  // (A register double buffer for the operands themselves was measured and dropped: hipcc re-rotates the loop so that the
+  // MFMAs consume the loads of their own iteration, and the second buffer only costs occupancy.  Overlap comes from the
+  // other waves of the SIMD; the index tables are still fetched one item ahead.)
   Idx ix1, ix2;
-  Ops nxt;
   load_idx(wave, ix1);
-  load_idx(wave + NW, ix2);
-  load_ops(wave, ix1, nxt);
   for (int item = wave; item < nitems; item += NW) {
-    Ops cur = nxt;
-    load_ops(item + NW, ix2, nxt);
+    Ops cur;
+    load_ops(item, ix1, cur);
+    load_idx(item + NW, ix2);
     ix1 = ix2;
-    load_idx(item + 2 * NW, ix2);
     if (NCK) {
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk)
@@ -679,6 +688,14 @@ __global__ __launch_bounds__(256) void k3_pg(GA a) {
       d4 z = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) z = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.lop[kk], cur.yv[ct][kk], z, 0, 0, 0);
+      if (NCK) {      // rows of E W_self at boundary DoFs: the side-node factors Cn are summed from them (k3_side_nc)
+        const int col = ct * 16 + li;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+          const int row = 4 * r + lk;
+          if (row < MZ && col < My && cur.bslot[NCK ? r : 0] >= 0) a.Zb[((long)s * t.nbd + cur.bslot[NCK ? r : 0]) * N + col] = z[r];
+        }
+      }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -723,6 +740,7 @@ __global__ __launch_bounds__(256) void k3_pg(GA a) {
 
 template <int KIND, int RT, int CT>
 void launch_pg(const GA& a, int batch, int nw, hipStream_t st) {
+  if (nw * 64 > pg_max_threads(RT * CT)) nw = pg_max_threads(RT * CT) / 64;
   hipLaunchKernelGGL((k3_pg<KIND, RT, CT>), dim3(batch), dim3(64 * nw), sizeof(double) * RT * CT * 256, st, a);
 }
 
@@ -739,10 +757,10 @@ int dispatch_pg(const GA& a, int batch, int rt, int ct, int nw, hipStream_t st) 
 // (CW = 32 for <= 32 columns), four independent partial sums per thread so that the loads of four rows are in flight together.
 __global__ __launch_bounds__(256) void k3_vecs(T3 t, int Q, int N, const double* __restrict__ V, const double* __restrict__ b,
                                                const double* __restrict__ bdiv, const double* __restrict__ Rs,
-                                               double* __restrict__ rhs_red, double* __restrict__ r_fd) {
+                                               double* __restrict__ rhs_red, double* __restrict__ r_fd, int mode) {
   __shared__ double red[256];
   const int s = blockIdx.x, tid = threadIdx.x, QN = Q * N;
-  {
+  if (mode & 1) {
     const int CW = N <= 32 ? 32 : 64, G = 256 / CW, c = tid % CW, g = tid / CW;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (c < N) {
@@ -766,7 +784,7 @@ __global__ __launch_bounds__(256) void k3_vecs(T3 t, int Q, int N, const double*
     }
     __syncthreads();
   }
-  {
+  if (mode & 2) {
     const int CW = QN <= 32 ? 32 : 64, G = 256 / CW, c = tid % CW, g = tid / CW;
     double acc = 0.0;
     if (c < QN) {
@@ -823,23 +841,14 @@ __global__ __launch_bounds__(64) void k3_side_flux(T3 t, int Q, int N, const dou
   }
 }
 
-// Cn [S][nb][N] = -(P^T E W_self) at the boundary nodes
-__global__ __launch_bounds__(64) void k3_side_nc(T3 t, int N, const double* __restrict__ V, const double* __restrict__ ebar,
-                                                 const double* __restrict__ Avg, double* __restrict__ Cn) {
-  const int bn = blockIdx.x, s = blockIdx.y, c = threadIdx.x;
-  if (c >= N) return;
+// Cn [S][nb][N] = -(P^T E W_self) at the boundary nodes: sum of the rows k3_pg<NC> left in Zb over the DoFs of the node
+__global__ __launch_bounds__(256) void k3_side_nc(T3 t, int N, const double* __restrict__ Zb, double* __restrict__ Cn) {
+  const int s = blockIdx.y, c = threadIdx.x & 63, bn = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= N || bn >= t.nb) return;
   const int node = t.bnodes[bn];
-  const double* Vs = V + (long)s * t.n * N;
-  const double* Av = Avg + (long)s * t.nnodes * N;
+  const double* z = Zb + (long)s * t.nbd * N + c;
   double acc = 0.0;
-  for (int p = t.node_ptr[node]; p < t.node_ptr[node + 1]; ++p) {
-    const int d = t.node_dofs[p], e = d / 10, i = d - e * 10;
-    const double* L = ebar + ((long)s * t.nT + e) * 100 + i * 10;
-    for (int j = 0; j < 10; ++j) {
-      const int d2 = e * 10 + j;
-      acc += L[j] * (Vs[(long)d2 * N + c] - Av[(long)t.dof_node[d2] * N + c]);
-    }
-  }
+  for (int p = t.node_ptr[node]; p < t.node_ptr[node + 1]; ++p) acc += z[(long)t.dof_bslot[t.node_dofs[p]] * N];
   Cn[((long)s * t.nb + bn) * N + c] = -acc;
 }
 
@@ -1250,6 +1259,16 @@ int lrbms3_ctx_create(int device, lrbms3_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return LRBMS_E_HIP;
   lrbms3_ctx* c = new lrbms3_ctx();
   c->device = device;
+  for (int i = 0; i < 2; ++i)
+    if (hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) {
+      delete c;
+      return LRBMS_E_HIP;
+    }
+  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return LRBMS_E_HIP;
+  }
   *out = c;
   return LRBMS_OK;
 }
@@ -1258,6 +1277,11 @@ int lrbms3_ctx_destroy(lrbms3_ctx* ctx) {
   if (!ctx) return LRBMS_E_INVALID;
   (void)hipSetDevice(ctx->device);
   for (void* p : ctx->owned) (void)hipFree(p);
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
+    if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+  }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   for (auto& k : ctx->ktimers) {
     (void)hipEventDestroy(k.e0);
     (void)hipEventDestroy(k.e1);
@@ -1282,7 +1306,7 @@ int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, in
   T3& t = ctx->t;
   t.S = S; t.S_ext = S_ext;
   t.nT = d->n_T; t.n = 10 * d->n_T; t.nrt = d->n_rt; t.ncf = d->ncf; t.nbf = 6 * d->ncf; t.nvs = d->nvs;
-  t.nnodes = d->n_nodes; t.nb = d->nb; t.nbel = d->nbel; t.nsel = d->nsel;
+  t.nnodes = d->n_nodes; t.nb = d->nb; t.nbel = d->nbel; t.nsel = d->nsel; t.nbd = d->nbd;
   t.nA = d->nA; t.nB = d->nB; t.nC = d->nC; t.nFs = d->nFs; t.nFf = d->nFf;
   t.o_fs = d->o_fs; t.o_ff = d->o_ff; t.o_c = d->o_c; t.lam_stride = d->lam_stride; t.hat_stride = d->hat_stride;
   t.f_stride = d->f_stride;
@@ -1296,7 +1320,7 @@ int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, in
   UP(dof_node, n); UP(node_ptr, t.nnodes + 1); UP(node_dofs, n); UP(node_mask, t.nnodes); UP(node_count, t.nnodes);
   UP(side_nodes, 6 * t.nvs); UP(sn_ptr, 6 * t.nvs + 1);
   UP(sn_dofs, d->sn_ptr[6 * t.nvs]);
-  UP(bnodes, t.nb); UP(bnode_sides, t.nb * 3); UP(bel_elem, t.nbel); UP(bel_bnode, t.nbel * 10); UP(sel_elem, t.nsel);
+  UP(dof_bslot, n); UP(bnodes, t.nb); UP(bnode_sides, t.nb * 3); UP(bel_elem, t.nbel); UP(bel_bnode, t.nbel * 10); UP(sel_elem, t.nsel);
   UP(sel_sf, t.nsel * 4);
   UP(divc, 24);
   UP(TV, 6L * t.nA * 100); UP(TE, 6L * t.nB * 100); UP(TAA, 6L * t.nC * 100);
@@ -1361,7 +1385,7 @@ int lrbms3_assemble_flux(lrbms3_ctx* ctx, int32_t Q, const double* lam, double* 
 int64_t lrbms3_work_size(lrbms3_ctx* ctx, int32_t Q, int32_t N) {
   if (!ctx || !ctx->has_mesh) return -1;
   const T3& t = ctx->t;
-  return (int64_t)t.S * t.nrt * Q * N + (int64_t)t.S * t.nnodes * N;
+  return (int64_t)t.S * t.nrt * Q * N + (int64_t)t.S * t.nnodes * N + (int64_t)t.S * t.nbd * N;
 }
 
 int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* A_diag, const double* A_cpl,
@@ -1380,27 +1404,45 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
   ctx->ktime_n = ctx->ktime ? ctx->ktime_n : 0;
   double* Rs = work;
   double* Avg = work + (long)t.S * t.nrt * Q * N;
-  {
-    KScope3 k(ctx, "k3_flux", st);
-    hipLaunchKernelGGL(k3_flux, dim3((t.nrt + t.nbf + 3) / 4, t.S), dim3(256), 0, st, t, Q, N, V, Cf, Rs, Rb);
-  }
-  {
-    KScope3 k(ctx, "k3_node_avg", st);
-    hipLaunchKernelGGL(k3_node_avg, dim3((t.nnodes + 6 * t.nvs + 3) / 4, t.S), dim3(256), 0, st, t, N, V, Avg, As);
-  }
-  GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr};
+  double* Zb = Avg + (long)t.S * t.nnodes * N;
+  // Three independent chains, each on its own stream so that the latency-bound preparation kernels run beside the MFMA kernels:
+  //   caller's stream  B_sys (diagonal + coupling blocks), G_aa, rhs_red         -- need nothing but V and the element blocks
+  //   aux 0            flux image  ->  G_ab, G_bb, G_rdd, r_fd, side-face factors
+  //   aux 1            node averages  ->  G_nc, side-node factors
+  // (while per-kernel timing is on, everything runs on the caller's stream: overlapping kernels would stretch each other's
+  // event intervals)
+  hipStream_t sf = ctx->ktime ? st : ctx->aux[0], sn = ctx->ktime ? st : ctx->aux[1];
+  HIP3(ctx, hipEventRecord(ctx->ev_fork, st));
+  HIP3(ctx, hipStreamWaitEvent(sf, ctx->ev_fork, 0));
+  HIP3(ctx, hipStreamWaitEvent(sn, ctx->ev_fork, 0));
+  GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr, Zb};
   const int tn = (N + 15) / 16, tq = (Q * N + 15) / 16;
-  const int nw = 4;
+  static const int nw_env = getenv("LRBMS3_NW") ? atoi(getenv("LRBMS3_NW")) : 0;   // experiment knob: waves per workgroup
+  const int nw = nw_env > 0 ? nw_env : 4;
+  const int nw_s = nw_env > 0 ? nw_env : 8;      // kernels with one workgroup per subdomain only: more waves each
   int bad = 0;
+  {
+    KScope3 k(ctx, "k3_flux", sf);
+    hipLaunchKernelGGL(k3_flux, dim3((t.nrt + t.nbf + 3) / 4, t.S), dim3(256), 0, sf, t, Q, N, V, Cf, Rs, Rb);
+  }
+  {
+    KScope3 k(ctx, "k3_node_avg", sn);
+    hipLaunchKernelGGL(k3_node_avg, dim3((t.nnodes + 6 * t.nvs + 3) / 4, t.S), dim3(256), 0, sn, t, N, V, Avg, As);
+  }
   {
     KScope3 k(ctx, "k3_pg<SYS>", st);
     a.out = B_sys;
     bad |= dispatch_pg<G_SYS>(a, Q * t.S, tn, tn, nw, st);
   }
   {
-    KScope3 k(ctx, "k3_pg<CPL>", st);
-    a.out = B_sys;
-    bad |= dispatch_pg<G_CPL>(a, Q * t.S * 6, tn, tn, nw, st);
+    KScope3 k(ctx, "k3_pg<AB>", sf);
+    a.out = G_ab;
+    bad |= dispatch_pg<G_AB>(a, Q * t.S, tn, tq, nw, sf);
+  }
+  {
+    KScope3 k(ctx, "k3_pg<NC>", sn);
+    a.out = G_nc;
+    bad |= dispatch_pg<G_NC>(a, t.S, tn, tn, nw_s, sn);
   }
   {
     KScope3 k(ctx, "k3_pg<AAA>", st);
@@ -1408,38 +1450,41 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
     bad |= dispatch_pg<G_AAA>(a, Q * Q * t.S, tn, tn, nw, st);
   }
   {
-    KScope3 k(ctx, "k3_pg<NC>", st);
-    a.out = G_nc;
-    bad |= dispatch_pg<G_NC>(a, t.S, tn, tn, nw, st);
-  }
-  {
-    KScope3 k(ctx, "k3_pg<AB>", st);
-    a.out = G_ab;
-    bad |= dispatch_pg<G_AB>(a, Q * t.S, tn, tq, nw, st);
-  }
-  {
-    KScope3 k(ctx, "k3_pg<BB>", st);
+    KScope3 k(ctx, "k3_pg<BB>", sf);
     a.out = G_bb;
-    bad |= dispatch_pg<G_BB>(a, t.S, tq, tq, nw, st);
+    bad |= dispatch_pg<G_BB>(a, t.S, tq, tq, nw_s, sf);
+  }
+  {
+    KScope3 k(ctx, "k3_side_nc", sn);
+    hipLaunchKernelGGL(k3_side_nc, dim3((t.nb + 3) / 4, t.S), dim3(256), 0, sn, t, N, Zb, Cn);
+  }
+  {
+    KScope3 k(ctx, "k3_pg<CPL>", st);
+    a.out = B_sys;
+    bad |= dispatch_pg<G_CPL>(a, Q * t.S * 6, tn, tn, nw, st);
   }
   if (bad) return fail3(ctx, LRBMS_E_INVALID, "project_estimate: unsupported tile shape");
   {
-    KScope3 k(ctx, "k3_gram<RDD>", st);
+    KScope3 k(ctx, "k3_gram<RDD>", sf);
     a.out = G_rdd;
-    hipLaunchKernelGGL(k3_gram<G_RDD>, dim3(t.S), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k3_gram<G_RDD>, dim3(t.S), dim3(256), 0, sf, a);
   }
   {
-    KScope3 k(ctx, "k3_vecs", st);
-    hipLaunchKernelGGL(k3_vecs, dim3(t.S), dim3(256), 0, st, t, Q, N, V, b, bdiv, Rs, rhs_red, r_fd);
+    KScope3 k(ctx, "k3_vecs<rhs>", st);
+    hipLaunchKernelGGL(k3_vecs, dim3(t.S), dim3(256), 0, st, t, Q, N, V, b, bdiv, Rs, rhs_red, r_fd, 1);
   }
   {
-    KScope3 k(ctx, "k3_side_flux", st);
-    hipLaunchKernelGGL(k3_side_flux, dim3(t.nbf, t.S), dim3(64), 0, st, t, Q, N, V, Aab, Bbb, Rs, Yb, Dp, Xab);
+    KScope3 k(ctx, "k3_side_flux", sf);
+    hipLaunchKernelGGL(k3_side_flux, dim3(t.nbf, t.S), dim3(64), 0, sf, t, Q, N, V, Aab, Bbb, Rs, Yb, Dp, Xab);
   }
   {
-    KScope3 k(ctx, "k3_side_nc", st);
-    hipLaunchKernelGGL(k3_side_nc, dim3(t.nb, t.S), dim3(64), 0, st, t, N, V, ebar, Avg, Cn);
+    KScope3 k(ctx, "k3_vecs<rfd>", sf);
+    hipLaunchKernelGGL(k3_vecs, dim3(t.S), dim3(256), 0, sf, t, Q, N, V, b, bdiv, Rs, rhs_red, r_fd, 2);
   }
+  HIP3(ctx, hipEventRecord(ctx->ev_join[0], sf));
+  HIP3(ctx, hipEventRecord(ctx->ev_join[1], sn));
+  HIP3(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0));
+  HIP3(ctx, hipStreamWaitEvent(st, ctx->ev_join[1], 0));
   LAUNCH3(ctx);
   return LRBMS_OK;
 }

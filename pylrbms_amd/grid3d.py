@@ -321,6 +321,10 @@ class SubdomainTemplate3D:
         dofb = self.node_bnode[self.dof_node].reshape(nT, NLOC)
         bel = np.nonzero(np.any(dofb >= 0, axis=1))[0]
         self.bel_elem, self.bel_bnode = bel.astype(np.int32), np.ascontiguousarray(dofb[bel])
+        # compact numbering of the DoFs that sit on a boundary node (rows of E W_self the side-node factors are summed from)
+        onb = dofb.reshape(-1) >= 0
+        self.nbd = int(onb.sum())
+        self.dof_bslot = np.where(onb, np.cumsum(onb) - 1, -1).astype(np.int32)
         sf = np.where(nb_elem < 0, (-(nb_elem + 1)) * ncf + face_pos, -1)
         sel = np.nonzero(np.any(sf >= 0, axis=1))[0]
         self.sel_elem, self.sel_sf = sel.astype(np.int32), np.ascontiguousarray(sf[sel].astype(np.int32))
