@@ -492,16 +492,38 @@ template <> struct PGT<G_BB> { static constexpr int MZ = 4, KY = 4; };
 
 constexpr int pg_max_threads(int tiles) { return tiles <= 4 ? 1024 : (tiles <= 8 ? 512 : 256); }   // VGPR budget 128 / 256 / 512
 
-template <int KIND, int RT, int CT>
-__global__ __launch_bounds__(pg_max_threads(RT * CT)) void k3_pg(GA a) {
+__device__ inline double ld8(const double* base, unsigned byte_off) {   // uniform base + 32-bit lane offset: no 64-bit VALU
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// On this chip the f64 MFMA stream of one wave and the VALU work of the other waves of the SIMD do not overlap (DESIGN.md
+// section 5.1), so the address arithmetic per item is kept minimal: every operand address is (uniform base of the item) +
+// (32-bit lane offset), and the lane offsets are (element term: one multiply per neighbour slot and item) + (lane constant
+// computed once in front of the loop).  The K index of the apply is scheduled so that a k-step reads ONE neighbour slot:
+// rows j = 0..3 and 4..7 of every slot as full steps, the rows 8, 9 of two slots paired into one step.
+__device__ inline double2 ld16(const double* base, unsigned byte_off) {
+  return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// WIDE (even tile counts and even N): lane li owns the adjacent output columns li * CT + ct (rows li * RT + rt) instead of
+// ct * 16 + li, and the two full k-steps of a slot read the rows j = 2 lk and 2 lk + 1, so a lane's operands of two tiles / two
+// k-steps are 16 contiguous bytes: half as many vector-memory instructions per item.  The address unit of a CU serves its four
+// SIMDs at a fixed number of cycles per instruction, and with 45 eight-byte loads per 38 MFMAs it, not the matrix pipe, set
+// the pace.
+template <int KIND, int RT, int CT, bool WIDE>
+__global__ __launch_bounds__(pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1))) void k3_pg(GA a) {
   extern __shared__ double lds[];   // [RT * CT][256]
-  constexpr int MZ = PGT<KIND>::MZ, KY = PGT<KIND>::KY, KS = (KY + 3) / 4, KR = (MZ + 3) / 4;
+  constexpr int MZ = PGT<KIND>::MZ, KY = PGT<KIND>::KY, KR = (MZ + 3) / 4;
+  constexpr int NG = KY == 50 ? 5 : 1;                       // neighbour slots whose rows the apply reads
+  constexpr int KS = KY == 4 ? 1 : 2 * NG + (NG + 1) / 2;    // k-steps: 13 for SYS, 3 for the 10-row kinds, 1 for the 4-row kinds
+  constexpr bool NCK = KIND == G_NC, FACEK = KIND == G_AB || KIND == G_BB;
   const T3& t = a.t;
   const int N = a.N, Q = a.Q, QN = Q * N;
   const int b = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NW = blockDim.x >> 6;
-  int s, q = 0, Mx, My, t2 = 0, side = 0, nitems = t.nT;
+  int s, q = 0, q2 = 0, Mx, My, t2 = 0, side = 0, nitems = t.nT;
   double* out;
   if (KIND == G_SYS) {
     q = b / t.S; s = b - q * t.S; Mx = My = N;
@@ -512,9 +534,12 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT)) void k3_pg(GA a) {
     q = qs / t.S; s = qs - q * t.S; Mx = My = N; nitems = t.ncf;
     t2 = t.nbr[s * 7 + side_slot(side)];
     out = a.out + (((long)q * t.S + s) * 7 + side_slot(side)) * N * N;
-  } else if (KIND == G_AAA) {
-    s = b % t.S; Mx = My = N;
-    out = a.out + (long)b * N * N;
+  } else if (KIND == G_AAA) {       // one workgroup per pair q <= q2 (row-major); the block (q2, q) is the transpose
+    int p = b / t.S;
+    s = b - p * t.S; Mx = My = N;
+    while (p >= Q - q) p -= Q - q, ++q;
+    q2 = q + p;
+    out = a.out + (((long)q * Q + q2) * t.S + s) * N * N;
   } else if (KIND == G_NC) {
     s = b; Mx = My = N;
     out = a.out + (long)b * N * N;
@@ -530,8 +555,78 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT)) void k3_pg(GA a) {
     return;
   }
   const double* Vs = a.V + (long)s * t.n * N;
+  const double* Yb = KIND == G_CPL ? a.V + (long)t2 * t.n * N : Vs;
   const double* Av = a.Avg + (long)s * t.nnodes * N;
   const double* Rss = a.Rs + (long)s * t.nrt * QN;
+  const double* Lall;               // element blocks of this (subdomain, operator): item e at Lall + e * LSTRIDE
+  constexpr int LSTRIDE = KIND == G_SYS ? 500 : (KIND == G_AB ? 40 : (KIND == G_BB ? 16 : 100));
+  if (KIND == G_SYS) Lall = a.A_diag + ((long)q * t.S + s) * t.nT * 500;
+  if (KIND == G_AAA) Lall = a.Aaa + (((long)q * Q + q2) * t.S + s) * t.nT * 100;
+  if (KIND == G_NC) Lall = a.ebar + (long)s * t.nT * 100;
+  if (KIND == G_AB) Lall = a.Aab + ((long)q * t.S + s) * t.nT * 40;
+  if (KIND == G_BB) Lall = a.Bbb + (long)s * t.nT * 16;
+  if (KIND == G_CPL) Lall = a.A_cpl + (((long)q * t.S + s) * 6 + side) * t.ncf * 100;
+
+  // ---- lane constants
+  const unsigned rowb = (unsigned)N * 8u, erow = 10u * rowb;            // bytes per DoF row / per element of the basis slab
+  const int lic = li < MZ ? li : MZ - 1;
+  unsigned yc[KS][CT];        // Y: (row j of the step) * rowb + column
+  unsigned lc[KS];            // L: offset inside the item's block(s)
+  int sA[KS];                 // neighbour slot this lane reads in step k (lane constant)
+  bool pad[KS];               // lane is K padding in this step
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    int g, j;
+    bool pd = false;
+    if (KY == 4) {
+      g = 0; j = lk;
+    } else if (k < 2 * NG) {
+      g = k >> 1; j = WIDE ? 2 * lk + (k & 1) : 4 * (k & 1) + lk;
+    } else {                   // rows 8, 9 of slot gA (lanes lk < 2) and of slot gA + 1 (lanes lk >= 2)
+      const int gA = 2 * (k - 2 * NG);
+      g = lk < 2 ? gA : gA + 1;
+      j = 8 + (lk & 1);
+      if (g >= NG) g = gA, pd = true;
+    }
+    sA[k] = g; pad[k] = pd;
+    if (KIND == G_SYS) lc[k] = 8u * (g * 100 + lic * 10 + j);
+    else if (KIND == G_AB) lc[k] = 8u * (lic * 4 + j);
+    else if (KIND == G_BB) lc[k] = 8u * (j * 4 + lic);                                        // symmetric: read transposed
+    else lc[k] = 8u * (lic * 10 + j);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      int col;
+      if (WIDE) {              // pairs of columns stay inside the (even) row: the last pair is repeated for the padding lanes
+        const int c0 = li * CT + (ct & ~1);
+        col = (c0 + 1 < My ? c0 : My - 2) + (ct & 1);
+      } else {
+        const int col0 = ct * 16 + li;
+        col = col0 < My ? col0 : My - 1;
+      }
+      yc[k][ct] = (FACEK ? 0u : (unsigned)j * rowb) + 8u * col;
+    }
+  }
+  unsigned xc[KR][RT];
+  bool xin[KR];
+#pragma unroll
+  for (int r = 0; r < KR; ++r) {
+    const int row0 = 4 * r + lk;
+    xin[r] = row0 < MZ;
+    const int row = xin[r] ? row0 : MZ - 1;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      int col;
+      if (WIDE) {
+        const int c0 = li * RT + (rt & ~1);
+        col = (c0 + 1 < Mx ? c0 : Mx - 2) + (rt & 1);
+      } else {
+        const int col0 = rt * 16 + li;
+        col = col0 < Mx ? col0 : Mx - 1;
+      }
+      xc[r][rt] = (KIND == G_BB ? 0u : (unsigned)row * rowb) + 8u * col;
+    }
+  }
+  const double* zero = t.zeros + lane;
 
   d4 acc[RT][CT];
 #pragma unroll
@@ -539,23 +634,11 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT)) void k3_pg(GA a) {
 #pragma unroll
     for (int j = 0; j < CT; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  // Software pipeline, two stages ahead: the index tables of item i + 2 (element neighbours, RT0 / node numbers) and all
-  // operands of item i + 1 are in flight while the MFMAs of item i run.  Every load is unconditional (addresses clamped into
-  // the arrays, padding lanes zeroed by selects where it matters: rows >= MZ of L and X, k >= KY of L), so the loop body is
-  // branch-free and the loads issue back to back.  Padded COLUMNS may hold finite garbage: it only reaches accumulator rows /
-  // columns that are never stored.
+  // index tables of an item (fetched one item ahead): element, its neighbours (SYS), node / RT0 numbers of this lane's rows
   struct Idx {
     int e, eo;
-    int nb[4];       // SYS: inner neighbour elements
-    int aux[KR];     // NC: Lagrange node of row 4 r + lk;  AB / BB: RT0 DoF of face lk
-  };
-  constexpr bool NCK = KIND == G_NC;
-  struct Ops {
-    double lop[KS];       // A operands of the apply: L[i = li][cc = 4 kk + lk]
-    double yv[CT][KS];    // B operands of the apply: Y[row cc][col = ct * 16 + li]
-    double xop[RT][KR];   // A operands of the Gram product: X[row = 4 r + lk][col = rt * 16 + li]
-    double yav[NCK ? CT : 1][NCK ? KS : 1], xav[NCK ? RT : 1][NCK ? KR : 1];   // NC: node averages, subtracted when consumed
-    int bslot[NCK ? KR : 1];                                                    // NC: boundary-DoF slot of row 4 r + lk
+    int nb[4];
+    int aux[KR], auy[KR];
   };
   const int last = nitems - 1;
   auto load_idx = [&](int item, Idx& ix) {
@@ -574,132 +657,142 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT)) void k3_pg(GA a) {
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
       ix.aux[r] = 0;
-      if (KIND == G_NC) {
+      ix.auy[r] = 0;
+      if (NCK) {
         const int row = 4 * r + lk;
-        ix.aux[r] = t.dof_node[item * 10 + (row < 10 ? row : 9)];
+        ix.aux[r] = t.dof_node[item * 10 + (row < 10 ? row : 9)];                      // node of X row 4 r + lk
+        const int j = r < 2 ? (WIDE ? 2 * lk + r : 4 * r + lk) : 8 + (lk & 1);          // node of the Y row of k-step r
+        ix.auy[r] = t.dof_node[item * 10 + j];
       }
     }
-    if (KIND == G_AB || KIND == G_BB) ix.aux[0] = t.elem_rt[item * 4 + lk];
+    if (FACEK) ix.aux[0] = t.elem_rt[item * 4 + lk];
   };
-  // no arithmetic on freshly loaded values here (a select or a subtraction would make the compiler wait for the load inside
-  // this iteration): padding lanes load from t.zeros instead, chosen by ADDRESS
-  auto load_ops = [&](int item, const Idx& ix, Ops& o) {
-    item = item < last ? item : last;
-    const bool on = KIND != G_CPL || ix.e >= 0;
-    const int e = on ? ix.e : 0, eo = on ? ix.eo : 0;
-    const double* Lb;
-    const double* Yb = Vs;
-    if (KIND == G_SYS) Lb = a.A_diag + ((((long)q * t.S + s) * t.nT + e) * 5) * 100;
-    if (KIND == G_AAA) Lb = a.Aaa + ((long)b * t.nT + e) * 100;
-    if (KIND == G_NC) Lb = a.ebar + ((long)s * t.nT + e) * 100;
-    if (KIND == G_AB) Lb = a.Aab + (((long)q * t.S + s) * t.nT + e) * 40;
-    if (KIND == G_BB) Lb = a.Bbb + ((long)s * t.nT + e) * 16;
-    if (KIND == G_CPL) {
-      Lb = a.A_cpl + ((((long)q * t.S + s) * 6 + side) * t.ncf + item) * 100;
-      Yb = a.V + (long)t2 * t.n * N;
-    }
-    const double* zero = t.zeros + lane;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      const int cc0 = 4 * kk + lk;
-      const bool kin = cc0 < KY;
-      const int cc = kin ? cc0 : KY - 1;
-      const double* lp;
-      bool lon = kin && li < MZ && on;
-      long r;
+
+  Idx ix1, ix2;
+  load_idx(wave, ix1);
+  for (int item0 = wave; item0 < nitems; item0 += NW) {
+    const int item = item0 < last ? item0 : last;
+    // ---- operand loads of the item, all issued before the first MFMA (no arithmetic on loaded values here)
+    const bool on = KIND != G_CPL || ix1.e >= 0;
+    const int e = on ? ix1.e : 0;
+    const double* Lb = Lall + (long)item * LSTRIDE;
+    unsigned eb[NG];                          // byte offset of the rows of the slot's element
+    if (FACEK) {
+      eb[0] = (unsigned)ix1.aux[0] * ((unsigned)QN * 8u);
+    } else if (KIND == G_CPL) {
+      eb[0] = (unsigned)(on ? ix1.eo : 0) * erow;
+    } else {
+      eb[0] = (unsigned)e * erow;
       if (KIND == G_SYS) {
-        const int slot = cc / 10, j = cc - slot * 10;
-        lp = Lb + slot * 100 + (slot == 0 ? j * 10 + li : li * 10 + j);      // the diagonal block is symmetric
-        int ee = e;
-        if (slot == 1) ee = ix.nb[0];
-        if (slot == 2) ee = ix.nb[1];
-        if (slot == 3) ee = ix.nb[2];
-        if (slot == 4) ee = ix.nb[3];
-        if (ee < 0) ee = e, lon = false;        // side face: no inner neighbour (the block is zero anyway)
-        r = (long)ee * 10 + j;
-      } else {
-        // symmetric blocks (E, A_aa, B_bb) are read transposed: 10 consecutive doubles per k index instead of a stride of 80 B
-        lp = (KIND == G_AAA || KIND == G_NC || KIND == G_BB) ? Lb + cc * KY + li : Lb + li * KY + cc;
-        if (KIND == G_AAA || KIND == G_NC) r = (long)e * 10 + cc;
-        else if (KIND == G_CPL) r = (long)eo * 10 + cc;
-        else r = ix.aux[0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+          const int ee = ix1.nb[g - 1];
+          eb[g] = (unsigned)(ee < 0 ? e : ee) * erow;     // side face: no inner neighbour, its block is zero
+        }
       }
-      o.lop[kk] = *(lon ? lp : zero);
-      long nd = 0;
-      if (KIND == G_NC) nd = (long)ix.aux[kk] * N;
+    }
+    const unsigned ex = (unsigned)e * erow;
+    double lop[KS], yv[CT][KS], xop[RT][KR];
+    int dnode[NCK ? KS : 1];
+    if (NCK) {
+#pragma unroll
+      for (int k = 0; k < KS; ++k) dnode[NCK ? k : 0] = ix1.auy[NCK ? k : 0];
+    }
+    double yav[NCK ? CT : 1][NCK ? KS : 1], xav[NCK ? RT : 1][NCK ? KR : 1];
+    int bslot[NCK ? KR : 1];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      unsigned eo = eb[0];
+      if (NG > 1) {
+        if (k < 2 * NG) eo = eb[k >> 1];
+        else eo = (lk < 2 || 2 * (k - 2 * NG) + 1 >= NG) ? eb[2 * (k - 2 * NG)] : eb[(2 * (k - 2 * NG) + 1) % NG];
+      }
+      if (WIDE && KY != 4 && k < 2 * NG) {          // full steps: rows j = 2 lk, 2 lk + 1 of the slot in one 16-byte load
+        if ((k & 1) == 0) {
+          const double2 v = on ? ld16(Lb, lc[k]) : *reinterpret_cast<const double2*>(t.zeros);
+          lop[k] = v.x;
+          lop[k + 1 < KS ? k + 1 : k] = v.y;
+        }
+      } else {
+        lop[k] = (pad[k] || !on) ? *zero : ld8(Lb, lc[k]);
+      }
+      unsigned nd = 0;
+      if (NCK) nd = (unsigned)dnode[NCK ? k : 0] * rowb;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const int col0 = ct * 16 + li;
-        const int col = col0 < My ? col0 : My - 1;
-        if (KIND == G_AB || KIND == G_BB) {
-          o.yv[ct][kk] = Rss[r * QN + col];
+        if (WIDE) {
+          if ((ct & 1) == 0) {
+            const double2 v = ld16(FACEK ? Rss : Yb, eo + yc[k][ct]);
+            yv[ct][k] = v.x;
+            yv[ct + 1 < CT ? ct + 1 : ct][k] = v.y;
+            if (NCK) {
+              const double2 w = ld16(Av, nd + 8u * (yc[k][ct] % rowb / 8u));
+              yav[NCK ? ct : 0][NCK ? k : 0] = w.x;
+              yav[NCK ? (ct + 1 < CT ? ct + 1 : ct) : 0][NCK ? k : 0] = w.y;
+            }
+          }
         } else {
-          o.yv[ct][kk] = Yb[r * N + col];
-          if (NCK) o.yav[NCK ? ct : 0][NCK ? kk : 0] = Av[nd + col];
+          yv[ct][k] = ld8(FACEK ? Rss : Yb, eo + yc[k][ct]);
+          if (NCK) yav[NCK ? ct : 0][NCK ? k : 0] = ld8(Av, nd + 8u * (yc[k][ct] % rowb / 8u));
         }
       }
     }
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
-      const int row0 = 4 * r + lk;
-      const bool rin = row0 < MZ;
-      const int row = rin ? row0 : MZ - 1;
-      long base, nd = 0;
-      if (KIND == G_BB) {
-        base = (long)ix.aux[0] * QN;        // KR == 1: row == lk
-      } else {
-        base = ((long)e * 10 + row) * N;
-        if (KIND == G_NC) nd = (long)ix.aux[r] * N;
+      unsigned nd = 0;
+      if (NCK) {
+        nd = (unsigned)ix1.aux[r] * rowb;
+        bslot[NCK ? r : 0] = t.dof_bslot[e * 10 + (4 * r + lk < MZ ? 4 * r + lk : MZ - 1)];
       }
-      if (NCK) o.bslot[NCK ? r : 0] = t.dof_bslot[e * 10 + row];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const int col0 = rt * 16 + li;
-        const int col = col0 < Mx ? col0 : Mx - 1;
-        const double* xp = (KIND == G_BB ? Rss : Vs) + base + col;
-        o.xop[rt][r] = *(rin ? xp : zero);
-        if (NCK) o.xav[NCK ? rt : 0][NCK ? r : 0] = *(rin ? Av + nd + col : zero);
+        const unsigned off = (KIND == G_BB ? eb[0] : ex) + xc[r][rt];
+        if (WIDE) {
+          if ((rt & 1) == 0) {
+            const double2 v = xin[r] ? ld16(KIND == G_BB ? Rss : Vs, off) : *reinterpret_cast<const double2*>(t.zeros);
+            xop[rt][r] = v.x;
+            xop[rt + 1 < RT ? rt + 1 : rt][r] = v.y;
+            if (NCK) {
+              const double2 w = xin[r] ? ld16(Av, nd + 8u * (xc[r][rt] % rowb / 8u)) : *reinterpret_cast<const double2*>(t.zeros);
+              xav[NCK ? rt : 0][NCK ? r : 0] = w.x;
+              xav[NCK ? (rt + 1 < RT ? rt + 1 : rt) : 0][NCK ? r : 0] = w.y;
+            }
+          }
+        } else {
+          xop[rt][r] = xin[r] ? ld8(KIND == G_BB ? Rss : Vs, off) : *zero;
+          if (NCK) xav[NCK ? rt : 0][NCK ? r : 0] = xin[r] ? ld8(Av, nd + 8u * (xc[r][rt] % rowb / 8u)) : *zero;
+        }
       }
     }
-  };
-
-  // (A register double buffer for the operands themselves was measured and dropped: hipcc re-rotates the loop so that the
-  // MFMAs consume the loads of their own iteration, and the second buffer only costs occupancy.  Overlap comes from the
-  // other waves of the SIMD; the index tables are still fetched one item ahead.)
-  Idx ix1, ix2;
-  load_idx(wave, ix1);
-  for (int item = wave; item < nitems; item += NW) {
-    Ops cur;
-    load_ops(item, ix1, cur);
-    load_idx(item + NW, ix2);
+    load_idx(item0 + NW, ix2);
     ix1 = ix2;
     if (NCK) {
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk)
+      for (int k = 0; k < KS; ++k)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) cur.yv[ct][kk] -= cur.yav[NCK ? ct : 0][NCK ? kk : 0];
+        for (int ct = 0; ct < CT; ++ct) yv[ct][k] -= yav[NCK ? ct : 0][NCK ? k : 0];
 #pragma unroll
       for (int r = 0; r < KR; ++r)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) cur.xop[rt][r] -= cur.xav[NCK ? rt : 0][NCK ? r : 0];
+        for (int rt = 0; rt < RT; ++rt) xop[rt][r] -= xav[NCK ? rt : 0][NCK ? r : 0];
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       d4 z = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) z = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.lop[kk], cur.yv[ct][kk], z, 0, 0, 0);
+      for (int k = 0; k < KS; ++k) z = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[k], yv[ct][k], z, 0, 0, 0);
       if (NCK) {      // rows of E W_self at boundary DoFs: the side-node factors Cn are summed from them (k3_side_nc)
-        const int col = ct * 16 + li;
+        const int col = WIDE ? li * CT + ct : ct * 16 + li;
 #pragma unroll
         for (int r = 0; r < KR; ++r) {
           const int row = 4 * r + lk;
-          if (row < MZ && col < My && cur.bslot[NCK ? r : 0] >= 0) a.Zb[((long)s * t.nbd + cur.bslot[NCK ? r : 0]) * N + col] = z[r];
+          if (row < MZ && col < My && bslot[NCK ? r : 0] >= 0) a.Zb[((long)s * t.nbd + bslot[NCK ? r : 0]) * N + col] = z[r];
         }
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < KR; ++r) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.xop[rt][r], z[r], acc[rt][ct], 0, 0, 0);
+        for (int r = 0; r < KR; ++r) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[rt][r], z[r], acc[rt][ct], 0, 0, 0);
     }
   }
   // ---- fixed-order sum over the waves: acc_0 + (acc_1 + (... + acc_{NW-1}))
@@ -724,15 +817,20 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT)) void k3_pg(GA a) {
     }
   }
   if (wave == 0) {
+    double* mirror = nullptr;       // AAA: block (q2, q) = transpose of block (q, q2)
+    if (KIND == G_AAA && q != q2) mirror = a.out + (((long)q2 * Q + q) * t.S + s) * N * N;
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
       for (int j = 0; j < CT; ++j) {
-        const int col = j * 16 + li;
+        const int col = WIDE ? li * CT + j : j * 16 + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = i * 16 + lk + 4 * r;
-          if (row < Mx && col < My) out[(long)row * My + col] = acc[i][j][r];
+          const int row = WIDE ? (lk + 4 * r) * RT + i : i * 16 + lk + 4 * r;
+          if (row < Mx && col < My) {
+            out[(long)row * My + col] = acc[i][j][r];
+            if (mirror) mirror[(long)col * My + row] = acc[i][j][r];
+          }
         }
       }
   }
@@ -740,15 +838,25 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT)) void k3_pg(GA a) {
 
 template <int KIND, int RT, int CT>
 void launch_pg(const GA& a, int batch, int nw, hipStream_t st) {
-  if (nw * 64 > pg_max_threads(RT * CT)) nw = pg_max_threads(RT * CT) / 64;
-  hipLaunchKernelGGL((k3_pg<KIND, RT, CT>), dim3(batch), dim3(64 * nw), sizeof(double) * RT * CT * 256, st, a);
+  constexpr int maxt = pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1));     // NC also holds the node averages of its operands
+  if (nw * 64 > maxt) nw = maxt / 64;
+  constexpr bool EVEN = RT % 2 == 0 && CT % 2 == 0;
+  if (EVEN && a.N % 2 == 0)
+    hipLaunchKernelGGL((k3_pg<KIND, RT, CT, EVEN>), dim3(batch), dim3(64 * nw), sizeof(double) * RT * CT * 256, st, a);
+  else
+    hipLaunchKernelGGL((k3_pg<KIND, RT, CT, false>), dim3(batch), dim3(64 * nw), sizeof(double) * RT * CT * 256, st, a);
 }
 
+// tile shapes: square (rt == ct) for everything but AB, where ct = tiles of Q N >= rt = tiles of N
 template <int KIND>
 int dispatch_pg(const GA& a, int batch, int rt, int ct, int nw, hipStream_t st) {
-#define PGCASE(R, C) if (rt == R && ct == C) { launch_pg<KIND, R, C>(a, batch, nw, st); return 0; }
-  PGCASE(1, 1) PGCASE(2, 2) PGCASE(3, 3) PGCASE(4, 4)
-  if (KIND == G_AB) { PGCASE(1, 2) PGCASE(1, 3) PGCASE(1, 4) PGCASE(2, 3) PGCASE(2, 4) PGCASE(3, 4) }
+#define PGCASE(R, C)                                 \
+  if (rt == R && ct == C) {                          \
+    launch_pg<KIND, R, C>(a, batch, nw, st);         \
+    return 0;                                        \
+  }
+  if constexpr (KIND != G_AB) { PGCASE(1, 1) PGCASE(2, 2) PGCASE(3, 3) PGCASE(4, 4) }
+  if constexpr (KIND == G_AB) { PGCASE(1, 1) PGCASE(1, 2) PGCASE(1, 3) PGCASE(1, 4) PGCASE(2, 2) PGCASE(2, 3) PGCASE(2, 4) PGCASE(3, 3) PGCASE(3, 4) PGCASE(4, 4) }
 #undef PGCASE
   return -1;
 }
@@ -1429,6 +1537,7 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
     KScope3 k(ctx, "k3_node_avg", sn);
     hipLaunchKernelGGL(k3_node_avg, dim3((t.nnodes + 6 * t.nvs + 3) / 4, t.S), dim3(256), 0, sn, t, N, V, Avg, As);
   }
+  const int npair = Q * (Q + 1) / 2;       // A_aa: pairs q <= q', the transposed blocks are written from the same accumulators
   {
     KScope3 k(ctx, "k3_pg<SYS>", st);
     a.out = B_sys;
@@ -1447,7 +1556,7 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
   {
     KScope3 k(ctx, "k3_pg<AAA>", st);
     a.out = G_aa;
-    bad |= dispatch_pg<G_AAA>(a, Q * Q * t.S, tn, tn, nw, st);
+    bad |= dispatch_pg<G_AAA>(a, npair * t.S, tn, tn, nw, st);
   }
   {
     KScope3 k(ctx, "k3_pg<BB>", sf);
