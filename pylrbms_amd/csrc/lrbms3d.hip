@@ -28,7 +28,7 @@ struct T3 {
   int nA, nB, nC, nFs, nFf, o_fs, o_ff, o_c, lam_stride, hat_stride, f_stride;
   double volume, kmin;
   const int *nbr, *phys;
-  const int *elem_type, *nb_elem, *nb_out, *face_pos, *tsign, *elem_rt, *rt_e0, *rt_f0, *rt_e1, *rt_f1;
+  const int *elem_type, *order, *nb_elem, *nb_out, *face_pos, *tsign, *elem_rt, *rt_e0, *rt_f0, *rt_e1, *rt_f1;
   const int *side_elem, *side_face, *side_elem_out, *side_face_out;
   const int *dof_node, *node_ptr, *node_dofs, *node_mask, *node_count, *side_nodes, *sn_ptr, *sn_dofs;
   const int *dof_bslot, *bnodes, *bnode_sides, *bel_elem, *bel_bnode, *sel_elem, *sel_sf;
@@ -519,7 +519,16 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1))) v
   constexpr bool NCK = KIND == G_NC, FACEK = KIND == G_AB || KIND == G_BB;
   const T3& t = a.t;
   const int N = a.N, Q = a.Q, QN = Q * N;
-  const int b = blockIdx.x;
+  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  All operator blocks of one subdomain read the same
+  // basis rows, so they get ids that differ by multiples of 8 inside one chunk of 8 subdomains: same XCD, launched together.
+  const int nops = KIND == G_SYS || KIND == G_AB ? Q : (KIND == G_AAA ? Q * (Q + 1) / 2 : (KIND == G_CPL ? 6 * Q : 1));
+  int b;
+  {
+    const int x = blockIdx.x, chunk = x / (8 * nops), within = x - chunk * 8 * nops;
+    const int o = within >> 3, sx = chunk * 8 + (within & 7);
+    if (sx >= t.S) return;
+    b = KIND == G_CPL ? ((o / 6) * t.S + sx) * 6 + o % 6 : o * t.S + sx;
+  }
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NW = blockDim.x >> 6;
@@ -643,6 +652,7 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1))) v
   const int last = nitems - 1;
   auto load_idx = [&](int item, Idx& ix) {
     item = item < last ? item : last;
+    if (KIND != G_CPL) item = t.order[item];          // element visited at this position of the traversal
     ix.e = item;
     ix.eo = 0;
     if (KIND == G_CPL) {
@@ -675,7 +685,7 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1))) v
     // ---- operand loads of the item, all issued before the first MFMA (no arithmetic on loaded values here)
     const bool on = KIND != G_CPL || ix1.e >= 0;
     const int e = on ? ix1.e : 0;
-    const double* Lb = Lall + (long)item * LSTRIDE;
+    const double* Lb = Lall + (long)(KIND == G_CPL ? item : e) * LSTRIDE;
     unsigned eb[NG];                          // byte offset of the rows of the slot's element
     if (FACEK) {
       eb[0] = (unsigned)ix1.aux[0] * ((unsigned)QN * 8u);
@@ -838,6 +848,7 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1))) v
 
 template <int KIND, int RT, int CT>
 void launch_pg(const GA& a, int batch, int nw, hipStream_t st) {
+  batch = batch / a.t.S * ((a.t.S + 7) / 8 * 8);     // whole chunks of 8 subdomains (k3_pg: XCD-aware block ids)
   constexpr int maxt = pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1));     // NC also holds the node averages of its operands
   if (nw * 64 > maxt) nw = maxt / 64;
   constexpr bool EVEN = RT % 2 == 0 && CT % 2 == 0;
@@ -1422,7 +1433,7 @@ int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, in
   const long nT = t.nT, n = t.n;
   int rc;
 #define UP(field, count) if ((rc = upload(ctx, d->field, (long)(count), &t.field)) != LRBMS_OK) return rc
-  UP(elem_type, nT); UP(nb_elem, nT * 4); UP(nb_out, nT * 4); UP(face_pos, nT * 4); UP(tsign, nT * 4); UP(elem_rt, nT * 4);
+  UP(elem_type, nT); UP(order, nT); UP(nb_elem, nT * 4); UP(nb_out, nT * 4); UP(face_pos, nT * 4); UP(tsign, nT * 4); UP(elem_rt, nT * 4);
   UP(rt_e0, t.nrt); UP(rt_f0, t.nrt); UP(rt_e1, t.nrt); UP(rt_f1, t.nrt);
   UP(side_elem, t.nbf); UP(side_face, t.nbf); UP(side_elem_out, t.nbf); UP(side_face_out, t.nbf);
   UP(dof_node, n); UP(node_ptr, t.nnodes + 1); UP(node_dofs, n); UP(node_mask, t.nnodes); UP(node_count, t.nnodes);

@@ -328,6 +328,12 @@ class SubdomainTemplate3D:
         sf = np.where(nb_elem < 0, (-(nb_elem + 1)) * ncf + face_pos, -1)
         sel = np.nonzero(np.any(sf >= 0, axis=1))[0]
         self.sel_elem, self.sel_sf = sel.astype(np.int32), np.ascontiguousarray(sf[sel].astype(np.int32))
+        # traversal order of the element loops of the pass: cubes in 2 x 2 x 2 blocks, so that most face neighbours of an element
+        # (whose basis rows it reads) are visited within the next few dozen items and still sit in the L2
+        cb = self.elem_cube
+        key = (((cb[:, 2] // 2) * ((ky + 1) // 2) + cb[:, 1] // 2) * ((kx + 1) // 2) + cb[:, 0] // 2) * 8 + \
+            ((cb[:, 2] % 2) * 2 + cb[:, 1] % 2) * 2 + cb[:, 0] % 2
+        self.order = np.argsort(key * 6 + self.elem_type, kind='stable').astype(np.int32)
         self._geometry()
 
     # ------------------------------------------------------------------ reference tetrahedra
