@@ -233,67 +233,98 @@ __global__ __launch_bounds__(64) void k3_assemble_flux(T3 t, const double* __res
 }
 
 // ------------------------------------------------------------------------------------------------- pass: preparation
-// R_self [S][n_rt][QN]: RT0 flux image of the own basis on the own faces;  Rb [S][nbf][QN]: the neighbour's share on the side faces
+// R_self [S][n_rt][QN]: RT0 flux image of the own basis on the own faces;  Rb [S][nbf][QN]: the neighbour's share on the side faces.
+// One wave per row: the row's elements, orientation and the ten flux coefficients per (element, q) are wave-uniform and come
+// through the scalar cache; the only vector-memory instructions are the loads of the basis rows (the address unit, not the
+// HBM, bounds these kernels).
 __global__ __launch_bounds__(256) void k3_flux(T3 t, int Q, int N, const double* __restrict__ V, const double* __restrict__ Cf,
                                                double* __restrict__ Rs, double* __restrict__ Rb) {
   const int s = blockIdx.y, QN = Q * N;
-  const int c = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= QN || row >= t.nrt + t.nbf) return;
-  const int q = c / N, j = c - q * N;
+  const int c = threadIdx.x & 63;
+  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (row >= t.nrt + t.nbf) return;
+  const int cc = c < QN ? c : QN - 1;
+  const int q = cc / N, j = cc - q * N;
+  int es[2], fs[2], ss[2], sg[2];
   if (row < t.nrt) {
-    double acc = 0.0;
-    for (int k = 0; k < 2; ++k) {
-      const int e = k ? t.rt_e1[row] : t.rt_e0[row], f = k ? t.rt_f1[row] : t.rt_f0[row];
-      if (e < 0) continue;
-      const double* co = Cf + (((long)q * t.S_ext + s) * t.nT + e) * 40 + f * 10;
-      const double* v = V + ((long)s * t.n + e * 10) * N + j;
-      double a = 0.0;
-      for (int i = 0; i < 10; ++i) a += co[i] * v[(long)i * N];
-      acc += sgn3(t, s, e, f) * a;
-    }
-    Rs[((long)s * t.nrt + row) * QN + c] = acc;
+    es[0] = t.rt_e0[row]; fs[0] = t.rt_f0[row]; es[1] = t.rt_e1[row]; fs[1] = t.rt_f1[row];
+    ss[0] = ss[1] = s;
+    sg[0] = sgn3(t, s, es[0], fs[0]);
+    sg[1] = es[1] >= 0 ? sgn3(t, s, es[1], fs[1]) : 0;
   } else {
-    const int sf = row - t.nrt, side = sf / t.ncf;
-    const int t2 = t.nbr[s * 7 + side_slot(side)];
-    const int e = t.side_elem_out[sf], f = t.side_face_out[sf];
-    double acc = 0.0;
-    if (t2 >= 0 && e >= 0) {
-      const double* co = Cf + (((long)q * t.S_ext + t2) * t.nT + e) * 40 + f * 10;
-      const double* v = V + ((long)t2 * t.n + e * 10) * N + j;
-      for (int i = 0; i < 10; ++i) acc += co[i] * v[(long)i * N];
-      acc *= t.tsign[e * 4 + f];      // a coupling face of the neighbour: its template orientation
+    const int sf = row - t.nrt;
+    const int t2 = t.nbr[s * 7 + side_slot(sf / t.ncf)];
+    es[0] = t.side_elem_out[sf]; fs[0] = t.side_face_out[sf]; es[1] = -1; fs[1] = 0;
+    ss[0] = ss[1] = t2;
+    sg[0] = sg[1] = 0;
+    if (t2 >= 0 && es[0] >= 0) sg[0] = t.tsign[es[0] * 4 + fs[0]];      // a coupling face of the neighbour: its template orientation
+    else es[0] = -1;
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (es[k] < 0) continue;                                             // wave-uniform
+    const double* v = V + ((long)ss[k] * t.n + es[k] * 10) * N + j;
+    const double* co0 = Cf + (((long)0 * t.S_ext + ss[k]) * t.nT + es[k]) * 40 + fs[k] * 10;
+    const long qstride = (long)t.S_ext * t.nT * 40;
+    double vv[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) vv[i] = v[(long)i * N];
+    double a = 0.0;
+    for (int qq = 0; qq < Q; ++qq) {                                     // uniform coefficients; the lane keeps its own q
+      const double* co = co0 + qq * qstride;
+      double aq = 0.0;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) aq += co[i] * vv[i];
+      a = qq == q ? aq : a;
     }
-    Rb[((long)s * t.nbf + sf) * QN + c] = acc;
+    acc += sg[k] * a;
+  }
+  if (c < QN) {
+    if (row < t.nrt) Rs[((long)s * t.nrt + row) * QN + c] = acc;
+    else Rb[((long)s * t.nbf + row - t.nrt) * QN + c] = acc;
   }
 }
 
 // Avg [S][n_nodes][N]: own share of the Oswald node average (0 on the physical boundary: the interpolant vanishes there);
-// As [S][6][nvs][N]: the neighbours' shares at the side nodes
+// As [S][6][nvs][N]: the neighbours' shares at the side nodes.  One wave per node, DoF lists through the scalar cache.
 __global__ __launch_bounds__(256) void k3_node_avg(T3 t, int N, const double* __restrict__ V, double* __restrict__ Avg,
                                                    double* __restrict__ As) {
   const int s = blockIdx.y;
-  const int j = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= N || row >= t.nnodes + 6 * t.nvs) return;
+  const int j = threadIdx.x & 63;
+  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (row >= t.nnodes + 6 * t.nvs) return;
+  const int jc = j < N ? j : N - 1;
   const int phys = t.phys[s];
+  int p0 = 0, p1 = 0, node, src = s;
+  const int* list;
   if (row < t.nnodes) {
-    double acc = 0.0;
-    if (!(t.node_mask[row] & phys)) {
-      const double* v = V + (long)s * t.n * N + j;
-      for (int p = t.node_ptr[row]; p < t.node_ptr[row + 1]; ++p) acc += v[(long)t.node_dofs[p] * N];
-      acc /= (double)t.node_count[row];
-    }
-    Avg[((long)s * t.nnodes + row) * N + j] = acc;
+    node = row;
+    list = t.node_dofs;
+    if (!(t.node_mask[node] & phys)) p0 = t.node_ptr[row], p1 = t.node_ptr[row + 1];
   } else {
-    const int sp = row - t.nnodes, side = sp / t.nvs;
-    const int node = t.side_nodes[sp];
-    const int t2 = t.nbr[s * 7 + side_slot(side)];
-    double acc = 0.0;
-    if (node >= 0 && t2 >= 0 && !(t.node_mask[node] & phys)) {
-      const double* v = V + (long)t2 * t.n * N + j;
-      for (int p = t.sn_ptr[sp]; p < t.sn_ptr[sp + 1]; ++p) acc += v[(long)t.sn_dofs[p] * N];
-      acc /= (double)t.node_count[node];
+    const int sp = row - t.nnodes;
+    node = t.side_nodes[sp];
+    src = t.nbr[s * 7 + side_slot(sp / t.nvs)];
+    list = t.sn_dofs;
+    if (node >= 0 && src >= 0 && !(t.node_mask[node] & phys)) p0 = t.sn_ptr[sp], p1 = t.sn_ptr[sp + 1];
+  }
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (p1 > p0) {
+    const double* v = V + (long)src * t.n * N + jc;
+    int p = p0;
+    for (; p + 3 < p1; p += 4) {
+      a0 += v[(long)list[p] * N];
+      a1 += v[(long)list[p + 1] * N];
+      a2 += v[(long)list[p + 2] * N];
+      a3 += v[(long)list[p + 3] * N];
     }
-    As[((long)s * 6 * t.nvs + sp) * N + j] = acc;
+    for (; p < p1; ++p) a0 += v[(long)list[p] * N];
+    a0 = ((a0 + a1) + (a2 + a3)) / (double)t.node_count[node];
+  }
+  if (j < N) {
+    if (row < t.nnodes) Avg[((long)s * t.nnodes + row) * N + j] = a0;
+    else As[((long)s * 6 * t.nvs + row - t.nnodes) * N + j] = a0;
   }
 }
 
