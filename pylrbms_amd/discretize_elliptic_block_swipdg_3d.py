@@ -1,0 +1,108 @@
+"""Block SWIPDG P2 discretization in 3D on the HIP path (BASELINE.json config 5) behind the reference's API shape.
+
+The reference's ``discretize`` (python/dune/pylrbms/discretize_elliptic_block_swipdg.py:530-811) binds the 2D / P1 operators
+only (:22-23); this module gives the 3D / P2 path the same surface for the calls on the hot path:
+
+    d, data = discretize(grid_and_problem_data)          # :530       offline assembly (lrbms3_assemble_*)
+    d.estimate(U, mu)                                     # :205-217   full-order estimate of a block DG vector
+    reductor = LRBMSReductor3D(d, bases)                  # reductor.py:17-31
+    rd = reductor.reduce()                                # reductor.py:33-73   one lrbms3_project_estimate pass
+    u = rd.solve(mu);  rd.estimate(u, mu)                 # online (estimators.py:45-130)
+
+``grid_and_problem_data``: the dict of ``pylrbms_amd.multiscale_problem3d.init_grid_and_problem`` (grid, lambda functions and
+coefficient functionals, lambda_bar / lambda_hat, f, mu_bar / mu_hat).  Full-order solves (snapshot generation) are not part of
+the 3D path yet: bases come from the caller."""
+import numpy as np
+
+from pylrbms_amd.engine3d import Engine3D
+
+
+class BlockDiscretization3D:
+    def __init__(self, p, device_index=0):
+        self.grid = p['grid']
+        lam = p['lambda']
+        self.coefficients = list(lam['coefficients'])
+        self.mu_bar, self.mu_hat = p['mu_bar'], p['mu_hat']
+        self.engine = Engine3D(self.grid, lam['functions'], p['f'], p['lambda_bar'], p['lambda_hat'],
+                               data_degree=p.get('data_degree', 2), device_index=device_index).assemble()
+        self.Q = self.engine.Q
+        self.parameter_range = p.get('parameter_range')
+
+    def theta(self, mu):
+        return np.array([float(c(mu)) for c in self.coefficients], dtype=np.float64)
+
+    def alpha(self, mu, mu2):
+        """min_q theta_q(mu) / theta_q(mu2) as written in the reference: the loop returns in its first pass
+        (estimators.py:114-121), i.e. the first component only."""
+        return self.coefficients[0](mu) / self.coefficients[0](mu2)
+
+    def gamma(self, mu, mu2):
+        return max(c(mu) / c(mu2) for c in self.coefficients)
+
+    def combine(self, eta_loc, mu, decompose=False):
+        """EstimatorBase._estimate_elliptic (estimators.py:99-112) from the local terms [3, S]."""
+        nc, r, df = (np.asarray(x, dtype=np.float64) for x in eta_loc)
+        a_bar, a_hat, g_bar = self.alpha(mu, self.mu_bar), self.alpha(mu, self.mu_hat), self.gamma(mu, self.mu_bar)
+        eta = (1.0 / np.sqrt(a_bar)) * (np.sqrt(g_bar) * np.linalg.norm(nc) + (1.0 / np.sqrt(a_hat)) * np.linalg.norm(r + df))
+        if not decompose:
+            return eta
+        return eta, (nc, r, df), (2.0 / a_bar) * (g_bar * nc ** 2 + (1.0 / a_hat) * (r + df) ** 2)
+
+    def apply(self, U, mu):
+        """A(mu) U for a block DG array U [S, n, M] (BlockOperator.apply, :500-507)."""
+        eng = self.engine
+        return eng.ctx.fom_apply(self.Q, self.theta(mu), eng.ops['A_diag'], eng.ops['A_cpl'], U)
+
+    def estimate(self, U, mu, decompose=False):
+        """Full-order estimate of the block DG vector U [S, n] (:205-217): the pass with U as a one-column basis, u = 1."""
+        eng = self.engine
+        V = (U if isinstance(U, eng.ctx.torch.Tensor) else eng.ctx.from_numpy(np.asarray(U))).reshape(eng.S_ext, eng.t.n, 1).contiguous()
+        out = eng.project_and_estimate(V)
+        ones = eng.ctx.zeros(eng.S_ext, 1) + 1.0
+        return self.combine(eng.reduced_estimate(self.theta(mu), ones, out).cpu().numpy(), mu, decompose)
+
+
+class ReducedDiscretization3D:
+    """``rd``: the 7-slot block-sparse reduced system and the projected estimator operators (factored layout), in HBM."""
+
+    def __init__(self, reductor, out):
+        self.reductor, self.d, self.out = reductor, reductor.d, out
+        self.N = out['rhs_red'].shape[1]
+
+    @property
+    def operators(self):
+        """Dense blocks of the projected estimator operators (reference: ``rd.operators``), built on request from the factors."""
+        from pylrbms_amd.engine3d import expand_factored
+        return expand_factored(self.d.engine, self.out, self.d.Q, self.N)
+
+    def solve(self, mu, rtol=1e-12, max_iter=20000, return_info=False):
+        u, info = self.d.engine.reduced_solve(self.d.theta(mu), self.out, rtol=rtol, max_iter=max_iter)
+        return (u, info) if return_info else u
+
+    def estimate(self, u, mu, decompose=False):
+        eta_loc = self.d.engine.reduced_estimate(self.d.theta(mu), u.contiguous(), self.out)
+        return self.d.combine(eta_loc.cpu().numpy(), mu, decompose)
+
+
+class LRBMSReductor3D:
+    """``LRBMSReductor`` (reference reductor.py:17-78) for the 3D path: local bases as one device slab [S, n, N]."""
+
+    def __init__(self, d, bases):
+        self.d = d
+        eng = d.engine
+        self.bases = bases if isinstance(bases, eng.ctx.torch.Tensor) else eng.ctx.from_numpy(np.asarray(bases))
+        assert tuple(self.bases.shape[:2]) == (eng.S_ext, eng.t.n)
+
+    def reduce(self):
+        return ReducedDiscretization3D(self, self.d.engine.project_and_estimate(self.bases.contiguous()))
+
+    def reconstruct(self, u):
+        import torch
+        return torch.einsum('snj,sj->sn', self.bases, u)
+
+
+def discretize(grid_and_problem_data, device_index=0):
+    d = BlockDiscretization3D(grid_and_problem_data, device_index=device_index)
+    eng = d.engine
+    data = {'grid': d.grid, 'engine': eng, 'operators': eng.ops}
+    return d, data

@@ -1,0 +1,45 @@
+"""The 3D / P2 path through its API shim (discretize -> LRBMSReductor3D.reduce -> rd.solve / rd.estimate, d.estimate) against the
+CPU oracle: the call sequence of the reference's driver (python/scripts/online_adaptive_lrbms.py:56-141) on BASELINE.json
+config 5's problem family.  PARITY UNPINNED beyond the oracle (no 3D reference counterpart)."""
+import numpy as np
+import pytest
+
+import common3d as c3
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', ['aniso_2x2x1', 'interior_3x3x3'])
+def test_driver_sequence_matches_the_oracle(name):
+    from pylrbms_amd.discretize_elliptic_block_swipdg_3d import LRBMSReductor3D, discretize
+    p = c3.make_problem(name)
+    o = c3.oracle_of(p)
+    pd = {'grid': p['grid'], 'lambda': {'functions': p['lambdas'], 'coefficients': p['thetas']}, 'lambda_bar': p['lambda_bar'],
+          'lambda_hat': p['lambda_hat'], 'f': p['f'], 'mu_bar': p['mu_bar'], 'mu_hat': p['mu_hat']}
+    d, data = discretize(pd)
+    V = c3.make_bases3d(o.S, o.n, p['N'], seed=11)
+    red = LRBMSReductor3D(d, V)
+    rd = red.reduce()
+    mu = p['mu']
+    u, (it, res) = rd.solve(mu, rtol=1e-13, return_info=True)
+    ord_ = c3.reduce_with_oracle(p, o, V)
+    uo = ord_.solve(mu)
+    assert c3.rel(u.cpu().numpy(), np.stack(uo)) < 1e-10
+    eta, (nc, r, df), ind = rd.estimate(u, mu, decompose=True)
+    eta_o, (nco, ro, dfo), _ = ord_.estimate(uo, mu, decompose=True)
+    assert abs(eta - eta_o) < 1e-9 * eta_o
+    for a, b in ((nc, nco), (r, ro), (df, dfo)):
+        assert c3.rel(a, b) < 1e-8
+    # the reduced estimate is the full-order estimate of the reconstruction ...
+    U = red.reconstruct(u)
+    eta_f = d.estimate(U, mu)
+    assert abs(eta_f - eta) < 1e-8 * eta
+    # ... and the full-order estimate of an arbitrary DG function matches the oracle's
+    W = np.random.default_rng(2).standard_normal((o.S, o.n))
+    assert abs(d.estimate(W, mu) - o.estimate(W.ravel(), mu)) < 1e-9 * o.estimate(W.ravel(), mu)
+    # block operator = global operator
+    y = d.apply(d.engine.ctx.from_numpy(W[:, :, None]), mu).cpu().numpy()
+    assert c3.rel(y.ravel(), o.system_matrix(mu) @ W.ravel()) < 1e-11
+    # Galerkin orthogonality of the reduced solution
+    res_ = o.b - o.system_matrix(mu) @ U.cpu().numpy().ravel()
+    assert max(np.abs(V[ii].T @ res_[o.dofs_of(ii)]).max() for ii in range(o.S)) < 1e-9
