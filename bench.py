@@ -238,10 +238,11 @@ def main():
     if args.config.startswith('cfg5'):
         # BASELINE.json config 5 (3D diffusion, SWIPDG p = 2): its own line (bench3d.py); one rank holds all subdomains
         import bench3d
-        if world > 1:
-            raise SystemExit('--config {} runs on one rank (replicas only)'.format(args.config))
-        print(json.dumps(bench3d.run(args.config, args.steps, args.warmup, device_index=local_rank, cpu=not args.no_cpu_baseline,
-                                     online=not args.no_online)), flush=True)
+        line = bench3d.run(args.config, args.steps, args.warmup, device_index=int(os.environ.get('LRBMS_BENCH_DEVICE', local_rank)),
+                           cpu=not args.no_cpu_baseline, online=not args.no_online, world=world, rank=rank,
+                           backend=os.environ.get('LRBMS_BENCH_BACKEND', 'nccl'))
+        if line is not None:
+            print(json.dumps(line), flush=True)
         return
     cfg = CONFIGS[args.config]
     N = cfg['N']

@@ -32,7 +32,7 @@ def mfma_counts(n_T, ncf, N, Q):
     tn, tq = (N + 15) // 16, (Q * N + 15) // 16
     per = {'k3_pg<SYS>': (13 * tn + tn * 3 * tn) * n_T * Q,
            'k3_pg<CPL>': (3 * tn + tn * 3 * tn) * ncf * 6 * Q,
-           'k3_pg<AAA>': (3 * tn + tn * 3 * tn) * n_T * Q * Q,
+           'k3_pg<AAA>': (3 * tn + tn * 3 * tn) * n_T * (Q * (Q + 1) // 2),      # pairs q <= q', mirrored at the store
            'k3_pg<NC>': (3 * tn + tn * 3 * tn) * n_T,
            'k3_pg<AB>': (1 * tq + tn * 3 * tq) * n_T * Q,
            'k3_pg<BB>': (1 * tq + tq * 1 * tq) * n_T}
@@ -73,15 +73,26 @@ def cpu_baseline3d(N):
             'os_cpu_count': os.cpu_count()}
 
 
-def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True):
+def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True, world=1, rank=0, backend='nccl'):
+    """One rank of the config-5 bench.  world > 1 (launched by torch.distributed.run): the 8 x 8 x 8 subdomains are cut into
+    one 3D tile per rank (strong scaling, as BASELINE.json config 5 asks for 8 GPUs), every step = one halo exchange of the
+    neighbour rows (all_to_all_single over RCCL, point to point) + one pass; rank 0 returns the line, the others None."""
     cfg = CONFIGS3D[config]
     N = cfg['N']
-    base = cpu_baseline3d(N) if cpu else None
+    base = cpu_baseline3d(N) if (cpu and world == 1) else None
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch
+    import torch.distributed as dist
     from pylrbms_amd import multiscale_problem3d
     from pylrbms_amd.engine3d import Engine3D
-    p = multiscale_problem3d.init_grid_and_problem({'num_subdomains': cfg['num_subdomains'],
-                                                    'cubes_per_subdomain': cfg['cubes_per_subdomain']})
+    torch.cuda.set_device(device_index)
+    if world > 1:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device_index))
+        else:
+            dist.init_process_group(backend)
+    pcfg = {'num_subdomains': cfg['num_subdomains'], 'cubes_per_subdomain': cfg['cubes_per_subdomain']}
+    p = multiscale_problem3d.init_grid_and_problem(pcfg, rank=rank, world_size=world)
     lam = p['lambda']
     t0 = time.perf_counter()
     eng = Engine3D(p['grid'], lam['functions'], p['f'], p['lambda_bar'], p['lambda_hat'], data_degree=p['data_degree'],
@@ -96,22 +107,42 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
     torch.cuda.synchronize()
     assemble_ms = e0.elapsed_time(e1)
     t, S, Q = eng.t, eng.S, eng.Q
-    g = torch.Generator(device='cuda').manual_seed(0)
-    V = torch.randn(eng.S_ext, t.n, N, dtype=torch.float64, device='cuda', generator=g)
-    V[:, :, 0] = 1.0
+    S_total = p['grid'].num_subdomains
+    g = torch.Generator(device='cuda').manual_seed(rank)
+    V = torch.zeros(eng.S_ext, t.n, N, dtype=torch.float64, device='cuda')
+    V[:S] = torch.randn(S, t.n, N, dtype=torch.float64, device='cuda', generator=g)
+    V[:S, :, 0] = 1.0
+    halo = None
+    if world > 1:
+        from pylrbms_amd.grid3d import DDSubdomainsGrid3D
+        from pylrbms_amd.parallel import HaloExchange, HaloPlan
+        gr = p['grid']
+        plan = HaloPlan(lambda r: DDSubdomainsGrid3D(gr.lower_left, gr.upper_right, gr.K, gr.P, rank=r, world_size=world), world, rank)
+        halo = HaloExchange(plan, N, V.device)
     out, work = eng.alloc_outputs(N), eng.alloc_work(N)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(warmup):
-        eng.project_and_estimate(V, out, work)
-    torch.cuda.synchronize()
+        eng.project_and_estimate(V, out, work, halo=halo)
+    fence()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
     for _ in range(steps):
-        eng.project_and_estimate(V, out, work)
+        eng.project_and_estimate(V, out, work, halo=halo)
     e1.record()
-    torch.cuda.synchronize()
+    fence()
     elapsed = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1) / steps
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=V.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
     eng.ctx.kernel_timing(True)
     for _ in range(steps):
         eng.project_and_estimate(V, out, work)
@@ -143,15 +174,30 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
                 'compulsory_GBps': (inputs + outputs) / (dev_ms * 1e-3) / 1e9,
                 'compulsory_frac_of_hbm_peak': (inputs + outputs) / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 'device_ms_per_step': dev_ms, 'kernels': table, 'kernels_sum_us': sum(r['us'] for r in table)}
-    res = {'metric': 'offline project+estimate throughput', 'value': S * steps / elapsed, 'unit': 'subdomains/s', 'n_gpus': 1,
-           'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * elapsed / steps, 'higher_is_better': True, 'scaling': 'weak',
+    mine = [float(S), float(len(eng.halo)), float(halo.send_bytes if halo is not None else 0), float(halo.recv_bytes if halo is not None else 0)]
+    if world > 1:
+        gathered = [torch.zeros(4, dtype=torch.float64, device=V.device) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor(mine, dtype=torch.float64, device=V.device))
+        rows_d = [x.cpu().tolist() for x in gathered]
+    else:
+        rows_d = [mine]
+    dist_info = {'backend': backend if world > 1 else None, 'world_size': dist.get_world_size() if world > 1 else 1,
+                 'subdomains_per_rank': [int(r[0]) for r in rows_d], 'halo_subdomains_per_rank': [int(r[1]) for r in rows_d],
+                 'halo_bytes_sent_per_rank_per_step': [int(r[2]) for r in rows_d],
+                 'halo_bytes_received_per_rank_per_step': [int(r[3]) for r in rows_d]}
+    if world > 1:
+        online = False
+    res = {'metric': 'offline project+estimate throughput', 'value': S_total * steps / elapsed, 'unit': 'subdomains/s', 'n_gpus': world,
+           'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * elapsed / steps, 'higher_is_better': True,
+           'scaling': 'strong' if world > 1 else 'weak',
            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
            'config': {'workload': 'BASELINE.json config 5{}: 3D diffusion, {}x{}x{} subdomains, SWIPDG p=2 on Kuhn tetrahedra, k_c={} '
                                   '(n={} DG DoFs, n_rt={} RT0 DoFs per subdomain), Q={}, local basis dim {}'.format(
                                       '' if config == 'cfg5' else ' (per-rank tile of the 8-GPU run)', *cfg['num_subdomains'],
                                       cfg['cubes_per_subdomain'], t.n, t.n_rt, Q, N),
-                      'subdomains': S, 'N': N, 'Q': Q, 'parallelism': 'one rank holds every subdomain'},
-           'roofline': roofline,
+                      'subdomains': S_total, 'N': N, 'Q': Q,
+                      'parallelism': 'one rank holds every subdomain' if world == 1 else '3D subdomain tiles x{}'.format(world)},
+           'roofline': roofline, 'distributed': dist_info,
            'assemble': {'ms': assemble_ms, 'value': S / (1e-3 * assemble_ms), 'unit': 'subdomains/s',
                         'host_sampling_and_upload_s': setup_s}}
     if online:
@@ -174,7 +220,10 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
                          'solver': 'block-Jacobi PCG on the 7-slot block-sparse reduced system, rtol 1e-12, one parameter per call'}
     if base is not None:
         res['cpu_baseline'] = base
-    return res
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return res if rank == 0 else None
 
 
 if __name__ == '__main__':

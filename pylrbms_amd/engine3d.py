@@ -68,10 +68,14 @@ class Engine3D:
     def alloc_work(self, N):
         return self.ctx.empty(self.ctx.work_size(self.Q, N))
 
-    def project_and_estimate(self, V, out=None, work=None):
-        """One pass of the hot path over all local subdomains; V [S_ext, n, N] with the halo filled."""
+    def project_and_estimate(self, V, out=None, work=None, halo=None):
+        """One pass of the hot path over all local subdomains; V [S_ext, n, N] with the halo filled -- or ``halo`` (a
+        ``pylrbms_amd.parallel.HaloExchange`` on this rank's 3D tile) fills it first: one exchange step per pass, the rows
+        of the cube layer next to every foreign side."""
         if self.ops is None:
             raise NativeError('assemble() must run before project_and_estimate()')
+        if halo is not None:
+            halo(V)
         N = V.shape[2]
         out = out if out is not None else self.alloc_outputs(N)
         work = work if work is not None else self.alloc_work(N)

@@ -43,29 +43,50 @@ def side_rows(template):
     return rows
 
 
+def side_rows3d(template):
+    """3D (pylrbms_amd.grid3d.SubdomainTemplate3D): for each side 0..5 the sorted DoF rows of all elements with a Lagrange node
+    on that side -- the cube layer next to it; what the coupling blocks, the node averages and the flux image of the pass read
+    of a neighbour's basis."""
+    t = template
+    from pylrbms_amd.grid3d import NLOC, SIDE_AXIS, SIDE_DIR
+    rows = []
+    for a in range(6):
+        ax = SIDE_AXIS[a]
+        layer = 0 if SIDE_DIR[a] < 0 else t.kc[ax] - 1
+        elems = np.nonzero(t.elem_cube[:, ax] == layer)[0]
+        rows.append(np.sort((NLOC * elems[:, None] + np.arange(NLOC)[None, :]).ravel()).astype(np.int64))
+    return rows
+
+
 class HaloPlan:
     """Who sends which rows of which subdomain: derived by every rank from the grid partition alone (no handshake)."""
 
     def __init__(self, grid_factory, world_size, rank):
-        """``grid_factory(rank)`` returns the DDSubdomainsGrid as seen by ``rank`` (same global grid, other tile)."""
+        """``grid_factory(rank)`` returns the DDSubdomainsGrid (2D) or DDSubdomainsGrid3D as seen by ``rank`` (same global
+        grid, other tile)."""
         grids = [grid_factory(r) for r in range(world_size)]
         g = grids[rank]
         self.rank, self.world_size = rank, world_size
         t = g.template
-        rows = side_rows(t)
-        opposite = {0: 3, 1: 2, 2: 1, 3: 0}
+        if getattr(g, 'dim', 2) == 3:
+            rows = side_rows3d(t)
+            slot_of_side = (0, 1, 2, 4, 5, 6)
+        else:
+            rows = side_rows(t)
+            slot_of_side = (0, 1, 3, 4)
+        nsides = len(rows)
+        opposite = {sd: nsides - 1 - sd for sd in range(nsides)}
         owner = {}
         for r, gr in enumerate(grids):
             for s in gr.subdomains_on_rank:
                 owner[s] = r
-        slot_of_side = (0, 1, 3, 4)
         # send list of rank r: for each owned subdomain s and each side whose neighbour lives elsewhere,
         # the rows of s touching that side.  Deterministic order: (s ascending, side ascending).
         self.send_items = []      # per rank: list of (subdomain, side)
         for r, gr in enumerate(grids):
             items = []
             for s in gr.subdomains_on_rank:
-                for sd in range(4):
+                for sd in range(nsides):
                     j = g.neighbor_slots[s, slot_of_side[sd]]
                     if j >= 0 and owner[int(j)] != r:
                         items.append((s, sd))
