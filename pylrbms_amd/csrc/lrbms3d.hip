@@ -518,7 +518,7 @@ template <> struct PGT<G_SYS> { static constexpr int MZ = 10, KY = 50; };
 template <> struct PGT<G_AAA> { static constexpr int MZ = 10, KY = 10; };
 template <> struct PGT<G_NC> { static constexpr int MZ = 10, KY = 10; };
 template <> struct PGT<G_CPL> { static constexpr int MZ = 10, KY = 10; };
-template <> struct PGT<G_AB> { static constexpr int MZ = 10, KY = 4; };
+template <> struct PGT<G_AB> { static constexpr int MZ = 4, KY = 10; };    // contracted through the 4 faces: W = A_ab^T V_e first
 template <> struct PGT<G_BB> { static constexpr int MZ = 4, KY = 4; };
 
 constexpr int pg_max_threads(int tiles) { return tiles <= 4 ? 1024 : (tiles <= 8 ? 512 : 256); }   // VGPR budget 128 / 256 / 512
@@ -709,10 +709,83 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1))) v
     if (FACEK) ix.aux[0] = t.elem_rt[item * 4 + lk];
   };
 
+  // G_ab: lane constants of its own form (below)
+  unsigned abl[3], abv[3][RT];
+  bool abpad[3];
+  if constexpr (KIND == G_AB) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = k < 2 ? (WIDE ? 2 * lk + k : 4 * k + lk) : 8 + (lk & 1);
+      abpad[k] = k == 2 && lk >= 2;
+      abl[k] = 8u * (j * 4 + (li < 4 ? li : 3));            // A_ab[e][j][f = li]: rows f >= 4 of the product are never used
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        int col;
+        if (WIDE) {
+          const int c0 = li * RT + (rt & ~1);
+          col = (c0 + 1 < N ? c0 : N - 2) + (rt & 1);
+        } else {
+          const int col0 = rt * 16 + li;
+          col = col0 < N ? col0 : N - 1;
+        }
+        abv[k][rt] = (unsigned)j * rowb + 8u * col;
+      }
+    }
+  }
+
   Idx ix1, ix2;
   load_idx(wave, ix1);
   for (int item0 = wave; item0 < nitems; item0 += NW) {
     const int item = item0 < last ? item0 : last;
+    if constexpr (KIND == G_AB) {
+      // G_ab[q] = sum_e V_e^T A_ab R_e = sum_e (A_ab^T V_e)^T R_e: contracted through the FOUR faces instead of the ten DoFs.
+      //   W = A_ab^T V_e   [4 x N]    A operand A_ab^T (rows f), B operand the rows of V_e: 3 k-steps per row tile
+      //   G += W^T R_e                 A operand = accumulator element 0 of W (lane: f = lk, i = li), B operand the four RT0 rows
+      // 3 RT + RT CT = 14 MFMAs per element at config 5 instead of 28.
+      const int e = ix1.e;
+      const double* Lb = Lall + (long)e * LSTRIDE;
+      const unsigned ex = (unsigned)e * erow, rb = (unsigned)ix1.aux[0] * ((unsigned)QN * 8u);
+      double lop[3], vv[RT][3], re[CT];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        lop[k] = abpad[k] ? *zero : ld8(Lb, abl[k]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          if (WIDE) {
+            if ((rt & 1) == 0) {
+              const double2 v = ld16(Vs, ex + abv[k][rt]);
+              vv[rt][k] = v.x;
+              vv[rt + 1 < RT ? rt + 1 : rt][k] = v.y;
+            }
+          } else {
+            vv[rt][k] = ld8(Vs, ex + abv[k][rt]);
+          }
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        if (WIDE) {
+          if ((ct & 1) == 0) {
+            const double2 v = ld16(Rss, rb + yc[0][ct]);
+            re[ct] = v.x;
+            re[ct + 1 < CT ? ct + 1 : ct] = v.y;
+          }
+        } else {
+          re[ct] = ld8(Rss, rb + yc[0][ct]);
+        }
+      }
+      load_idx(item0 + NW, ix2);
+      ix1 = ix2;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        d4 z = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) z = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[k], vv[rt][k], z, 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[0], re[ct], acc[rt][ct], 0, 0, 0);
+      }
+      continue;
+    }
     // ---- operand loads of the item, all issued before the first MFMA (no arithmetic on loaded values here)
     const bool on = KIND != G_CPL || ix1.e >= 0;
     const int e = on ? ix1.e : 0;
