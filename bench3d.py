@@ -35,7 +35,7 @@ def mfma_counts(n_T, ncf, N, Q):
            'k3_pg<AAA>': (3 * tn + tn * 3 * tn) * n_T * (Q * (Q + 1) // 2),      # pairs q <= q', mirrored at the store
            'k3_pg<NC>': (3 * tn + tn * 3 * tn) * n_T,
            'k3_pg<AB>': (3 * tn + tn * tq) * n_T * Q,                              # contracted through the four faces
-           'k3_pg<BB>': (1 * tq + tq * 1 * tq) * n_T}
+           'k3_pg<BB>': 2 * (tq + tq * (tq + 1) // 2) * n_T}                     # G_bb and G_rdd: apply + upper tile triangle each
     return per
 
 

@@ -3,11 +3,11 @@
 // Kuhn triangulation: every element is a translate of one of six reference tetrahedra, so every local integral is a
 // contraction of coefficient samples with a reference table (pylrbms_amd/grid3d.py builds the tables on the host, once):
 //     block[e][c] = sum_k sample[e][k] * TABLE[type(e)][k][c].
-// The pass (lrbms3_project_estimate) is built from one MFMA kernel template, k3_gram<KIND>: G = sum_rows x_row^T y_row with
-// the rows of X and Y = L X' produced on the fly from the basis slab and the element blocks (never written to HBM), fp64
-// v_mfma_f64_16x16x4_f64 accumulation, one workgroup per (subdomain, operator).  Images of a NEIGHBOUR's basis live on the
-// side faces / side nodes of the target subdomain only: they are returned as factors (Rb, Yb, Dp, Xab, As, Cn) and the
-// estimate kernel consumes the factors (header).
+// The pass (lrbms3_project_estimate) is built from one MFMA kernel template, k3_pg<KIND>: G = sum_items X^T (L Y) with the
+// element-local apply L Y and the projection both on the fp64 matrix cores, operands straight from global memory (no LDS
+// staging, no VALU arithmetic in the loop), one wave per item, one workgroup per (subdomain, operator).  Images of a NEIGHBOUR's
+// basis live on the side faces / side nodes of the target subdomain only: they are returned as factors (Rb, Yb, Dp, Xab, As, Cn)
+// and the estimate kernel consumes the factors (header).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -328,8 +328,8 @@ __global__ __launch_bounds__(256) void k3_node_avg(T3 t, int N, const double* __
   }
 }
 
-// ------------------------------------------------------------------------------------------------- pass: Gram kernel
-enum { G_SYS = 0, G_AAA, G_NC, G_AB, G_BB, G_RDD, G_CPL };
+// ------------------------------------------------------------------------------------------------- pass: projections
+enum { G_SYS = 0, G_AAA = 1, G_NC = 2, G_AB = 3, G_BB = 4, G_CPL = 6 };
 
 struct GA {
   T3 t;
@@ -337,174 +337,9 @@ struct GA {
   const double *V, *A_diag, *A_cpl, *ebar, *Aaa, *Aab, *Bbb, *Rs, *Avg;
   double* out;
   double* Zb;   // NC: rows of E W_self at the boundary DoFs [S][nbd][N]
+  double *out2, *out3;     // BB: G_rdd [S][QN][QN], r_fd [S][QN] (accumulated beside G_bb: they share every operand)
+  const double* bdiv;
 };
-
-constexpr int BK = 16, LD = 64 + 16;
-
-template <int KIND>
-__global__ __launch_bounds__(256) void k3_gram(GA a) {
-  __shared__ double Xs[BK][LD];
-  __shared__ double Ys[BK][LD];
-  const T3& t = a.t;
-  const int N = a.N, Q = a.Q, QN = Q * N;
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wr = wave >> 1, wc = wave & 1, li = lane & 15, lk = lane >> 4;
-  const int srow = tid >> 4, c0 = (tid & 15) * 4;
-
-  int s, q = 0, K, Mx, My, t2 = 0, side = 0;
-  double* out;
-  if (KIND == G_SYS) {
-    q = b / t.S; s = b - q * t.S; K = t.n; Mx = My = N;
-    out = a.out + (((long)q * t.S + s) * 7 + 3) * N * N;
-  } else if (KIND == G_CPL) {
-    side = b % 6;
-    const int qs = b / 6;
-    q = qs / t.S; s = qs - q * t.S; K = t.ncf * 10; Mx = My = N;
-    t2 = t.nbr[s * 7 + side_slot(side)];
-    out = a.out + (((long)q * t.S + s) * 7 + side_slot(side)) * N * N;
-  } else if (KIND == G_AAA) {
-    s = b % t.S; K = t.n; Mx = My = N;
-    out = a.out + (long)b * N * N;
-  } else if (KIND == G_NC) {
-    s = b; K = t.n; Mx = My = N;
-    out = a.out + (long)b * N * N;
-  } else if (KIND == G_AB) {
-    q = b / t.S; s = b - q * t.S; K = t.n; Mx = N; My = QN;
-    out = a.out + (long)b * N * QN;
-  } else if (KIND == G_BB) {
-    s = b; K = t.nT * 4; Mx = My = QN;
-    out = a.out + (long)b * QN * QN;
-  } else {
-    s = b; K = t.nT; Mx = My = QN;
-    out = a.out + (long)b * QN * QN;
-  }
-  const int ldo = My;
-
-  if (KIND == G_CPL && t2 < 0) {
-    for (int i = tid; i < Mx * My; i += 256) out[i] = 0.0;
-    return;
-  }
-
-  d4 acc[2][2];
-  for (int i = 0; i < 2; ++i)
-    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* Vs = a.V + (long)s * t.n * N;
-
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    const int kr = k0 + srow;
-    double xv[4] = {0, 0, 0, 0}, yv[4] = {0, 0, 0, 0};
-    if (kr < K) {
-      if (KIND == G_SYS || KIND == G_AAA || KIND == G_CPL) {
-        int e, i = kr % 10;
-        const double *L, *Vy;
-        int nslot = 1;
-        if (KIND == G_CPL) {
-          const int sp = side * t.ncf + kr / 10;
-          e = t.side_elem[sp];
-          L = a.A_cpl + ((((long)q * t.S + s) * 6 + side) * t.ncf + kr / 10) * 100 + i * 10;
-          Vy = a.V + ((long)t2 * t.n + t.side_elem_out[sp] * 10) * N;
-        } else {
-          e = kr / 10;
-          if (KIND == G_SYS) {
-            L = a.A_diag + ((((long)q * t.S + s) * t.nT + e) * 5) * 100 + i * 10;
-            nslot = 5;
-          } else {
-            L = a.Aaa + ((long)b * t.nT + e) * 100 + i * 10;
-          }
-          Vy = Vs + (long)e * 10 * N;
-        }
-        if (e >= 0) {
-          const double* xp = Vs + ((long)e * 10 + i) * N;
-          for (int c = 0; c < 4; ++c)
-            if (c0 + c < N) xv[c] = xp[c0 + c];
-          for (int slot = 0; slot < nslot; ++slot) {
-            const double* vy = Vy;
-            if (KIND == G_SYS && slot > 0) {
-              const int ee = t.nb_elem[e * 4 + slot - 1];
-              if (ee < 0) continue;
-              vy = Vs + (long)ee * 10 * N;
-            }
-            const double* Ls = L + slot * 100;
-            for (int j = 0; j < 10; ++j) {
-              const double l = Ls[j];
-              for (int c = 0; c < 4; ++c)
-                if (c0 + c < N) yv[c] += l * vy[(long)j * N + c0 + c];
-            }
-          }
-        }
-      } else if (KIND == G_NC) {
-        const int e = kr / 10, i = kr - e * 10;
-        const double* L = a.ebar + ((long)s * t.nT + e) * 100 + i * 10;
-        const double* Av = a.Avg + (long)s * t.nnodes * N;
-        for (int c = 0; c < 4; ++c)
-          if (c0 + c < N) xv[c] = Vs[(long)kr * N + c0 + c] - Av[(long)t.dof_node[kr] * N + c0 + c];
-        for (int j = 0; j < 10; ++j) {
-          const double l = L[j];
-          const int d = e * 10 + j;
-          const long nd = (long)t.dof_node[d] * N;
-          for (int c = 0; c < 4; ++c)
-            if (c0 + c < N) yv[c] += l * (Vs[(long)d * N + c0 + c] - Av[nd + c0 + c]);
-        }
-      } else if (KIND == G_AB) {
-        const int e = kr / 10, i = kr - e * 10;
-        for (int c = 0; c < 4; ++c)
-          if (c0 + c < N) xv[c] = Vs[(long)kr * N + c0 + c];
-        const double* L = a.Aab + (((long)q * t.S + s) * t.nT + e) * 40 + i * 4;
-        for (int f = 0; f < 4; ++f) {
-          const double l = L[f];
-          const double* r = a.Rs + ((long)s * t.nrt + t.elem_rt[e * 4 + f]) * QN;
-          for (int c = 0; c < 4; ++c)
-            if (c0 + c < QN) yv[c] += l * r[c0 + c];
-        }
-      } else if (KIND == G_BB) {
-        const int e = kr >> 2, f = kr & 3;
-        const double* L = a.Bbb + ((long)s * t.nT + e) * 16 + f * 4;
-        const double* rx = a.Rs + ((long)s * t.nrt + t.elem_rt[kr]) * QN;
-        for (int c = 0; c < 4; ++c)
-          if (c0 + c < QN) xv[c] = rx[c0 + c];
-        for (int g = 0; g < 4; ++g) {
-          const double l = L[g];
-          const double* r = a.Rs + ((long)s * t.nrt + t.elem_rt[e * 4 + g]) * QN;
-          for (int c = 0; c < 4; ++c)
-            if (c0 + c < QN) yv[c] += l * r[c0 + c];
-        }
-      } else {   // G_RDD
-        const int e = kr, ty = t.elem_type[e];
-        for (int f = 0; f < 4; ++f) {
-          const double l = sgn3(t, s, e, f) * t.divc[ty * 4 + f];
-          const double* r = a.Rs + ((long)s * t.nrt + t.elem_rt[e * 4 + f]) * QN;
-          for (int c = 0; c < 4; ++c)
-            if (c0 + c < QN) xv[c] += l * r[c0 + c];
-        }
-        for (int c = 0; c < 4; ++c) yv[c] = t.volume * xv[c];
-      }
-    }
-    __syncthreads();
-    for (int c = 0; c < 4; ++c) {
-      Xs[srow][c0 + c] = xv[c];
-      Ys[srow][c0 + c] = yv[c];
-    }
-    __syncthreads();
-    if (wr * 32 < Mx && wc * 32 < My) {
-      for (int kk = 0; kk < BK; kk += 4) {
-        double av[2], bv[2];
-        for (int mi = 0; mi < 2; ++mi) av[mi] = Xs[kk + lk][wr * 32 + mi * 16 + li];
-        for (int ni = 0; ni < 2; ++ni) bv[ni] = Ys[kk + lk][wc * 32 + ni * 16 + li];
-        for (int mi = 0; mi < 2; ++mi)
-          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
-      }
-    }
-  }
-  for (int mi = 0; mi < 2; ++mi)
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = wc * 32 + ni * 16 + li;
-      for (int r = 0; r < 4; ++r) {
-        const int row = wr * 32 + mi * 16 + lk + 4 * r;
-        if (row < Mx && col < My) out[(long)row * ldo + col] = acc[mi][ni][r];
-      }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------- pass: MFMA pipeline
 // G = sum_items X^T (L Y), everything on the matrix cores, operands straight from global memory (L2 / L1 resident):
@@ -542,7 +377,7 @@ __device__ inline double2 ld16(const double* base, unsigned byte_off) {
 // SIMDs at a fixed number of cycles per instruction, and with 45 eight-byte loads per 38 MFMAs it, not the matrix pipe, set
 // the pace.
 template <int KIND, int RT, int CT, bool WIDE>
-__global__ __launch_bounds__(pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1))) void k3_pg(GA a) {
+__global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT * CT * (KIND == G_NC ? 2 : 1))) void k3_pg(GA a) {
   extern __shared__ double lds[];   // [RT * CT][256]
   constexpr int MZ = PGT<KIND>::MZ, KY = PGT<KIND>::KY, KR = (MZ + 3) / 4;
   constexpr int NG = KY == 50 ? 5 : 1;                       // neighbour slots whose rows the apply reads
@@ -709,6 +544,19 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1))) v
     if (FACEK) ix.aux[0] = t.elem_rt[item * 4 + lk];
   };
 
+  // G_bb: second accumulator set (G_rdd, upper tile triangle like G_bb) and the r_fd row
+  constexpr bool BBK = KIND == G_BB;
+  d4 accd[BBK ? RT : 1][BBK ? CT : 1];
+  double fd[BBK ? CT : 1];
+  if constexpr (BBK) {
+    static_assert(KIND != G_BB || RT == CT, "G_bb is square");
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j) accd[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < CT; ++j) fd[j] = 0.0;
+  }
   // G_ab: lane constants of its own form (below)
   unsigned abl[3], abv[3][RT];
   bool abpad[3];
@@ -737,6 +585,57 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1))) v
   load_idx(wave, ix1);
   for (int item0 = wave; item0 < nitems; item0 += NW) {
     const int item = item0 < last ? item0 : last;
+    if constexpr (KIND == G_BB) {
+      // Three operators of the four RT0 rows R_e of an element, one set of loads:
+      //   G_bb  += R_e^T (B_bb R_e)                        apply (A operand B_bb, symmetric) + projection, upper tile triangle
+      //   G_rdd += |T| (d^T R_e)^T (d^T R_e)               d_f = +-|f| / |T|: z1 = d^T R_e is ONE row, so the projection is a
+      //                                                    k = 1 product of z1 with itself (lanes lk = 0 carry it)
+      //   r_fd  += (int_T f) z1                            a VALU accumulation of the same row
+      const int e = ix1.e;
+      const double* Lb = Lall + (long)e * LSTRIDE;
+      const unsigned rb = (unsigned)ix1.aux[0] * ((unsigned)QN * 8u);
+      const int ty = t.elem_type[e];
+      double dd[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) dd[f] = sgn3(t, s, e, f) * t.divc[ty * 4 + f];
+      const double bd = a.bdiv[(long)s * t.nT + e];
+      const double lopB = ld8(Lb, 8u * (lk * 4 + (li < 4 ? li : 3)));
+      double re[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        if (WIDE) {
+          if ((ct & 1) == 0) {
+            const double2 v = ld16(Rss, rb + yc[0][ct]);
+            re[ct] = v.x;
+            re[ct + 1 < CT ? ct + 1 : ct] = v.y;
+          }
+        } else {
+          re[ct] = ld8(Rss, rb + yc[0][ct]);
+        }
+      }
+      load_idx(item0 + NW, ix2);
+      ix1 = ix2;
+      const double dsel = lk == 0 ? dd[0] : (lk == 1 ? dd[1] : (lk == 2 ? dd[2] : dd[3]));
+      const double l1 = li == 0 ? dsel : 0.0;             // A operand of z1: row 0 = d^T, all other rows zero
+      double zb[CT], z1[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const d4 z0 = (d4){0.0, 0.0, 0.0, 0.0};
+        zb[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(lopB, re[ct], z0, 0, 0, 0)[0];      // rows f = lk of B_bb R_e
+        z1[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, re[ct], z0, 0, 0, 0)[0];        // row 0 in the lanes lk = 0, zero elsewhere
+        fd[ct] += bd * z1[ct];
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const double a1 = t.volume * z1[rt];
+#pragma unroll
+        for (int ct = rt; ct < CT; ++ct) {
+          acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(re[rt], zb[ct], acc[rt][ct], 0, 0, 0);
+          accd[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, z1[ct], accd[rt][ct], 0, 0, 0);
+        }
+      }
+      continue;
+    }
     if constexpr (KIND == G_AB) {
       // G_ab[q] = sum_e V_e^T A_ab R_e = sum_e (A_ab^T V_e)^T R_e: contracted through the FOUR faces instead of the ten DoFs.
       //   W = A_ab^T V_e   [4 x N]    A operand A_ab^T (rows f), B operand the rows of V_e: 3 k-steps per row tile
@@ -909,6 +808,73 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1))) v
         for (int r = 0; r < KR; ++r) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[rt][r], z[r], acc[rt][ct], 0, 0, 0);
     }
   }
+  if constexpr (BBK) {
+    // fixed-order sum over the waves of both accumulator sets (upper tile triangle) and of the r_fd row, then the stores with the
+    // mirrored tiles
+    constexpr int NTRI = RT * (RT + 1) / 2;
+    double* lfd = lds + 2 * NTRI * 256;
+    for (int w = NW - 1; w > 0; --w) {
+      __syncthreads();
+      if (wave == w) {
+        int tix = 0;
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = i; j < CT; ++j, ++tix)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              lds[(tix * 4 + r) * 64 + lane] = acc[i][j][r];
+              lds[((NTRI + tix) * 4 + r) * 64 + lane] = accd[i][j][r];
+            }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) lfd[j * 64 + lane] = fd[j];
+      }
+      __syncthreads();
+      if (wave == w - 1) {
+        int tix = 0;
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = i; j < CT; ++j, ++tix)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              acc[i][j][r] += lds[(tix * 4 + r) * 64 + lane];
+              accd[i][j][r] += lds[((NTRI + tix) * 4 + r) * 64 + lane];
+            }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) fd[j] += lfd[j * 64 + lane];
+      }
+    }
+    if (wave == 0) {
+      double* o2 = a.out2 + (long)s * QN * QN;
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = i; j < CT; ++j) {
+          const int col = WIDE ? li * CT + j : j * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = WIDE ? (lk + 4 * r) * RT + i : i * 16 + lk + 4 * r;
+            if (row < Mx && col < My) {
+              out[(long)row * My + col] = acc[i][j][r];
+              o2[(long)row * My + col] = accd[i][j][r];
+              if (i != j) {
+                out[(long)col * My + row] = acc[i][j][r];
+                o2[(long)col * My + row] = accd[i][j][r];
+              }
+            }
+          }
+        }
+      if (lk == 0) {
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          const int col = WIDE ? li * CT + j : j * 16 + li;
+          if (col < My) a.out3[(long)s * QN + col] = fd[j];
+        }
+      }
+    }
+    return;
+  }
   // ---- fixed-order sum over the waves: acc_0 + (acc_1 + (... + acc_{NW-1}))
   for (int w = NW - 1; w > 0; --w) {
     __syncthreads();
@@ -953,13 +919,14 @@ __global__ __launch_bounds__(pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1))) v
 template <int KIND, int RT, int CT>
 void launch_pg(const GA& a, int batch, int nw, hipStream_t st) {
   batch = batch / a.t.S * ((a.t.S + 7) / 8 * 8);     // whole chunks of 8 subdomains (k3_pg: XCD-aware block ids)
-  constexpr int maxt = pg_max_threads(RT * CT * (KIND == G_NC ? 2 : 1));     // NC also holds the node averages of its operands
+  constexpr int maxt = pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT * CT * (KIND == G_NC ? 2 : 1));   // NC also holds the node averages of its operands; BB: two upper tile triangles
   if (nw * 64 > maxt) nw = maxt / 64;
   constexpr bool EVEN = RT % 2 == 0 && CT % 2 == 0;
+  const size_t ldsb = sizeof(double) * (KIND == G_BB ? RT * (RT + 1) * 256 + CT * 64 : RT * CT * 256);   // BB: two upper triangles + r_fd
   if (EVEN && a.N % 2 == 0)
-    hipLaunchKernelGGL((k3_pg<KIND, RT, CT, EVEN>), dim3(batch), dim3(64 * nw), sizeof(double) * RT * CT * 256, st, a);
+    hipLaunchKernelGGL((k3_pg<KIND, RT, CT, EVEN>), dim3(batch), dim3(64 * nw), ldsb, st, a);
   else
-    hipLaunchKernelGGL((k3_pg<KIND, RT, CT, false>), dim3(batch), dim3(64 * nw), sizeof(double) * RT * CT * 256, st, a);
+    hipLaunchKernelGGL((k3_pg<KIND, RT, CT, false>), dim3(batch), dim3(64 * nw), ldsb, st, a);
 }
 
 // tile shapes: square (rt == ct) for everything but AB, where ct = tiles of Q N >= rt = tiles of N
@@ -976,58 +943,32 @@ int dispatch_pg(const GA& a, int batch, int rt, int ct, int nw, hipStream_t st) 
   return -1;
 }
 
-// rhs_red [S][N] = V^T b,  r_fd [S][QN] = sum_e bdiv_e div R_self|_e.  256 threads = G row groups x CW column lanes
-// (CW = 32 for <= 32 columns), four independent partial sums per thread so that the loads of four rows are in flight together.
-__global__ __launch_bounds__(256) void k3_vecs(T3 t, int Q, int N, const double* __restrict__ V, const double* __restrict__ b,
-                                               const double* __restrict__ bdiv, const double* __restrict__ Rs,
-                                               double* __restrict__ rhs_red, double* __restrict__ r_fd, int mode) {
+// rhs_red [S][N] = V^T b.  256 threads = G row groups x CW column lanes (CW = 32 for <= 32 columns), four independent partial
+// sums per thread so that the loads of four rows are in flight together.  (r_fd comes out of k3_pg<BB>.)
+__global__ __launch_bounds__(256) void k3_vecs(T3 t, int N, const double* __restrict__ V, const double* __restrict__ b,
+                                               double* __restrict__ rhs_red) {
   __shared__ double red[256];
-  const int s = blockIdx.x, tid = threadIdx.x, QN = Q * N;
-  if (mode & 1) {
-    const int CW = N <= 32 ? 32 : 64, G = 256 / CW, c = tid % CW, g = tid / CW;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (c < N) {
-      const double* v = V + (long)s * t.n * N + c;
-      const double* bs = b + (long)s * t.n;
-      int kr = g;
-      for (; kr + 3 * G < t.n; kr += 4 * G) {
-        a0 += bs[kr] * v[(long)kr * N];
-        a1 += bs[kr + G] * v[(long)(kr + G) * N];
-        a2 += bs[kr + 2 * G] * v[(long)(kr + 2 * G) * N];
-        a3 += bs[kr + 3 * G] * v[(long)(kr + 3 * G) * N];
-      }
-      for (; kr < t.n; kr += G) a0 += bs[kr] * v[(long)kr * N];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int CW = N <= 32 ? 32 : 64, G = 256 / CW, c = tid % CW, g = tid / CW;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (c < N) {
+    const double* v = V + (long)s * t.n * N + c;
+    const double* bs = b + (long)s * t.n;
+    int kr = g;
+    for (; kr + 3 * G < t.n; kr += 4 * G) {
+      a0 += bs[kr] * v[(long)kr * N];
+      a1 += bs[kr + G] * v[(long)(kr + G) * N];
+      a2 += bs[kr + 2 * G] * v[(long)(kr + 2 * G) * N];
+      a3 += bs[kr + 3 * G] * v[(long)(kr + 3 * G) * N];
     }
-    red[tid] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (g == 0 && c < N) {
-      double acc = 0.0;
-      for (int k = 0; k < G; ++k) acc += red[k * CW + c];
-      rhs_red[(long)s * N + c] = acc;
-    }
-    __syncthreads();
+    for (; kr < t.n; kr += G) a0 += bs[kr] * v[(long)kr * N];
   }
-  if (mode & 2) {
-    const int CW = QN <= 32 ? 32 : 64, G = 256 / CW, c = tid % CW, g = tid / CW;
+  red[tid] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && c < N) {
     double acc = 0.0;
-    if (c < QN) {
-      const double* rs = Rs + (long)s * t.nrt * QN + c;
-      for (int e = g; e < t.nT; e += G) {
-        const int ty = t.elem_type[e];
-        const int4 rt = *reinterpret_cast<const int4*>(t.elem_rt + e * 4);
-        const double r0 = rs[(long)rt.x * QN], r1 = rs[(long)rt.y * QN], r2 = rs[(long)rt.z * QN], r3 = rs[(long)rt.w * QN];
-        const double dv = sgn3(t, s, e, 0) * t.divc[ty * 4] * r0 + sgn3(t, s, e, 1) * t.divc[ty * 4 + 1] * r1 +
-                          sgn3(t, s, e, 2) * t.divc[ty * 4 + 2] * r2 + sgn3(t, s, e, 3) * t.divc[ty * 4 + 3] * r3;
-        acc += bdiv[(long)s * t.nT + e] * dv;
-      }
-    }
-    red[tid] = acc;
-    __syncthreads();
-    if (g == 0 && c < QN) {
-      double a = 0.0;
-      for (int k = 0; k < G; ++k) a += red[k * CW + c];
-      r_fd[(long)s * QN + c] = a;
-    }
+    for (int k = 0; k < G; ++k) acc += red[k * CW + c];
+    rhs_red[(long)s * N + c] = acc;
   }
 }
 
@@ -1638,7 +1579,7 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
   HIP3(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP3(ctx, hipStreamWaitEvent(sf, ctx->ev_fork, 0));
   HIP3(ctx, hipStreamWaitEvent(sn, ctx->ev_fork, 0));
-  GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr, Zb};
+  GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr, Zb, G_rdd, r_fd, bdiv};
   const int tn = (N + 15) / 16, tq = (Q * N + 15) / 16;
   static const int nw_env = getenv("LRBMS3_NW") ? atoi(getenv("LRBMS3_NW")) : 0;   // experiment knob: waves per workgroup
   const int nw = nw_env > 0 ? nw_env : 4;
@@ -1689,21 +1630,12 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
   }
   if (bad) return fail3(ctx, LRBMS_E_INVALID, "project_estimate: unsupported tile shape");
   {
-    KScope3 k(ctx, "k3_gram<RDD>", sf);
-    a.out = G_rdd;
-    hipLaunchKernelGGL(k3_gram<G_RDD>, dim3(t.S), dim3(256), 0, sf, a);
-  }
-  {
-    KScope3 k(ctx, "k3_vecs<rhs>", st);
-    hipLaunchKernelGGL(k3_vecs, dim3(t.S), dim3(256), 0, st, t, Q, N, V, b, bdiv, Rs, rhs_red, r_fd, 1);
+    KScope3 k(ctx, "k3_vecs", st);
+    hipLaunchKernelGGL(k3_vecs, dim3(t.S), dim3(256), 0, st, t, N, V, b, rhs_red);
   }
   {
     KScope3 k(ctx, "k3_side_flux", sf);
     hipLaunchKernelGGL(k3_side_flux, dim3(t.nbf, t.S), dim3(64), 0, sf, t, Q, N, V, Aab, Bbb, Rs, Yb, Dp, Xab);
-  }
-  {
-    KScope3 k(ctx, "k3_vecs<rfd>", sf);
-    hipLaunchKernelGGL(k3_vecs, dim3(t.S), dim3(256), 0, sf, t, Q, N, V, b, bdiv, Rs, rhs_red, r_fd, 2);
   }
   HIP3(ctx, hipEventRecord(ctx->ev_join[0], sf));
   HIP3(ctx, hipEventRecord(ctx->ev_join[1], sn));
