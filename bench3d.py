@@ -26,11 +26,14 @@ PEAK_FP64_MFMA_TFLOPS = 78.6
 MFMA_FLOPS = 2 * 16 * 16 * 4
 
 
-def mfma_counts(n_T, ncf, N, Q):
+def mfma_counts(t, N, Q):
     """Executed v_mfma_f64_16x16x4 per subdomain and kernel of the pass (k3_pg<KIND>: per item KS * CT apply steps +
     RT * KR * CT projection steps; csrc/lrbms3d.hip)."""
     tn, tq = (N + 15) // 16, (Q * N + 15) // 16
-    per = {'k3_pg<SYS>': (13 * tn + tn * 3 * tn) * n_T * Q,
+    n_T, ncf = t.n_T, t.ncf
+    nsl = 1 + (t.up_face >= 0).sum(axis=1)                                  # slots read per element in the symmetric form of B_sys
+    sys_steps = int((2 * nsl + (nsl + 1) // 2).sum())
+    per = {'k3_pg<SYS>': (sys_steps * tn + tn * 3 * tn * n_T) * Q,
            'k3_pg<CPL>': (3 * tn + tn * 3 * tn) * ncf * 6 * Q,
            'k3_pg<AAA>': (3 * tn + tn * 3 * tn) * n_T * (Q * (Q + 1) // 2),      # pairs q <= q', mirrored at the store
            'k3_pg<NC>': (3 * tn + tn * 3 * tn) * n_T,
@@ -151,7 +154,7 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
     agg = {}
     for name, v in rows:
         agg.setdefault(name, []).append(v)
-    counts = mfma_counts(t.n_T, t.ncf, N, Q)
+    counts = mfma_counts(t, N, Q)
     table = []
     for name, v in sorted(agg.items(), key=lambda kv: -np.mean(kv[1])):
         us = 1e3 * float(np.mean(v))

@@ -39,6 +39,7 @@ typedef struct {
   int32_t hat_stride, f_stride;                   /* lambda_hat and f records: volB | volC;  lambda_bar record: volB */
   double volume, kmin;                            /* |T|; smallest eigenvalue of the symmetric part of kappa */
   const int32_t *elem_type;                       /* [n_T] 0..5 */
+  const int32_t *up_face;                         /* [n_T][4] faces whose inner neighbour has the higher element index (-1 padded) */
   const int32_t *order;                           /* [n_T] traversal order of the element loops (a permutation; cache locality only) */
   const int32_t *nb_elem, *nb_out, *face_pos, *tsign, *elem_rt;   /* [n_T][4]: inner neighbour or -(1+side); the neighbour's
                                                      element across a side face; position on the side; RT0 orientation; RT0 DoF */

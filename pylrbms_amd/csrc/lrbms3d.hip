@@ -28,7 +28,7 @@ struct T3 {
   int nA, nB, nC, nFs, nFf, o_fs, o_ff, o_c, lam_stride, hat_stride, f_stride;
   double volume, kmin;
   const int *nbr, *phys;
-  const int *elem_type, *order, *nb_elem, *nb_out, *face_pos, *tsign, *elem_rt, *rt_e0, *rt_f0, *rt_e1, *rt_f1;
+  const int *elem_type, *up_face, *order, *nb_elem, *nb_out, *face_pos, *tsign, *elem_rt, *rt_e0, *rt_f0, *rt_e1, *rt_f1;
   const int *side_elem, *side_face, *side_elem_out, *side_face_out;
   const int *dof_node, *node_ptr, *node_dofs, *node_mask, *node_count, *side_nodes, *sn_ptr, *sn_dofs;
   const int *dof_bslot, *bnodes, *bnode_sides, *bel_elem, *bel_bnode, *sel_elem, *sel_sf;
@@ -377,7 +377,7 @@ __device__ inline double2 ld16(const double* base, unsigned byte_off) {
 // SIMDs at a fixed number of cycles per instruction, and with 45 eight-byte loads per 38 MFMAs it, not the matrix pipe, set
 // the pace.
 template <int KIND, int RT, int CT, bool WIDE>
-__global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT * CT * (KIND == G_NC ? 2 : 1))) void k3_pg(GA a) {
+__global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT * CT * (KIND == G_NC || KIND == G_SYS ? 2 : 1))) void k3_pg(GA a) {
   extern __shared__ double lds[];   // [RT * CT][256]
   constexpr int MZ = PGT<KIND>::MZ, KY = PGT<KIND>::KY, KR = (MZ + 3) / 4;
   constexpr int NG = KY == 50 ? 5 : 1;                       // neighbour slots whose rows the apply reads
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
   // index tables of an item (fetched one item ahead): element, its neighbours (SYS), node / RT0 numbers of this lane's rows
   struct Idx {
     int e, eo;
-    int nb[4];
+    int nb[4], up[4];
     int aux[KR], auy[KR];
   };
   const int last = nitems - 1;
@@ -529,6 +529,8 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
     if (KIND == G_SYS) {
       const int4 v = *reinterpret_cast<const int4*>(t.nb_elem + item * 4);
       ix.nb[0] = v.x; ix.nb[1] = v.y; ix.nb[2] = v.z; ix.nb[3] = v.w;
+      const int4 u = *reinterpret_cast<const int4*>(t.up_face + item * 4);
+      ix.up[0] = u.x; ix.up[1] = u.y; ix.up[2] = u.z; ix.up[3] = u.w;
     }
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
@@ -556,6 +558,26 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
       for (int j = 0; j < CT; ++j) accd[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < CT; ++j) fd[j] = 0.0;
+  }
+  // B_sys: lane constants of the symmetric form (below)
+  unsigned sl_full, sy_full[2][CT], sl_rem, sy_rem[CT];
+  if constexpr (KIND == G_SYS) {
+    sl_full = 8u * (lic * 10 + (WIDE ? 2 * lk : lk));                 // rows j = 2 lk, 2 lk + 1 (one 16-byte load) / j = lk, 4 + lk
+    sl_rem = 8u * (lic * 10 + 8 + (lk & 1));
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      int col;
+      if (WIDE) {
+        const int c0 = li * CT + (ct & ~1);
+        col = (c0 + 1 < N ? c0 : N - 2) + (ct & 1);
+      } else {
+        const int col0 = ct * 16 + li;
+        col = col0 < N ? col0 : N - 1;
+      }
+#pragma unroll
+      for (int par = 0; par < 2; ++par) sy_full[par][ct] = (unsigned)(WIDE ? 2 * lk + par : 4 * par + lk) * rowb + 8u * col;
+      sy_rem[ct] = (unsigned)(8 + (lk & 1)) * rowb + 8u * col;
+    }
   }
   // G_ab: lane constants of its own form (below)
   unsigned abl[3], abv[3][RT];
@@ -585,6 +607,113 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
   load_idx(wave, ix1);
   for (int item0 = wave; item0 < nitems; item0 += NW) {
     const int item = item0 < last ? item0 : last;
+    if constexpr (KIND == G_SYS) {
+      // Symmetric form: A[e', e] = A[e, e']^T, so with H = sum_e V_e^T (1/2 A_ee V_e + sum_{e' > e} A[e, e'] V_e') the projection is
+      // B = H + H^T (epilogue).  Per element only the diagonal block and the blocks towards the neighbours with the HIGHER index
+      // are read (t.up_face, on average 1.75 of 3.5 inner faces): 55 % of the A_diag bytes and of the neighbour rows, and
+      // 2 s + ceil(s / 2) k-steps for s = 1 + #upper slots instead of 13.  Slots are wave-uniform, skipped slots cost nothing.
+      const int e = ix1.e;
+      const double* Lb = Lall + (long)e * LSTRIDE;
+      const unsigned ex = (unsigned)e * erow;
+      const int nsl = 1 + (ix1.up[0] >= 0) + (ix1.up[1] >= 0) + (ix1.up[2] >= 0) + (ix1.up[3] >= 0);
+      unsigned ebs[5], bos[5];
+      ebs[0] = ex;
+      bos[0] = 0u;
+#pragma unroll
+      for (int g = 1; g < 5; ++g) {
+        const int f = ix1.up[g - 1], fc = f < 0 ? 0 : f;
+        const int ee = fc == 0 ? ix1.nb[0] : (fc == 1 ? ix1.nb[1] : (fc == 2 ? ix1.nb[2] : ix1.nb[3]));
+        ebs[g] = (unsigned)(f < 0 ? e : ee) * erow;
+        bos[g] = f < 0 ? 0u : 800u * (1 + fc);
+      }
+      double lop[13], yv[CT][13], xop[RT][KR];
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        if (g < nsl) {                                    // wave-uniform
+          if (WIDE) {
+            const double2 v = ld16(Lb, bos[g] + sl_full);
+            lop[2 * g] = v.x;
+            lop[2 * g + 1] = v.y;
+          } else {
+            lop[2 * g] = ld8(Lb, bos[g] + sl_full);
+            lop[2 * g + 1] = ld8(Lb, bos[g] + sl_full + 32u);
+          }
+#pragma unroll
+          for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              if (WIDE) {
+                if ((ct & 1) == 0) {
+                  const double2 v = ld16(Vs, ebs[g] + sy_full[par][ct]);
+                  yv[ct][2 * g + par] = v.x;
+                  yv[ct + 1 < CT ? ct + 1 : ct][2 * g + par] = v.y;
+                }
+              } else {
+                yv[ct][2 * g + par] = ld8(Vs, ebs[g] + sy_full[par][ct]);
+              }
+            }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {                       // rows 8, 9 of slots 2 r (lanes lk < 2) and 2 r + 1 (lanes lk >= 2)
+        if (2 * r < nsl) {
+          const int gB = 2 * r + 1 < 5 ? 2 * r + 1 : 2 * r;
+          const bool hasB = 2 * r + 1 < nsl;
+          const unsigned eo = (lk < 2 || !hasB) ? ebs[2 * r] : ebs[gB];
+          const unsigned bo = (lk < 2 || !hasB) ? bos[2 * r] : bos[gB];
+          lop[10 + r] = (lk >= 2 && !hasB) ? *zero : ld8(Lb, bo + sl_rem);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            if (WIDE) {
+              if ((ct & 1) == 0) {
+                const double2 v = ld16(Vs, eo + sy_rem[ct]);
+                yv[ct][10 + r] = v.x;
+                yv[ct + 1 < CT ? ct + 1 : ct][10 + r] = v.y;
+              }
+            } else {
+              yv[ct][10 + r] = ld8(Vs, eo + sy_rem[ct]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < KR; ++r)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          if (WIDE) {
+            if ((rt & 1) == 0) {
+              const double2 v = xin[r] ? ld16(Vs, ex + xc[r][rt]) : *reinterpret_cast<const double2*>(t.zeros);
+              xop[rt][r] = v.x;
+              xop[rt + 1 < RT ? rt + 1 : rt][r] = v.y;
+            }
+          } else {
+            xop[rt][r] = xin[r] ? ld8(Vs, ex + xc[r][rt]) : *zero;
+          }
+        }
+      load_idx(item0 + NW, ix2);
+      ix1 = ix2;
+      lop[0] *= 0.5;                                      // the diagonal block enters H with the factor 1/2
+      lop[1] *= 0.5;
+      lop[10] *= lk < 2 ? 0.5 : 1.0;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        d4 z = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < 5; ++g)
+          if (g < nsl) {
+            z = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[2 * g], yv[ct][2 * g], z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[2 * g + 1], yv[ct][2 * g + 1], z, 0, 0, 0);
+          }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          if (2 * r < nsl) z = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[10 + r], yv[ct][10 + r], z, 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < KR; ++r) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[rt][r], z[r], acc[rt][ct], 0, 0, 0);
+      }
+      continue;
+    }
     if constexpr (KIND == G_BB) {
       // Three operators of the four RT0 rows R_e of an element, one set of loads:
       //   G_bb  += R_e^T (B_bb R_e)                        apply (A operand B_bb, symmetric) + projection, upper tile triangle
@@ -896,6 +1025,28 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
           for (int r = 0; r < 4; ++r) acc[i][j][r] += lds[((i * CT + j) * 4 + r) * 64 + lane];
     }
   }
+  if constexpr (KIND == G_SYS) {       // B = H + H^T through the LDS (Mx My <= RT CT 256 doubles)
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          const int col = WIDE ? li * CT + j : j * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = WIDE ? (lk + 4 * r) * RT + i : i * 16 + lk + 4 * r;
+            if (row < Mx && col < My) lds[row * My + col] = acc[i][j][r];
+          }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < Mx * My; i += blockDim.x) {
+      const int row = i / My, col = i - row * My;
+      out[i] = lds[i] + lds[col * My + row];
+    }
+    return;
+  }
   if (wave == 0) {
     double* mirror = nullptr;       // AAA: block (q2, q) = transpose of block (q, q2)
     if (KIND == G_AAA && q != q2) mirror = a.out + (((long)q2 * Q + q) * t.S + s) * N * N;
@@ -919,7 +1070,7 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
 template <int KIND, int RT, int CT>
 void launch_pg(const GA& a, int batch, int nw, hipStream_t st) {
   batch = batch / a.t.S * ((a.t.S + 7) / 8 * 8);     // whole chunks of 8 subdomains (k3_pg: XCD-aware block ids)
-  constexpr int maxt = pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT * CT * (KIND == G_NC ? 2 : 1));   // NC also holds the node averages of its operands; BB: two upper tile triangles
+  constexpr int maxt = pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT * CT * (KIND == G_NC || KIND == G_SYS ? 2 : 1));   // NC also holds the node averages of its operands; BB: two upper tile triangles
   if (nw * 64 > maxt) nw = maxt / 64;
   constexpr bool EVEN = RT % 2 == 0 && CT % 2 == 0;
   const size_t ldsb = sizeof(double) * (KIND == G_BB ? RT * (RT + 1) * 256 + CT * 64 : RT * CT * 256);   // BB: two upper triangles + r_fd
@@ -1478,7 +1629,7 @@ int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, in
   const long nT = t.nT, n = t.n;
   int rc;
 #define UP(field, count) if ((rc = upload(ctx, d->field, (long)(count), &t.field)) != LRBMS_OK) return rc
-  UP(elem_type, nT); UP(order, nT); UP(nb_elem, nT * 4); UP(nb_out, nT * 4); UP(face_pos, nT * 4); UP(tsign, nT * 4); UP(elem_rt, nT * 4);
+  UP(elem_type, nT); UP(up_face, nT * 4); UP(order, nT); UP(nb_elem, nT * 4); UP(nb_out, nT * 4); UP(face_pos, nT * 4); UP(tsign, nT * 4); UP(elem_rt, nT * 4);
   UP(rt_e0, t.nrt); UP(rt_f0, t.nrt); UP(rt_e1, t.nrt); UP(rt_f1, t.nrt);
   UP(side_elem, t.nbf); UP(side_face, t.nbf); UP(side_elem_out, t.nbf); UP(side_face_out, t.nbf);
   UP(dof_node, n); UP(node_ptr, t.nnodes + 1); UP(node_dofs, n); UP(node_mask, t.nnodes); UP(node_count, t.nnodes);

@@ -216,6 +216,13 @@ class SubdomainTemplate3D:
                     side_lists[side].append((e, f, int(local_index[E2]), f2))
                     tsign[e, f] = -1 if side < 3 else 1                               # the neighbour with the lower id is "minus"
         self.nb_elem, self.nb_face, self.nb_out, self.face_pos, self.tsign = nb_elem, nb_face, nb_out, face_pos, tsign
+        # faces whose inner neighbour has the HIGHER element index (compact list, -1 padded): the symmetric form of the system
+        # projection reads the diagonal block and these blocks only (A[e', e] = A[e, e']^T)
+        up = np.full((nT, 4), -1, dtype=np.int32)
+        for e in range(nT):
+            fs = [f for f in range(4) if nb_elem[e, f] > e]
+            up[e, :len(fs)] = fs
+        self.up_face = up
         self.nb_type, self.nb_face_of_type, self.nb_cube_off = nb_type, nb_face_of_type, nb_cube_off
         ncf = max(len(s) for s in side_lists)
         self.ncf, self.nbf = ncf, 6 * ncf
