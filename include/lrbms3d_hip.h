@@ -51,6 +51,7 @@ typedef struct {
   const int32_t *side_nodes;                      /* [6][nvs] node at position p of side a (-1 padded) */
   const int32_t *sn_ptr, *sn_dofs;                /* CSR (side, pos) -> the NEIGHBOUR's DoFs at that node: [6 nvs + 1], [...] */
   const int32_t *dof_bslot;                       /* [n] compact index (0 .. nbd-1) of a DoF on a boundary node, else -1 */
+  const int32_t *bn_ptr, *bn_slots;               /* CSR boundary node -> compact indices of its own DoFs: [nb + 1], [nbd] */
   const int32_t *bnodes, *bnode_sides;            /* [nb] boundary nodes; [nb][3] their (side * nvs + pos) memberships, -1 padded */
   const int32_t *bel_elem, *bel_bnode;            /* [nbel] elements with a boundary node; [nbel][10] boundary-node index per DoF or -1 */
   const int32_t *sel_elem, *sel_sf;               /* [nsel] elements with a side face; [nsel][4] side-face index per face or -1 */

@@ -10,7 +10,7 @@ _INT_FIELDS = ('n_T', 'n_rt', 'ncf', 'nvs', 'n_nodes', 'nb', 'nbel', 'nsel', 'nb
                'lam_stride', 'hat_stride', 'f_stride')
 _I32_TABLES = ('elem_type', 'up_face', 'order', 'nb_elem', 'nb_out', 'face_pos', 'tsign', 'elem_rt', 'rt_e0', 'rt_f0', 'rt_e1', 'rt_f1', 'side_elem',
                'side_face', 'side_elem_out', 'side_face_out', 'dof_node', 'node_ptr', 'node_dofs', 'node_mask', 'node_count',
-               'side_nodes', 'sn_ptr', 'sn_dofs', 'dof_bslot', 'bnodes', 'bnode_sides', 'bel_elem', 'bel_bnode', 'sel_elem', 'sel_sf')
+               'side_nodes', 'sn_ptr', 'sn_dofs', 'dof_bslot', 'bn_ptr', 'bn_slots', 'bnodes', 'bnode_sides', 'bel_elem', 'bel_bnode', 'sel_elem', 'sel_sf')
 _DBL_TABLES = ('divc', 'TV', 'TE', 'TAA', 'TFo', 'TFn', 'TFb', 'TC', 'TCb', 'TPH', 'TM', 'TB', 'TAB', 'WB', 'WC')
 
 

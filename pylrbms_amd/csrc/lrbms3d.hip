@@ -31,7 +31,7 @@ struct T3 {
   const int *elem_type, *up_face, *order, *nb_elem, *nb_out, *face_pos, *tsign, *elem_rt, *rt_e0, *rt_f0, *rt_e1, *rt_f1;
   const int *side_elem, *side_face, *side_elem_out, *side_face_out;
   const int *dof_node, *node_ptr, *node_dofs, *node_mask, *node_count, *side_nodes, *sn_ptr, *sn_dofs;
-  const int *dof_bslot, *bnodes, *bnode_sides, *bel_elem, *bel_bnode, *sel_elem, *sel_sf;
+  const int *dof_bslot, *bn_ptr, *bn_slots, *bnodes, *bnode_sides, *bel_elem, *bel_bnode, *sel_elem, *sel_sf;
   const double *divc, *TV, *TE, *TAA, *TFo, *TFn, *TFb, *TC, *TCb, *TPH, *TM, *TB, *TAB, *WB, *WC;
   const double* zeros;   // [64] zeros: target of the loads of padding lanes
 };
@@ -1156,15 +1156,23 @@ __global__ __launch_bounds__(64) void k3_side_flux(T3 t, int Q, int N, const dou
   }
 }
 
-// Cn [S][nb][N] = -(P^T E W_self) at the boundary nodes: sum of the rows k3_pg<NC> left in Zb over the DoFs of the node
+// Cn [S][nb][N] = -(P^T E W_self) at the boundary nodes: sum of the rows k3_pg<NC> left in Zb over the DoFs of the node.
+// One wave per node, its slot list through the scalar cache.
 __global__ __launch_bounds__(256) void k3_side_nc(T3 t, int N, const double* __restrict__ Zb, double* __restrict__ Cn) {
-  const int s = blockIdx.y, c = threadIdx.x & 63, bn = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= N || bn >= t.nb) return;
-  const int node = t.bnodes[bn];
-  const double* z = Zb + (long)s * t.nbd * N + c;
-  double acc = 0.0;
-  for (int p = t.node_ptr[node]; p < t.node_ptr[node + 1]; ++p) acc += z[(long)t.dof_bslot[t.node_dofs[p]] * N];
-  Cn[((long)s * t.nb + bn) * N + c] = -acc;
+  const int s = blockIdx.y, c = threadIdx.x & 63;
+  const int bn = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (bn >= t.nb) return;
+  const int cc = c < N ? c : N - 1;
+  const double* z = Zb + (long)s * t.nbd * N + cc;
+  const int p0 = t.bn_ptr[bn], p1 = t.bn_ptr[bn + 1];
+  double a0 = 0.0, a1 = 0.0;
+  int p = p0;
+  for (; p + 1 < p1; p += 2) {
+    a0 += z[(long)t.bn_slots[p] * N];
+    a1 += z[(long)t.bn_slots[p + 1] * N];
+  }
+  if (p < p1) a0 += z[(long)t.bn_slots[p] * N];
+  if (c < N) Cn[((long)s * t.nb + bn) * N + c] = -(a0 + a1);
 }
 
 // ------------------------------------------------------------------------------------------------- online: estimate
@@ -1635,7 +1643,7 @@ int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, in
   UP(dof_node, n); UP(node_ptr, t.nnodes + 1); UP(node_dofs, n); UP(node_mask, t.nnodes); UP(node_count, t.nnodes);
   UP(side_nodes, 6 * t.nvs); UP(sn_ptr, 6 * t.nvs + 1);
   UP(sn_dofs, d->sn_ptr[6 * t.nvs]);
-  UP(dof_bslot, n); UP(bnodes, t.nb); UP(bnode_sides, t.nb * 3); UP(bel_elem, t.nbel); UP(bel_bnode, t.nbel * 10); UP(sel_elem, t.nsel);
+  UP(dof_bslot, n); UP(bn_ptr, t.nb + 1); UP(bn_slots, t.nbd); UP(bnodes, t.nb); UP(bnode_sides, t.nb * 3); UP(bel_elem, t.nbel); UP(bel_bnode, t.nbel * 10); UP(sel_elem, t.nsel);
   UP(sel_sf, t.nsel * 4);
   UP(divc, 24);
   UP(TV, 6L * t.nA * 100); UP(TE, 6L * t.nB * 100); UP(TAA, 6L * t.nC * 100);
@@ -1726,7 +1734,9 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
   //   aux 1            node averages  ->  G_nc, side-node factors
   // (while per-kernel timing is on, everything runs on the caller's stream: overlapping kernels would stretch each other's
   // event intervals)
-  hipStream_t sf = ctx->ktime ? st : ctx->aux[0], sn = ctx->ktime ? st : ctx->aux[1];
+  static const bool serial_env = getenv("LRBMS3_SERIAL") != nullptr;      // profiling knob: rocprofv3 kernel statistics of a serial pass
+  const bool serial = ctx->ktime || serial_env;
+  hipStream_t sf = serial ? st : ctx->aux[0], sn = serial ? st : ctx->aux[1];
   HIP3(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP3(ctx, hipStreamWaitEvent(sf, ctx->ev_fork, 0));
   HIP3(ctx, hipStreamWaitEvent(sn, ctx->ev_fork, 0));

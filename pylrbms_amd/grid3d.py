@@ -332,6 +332,11 @@ class SubdomainTemplate3D:
         onb = dofb.reshape(-1) >= 0
         self.nbd = int(onb.sum())
         self.dof_bslot = np.where(onb, np.cumsum(onb) - 1, -1).astype(np.int32)
+        ptr, idx = [0], []
+        for g in bn:                                     # boundary node -> compact slots of its own DoFs (k3_side_nc)
+            idx.extend(int(self.dof_bslot[d]) for d in self.node_dofs[self.node_ptr[g]:self.node_ptr[g + 1]])
+            ptr.append(len(idx))
+        self.bn_ptr, self.bn_slots = np.array(ptr, dtype=np.int32), np.array(idx, dtype=np.int32)
         sf = np.where(nb_elem < 0, (-(nb_elem + 1)) * ncf + face_pos, -1)
         sel = np.nonzero(np.any(sf >= 0, axis=1))[0]
         self.sel_elem, self.sel_sf = sel.astype(np.int32), np.ascontiguousarray(sf[sel].astype(np.int32))
