@@ -237,52 +237,88 @@ __global__ __launch_bounds__(64) void k3_assemble_flux(T3 t, const double* __res
 // One wave per row: the row's elements, orientation and the ten flux coefficients per (element, q) are wave-uniform and come
 // through the scalar cache; the only vector-memory instructions are the loads of the basis rows (the address unit, not the
 // HBM, bounds these kernels).
+constexpr int FLUX_R = 1;     // rows per wave (4 rows with their loads grouped was measured: slower)
+
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The row blocks of one subdomain read overlapping basis
+// rows, so a 1D grid is decoded such that all blocks of a subdomain get ids that are equal modulo 8 (one XCD) and close in time:
+// chunks of 8 subdomains, inside a chunk the subdomain is the fast index.  Returns false for the padding of the last chunk.
+__device__ inline bool xcd_block(int nblk, int S, int& xblk, int& s) {
+  const int L = blockIdx.x, chunk = L / (8 * nblk), in = L - chunk * 8 * nblk;
+  s = chunk * 8 + (in & 7);
+  xblk = in >> 3;
+  return s < S;
+}
+inline unsigned xcd_grid(int nblk, int S) { return (unsigned)((S + 7) / 8 * 8 * nblk); }
+
 __global__ __launch_bounds__(256) void k3_flux(T3 t, int Q, int N, const double* __restrict__ V, const double* __restrict__ Cf,
                                                double* __restrict__ Rs, double* __restrict__ Rb) {
-  const int s = blockIdx.y, QN = Q * N;
-  const int c = threadIdx.x & 63;
-  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (row >= t.nrt + t.nbf) return;
-  const int cc = c < QN ? c : QN - 1;
-  const int q = cc / N, j = cc - q * N;
-  int es[2], fs[2], ss[2], sg[2];
-  if (row < t.nrt) {
-    es[0] = t.rt_e0[row]; fs[0] = t.rt_f0[row]; es[1] = t.rt_e1[row]; fs[1] = t.rt_f1[row];
-    ss[0] = ss[1] = s;
-    sg[0] = sgn3(t, s, es[0], fs[0]);
-    sg[1] = es[1] >= 0 ? sgn3(t, s, es[1], fs[1]) : 0;
-  } else {
-    const int sf = row - t.nrt;
-    const int t2 = t.nbr[s * 7 + side_slot(sf / t.ncf)];
-    es[0] = t.side_elem_out[sf]; fs[0] = t.side_face_out[sf]; es[1] = -1; fs[1] = 0;
-    ss[0] = ss[1] = t2;
-    sg[0] = sg[1] = 0;
-    if (t2 >= 0 && es[0] >= 0) sg[0] = t.tsign[es[0] * 4 + fs[0]];      // a coupling face of the neighbour: its template orientation
-    else es[0] = -1;
-  }
-  double acc = 0.0;
+  const int QN = Q * N, nrows = t.nrt + t.nbf;
+  int s, xblk;
+  if (!xcd_block((nrows + 4 * FLUX_R - 1) / (4 * FLUX_R), t.S, xblk, s)) return;
+  const int lane = threadIdx.x & 63, half = lane >> 5, jl = lane & 31;
+  const int row0 = __builtin_amdgcn_readfirstlane((xblk * 4 + (threadIdx.x >> 6)) * FLUX_R);
+  if (row0 >= nrows) return;
+  // The (<= 2) elements of a face are dealt to the two halves of the wave: lanes 0..31 take the first, lanes 32..63 the second,
+  // lane = basis column.  Every basis row is loaded once per face (ten instead of twenty vector-memory instructions), both affine
+  // components are formed in the lane from wave-uniform coefficients, and the halves meet through one lane exchange.
+  const double* c0[FLUX_R];
+  const double* c1[FLUX_R];
+  double sgh[FLUX_R];
+  long vrow[FLUX_R];
+  double* dst[FLUX_R];
+  bool on[FLUX_R];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    if (es[k] < 0) continue;                                             // wave-uniform
-    const double* v = V + ((long)ss[k] * t.n + es[k] * 10) * N + j;
-    const double* co0 = Cf + (((long)0 * t.S_ext + ss[k]) * t.nT + es[k]) * 40 + fs[k] * 10;
-    const long qstride = (long)t.S_ext * t.nT * 40;
-    double vv[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) vv[i] = v[(long)i * N];
-    double a = 0.0;
-    for (int qq = 0; qq < Q; ++qq) {                                     // uniform coefficients; the lane keeps its own q
-      const double* co = co0 + qq * qstride;
-      double aq = 0.0;
-#pragma unroll
-      for (int i = 0; i < 10; ++i) aq += co[i] * vv[i];
-      a = qq == q ? aq : a;
+  for (int r = 0; r < FLUX_R; ++r) {
+    const int row = row0 + r < nrows ? row0 + r : nrows - 1;
+    on[r] = row0 + r < nrows;
+    int es[2], fs[2], ss[2], sg[2];
+    if (row < t.nrt) {
+      es[0] = t.rt_e0[row]; fs[0] = t.rt_f0[row]; es[1] = t.rt_e1[row]; fs[1] = t.rt_f1[row];
+      ss[0] = ss[1] = s;
+      sg[0] = sgn3(t, s, es[0], fs[0]);
+      sg[1] = es[1] >= 0 ? sgn3(t, s, es[1], fs[1]) : 0;
+    } else {
+      const int sf = row - t.nrt;
+      const int t2 = t.nbr[s * 7 + side_slot(sf / t.ncf)];
+      es[0] = t.side_elem_out[sf]; fs[0] = t.side_face_out[sf]; es[1] = -1; fs[1] = 0;
+      ss[0] = ss[1] = t2;
+      sg[0] = sg[1] = 0;
+      if (t2 >= 0 && es[0] >= 0) sg[0] = t.tsign[es[0] * 4 + fs[0]];      // a coupling face of the neighbour: its template orientation
+      else es[0] = -1;
     }
-    acc += sg[k] * a;
+    if (es[0] < 0) ss[0] = 0, es[0] = 0, fs[0] = 0;                        // nothing to add: sign 0, any valid address
+    if (es[1] < 0) ss[1] = ss[0], es[1] = es[0], fs[1] = fs[0];
+    c0[r] = Cf + ((long)ss[0] * t.nT + es[0]) * 40 + fs[0] * 10;
+    c1[r] = Cf + ((long)ss[1] * t.nT + es[1]) * 40 + fs[1] * 10;
+    sgh[r] = (double)(half ? sg[1] : sg[0]);
+    vrow[r] = half ? ((long)ss[1] * t.n + es[1] * 10) : ((long)ss[0] * t.n + es[0] * 10);
+    dst[r] = row < t.nrt ? Rs + ((long)s * t.nrt + row) * QN : Rb + ((long)s * t.nbf + row - t.nrt) * QN;
   }
-  if (c < QN) {
-    if (row < t.nrt) Rs[((long)s * t.nrt + row) * QN + c] = acc;
-    else Rb[((long)s * t.nbf + row - t.nrt) * QN + c] = acc;
+  const long qstride = (long)t.S_ext * t.nT * 40;
+  for (int j0 = 0; j0 < N; j0 += 32) {
+    const int j = j0 + jl, jc = j < N ? j : N - 1;
+    double vv[FLUX_R][10];
+#pragma unroll
+    for (int r = 0; r < FLUX_R; ++r) {
+      const double* v = V + vrow[r] * N + jc;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) vv[r][i] = v[(long)i * N];
+    }
+#pragma unroll
+    for (int r = 0; r < FLUX_R; ++r)
+      for (int q = 0; q < Q; ++q) {
+        const double* a0 = c0[r] + q * qstride;
+        const double* a1 = c1[r] + q * qstride;
+        double s0 = 0.0, s1 = 0.0;          // both coefficient rows are wave-uniform (scalar loads); the lane keeps its half's sum
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          s0 += a0[i] * vv[r][i];
+          s1 += a1[i] * vv[r][i];
+        }
+        const double acc = (half ? s1 : s0) * sgh[r];
+        const double other = __shfl_xor(acc, 32);
+        if (half == 0 && j < N && on[r]) dst[r][q * N + j] = acc + other;
+      }
   }
 }
 
@@ -290,9 +326,10 @@ __global__ __launch_bounds__(256) void k3_flux(T3 t, int Q, int N, const double*
 // As [S][6][nvs][N]: the neighbours' shares at the side nodes.  One wave per node, DoF lists through the scalar cache.
 __global__ __launch_bounds__(256) void k3_node_avg(T3 t, int N, const double* __restrict__ V, double* __restrict__ Avg,
                                                    double* __restrict__ As) {
-  const int s = blockIdx.y;
+  int s, xblk;
+  if (!xcd_block((t.nnodes + 6 * t.nvs + 3) / 4, t.S, xblk, s)) return;
   const int j = threadIdx.x & 63;
-  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int row = __builtin_amdgcn_readfirstlane(xblk * 4 + (threadIdx.x >> 6));
   if (row >= t.nnodes + 6 * t.nvs) return;
   const int jc = j < N ? j : N - 1;
   const int phys = t.phys[s];
@@ -1748,11 +1785,11 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
   int bad = 0;
   {
     KScope3 k(ctx, "k3_flux", sf);
-    hipLaunchKernelGGL(k3_flux, dim3((t.nrt + t.nbf + 3) / 4, t.S), dim3(256), 0, sf, t, Q, N, V, Cf, Rs, Rb);
+    hipLaunchKernelGGL(k3_flux, dim3(xcd_grid((t.nrt + t.nbf + 4 * FLUX_R - 1) / (4 * FLUX_R), t.S)), dim3(256), 0, sf, t, Q, N, V, Cf, Rs, Rb);
   }
   {
     KScope3 k(ctx, "k3_node_avg", sn);
-    hipLaunchKernelGGL(k3_node_avg, dim3((t.nnodes + 6 * t.nvs + 3) / 4, t.S), dim3(256), 0, sn, t, N, V, Avg, As);
+    hipLaunchKernelGGL(k3_node_avg, dim3(xcd_grid((t.nnodes + 6 * t.nvs + 3) / 4, t.S)), dim3(256), 0, sn, t, N, V, Avg, As);
   }
   const int npair = Q * (Q + 1) / 2;       // A_aa: pairs q <= q', the transposed blocks are written from the same accumulators
   {
