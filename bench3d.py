@@ -221,6 +221,18 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
         res['online'] = {'metric': 'online reduced solves (O1)', 'value': 1.0 / t_solve, 'unit': 'mu-solves/s',
                          'estimates_per_s': 1.0 / t_est, 'reduced_dim': S * N, 'cg_iterations': info[0], 'relative_residual': info[1],
                          'solver': 'block-Jacobi PCG on the 7-slot block-sparse reduced system, rtol 1e-12, one parameter per call'}
+    if online:
+        # snapshot generation: one full-order solve (block-Jacobi CG on the never-assembled block operator)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        try:
+            _, finfo = eng.ctx.fom_solve(Q, np.array([1.0, 0.5]), eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=1e-8,
+                                         max_iter=20000)
+            torch.cuda.synchronize()
+            res['snapshot'] = {'metric': 'full-order solve (d.solve)', 'ms': 1e3 * (time.perf_counter() - t0), 'dofs': S * t.n,
+                               'cg_iterations': finfo[0], 'relative_residual': finfo[1], 'rtol': 1e-8}
+        except Exception as exc:                      # reported, not fatal for the bench line
+            res['snapshot'] = {'error': str(exc)}
     if base is not None:
         res['cpu_baseline'] = base
     if world > 1:

@@ -131,6 +131,13 @@ int64_t lrbms3_reduced_solve_work_size(lrbms3_ctx* ctx, int32_t N);
 int lrbms3_reduced_solve(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* B_sys, const double* rhs_red,
                          double* work, double* u, double rtol, int32_t max_iter, double* info, void* stream);
 
+/* Snapshot generation: A(mu) x = b on the never-assembled block operator, CG with the 10 x 10 element blocks as block-Jacobi
+ * preconditioner (S_ext == S).  b, x [S][n]; work: lrbms3_fom_solve_work_size doubles; info[0] = iterations, info[1] = final
+ * relative residual (host, may be NULL); LRBMS_E_NOT_CONVERGED above rtol after max_iter.  2D: lrbms_fom_solve. */
+int64_t lrbms3_fom_solve_work_size(lrbms3_ctx* ctx);
+int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const double* A_diag, const double* A_cpl, const double* b,
+                     double* work, double* x, double rtol, int32_t max_iter, double* info, void* stream);
+
 /* y [S][n][M] = sum_q theta_q (A_diag_q x_s + sum_sides A_cpl_q x_neighbour), x [S_ext][n][M].  2D: lrbms_fom_apply. */
 int lrbms3_fom_apply(lrbms3_ctx* ctx, int32_t Q, int32_t M, const double* theta, const double* A_diag, const double* A_cpl,
                      const double* x, double* y, void* stream);

@@ -35,6 +35,8 @@ SIGNATURES3 = {
     'lrbms3_reduced_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 18 + [c_dbl, c_vp, c_vp]),
     'lrbms3_reduced_solve_work_size': (c_i64, [c_vp, c_i32]),
     'lrbms3_reduced_solve': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
+    'lrbms3_fom_solve_work_size': (c_i64, [c_vp]),
+    'lrbms3_fom_solve': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms3_fom_apply': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 
@@ -247,6 +249,19 @@ class Native3DContext:
                                            float(rtol), int(max_iter), info, self._stream())
         self._check(rc, 'lrbms3_reduced_solve')
         return u, (int(info[0]), float(info[1]))
+
+    def fom_solve(self, Q, theta, A_diag, A_cpl, b, rtol=1e-10, max_iter=50000, work=None):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        if work is None:
+            work = self.empty(int(self.lib.lrbms3_fom_solve_work_size(self.handle)))
+        x = self.empty(self.S, self.n)
+        info = (c_dbl * 2)()
+        rc = self.lib.lrbms3_fom_solve(self.handle, Q, th.ctypes.data_as(_P_DBL),
+                                       self._ptr(A_diag, (Q, self.S, self.n_T, 5, 100), 'A_diag'),
+                                       self._ptr(A_cpl, (Q, self.S, 6, self.ncf, 100), 'A_cpl'), self._ptr(b, (self.S, self.n), 'b'),
+                                       c_vp(work.data_ptr()), c_vp(x.data_ptr()), float(rtol), int(max_iter), info, self._stream())
+        self._check(rc, 'lrbms3_fom_solve')
+        return x, (int(info[0]), float(info[1]))
 
     def fom_apply(self, Q, theta, A_diag, A_cpl, x):
         M = x.shape[2]

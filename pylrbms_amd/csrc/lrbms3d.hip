@@ -1591,6 +1591,142 @@ __global__ __launch_bounds__(256) void k3_fom_apply(T3 t, int Q, int M, QV th, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------- full-order solve (snapshots)
+// A(mu) x = b on the never-assembled block operator: CG with the 10 x 10 element blocks as block-Jacobi preconditioner.  The
+// operator is combined once per solve (Amu = sum_q theta_q A_q); an iteration is three kernels + three one-block reductions,
+// all scalars stay on the device.  EPB elements (10 rows each) per workgroup.
+constexpr int FOM_EPB = 24;
+
+// inverse of the diagonal 10 x 10 blocks (SPD): Gauss-Jordan, one thread per element, the block in LDS
+__global__ __launch_bounds__(64) void k3f_block_inverse(T3 t, const double* __restrict__ Amu, double* __restrict__ Dinv) {
+  __shared__ double a[64][101];
+  const int s = blockIdx.y, e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= t.nT) return;
+  double* m = a[threadIdx.x];
+  const double* src = Amu + (((long)s * t.nT + e) * 5) * 100;
+  for (int i = 0; i < 100; ++i) m[i] = src[i];
+  double inv[100];
+  for (int i = 0; i < 100; ++i) inv[i] = (i / 10 == i % 10) ? 1.0 : 0.0;
+  for (int p = 0; p < 10; ++p) {
+    const double ip = 1.0 / m[p * 10 + p];
+    for (int c = 0; c < 10; ++c) {
+      m[p * 10 + c] *= ip;
+      inv[p * 10 + c] *= ip;
+    }
+    for (int r = 0; r < 10; ++r) {
+      if (r == p) continue;
+      const double f = m[r * 10 + p];
+      for (int c = 0; c < 10; ++c) {
+        m[r * 10 + c] -= f * m[p * 10 + c];
+        inv[r * 10 + c] -= f * inv[p * 10 + c];
+      }
+    }
+  }
+  double* dst = Dinv + ((long)s * t.nT + e) * 100;
+  for (int i = 0; i < 100; ++i) dst[i] = inv[i];
+}
+
+// scal: [0] rz_old  [1] rz_new  [2] pAp  [3] rr  [4] bb
+// p = z + beta p  (beta = rz_new / rz_old, 0 in the first iteration)
+__global__ __launch_bounds__(256) void k3f_dir(long total, int first, const double* __restrict__ scal, const double* __restrict__ z,
+                                               double* __restrict__ p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const double beta = first ? 0.0 : scal[1] / scal[0];
+  p[i] = z[i] + beta * p[i];
+}
+
+// y = Amu p on the block-ELL + coupling data; partial p.y per workgroup
+__global__ __launch_bounds__(256) void k3f_matvec(T3 t, const double* __restrict__ Amu, const double* __restrict__ Cmu,
+                                                  const double* __restrict__ p, double* __restrict__ y, double* __restrict__ part) {
+  __shared__ double red[256];
+  const int s = blockIdx.y, tid = threadIdx.x;
+  const int el = tid / 10, i = tid - el * 10, e = blockIdx.x * FOM_EPB + el;
+  double acc = 0.0, py = 0.0;
+  if (el < FOM_EPB && e < t.nT) {
+    const double* A = Amu + (((long)s * t.nT + e) * 5) * 100 + i * 10;
+    for (int slot = 0; slot < 5; ++slot) {
+      int ee = e, ss = s;
+      const double* L = A + slot * 100;
+      if (slot > 0) {
+        ee = t.nb_elem[e * 4 + slot - 1];
+        if (ee < 0) {
+          const int side = -(ee + 1);
+          ss = t.nbr[s * 7 + side_slot(side)];
+          if (ss < 0) continue;
+          L = Cmu + (((long)s * 6 + side) * t.ncf + t.face_pos[e * 4 + slot - 1]) * 100 + i * 10;
+          ee = t.nb_out[e * 4 + slot - 1];
+        }
+      }
+      const double* pv = p + ((long)ss * t.n + ee * 10);
+#pragma unroll
+      for (int j = 0; j < 10; ++j) acc += L[j] * pv[j];
+    }
+    const long d = (long)s * t.n + e * 10 + i;
+    y[d] = acc;
+    py = acc * p[d];
+  }
+  red[tid] = py;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) part[(long)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
+// x += alpha p, r -= alpha y, z = Dinv r; partials r.z and r.r per workgroup (init: x = 0, r = b: alpha = 0 with p = y = any)
+__global__ __launch_bounds__(256) void k3f_update(T3 t, int init, const double* __restrict__ scal, const double* __restrict__ Dinv,
+                                                  const double* __restrict__ p, const double* __restrict__ y, const double* __restrict__ b,
+                                                  double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
+                                                  double* __restrict__ prz, double* __restrict__ prr) {
+  __shared__ double rs[256], red[256];
+  const int s = blockIdx.y, tid = threadIdx.x;
+  const int el = tid / 10, i = tid - el * 10, e = blockIdx.x * FOM_EPB + el;
+  const bool on = el < FOM_EPB && e < t.nT;
+  const long d = (long)s * t.n + e * 10 + i;
+  double ri = 0.0;
+  if (on) {
+    if (init) {
+      ri = b[d];
+      x[d] = 0.0;
+    } else {
+      const double alpha = scal[0] / scal[2];
+      x[d] += alpha * p[d];
+      ri = r[d] - alpha * y[d];
+    }
+    r[d] = ri;
+  }
+  rs[tid] = ri;
+  __syncthreads();
+  double zi = 0.0;
+  if (on) {
+    const double* D = Dinv + ((long)s * t.nT + e) * 100 + i * 10;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) zi += D[j] * rs[el * 10 + j];
+    z[d] = zi;
+  }
+  red[tid] = ri * zi;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  if (tid == 0) prz[blk] = red[0];
+  __syncthreads();
+  red[tid] = ri * ri;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) prr[blk] = red[0];
+}
+
+// scalar bookkeeping of an iteration on the device: after the update rz_old <- rz_new is a rotation of two slots
+__global__ void k3f_rotate(double* scal) { scal[0] = scal[1]; }
+
 template <typename T>
 int upload(lrbms3_ctx* ctx, const T* host, long count, const T** dev) {
   void* p = nullptr;
@@ -1946,6 +2082,74 @@ int lrbms3_reduced_solve(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* th
   }
   if (info) info[0] = it, info[1] = rel;
   if (rel > rtol) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve: not converged");
+  return LRBMS_OK;
+}
+
+int64_t lrbms3_fom_solve_work_size(lrbms3_ctx* ctx) {
+  if (!ctx || !ctx->has_mesh) return -1;
+  const T3& t = ctx->t;
+  const int64_t nblk = (int64_t)t.S * ((t.nT + FOM_EPB - 1) / FOM_EPB);
+  return (int64_t)t.S * t.nT * 500 + (int64_t)t.S * 6 * t.ncf * 100 + (int64_t)t.S * t.nT * 100 + 4 * (int64_t)t.S * t.n + 3 * nblk + 16;
+}
+
+int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const double* A_diag, const double* A_cpl, const double* b,
+                     double* work, double* x, double rtol, int32_t max_iter, double* info, void* stream) {
+  REQUIRE3(ctx);
+  const T3& t = ctx->t;
+  if (t.S_ext != t.S) return fail3(ctx, LRBMS_E_INVALID, "fom_solve: needs all subdomains on this rank");
+  if (Q < 1 || Q > 8 || !theta || !A_diag || !A_cpl || !b || !work || !x) return fail3(ctx, LRBMS_E_INVALID, "fom_solve: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const long S = t.S, nd = S * t.nT * 500, nc = S * 6 * t.ncf * 100, total = S * t.n;
+  const int nbx = (t.nT + FOM_EPB - 1) / FOM_EPB;
+  const long nblk = S * nbx;
+  double* Amu = work;
+  double* Cmu = Amu + nd;
+  double* Dinv = Cmu + nc;
+  double* r = Dinv + S * t.nT * 100;
+  double* z = r + total;
+  double* p = z + total;
+  double* y = p + total;
+  double* prz = y + total;
+  double* ppy = prz + nblk;
+  double* prr = ppy + nblk;
+  double* scal = prr + nblk;
+  const QV th = make_theta(Q, theta);
+  hipLaunchKernelGGL(k3_combine, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, nd, Q, th, A_diag, Amu);
+  hipLaunchKernelGGL(k3_combine, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, nc, Q, th, A_cpl, Cmu);
+  hipLaunchKernelGGL(k3f_block_inverse, dim3((t.nT + 63) / 64, S), dim3(64), 0, st, t, Amu, Dinv);
+  const dim3 grid(nbx, S);
+  hipLaunchKernelGGL(k3f_update, grid, dim3(256), 0, st, t, 1, scal, Dinv, p, y, b, x, r, z, prz, prr);
+  hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, prz, scal + 1);
+  hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, prr, scal + 4);
+  LAUNCH3(ctx);
+  double bb = 0.0;
+  HIP3(ctx, hipMemcpyAsync(&bb, scal + 4, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP3(ctx, hipStreamSynchronize(st));
+  if (info) info[0] = 0, info[1] = 0;
+  if (bb == 0.0) return LRBMS_OK;
+  int it = 0;
+  double rel = 1.0;
+  const int check = 16;
+  while (it < max_iter) {
+    for (int k = 0; k < check && it < max_iter; ++k, ++it) {
+      hipLaunchKernelGGL(k3f_dir, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, it == 0 ? 1 : 0, scal, z, p);
+      hipLaunchKernelGGL(k3f_rotate, dim3(1), dim3(1), 0, st, scal);                  // rz_old <- rz_new (read by this iteration's update)
+      hipLaunchKernelGGL(k3f_matvec, grid, dim3(256), 0, st, t, Amu, Cmu, p, y, ppy);
+      hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, ppy, scal + 2);
+      hipLaunchKernelGGL(k3f_update, grid, dim3(256), 0, st, t, 0, scal, Dinv, p, y, b, x, r, z, prz, prr);
+      hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, prz, scal + 1);
+    }
+    hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, prr, scal + 3);
+    LAUNCH3(ctx);
+    double rr = 0.0;
+    HIP3(ctx, hipMemcpyAsync(&rr, scal + 3, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP3(ctx, hipStreamSynchronize(st));
+    rel = sqrt(rr / bb);
+    if (!(rel == rel)) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "fom_solve: NaN residual");
+    if (rel <= rtol) break;
+  }
+  if (info) info[0] = it, info[1] = rel;
+  if (rel > rtol) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "fom_solve: not converged");
   return LRBMS_OK;
 }
 

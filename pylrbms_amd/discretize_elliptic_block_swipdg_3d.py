@@ -10,8 +10,7 @@ only (:22-23); this module gives the 3D / P2 path the same surface for the calls
     u = rd.solve(mu);  rd.estimate(u, mu)                 # online (estimators.py:45-130)
 
 ``grid_and_problem_data``: the dict of ``pylrbms_amd.multiscale_problem3d.init_grid_and_problem`` (grid, lambda functions and
-coefficient functionals, lambda_bar / lambda_hat, f, mu_bar / mu_hat).  Full-order solves (snapshot generation) are not part of
-the 3D path yet: bases come from the caller."""
+coefficient functionals, lambda_bar / lambda_hat, f, mu_bar / mu_hat).  ``d.solve(mu)`` generates snapshots (block-Jacobi CG)."""
 import numpy as np
 
 from pylrbms_amd.engine3d import Engine3D
@@ -47,6 +46,14 @@ class BlockDiscretization3D:
         if not decompose:
             return eta
         return eta, (nc, r, df), (2.0 / a_bar) * (g_bar * nc ** 2 + (1.0 / a_hat) * (r + df) ** 2)
+
+    def solve(self, mu, rtol=1e-10, max_iter=50000, return_info=False):
+        """``d.solve(mu)`` (:219-225): the full-order solution as a block DG vector [S, n] -- CG on the never-assembled block
+        operator with the 10 x 10 element blocks as preconditioner (``lrbms3_fom_solve``); snapshot generation."""
+        eng = self.engine
+        U, info = eng.ctx.fom_solve(self.Q, self.theta(mu), eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=rtol,
+                                    max_iter=max_iter)
+        return (U, info) if return_info else U
 
     def apply(self, U, mu):
         """A(mu) U for a block DG array U [S, n, M] (BlockOperator.apply, :500-507)."""

@@ -43,3 +43,35 @@ def test_driver_sequence_matches_the_oracle(name):
     # Galerkin orthogonality of the reduced solution
     res_ = o.b - o.system_matrix(mu) @ U.cpu().numpy().ravel()
     assert max(np.abs(V[ii].T @ res_[o.dofs_of(ii)]).max() for ii in range(o.S)) < 1e-9
+
+
+def test_snapshots_bases_reduced_model_workflow():
+    """The offline / online sequence of the reference's driver (online_adaptive_lrbms.py:56-141) in 3D: full-order snapshots
+    (d.solve, checked against the oracle's sparse LU) -> local bases (constant + restricted snapshots) -> reduce -> reduced
+    solve at a new parameter -> the reduced solution is the Galerkin projection: it reproduces a snapshot parameter exactly and
+    its estimate is the full-order estimate of its reconstruction."""
+    import torch
+    from pylrbms_amd.discretize_elliptic_block_swipdg_3d import LRBMSReductor3D, discretize
+    p = c3.make_problem('aniso_2x2x1')
+    o = c3.oracle_of(p)
+    pd = {'grid': p['grid'], 'lambda': {'functions': p['lambdas'], 'coefficients': p['thetas']}, 'lambda_bar': p['lambda_bar'],
+          'lambda_hat': p['lambda_hat'], 'f': p['f'], 'mu_bar': p['mu_bar'], 'mu_hat': p['mu_hat']}
+    d, _ = discretize(pd)
+    snaps = []
+    for mu in (0.2, 0.9):
+        U, (it, res) = d.solve(mu, rtol=1e-12, return_info=True)
+        assert it > 0 and res <= 1e-12
+        assert c3.rel(U.cpu().numpy().ravel(), o.solve(mu)) < 1e-9
+        snaps.append(U)
+    V = torch.stack([torch.ones_like(snaps[0])] + snaps, dim=2)                # [S, n, 3]
+    V = torch.linalg.qr(V)[0].contiguous()
+    red = LRBMSReductor3D(d, V)
+    rd = red.reduce()
+    u = rd.solve(0.9, rtol=1e-13)
+    assert c3.rel(red.reconstruct(u).cpu().numpy().ravel(), o.solve(0.9)) < 1e-8          # a snapshot parameter is reproduced
+    mu = 0.5
+    u = rd.solve(mu, rtol=1e-13)
+    Ur = red.reconstruct(u)
+    err = Ur.cpu().numpy().ravel() - o.solve(mu)
+    assert np.sqrt(o.energy_norm2(err, mu)) < 0.05 * np.sqrt(o.energy_norm2(o.solve(mu), mu))
+    assert abs(rd.estimate(u, mu) - d.estimate(Ur, mu)) < 1e-8 * rd.estimate(u, mu)
