@@ -113,3 +113,34 @@ def test_product_reproduces_the_committed_3d_fixtures():
             assert c3.rel(got, gold[key]) < 1e-10, key
         u, _ = eng.reduced_solve(th, out, rtol=1e-13)
         assert c3.rel(u.cpu().numpy(), gold['u']) < 1e-10
+
+
+@pytest.mark.parametrize('name,N', [('q1_strip', 64), ('aniso_2x2x1', 32), ('q1_strip', 1), ('q3_2x1x2', 7)])
+def test_limit_sizes_of_the_pass(name, N):
+    """The largest basis sizes the pass takes (N = 64 with Q = 1: 4 x 4 tiles per wave; Q N = 64), the smallest (N = 1) and an odd
+    size with three components (the 8-byte operand form of the kernels), against the oracle; one size beyond the limit is refused."""
+    from pylrbms_amd._native import NativeError
+    from pylrbms_amd.engine3d import Engine3D, expand_factored
+    p = c3.make_problem(name)
+    p['N'] = N
+    d = c3.oracle_of(p)
+    eng = Engine3D(p['grid'], p['lambdas'], p['f'], p['lambda_bar'], p['lambda_hat']).assemble()
+    V = c3.make_bases3d(d.S, d.n, max(N, 2), seed=5)[:, :, -N:].copy()      # N = 1: a non-constant column (gradients do not vanish)
+    out = eng.project_and_estimate(eng.ctx.from_numpy(V))
+    dense = {k: v.cpu().numpy() for k, v in expand_factored(eng, out, d.Q, N).items()}
+    rd = c3.reduce_with_oracle(p, d, V)
+    worst = 0.0
+    for ii in range(d.S):
+        ref = c3.oracle_dense_blocks(p, d, rd, ii)
+        for k in ('G_nc', 'G_bb', 'G_rdd', 'r_fd'):
+            worst = max(worst, c3.rel(dense[k][ii], ref[k]))
+        worst = max(worst, c3.rel(dense['G_ab'][:, ii], ref['G_ab']), c3.rel(dense['G_aa'][:, :, ii], ref['G_aa']),
+                    c3.rel(dense['B_sys'][:, ii], ref['B_sys']), c3.rel(dense['rhs_red'][ii], rd.rhs[ii]))
+    assert worst < TOL, worst
+    u = np.random.default_rng(1).standard_normal((d.S, N))
+    eta = eng.reduced_estimate(c3.theta_of(p, p['mu']), eng.ctx.from_numpy(u), out).cpu().numpy()
+    for got, want in zip(eta, rd.local_terms([u[ii] for ii in range(d.S)], p['mu'])):
+        assert c3.rel(got, want) < 1e-10
+    if name == 'aniso_2x2x1':
+        with pytest.raises(NativeError):
+            eng.project_and_estimate(eng.ctx.from_numpy(c3.make_bases3d(d.S, d.n, 33, seed=5)))       # Q N = 66 > 64
