@@ -131,6 +131,15 @@ int64_t lrbms3_reduced_solve_work_size(lrbms3_ctx* ctx, int32_t N);
 int lrbms3_reduced_solve(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* B_sys, const double* rhs_red,
                          double* work, double* u, double rtol, int32_t max_iter, double* info, void* stream);
 
+/* Throughput form of the reduced solve: nmu <= 16 parameters at once (N <= 32).  theta [nmu][Q] host; u [S][N][nmu] (parameter
+ * fastest).  Every projected block is read once per CG iteration for the whole batch, one block-Jacobi preconditioner at the
+ * batch-mean theta, independent CG scalars per parameter.  info[0] = iterations, info[1] = worst relative residual.
+ * 2D: lrbms_reduced_solve_batch. */
+int64_t lrbms3_reduced_solve_batch_work_size(lrbms3_ctx* ctx, int32_t N, int32_t nmu);
+int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* B_sys,
+                               const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
+                               void* stream);
+
 /* Snapshot generation: A(mu) x = b on the never-assembled block operator, CG with the 10 x 10 element blocks as block-Jacobi
  * preconditioner (S_ext == S).  b, x [S][n]; work: lrbms3_fom_solve_work_size doubles; info[0] = iterations, info[1] = final
  * relative residual (host, may be NULL); LRBMS_E_NOT_CONVERGED above rtol after max_iter.  2D: lrbms_fom_solve. */

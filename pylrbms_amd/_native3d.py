@@ -35,6 +35,8 @@ SIGNATURES3 = {
     'lrbms3_reduced_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 18 + [c_dbl, c_vp, c_vp]),
     'lrbms3_reduced_solve_work_size': (c_i64, [c_vp, c_i32]),
     'lrbms3_reduced_solve': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
+    'lrbms3_reduced_solve_batch_work_size': (c_i64, [c_vp, c_i32, c_i32]),
+    'lrbms3_reduced_solve_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms3_fom_solve_work_size': (c_i64, [c_vp]),
     'lrbms3_fom_solve': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms3_fom_apply': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -248,6 +250,23 @@ class Native3DContext:
                                            self._ptr(rhs_red, (S, N), 'rhs_red'), c_vp(work.data_ptr()), c_vp(u.data_ptr()),
                                            float(rtol), int(max_iter), info, self._stream())
         self._check(rc, 'lrbms3_reduced_solve')
+        return u, (int(info[0]), float(info[1]))
+
+    def reduced_solve_batch(self, Q, thetas, B_sys, rhs_red, rtol=1e-13, max_iter=5000, work=None):
+        """thetas [nmu, Q] (nmu <= 16) -> u [S, N, nmu] (parameter fastest), (iterations, worst relative residual)."""
+        N, S = rhs_red.shape[1], self.S
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        nmu = th.shape[0]
+        assert th.shape == (nmu, Q)
+        if work is None:
+            work = self.empty(int(self.lib.lrbms3_reduced_solve_batch_work_size(self.handle, N, nmu)))
+        u = self.empty(S, N, nmu)
+        info = (c_dbl * 2)()
+        rc = self.lib.lrbms3_reduced_solve_batch(self.handle, Q, N, nmu, th.ctypes.data_as(_P_DBL),
+                                                 self._ptr(B_sys, (Q, S, 7, N, N), 'B_sys'), self._ptr(rhs_red, (S, N), 'rhs_red'),
+                                                 c_vp(work.data_ptr()), c_vp(u.data_ptr()), float(rtol), int(max_iter), info,
+                                                 self._stream())
+        self._check(rc, 'lrbms3_reduced_solve_batch')
         return u, (int(info[0]), float(info[1]))
 
     def fom_solve(self, Q, theta, A_diag, A_cpl, b, rtol=1e-10, max_iter=50000, work=None):

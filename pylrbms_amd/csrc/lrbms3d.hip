@@ -1558,6 +1558,141 @@ __global__ __launch_bounds__(256) void k3_reduce1(int S, const double* __restric
   if (tid == 0) out[0] = red[0];
 }
 
+// ------------------------------------------------------------------------------------------------- online: batched reduced solve
+// nmu <= 16 parameters at once: every projected block is read once per iteration for the whole batch, one block-Jacobi
+// preconditioner at the batch-mean theta (any SPD preconditioner is admissible), independent CG scalars per parameter.
+// Vectors [S][N][nmu] (parameter fastest).  Threads (i = row, m = parameter).
+struct TB { double v[16][8]; };     // theta [nmu][Q]
+
+// scal [5][16]: rz_old, rz_new, pAp, rr, bb per parameter;  partial arrays [S][16]
+__global__ __launch_bounds__(256) void k3b_reduce(int S, int nmu, const double* __restrict__ part, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x, m = tid & 15, g = tid >> 4;
+  double acc = 0.0;
+  if (m < nmu)
+    for (int k = g; k < S; k += 16) acc += part[(long)k * 16 + m];
+  red[tid] = acc;
+  __syncthreads();
+  for (int w = 128; w >= 16; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  if (tid < 16) out[tid] = red[tid];
+}
+
+__global__ __launch_bounds__(512) void k3b_init(int N, int nmu, const double* __restrict__ rhs, const double* __restrict__ Dinv,
+                                                double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
+                                                double* __restrict__ p, double* __restrict__ prz, double* __restrict__ prr) {
+  extern __shared__ double lds[];      // [N] rhs + [N][16] products
+  const int s = blockIdx.x, tid = threadIdx.x, i = tid >> 4, m = tid & 15;
+  for (int k = tid; k < N; k += 512) lds[k] = rhs[(long)s * N + k];
+  __syncthreads();
+  double ri = 0.0, zi = 0.0;
+  const bool on = i < N && m < nmu;
+  if (on) {
+    ri = lds[i];
+    const double* D = Dinv + ((long)s * N + i) * N;
+    for (int j = 0; j < N; ++j) zi += D[j] * lds[j];
+    const long d = ((long)s * N + i) * nmu + m;
+    x[d] = 0.0; r[d] = ri; z[d] = zi; p[d] = 0.0;
+  }
+  double* pr = lds + N;
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    if (i < 32) pr[i * 16 + m] = on ? (pass ? ri * ri : ri * zi) : 0.0;
+    __syncthreads();
+    if (tid < 16) {
+      double a = 0.0;
+      for (int k = 0; k < N; ++k) a += pr[k * 16 + tid];
+      (pass ? prr : prz)[(long)s * 16 + tid] = a;
+    }
+  }
+}
+
+// direction + matvec: p_new = z + beta_m p_old on the neighbourhood (own part stored), Ap = sum_q theta_qm sum_slot B_q p_new
+__global__ __launch_bounds__(512) void k3b_matvec(T3 t, int Q, int N, int nmu, int first, TB th, const double* __restrict__ B,
+                                                  const double* __restrict__ z, const double* __restrict__ p_old,
+                                                  double* __restrict__ p_new, double* __restrict__ Ap, const double* __restrict__ scal,
+                                                  double* __restrict__ ppap) {
+  extern __shared__ double lds[];      // [7][N][16] direction + [32][16] products
+  const int s = blockIdx.x, tid = threadIdx.x, i = tid >> 4, m = tid & 15, S = t.S;
+  for (int k = tid; k < 7 * N * 16; k += 512) {
+    const int slot = k / (N * 16), j = (k >> 4) % N, mm = k & 15;
+    const int s2 = t.nbr[s * 7 + slot];
+    double v = 0.0;
+    if (s2 >= 0 && mm < nmu) {
+      const long d = ((long)s2 * N + j) * nmu + mm;
+      const double bm = (first || scal[mm] == 0.0) ? 0.0 : scal[16 + mm] / scal[mm];     // a converged parameter (r = 0) stays put
+      v = z[d] + bm * p_old[d];
+    }
+    lds[k] = v;
+  }
+  __syncthreads();
+  double acc = 0.0;
+  const bool on = i < N && m < nmu;
+  if (on) {
+    p_new[((long)s * N + i) * nmu + m] = lds[(3 * N + i) * 16 + m];
+    for (int q = 0; q < Q; ++q) {
+      double aq = 0.0;
+      for (int slot = 0; slot < 7; ++slot) {
+        if (t.nbr[s * 7 + slot] < 0) continue;
+        const double* row = B + ((((long)q * S + s) * 7 + slot) * N + i) * N;
+        const double* ps = lds + slot * N * 16 + m;
+        for (int j = 0; j < N; ++j) aq += row[j] * ps[j * 16];
+      }
+      acc += th.v[m][q] * aq;
+    }
+    Ap[((long)s * N + i) * nmu + m] = acc;
+  }
+  double* pr = lds + 7 * N * 16;
+  __syncthreads();
+  if (i < 32) pr[i * 16 + m] = on ? acc * lds[(3 * N + i) * 16 + m] : 0.0;
+  __syncthreads();
+  if (tid < 16) {
+    double a = 0.0;
+    for (int k = 0; k < N && k < 32; ++k) a += pr[k * 16 + tid];
+    ppap[(long)s * 16 + tid] = a;
+  }
+}
+
+__global__ __launch_bounds__(512) void k3b_update(int N, int nmu, const double* __restrict__ Dinv, const double* __restrict__ p,
+                                                  const double* __restrict__ Ap, double* __restrict__ x, double* __restrict__ r,
+                                                  double* __restrict__ z, const double* __restrict__ scal, double* __restrict__ prz,
+                                                  double* __restrict__ prr) {
+  extern __shared__ double lds[];      // [N][16] residual + [32][16] products
+  const int s = blockIdx.x, tid = threadIdx.x, i = tid >> 4, m = tid & 15;
+  const bool on = i < N && m < nmu;
+  double ri = 0.0, zi = 0.0;
+  if (on) {
+    const double pap = scal[32 + m];
+    const double alpha = pap != 0.0 ? scal[m] / pap : 0.0;          // a converged parameter (r = 0) stays put
+    const long d = ((long)s * N + i) * nmu + m;
+    x[d] += alpha * p[d];
+    ri = r[d] - alpha * Ap[d];
+    r[d] = ri;
+  }
+  if (i < N) lds[i * 16 + m] = ri;
+  __syncthreads();
+  if (on) {
+    const double* D = Dinv + ((long)s * N + i) * N;
+    for (int j = 0; j < N; ++j) zi += D[j] * lds[j * 16 + m];
+    z[((long)s * N + i) * nmu + m] = zi;
+  }
+  double* pr = lds + N * 16;
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    if (i < 32) pr[i * 16 + m] = on ? (pass ? ri * ri : ri * zi) : 0.0;
+    __syncthreads();
+    if (tid < 16) {
+      double a = 0.0;
+      for (int k = 0; k < N && k < 32; ++k) a += pr[k * 16 + tid];
+      (pass ? prr : prz)[(long)s * 16 + tid] = a;
+    }
+  }
+}
+
+__global__ void k3b_rotate(double* scal) { scal[threadIdx.x] = scal[16 + threadIdx.x]; }
+
 // ------------------------------------------------------------------------------------------------- full-order apply
 __global__ __launch_bounds__(256) void k3_fom_apply(T3 t, int Q, int M, QV th, const double* __restrict__ A_diag,
                                                     const double* __restrict__ A_cpl, const double* __restrict__ x,
@@ -2082,6 +2217,83 @@ int lrbms3_reduced_solve(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* th
   }
   if (info) info[0] = it, info[1] = rel;
   if (rel > rtol) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve: not converged");
+  return LRBMS_OK;
+}
+
+int64_t lrbms3_reduced_solve_batch_work_size(lrbms3_ctx* ctx, int32_t N, int32_t nmu) {
+  if (!ctx || !ctx->has_mesh) return -1;
+  const int64_t S = ctx->t.S;
+  return S * 7 * N * N + S * N * N + 5 * S * N * nmu + 3 * S * 16 + 5 * 16 + 16;
+}
+
+int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* B_sys,
+                               const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
+                               void* stream) {
+  REQUIRE3(ctx);
+  const T3& t = ctx->t;
+  if (t.S_ext != t.S) return fail3(ctx, LRBMS_E_INVALID, "reduced_solve_batch: needs all subdomains on this rank");
+  if (Q < 1 || Q > 8 || N < 1 || N > 32 || nmu < 1 || nmu > 16 || !theta || !B_sys || !rhs_red || !work || !u)
+    return fail3(ctx, LRBMS_E_INVALID, "reduced_solve_batch: needs N <= 32 and nmu <= 16");
+  hipStream_t st = (hipStream_t)stream;
+  const long S = t.S, per_q = S * 7 * N * N, nv = S * N * nmu;
+  double* Amu = work;                 // blocks at the batch-mean theta: only its diagonal blocks are used (preconditioner)
+  double* Dinv = Amu + per_q;
+  double* r = Dinv + S * N * N;
+  double* z = r + nv;
+  double* p0 = z + nv;
+  double* p1 = p0 + nv;
+  double* Ap = p1 + nv;
+  double* prz = Ap + nv;
+  double* ppap = prz + S * 16;
+  double* prr = ppap + S * 16;
+  double* scal = prr + S * 16;        // [5][16]
+  TB th{};
+  QV mean{};
+  for (int m = 0; m < nmu; ++m)
+    for (int q = 0; q < Q; ++q) {
+      th.v[m][q] = theta[m * Q + q];
+      mean.v[q] += theta[m * Q + q] / nmu;
+    }
+  hipLaunchKernelGGL(k3_combine, dim3((unsigned)((per_q + 255) / 256)), dim3(256), 0, st, per_q, Q, mean, B_sys, Amu);
+  hipLaunchKernelGGL(k3_block_inverse, dim3(S), dim3(256), sizeof(double) * N * (2 * N + 1), st, N, Amu, Dinv);
+  HIP3(ctx, hipMemsetAsync(scal, 0, sizeof(double) * 80, st));
+  hipLaunchKernelGGL(k3b_init, dim3(S), dim3(512), sizeof(double) * (N + 32 * 16), st, N, nmu, rhs_red, Dinv, u, r, z, p0, prz, prr);
+  hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prz, scal + 16);
+  hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prr, scal + 64);
+  LAUNCH3(ctx);
+  double bb[16];
+  HIP3(ctx, hipMemcpyAsync(bb, scal + 64, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+  HIP3(ctx, hipStreamSynchronize(st));
+  if (info) info[0] = 0, info[1] = 0;
+  double *po = p0, *pn = p1;
+  int it = 0;
+  double rel = 0.0;
+  const int check = 8;
+  const size_t lds_mv = sizeof(double) * (7 * N * 16 + 32 * 16), lds_up = sizeof(double) * (N * 16 + 32 * 16);
+  while (it < max_iter) {
+    for (int k = 0; k < check && it < max_iter; ++k, ++it) {
+      hipLaunchKernelGGL(k3b_matvec, dim3(S), dim3(512), lds_mv, st, t, Q, N, nmu, it == 0 ? 1 : 0, th, B_sys, z, po, pn, Ap, scal, ppap);
+      hipLaunchKernelGGL(k3b_rotate, dim3(1), dim3(16), 0, st, scal);                    // rz_old <- rz_new
+      hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, ppap, scal + 32);
+      hipLaunchKernelGGL(k3b_update, dim3(S), dim3(512), lds_up, st, N, nmu, Dinv, pn, Ap, u, r, z, scal, prz, prr);
+      hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prz, scal + 16);
+      std::swap(po, pn);
+    }
+    hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prr, scal + 48);
+    LAUNCH3(ctx);
+    double rr[16];
+    HIP3(ctx, hipMemcpyAsync(rr, scal + 48, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+    HIP3(ctx, hipStreamSynchronize(st));
+    rel = 0.0;
+    for (int m = 0; m < nmu; ++m) {
+      const double rm = bb[m] > 0.0 ? sqrt(rr[m] / bb[m]) : 0.0;
+      if (!(rm == rm)) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve_batch: NaN residual");
+      rel = rm > rel ? rm : rel;
+    }
+    if (rel <= rtol) break;
+  }
+  if (info) info[0] = it, info[1] = rel;
+  if (rel > rtol) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve_batch: not converged");
   return LRBMS_OK;
 }
 

@@ -86,6 +86,19 @@ class ReducedDiscretization3D:
         u, info = self.d.engine.reduced_solve(self.d.theta(mu), self.out, rtol=rtol, max_iter=max_iter)
         return (u, info) if return_info else u
 
+    def solve_batch(self, mus, rtol=1e-12, max_iter=20000, return_info=False):
+        """Reduced solutions for a list of parameters, <= 16 per native call: [len(mus), S, N]."""
+        import torch
+        eng, out = self.d.engine, []
+        info = (0, 0.0)
+        for b0 in range(0, len(mus), 16):
+            th = np.stack([self.d.theta(mu) for mu in mus[b0:b0 + 16]])
+            ub, inf = eng.ctx.reduced_solve_batch(self.d.Q, th, self.out['B_sys'], self.out['rhs_red'], rtol=rtol, max_iter=max_iter)
+            out.append(ub.permute(2, 0, 1))
+            info = (max(info[0], inf[0]), max(info[1], inf[1]))
+        U = torch.cat(out, dim=0).contiguous()
+        return (U, info) if return_info else U
+
     def estimate(self, u, mu, decompose=False):
         eta_loc = self.d.engine.reduced_estimate(self.d.theta(mu), u.contiguous(), self.out)
         return self.d.combine(eta_loc.cpu().numpy(), mu, decompose)

@@ -144,3 +144,18 @@ def test_limit_sizes_of_the_pass(name, N):
     if name == 'aniso_2x2x1':
         with pytest.raises(NativeError):
             eng.project_and_estimate(eng.ctx.from_numpy(c3.make_bases3d(d.S, d.n, 33, seed=5)))       # Q N = 66 > 64
+
+
+def test_batched_reduced_solve_matches_single_solves_and_the_oracle(case):
+    p, d, eng, rd, out = case['p'], case['d'], case['eng'], case['rd'], case['out']
+    if p['N'] > 32:
+        pytest.skip('batched solve takes N <= 32')
+    mus = [0.15, p['mu'], 0.55, 0.9, 1.2][:5]
+    thetas = np.stack([c3.theta_of(p, mu) for mu in mus])
+    ub, (it, res) = eng.ctx.reduced_solve_batch(d.Q, thetas, out['B_sys'], out['rhs_red'], rtol=1e-13)
+    assert res <= 1e-13 and it > 0
+    for m, mu in enumerate(mus):
+        ref = np.stack(rd.solve(mu))
+        assert c3.rel(ub[:, :, m].cpu().numpy(), ref) < 1e-10, (m, c3.rel(ub[:, :, m].cpu().numpy(), ref))
+        us, _ = eng.reduced_solve(thetas[m], out, rtol=1e-13)
+        assert c3.rel(ub[:, :, m].cpu().numpy(), us.cpu().numpy()) < 1e-10
