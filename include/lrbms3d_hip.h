@@ -112,6 +112,16 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
                             double* G_bb, double* G_rdd, double* G_ab, double* G_aa, double* r_fd, double* Rb, double* Yb,
                             double* Dp, double* Xab, double* As, double* Cn, void* stream);
 
+/* The same pass in two halves for a sharded run that overlaps its halo exchange with compute: phase 1 reads the first S
+ * (rank-local) slabs of V only -- everything but the neighbours' shares; phase 2 needs the halo slabs and writes Rb, As and the
+ * coupling blocks of B_sys.  phase 0 == lrbms3_project_estimate; 1 followed by 2 is bit-identical to 0 (same buffers, same
+ * work).  2D: lrbms_project_estimate_fused_phase. */
+int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int32_t N, const double* V, const double* A_diag,
+                                  const double* A_cpl, const double* b, const double* ebar, const double* Aaa, const double* Aab,
+                                  const double* Bbb, const double* bdiv, const double* Cf, double* work, double* B_sys,
+                                  double* rhs_red, double* G_nc, double* G_bb, double* G_rdd, double* G_ab, double* G_aa,
+                                  double* r_fd, double* Rb, double* Yb, double* Dp, double* Xab, double* As, double* Cn, void* stream);
+
 /* Per-kernel device timing of the pass, as lrbms_kernel_timing / lrbms_kernel_timing_read. */
 int lrbms3_kernel_timing(lrbms3_ctx* ctx, int32_t enable);
 int lrbms3_kernel_timing_read(lrbms3_ctx* ctx, char* names, int64_t names_cap, double* ms, int32_t cap, int32_t* count);

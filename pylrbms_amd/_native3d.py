@@ -30,6 +30,7 @@ SIGNATURES3 = {
     'lrbms3_assemble_flux': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     'lrbms3_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms3_project_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 26),
+    'lrbms3_project_estimate_phase': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32] + [c_vp] * 26),
     'lrbms3_kernel_timing': (ctypes.c_int, [c_vp, c_i32]),
     'lrbms3_kernel_timing_read': (ctypes.c_int, [c_vp, ctypes.c_char_p, c_i64, _P_DBL, c_i32, _P_I32]),
     'lrbms3_reduced_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 18 + [c_dbl, c_vp, c_vp]),
@@ -192,7 +193,7 @@ class Native3DContext:
     def work_size(self, Q, N):
         return int(self.lib.lrbms3_work_size(self.handle, Q, N))
 
-    def project_estimate(self, Q, V, ops, work, out):
+    def project_estimate(self, Q, V, ops, work, out, phase=0):
         N = V.shape[2]
         S, nT = self.S, self.n_T
         shp = self.out_shapes(Q, N)
@@ -205,8 +206,8 @@ class Native3DContext:
             raise NativeError('work buffer too small')
         args.append(c_vp(work.data_ptr()))
         args += [self._ptr(out[k], shp[k], k) for k in self.OUT_NAMES]
-        rc = self.lib.lrbms3_project_estimate(self.handle, Q, N, *args, self._stream())
-        self._check(rc, 'lrbms3_project_estimate')
+        rc = self.lib.lrbms3_project_estimate_phase(self.handle, int(phase), Q, N, *args, self._stream())
+        self._check(rc, 'lrbms3_project_estimate_phase')
         return out
 
     def kernel_timing(self, enable):

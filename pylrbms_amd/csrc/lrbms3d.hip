@@ -250,13 +250,13 @@ __device__ inline bool xcd_block(int nblk, int S, int& xblk, int& s) {
 }
 inline unsigned xcd_grid(int nblk, int S) { return (unsigned)((S + 7) / 8 * 8 * nblk); }
 
-__global__ __launch_bounds__(256) void k3_flux(T3 t, int Q, int N, const double* __restrict__ V, const double* __restrict__ Cf,
-                                               double* __restrict__ Rs, double* __restrict__ Rb) {
-  const int QN = Q * N, nrows = t.nrt + t.nbf;
+__global__ __launch_bounds__(256) void k3_flux(T3 t, int Q, int N, int rbeg, int rend, const double* __restrict__ V,
+                                               const double* __restrict__ Cf, double* __restrict__ Rs, double* __restrict__ Rb) {
+  const int QN = Q * N, nrows = rend;          // rows [rbeg, rend) of [own faces | side faces]
   int s, xblk;
-  if (!xcd_block((nrows + 4 * FLUX_R - 1) / (4 * FLUX_R), t.S, xblk, s)) return;
+  if (!xcd_block((rend - rbeg + 4 * FLUX_R - 1) / (4 * FLUX_R), t.S, xblk, s)) return;
   const int lane = threadIdx.x & 63, half = lane >> 5, jl = lane & 31;
-  const int row0 = __builtin_amdgcn_readfirstlane((xblk * 4 + (threadIdx.x >> 6)) * FLUX_R);
+  const int row0 = __builtin_amdgcn_readfirstlane(rbeg + (xblk * 4 + (threadIdx.x >> 6)) * FLUX_R);
   if (row0 >= nrows) return;
   // The (<= 2) elements of a face are dealt to the two halves of the wave: lanes 0..31 take the first, lanes 32..63 the second,
   // lane = basis column.  Every basis row is loaded once per face (ten instead of twenty vector-memory instructions), both affine
@@ -324,13 +324,13 @@ __global__ __launch_bounds__(256) void k3_flux(T3 t, int Q, int N, const double*
 
 // Avg [S][n_nodes][N]: own share of the Oswald node average (0 on the physical boundary: the interpolant vanishes there);
 // As [S][6][nvs][N]: the neighbours' shares at the side nodes.  One wave per node, DoF lists through the scalar cache.
-__global__ __launch_bounds__(256) void k3_node_avg(T3 t, int N, const double* __restrict__ V, double* __restrict__ Avg,
-                                                   double* __restrict__ As) {
+__global__ __launch_bounds__(256) void k3_node_avg(T3 t, int N, int rbeg, int rend, const double* __restrict__ V,
+                                                   double* __restrict__ Avg, double* __restrict__ As) {
   int s, xblk;
-  if (!xcd_block((t.nnodes + 6 * t.nvs + 3) / 4, t.S, xblk, s)) return;
+  if (!xcd_block((rend - rbeg + 3) / 4, t.S, xblk, s)) return;          // rows [rbeg, rend) of [own nodes | side nodes]
   const int j = threadIdx.x & 63;
-  const int row = __builtin_amdgcn_readfirstlane(xblk * 4 + (threadIdx.x >> 6));
-  if (row >= t.nnodes + 6 * t.nvs) return;
+  const int row = __builtin_amdgcn_readfirstlane(rbeg + xblk * 4 + (threadIdx.x >> 6));
+  if (row >= rend) return;
   const int jc = j < N ? j : N - 1;
   const int phys = t.phys[s];
   int p0 = 0, p1 = 0, node, src = s;
@@ -2024,7 +2024,18 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
                             const double* bdiv, const double* Cf, double* work, double* B_sys, double* rhs_red, double* G_nc,
                             double* G_bb, double* G_rdd, double* G_ab, double* G_aa, double* r_fd, double* Rb, double* Yb,
                             double* Dp, double* Xab, double* As, double* Cn, void* stream) {
+  return lrbms3_project_estimate_phase(ctx, 0, Q, N, V, A_diag, A_cpl, b, ebar, Aaa, Aab, Bbb, bdiv, Cf, work, B_sys, rhs_red, G_nc,
+                                       G_bb, G_rdd, G_ab, G_aa, r_fd, Rb, Yb, Dp, Xab, As, Cn, stream);
+}
+
+int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int32_t N, const double* V, const double* A_diag,
+                                  const double* A_cpl, const double* b, const double* ebar, const double* Aaa, const double* Aab,
+                                  const double* Bbb, const double* bdiv, const double* Cf, double* work, double* B_sys,
+                                  double* rhs_red, double* G_nc, double* G_bb, double* G_rdd, double* G_ab, double* G_aa,
+                                  double* r_fd, double* Rb, double* Yb, double* Dp, double* Xab, double* As, double* Cn, void* stream) {
   REQUIRE3(ctx);
+  if (phase < 0 || phase > 2) return fail3(ctx, LRBMS_E_INVALID, "project_estimate: phase must be 0, 1 or 2");
+  const bool own = phase != 2, side = phase != 1;        // 1: everything that reads rank-local slabs only; 2: the rest
   if (Q < 1 || Q > 8 || N < 1 || N > 64 || Q * N > 64)
     return fail3(ctx, LRBMS_E_INVALID, "project_estimate: needs N <= 64 and Q N <= 64");
   if (!V || !A_diag || !A_cpl || !b || !ebar || !Aaa || !Aab || !Bbb || !bdiv || !Cf || !work || !B_sys || !rhs_red || !G_nc ||
@@ -2055,54 +2066,56 @@ int lrbms3_project_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
   const int nw_s = nw_env > 0 ? nw_env : 8;      // kernels with one workgroup per subdomain only: more waves each
   int bad = 0;
   {
-    KScope3 k(ctx, "k3_flux", sf);
-    hipLaunchKernelGGL(k3_flux, dim3(xcd_grid((t.nrt + t.nbf + 4 * FLUX_R - 1) / (4 * FLUX_R), t.S)), dim3(256), 0, sf, t, Q, N, V, Cf, Rs, Rb);
+    const int r0 = own ? 0 : t.nrt, r1 = side ? t.nrt + t.nbf : t.nrt;      // own faces | side faces (the neighbours' share: halo)
+    KScope3 k(ctx, own ? "k3_flux" : "k3_flux<side>", sf);
+    hipLaunchKernelGGL(k3_flux, dim3(xcd_grid((r1 - r0 + 4 * FLUX_R - 1) / (4 * FLUX_R), t.S)), dim3(256), 0, sf, t, Q, N, r0, r1, V, Cf, Rs, Rb);
   }
   {
-    KScope3 k(ctx, "k3_node_avg", sn);
-    hipLaunchKernelGGL(k3_node_avg, dim3(xcd_grid((t.nnodes + 6 * t.nvs + 3) / 4, t.S)), dim3(256), 0, sn, t, N, V, Avg, As);
+    const int r0 = own ? 0 : t.nnodes, r1 = side ? t.nnodes + 6 * t.nvs : t.nnodes;
+    KScope3 k(ctx, own ? "k3_node_avg" : "k3_node_avg<side>", sn);
+    hipLaunchKernelGGL(k3_node_avg, dim3(xcd_grid((r1 - r0 + 3) / 4, t.S)), dim3(256), 0, sn, t, N, r0, r1, V, Avg, As);
   }
   const int npair = Q * (Q + 1) / 2;       // A_aa: pairs q <= q', the transposed blocks are written from the same accumulators
-  {
+  if (own) {
     KScope3 k(ctx, "k3_pg<SYS>", st);
     a.out = B_sys;
     bad |= dispatch_pg<G_SYS>(a, Q * t.S, tn, tn, nw, st);
   }
-  {
+  if (own) {
     KScope3 k(ctx, "k3_pg<AB>", sf);
     a.out = G_ab;
     bad |= dispatch_pg<G_AB>(a, Q * t.S, tn, tq, nw, sf);
   }
-  {
+  if (own) {
     KScope3 k(ctx, "k3_pg<NC>", sn);
     a.out = G_nc;
     bad |= dispatch_pg<G_NC>(a, t.S, tn, tn, nw_s, sn);
   }
-  {
+  if (own) {
     KScope3 k(ctx, "k3_pg<AAA>", st);
     a.out = G_aa;
     bad |= dispatch_pg<G_AAA>(a, npair * t.S, tn, tn, nw, st);
   }
-  {
+  if (own) {
     KScope3 k(ctx, "k3_pg<BB>", sf);
     a.out = G_bb;
     bad |= dispatch_pg<G_BB>(a, t.S, tq, tq, nw_s, sf);
   }
-  {
+  if (own) {
     KScope3 k(ctx, "k3_side_nc", sn);
     hipLaunchKernelGGL(k3_side_nc, dim3((t.nb + 3) / 4, t.S), dim3(256), 0, sn, t, N, Zb, Cn);
   }
-  {
+  if (side) {
     KScope3 k(ctx, "k3_pg<CPL>", st);
     a.out = B_sys;
     bad |= dispatch_pg<G_CPL>(a, Q * t.S * 6, tn, tn, nw, st);
   }
   if (bad) return fail3(ctx, LRBMS_E_INVALID, "project_estimate: unsupported tile shape");
-  {
+  if (own) {
     KScope3 k(ctx, "k3_vecs", st);
     hipLaunchKernelGGL(k3_vecs, dim3(t.S), dim3(256), 0, st, t, N, V, b, rhs_red);
   }
-  {
+  if (own) {
     KScope3 k(ctx, "k3_side_flux", sf);
     hipLaunchKernelGGL(k3_side_flux, dim3(t.nbf, t.S), dim3(64), 0, sf, t, Q, N, V, Aab, Bbb, Rs, Yb, Dp, Xab);
   }

@@ -159,3 +159,18 @@ def test_batched_reduced_solve_matches_single_solves_and_the_oracle(case):
         assert c3.rel(ub[:, :, m].cpu().numpy(), ref) < 1e-10, (m, c3.rel(ub[:, :, m].cpu().numpy(), ref))
         us, _ = eng.reduced_solve(thetas[m], out, rtol=1e-13)
         assert c3.rel(ub[:, :, m].cpu().numpy(), us.cpu().numpy()) < 1e-10
+
+
+def test_phased_pass_is_bit_identical_to_the_whole_pass(case):
+    """lrbms3_project_estimate_phase: 1 (rank-local slabs only) followed by 2 (neighbour rows) == 0, bit for bit."""
+    import torch
+    eng, Vd, out = case['eng'], case['Vd'], case['out']
+    N = Vd.shape[2]
+    out2, work = eng.alloc_outputs(N), eng.alloc_work(N)
+    for v in out2.values():
+        v.fill_(float('nan'))
+    eng.ctx.project_estimate(eng.Q, Vd, eng.ops, work, out2, phase=1)
+    eng.ctx.project_estimate(eng.Q, Vd, eng.ops, work, out2, phase=2)
+    torch.cuda.synchronize()
+    for k in out:
+        assert torch.equal(out[k], out2[k]), k

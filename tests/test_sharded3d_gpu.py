@@ -44,12 +44,12 @@ def _worker(rank, world, port, ref_path, outdir):
         n = grid.template.n
         Vg = _bases(grid.num_subdomains, n)
         V = eng.ctx.zeros(eng.S_ext, n, N)
-        V[eng.S:] = float('nan')                       # the halo slabs hold nothing until the exchange has run
+        V[eng.S:] = float('nan')                       # the halo slabs hold nothing until the exchange has run: phase 1 must not
+                                                       # read them (rows the exchange does not fill are never read at all)
         V[:eng.S] = eng.ctx.from_numpy(Vg[eng.local])
         plan = HaloPlan(lambda r: DDSubdomainsGrid3D(grid.lower_left, grid.upper_right, grid.K, grid.P, rank=r, world_size=world),
                         world, rank)
         halo = HaloExchange(plan, N, V.device)
-        V[eng.S:] = 0.0                                # rows the kernels never read stay zero (NaN * 0 would poison padding lanes)
         out = eng.project_and_estimate(V, halo=halo)
         torch.cuda.synchronize()
         ref = pickle.load(open(ref_path, 'rb'))
