@@ -182,41 +182,72 @@ __global__ __launch_bounds__(256) void k3_scalars(T3 t, const double* __restrict
   }
 }
 
-__global__ __launch_bounds__(128) void k3_assemble_products(T3 t, int Q, const double* __restrict__ lam,
-                                                            const double* __restrict__ lbar, const double* __restrict__ lhat,
-                                                            double* __restrict__ ebar, double* __restrict__ Aaa,
-                                                            double* __restrict__ Aab, double* __restrict__ Bbb) {
-  extern __shared__ double lds[];   // [Q + 1][nC]: lambda_q / lambda_hat, 1 / lambda_hat
-  const int e = blockIdx.x, s = blockIdx.y, c = threadIdx.x;
-  const int ty = t.elem_type[e], nC = t.nC;
-  const double* rh = lhat + ((long)s * t.nT + e) * t.hat_stride + t.nB;
-  for (int k = c; k < nC; k += 128) {
-    const double ih = 1.0 / rh[k];
-    lds[Q * nC + k] = ih;
-    for (int q = 0; q < Q; ++q) lds[q * nC + k] = lam[(((long)q * t.S_ext + s) * t.nT + e) * t.lam_stride + t.o_c + k] * ih;
-  }
-  __syncthreads();
+// Products and estimator operators on the matrix cores.  For the elements of ONE type the contraction
+//     out[e][c] = sum_k W(e, k) TABLE[type][k][c]
+// is a GEMM of the sample rows with the reference table: A operand = W (lane: element li, quadrature point lk), B operand = the
+// table chunk staged in LDS once per workgroup (64 elements = 4 waves x 16), accumulators = 16 elements x 16 entries per tile.
+// (The first version had one workgroup per element re-read the whole 173 KB table from L2 and divide per term: 15.8 ms at
+// config 5.)  OP: 0 ebar (W = lambda_bar), 1 A_aa pair (W = lambda_q lambda_q' / lambda_hat), 2 A_ab (W = lambda_q / lambda_hat,
+// orientation sign of column f at the store), 3 B_bb (W = 1 / lambda_hat, signs of row and column).
+constexpr int ASM_KC = 32;        // quadrature points per staged table chunk
+
+template <int OP, int NCT>
+__global__ __launch_bounds__(256) void k3_asm(T3 t, int Q, int q, int q2, const double* __restrict__ lam, const double* __restrict__ lbar,
+                                              const double* __restrict__ lhat, double* __restrict__ out, double* __restrict__ out_mirror) {
+  __shared__ double Ts[ASM_KC][NCT * 16 + 4];
+  constexpr int C = OP == 2 ? 40 : (OP == 3 ? 16 : 100);
+  const int ty = blockIdx.x % 6, grp = blockIdx.x / 6, s = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int ncube = t.nT / 6;
+  const int cube = grp * 64 + wave * 16 + li;                        // this lane's element (A operand row)
+  const int e = (cube < ncube ? cube : ncube - 1) * 6 + ty;
+  const int K = OP == 0 ? t.nB : t.nC;
+  const double* tab = (OP == 0 ? t.TE : (OP == 1 ? t.TAA : (OP == 2 ? t.TAB : t.TB))) + (long)ty * K * C;
   const long se = (long)s * t.nT + e;
-  if (c < 100) {
-    ebar[se * 100 + c] = contract(lbar + se * t.nB, t.TE + (long)ty * t.nB * 100, t.nB, 100, c);
-    const double* tab = t.TAA + (long)ty * nC * 100;
-    for (int q = 0; q < Q; ++q)
-      for (int q2 = 0; q2 < Q; ++q2) {
-        // lambda_q lambda_q' / lambda_hat = (lq/lh) (lq'/lh) / (1/lh)
-        double acc = 0.0;
-        for (int k = 0; k < nC; ++k) acc += lds[q * nC + k] * lds[q2 * nC + k] / lds[Q * nC + k] * tab[(long)k * 100 + c];
-        Aaa[((((long)q * Q + q2) * t.S + s) * t.nT + e) * 100 + c] = acc;
+  const double* w0 = OP == 0 ? lbar + se * t.nB : lhat + se * t.hat_stride + t.nB;                 // lambda_bar | lambda_hat at rule C
+  const double* w1 = lam + (((long)q * t.S_ext + s) * t.nT + e) * t.lam_stride + t.o_c;           // lambda_q at rule C
+  const double* w2 = lam + (((long)q2 * t.S_ext + s) * t.nT + e) * t.lam_stride + t.o_c;
+  d4 acc[NCT];
+#pragma unroll
+  for (int j = 0; j < NCT; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < K; k0 += ASM_KC) {
+    __syncthreads();
+    for (int i = tid; i < ASM_KC * NCT * 16; i += 256) {
+      const int kk = i / (NCT * 16), c = i - kk * NCT * 16;
+      Ts[kk][c] = (k0 + kk < K && c < C) ? tab[(long)(k0 + kk) * C + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < ASM_KC / 4; ++ks) {
+      const int k = k0 + 4 * ks + lk;
+      double w = 0.0;
+      if (k < K) {
+        if (OP == 0) w = w0[k];
+        else if (OP == 1) w = w1[k] * w2[k] / w0[k];
+        else if (OP == 2) w = w1[k] / w0[k];
+        else w = 1.0 / w0[k];
       }
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, Ts[4 * ks + lk][j * 16 + li], acc[j], 0, 0, 0);
+    }
   }
-  if (c < 40) {
-    const int f = c & 3;
-    const double sg = (double)sgn3(t, s, e, f);
-    for (int q = 0; q < Q; ++q)
-      Aab[(((long)q * t.S + s) * t.nT + e) * 40 + c] = sg * contract(lds + q * nC, t.TAB + (long)ty * nC * 40, nC, 40, c);
-  }
-  if (c < 16) {
-    const double sg = (double)(sgn3(t, s, e, c >> 2) * sgn3(t, s, e, c & 3));
-    Bbb[se * 16 + c] = sg * contract(lds + Q * nC, t.TB + (long)ty * nC * 16, nC, 16, c);
+  // D layout: lane holds elements lk + 4 r of the wave's 16, entry j * 16 + li
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int cb = grp * 64 + wave * 16 + lk + 4 * r;
+    if (cb >= ncube) continue;
+    const int eo = cb * 6 + ty;
+    const long so = (long)s * t.nT + eo;
+#pragma unroll
+    for (int j = 0; j < NCT; ++j) {
+      const int c = j * 16 + li;
+      if (c >= C) continue;
+      double v = acc[j][r];
+      if (OP == 2) v *= (double)sgn3(t, s, eo, c & 3);
+      if (OP == 3) v *= (double)(sgn3(t, s, eo, c >> 2) * sgn3(t, s, eo, c & 3));
+      out[so * C + c] = v;
+      if (OP == 1 && out_mirror) out_mirror[so * C + c] = v;
+    }
   }
 }
 
@@ -1996,10 +2027,19 @@ int lrbms3_assemble_products(lrbms3_ctx* ctx, int32_t Q, const double* lam, cons
   if (Q < 1 || Q > 8 || !lam || !lbar || !lhat || !ebar || !Aaa || !Aab || !Bbb)
     return fail3(ctx, LRBMS_E_INVALID, "assemble_products: bad argument");
   const T3& t = ctx->t;
-  const size_t lds = sizeof(double) * (Q + 1) * t.nC;
-  if (lds > 64 * 1024) return fail3(ctx, LRBMS_E_INVALID, "assemble_products: estimator rule too large for the LDS");
-  hipLaunchKernelGGL(k3_assemble_products, dim3(t.nT, t.S), dim3(128), lds, (hipStream_t)stream, t, Q, lam, lbar, lhat, ebar, Aaa,
-                     Aab, Bbb);
+  if (t.nT % 6) return fail3(ctx, LRBMS_E_INVALID, "assemble_products: template is not made of whole cubes");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(6 * ((t.nT / 6 + 63) / 64), t.S);
+  hipLaunchKernelGGL((k3_asm<0, 7>), grid, dim3(256), 0, st, t, Q, 0, 0, lam, lbar, lhat, ebar, (double*)nullptr);
+  const long blk = (long)t.S * t.nT * 100;
+  for (int q = 0; q < Q; ++q)
+    for (int q2 = q; q2 < Q; ++q2)         // A_aa[q][q'] = A_aa[q'][q]: one contraction, two stores
+      hipLaunchKernelGGL((k3_asm<1, 7>), grid, dim3(256), 0, st, t, Q, q, q2, lam, lbar, lhat, Aaa + ((long)q * Q + q2) * blk,
+                         q2 != q ? Aaa + ((long)q2 * Q + q) * blk : (double*)nullptr);
+  for (int q = 0; q < Q; ++q)
+    hipLaunchKernelGGL((k3_asm<2, 3>), grid, dim3(256), 0, st, t, Q, q, q, lam, lbar, lhat, Aab + (long)q * t.S * t.nT * 40,
+                       (double*)nullptr);
+  hipLaunchKernelGGL((k3_asm<3, 1>), grid, dim3(256), 0, st, t, Q, 0, 0, lam, lbar, lhat, Bbb, (double*)nullptr);
   LAUNCH3(ctx);
   return LRBMS_OK;
 }
