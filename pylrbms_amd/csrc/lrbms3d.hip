@@ -33,6 +33,7 @@ struct T3 {
   const int *dof_node, *node_ptr, *node_dofs, *node_mask, *node_count, *side_nodes, *sn_ptr, *sn_dofs;
   const int *dof_bslot, *bn_ptr, *bn_slots, *bnodes, *bnode_sides, *bel_elem, *bel_bnode, *sel_elem, *sel_sf;
   const double *divc, *TV, *TE, *TAA, *TFo, *TFn, *TFb, *TC, *TCb, *TPH, *TM, *TB, *TAB, *WB, *WC;
+  const double* TSD;     // [6][nA + 8 nFs][100] system diagonal block: TV | per face (TFo | TFb)  (built at mesh upload)
   const double* zeros;   // [64] zeros: target of the loads of padding lanes
 };
 
@@ -108,50 +109,6 @@ __device__ inline double contract(const double* __restrict__ smp, const double* 
   return acc;
 }
 
-__global__ __launch_bounds__(128) void k3_assemble_system(T3 t, const double* __restrict__ lam, double* __restrict__ A_diag,
-                                                          double* __restrict__ A_cpl) {
-  const int e = blockIdx.x, s = blockIdx.y, q = blockIdx.z, c = threadIdx.x;
-  if (c >= 100) return;
-  const int ty = t.elem_type[e];
-  const double* rec = lam + (((long)q * t.S_ext + s) * t.nT + e) * t.lam_stride;
-  double* out = A_diag + ((((long)q * t.S + s) * t.nT + e) * 5) * 100;
-  double acc = contract(rec, t.TV + (long)ty * t.nA * 100, t.nA, 100, c);
-  for (int f = 0; f < 4; ++f) {
-    const int nb = t.nb_elem[e * 4 + f];
-    const double* lf = rec + t.o_fs + f * t.nFs;
-    const long toff = ((long)(ty * 4 + f) * t.nFs) * 100;
-    if (nb >= 0) {
-      acc += contract(lf, t.TFo + toff, t.nFs, 100, c);
-      out[(1 + f) * 100 + c] = contract(lf, t.TFn + toff, t.nFs, 100, c);
-    } else {
-      const int side = -(nb + 1);
-      double* cp = A_cpl + ((((long)q * t.S + s) * 6 + side) * t.ncf + t.face_pos[e * 4 + f]) * 100;
-      out[(1 + f) * 100 + c] = 0.0;
-      if ((t.phys[s] >> side) & 1) {
-        acc += contract(lf, t.TFb + toff, t.nFs, 100, c);
-        cp[c] = 0.0;
-      } else {
-        acc += contract(lf, t.TFo + toff, t.nFs, 100, c);
-        cp[c] = contract(lf, t.TFn + toff, t.nFs, 100, c);
-      }
-    }
-  }
-  out[c] = acc;
-}
-
-__global__ __launch_bounds__(64) void k3_assemble_rhs(T3 t, const double* __restrict__ f_smp, double* __restrict__ b,
-                                                      double* __restrict__ bdiv) {
-  const int e = blockIdx.x, s = blockIdx.y, i = threadIdx.x;
-  const int ty = t.elem_type[e];
-  const double* rec = f_smp + ((long)s * t.nT + e) * t.f_stride;
-  if (i < 10) b[((long)s * t.nT + e) * 10 + i] = contract(rec, t.TPH + (long)ty * t.nB * 10, t.nB, 10, i);
-  if (i == 32) {
-    double acc = 0.0;
-    for (int k = 0; k < t.nC; ++k) acc += t.WC[k] * rec[t.nB + k];
-    bdiv[(long)s * t.nT + e] = acc;
-  }
-}
-
 // f2 = ||f||^2, ceps = min lambda_hat * kmin per subdomain: one workgroup, fixed-order tree
 __global__ __launch_bounds__(256) void k3_scalars(T3 t, const double* __restrict__ f_smp, const double* __restrict__ lhat,
                                                   double* __restrict__ f2, double* __restrict__ ceps) {
@@ -191,22 +148,45 @@ __global__ __launch_bounds__(256) void k3_scalars(T3 t, const double* __restrict
 // orientation sign of column f at the store), 3 B_bb (W = 1 / lambda_hat, signs of row and column).
 constexpr int ASM_KC = 32;        // quadrature points per staged table chunk
 
+//   4 rhs b (W = f at rule B, table w |T| phi_i), 5 int_T f (W = f at rule C, table = the weights), 6 diagonal block of the SWIPDG
+//   system (K = volume rule + 4 faces x (inner-face table | Dirichlet table), the weight of the table that does not apply to the
+//   face set to zero), 7 block towards the neighbour across face `fq2` (inner: A_diag slot 1 + f; coupling face: A_cpl; zero else).
 template <int OP, int NCT>
 __global__ __launch_bounds__(256) void k3_asm(T3 t, int Q, int q, int q2, const double* __restrict__ lam, const double* __restrict__ lbar,
                                               const double* __restrict__ lhat, double* __restrict__ out, double* __restrict__ out_mirror) {
   __shared__ double Ts[ASM_KC][NCT * 16 + 4];
-  constexpr int C = OP == 2 ? 40 : (OP == 3 ? 16 : 100);
+  constexpr int C = OP == 2 ? 40 : (OP == 3 ? 16 : (OP == 4 ? 10 : (OP == 5 ? 1 : 100)));
   const int ty = blockIdx.x % 6, grp = blockIdx.x / 6, s = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int ncube = t.nT / 6;
   const int cube = grp * 64 + wave * 16 + li;                        // this lane's element (A operand row)
   const int e = (cube < ncube ? cube : ncube - 1) * 6 + ty;
-  const int K = OP == 0 ? t.nB : t.nC;
-  const double* tab = (OP == 0 ? t.TE : (OP == 1 ? t.TAA : (OP == 2 ? t.TAB : t.TB))) + (long)ty * K * C;
+  const int fq = q2;                                                 // OP 7: the face
+  const int K = OP == 0 || OP == 4 ? t.nB : (OP == 6 ? t.nA + 8 * t.nFs : (OP == 7 ? t.nFs : t.nC));
+  const double* tab;
+  if (OP == 0) tab = t.TE + (long)ty * K * C;
+  if (OP == 1) tab = t.TAA + (long)ty * K * C;
+  if (OP == 2) tab = t.TAB + (long)ty * K * C;
+  if (OP == 3) tab = t.TB + (long)ty * K * C;
+  if (OP == 4) tab = t.TPH + (long)ty * K * C;
+  if (OP == 5) tab = t.WC;
+  if (OP == 6) tab = t.TSD + (long)ty * K * C;
+  if (OP == 7) tab = t.TFn + ((long)(ty * 4 + fq) * K) * C;
   const long se = (long)s * t.nT + e;
-  const double* w0 = OP == 0 ? lbar + se * t.nB : lhat + se * t.hat_stride + t.nB;                 // lambda_bar | lambda_hat at rule C
-  const double* w1 = lam + (((long)q * t.S_ext + s) * t.nT + e) * t.lam_stride + t.o_c;           // lambda_q at rule C
+  // OP 0: lambda_bar; 1-3: lambda_hat at rule C; 4 / 5: f at rule B / C (passed as lbar)
+  const double* w0 = OP == 0 ? lbar + se * t.nB : (OP == 4 ? lbar + se * t.f_stride : (OP == 5 ? lbar + se * t.f_stride + t.nB
+                                                                                        : lhat + se * t.hat_stride + t.nB));
+  const double* rec = lam + (((long)q * t.S_ext + s) * t.nT + e) * t.lam_stride;                   // lambda_q record of the element
+  const double* w1 = rec + t.o_c;                                                                  // ... at rule C
   const double* w2 = lam + (((long)q2 * t.S_ext + s) * t.nT + e) * t.lam_stride + t.o_c;
+  bool bnd[4] = {false, false, false, false};                        // OP 6 / 7: face on the physical boundary
+  if (OP == 6 || OP == 7) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int nb = t.nb_elem[e * 4 + f];
+      bnd[f] = nb < 0 && ((t.phys[s] >> (-(nb + 1))) & 1);
+    }
+  }
   d4 acc[NCT];
 #pragma unroll
   for (int j = 0; j < NCT; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -222,10 +202,22 @@ __global__ __launch_bounds__(256) void k3_asm(T3 t, int Q, int q, int q2, const 
       const int k = k0 + 4 * ks + lk;
       double w = 0.0;
       if (k < K) {
-        if (OP == 0) w = w0[k];
+        if (OP == 0 || OP == 4 || OP == 5) w = w0[k];
         else if (OP == 1) w = w1[k] * w2[k] / w0[k];
         else if (OP == 2) w = w1[k] / w0[k];
-        else w = 1.0 / w0[k];
+        else if (OP == 3) w = 1.0 / w0[k];
+        else if (OP == 6) {
+          if (k < t.nA) {
+            w = rec[k];
+          } else {                       // face f: nFs points against the inner-face table, then the same points against the Dirichlet table
+            const int kf = k - t.nA, f = kf / (2 * t.nFs), r2 = kf - f * 2 * t.nFs, dir = r2 >= t.nFs, pt = dir ? r2 - t.nFs : r2;
+            const bool bf = f == 0 ? bnd[0] : (f == 1 ? bnd[1] : (f == 2 ? bnd[2] : bnd[3]));
+            w = (bf == (dir != 0)) ? rec[t.o_fs + f * t.nFs + pt] : 0.0;
+          }
+        } else {
+          const bool bf = fq == 0 ? bnd[0] : (fq == 1 ? bnd[1] : (fq == 2 ? bnd[2] : bnd[3]));
+          w = bf ? 0.0 : rec[t.o_fs + fq * t.nFs + k];
+        }
       }
 #pragma unroll
       for (int j = 0; j < NCT; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, Ts[4 * ks + lk][j * 16 + li], acc[j], 0, 0, 0);
@@ -245,8 +237,19 @@ __global__ __launch_bounds__(256) void k3_asm(T3 t, int Q, int q, int q2, const 
       double v = acc[j][r];
       if (OP == 2) v *= (double)sgn3(t, s, eo, c & 3);
       if (OP == 3) v *= (double)(sgn3(t, s, eo, c >> 2) * sgn3(t, s, eo, c & 3));
-      out[so * C + c] = v;
-      if (OP == 1 && out_mirror) out_mirror[so * C + c] = v;
+      if (OP == 6) {
+        out[(((long)q * t.S + s) * t.nT + eo) * 500 + c] = v;
+      } else if (OP == 7) {
+        const int nb = t.nb_elem[eo * 4 + fq];
+        out[(((long)q * t.S + s) * t.nT + eo) * 500 + (1 + fq) * 100 + c] = nb >= 0 ? v : 0.0;
+        if (nb < 0) {
+          const int side = -(nb + 1);
+          out_mirror[((((long)q * t.S + s) * 6 + side) * t.ncf + t.face_pos[eo * 4 + fq]) * 100 + c] = ((t.phys[s] >> side) & 1) ? 0.0 : v;
+        }
+      } else {
+        out[so * C + c] = v;
+        if (OP == 1 && out_mirror) out_mirror[so * C + c] = v;
+      }
     }
   }
 }
@@ -1996,6 +1999,19 @@ int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, in
     const double z[64] = {0.0};
     if ((rc = upload(ctx, z, 64L, &t.zeros)) != LRBMS_OK) return rc;
   }
+  {      // concatenated table of the diagonal block: volume rule, then per face the inner-face and the Dirichlet table
+    const long KD = t.nA + 8L * t.nFs;
+    std::vector<double> tsd((size_t)6 * KD * 100);
+    for (int ty = 0; ty < 6; ++ty) {
+      double* dst = tsd.data() + (size_t)ty * KD * 100;
+      memcpy(dst, d->TV + (size_t)ty * t.nA * 100, sizeof(double) * t.nA * 100);
+      for (int f = 0; f < 4; ++f) {
+        memcpy(dst + ((size_t)t.nA + (size_t)f * 2 * t.nFs) * 100, d->TFo + ((size_t)(ty * 4 + f) * t.nFs) * 100, sizeof(double) * t.nFs * 100);
+        memcpy(dst + ((size_t)t.nA + (size_t)f * 2 * t.nFs + t.nFs) * 100, d->TFb + ((size_t)(ty * 4 + f) * t.nFs) * 100, sizeof(double) * t.nFs * 100);
+      }
+    }
+    if ((rc = upload(ctx, tsd.data(), (long)tsd.size(), &t.TSD)) != LRBMS_OK) return rc;
+  }
   ctx->nbr_host.assign(nbr, nbr + (long)S * 7);
   ctx->has_mesh = true;
   return LRBMS_OK;
@@ -2005,7 +2021,15 @@ int lrbms3_assemble_system(lrbms3_ctx* ctx, int32_t Q, const double* lam, double
   REQUIRE3(ctx);
   if (Q < 1 || Q > 8 || !lam || !A_diag || !A_cpl) return fail3(ctx, LRBMS_E_INVALID, "assemble_system: bad argument");
   const T3& t = ctx->t;
-  hipLaunchKernelGGL(k3_assemble_system, dim3(t.nT, t.S, Q), dim3(128), 0, (hipStream_t)stream, t, lam, A_diag, A_cpl);
+  if (t.nT % 6) return fail3(ctx, LRBMS_E_INVALID, "assemble_system: template is not made of whole cubes");
+  const dim3 grid(6 * ((t.nT / 6 + 63) / 64), t.S);
+  for (int q = 0; q < Q; ++q) {
+    hipLaunchKernelGGL((k3_asm<6, 7>), grid, dim3(256), 0, (hipStream_t)stream, t, Q, q, 0, lam, (const double*)nullptr,
+                       (const double*)nullptr, A_diag, (double*)nullptr);
+    for (int f = 0; f < 4; ++f)
+      hipLaunchKernelGGL((k3_asm<7, 7>), grid, dim3(256), 0, (hipStream_t)stream, t, Q, q, f, lam, (const double*)nullptr,
+                         (const double*)nullptr, A_diag, A_cpl);
+  }
   LAUNCH3(ctx);
   return LRBMS_OK;
 }
@@ -2015,7 +2039,10 @@ int lrbms3_assemble_rhs(lrbms3_ctx* ctx, const double* f_smp, const double* lhat
   REQUIRE3(ctx);
   if (!f_smp || !lhat || !b || !f2 || !ceps || !bdiv) return fail3(ctx, LRBMS_E_INVALID, "assemble_rhs: null argument");
   const T3& t = ctx->t;
-  hipLaunchKernelGGL(k3_assemble_rhs, dim3(t.nT, t.S), dim3(64), 0, (hipStream_t)stream, t, f_smp, b, bdiv);
+  if (t.nT % 6) return fail3(ctx, LRBMS_E_INVALID, "assemble_rhs: template is not made of whole cubes");
+  const dim3 grid(6 * ((t.nT / 6 + 63) / 64), t.S);
+  hipLaunchKernelGGL((k3_asm<4, 1>), grid, dim3(256), 0, (hipStream_t)stream, t, 1, 0, 0, f_smp, f_smp, lhat, b, (double*)nullptr);
+  hipLaunchKernelGGL((k3_asm<5, 1>), grid, dim3(256), 0, (hipStream_t)stream, t, 1, 0, 0, f_smp, f_smp, lhat, bdiv, (double*)nullptr);
   hipLaunchKernelGGL(k3_scalars, dim3(t.S), dim3(256), 0, (hipStream_t)stream, t, f_smp, lhat, f2, ceps);
   LAUNCH3(ctx);
   return LRBMS_OK;
