@@ -135,6 +135,15 @@ int lrbms3_reduced_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
                             const double* Cn, const double* ebar, const double* Bbb, const double* bdiv, const double* f2,
                             const double* ceps, double hdiam, double* eta_loc, void* stream);
 
+/* Throughput form: nmu parameters at once (passes of 8): theta [nmu][Q] host, u [S_ext][N][nmu] (parameter fastest, the layout
+ * lrbms3_reduced_solve_batch returns), eta_loc [3][S][nmu].  Every operator and factor is read once per pass of 8.
+ * 2D: lrbms_reduced_estimate_batch_factored. */
+int lrbms3_reduced_estimate_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* u,
+                                  const double* G_nc, const double* G_bb, const double* G_rdd, const double* G_ab, const double* G_aa,
+                                  const double* r_fd, const double* Rb, const double* Yb, const double* Dp, const double* Xab,
+                                  const double* As, const double* Cn, const double* ebar, const double* Bbb, const double* bdiv,
+                                  const double* f2, const double* ceps, double hdiam, double* eta_loc, void* stream);
+
 /* (sum_q theta_q B_sys_q) u = rhs_red by block-Jacobi preconditioned CG on the 7-slot block-sparse reduced system (S_ext == S).
  * info[0] = iterations, info[1] = final relative residual (host, may be NULL).  2D: lrbms_reduced_solve. */
 int64_t lrbms3_reduced_solve_work_size(lrbms3_ctx* ctx, int32_t N);

@@ -34,6 +34,7 @@ SIGNATURES3 = {
     'lrbms3_kernel_timing': (ctypes.c_int, [c_vp, c_i32]),
     'lrbms3_kernel_timing_read': (ctypes.c_int, [c_vp, ctypes.c_char_p, c_i64, _P_DBL, c_i32, _P_I32]),
     'lrbms3_reduced_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL] + [c_vp] * 18 + [c_dbl, c_vp, c_vp]),
+    'lrbms3_reduced_estimate_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL] + [c_vp] * 18 + [c_dbl, c_vp, c_vp]),
     'lrbms3_reduced_solve_work_size': (c_i64, [c_vp, c_i32]),
     'lrbms3_reduced_solve': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms3_reduced_solve_batch_work_size': (c_i64, [c_vp, c_i32, c_i32]),
@@ -237,6 +238,22 @@ class Native3DContext:
         rc = self.lib.lrbms3_reduced_estimate(self.handle, Q, N, th.ctypes.data_as(_P_DBL), *args, float(hdiam), c_vp(eta.data_ptr()),
                                               self._stream())
         self._check(rc, 'lrbms3_reduced_estimate')
+        return eta
+
+    def reduced_estimate_batch(self, Q, thetas, u, out, ops, hdiam):
+        """thetas [nmu, Q], u [S_ext, N, nmu] (parameter fastest) -> eta_loc [3, S, nmu]."""
+        N, nmu, S = u.shape[1], u.shape[2], self.S
+        shp = self.out_shapes(Q, N)
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        assert th.shape == (nmu, Q)
+        eta = self.empty(3, S, nmu)
+        names = ('G_nc', 'G_bb', 'G_rdd', 'G_ab', 'G_aa', 'r_fd', 'Rb', 'Yb', 'Dp', 'Xab', 'As', 'Cn')
+        args = [self._ptr(u, (self.S_ext, N, nmu), 'u')] + [self._ptr(out[k], shp[k], k) for k in names]
+        args += [self._ptr(ops['ebar'], (S, self.n_T, 100), 'ebar'), self._ptr(ops['Bbb'], (S, self.n_T, 16), 'Bbb'),
+                 self._ptr(ops['bdiv'], (S, self.n_T), 'bdiv'), self._ptr(ops['f2'], (S,), 'f2'), self._ptr(ops['ceps'], (S,), 'ceps')]
+        rc = self.lib.lrbms3_reduced_estimate_batch(self.handle, Q, N, nmu, th.ctypes.data_as(_P_DBL), *args, float(hdiam),
+                                                    c_vp(eta.data_ptr()), self._stream())
+        self._check(rc, 'lrbms3_reduced_estimate_batch')
         return eta
 
     def reduced_solve(self, Q, theta, B_sys, rhs_red, rtol=1e-13, max_iter=5000, work=None):

@@ -1409,6 +1409,159 @@ __global__ __launch_bounds__(256) void k3_estimate(T3 t, int Q, int N, QV th, EA
   }
 }
 
+// Batched form: MB = 8 parameters per workgroup pass.  Threads = (worker w = tid >> 3, parameter m = tid & 7): the eight
+// parameter lanes of a worker read the same factor row (one address, broadcast) and their own coefficient column from LDS, so
+// every projected operator and factor is read once per batch.  u [S_ext][N][nmu] (parameter fastest), eta [3][S][nmu].
+constexpr int EST_MB = 8;
+struct TB8 { double v[EST_MB][8]; };
+
+__global__ __launch_bounds__(256) void k3_estimate_batch(T3 t, int Q, int N, int nmu, int m0, TB8 th, EA a) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x, tid = threadIdx.x, w = tid >> 3, m = tid & 7, QN = Q * N, NWK = 32;
+  const int mb = nmu - m0 < EST_MB ? nmu - m0 : EST_MB;      // parameters of this pass
+  double* us = lds;                       // [7][N][8]
+  double* ur = us + 7 * N * 8;            // [QN][8]
+  double* zf = ur + QN * 8;               // [nbf][8]
+  double* z = zf + t.nbf * 8;             // [nb][8]
+  double* red = z + t.nb * 8;             // [256]
+  for (int i = tid; i < 7 * N * 8; i += 256) {
+    const int mm = i & 7, row = i >> 3, s2 = t.nbr[s * 7 + row / N];
+    us[i] = (s2 >= 0 && mm < mb) ? a.u[((long)s2 * N + row % N) * nmu + m0 + mm] : 0.0;
+  }
+  __syncthreads();
+  const double* u0 = us + 3 * N * 8 + m;          // own coefficients of parameter m: u0[j * 8]
+  for (int i = tid; i < QN * 8; i += 256) {
+    const int mm = i & 7, c = i >> 3;
+    ur[i] = th.v[mm][c / N] * us[(3 * N + c % N) * 8 + mm];
+  }
+  for (int sf = w; sf < t.nbf; sf += NWK) {
+    const double* ua = us + side_slot(sf / t.ncf) * N * 8 + m;
+    const double* r = a.Rb + ((long)s * t.nbf + sf) * QN;
+    double acc = 0.0;
+    for (int q = 0; q < Q; ++q) {
+      double aq = 0.0;
+      for (int j = 0; j < N; ++j) aq += r[q * N + j] * ua[j * 8];
+      acc += th.v[m][q] * aq;
+    }
+    zf[sf * 8 + m] = acc;
+  }
+  for (int bn = w; bn < t.nb; bn += NWK) {
+    double acc = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      const int sp = t.bnode_sides[bn * 3 + k];
+      if (sp < 0) continue;
+      const double* ua = us + side_slot(sp / t.nvs) * N * 8 + m;
+      const double* r = a.As + ((long)s * 6 * t.nvs + sp) * N;
+      for (int j = 0; j < N; ++j) acc += r[j] * ua[j * 8];
+    }
+    z[bn * 8 + m] = acc;
+  }
+  __syncthreads();
+  const double* urm = ur + m;
+  double p_nc = 0.0, p_bb = 0.0, p_dd = 0.0, p_fd = 0.0, p_ab = 0.0, p_aa = 0.0;
+  for (int r = w; r < N; r += NWK) {
+    const double* g = a.G_nc + ((long)s * N + r) * N;
+    double d = 0.0;
+    for (int j = 0; j < N; ++j) d += g[j] * u0[j * 8];
+    p_nc += u0[r * 8] * d;
+    for (int q = 0; q < Q; ++q) {
+      const double* gab = a.G_ab + (((long)q * t.S + s) * N + r) * QN;
+      double dab = 0.0;
+      for (int j = 0; j < QN; ++j) dab += gab[j] * urm[j * 8];
+      p_ab += th.v[m][q] * u0[r * 8] * dab;
+      for (int q2 = 0; q2 < Q; ++q2) {
+        const double* ga = a.G_aa + ((((long)q * Q + q2) * t.S + s) * N + r) * N;
+        double da = 0.0;
+        for (int j = 0; j < N; ++j) da += ga[j] * u0[j * 8];
+        p_aa += th.v[m][q] * th.v[m][q2] * u0[r * 8] * da;
+      }
+    }
+  }
+  for (int bn = w; bn < t.nb; bn += NWK) {
+    const double* g = a.Cn + ((long)s * t.nb + bn) * N;
+    double d = 0.0;
+    for (int j = 0; j < N; ++j) d += g[j] * u0[j * 8];
+    p_nc += 2.0 * z[bn * 8 + m] * d;
+  }
+  for (int k = w; k < t.nbel; k += NWK) {
+    const int e = t.bel_elem[k];
+    const double* E = a.ebar + ((long)s * t.nT + e) * 100;
+    double ze[10];
+    for (int i = 0; i < 10; ++i) {
+      const int bn = t.bel_bnode[k * 10 + i];
+      ze[i] = bn >= 0 ? z[bn * 8 + m] : 0.0;
+    }
+    for (int i = 0; i < 10; ++i) {
+      double d = 0.0;
+      for (int j = 0; j < 10; ++j) d += E[i * 10 + j] * ze[j];
+      p_nc += ze[i] * d;
+    }
+  }
+  for (int r = w; r < QN; r += NWK) {
+    const double* gb = a.G_bb + ((long)s * QN + r) * QN;
+    const double* gd = a.G_rdd + ((long)s * QN + r) * QN;
+    double db = 0.0, dd = 0.0;
+    for (int j = 0; j < QN; ++j) {
+      db += gb[j] * urm[j * 8];
+      dd += gd[j] * urm[j * 8];
+    }
+    p_bb += urm[r * 8] * db;
+    p_dd += urm[r * 8] * dd;
+    p_fd += a.r_fd[(long)s * QN + r] * urm[r * 8];
+  }
+  for (int sf = w; sf < t.nbf; sf += NWK) {
+    const double zz = zf[sf * 8 + m];
+    const double* yb = a.Yb + ((long)s * t.nbf + sf) * QN;
+    const double* dp = a.Dp + ((long)s * t.nbf + sf) * QN;
+    double db = 0.0, dd = 0.0;
+    for (int j = 0; j < QN; ++j) {
+      db += yb[j] * urm[j * 8];
+      dd += dp[j] * urm[j * 8];
+    }
+    p_bb += 2.0 * zz * db;
+    p_dd += 2.0 * zz * dd;
+    for (int q = 0; q < Q; ++q) {
+      const double* xa = a.Xab + (((long)q * t.S + s) * t.nbf + sf) * N;
+      double d = 0.0;
+      for (int j = 0; j < N; ++j) d += xa[j] * u0[j * 8];
+      p_ab += th.v[m][q] * zz * d;
+    }
+  }
+  for (int k = w; k < t.nsel; k += NWK) {
+    const int e = t.sel_elem[k], ty = t.elem_type[e];
+    const double* B = a.Bbb + ((long)s * t.nT + e) * 16;
+    double ze[4], dv = 0.0;
+    for (int f = 0; f < 4; ++f) {
+      const int sf = t.sel_sf[k * 4 + f];
+      ze[f] = sf >= 0 ? zf[sf * 8 + m] : 0.0;
+      dv += sgn3(t, s, e, f) * t.divc[ty * 4 + f] * ze[f];
+    }
+    for (int f = 0; f < 4; ++f)
+      for (int g = 0; g < 4; ++g) p_bb += ze[f] * B[f * 4 + g] * ze[g];
+    p_dd += t.volume * dv * dv;
+    p_fd += a.bdiv[(long)s * t.nT + e] * dv;
+  }
+  // sums over the 32 workers per parameter, fixed order
+  double tot[6];
+  const double part[6] = {p_nc, p_bb, p_dd, p_fd, p_ab, p_aa};
+  for (int k = 0; k < 6; ++k) {
+    __syncthreads();
+    red[tid] = part[k];
+    __syncthreads();
+    double acc = 0.0;
+    if (tid < 8)
+      for (int ww = 0; ww < NWK; ++ww) acc += red[ww * 8 + tid];
+    tot[k] = acc;
+  }
+  if (tid < mb) {
+    const double pi = 3.14159265358979323846;
+    const long o = (long)s * nmu + m0 + tid;
+    a.eta[o] = tot[0];
+    a.eta[(long)t.S * nmu + o] = (a.f2[s] - 2.0 * tot[3] + tot[2]) * (1.0 / (pi * pi)) / a.ceps[s] * a.hdiam * a.hdiam;
+    a.eta[2L * t.S * nmu + o] = tot[1] + 2.0 * tot[4] + tot[5];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------- online: reduced solve
 __global__ __launch_bounds__(256) void k3_combine(long per_q, int Q, QV th, const double* __restrict__ B, double* __restrict__ Amu) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -2233,6 +2386,28 @@ int lrbms3_reduced_estimate(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double*
   const size_t lds = sizeof(double) * (7 * N + Q * N + t.nbf + t.nb + 256);
   if (lds > 64 * 1024) return fail3(ctx, LRBMS_E_INVALID, "reduced_estimate: template too large for the LDS");
   hipLaunchKernelGGL(k3_estimate, dim3(t.S), dim3(256), lds, (hipStream_t)stream, t, Q, N, make_theta(Q, theta), a);
+  LAUNCH3(ctx);
+  return LRBMS_OK;
+}
+
+int lrbms3_reduced_estimate_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* u,
+                                  const double* G_nc, const double* G_bb, const double* G_rdd, const double* G_ab, const double* G_aa,
+                                  const double* r_fd, const double* Rb, const double* Yb, const double* Dp, const double* Xab,
+                                  const double* As, const double* Cn, const double* ebar, const double* Bbb, const double* bdiv,
+                                  const double* f2, const double* ceps, double hdiam, double* eta_loc, void* stream) {
+  REQUIRE3(ctx);
+  if (Q < 1 || Q > 8 || N < 1 || Q * N > 64 || nmu < 1 || !theta || !u || !eta_loc)
+    return fail3(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: bad argument");
+  const T3& t = ctx->t;
+  EA a{u, G_nc, G_bb, G_rdd, G_ab, G_aa, r_fd, Rb, Yb, Dp, Xab, As, Cn, ebar, Bbb, bdiv, f2, ceps, hdiam, eta_loc};
+  const size_t lds = sizeof(double) * ((size_t)(7 * N + Q * N + t.nbf + t.nb) * EST_MB + 256);
+  if (lds > 64 * 1024) return fail3(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: template too large for the LDS");
+  for (int m0 = 0; m0 < nmu; m0 += EST_MB) {
+    TB8 th{};
+    for (int m = 0; m < EST_MB && m0 + m < nmu; ++m)
+      for (int q = 0; q < Q; ++q) th.v[m][q] = theta[(m0 + m) * Q + q];
+    hipLaunchKernelGGL(k3_estimate_batch, dim3(t.S), dim3(256), lds, (hipStream_t)stream, t, Q, N, nmu, m0, th, a);
+  }
   LAUNCH3(ctx);
   return LRBMS_OK;
 }

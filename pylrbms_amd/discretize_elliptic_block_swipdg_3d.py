@@ -99,6 +99,13 @@ class ReducedDiscretization3D:
         U = torch.cat(out, dim=0).contiguous()
         return (U, info) if return_info else U
 
+    def estimate_batch(self, U, mus):
+        """Estimates of the reduced solutions U [len(mus), S, N] (as ``solve_batch`` returns them): list of eta."""
+        eng = self.d.engine
+        th = np.stack([self.d.theta(mu) for mu in mus])
+        eta = eng.ctx.reduced_estimate_batch(self.d.Q, th, U.permute(1, 2, 0).contiguous(), self.out, eng.ops, eng.hdiam).cpu().numpy()
+        return [self.d.combine(eta[:, :, m], mu) for m, mu in enumerate(mus)]
+
     def estimate(self, u, mu, decompose=False):
         eta_loc = self.d.engine.reduced_estimate(self.d.theta(mu), u.contiguous(), self.out)
         return self.d.combine(eta_loc.cpu().numpy(), mu, decompose)

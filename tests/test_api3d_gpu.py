@@ -75,3 +75,19 @@ def test_snapshots_bases_reduced_model_workflow():
     err = Ur.cpu().numpy().ravel() - o.solve(mu)
     assert np.sqrt(o.energy_norm2(err, mu)) < 0.05 * np.sqrt(o.energy_norm2(o.solve(mu), mu))
     assert abs(rd.estimate(u, mu) - d.estimate(Ur, mu)) < 1e-8 * rd.estimate(u, mu)
+
+
+def test_batched_online_phase_through_the_api():
+    from pylrbms_amd.discretize_elliptic_block_swipdg_3d import LRBMSReductor3D, discretize
+    p = c3.make_problem('aniso_2x2x1')
+    pd = {'grid': p['grid'], 'lambda': {'functions': p['lambdas'], 'coefficients': p['thetas']}, 'lambda_bar': p['lambda_bar'],
+          'lambda_hat': p['lambda_hat'], 'f': p['f'], 'mu_bar': p['mu_bar'], 'mu_hat': p['mu_hat']}
+    d, _ = discretize(pd)
+    rd = LRBMSReductor3D(d, c3.make_bases3d(d.engine.S, d.engine.t.n, 6, seed=1)).reduce()
+    mus = [0.1 + 0.05 * k for k in range(19)]                          # two native batches (16 + 3)
+    U = rd.solve_batch(mus, rtol=1e-13)
+    etas = rd.estimate_batch(U, mus)
+    for k in (0, 7, 18):
+        u = rd.solve(mus[k], rtol=1e-13)
+        assert c3.rel(U[k].cpu().numpy(), u.cpu().numpy()) < 1e-10
+        assert abs(etas[k] - rd.estimate(u, mus[k])) < 1e-10 * etas[k]

@@ -174,3 +174,18 @@ def test_phased_pass_is_bit_identical_to_the_whole_pass(case):
     torch.cuda.synchronize()
     for k in out:
         assert torch.equal(out[k], out2[k]), k
+
+
+def test_batched_estimate_matches_single_estimates(case):
+    p, d, eng, rd, out = case['p'], case['d'], case['eng'], case['rd'], case['out']
+    rng = np.random.default_rng(8)
+    nmu = 11                                            # two passes of the kernel: 8 + 3
+    mus = list(rng.uniform(0.1, 1.3, size=nmu))
+    U = rng.standard_normal((d.S, p['N'], nmu))
+    thetas = np.stack([c3.theta_of(p, mu) for mu in mus])
+    eta = eng.ctx.reduced_estimate_batch(d.Q, thetas, eng.ctx.from_numpy(U), out, eng.ops, eng.hdiam).cpu().numpy()
+    for m, mu in enumerate(mus):
+        ref = rd.local_terms([U[ii, :, m] for ii in range(d.S)], mu)
+        one = eng.reduced_estimate(thetas[m], eng.ctx.from_numpy(np.ascontiguousarray(U[:, :, m])), out).cpu().numpy()
+        for k in range(3):
+            assert c3.rel(eta[k, :, m], ref[k]) < 1e-10 and c3.rel(eta[k, :, m], one[k]) < 1e-12, (m, k)
