@@ -91,6 +91,13 @@ class ReducedDiscretization3D:
         import torch
         eng, out = self.d.engine, []
         info = (0, 0.0)
+        if self.N > 32:                       # the batched kernels take N <= 32: one native solve per parameter
+            for mu in mus:
+                u, inf = self.solve(mu, rtol=rtol, max_iter=max_iter, return_info=True)
+                out.append(u[None])
+                info = (max(info[0], inf[0]), max(info[1], inf[1]))
+            U = torch.cat(out, dim=0).contiguous()
+            return (U, info) if return_info else U
         for b0 in range(0, len(mus), 16):
             th = np.stack([self.d.theta(mu) for mu in mus[b0:b0 + 16]])
             ub, inf = eng.ctx.reduced_solve_batch(self.d.Q, th, self.out['B_sys'], self.out['rhs_red'], rtol=rtol, max_iter=max_iter)

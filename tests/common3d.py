@@ -35,6 +35,8 @@ PROBLEMS = {
     'q1_strip': ([3, 1, 1], 2, [_lam2], [lambda mu: mu], np.eye(3), 3, 1.3),
     'q3_2x1x2': ([2, 1, 2], 1, [_one, _lam1, _lam2], [lambda mu: 1.0, lambda mu: mu, lambda mu: mu * mu], KAPPA_ANISO, 6, 0.6),
     'wide_basis': ([2, 1, 1], 2, [_one, _lam1], [lambda mu: 1.0, lambda mu: mu], np.eye(3), 30, 0.4),
+    # unequal cubes per direction: sides with fewer faces / nodes than the padded tables hold, odd cube counts in the traversal
+    'kc_3x1x2': ([2, 2, 2], (3, 1, 2), [_one, _lam1], [lambda mu: 1.0, lambda mu: mu], KAPPA_ANISO, 4, 0.8),
 }
 
 
@@ -47,7 +49,7 @@ def make_problem(name):
 
 
 def oracle_of(p):
-    mesh = KuhnMesh3D(np.asarray(p['P']) * p['kc'], p['P'])
+    mesh = KuhnMesh3D(np.asarray(p['P']) * np.asarray(p['kc']), p['P'])
     return Discretization3D(mesh, p['lambdas'], p['thetas'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], p['mu_bar'],
                             p['mu_hat'])
 
