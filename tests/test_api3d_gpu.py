@@ -91,3 +91,42 @@ def test_batched_online_phase_through_the_api():
         u = rd.solve(mus[k], rtol=1e-13)
         assert c3.rel(U[k].cpu().numpy(), u.cpu().numpy()) < 1e-10
         assert abs(etas[k] - rd.estimate(u, mus[k])) < 1e-10 * etas[k]
+
+
+def test_experimental_orders_of_convergence_of_the_product():
+    """Convergence study of the 3D / P2 PRODUCT (the validation the reference's OS2015_convergence_study.py performs in 2D):
+    full-order solves on 2^3, 3^3, 4^3 cubes of one subdomain for u = sin(pi x) sin(pi y) sin(pi z); L2 / H1 errors (evaluated with
+    the oracle's quadrature on the host) converge with orders 3 / 2, the estimate decreases and equals the oracle's."""
+    from oracle.lrbms3d import Discretization3D
+    from oracle.mesh3d import KuhnMesh3D
+    from pylrbms_amd.discretize_elliptic_block_swipdg_3d import discretize
+    from pylrbms_amd.grid3d import make_grid3d
+    pi = np.pi
+    one = lambda x: 1.0 + 0.0 * x[..., 0]                                                           # noqa: E731
+    uex = lambda x: np.sin(pi * x[..., 0]) * np.sin(pi * x[..., 1]) * np.sin(pi * x[..., 2])        # noqa: E731
+    f = lambda x: 3 * pi * pi * uex(x)                                                              # noqa: E731
+    rows = []
+    for K in (2, 3, 4):
+        grid = make_grid3d(num_subdomains=(1, 1, 1), cubes_per_subdomain_and_dim=K)
+        pd = {'grid': grid, 'lambda': {'functions': [one], 'coefficients': [lambda mu: 1.0]}, 'lambda_bar': one, 'lambda_hat': one,
+              'f': f, 'mu_bar': 1.0, 'mu_hat': 1.0, 'data_degree': 4}
+        d, _ = discretize(pd)
+        U = d.solve(1.0, rtol=1e-12)
+        m = KuhnMesh3D([K] * 3, [1, 1, 1])
+        o = Discretization3D(m, [one], [lambda mu: 1.0], np.eye(3), f, one, one, 1.0, 1.0, data_degree=4)
+        u = U.cpu().numpy().ravel()
+        assert c3.rel(u, o.solve(1.0)) < 1e-8
+        x, w, phi, grad = o._vol_points(8)
+        Ue = u.reshape(m.num_elements, 10)
+        uh, gh = np.einsum('ki,ei->ek', phi, Ue), np.einsum('ekia,ei->eka', grad, Ue)
+        c, s_ = np.cos(pi * x), np.sin(pi * x)
+        ge = pi * np.stack([c[..., 0] * s_[..., 1] * s_[..., 2], s_[..., 0] * c[..., 1] * s_[..., 2], s_[..., 0] * s_[..., 1] * c[..., 2]], -1)
+        l2 = np.sqrt(np.einsum('k,e,ek->', w, m.volume, (uh - uex(x)) ** 2))
+        h1 = np.sqrt(np.einsum('k,e,eka->', w, m.volume, (gh - ge) ** 2))
+        eta = d.estimate(U, 1.0)
+        assert abs(eta - o.estimate(u, 1.0)) < 1e-8 * eta
+        rows.append((K, l2, h1, eta))
+    (k0, a0, b0, e0), (k1, a1, b1, e1) = rows[1], rows[2]
+    rate = lambda x0, x1: np.log(x0 / x1) / np.log(k1 / k0)                                         # noqa: E731
+    assert rate(a0, a1) > 2.8 and rate(b0, b1) > 1.8
+    assert e1 < e0 < rows[0][3]
