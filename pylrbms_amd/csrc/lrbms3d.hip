@@ -410,6 +410,8 @@ struct GA {
   double* Zb;   // NC: rows of E W_self at the boundary DoFs [S][nbd][N]
   double *out2, *out3;     // BB: G_rdd [S][QN][QN], r_fd [S][QN] (accumulated beside G_bb: they share every operand)
   const double* bdiv;
+  const double* b;        // SYS: right-hand side [S][n]; rhs_red = V^T b rides on the X operands of the q = 0 blocks
+  double* out4;           // SYS: rhs_red [S][N]
 };
 
 // ------------------------------------------------------------------------------------------------- pass: MFMA pipeline
@@ -630,7 +632,10 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
 #pragma unroll
     for (int j = 0; j < CT; ++j) fd[j] = 0.0;
   }
-  // B_sys: lane constants of the symmetric form (below)
+  // B_sys: lane constants of the symmetric form (below); rhs_red accumulators of the q = 0 blocks
+  double racc[KIND == G_SYS ? RT : 1];
+#pragma unroll
+  for (int i = 0; i < (KIND == G_SYS ? RT : 1); ++i) racc[i] = 0.0;
   unsigned sl_full, sy_full[2][CT], sl_rem, sy_rem[CT];
   if constexpr (KIND == G_SYS) {
     sl_full = 8u * (lic * 10 + (WIDE ? 2 * lk : lk));                 // rows j = 2 lk, 2 lk + 1 (one 16-byte load) / j = lk, 4 + lk
@@ -761,6 +766,9 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
             xop[rt][r] = xin[r] ? ld8(Vs, ex + xc[r][rt]) : *zero;
           }
         }
+      double bv[KR];                                      // q = 0 (wave-uniform): the element's entries of b for rhs_red = V^T b
+#pragma unroll
+      for (int r = 0; r < KR; ++r) bv[r] = (q == 0 && xin[r]) ? a.b[(long)s * t.n + e * 10 + 4 * r + lk] : 0.0;
       load_idx(item0 + NW, ix2);
       ix1 = ix2;
       lop[0] *= 0.5;                                      // the diagonal block enters H with the factor 1/2
@@ -783,6 +791,10 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
 #pragma unroll
           for (int r = 0; r < KR; ++r) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[rt][r], z[r], acc[rt][ct], 0, 0, 0);
       }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < KR; ++r) racc[rt] += xop[rt][r] * bv[r];
       continue;
     }
     if constexpr (KIND == G_BB) {
@@ -1097,6 +1109,27 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
     }
   }
   if constexpr (KIND == G_SYS) {       // B = H + H^T through the LDS (Mx My <= RT CT 256 doubles)
+    if (q == 0) {                      // rhs_red: sum over the four k lanes, then over the waves in a fixed order
+      __shared__ double rsh[16][RT * 16];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        double v = racc[i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lk == 0) rsh[wave][i * 16 + li] = v;
+      }
+      __syncthreads();
+      if (wave == 0 && lk == 0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          double v = 0.0;
+          for (int ww = 0; ww < NW; ++ww) v += rsh[ww][i * 16 + li];
+          const int col = WIDE ? li * RT + i : i * 16 + li;
+          if (col < N) a.out4[(long)s * N + col] = v;
+        }
+      }
+    }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
@@ -1163,35 +1196,6 @@ int dispatch_pg(const GA& a, int batch, int rt, int ct, int nw, hipStream_t st) 
   if constexpr (KIND == G_AB) { PGCASE(1, 1) PGCASE(1, 2) PGCASE(1, 3) PGCASE(1, 4) PGCASE(2, 2) PGCASE(2, 3) PGCASE(2, 4) PGCASE(3, 3) PGCASE(3, 4) PGCASE(4, 4) }
 #undef PGCASE
   return -1;
-}
-
-// rhs_red [S][N] = V^T b.  256 threads = G row groups x CW column lanes (CW = 32 for <= 32 columns), four independent partial
-// sums per thread so that the loads of four rows are in flight together.  (r_fd comes out of k3_pg<BB>.)
-__global__ __launch_bounds__(256) void k3_vecs(T3 t, int N, const double* __restrict__ V, const double* __restrict__ b,
-                                               double* __restrict__ rhs_red) {
-  __shared__ double red[256];
-  const int s = blockIdx.x, tid = threadIdx.x;
-  const int CW = N <= 32 ? 32 : 64, G = 256 / CW, c = tid % CW, g = tid / CW;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  if (c < N) {
-    const double* v = V + (long)s * t.n * N + c;
-    const double* bs = b + (long)s * t.n;
-    int kr = g;
-    for (; kr + 3 * G < t.n; kr += 4 * G) {
-      a0 += bs[kr] * v[(long)kr * N];
-      a1 += bs[kr + G] * v[(long)(kr + G) * N];
-      a2 += bs[kr + 2 * G] * v[(long)(kr + 2 * G) * N];
-      a3 += bs[kr + 3 * G] * v[(long)(kr + 3 * G) * N];
-    }
-    for (; kr < t.n; kr += G) a0 += bs[kr] * v[(long)kr * N];
-  }
-  red[tid] = (a0 + a1) + (a2 + a3);
-  __syncthreads();
-  if (g == 0 && c < N) {
-    double acc = 0.0;
-    for (int k = 0; k < G; ++k) acc += red[k * CW + c];
-    rhs_red[(long)s * N + c] = acc;
-  }
 }
 
 // per side face: Yb = row of B R_self, Dp = |T| div_f div R_self, Xab_q = A_ab_q^T V at the face
@@ -2176,6 +2180,8 @@ int lrbms3_assemble_system(lrbms3_ctx* ctx, int32_t Q, const double* lam, double
   const T3& t = ctx->t;
   if (t.nT % 6) return fail3(ctx, LRBMS_E_INVALID, "assemble_system: template is not made of whole cubes");
   const dim3 grid(6 * ((t.nT / 6 + 63) / 64), t.S);
+  // sides with fewer faces than the padded row length (unequal cubes per direction) leave positions no kernel writes: zero
+  HIP3(ctx, hipMemsetAsync(A_cpl, 0, sizeof(double) * (size_t)Q * t.S * 6 * t.ncf * 100, (hipStream_t)stream));
   for (int q = 0; q < Q; ++q) {
     hipLaunchKernelGGL((k3_asm<6, 7>), grid, dim3(256), 0, (hipStream_t)stream, t, Q, q, 0, lam, (const double*)nullptr,
                        (const double*)nullptr, A_diag, (double*)nullptr);
@@ -2279,7 +2285,7 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
   HIP3(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP3(ctx, hipStreamWaitEvent(sf, ctx->ev_fork, 0));
   HIP3(ctx, hipStreamWaitEvent(sn, ctx->ev_fork, 0));
-  GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr, Zb, G_rdd, r_fd, bdiv};
+  GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr, Zb, G_rdd, r_fd, bdiv, b, rhs_red};
   const int tn = (N + 15) / 16, tq = (Q * N + 15) / 16;
   static const int nw_env = getenv("LRBMS3_NW") ? atoi(getenv("LRBMS3_NW")) : 0;   // experiment knob: waves per workgroup
   const int nw = nw_env > 0 ? nw_env : 4;
@@ -2331,10 +2337,6 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
     bad |= dispatch_pg<G_CPL>(a, Q * t.S * 6, tn, tn, nw, st);
   }
   if (bad) return fail3(ctx, LRBMS_E_INVALID, "project_estimate: unsupported tile shape");
-  if (own) {
-    KScope3 k(ctx, "k3_vecs", st);
-    hipLaunchKernelGGL(k3_vecs, dim3(t.S), dim3(256), 0, st, t, N, V, b, rhs_red);
-  }
   if (own) {
     KScope3 k(ctx, "k3_side_flux", sf);
     hipLaunchKernelGGL(k3_side_flux, dim3(t.nbf, t.S), dim3(64), 0, sf, t, Q, N, V, Aab, Bbb, Rs, Yb, Dp, Xab);
