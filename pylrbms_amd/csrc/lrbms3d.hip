@@ -47,6 +47,7 @@ struct lrbms3_ctx {
   std::vector<int32_t> nbr_host;
   hipStream_t aux[2] = {nullptr, nullptr};          // library-owned streams: the flux chain and the Oswald chain of the pass
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  bool side_padding = false;       // some side has fewer faces than ncf (unequal cubes per direction): padded factor rows exist
   bool ktime = false;
   struct KTimer { const char* name; hipEvent_t e0, e1; };
   std::vector<KTimer> ktimers;
@@ -412,6 +413,7 @@ struct GA {
   const double* bdiv;
   const double* b;        // SYS: right-hand side [S][n]; rhs_red = V^T b rides on the X operands of the q = 0 blocks
   double* out4;           // SYS: rhs_red [S][N]
+  double *Yb, *Dp, *Xab;  // BB: rows of B R_self and |T| div div R_self at the side faces; AB: A_ab^T V at the side faces
 };
 
 // ------------------------------------------------------------------------------------------------- pass: MFMA pipeline
@@ -428,6 +430,16 @@ template <> struct PGT<G_NC> { static constexpr int MZ = 10, KY = 10; };
 template <> struct PGT<G_CPL> { static constexpr int MZ = 10, KY = 10; };
 template <> struct PGT<G_AB> { static constexpr int MZ = 4, KY = 10; };    // contracted through the 4 faces: W = A_ab^T V_e first
 template <> struct PGT<G_BB> { static constexpr int MZ = 4, KY = 4; };
+
+// side-face index (side * ncf + pos) of face f of element e, or -1; `has`: the neighbour across that side exists
+__device__ inline int side_face_of(const T3& t, int s, int e, int f, bool& has) {
+  const int nb = t.nb_elem[e * 4 + f];
+  has = false;
+  if (nb >= 0) return -1;
+  const int side = -(nb + 1);
+  has = t.nbr[s * 7 + side_slot(side)] >= 0;
+  return side * t.ncf + t.face_pos[e * 4 + f];
+}
 
 constexpr int pg_max_threads(int tiles) { return tiles <= 4 ? 1024 : (tiles <= 8 ? 512 : 256); }   // VGPR budget 128 / 256 / 512
 
@@ -828,14 +840,27 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
       load_idx(item0 + NW, ix2);
       ix1 = ix2;
       const double dsel = lk == 0 ? dd[0] : (lk == 1 ? dd[1] : (lk == 2 ? dd[2] : dd[3]));
-      const double l1 = li == 0 ? dsel : 0.0;             // A operand of z1: row 0 = d^T, all other rows zero
-      double zb[CT], z1[CT];
+      const double l1 = li < 4 ? dsel : 0.0;              // A operand of z1: rows 0..3 = d^T (every k lane then holds the row)
+      bool shas;
+      const int sfi = side_face_of(t, s, e, lk, shas);    // this lane's face f = lk as a side face
+      double zb[CT], z1r[CT], z1[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const d4 z0 = (d4){0.0, 0.0, 0.0, 0.0};
         zb[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(lopB, re[ct], z0, 0, 0, 0)[0];      // rows f = lk of B_bb R_e
-        z1[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, re[ct], z0, 0, 0, 0)[0];        // row 0 in the lanes lk = 0, zero elsewhere
+        z1r[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, re[ct], z0, 0, 0, 0)[0];       // d^T R_e, replicated in the four k lanes
+        z1[ct] = lk == 0 ? z1r[ct] : 0.0;                                                 // ... as a k = 1 operand
         fd[ct] += bd * z1[ct];
+      }
+      if (sfi >= 0) {      // side-face factors (read by the estimate): Yb = row of B R_self, Dp = |T| d_f (d^T R_self); 0 if no neighbour
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int col = WIDE ? li * CT + ct : ct * 16 + li;
+          if (col < My) {
+            a.Yb[((long)s * t.nbf + sfi) * QN + col] = shas ? zb[ct] : 0.0;
+            a.Dp[((long)s * t.nbf + sfi) * QN + col] = shas ? t.volume * dsel * z1r[ct] : 0.0;
+          }
+        }
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
@@ -856,6 +881,8 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
       const int e = ix1.e;
       const double* Lb = Lall + (long)e * LSTRIDE;
       const unsigned ex = (unsigned)e * erow, rb = (unsigned)ix1.aux[0] * ((unsigned)QN * 8u);
+      bool shas;
+      const int sfi = side_face_of(t, s, e, lk, shas);    // this lane's face f = lk as a side face
       double lop[3], vv[RT][3], re[CT];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -892,6 +919,10 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
         d4 z = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < 3; ++k) z = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[k], vv[rt][k], z, 0, 0, 0);
+        if (sfi >= 0) {        // side-face factor Xab_q = (A_ab^T V_e) at the face (0 if there is no neighbour)
+          const int col = WIDE ? li * RT + rt : rt * 16 + li;
+          if (col < N) a.Xab[(((long)q * t.S + s) * t.nbf + sfi) * N + col] = shas ? z[0] : 0.0;
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[0], re[ct], acc[rt][ct], 0, 0, 0);
       }
@@ -1196,39 +1227,6 @@ int dispatch_pg(const GA& a, int batch, int rt, int ct, int nw, hipStream_t st) 
   if constexpr (KIND == G_AB) { PGCASE(1, 1) PGCASE(1, 2) PGCASE(1, 3) PGCASE(1, 4) PGCASE(2, 2) PGCASE(2, 3) PGCASE(2, 4) PGCASE(3, 3) PGCASE(3, 4) PGCASE(4, 4) }
 #undef PGCASE
   return -1;
-}
-
-// per side face: Yb = row of B R_self, Dp = |T| div_f div R_self, Xab_q = A_ab_q^T V at the face
-__global__ __launch_bounds__(64) void k3_side_flux(T3 t, int Q, int N, const double* __restrict__ V, const double* __restrict__ Aab,
-                                                   const double* __restrict__ Bbb, const double* __restrict__ Rs,
-                                                   double* __restrict__ Yb, double* __restrict__ Dp, double* __restrict__ Xab) {
-  const int sf = blockIdx.x, s = blockIdx.y, c = threadIdx.x, QN = Q * N;
-  const int e = t.side_elem[sf], f = t.side_face[sf];
-  const bool on = e >= 0 && t.nbr[s * 7 + side_slot(sf / t.ncf)] >= 0;
-  if (c < QN) {
-    double yb = 0.0, dp = 0.0;
-    if (on) {
-      const int ty = t.elem_type[e];
-      double dv = 0.0;
-      for (int g = 0; g < 4; ++g) {
-        const double r = Rs[((long)s * t.nrt + t.elem_rt[e * 4 + g]) * QN + c];
-        yb += Bbb[((long)s * t.nT + e) * 16 + f * 4 + g] * r;
-        dv += sgn3(t, s, e, g) * t.divc[ty * 4 + g] * r;
-      }
-      dp = t.volume * sgn3(t, s, e, f) * t.divc[ty * 4 + f] * dv;
-    }
-    Yb[((long)s * t.nbf + sf) * QN + c] = yb;
-    Dp[((long)s * t.nbf + sf) * QN + c] = dp;
-  }
-  if (c < N) {
-    for (int q = 0; q < Q; ++q) {
-      double acc = 0.0;
-      if (on)
-        for (int i = 0; i < 10; ++i)
-          acc += Aab[(((long)q * t.S + s) * t.nT + e) * 40 + i * 4 + f] * V[((long)s * t.n + e * 10 + i) * N + c];
-      Xab[(((long)q * t.S + s) * t.nbf + sf) * N + c] = acc;
-    }
-  }
 }
 
 // Cn [S][nb][N] = -(P^T E W_self) at the boundary nodes: sum of the rows k3_pg<NC> left in Zb over the DoFs of the node.
@@ -2170,6 +2168,8 @@ int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, in
     if ((rc = upload(ctx, tsd.data(), (long)tsd.size(), &t.TSD)) != LRBMS_OK) return rc;
   }
   ctx->nbr_host.assign(nbr, nbr + (long)S * 7);
+  ctx->side_padding = false;
+  for (int i = 0; i < t.nbf; ++i) ctx->side_padding = ctx->side_padding || d->side_elem[i] < 0;
   ctx->has_mesh = true;
   return LRBMS_OK;
 }
@@ -2285,7 +2285,12 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
   HIP3(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP3(ctx, hipStreamWaitEvent(sf, ctx->ev_fork, 0));
   HIP3(ctx, hipStreamWaitEvent(sn, ctx->ev_fork, 0));
-  GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr, Zb, G_rdd, r_fd, bdiv, b, rhs_red};
+  GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr, Zb, G_rdd, r_fd, bdiv, b, rhs_red, Yb, Dp, Xab};
+  if (own && ctx->side_padding) {      // padded side-face rows are written by no kernel: define them (the estimate multiplies them by 0)
+    HIP3(ctx, hipMemsetAsync(Yb, 0, sizeof(double) * (size_t)t.S * t.nbf * Q * N, sf));
+    HIP3(ctx, hipMemsetAsync(Dp, 0, sizeof(double) * (size_t)t.S * t.nbf * Q * N, sf));
+    HIP3(ctx, hipMemsetAsync(Xab, 0, sizeof(double) * (size_t)Q * t.S * t.nbf * N, sf));
+  }
   const int tn = (N + 15) / 16, tq = (Q * N + 15) / 16;
   static const int nw_env = getenv("LRBMS3_NW") ? atoi(getenv("LRBMS3_NW")) : 0;   // experiment knob: waves per workgroup
   const int nw = nw_env > 0 ? nw_env : 4;
@@ -2337,10 +2342,6 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
     bad |= dispatch_pg<G_CPL>(a, Q * t.S * 6, tn, tn, nw, st);
   }
   if (bad) return fail3(ctx, LRBMS_E_INVALID, "project_estimate: unsupported tile shape");
-  if (own) {
-    KScope3 k(ctx, "k3_side_flux", sf);
-    hipLaunchKernelGGL(k3_side_flux, dim3(t.nbf, t.S), dim3(64), 0, sf, t, Q, N, V, Aab, Bbb, Rs, Yb, Dp, Xab);
-  }
   HIP3(ctx, hipEventRecord(ctx->ev_join[0], sf));
   HIP3(ctx, hipEventRecord(ctx->ev_join[1], sn));
   HIP3(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0));
