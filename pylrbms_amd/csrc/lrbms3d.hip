@@ -2307,6 +2307,13 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
     hipLaunchKernelGGL(k3_node_avg, dim3(xcd_grid((r1 - r0 + 3) / 4, t.S)), dim3(256), 0, sn, t, N, r0, r1, V, Avg, As);
   }
   const int npair = Q * (Q + 1) / 2;       // A_aa: pairs q <= q', the transposed blocks are written from the same accumulators
+  // (launch order measured: the MFMA-bound G_aa kernel first on the caller's stream, beside the latency-bound preparation
+  // kernels of the other two chains, the HBM-bound system kernel after it: 2.39 -> 2.29 ms; a fourth stream for G_aa: slower)
+  if (own) {
+    KScope3 k(ctx, "k3_pg<AAA>", st);
+    a.out = G_aa;
+    bad |= dispatch_pg<G_AAA>(a, npair * t.S, tn, tn, nw, st);
+  }
   if (own) {
     KScope3 k(ctx, "k3_pg<SYS>", st);
     a.out = B_sys;
@@ -2321,11 +2328,6 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
     KScope3 k(ctx, "k3_pg<NC>", sn);
     a.out = G_nc;
     bad |= dispatch_pg<G_NC>(a, t.S, tn, tn, nw_s, sn);
-  }
-  if (own) {
-    KScope3 k(ctx, "k3_pg<AAA>", st);
-    a.out = G_aa;
-    bad |= dispatch_pg<G_AAA>(a, npair * t.S, tn, tn, nw, st);
   }
   if (own) {
     KScope3 k(ctx, "k3_pg<BB>", sf);
