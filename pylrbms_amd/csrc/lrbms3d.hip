@@ -2332,7 +2332,7 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
   if (own) {
     KScope3 k(ctx, "k3_pg<BB>", sf);
     a.out = G_bb;
-    bad |= dispatch_pg<G_BB>(a, t.S, tq, tq, nw_s, sf);
+    bad |= dispatch_pg<G_BB>(a, t.S, tq, tq, nw, sf);          // 4 waves: 291 us, 8 waves: 307 us (tools/nw_sweep.sh)
   }
   if (own) {
     KScope3 k(ctx, "k3_side_nc", sn);
