@@ -254,8 +254,11 @@ def main():
     cpu5 = None
     do_cfg5 = world == 1 and rank == 0 and args.config == 'cfg3' and not args.no_config5
     if do_cfg5 and not args.no_cpu_baseline:
-        import bench3d
-        cpu5 = bench3d.cpu_baseline3d(bench3d.CONFIGS3D['cfg5']['N'])
+        try:
+            import bench3d
+            cpu5 = bench3d.cpu_baseline3d(bench3d.CONFIGS3D['cfg5']['N'])
+        except Exception as exc:
+            cpu5 = {'error': '{}: {}'.format(type(exc).__name__, exc)}
 
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before the HIP runtime is loaded (dmabuf IPC only)
     import torch
@@ -551,9 +554,12 @@ def main():
             import bench3d
             del buf, V
             torch.cuda.empty_cache()
-            out['config5'] = bench3d.run('cfg5', steps=10, warmup=2, device_index=local_rank, cpu=False, online=not args.no_online)
-            if cpu5 is not None:
-                out['config5']['cpu_baseline'] = cpu5
+            try:
+                out['config5'] = bench3d.run('cfg5', steps=10, warmup=2, device_index=local_rank, cpu=False, online=not args.no_online)
+                if cpu5 is not None:
+                    out['config5']['cpu_baseline'] = cpu5
+            except Exception as exc:           # the config-3 line must not depend on the second leg: report, do not fail
+                out['config5'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
