@@ -47,6 +47,8 @@ struct lrbms3_ctx {
   std::vector<int32_t> nbr_host;
   hipStream_t aux[2] = {nullptr, nullptr};          // library-owned streams: the flux chain and the Oswald chain of the pass
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  double* pg_part = nullptr;       // K-split partial results of the k3_pg kernels (library-owned, grown on demand)
+  long pg_part_cap = 0;
   bool side_padding = false;       // some side has fewer faces than ncf (unequal cubes per direction): padded factor rows exist
   bool ktime = false;
   struct KTimer { const char* name; hipEvent_t e0, e1; };
@@ -414,6 +416,8 @@ struct GA {
   const double* b;        // SYS: right-hand side [S][n]; rhs_red = V^T b rides on the X operands of the q = 0 blocks
   double* out4;           // SYS: rhs_red [S][N]
   double *Yb, *Dp, *Xab;  // BB: rows of B R_self and |T| div div R_self at the side faces; AB: A_ab^T V at the side faces
+  int ksplit;             // > 1: the items of a (subdomain, operator) are dealt to ksplit workgroups, partial results go to `part`
+  double* part;           //      [batch][ksplit][pg_part_size] and k3_pg_combine sums them in a fixed order
 };
 
 // ------------------------------------------------------------------------------------------------- pass: MFMA pipeline
@@ -443,6 +447,58 @@ __device__ inline int side_face_of(const T3& t, int s, int e, int f, bool& has) 
 
 constexpr int pg_max_threads(int tiles) { return tiles <= 4 ? 1024 : (tiles <= 8 ? 512 : 256); }   // VGPR budget 128 / 256 / 512
 
+// Block id -> (subdomain, operator, part).  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2); all operator
+// blocks (and all parts) of one subdomain read the same basis rows, so they get ids that differ by multiples of 8 inside one chunk
+// of 8 subdomains: same XCD, launched together.
+template <int KIND>
+struct PGBlock {
+  int b, s, q, q2, Mx, My, t2, side, part;
+  double* out;
+  __device__ bool decode(const GA& a, int x) {
+    const T3& t = a.t;
+    const int N = a.N, Q = a.Q, QN = Q * N, ks = a.ksplit;
+    const int nops = KIND == G_SYS || KIND == G_AB ? Q : (KIND == G_AAA ? Q * (Q + 1) / 2 : (KIND == G_CPL ? 6 * Q : 1));
+    const int chunk = x / (8 * nops * ks), within = x - chunk * 8 * nops * ks;
+    const int op = (within >> 3) / ks, sx = chunk * 8 + (within & 7);
+    part = (within >> 3) - op * ks;
+    if (sx >= t.S) return false;
+    b = KIND == G_CPL ? ((op / 6) * t.S + sx) * 6 + op % 6 : op * t.S + sx;
+    q = q2 = t2 = side = 0;
+    if (KIND == G_SYS) {
+      q = b / t.S; s = b - q * t.S; Mx = My = N;
+      out = a.out + (((long)q * t.S + s) * 7 + 3) * N * N;
+    } else if (KIND == G_CPL) {
+      side = b % 6;
+      const int qs = b / 6;
+      q = qs / t.S; s = qs - q * t.S; Mx = My = N;
+      t2 = t.nbr[s * 7 + side_slot(side)];
+      out = a.out + (((long)q * t.S + s) * 7 + side_slot(side)) * N * N;
+    } else if (KIND == G_AAA) {       // one block per pair q <= q2 (row-major); the block (q2, q) is the transpose
+      int p = b / t.S;
+      s = b - p * t.S; Mx = My = N;
+      while (p >= Q - q) p -= Q - q, ++q;
+      q2 = q + p;
+      out = a.out + (((long)q * Q + q2) * t.S + s) * N * N;
+    } else if (KIND == G_NC) {
+      s = b; Mx = My = N;
+      out = a.out + (long)b * N * N;
+    } else if (KIND == G_AB) {
+      q = b / t.S; s = b - q * t.S; Mx = N; My = QN;
+      out = a.out + (long)b * N * QN;
+    } else {
+      s = b; Mx = My = QN;
+      out = a.out + (long)b * QN * QN;
+    }
+    return true;
+  }
+};
+
+// doubles of one partial result: the output matrix (BB: G_bb and G_rdd) plus one row (SYS: rhs_red, BB: r_fd)
+template <int KIND>
+__host__ __device__ inline long pg_part_size(int N, int QN) {
+  return KIND == G_BB ? 2L * QN * QN + QN : (KIND == G_AB ? (long)N * QN : (KIND == G_SYS ? (long)N * N + N : (long)N * N));
+}
+
 __device__ inline double ld8(const double* base, unsigned byte_off) {   // uniform base + 32-bit lane offset: no 64-bit VALU
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
 }
@@ -470,48 +526,17 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
   constexpr bool NCK = KIND == G_NC, FACEK = KIND == G_AB || KIND == G_BB;
   const T3& t = a.t;
   const int N = a.N, Q = a.Q, QN = Q * N;
-  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  All operator blocks of one subdomain read the same
-  // basis rows, so they get ids that differ by multiples of 8 inside one chunk of 8 subdomains: same XCD, launched together.
-  const int nops = KIND == G_SYS || KIND == G_AB ? Q : (KIND == G_AAA ? Q * (Q + 1) / 2 : (KIND == G_CPL ? 6 * Q : 1));
-  int b;
-  {
-    const int x = blockIdx.x, chunk = x / (8 * nops), within = x - chunk * 8 * nops;
-    const int o = within >> 3, sx = chunk * 8 + (within & 7);
-    if (sx >= t.S) return;
-    b = KIND == G_CPL ? ((o / 6) * t.S + sx) * 6 + o % 6 : o * t.S + sx;
-  }
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NW = blockDim.x >> 6;
-  int s, q = 0, q2 = 0, Mx, My, t2 = 0, side = 0, nitems = t.nT;
-  double* out;
-  if (KIND == G_SYS) {
-    q = b / t.S; s = b - q * t.S; Mx = My = N;
-    out = a.out + (((long)q * t.S + s) * 7 + 3) * N * N;
-  } else if (KIND == G_CPL) {
-    side = b % 6;
-    const int qs = b / 6;
-    q = qs / t.S; s = qs - q * t.S; Mx = My = N; nitems = t.ncf;
-    t2 = t.nbr[s * 7 + side_slot(side)];
-    out = a.out + (((long)q * t.S + s) * 7 + side_slot(side)) * N * N;
-  } else if (KIND == G_AAA) {       // one workgroup per pair q <= q2 (row-major); the block (q2, q) is the transpose
-    int p = b / t.S;
-    s = b - p * t.S; Mx = My = N;
-    while (p >= Q - q) p -= Q - q, ++q;
-    q2 = q + p;
-    out = a.out + (((long)q * Q + q2) * t.S + s) * N * N;
-  } else if (KIND == G_NC) {
-    s = b; Mx = My = N;
-    out = a.out + (long)b * N * N;
-  } else if (KIND == G_AB) {
-    q = b / t.S; s = b - q * t.S; Mx = N; My = QN;
-    out = a.out + (long)b * N * QN;
-  } else {
-    s = b; Mx = My = QN;
-    out = a.out + (long)b * QN * QN;
-  }
-  if (KIND == G_CPL && t2 < 0) {
-    for (int i = tid; i < Mx * My; i += blockDim.x) out[i] = 0.0;
+  PGBlock<KIND> B;
+  if (!B.decode(a, blockIdx.x)) return;
+  const int b = B.b, s = B.s, q = B.q, q2 = B.q2, Mx = B.Mx, My = B.My, t2 = B.t2, side = B.side, part = B.part;
+  double* out = B.out;
+  int nitems = KIND == G_CPL ? t.ncf : t.nT;
+  if (KIND == G_CPL && t2 < 0) {        // no neighbour on that side: the block is zero (the combine kernel skips it too)
+    if (part == 0)
+      for (int i = tid; i < Mx * My; i += blockDim.x) out[i] = 0.0;
     return;
   }
   const double* Vs = a.V + (long)s * t.n * N;
@@ -691,9 +716,13 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
     }
   }
 
+  // the items of this part: a contiguous range of the traversal
+  const int plen = (nitems + a.ksplit - 1) / a.ksplit, pbeg = part * plen;
+  const int pend = pbeg + plen < nitems ? pbeg + plen : nitems;
+  double* P = a.ksplit > 1 ? a.part + ((long)b * a.ksplit + part) * pg_part_size<KIND>(N, QN) : nullptr;
   Idx ix1, ix2;
-  load_idx(wave, ix1);
-  for (int item0 = wave; item0 < nitems; item0 += NW) {
+  load_idx(pbeg + wave, ix1);
+  for (int item0 = pbeg + wave; item0 < pend; item0 += NW) {
     const int item = item0 < last ? item0 : last;
     if constexpr (KIND == G_SYS) {
       // Symmetric form: A[e', e] = A[e, e']^T, so with H = sum_e V_e^T (1/2 A_ee V_e + sum_{e' > e} A[e, e'] V_e') the projection is
@@ -1088,6 +1117,34 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
         for (int j = 0; j < CT; ++j) fd[j] += lfd[j * 64 + lane];
       }
     }
+    if (wave == 0 && P) {                  // K-split: both matrices in full (mirrored) and the r_fd row as a partial result
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = i; j < CT; ++j) {
+          const int col = WIDE ? li * CT + j : j * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = WIDE ? (lk + 4 * r) * RT + i : i * 16 + lk + 4 * r;
+            if (row < Mx && col < My) {
+              P[(long)row * My + col] = acc[i][j][r];
+              P[(long)QN * QN + (long)row * My + col] = accd[i][j][r];
+              if (i != j) {
+                P[(long)col * My + row] = acc[i][j][r];
+                P[(long)QN * QN + (long)col * My + row] = accd[i][j][r];
+              }
+            }
+          }
+        }
+      if (lk == 0) {
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          const int col = WIDE ? li * CT + j : j * 16 + li;
+          if (col < My) P[2L * QN * QN + col] = fd[j];
+        }
+      }
+      return;
+    }
     if (wave == 0) {
       double* o2 = a.out2 + (long)s * QN * QN;
 #pragma unroll
@@ -1157,9 +1214,25 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
           double v = 0.0;
           for (int ww = 0; ww < NW; ++ww) v += rsh[ww][i * 16 + li];
           const int col = WIDE ? li * RT + i : i * 16 + li;
-          if (col < N) a.out4[(long)s * N + col] = v;
+          if (col < N) (P ? P[(long)N * N + col] : a.out4[(long)s * N + col]) = v;
         }
       }
+    }
+    if (P) {                                // K-split: H itself is the partial result, the combine kernel forms H + H^T
+      if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < CT; ++j) {
+            const int col = WIDE ? li * CT + j : j * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = WIDE ? (lk + 4 * r) * RT + i : i * 16 + lk + 4 * r;
+              if (row < Mx && col < My) P[(long)row * My + col] = acc[i][j][r];
+            }
+          }
+      }
+      return;
     }
     __syncthreads();
     if (wave == 0) {
@@ -1182,6 +1255,20 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
     }
     return;
   }
+  if (wave == 0 && P) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const int col = WIDE ? li * CT + j : j * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = WIDE ? (lk + 4 * r) * RT + i : i * 16 + lk + 4 * r;
+          if (row < Mx && col < My) P[(long)row * My + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   if (wave == 0) {
     double* mirror = nullptr;       // AAA: block (q2, q) = transpose of block (q, q2)
     if (KIND == G_AAA && q != q2) mirror = a.out + (((long)q2 * Q + q) * t.S + s) * N * N;
@@ -1202,9 +1289,59 @@ __global__ __launch_bounds__(pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT
   }
 }
 
+// K-split: sum of the partial results of a (subdomain, operator) in the fixed order part = 0 .. ksplit - 1, then the epilogue of
+// the kind (B_sys = H + H^T and rhs_red; mirrored A_aa block; G_bb, G_rdd, r_fd)
+template <int KIND>
+__global__ __launch_bounds__(256) void k3_pg_combine(GA a) {
+  PGBlock<KIND> B;
+  GA a1 = a;
+  a1.ksplit = 1;
+  if (!B.decode(a1, blockIdx.x)) return;
+  const T3& t = a.t;
+  const int N = a.N, Q = a.Q, QN = Q * N, ks = a.ksplit;
+  if (KIND == G_CPL && B.t2 < 0) return;
+  const long psz = pg_part_size<KIND>(N, QN);
+  const double* P = a.part + (long)B.b * ks * psz;
+  const int Mx = B.Mx, My = B.My, nent = Mx * My;
+  for (int i = threadIdx.x; i < nent; i += 256) {
+    double v = 0.0;
+    for (int p = 0; p < ks; ++p) v += P[p * psz + i];
+    if (KIND == G_SYS) {
+      const int row = i / My, col = i - row * My;
+      double vt = 0.0;
+      for (int p = 0; p < ks; ++p) vt += P[p * psz + (long)col * My + row];
+      B.out[i] = v + vt;
+    } else {
+      B.out[i] = v;
+      if (KIND == G_AAA && B.q != B.q2) {
+        const int row = i / My, col = i - row * My;
+        a.out[(((long)B.q2 * Q + B.q) * t.S + B.s) * N * N + (long)col * My + row] = v;
+      }
+      if (KIND == G_BB) {
+        double v2 = 0.0;
+        for (int p = 0; p < ks; ++p) v2 += P[p * psz + (long)QN * QN + i];
+        a.out2[(long)B.s * QN * QN + i] = v2;
+      }
+    }
+  }
+  if (KIND == G_SYS && B.q == 0)
+    for (int i = threadIdx.x; i < N; i += 256) {
+      double v = 0.0;
+      for (int p = 0; p < ks; ++p) v += P[p * psz + (long)N * N + i];
+      a.out4[(long)B.s * N + i] = v;
+    }
+  if (KIND == G_BB)
+    for (int i = threadIdx.x; i < QN; i += 256) {
+      double v = 0.0;
+      for (int p = 0; p < ks; ++p) v += P[p * psz + 2L * QN * QN + i];
+      a.out3[(long)B.s * QN + i] = v;
+    }
+}
+
 template <int KIND, int RT, int CT>
 void launch_pg(const GA& a, int batch, int nw, hipStream_t st) {
-  batch = batch / a.t.S * ((a.t.S + 7) / 8 * 8);     // whole chunks of 8 subdomains (k3_pg: XCD-aware block ids)
+  const int batch1 = batch / a.t.S * ((a.t.S + 7) / 8 * 8);     // whole chunks of 8 subdomains (PGBlock: XCD-aware block ids)
+  batch = batch1 * a.ksplit;
   constexpr int maxt = pg_max_threads(KIND == G_BB ? (RT > 2 ? 8 : 4) : RT * CT * (KIND == G_NC || KIND == G_SYS ? 2 : 1));   // NC also holds the node averages of its operands; BB: two upper tile triangles
   if (nw * 64 > maxt) nw = maxt / 64;
   constexpr bool EVEN = RT % 2 == 0 && CT % 2 == 0;
@@ -1213,6 +1350,7 @@ void launch_pg(const GA& a, int batch, int nw, hipStream_t st) {
     hipLaunchKernelGGL((k3_pg<KIND, RT, CT, EVEN>), dim3(batch), dim3(64 * nw), ldsb, st, a);
   else
     hipLaunchKernelGGL((k3_pg<KIND, RT, CT, false>), dim3(batch), dim3(64 * nw), ldsb, st, a);
+  if (a.ksplit > 1) hipLaunchKernelGGL((k3_pg_combine<KIND>), dim3(batch1), dim3(256), 0, st, a);
 }
 
 // tile shapes: square (rt == ct) for everything but AB, where ct = tiles of Q N >= rt = tiles of N
@@ -2097,6 +2235,7 @@ int lrbms3_ctx_destroy(lrbms3_ctx* ctx) {
   if (!ctx) return LRBMS_E_INVALID;
   (void)hipSetDevice(ctx->device);
   for (void* p : ctx->owned) (void)hipFree(p);
+  if (ctx->pg_part) (void)hipFree(ctx->pg_part);
   for (int i = 0; i < 2; ++i) {
     if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
@@ -2285,7 +2424,7 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
   HIP3(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP3(ctx, hipStreamWaitEvent(sf, ctx->ev_fork, 0));
   HIP3(ctx, hipStreamWaitEvent(sn, ctx->ev_fork, 0));
-  GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr, Zb, G_rdd, r_fd, bdiv, b, rhs_red, Yb, Dp, Xab};
+  GA a{t, Q, N, V, A_diag, A_cpl, ebar, Aaa, Aab, Bbb, Rs, Avg, nullptr, Zb, G_rdd, r_fd, bdiv, b, rhs_red, Yb, Dp, Xab, 1, nullptr};
   if (own && ctx->side_padding) {      // padded side-face rows are written by no kernel: define them (the estimate multiplies them by 0)
     HIP3(ctx, hipMemsetAsync(Yb, 0, sizeof(double) * (size_t)t.S * t.nbf * Q * N, sf));
     HIP3(ctx, hipMemsetAsync(Dp, 0, sizeof(double) * (size_t)t.S * t.nbf * Q * N, sf));
@@ -2307,30 +2446,74 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
     hipLaunchKernelGGL(k3_node_avg, dim3(xcd_grid((r1 - r0 + 3) / 4, t.S)), dim3(256), 0, sn, t, N, r0, r1, V, Avg, As);
   }
   const int npair = Q * (Q + 1) / 2;       // A_aa: pairs q <= q', the transposed blocks are written from the same accumulators
+  // K-split for small per-rank subdomain counts (the 4 x 4 x 4 tile of an 8-GPU run has 64): one workgroup per (subdomain,
+  // operator) would leave most of the 256 CUs idle, so the element range is dealt to ksplit workgroups and k3_pg_combine sums
+  // their partial results in a fixed order.  Off (ksplit = 1, no extra launch) from ~400 workgroups per kernel on.
+  static const int ks_env = getenv("LRBMS3_KSPLIT") ? atoi(getenv("LRBMS3_KSPLIT")) : 0;          // experiment knob
+  auto ksplit_of = [&](int nblocks) {
+    if (ks_env > 0) return ks_env < 8 ? ks_env : 8;
+    if (nblocks >= 384) return 1;
+    const int k = (512 + nblocks - 1) / nblocks;
+    return k < 8 ? k : 8;
+  };
+  const int QNl = Q * N;
+  const int ks_sys = ksplit_of(Q * t.S), ks_aaa = ksplit_of(npair * t.S), ks_nc = ksplit_of(t.S), ks_ab = ksplit_of(Q * t.S),
+            ks_bb = ksplit_of(t.S), ks_cpl = ksplit_of(Q * t.S * 6);
+  const long need_sys = ks_sys > 1 ? (long)Q * t.S * ks_sys * pg_part_size<G_SYS>(N, QNl) : 0,
+             need_aaa = ks_aaa > 1 ? (long)npair * t.S * ks_aaa * pg_part_size<G_AAA>(N, QNl) : 0,
+             need_nc = ks_nc > 1 ? (long)t.S * ks_nc * pg_part_size<G_NC>(N, QNl) : 0,
+             need_ab = ks_ab > 1 ? (long)Q * t.S * ks_ab * pg_part_size<G_AB>(N, QNl) : 0,
+             need_bb = ks_bb > 1 ? (long)t.S * ks_bb * pg_part_size<G_BB>(N, QNl) : 0,
+             need_cpl = ks_cpl > 1 ? (long)Q * t.S * 6 * ks_cpl * pg_part_size<G_CPL>(N, QNl) : 0;
+  const long need = need_sys + need_aaa + need_nc + need_ab + need_bb + need_cpl;
+  if (need > ctx->pg_part_cap) {
+    HIP3(ctx, hipDeviceSynchronize());
+    if (ctx->pg_part) (void)hipFree(ctx->pg_part);
+    ctx->pg_part = nullptr;
+    ctx->pg_part_cap = 0;
+    HIP3(ctx, hipMalloc((void**)&ctx->pg_part, sizeof(double) * need));
+    ctx->pg_part_cap = need;
+  }
+  double* part_sys = ctx->pg_part;
+  double* part_aaa = part_sys + need_sys;
+  double* part_nc = part_aaa + need_aaa;
+  double* part_ab = part_nc + need_nc;
+  double* part_bb = part_ab + need_ab;
+  double* part_cpl = part_bb + need_bb;
   // (launch order measured: the MFMA-bound G_aa kernel first on the caller's stream, beside the latency-bound preparation
   // kernels of the other two chains, the HBM-bound system kernel after it: 2.39 -> 2.29 ms; a fourth stream for G_aa: slower)
   if (own) {
     KScope3 k(ctx, "k3_pg<AAA>", st);
+    a.ksplit = ks_aaa;
+    a.part = part_aaa;
     a.out = G_aa;
     bad |= dispatch_pg<G_AAA>(a, npair * t.S, tn, tn, nw, st);
   }
   if (own) {
     KScope3 k(ctx, "k3_pg<SYS>", st);
+    a.ksplit = ks_sys;
+    a.part = part_sys;
     a.out = B_sys;
     bad |= dispatch_pg<G_SYS>(a, Q * t.S, tn, tn, nw, st);
   }
   if (own) {
     KScope3 k(ctx, "k3_pg<AB>", sf);
+    a.ksplit = ks_ab;
+    a.part = part_ab;
     a.out = G_ab;
     bad |= dispatch_pg<G_AB>(a, Q * t.S, tn, tq, nw, sf);
   }
   if (own) {
     KScope3 k(ctx, "k3_pg<NC>", sn);
+    a.ksplit = ks_nc;
+    a.part = part_nc;
     a.out = G_nc;
     bad |= dispatch_pg<G_NC>(a, t.S, tn, tn, nw_s, sn);
   }
   if (own) {
     KScope3 k(ctx, "k3_pg<BB>", sf);
+    a.ksplit = ks_bb;
+    a.part = part_bb;
     a.out = G_bb;
     bad |= dispatch_pg<G_BB>(a, t.S, tq, tq, nw, sf);          // 4 waves: 291 us, 8 waves: 307 us (tools/nw_sweep.sh)
   }
@@ -2340,6 +2523,8 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
   }
   if (side) {
     KScope3 k(ctx, "k3_pg<CPL>", st);
+    a.ksplit = ks_cpl;
+    a.part = part_cpl;
     a.out = B_sys;
     bad |= dispatch_pg<G_CPL>(a, Q * t.S * 6, tn, tn, nw, st);
   }
