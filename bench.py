@@ -555,7 +555,8 @@ def main():
             del buf, V
             torch.cuda.empty_cache()
             try:
-                out['config5'] = bench3d.run('cfg5', steps=10, warmup=2, device_index=local_rank, cpu=False, online=not args.no_online)
+                out['config5'] = bench3d.run('cfg5', steps=args.steps, warmup=args.warmup, device_index=local_rank, cpu=False,
+                                             online=not args.no_online)
                 if cpu5 is not None:
                     out['config5']['cpu_baseline'] = cpu5
             except Exception as exc:           # the config-3 line must not depend on the second leg: report, do not fail

@@ -1,6 +1,8 @@
 // C ABI of liblrbms_hip.so (declared in include/lrbms_hip.h): context, mesh upload, argument checks, dispatch.
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "lrbms_dev.h"
 
@@ -72,6 +74,42 @@ void free_owned(lrbms_ctx* ctx) {
 
 }  // namespace
 
+// ---- the process-wide side streams (lrbms_dev.h)
+namespace {
+struct SideStream { hipStream_t s = nullptr; int users = 0; };
+std::mutex side_mutex;
+std::map<int, SideStream> side_streams;     // key: device * 4 + i
+}  // namespace
+
+hipStream_t lrbms_side_stream_acquire(int device, int i) {
+  if (i < 0 || i >= 3) return nullptr;
+  std::lock_guard<std::mutex> lock(side_mutex);
+  SideStream& e = side_streams[device * 4 + i];
+  if (!e.s) {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+    if (cur != device && hipSetDevice(device) != hipSuccess) return nullptr;
+    const bool ok = hipStreamCreateWithFlags(&e.s, hipStreamNonBlocking) == hipSuccess;
+    if (cur != device) (void)hipSetDevice(cur);
+    if (!ok) {
+      e.s = nullptr;
+      return nullptr;
+    }
+  }
+  ++e.users;
+  return e.s;
+}
+
+void lrbms_side_stream_release(int device, int i) {
+  std::lock_guard<std::mutex> lock(side_mutex);
+  auto it = side_streams.find(device * 4 + i);
+  if (it == side_streams.end() || it->second.users <= 0) return;
+  if (--it->second.users == 0) {
+    (void)hipStreamDestroy(it->second.s);      // waits for nothing: the last context synchronised its work before it went
+    side_streams.erase(it);
+  }
+}
+
 extern "C" {
 
 const char* lrbms_version(void) { return "lrbms_hip 0.1.0 (gfx950)"; }
@@ -87,12 +125,9 @@ int lrbms_ctx_create(int device, lrbms_ctx** out) {
   ctx->device = device;
   bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; i < 3 && ok; ++i)
-    ok = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess &&
+    ok = (ctx->aux[i] = lrbms_side_stream_acquire(device, i)) != nullptr &&
          hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
-  if (!ok) {
-    delete ctx;
-    return LRBMS_E_HIP;
-  }
+  if (!ok) return lrbms_ctx_destroy(ctx), LRBMS_E_HIP;     // gives back what was acquired
   *out = ctx;
   return LRBMS_OK;
 }
@@ -105,7 +140,7 @@ int lrbms_ctx_destroy(lrbms_ctx* ctx) {
   if (ctx->ksp_part) (void)hipFree(ctx->ksp_part);
   if (ctx->ksp_ticket) (void)hipFree(ctx->ksp_ticket);
   for (int i = 0; i < 3; ++i) {
-    if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
+    if (ctx->aux[i]) lrbms_side_stream_release(ctx->device, i);
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

@@ -19,6 +19,10 @@
 
 #include "../../include/lrbms3d_hip.h"
 
+// the process-wide side streams (capi.hip; see lrbms_dev.h): shared with the 2D contexts so that all of them fit the hardware queues
+hipStream_t lrbms_side_stream_acquire(int device, int i);
+void lrbms_side_stream_release(int device, int i);
+
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -2218,15 +2222,10 @@ int lrbms3_ctx_create(int device, lrbms3_ctx** out) {
   lrbms3_ctx* c = new lrbms3_ctx();
   c->device = device;
   for (int i = 0; i < 2; ++i)
-    if (hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) {
-      delete c;
-      return LRBMS_E_HIP;
-    }
-  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) {
-    delete c;
-    return LRBMS_E_HIP;
-  }
+    if ((c->aux[i] = lrbms_side_stream_acquire(device, i)) == nullptr ||
+        hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
+      return lrbms3_ctx_destroy(c), LRBMS_E_HIP;
+  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return lrbms3_ctx_destroy(c), LRBMS_E_HIP;
   *out = c;
   return LRBMS_OK;
 }
@@ -2237,7 +2236,7 @@ int lrbms3_ctx_destroy(lrbms3_ctx* ctx) {
   for (void* p : ctx->owned) (void)hipFree(p);
   if (ctx->pg_part) (void)hipFree(ctx->pg_part);
   for (int i = 0; i < 2; ++i) {
-    if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
+    if (ctx->aux[i]) lrbms_side_stream_release(ctx->device, i);
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

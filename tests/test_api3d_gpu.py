@@ -130,3 +130,36 @@ def test_experimental_orders_of_convergence_of_the_product():
     rate = lambda x0, x1: np.log(x0 / x1) / np.log(k1 / k0)                                         # noqa: E731
     assert rate(a0, a1) > 2.8 and rate(b0, b1) > 1.8
     assert e1 < e0 < rows[0][3]
+
+
+def test_contexts_of_one_process_share_the_side_streams():
+    """HIP maps streams onto few hardware queues, so every context of the process (2D and 3D) uses the same library-owned side
+    streams (csrc/lrbms_dev.h): two 2D contexts report the same handles, and a 3D pass gives bit-identical results whether or not
+    other contexts are alive and after they are gone (the pool is reference-counted)."""
+    import torch
+    from pylrbms_amd._native import NativeContext
+    from pylrbms_amd.engine3d import Engine3D
+    p = c3.make_problem('aniso_2x2x1')
+    o = c3.oracle_of(p)
+    V = c3.make_bases3d(o.S, o.n, p['N'], seed=5)
+
+    def one_pass():
+        eng = Engine3D(p['grid'], p['lambdas'], p['f'], p['lambda_bar'], p['lambda_hat']).assemble()
+        out = eng.project_and_estimate(eng.ctx.from_numpy(V))
+        torch.cuda.synchronize()
+        res = {k: v.cpu().numpy().copy() for k, v in out.items()}
+        eng.ctx.close()
+        return res
+    alone = one_pass()
+    a, b = NativeContext(0), NativeContext(0)
+    try:
+        for i in range(3):
+            ha, hb = a.lib.lrbms_ctx_aux_stream(a.handle, i), b.lib.lrbms_ctx_aux_stream(b.handle, i)
+            assert ha and ha == hb
+        beside = one_pass()
+    finally:
+        a.close()
+        b.close()
+    after = one_pass()
+    for k in alone:
+        assert np.array_equal(alone[k], beside[k]) and np.array_equal(alone[k], after[k]), k
