@@ -273,7 +273,8 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            from pylrbms_amd.parallel import init_rccl
+            init_rccl(torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)
 

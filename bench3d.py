@@ -91,7 +91,8 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
     torch.cuda.set_device(device_index)
     if world > 1:
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', device_index))
+            from pylrbms_amd.parallel import init_rccl
+            init_rccl(torch.device('cuda', device_index))
         else:
             dist.init_process_group(backend)
     pcfg = {'num_subdomains': cfg['num_subdomains'], 'cubes_per_subdomain': cfg['cubes_per_subdomain']}

@@ -17,6 +17,20 @@ Works with any torch.distributed backend (``nccl`` = RCCL on the GPUs, ``gloo`` 
 import numpy as np
 
 
+def init_rccl(device, **kw):
+    """``torch.distributed.init_process_group('nccl', device_id=device, ...)`` with the collectives' stream taken from the
+    HIGH-priority pool.  HIP maps the streams of a priority level onto four hardware queues; the caller's stream and the
+    library's side streams (csrc/lrbms_dev.h) can fill them, and a stream that shares a queue runs behind that queue's kernels
+    -- an exchange that lands behind the pass's long MFMA kernel overlaps with nothing.  High-priority
+    streams have queues of their own, so the exchange never depends on the order in which streams were created."""
+    import torch.distributed as dist
+    try:
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    except Exception:                 # a build of torch without the option: the default stream pool
+        opts = None
+    dist.init_process_group('nccl', device_id=device, pg_options=opts, **kw)
+
+
 class Communicator:
     """Minimal stand-in for the ``mpi_comm`` argument of the reference API (rank / size only)."""
 

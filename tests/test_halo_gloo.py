@@ -113,8 +113,11 @@ def _loopback_case(device, backend, port):
     all_to_all to the rank itself and lands in the halo slabs (the collective branch of HaloExchange.start / finish)."""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    kw = {'device_id': torch.device(device)} if backend == 'nccl' else {}
-    dist.init_process_group(backend, rank=0, world_size=1, **kw)
+    if backend == 'nccl':
+        from pylrbms_amd.parallel import init_rccl
+        init_rccl(torch.device(device), rank=0, world_size=1)          # what bench.py calls on every rank
+    else:
+        dist.init_process_group(backend, rank=0, world_size=1)
     try:
         mk = lambda r: DDSubdomainsGrid([0, 0], [1, 1], (P[0] * KC, P[1] * KC), P, rank=r, world_size=2)  # noqa: E731
         grid = mk(0)
