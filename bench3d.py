@@ -246,15 +246,21 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
                          'solver': 'block-Jacobi PCG on the 7-slot block-sparse reduced system, rtol 1e-12, 16 parameters per call '
                                    '(lrbms3_reduced_solve_batch: every projected block read once per iteration for the batch)'}
     if online:
-        # snapshot generation: one full-order solve (block-Jacobi CG on the never-assembled block operator)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        # snapshot generation: one full-order solve (two-level CG on the never-assembled block operator: element blocks + P1 per subdomain)
         try:
-            _, finfo = eng.ctx.fom_solve(Q, np.array([1.0, 0.5]), eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=1e-8,
-                                         max_iter=20000)
-            torch.cuda.synchronize()
-            res['snapshot'] = {'metric': 'full-order solve (d.solve)', 'ms': 1e3 * (time.perf_counter() - t0), 'dofs': S * t.n,
-                               'cg_iterations': finfo[0], 'relative_residual': finfo[1], 'rtol': 1e-8}
+            fwork = eng.ctx.empty(int(eng.ctx.lib.lrbms3_fom_solve_work_size(eng.ctx.handle)))
+            for rep in range(2):                      # the first call creates the rocBLAS handle and loads rocSOLVER's kernels
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, finfo = eng.ctx.fom_solve(Q, np.array([1.0, 0.5]), eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=1e-8,
+                                             max_iter=20000, work=fwork)
+                torch.cuda.synchronize()
+                fms = 1e3 * (time.perf_counter() - t0)
+            del fwork
+            res['snapshot'] = {'metric': 'full-order solve (d.solve)', 'ms': fms, 'dofs': S * t.n,
+                               'cg_iterations': finfo[0], 'relative_residual': finfo[1], 'rtol': 1e-8,
+                               'preconditioner': 'inverse 10x10 element blocks + Galerkin coarse level on P1 per subdomain '
+                                                 '(built inside the timed solve)'}
         except Exception as exc:                      # reported, not fatal for the bench line
             res['snapshot'] = {'error': str(exc)}
     if base is not None:

@@ -159,9 +159,17 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
                                const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
                                void* stream);
 
-/* Snapshot generation: A(mu) x = b on the never-assembled block operator, CG with the 10 x 10 element blocks as block-Jacobi
- * preconditioner (S_ext == S).  b, x [S][n]; work: lrbms3_fom_solve_work_size doubles; info[0] = iterations, info[1] = final
- * relative residual (host, may be NULL); LRBMS_E_NOT_CONVERGED above rtol after max_iter.  2D: lrbms_fom_solve. */
+/* Snapshot generation: A(mu) x = b on the never-assembled block operator (S_ext == S), CG with a two-level additive
+ * preconditioner: the inverse 10 x 10 element blocks plus, if lrbms3_fom_coarse_space was called, the Galerkin coarse problem on
+ * nc functions per subdomain (dense (nc S)^2 inverse by rocSOLVER per solve; the 2D solver's coarse space are the subdomain
+ * indicator functions).  b, x [S][n]; work: lrbms3_fom_solve_work_size doubles; info[0] = iterations, info[1] = final relative
+ * residual (host, may be NULL); LRBMS_E_NOT_CONVERGED above rtol after max_iter.  2D: lrbms_fom_solve
+ * (DuneDiscretization._solve, discretize_elliptic_block_swipdg.py:219-225, has no 3D counterpart in the reference).
+ *
+ * lrbms3_fom_coarse_space: Phi [n][nc], the values of the nc <= 4 coarse functions at the local DoFs -- functions of the
+ * subdomain-local coordinates, hence one table for all subdomains (the host mirror passes 1, x, y, z: P1 per subdomain);
+ * nc = 0 switches the coarse level off.  Needs the mesh. */
+int lrbms3_fom_coarse_space(lrbms3_ctx* ctx, int32_t nc, const double* Phi);
 int64_t lrbms3_fom_solve_work_size(lrbms3_ctx* ctx);
 int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const double* A_diag, const double* A_cpl, const double* b,
                      double* work, double* x, double rtol, int32_t max_iter, double* info, void* stream);

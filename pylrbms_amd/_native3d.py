@@ -39,6 +39,7 @@ SIGNATURES3 = {
     'lrbms3_reduced_solve': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms3_reduced_solve_batch_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms3_reduced_solve_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
+    'lrbms3_fom_coarse_space': (ctypes.c_int, [c_vp, c_i32, _P_DBL]),
     'lrbms3_fom_solve_work_size': (c_i64, [c_vp]),
     'lrbms3_fom_solve': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms3_fom_apply': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -144,6 +145,20 @@ class Native3DContext:
         self._check(rc, 'lrbms3_mesh_upload')
         self.n_T, self.n, self.n_rt, self.ncf, self.nbf, self.nvs, self.nb, self.n_nodes = (t.n_T, t.n, t.n_rt, t.ncf, t.nbf, t.nvs,
                                                                                               t.nb, t.n_nodes)
+        # coarse space of the full-order solver's preconditioner: P1 per subdomain in the local coordinates, centred and scaled
+        x = np.asarray(t.node_coordinates(), dtype=np.float64)
+        ext = x.max(axis=0) - x.min(axis=0)
+        self.fom_coarse_space(np.concatenate([np.ones((t.n, 1)), (x - 0.5 * (x.max(axis=0) + x.min(axis=0))) / ext], axis=1))
+
+    def fom_coarse_space(self, Phi):
+        """Phi [n, nc] (nc <= 4) values of the coarse functions of ``fom_solve``'s two-level preconditioner at the local DoFs,
+        the same for every subdomain; ``None`` switches the coarse level off."""
+        if Phi is None:
+            self._check(self.lib.lrbms3_fom_coarse_space(self.handle, 0, None), 'lrbms3_fom_coarse_space')
+            return
+        Phi = np.ascontiguousarray(Phi, dtype=np.float64)
+        assert Phi.ndim == 2 and Phi.shape[0] == self.t.n and 1 <= Phi.shape[1] <= 4
+        self._check(self.lib.lrbms3_fom_coarse_space(self.handle, int(Phi.shape[1]), Phi.ctypes.data_as(_P_DBL)), 'lrbms3_fom_coarse_space')
 
     # ------------------------------------------------------------------ assembly
     def assemble_system(self, lam):

@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+#include <rocsolver/rocsolver.h>
+
 #include "../../include/lrbms3d_hip.h"
 
 // the process-wide side streams (capi.hip; see lrbms_dev.h): shared with the 2D contexts so that all of them fit the hardware queues
@@ -49,6 +51,10 @@ struct lrbms3_ctx {
   T3 t{};
   std::vector<void*> owned;
   std::vector<int32_t> nbr_host;
+  // coarse space of the full-order solver (lrbms3_fom_coarse_space): nc functions per subdomain, values at the local DoFs
+  int fom_nc = 0;
+  double* fom_phi = nullptr;      // [n][4] device, zero-padded columns
+  void* blas = nullptr;           // rocBLAS handle (dense coarse inverse), created on first use
   hipStream_t aux[2] = {nullptr, nullptr};          // library-owned streams: the flux chain and the Oswald chain of the pass
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   double* pg_part = nullptr;       // K-split partial results of the k3_pg kernels (library-owned, grown on demand)
@@ -2094,12 +2100,20 @@ __global__ __launch_bounds__(64) void k3f_block_inverse(T3 t, const double* __re
 
 // scal: [0] rz_old  [1] rz_new  [2] pAp  [3] rr  [4] bb
 // p = z + beta p  (beta = rz_new / rz_old, 0 in the first iteration)
+//   with the coarse level: z + R0^T y0 in the place of z (y0 [S][nc], Phi [n][4])
 __global__ __launch_bounds__(256) void k3f_dir(long total, int first, const double* __restrict__ scal, const double* __restrict__ z,
-                                               double* __restrict__ p) {
+                                               double* __restrict__ p, int n, int nc, const double* __restrict__ Phi,
+                                               const double* __restrict__ y0) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const double beta = first ? 0.0 : scal[1] / scal[0];
-  p[i] = z[i] + beta * p[i];
+  double zi = z[i];
+  if (nc > 0) {
+    const long s = i / n;
+    const int dof = (int)(i - s * n);
+    for (int k = 0; k < nc; ++k) zi += Phi[dof * 4 + k] * y0[s * nc + k];
+  }
+  p[i] = zi + beta * p[i];
 }
 
 // y = Amu p on the block-ELL + coupling data; partial p.y per workgroup
@@ -2145,7 +2159,8 @@ __global__ __launch_bounds__(256) void k3f_matvec(T3 t, const double* __restrict
 __global__ __launch_bounds__(256) void k3f_update(T3 t, int init, const double* __restrict__ scal, const double* __restrict__ Dinv,
                                                   const double* __restrict__ p, const double* __restrict__ y, const double* __restrict__ b,
                                                   double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
-                                                  double* __restrict__ prz, double* __restrict__ prr) {
+                                                  double* __restrict__ prz, double* __restrict__ prr, int nc,
+                                                  const double* __restrict__ Phi, double* __restrict__ pr0) {
   __shared__ double rs[256], red[256];
   const int s = blockIdx.y, tid = threadIdx.x;
   const int el = tid / 10, i = tid - el * 10, e = blockIdx.x * FOM_EPB + el;
@@ -2188,6 +2203,123 @@ __global__ __launch_bounds__(256) void k3f_update(T3 t, int init, const double* 
     __syncthreads();
   }
   if (tid == 0) prr[blk] = red[0];
+  // restriction of the residual to the coarse space: partial sums phi_k . r of this workgroup's rows (fixed-order tree)
+  for (int k = 0; k < nc; ++k) {
+    __syncthreads();
+    red[tid] = on ? ri * Phi[(e * 10 + i) * 4 + k] : 0.0;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) red[tid] += red[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) pr0[blk * 4 + k] = red[0];
+  }
+}
+
+// ---- coarse level of the full-order preconditioner: M^-1 = blockdiag(A_ee)^-1 + R0^T (R0 A R0^T)^-1 R0 (additive, SPD), the rows
+// of R0 = nc functions per subdomain (P1 in the subdomain-local coordinates by default: Phi [n][4], the same table everywhere).
+// A1b [S][7][16]: the 4 x 4 blocks phi_{s,k}^T A phi_{t,l} for t = the subdomain itself (slot 3) and its six neighbours.
+__global__ __launch_bounds__(256) void k3f_coarse_blocks(T3 t, const double* __restrict__ Phi, const double* __restrict__ Amu,
+                                                         const double* __restrict__ Cmu, double* __restrict__ A1b) {
+  __shared__ double red[16][256];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int el = tid / 10, i = tid - el * 10;
+  for (int t7 = 0; t7 < 7; ++t7) {
+    double acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0;
+    if (el < 25)
+      for (int e = el; e < t.nT; e += 25) {
+        const double* A = Amu + (((long)s * t.nT + e) * 5) * 100 + i * 10;
+        const double* ph = Phi + (e * 10 + i) * 4;
+        for (int slot = 0; slot < 5; ++slot) {
+          int ee = e, tgt = 3;
+          const double* L = A + slot * 100;
+          if (slot > 0) {
+            ee = t.nb_elem[e * 4 + slot - 1];
+            if (ee < 0) {
+              const int side = -(ee + 1);
+              tgt = side_slot(side);
+              if (t.nbr[s * 7 + tgt] < 0) continue;
+              L = Cmu + (((long)s * 6 + side) * t.ncf + t.face_pos[e * 4 + slot - 1]) * 100 + i * 10;
+              ee = t.nb_out[e * 4 + slot - 1];
+            }
+          }
+          if (tgt != t7) continue;
+          double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int j = 0; j < 10; ++j) {
+            const double lj = L[j];
+            const double* pj = Phi + (ee * 10 + j) * 4;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) a[l] += lj * pj[l];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) acc[k * 4 + l] += ph[k] * a[l];
+        }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) red[c][tid] = acc[c];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      for (int idx = tid; idx < 16 * w; idx += 256) {
+        const int c = idx / w, k = idx - c * w;
+        red[c][k] += red[c][k + w];
+      }
+      __syncthreads();
+    }
+    if (tid < 16) A1b[((long)s * 7 + t7) * 16 + tid] = red[tid][0];
+  }
+}
+
+// dense coarse matrix [M][M], M = nc S, from the blocks (zero-filled before); identity for the inverse
+__global__ __launch_bounds__(256) void k3f_coarse_dense(T3 t, int nc, const double* __restrict__ A1b, double* __restrict__ A1,
+                                                        double* __restrict__ Id) {
+  const long M = (long)nc * t.S;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < M) Id[idx * M + idx] = 1.0;
+  if (idx >= (long)t.S * 7 * 16) return;
+  const int kl = (int)(idx & 15), t7 = (int)((idx >> 4) % 7), s = (int)(idx / 112);
+  const int k = kl >> 2, l = kl & 3;
+  const int tt = t7 == 3 ? s : t.nbr[s * 7 + t7];
+  if (tt < 0 || k >= nc || l >= nc) return;
+  A1[((long)s * nc + k) * M + (long)tt * nc + l] = A1b[idx];
+}
+
+// r0 [M] from the workgroups' partial sums (fixed order)
+__global__ __launch_bounds__(256) void k3f_coarse_r0(int S, int nbx, int nc, const double* __restrict__ pr0, double* __restrict__ r0) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= S * nc) return;
+  const int s = m / nc, k = m - s * nc;
+  double v = 0.0;
+  for (int bx = 0; bx < nbx; ++bx) v += pr0[((long)s * nbx + bx) * 4 + k];
+  r0[m] = v;
+}
+
+// y0 = A1inv r0, one wave per row; prc [M] = r0 . y0 contributions to r.z
+__global__ __launch_bounds__(256) void k3f_coarse_apply(int M, const double* __restrict__ A1inv, const double* __restrict__ r0,
+                                                        double* __restrict__ y0, double* __restrict__ prc) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const double* a = A1inv + (long)row * M;
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  int c = lane;
+  for (; c + 192 < M; c += 256) {
+    v0 += a[c] * r0[c];
+    v1 += a[c + 64] * r0[c + 64];
+    v2 += a[c + 128] * r0[c + 128];
+    v3 += a[c + 192] * r0[c + 192];
+  }
+  for (; c < M; c += 64) v0 += a[c] * r0[c];
+  double v = (v0 + v1) + (v2 + v3);
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (lane == 0) {
+    y0[row] = v;
+    prc[row] = v * r0[row];
+  }
 }
 
 // scalar bookkeeping of an iteration on the device: after the update rz_old <- rz_new is a rotation of two slots
@@ -2235,6 +2367,7 @@ int lrbms3_ctx_destroy(lrbms3_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   for (void* p : ctx->owned) (void)hipFree(p);
   if (ctx->pg_part) (void)hipFree(ctx->pg_part);
+  if (ctx->blas) (void)rocblas_destroy_handle((rocblas_handle)ctx->blas);
   for (int i = 0; i < 2; ++i) {
     if (ctx->aux[i]) lrbms_side_stream_release(ctx->device, i);
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
@@ -2741,11 +2874,31 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
   return LRBMS_OK;
 }
 
+int lrbms3_fom_coarse_space(lrbms3_ctx* ctx, int32_t nc, const double* Phi) {
+  REQUIRE3(ctx);
+  if (nc < 0 || nc > 4 || (nc > 0 && !Phi)) return fail3(ctx, LRBMS_E_INVALID, "fom_coarse_space: 0 <= nc <= 4 functions, Phi [n][nc]");
+  if (!ctx->has_mesh) return fail3(ctx, LRBMS_E_STATE, "fom_coarse_space: upload the mesh first");
+  const T3& t = ctx->t;
+  ctx->fom_nc = 0;
+  if (nc == 0) return LRBMS_OK;
+  std::vector<double> padded((size_t)t.n * 4, 0.0);
+  for (long d = 0; d < t.n; ++d)
+    for (int k = 0; k < nc; ++k) padded[d * 4 + k] = Phi[d * nc + k];
+  if (!ctx->fom_phi) {
+    HIP3(ctx, hipMalloc((void**)&ctx->fom_phi, sizeof(double) * (size_t)t.n * 4));
+    ctx->owned.push_back(ctx->fom_phi);
+  }
+  HIP3(ctx, hipMemcpy(ctx->fom_phi, padded.data(), sizeof(double) * padded.size(), hipMemcpyHostToDevice));
+  ctx->fom_nc = nc;
+  return LRBMS_OK;
+}
+
 int64_t lrbms3_fom_solve_work_size(lrbms3_ctx* ctx) {
   if (!ctx || !ctx->has_mesh) return -1;
   const T3& t = ctx->t;
-  const int64_t nblk = (int64_t)t.S * ((t.nT + FOM_EPB - 1) / FOM_EPB);
-  return (int64_t)t.S * t.nT * 500 + (int64_t)t.S * 6 * t.ncf * 100 + (int64_t)t.S * t.nT * 100 + 4 * (int64_t)t.S * t.n + 3 * nblk + 16;
+  const int64_t nblk = (int64_t)t.S * ((t.nT + FOM_EPB - 1) / FOM_EPB), M = 4 * (int64_t)t.S;
+  return (int64_t)t.S * t.nT * 500 + (int64_t)t.S * 6 * t.ncf * 100 + (int64_t)t.S * t.nT * 100 + 4 * (int64_t)t.S * t.n + 3 * nblk + 16 +
+         M + 4 * nblk + 2 * M + (int64_t)t.S * 112 + 2 * M * M + 2;       // coarse level: prc, pr0, r0, y0, blocks, A1, A1inv, info
 }
 
 int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const double* A_diag, const double* A_cpl, const double* b,
@@ -2755,27 +2908,71 @@ int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const doub
   if (t.S_ext != t.S) return fail3(ctx, LRBMS_E_INVALID, "fom_solve: needs all subdomains on this rank");
   if (Q < 1 || Q > 8 || !theta || !A_diag || !A_cpl || !b || !work || !x) return fail3(ctx, LRBMS_E_INVALID, "fom_solve: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  const long S = t.S, nd = S * t.nT * 500, nc = S * 6 * t.ncf * 100, total = S * t.n;
+  const long S = t.S, nd = S * t.nT * 500, ncp = S * 6 * t.ncf * 100, total = S * t.n;
   const int nbx = (t.nT + FOM_EPB - 1) / FOM_EPB;
-  const long nblk = S * nbx;
+  const long nblk = S * nbx, Mmax = 4 * S;
   double* Amu = work;
   double* Cmu = Amu + nd;
-  double* Dinv = Cmu + nc;
+  double* Dinv = Cmu + ncp;
   double* r = Dinv + S * t.nT * 100;
   double* z = r + total;
   double* p = z + total;
   double* y = p + total;
   double* prz = y + total;
-  double* ppy = prz + nblk;
+  double* prc = prz + nblk;            // coarse contributions to r.z: summed with prz by ONE reduction
+  double* ppy = prc + Mmax;
   double* prr = ppy + nblk;
   double* scal = prr + nblk;
+  double* pr0 = scal + 16;
+  double* r0 = pr0 + 4 * nblk;
+  double* y0 = r0 + Mmax;
+  double* A1b = y0 + Mmax;
+  double* A1 = A1b + S * 112;
+  double* A1inv = A1 + Mmax * Mmax;
+  rocblas_int* pinfo = (rocblas_int*)(A1inv + Mmax * Mmax);
   const QV th = make_theta(Q, theta);
   hipLaunchKernelGGL(k3_combine, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, nd, Q, th, A_diag, Amu);
-  hipLaunchKernelGGL(k3_combine, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, nc, Q, th, A_cpl, Cmu);
+  hipLaunchKernelGGL(k3_combine, dim3((unsigned)((ncp + 255) / 256)), dim3(256), 0, st, ncp, Q, th, A_cpl, Cmu);
   hipLaunchKernelGGL(k3f_block_inverse, dim3((t.nT + 63) / 64, S), dim3(64), 0, st, t, Amu, Dinv);
+  // ---- coarse level (LRBMS3_FOM_COARSE=0 switches it off: A/B knob)
+  static const bool coarse_env = !(getenv("LRBMS3_FOM_COARSE") && getenv("LRBMS3_FOM_COARSE")[0] == '0');
+  int nc = coarse_env ? ctx->fom_nc : 0;
+  const double* Phi = ctx->fom_phi;
+  const long M = (long)nc * S;
+  if (nc > 0) {
+    if (!ctx->blas) {
+      rocblas_handle h = nullptr;
+      if (rocblas_create_handle(&h) != rocblas_status_success) return fail3(ctx, LRBMS_E_HIP, "rocblas_create_handle failed");
+      ctx->blas = h;
+    }
+    rocblas_handle h = (rocblas_handle)ctx->blas;
+    if (rocblas_set_stream(h, st) != rocblas_status_success) return fail3(ctx, LRBMS_E_HIP, "rocblas_set_stream failed");
+    hipLaunchKernelGGL(k3f_coarse_blocks, dim3(S), dim3(256), 0, st, t, Phi, Amu, Cmu, A1b);
+    HIP3(ctx, hipMemsetAsync(A1, 0, sizeof(double) * 2 * M * M, st));             // A1 and the identity behind it (A1inv at M * M when nc = 4)
+    double* Id = A1 + M * M;
+    hipLaunchKernelGGL(k3f_coarse_dense, dim3((unsigned)((std::max(M, S * 112) + 255) / 256)), dim3(256), 0, st, t, nc, A1b, A1, Id);
+    LAUNCH3(ctx);
+    if (rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)M, A1, (rocblas_int)M, pinfo) != rocblas_status_success)
+      return fail3(ctx, LRBMS_E_HIP, "rocsolver_dpotrf failed");
+    rocblas_int hinfo = 0;
+    HIP3(ctx, hipMemcpyAsync(&hinfo, pinfo, sizeof(rocblas_int), hipMemcpyDeviceToHost, st));
+    HIP3(ctx, hipStreamSynchronize(st));
+    if (hinfo != 0) nc = 0;                                   // not positive definite (dependent functions): block-Jacobi alone
+    else if (rocsolver_dpotrs(h, rocblas_fill_lower, (rocblas_int)M, (rocblas_int)M, A1, (rocblas_int)M, Id, (rocblas_int)M) !=
+             rocblas_status_success)
+      return fail3(ctx, LRBMS_E_HIP, "rocsolver_dpotrs failed");
+    A1inv = Id;
+  }
+  const long nrz = nblk + (nc > 0 ? M : 0);
+  auto coarse = [&]() {
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k3f_coarse_r0, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)S, nbx, nc, pr0, r0);
+    hipLaunchKernelGGL(k3f_coarse_apply, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (int)M, A1inv, r0, y0, prc);
+  };
   const dim3 grid(nbx, S);
-  hipLaunchKernelGGL(k3f_update, grid, dim3(256), 0, st, t, 1, scal, Dinv, p, y, b, x, r, z, prz, prr);
-  hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, prz, scal + 1);
+  hipLaunchKernelGGL(k3f_update, grid, dim3(256), 0, st, t, 1, scal, Dinv, p, y, b, x, r, z, prz, prr, nc, Phi, pr0);
+  coarse();
+  hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nrz, prz, scal + 1);
   hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, prr, scal + 4);
   LAUNCH3(ctx);
   double bb = 0.0;
@@ -2788,12 +2985,13 @@ int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const doub
   const int check = 16;
   while (it < max_iter) {
     for (int k = 0; k < check && it < max_iter; ++k, ++it) {
-      hipLaunchKernelGGL(k3f_dir, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, it == 0 ? 1 : 0, scal, z, p);
+      hipLaunchKernelGGL(k3f_dir, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, it == 0 ? 1 : 0, scal, z, p, t.n, nc, Phi, y0);
       hipLaunchKernelGGL(k3f_rotate, dim3(1), dim3(1), 0, st, scal);                  // rz_old <- rz_new (read by this iteration's update)
       hipLaunchKernelGGL(k3f_matvec, grid, dim3(256), 0, st, t, Amu, Cmu, p, y, ppy);
       hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, ppy, scal + 2);
-      hipLaunchKernelGGL(k3f_update, grid, dim3(256), 0, st, t, 0, scal, Dinv, p, y, b, x, r, z, prz, prr);
-      hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, prz, scal + 1);
+      hipLaunchKernelGGL(k3f_update, grid, dim3(256), 0, st, t, 0, scal, Dinv, p, y, b, x, r, z, prz, prr, nc, Phi, pr0);
+      coarse();
+      hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nrz, prz, scal + 1);
     }
     hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, prr, scal + 3);
     LAUNCH3(ctx);

@@ -77,6 +77,30 @@ def test_snapshots_bases_reduced_model_workflow():
     assert abs(rd.estimate(u, mu) - d.estimate(Ur, mu)) < 1e-8 * rd.estimate(u, mu)
 
 
+@pytest.mark.parametrize('name', ['interior_3x3x3', 'kc_3x1x2'])
+def test_full_order_solver_with_every_coarse_space_matches_the_sparse_lu(name):
+    """lrbms3_fom_solve with its two-level preconditioner: no coarse level, subdomain constants (nc = 1), P1 per subdomain
+    (nc = 4, the default after mesh upload) -- the same solution as the oracle's sparse LU each time, fewer iterations with
+    the richer space; a rank-deficient coarse space (a zero column) falls back to the element blocks alone."""
+    from pylrbms_amd.engine3d import Engine3D
+    p = c3.make_problem(name)
+    o = c3.oracle_of(p)
+    eng = Engine3D(p['grid'], p['lambdas'], p['f'], p['lambda_bar'], p['lambda_hat']).assemble()
+    th = c3.theta_of(p, p['mu'])
+    want = o.solve(p['mu'])
+    n = eng.t.n
+    its = {}
+    U, info = eng.ctx.fom_solve(eng.Q, th, eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=1e-12)     # default: P1
+    assert c3.rel(U.cpu().numpy().ravel(), want) < 1e-9
+    its['P1'] = info[0]
+    for key, Phi in (('none', None), ('constants', np.ones((n, 1))), ('deficient', np.zeros((n, 2)))):
+        eng.ctx.fom_coarse_space(Phi)
+        U, info = eng.ctx.fom_solve(eng.Q, th, eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=1e-12)
+        assert c3.rel(U.cpu().numpy().ravel(), want) < 1e-9, key
+        its[key] = info[0]
+    assert its['P1'] <= its['constants'] <= its['none'] == its['deficient'] and its['P1'] < its['none'], its   # (counted in steps of 16)
+
+
 def test_batched_online_phase_through_the_api():
     from pylrbms_amd.discretize_elliptic_block_swipdg_3d import LRBMSReductor3D, discretize
     p = c3.make_problem('aniso_2x2x1')
