@@ -1884,9 +1884,18 @@ __global__ __launch_bounds__(64) void k3_pcg_update(int S, int N, const double* 
 __global__ __launch_bounds__(256) void k3_reduce1(int S, const double* __restrict__ part, double* __restrict__ out) {
   __shared__ double red[256];
   const int tid = threadIdx.x;
-  double acc = 0.0;
-  for (int k = tid; k < S; k += 256) acc += part[k];
-  red[tid] = acc;
+  // eight loads in flight per thread (a plain `acc += part[k]` loop waits one L2 round trip per entry: 11 us for 10 k entries)
+  double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int k = tid;
+  for (; k + 7 * 256 < S; k += 8 * 256) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[k + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += v[u];
+  }
+  for (; k < S; k += 256) a[0] += part[k];
+  red[tid] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
     if (tid < w) red[tid] += red[tid + w];
@@ -1946,21 +1955,150 @@ __global__ __launch_bounds__(512) void k3b_init(int N, int nmu, const double* __
   }
 }
 
-// direction + matvec: p_new = z + beta_m p_old on the neighbourhood (own part stored), Ap = sum_q theta_qm sum_slot B_q p_new
+// The CG scalars of an iteration are sums over the workgroups' partials [S][16] of the previous kernel; every workgroup (512
+// threads) forms them itself, in the same fixed order, so an iteration is two launches (no reduction kernels in between).
+// Returns the sum for parameter tid & 15 in every thread; buf [32][16] doubles of LDS.
+__device__ inline double sum_partials16(const double* __restrict__ part, int S, double* buf, int tid) {
+  const int m = tid & 15, g = tid >> 4, ng = blockDim.x >> 4;     // 16 or 32 groups (256 / 512 threads)
+  double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // eight loads in flight (a plain loop waits one L2 round trip per entry)
+  int k = g;
+  for (; k + 7 * ng < S; k += 8 * ng) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long)(k + u * ng) * 16 + m];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += v[u];
+  }
+  for (; k < S; k += ng) a[0] += part[(long)k * 16 + m];
+  const double acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  buf[g * 16 + m] = acc;
+  __syncthreads();
+  double v = 0.0;
+  for (int k = 0; k < ng; ++k) v += buf[k * 16 + m];
+  __syncthreads();
+  return v;
+}
+
+// The same direction + matvec on the matrix cores (N <= 32): Ap [rows i][16 parameters] = sum_q sum_slot B_q[slot] (theta_q . p[slot])
+// -- the A operand is a 16-row strip of a projected block straight from global memory (lane: row l & 15, columns 2 (l >> 4) and
+// + 1 of the wave's 8-column band: one 16-byte load for two k-steps), the B operand the direction of the slot from the LDS with the
+// parameter weight theta_qm folded in (a lane owns ONE parameter, l & 15).  Four waves, wave w owns the column band [8 w, 8 w + 8) of
+// every block, so the A_mu strips are read exactly once; the waves' tiles meet in the LDS in a fixed order.
+template <int RT>
+__global__ __launch_bounds__(256) void k3b_matvec_mfma(T3 t, int Q, int N, int nmu, int first, TB th, const double* __restrict__ B,
+                                                       const double* __restrict__ z, const double* __restrict__ p_old,
+                                                       double* __restrict__ p_new, double* __restrict__ Ap,
+                                                       const double* __restrict__ prz_new, const double* __restrict__ prz_old,
+                                                       double* __restrict__ ppap) {
+  extern __shared__ double lds[];      // [7][32][16] direction (rows >= N zero) + [4][RT][256] partial tiles + [32][16] sums
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4, S = t.S;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* dir = lds;
+  double* part = lds + 7 * 32 * 16;
+  double* buf = part + 4 * RT * 256;
+  double bm = 0.0;
+  if (!first) {
+    const double rz_new = sum_partials16(prz_new, S, buf, tid), rz_old = sum_partials16(prz_old, S, buf, tid);
+    bm = rz_old == 0.0 ? 0.0 : rz_new / rz_old;
+  }
+  for (int k = tid; k < 7 * 32 * 16; k += 256) {
+    const int slot = k >> 9, j = (k >> 4) & 31, mm = k & 15;
+    const int s2 = t.nbr[s * 7 + slot];
+    double v = 0.0;
+    if (s2 >= 0 && mm < nmu && j < N) {
+      const long d = ((long)s2 * N + j) * nmu + mm;
+      v = first ? z[d] : z[d] + bm * p_old[d];
+    }
+    dir[k] = v;
+  }
+  __syncthreads();
+  for (int k = tid; k < N * 16; k += 256) {
+    const int i = k >> 4, mm = k & 15;
+    if (mm < nmu) p_new[((long)s * N + i) * nmu + mm] = dir[(3 * 32 + i) * 16 + mm];
+  }
+  d4 acc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) acc[rt] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int c0 = 8 * wave + 2 * lk;                  // this lane's two columns of the band (clamped into the matrix: the matching
+  const bool even = (N & 1) == 0;                    // direction rows are zero beyond N)
+  const int ca = c0 < N ? c0 : N - 1, cb = c0 + 1 < N ? c0 + 1 : N - 1, cpair = c0 + 1 < N ? c0 : N - 2;
+  if (8 * wave < N) {
+    double thq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) thq[q] = q < Q ? th.v[li][q] : 0.0;
+    for (int slot = 0; slot < 7; ++slot) {
+      if (t.nbr[s * 7 + slot] < 0) continue;         // wave-uniform
+      const double p0 = dir[(slot * 32 + c0) * 16 + li], p1 = dir[(slot * 32 + c0 + 1) * 16 + li];
+      for (int q = 0; q < Q; ++q) {
+        const double b0 = thq[q] * p0, b1 = thq[q] * p1;
+        const double* blk = B + (((long)q * S + s) * 7 + slot) * N * N;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = rt * 16 + li < N ? rt * 16 + li : N - 1;
+          double a0, a1;
+          if (even) {
+            const double2 v = *reinterpret_cast<const double2*>(blk + row * N + cpair);
+            a0 = v.x; a1 = v.y;
+          } else {
+            a0 = blk[row * N + ca]; a1 = blk[row * N + cb];
+          }
+          acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[rt], 0, 0, 0);
+          acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[rt], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[((wave * RT + rt) * 4 + r) * 64 + lane] = acc[rt][r];
+  __syncthreads();
+  double pp = 0.0;
+  if (wave < RT) {                                   // wave rt finishes tile rt: rows rt * 16 + lk + 4 r, parameter li
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = 0.0;
+      for (int w = 0; w < 4; ++w) v += part[((w * RT + wave) * 4 + r) * 64 + lane];
+      const int row = wave * 16 + lk + 4 * r;
+      if (row < N && li < nmu) {
+        Ap[((long)s * N + row) * nmu + li] = v;
+        pp += v * dir[(3 * 32 + row) * 16 + li];
+      }
+    }
+    pp += __shfl_xor(pp, 16);
+    pp += __shfl_xor(pp, 32);
+    if (lk == 0) buf[wave * 16 + li] = pp;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    double a = 0.0;
+    for (int rt = 0; rt < RT; ++rt) a += buf[rt * 16 + tid];
+    ppap[(long)s * 16 + tid] = a;
+  }
+}
+
+// direction + matvec: p_new = z + beta_m p_old on the neighbourhood (own part stored), Ap = sum_q theta_qm sum_slot B_q p_new;
+// beta_m = r.z (prz_new) / previous r.z (prz_old)
 __global__ __launch_bounds__(512) void k3b_matvec(T3 t, int Q, int N, int nmu, int first, TB th, const double* __restrict__ B,
                                                   const double* __restrict__ z, const double* __restrict__ p_old,
-                                                  double* __restrict__ p_new, double* __restrict__ Ap, const double* __restrict__ scal,
-                                                  double* __restrict__ ppap) {
+                                                  double* __restrict__ p_new, double* __restrict__ Ap, const double* __restrict__ prz_new,
+                                                  const double* __restrict__ prz_old, double* __restrict__ ppap) {
   extern __shared__ double lds[];      // [7][N][16] direction + [32][16] products
   const int s = blockIdx.x, tid = threadIdx.x, i = tid >> 4, m = tid & 15, S = t.S;
+  double bm = 0.0;                     // (512 % 16 == 0: a thread fills entries of its own parameter only)
+  if (!first) {
+    double* buf = lds + 7 * N * 16;
+    const double rz_new = sum_partials16(prz_new, S, buf, tid), rz_old = sum_partials16(prz_old, S, buf, tid);
+    bm = rz_old == 0.0 ? 0.0 : rz_new / rz_old;                    // a converged parameter (r = 0) stays put
+  }
   for (int k = tid; k < 7 * N * 16; k += 512) {
     const int slot = k / (N * 16), j = (k >> 4) % N, mm = k & 15;
     const int s2 = t.nbr[s * 7 + slot];
     double v = 0.0;
     if (s2 >= 0 && mm < nmu) {
       const long d = ((long)s2 * N + j) * nmu + mm;
-      const double bm = (first || scal[mm] == 0.0) ? 0.0 : scal[16 + mm] / scal[mm];     // a converged parameter (r = 0) stays put
-      v = z[d] + bm * p_old[d];
+      v = first ? z[d] : z[d] + bm * p_old[d];
     }
     lds[k] = v;
   }
@@ -1994,15 +2132,16 @@ __global__ __launch_bounds__(512) void k3b_matvec(T3 t, int Q, int N, int nmu, i
 
 __global__ __launch_bounds__(512) void k3b_update(int N, int nmu, const double* __restrict__ Dinv, const double* __restrict__ p,
                                                   const double* __restrict__ Ap, double* __restrict__ x, double* __restrict__ r,
-                                                  double* __restrict__ z, const double* __restrict__ scal, double* __restrict__ prz,
+                                                  double* __restrict__ z, int S, const double* __restrict__ prz_cur,
+                                                  const double* __restrict__ ppap, double* __restrict__ prz,
                                                   double* __restrict__ prr) {
   extern __shared__ double lds[];      // [N][16] residual + [32][16] products
   const int s = blockIdx.x, tid = threadIdx.x, i = tid >> 4, m = tid & 15;
   const bool on = i < N && m < nmu;
   double ri = 0.0, zi = 0.0;
+  const double rz = sum_partials16(prz_cur, S, lds + N * 16, tid), pap = sum_partials16(ppap, S, lds + N * 16, tid);
   if (on) {
-    const double pap = scal[32 + m];
-    const double alpha = pap != 0.0 ? scal[m] / pap : 0.0;          // a converged parameter (r = 0) stays put
+    const double alpha = pap != 0.0 ? rz / pap : 0.0;               // a converged parameter (r = 0) stays put
     const long d = ((long)s * N + i) * nmu + m;
     x[d] += alpha * p[d];
     ri = r[d] - alpha * Ap[d];
@@ -2027,8 +2166,6 @@ __global__ __launch_bounds__(512) void k3b_update(int N, int nmu, const double* 
     }
   }
 }
-
-__global__ void k3b_rotate(double* scal) { scal[threadIdx.x] = scal[16 + threadIdx.x]; }
 
 // ------------------------------------------------------------------------------------------------- full-order apply
 __global__ __launch_bounds__(256) void k3_fom_apply(T3 t, int Q, int M, QV th, const double* __restrict__ A_diag,
@@ -2800,7 +2937,7 @@ int lrbms3_reduced_solve(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* th
 int64_t lrbms3_reduced_solve_batch_work_size(lrbms3_ctx* ctx, int32_t N, int32_t nmu) {
   if (!ctx || !ctx->has_mesh) return -1;
   const int64_t S = ctx->t.S;
-  return S * 7 * N * N + S * N * N + 5 * S * N * nmu + 3 * S * 16 + 5 * 16 + 16;
+  return S * 7 * N * N + S * N * N + 5 * S * N * nmu + 4 * S * 16 + 5 * 16 + 16;
 }
 
 int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* B_sys,
@@ -2820,10 +2957,10 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
   double* p0 = z + nv;
   double* p1 = p0 + nv;
   double* Ap = p1 + nv;
-  double* prz = Ap + nv;
-  double* ppap = prz + S * 16;
+  double* prz = Ap + nv;              // [2][S][16]: r.z partials of the last two updates (beta needs both)
+  double* ppap = prz + 2 * S * 16;
   double* prr = ppap + S * 16;
-  double* scal = prr + S * 16;        // [5][16]
+  double* scal = prr + S * 16;        // [5][16]: only the residual norms ([3], [4]) are reduced by a kernel of their own
   TB th{};
   QV mean{};
   for (int m = 0; m < nmu; ++m)
@@ -2835,7 +2972,6 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
   hipLaunchKernelGGL(k3_block_inverse, dim3(S), dim3(256), sizeof(double) * N * (2 * N + 1), st, N, Amu, Dinv);
   HIP3(ctx, hipMemsetAsync(scal, 0, sizeof(double) * 80, st));
   hipLaunchKernelGGL(k3b_init, dim3(S), dim3(512), sizeof(double) * (N + 32 * 16), st, N, nmu, rhs_red, Dinv, u, r, z, p0, prz, prr);
-  hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prz, scal + 16);
   hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prr, scal + 64);
   LAUNCH3(ctx);
   double bb[16];
@@ -2847,13 +2983,22 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
   double rel = 0.0;
   const int check = 8;
   const size_t lds_mv = sizeof(double) * (7 * N * 16 + 32 * 16), lds_up = sizeof(double) * (N * 16 + 32 * 16);
+  const size_t lds_mm = sizeof(double) * (7 * 32 * 16 + 4 * (N <= 16 ? 1 : 2) * 256 + 32 * 16);
+  static const bool mfma_mv = !(getenv("LRBMS3_BMV") && getenv("LRBMS3_BMV")[0] == '0');      // A/B knob: 0 = the VALU panel matvec
   while (it < max_iter) {
     for (int k = 0; k < check && it < max_iter; ++k, ++it) {
-      hipLaunchKernelGGL(k3b_matvec, dim3(S), dim3(512), lds_mv, st, t, Q, N, nmu, it == 0 ? 1 : 0, th, B_sys, z, po, pn, Ap, scal, ppap);
-      hipLaunchKernelGGL(k3b_rotate, dim3(1), dim3(16), 0, st, scal);                    // rz_old <- rz_new
-      hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, ppap, scal + 32);
-      hipLaunchKernelGGL(k3b_update, dim3(S), dim3(512), lds_up, st, N, nmu, Dinv, pn, Ap, u, r, z, scal, prz, prr);
-      hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prz, scal + 16);
+      double* rz_cur = prz + (it & 1) * S * 16;            // written by the previous update (or k3b_init)
+      double* rz_nxt = prz + ((it + 1) & 1) * S * 16;      // holds the r.z of the update before that until this update overwrites it
+      if (mfma_mv && N <= 16)
+        hipLaunchKernelGGL(k3b_matvec_mfma<1>, dim3(S), dim3(256), lds_mm, st, t, Q, N, nmu, it == 0 ? 1 : 0, th, B_sys, z, po, pn, Ap,
+                           rz_cur, rz_nxt, ppap);
+      else if (mfma_mv)
+        hipLaunchKernelGGL(k3b_matvec_mfma<2>, dim3(S), dim3(256), lds_mm, st, t, Q, N, nmu, it == 0 ? 1 : 0, th, B_sys, z, po, pn, Ap,
+                           rz_cur, rz_nxt, ppap);
+      else
+        hipLaunchKernelGGL(k3b_matvec, dim3(S), dim3(512), lds_mv, st, t, Q, N, nmu, it == 0 ? 1 : 0, th, B_sys, z, po, pn, Ap, rz_cur,
+                           rz_nxt, ppap);
+      hipLaunchKernelGGL(k3b_update, dim3(S), dim3(512), lds_up, st, N, nmu, Dinv, pn, Ap, u, r, z, (int)S, rz_cur, ppap, rz_nxt, prr);
       std::swap(po, pn);
     }
     hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prr, scal + 48);
