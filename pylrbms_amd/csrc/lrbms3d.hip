@@ -1786,8 +1786,17 @@ __global__ __launch_bounds__(64) void k3_pcg_init(int N, const double* __restric
 
 __device__ inline double sum_partials(const double* __restrict__ part, int S, double* red) {   // 64 threads, fixed order
   const int i = threadIdx.x;
-  double acc = 0.0;
-  for (int k = i; k < S; k += 64) acc += part[k];
+  double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // eight loads in flight per thread
+  int k = i;
+  for (; k + 7 * 64 < S; k += 8 * 64) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[k + u * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += v[u];
+  }
+  for (; k < S; k += 64) a[0] += part[k];
+  const double acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
   red[i] = acc;
   __syncthreads();
@@ -2235,15 +2244,15 @@ __global__ __launch_bounds__(64) void k3f_block_inverse(T3 t, const double* __re
   for (int i = 0; i < 100; ++i) dst[i] = inv[i];
 }
 
-// scal: [0] rz_old  [1] rz_new  [2] pAp  [3] rr  [4] bb
+// scal: [0], [1] r.z of the last two updates (alternating)  [2] pAp  [3] rr  [4] bb
 // p = z + beta p  (beta = rz_new / rz_old, 0 in the first iteration)
 //   with the coarse level: z + R0^T y0 in the place of z (y0 [S][nc], Phi [n][4])
-__global__ __launch_bounds__(256) void k3f_dir(long total, int first, const double* __restrict__ scal, const double* __restrict__ z,
-                                               double* __restrict__ p, int n, int nc, const double* __restrict__ Phi,
-                                               const double* __restrict__ y0) {
+__global__ __launch_bounds__(256) void k3f_dir(long total, int first, int cur, const double* __restrict__ scal,
+                                               const double* __restrict__ z, double* __restrict__ p, int n, int nc,
+                                               const double* __restrict__ Phi, const double* __restrict__ y0) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const double beta = first ? 0.0 : scal[1] / scal[0];
+  const double beta = first ? 0.0 : scal[cur] / scal[cur ^ 1];       // r.z of the last two updates alternate between slots 0 and 1
   double zi = z[i];
   if (nc > 0) {
     const long s = i / n;
@@ -2253,47 +2262,91 @@ __global__ __launch_bounds__(256) void k3f_dir(long total, int first, const doub
   p[i] = zi + beta * p[i];
 }
 
-// y = Amu p on the block-ELL + coupling data; partial p.y per workgroup
-__global__ __launch_bounds__(256) void k3f_matvec(T3 t, const double* __restrict__ Amu, const double* __restrict__ Cmu,
+// y = Amu p on the block-ELL + coupling data; partial p.y per workgroup.
+// Bound by the 0.8 GB of 10 x 10 blocks it streams, so (1) every block is read by ONE 16-byte-per-lane load of 50 lanes (800
+// contiguous bytes; lane l holds A[i][2c], A[i][2c + 1], i = l / 5, c = l % 5 -- a thread per row reading 80-byte rows costs a
+// cache-line lookup per lane and instruction, which, not the HBM, then sets the pace) and the products are summed across lanes;
+// (2) the operator is symmetric, A[e'][e] = A[e][e']^T: inside a subdomain only the blocks towards the neighbour with the HIGHER
+// element index are read from their own place (sum over the row: lanes l .. l + 4), the element on the other side reads the same
+// block and sums over the columns (lanes l, l + 5, ...).  The two readers are workgroups of the same subdomain, and the 1D grid
+// is decoded so that all workgroups of a subdomain run on one XCD (xcd_block): the second read comes from that XCD's L2 and HBM
+// delivers 61 % of the block bytes.  One wave per element at a time, four waves per workgroup.
+__global__ __launch_bounds__(256) void k3f_matvec(T3 t, int nbx, const double* __restrict__ Amu, const double* __restrict__ Cmu,
                                                   const double* __restrict__ p, double* __restrict__ y, double* __restrict__ part) {
-  __shared__ double red[256];
-  const int s = blockIdx.y, tid = threadIdx.x;
-  const int el = tid / 10, i = tid - el * 10, e = blockIdx.x * FOM_EPB + el;
-  double acc = 0.0, py = 0.0;
-  if (el < FOM_EPB && e < t.nT) {
-    const double* A = Amu + (((long)s * t.nT + e) * 5) * 100 + i * 10;
-    for (int slot = 0; slot < 5; ++slot) {
-      int ee = e, ss = s;
-      const double* L = A + slot * 100;
-      if (slot > 0) {
-        ee = t.nb_elem[e * 4 + slot - 1];
-        if (ee < 0) {
-          const int side = -(ee + 1);
-          ss = t.nbr[s * 7 + side_slot(side)];
-          if (ss < 0) continue;
-          L = Cmu + (((long)s * 6 + side) * t.ncf + t.face_pos[e * 4 + slot - 1]) * 100 + i * 10;
-          ee = t.nb_out[e * 4 + slot - 1];
-        }
-      }
-      const double* pv = p + ((long)ss * t.n + ee * 10);
-#pragma unroll
-      for (int j = 0; j < 10; ++j) acc += L[j] * pv[j];
+  __shared__ double red[4];
+  int s, bx;
+  if (!xcd_block(nbx, t.S, bx, s)) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool act = lane < 50;
+  const int li = act ? lane : 49, row = li / 5, c2 = 2 * (li - row * 5);
+  const double* As = Amu + (long)s * t.nT * 500;
+  const double* ps = p + (long)s * t.n;
+  double py = 0.0;
+  const int e1 = (bx + 1) * FOM_EPB < t.nT ? (bx + 1) * FOM_EPB : t.nT;
+  for (int e = bx * FOM_EPB + wave; e < e1; e += 4) {
+    const int4 nb = *reinterpret_cast<const int4*>(t.nb_elem + e * 4);
+    const int nbv[4] = {nb.x, nb.y, nb.z, nb.w};
+    double yr = 0.0, yc0 = 0.0, yc1 = 0.0;            // row sums (valid in lanes 5 i), column sums (valid in lanes 0 .. 4)
+    {                                                 // diagonal block
+      const double2 a = *reinterpret_cast<const double2*>(As + (long)e * 500 + li * 2);
+      const double2 pv = *reinterpret_cast<const double2*>(ps + e * 10 + c2);
+      yr = act ? a.x * pv.x + a.y * pv.y : 0.0;
     }
-    const long d = (long)s * t.n + e * 10 + i;
-    y[d] = acc;
-    py = acc * p[d];
+    // (the faces are wave-uniform branches; making every load unconditional -- faces without a neighbour pointing at the own block
+    // with weight zero -- was measured: 136 instead of 126 us, the kernel is within 25 % of its HBM time either way)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int ee = nbv[f];                          // wave-uniform
+      if (ee >= 0 && ee < e) {                        // the lower element's block towards e, used transposed
+        const int4 nb2 = *reinterpret_cast<const int4*>(t.nb_elem + ee * 4);
+        const int fb = nb2.x == e ? 0 : (nb2.y == e ? 1 : (nb2.z == e ? 2 : 3));
+        const double2 a = *reinterpret_cast<const double2*>(As + (long)ee * 500 + (1 + fb) * 100 + li * 2);
+        const double pr = ps[ee * 10 + row];
+        yc0 += act ? a.x * pr : 0.0;
+        yc1 += act ? a.y * pr : 0.0;
+        continue;
+      }
+      const double* L;
+      const double* pn;
+      if (ee >= 0) {
+        L = As + (long)e * 500 + (1 + f) * 100;
+        pn = ps + ee * 10;
+      } else {
+        const int side = -(ee + 1), ss = t.nbr[s * 7 + side_slot(side)];
+        if (ss < 0) continue;
+        L = Cmu + (((long)s * 6 + side) * t.ncf + t.face_pos[e * 4 + f]) * 100;
+        pn = p + (long)ss * t.n + t.nb_out[e * 4 + f] * 10;
+      }
+      const double2 a = *reinterpret_cast<const double2*>(L + li * 2);
+      const double2 pv = *reinterpret_cast<const double2*>(pn + c2);
+      yr += act ? a.x * pv.x + a.y * pv.y : 0.0;
+    }
+    // row sums: lanes l .. l + 4 (fixed order), result in lanes 5 i
+    double r1 = yr + __shfl_down(yr, 1);
+    r1 = r1 + __shfl_down(r1, 2);
+    const double rs = r1 + __shfl_down(yr, 4);
+    // column sums: lanes l, l + 5, ..., l + 45 (lanes >= 50 contribute zeros), result in lanes 0 .. 4
+    double c0 = yc0 + __shfl_down(yc0, 5), c1 = yc1 + __shfl_down(yc1, 5);
+    c0 += __shfl_down(c0, 10); c1 += __shfl_down(c1, 10);
+    c0 += __shfl_down(c0, 20); c1 += __shfl_down(c1, 20);
+    c0 += __shfl_down(yc0 + __shfl_down(yc0, 5), 40); c1 += __shfl_down(yc1 + __shfl_down(yc1, 5), 40);
+    // entry t of y_e in lane t < 10: row sum of row t + column sum of column t
+    const int tl = lane < 10 ? lane : 0;
+    const double ya = __shfl(rs, 5 * tl), yb0 = __shfl(c0, tl >> 1), yb1 = __shfl(c1, tl >> 1);
+    if (lane < 10) {
+      const double v = ya + ((lane & 1) ? yb1 : yb0);
+      y[(long)s * t.n + e * 10 + lane] = v;
+      py += v * ps[e * 10 + lane];
+    }
   }
-  red[tid] = py;
+  for (int o = 8; o > 0; o >>= 1) py += __shfl_down(py, o);          // lanes 0 .. 9 (others are zero)
+  if (lane == 0) red[wave] = py;
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (tid < w) red[tid] += red[tid + w];
-    __syncthreads();
-  }
-  if (tid == 0) part[(long)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+  if (threadIdx.x == 0) part[(long)s * nbx + bx] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // x += alpha p, r -= alpha y, z = Dinv r; partials r.z and r.r per workgroup (init: x = 0, r = b: alpha = 0 with p = y = any)
-__global__ __launch_bounds__(256) void k3f_update(T3 t, int init, const double* __restrict__ scal, const double* __restrict__ Dinv,
+__global__ __launch_bounds__(256) void k3f_update(T3 t, int init, int cur, const double* __restrict__ scal, const double* __restrict__ Dinv,
                                                   const double* __restrict__ p, const double* __restrict__ y, const double* __restrict__ b,
                                                   double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
                                                   double* __restrict__ prz, double* __restrict__ prr, int nc,
@@ -2309,7 +2362,7 @@ __global__ __launch_bounds__(256) void k3f_update(T3 t, int init, const double* 
       ri = b[d];
       x[d] = 0.0;
     } else {
-      const double alpha = scal[0] / scal[2];
+      const double alpha = scal[cur] / scal[2];
       x[d] += alpha * p[d];
       ri = r[d] - alpha * y[d];
     }
@@ -2459,8 +2512,6 @@ __global__ __launch_bounds__(256) void k3f_coarse_apply(int M, const double* __r
   }
 }
 
-// scalar bookkeeping of an iteration on the device: after the update rz_old <- rz_new is a rotation of two slots
-__global__ void k3f_rotate(double* scal) { scal[0] = scal[1]; }
 
 template <typename T>
 int upload(lrbms3_ctx* ctx, const T* host, long count, const T** dev) {
@@ -3115,9 +3166,9 @@ int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const doub
     hipLaunchKernelGGL(k3f_coarse_apply, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (int)M, A1inv, r0, y0, prc);
   };
   const dim3 grid(nbx, S);
-  hipLaunchKernelGGL(k3f_update, grid, dim3(256), 0, st, t, 1, scal, Dinv, p, y, b, x, r, z, prz, prr, nc, Phi, pr0);
+  hipLaunchKernelGGL(k3f_update, grid, dim3(256), 0, st, t, 1, 0, scal, Dinv, p, y, b, x, r, z, prz, prr, nc, Phi, pr0);
   coarse();
-  hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nrz, prz, scal + 1);
+  hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nrz, prz, scal + 0);
   hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, prr, scal + 4);
   LAUNCH3(ctx);
   double bb = 0.0;
@@ -3130,13 +3181,14 @@ int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const doub
   const int check = 16;
   while (it < max_iter) {
     for (int k = 0; k < check && it < max_iter; ++k, ++it) {
-      hipLaunchKernelGGL(k3f_dir, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, it == 0 ? 1 : 0, scal, z, p, t.n, nc, Phi, y0);
-      hipLaunchKernelGGL(k3f_rotate, dim3(1), dim3(1), 0, st, scal);                  // rz_old <- rz_new (read by this iteration's update)
-      hipLaunchKernelGGL(k3f_matvec, grid, dim3(256), 0, st, t, Amu, Cmu, p, y, ppy);
+      const int cur = it & 1;                       // slot of the current r.z (the update of this iteration writes the other one)
+      hipLaunchKernelGGL(k3f_dir, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, it == 0 ? 1 : 0, cur, scal, z, p, t.n, nc,
+                         Phi, y0);
+      hipLaunchKernelGGL(k3f_matvec, dim3(xcd_grid(nbx, (int)S)), dim3(256), 0, st, t, nbx, Amu, Cmu, p, y, ppy);
       hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, ppy, scal + 2);
-      hipLaunchKernelGGL(k3f_update, grid, dim3(256), 0, st, t, 0, scal, Dinv, p, y, b, x, r, z, prz, prr, nc, Phi, pr0);
+      hipLaunchKernelGGL(k3f_update, grid, dim3(256), 0, st, t, 0, cur, scal, Dinv, p, y, b, x, r, z, prz, prr, nc, Phi, pr0);
       coarse();
-      hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nrz, prz, scal + 1);
+      hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nrz, prz, scal + (cur ^ 1));
     }
     hipLaunchKernelGGL(k3_reduce1, dim3(1), dim3(256), 0, st, (int)nblk, prr, scal + 3);
     LAUNCH3(ctx);
