@@ -1565,6 +1565,28 @@ __global__ __launch_bounds__(256) void k3_estimate(T3 t, int Q, int N, QV th, EA
 constexpr int EST_MB = 8;
 struct TB8 { double v[EST_MB][8]; };
 
+// sum_j g[j] * u[j * 8]: a row of a projected operator (global) against a coefficient column in the LDS (parameter-fastest, 8 per
+// row), for the eight parameter lanes of a worker (consecutive lanes, same g, same control flow).  The lanes would all load the
+// same address -- 8 useful bytes per lane-group and instruction, and the address unit, not the memory, sets the pace -- so lane m
+// loads entry j0 + m of every 8-entry chunk (all chunks first: n <= 64) and the group passes the values around by lane shuffles.
+__device__ inline double dot_row8(const double* __restrict__ g, const double* u, int n) {
+  const int lane = threadIdx.x & 63, m = lane & 7, base = lane & ~7;
+  double mine[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) mine[c] = (c * 8 < n && c * 8 + m < n) ? g[c * 8 + m] : 0.0;
+  double d = 0.0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c * 8 >= n) break;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double gk = __shfl(mine[c], base + k);
+      if (c * 8 + k < n) d += gk * u[(c * 8 + k) * 8];
+    }
+  }
+  return d;
+}
+
 __global__ __launch_bounds__(256) void k3_estimate_batch(T3 t, int Q, int N, int nmu, int m0, TB8 th, EA a) {
   extern __shared__ double lds[];
   const int s = blockIdx.x, tid = threadIdx.x, w = tid >> 3, m = tid & 7, QN = Q * N, NWK = 32;
@@ -1590,7 +1612,7 @@ __global__ __launch_bounds__(256) void k3_estimate_batch(T3 t, int Q, int N, int
     double acc = 0.0;
     for (int q = 0; q < Q; ++q) {
       double aq = 0.0;
-      for (int j = 0; j < N; ++j) aq += r[q * N + j] * ua[j * 8];
+      aq = dot_row8(r + q * N, ua, N);
       acc += th.v[m][q] * aq;
     }
     zf[sf * 8 + m] = acc;
@@ -1602,7 +1624,7 @@ __global__ __launch_bounds__(256) void k3_estimate_batch(T3 t, int Q, int N, int
       if (sp < 0) continue;
       const double* ua = us + side_slot(sp / t.nvs) * N * 8 + m;
       const double* r = a.As + ((long)s * 6 * t.nvs + sp) * N;
-      for (int j = 0; j < N; ++j) acc += r[j] * ua[j * 8];
+      acc += dot_row8(r, ua, N);
     }
     z[bn * 8 + m] = acc;
   }
@@ -1611,26 +1633,22 @@ __global__ __launch_bounds__(256) void k3_estimate_batch(T3 t, int Q, int N, int
   double p_nc = 0.0, p_bb = 0.0, p_dd = 0.0, p_fd = 0.0, p_ab = 0.0, p_aa = 0.0;
   for (int r = w; r < N; r += NWK) {
     const double* g = a.G_nc + ((long)s * N + r) * N;
-    double d = 0.0;
-    for (int j = 0; j < N; ++j) d += g[j] * u0[j * 8];
+    const double d = dot_row8(g, u0, N);
     p_nc += u0[r * 8] * d;
     for (int q = 0; q < Q; ++q) {
       const double* gab = a.G_ab + (((long)q * t.S + s) * N + r) * QN;
-      double dab = 0.0;
-      for (int j = 0; j < QN; ++j) dab += gab[j] * urm[j * 8];
+      const double dab = dot_row8(gab, urm, QN);
       p_ab += th.v[m][q] * u0[r * 8] * dab;
       for (int q2 = 0; q2 < Q; ++q2) {
         const double* ga = a.G_aa + ((((long)q * Q + q2) * t.S + s) * N + r) * N;
-        double da = 0.0;
-        for (int j = 0; j < N; ++j) da += ga[j] * u0[j * 8];
+        const double da = dot_row8(ga, u0, N);
         p_aa += th.v[m][q] * th.v[m][q2] * u0[r * 8] * da;
       }
     }
   }
   for (int bn = w; bn < t.nb; bn += NWK) {
     const double* g = a.Cn + ((long)s * t.nb + bn) * N;
-    double d = 0.0;
-    for (int j = 0; j < N; ++j) d += g[j] * u0[j * 8];
+    const double d = dot_row8(g, u0, N);
     p_nc += 2.0 * z[bn * 8 + m] * d;
   }
   for (int k = w; k < t.nbel; k += NWK) {
@@ -1650,11 +1668,7 @@ __global__ __launch_bounds__(256) void k3_estimate_batch(T3 t, int Q, int N, int
   for (int r = w; r < QN; r += NWK) {
     const double* gb = a.G_bb + ((long)s * QN + r) * QN;
     const double* gd = a.G_rdd + ((long)s * QN + r) * QN;
-    double db = 0.0, dd = 0.0;
-    for (int j = 0; j < QN; ++j) {
-      db += gb[j] * urm[j * 8];
-      dd += gd[j] * urm[j * 8];
-    }
+    const double db = dot_row8(gb, urm, QN), dd = dot_row8(gd, urm, QN);
     p_bb += urm[r * 8] * db;
     p_dd += urm[r * 8] * dd;
     p_fd += a.r_fd[(long)s * QN + r] * urm[r * 8];
@@ -1663,17 +1677,12 @@ __global__ __launch_bounds__(256) void k3_estimate_batch(T3 t, int Q, int N, int
     const double zz = zf[sf * 8 + m];
     const double* yb = a.Yb + ((long)s * t.nbf + sf) * QN;
     const double* dp = a.Dp + ((long)s * t.nbf + sf) * QN;
-    double db = 0.0, dd = 0.0;
-    for (int j = 0; j < QN; ++j) {
-      db += yb[j] * urm[j * 8];
-      dd += dp[j] * urm[j * 8];
-    }
+    const double db = dot_row8(yb, urm, QN), dd = dot_row8(dp, urm, QN);
     p_bb += 2.0 * zz * db;
     p_dd += 2.0 * zz * dd;
     for (int q = 0; q < Q; ++q) {
       const double* xa = a.Xab + (((long)q * t.S + s) * t.nbf + sf) * N;
-      double d = 0.0;
-      for (int j = 0; j < N; ++j) d += xa[j] * u0[j * 8];
+      const double d = dot_row8(xa, u0, N);
       p_ab += th.v[m][q] * zz * d;
     }
   }
