@@ -159,6 +159,22 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
                                const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
                                void* stream);
 
+/* Coarse level of lrbms3_reduced_solve_batch's preconditioner, built once per reduced model (2D: lrbms_reduced_precond_build /
+ * _use): the Galerkin problem on the FIRST local basis vector of every subdomain (the constant the reductor starts every basis
+ * with, reference reductor.py:29-31), A0[s][t] = sum_q theta_q B_sys_q[s][slot of t][0][0], inverted densely (rocSOLVER) at the
+ * reference parameter theta; added to the inverse diagonal blocks it halves the iteration count at 8^3 subdomains.  Any SPD
+ * preconditioner is admissible, so one build serves every parameter.
+ *   lrbms3_reduced_precond_build   theta [Q] host; work: lrbms3_reduced_precond_work_size doubles; pc: lrbms3_reduced_precond_size
+ *                                  doubles, caller-owned, filled ([S][S] coarse inverse, then the inverse diagonal blocks
+ *                                  [S][N][N] at the same theta); LRBMS_E_INVALID if the coarse matrix is not positive definite
+ *   lrbms3_reduced_precond_use     subsequent lrbms3_reduced_solve_batch calls with basis size N use pc (it must stay alive);
+ *                                  NULL: the inverse diagonal blocks alone */
+int64_t lrbms3_reduced_precond_size(lrbms3_ctx* ctx, int32_t N);
+int64_t lrbms3_reduced_precond_work_size(lrbms3_ctx* ctx, int32_t N);
+int lrbms3_reduced_precond_build(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* B_sys, double* work,
+                                 double* pc, void* stream);
+int lrbms3_reduced_precond_use(lrbms3_ctx* ctx, int32_t N, const double* pc);
+
 /* Snapshot generation: A(mu) x = b on the never-assembled block operator (S_ext == S), CG with a two-level additive
  * preconditioner: the inverse 10 x 10 element blocks plus, if lrbms3_fom_coarse_space was called, the Galerkin coarse problem on
  * nc functions per subdomain (dense (nc S)^2 inverse by rocSOLVER per solve; the 2D solver's coarse space are the subdomain

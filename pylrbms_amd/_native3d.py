@@ -40,6 +40,10 @@ SIGNATURES3 = {
     'lrbms3_reduced_solve_batch_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms3_reduced_solve_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms3_fom_coarse_space': (ctypes.c_int, [c_vp, c_i32, _P_DBL]),
+    'lrbms3_reduced_precond_size': (c_i64, [c_vp, c_i32]),
+    'lrbms3_reduced_precond_work_size': (c_i64, [c_vp, c_i32]),
+    'lrbms3_reduced_precond_build': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp]),
+    'lrbms3_reduced_precond_use': (ctypes.c_int, [c_vp, c_i32, c_vp]),
     'lrbms3_fom_solve_work_size': (c_i64, [c_vp]),
     'lrbms3_fom_solve': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms3_fom_apply': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -301,6 +305,28 @@ class Native3DContext:
                                                  self._stream())
         self._check(rc, 'lrbms3_reduced_solve_batch')
         return u, (int(info[0]), float(info[1]))
+
+    def reduced_precond_build(self, Q, theta, B_sys):
+        """Two-level preconditioner of the batched reduced solve at the reference parameter ``theta``: one device buffer,
+        the coarse inverse [S, S] followed by the inverse diagonal blocks [S, N, N]."""
+        N, S = B_sys.shape[-1], self.S
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        assert th.shape == (Q,)
+        work = self.empty(int(self.lib.lrbms3_reduced_precond_work_size(self.handle, N)))
+        pc = self.empty(int(self.lib.lrbms3_reduced_precond_size(self.handle, N)))        # [S, S] coarse inverse | [S, N, N] inverse blocks
+        rc = self.lib.lrbms3_reduced_precond_build(self.handle, Q, N, th.ctypes.data_as(_P_DBL), self._ptr(B_sys, (Q, S, 7, N, N), 'B_sys'),
+                                                   c_vp(work.data_ptr()), c_vp(pc.data_ptr()), self._stream())
+        self._check(rc, 'lrbms3_reduced_precond_build')
+        self.torch.cuda.current_stream().synchronize()          # `work` goes out of scope
+        pc._lrbms_N = N
+        return pc
+
+    def reduced_precond_use(self, pc):
+        """Subsequent ``reduced_solve_batch`` calls use ``pc`` (``None``: inverse diagonal blocks alone).  The context keeps a reference."""
+        self._pc_keep = pc
+        rc = self.lib.lrbms3_reduced_precond_use(self.handle, int(pc._lrbms_N) if pc is not None else 0,
+                                                 c_vp(pc.data_ptr()) if pc is not None else None)
+        self._check(rc, 'lrbms3_reduced_precond_use')
 
     def fom_solve(self, Q, theta, A_diag, A_cpl, b, rtol=1e-10, max_iter=50000, work=None):
         th = np.ascontiguousarray(theta, dtype=np.float64)

@@ -54,7 +54,9 @@ struct lrbms3_ctx {
   // coarse space of the full-order solver (lrbms3_fom_coarse_space): nc functions per subdomain, values at the local DoFs
   int fom_nc = 0;
   double* fom_phi = nullptr;      // [n][4] device, zero-padded columns
-  void* blas = nullptr;           // rocBLAS handle (dense coarse inverse), created on first use
+  void* blas = nullptr;           // rocBLAS handle (dense coarse inverses), created on first use
+  const double* user_pc = nullptr;   // coarse inverse the batched reduced solve uses (lrbms3_reduced_precond_use), caller-owned
+  int user_pc_N = 0;
   hipStream_t aux[2] = {nullptr, nullptr};          // library-owned streams: the flux chain and the Oswald chain of the pass
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   double* pg_part = nullptr;       // K-split partial results of the k3_pg kernels (library-owned, grown on demand)
@@ -1973,6 +1975,14 @@ __global__ __launch_bounds__(512) void k3b_init(int N, int nmu, const double* __
   }
 }
 
+// Coarse level of the batched reduced solve (nullptr members: block-Jacobi alone): y0 [S][16] = A0^-1 r0 of the last residual,
+// prc_* [S][16] its contributions r0 . y0 to r.z -- summed with the fine partials wherever r.z is needed.
+struct CoarseB {
+  const double* y0;
+  const double* prc_new;
+  const double* prc_old;
+};
+
 // The CG scalars of an iteration are sums over the workgroups' partials [S][16] of the previous kernel; every workgroup (512
 // threads) forms them itself, in the same fixed order, so an iteration is two launches (no reduction kernels in between).
 // Returns the sum for parameter tid & 15 in every thread; buf [32][16] doubles of LDS.
@@ -2008,7 +2018,7 @@ __global__ __launch_bounds__(256) void k3b_matvec_mfma(T3 t, int Q, int N, int n
                                                        const double* __restrict__ z, const double* __restrict__ p_old,
                                                        double* __restrict__ p_new, double* __restrict__ Ap,
                                                        const double* __restrict__ prz_new, const double* __restrict__ prz_old,
-                                                       double* __restrict__ ppap) {
+                                                       double* __restrict__ ppap, CoarseB cl) {
   extern __shared__ double lds[];      // [7][32][16] direction (rows >= N zero) + [4][RT][256] partial tiles + [32][16] sums
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4, S = t.S;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2017,7 +2027,11 @@ __global__ __launch_bounds__(256) void k3b_matvec_mfma(T3 t, int Q, int N, int n
   double* buf = part + 4 * RT * 256;
   double bm = 0.0;
   if (!first) {
-    const double rz_new = sum_partials16(prz_new, S, buf, tid), rz_old = sum_partials16(prz_old, S, buf, tid);
+    double rz_new = sum_partials16(prz_new, S, buf, tid), rz_old = sum_partials16(prz_old, S, buf, tid);
+    if (cl.y0) {
+      rz_new += sum_partials16(cl.prc_new, S, buf, tid);
+      rz_old += sum_partials16(cl.prc_old, S, buf, tid);
+    }
     bm = rz_old == 0.0 ? 0.0 : rz_new / rz_old;
   }
   for (int k = tid; k < 7 * 32 * 16; k += 256) {
@@ -2026,7 +2040,9 @@ __global__ __launch_bounds__(256) void k3b_matvec_mfma(T3 t, int Q, int N, int n
     double v = 0.0;
     if (s2 >= 0 && mm < nmu && j < N) {
       const long d = ((long)s2 * N + j) * nmu + mm;
-      v = first ? z[d] : z[d] + bm * p_old[d];
+      double zt = z[d];
+      if (cl.y0 && j == 0) zt += cl.y0[s2 * 16 + mm];              // z = Dinv r + e_0 y0: the coarse correction
+      v = first ? zt : zt + bm * p_old[d];
     }
     dir[k] = v;
   }
@@ -2101,13 +2117,17 @@ __global__ __launch_bounds__(256) void k3b_matvec_mfma(T3 t, int Q, int N, int n
 __global__ __launch_bounds__(512) void k3b_matvec(T3 t, int Q, int N, int nmu, int first, TB th, const double* __restrict__ B,
                                                   const double* __restrict__ z, const double* __restrict__ p_old,
                                                   double* __restrict__ p_new, double* __restrict__ Ap, const double* __restrict__ prz_new,
-                                                  const double* __restrict__ prz_old, double* __restrict__ ppap) {
+                                                  const double* __restrict__ prz_old, double* __restrict__ ppap, CoarseB cl) {
   extern __shared__ double lds[];      // [7][N][16] direction + [32][16] products
   const int s = blockIdx.x, tid = threadIdx.x, i = tid >> 4, m = tid & 15, S = t.S;
   double bm = 0.0;                     // (512 % 16 == 0: a thread fills entries of its own parameter only)
   if (!first) {
     double* buf = lds + 7 * N * 16;
-    const double rz_new = sum_partials16(prz_new, S, buf, tid), rz_old = sum_partials16(prz_old, S, buf, tid);
+    double rz_new = sum_partials16(prz_new, S, buf, tid), rz_old = sum_partials16(prz_old, S, buf, tid);
+    if (cl.y0) {
+      rz_new += sum_partials16(cl.prc_new, S, buf, tid);
+      rz_old += sum_partials16(cl.prc_old, S, buf, tid);
+    }
     bm = rz_old == 0.0 ? 0.0 : rz_new / rz_old;                    // a converged parameter (r = 0) stays put
   }
   for (int k = tid; k < 7 * N * 16; k += 512) {
@@ -2116,7 +2136,9 @@ __global__ __launch_bounds__(512) void k3b_matvec(T3 t, int Q, int N, int nmu, i
     double v = 0.0;
     if (s2 >= 0 && mm < nmu) {
       const long d = ((long)s2 * N + j) * nmu + mm;
-      v = first ? z[d] : z[d] + bm * p_old[d];
+      double zt = z[d];
+      if (cl.y0 && j == 0) zt += cl.y0[s2 * 16 + mm];
+      v = first ? zt : zt + bm * p_old[d];
     }
     lds[k] = v;
   }
@@ -2151,13 +2173,15 @@ __global__ __launch_bounds__(512) void k3b_matvec(T3 t, int Q, int N, int nmu, i
 __global__ __launch_bounds__(512) void k3b_update(int N, int nmu, const double* __restrict__ Dinv, const double* __restrict__ p,
                                                   const double* __restrict__ Ap, double* __restrict__ x, double* __restrict__ r,
                                                   double* __restrict__ z, int S, const double* __restrict__ prz_cur,
-                                                  const double* __restrict__ ppap, double* __restrict__ prz,
-                                                  double* __restrict__ prr) {
+                                                  const double* __restrict__ prc_cur, const double* __restrict__ ppap,
+                                                  double* __restrict__ prz, double* __restrict__ prr) {
   extern __shared__ double lds[];      // [N][16] residual + [32][16] products
   const int s = blockIdx.x, tid = threadIdx.x, i = tid >> 4, m = tid & 15;
   const bool on = i < N && m < nmu;
   double ri = 0.0, zi = 0.0;
-  const double rz = sum_partials16(prz_cur, S, lds + N * 16, tid), pap = sum_partials16(ppap, S, lds + N * 16, tid);
+  double rz = sum_partials16(prz_cur, S, lds + N * 16, tid);
+  if (prc_cur) rz += sum_partials16(prc_cur, S, lds + N * 16, tid);
+  const double pap = sum_partials16(ppap, S, lds + N * 16, tid);
   if (on) {
     const double alpha = pap != 0.0 ? rz / pap : 0.0;               // a converged parameter (r = 0) stays put
     const long d = ((long)s * N + i) * nmu + m;
@@ -2181,6 +2205,61 @@ __global__ __launch_bounds__(512) void k3b_update(int N, int nmu, const double* 
       double a = 0.0;
       for (int k = 0; k < N && k < 32; ++k) a += pr[k * 16 + tid];
       (pass ? prr : prz)[(long)s * 16 + tid] = a;
+    }
+  }
+}
+
+// ---- coarse level of the reduced solvers: the Galerkin problem on the FIRST local basis vector of every subdomain (the constant the
+// reductor starts every basis with), A0[s][t] = A_mu[s][slot of t][0][0] -- a 7-point S x S matrix, inverted densely once per
+// reduced model at a reference parameter (lrbms3_reduced_precond_build; any SPD preconditioner is admissible for the other mu).
+__global__ __launch_bounds__(256) void k3r_coarse_fill(T3 t, int Q, int N, QV th, const double* __restrict__ B, double* __restrict__ A0,
+                                                       double* __restrict__ Id) {
+  const int idx = blockIdx.x * 256 + threadIdx.x, S = t.S;
+  if (idx >= S * 7) return;
+  const int s = idx / 7, slot = idx - s * 7;
+  if (slot == 3) Id[(long)s * S + s] = 1.0;
+  const int tt = slot == 3 ? s : t.nbr[s * 7 + slot];
+  if (tt < 0) return;
+  double v = 0.0;
+  for (int q = 0; q < Q; ++q) v += th.v[q] * B[(((long)q * S + s) * 7 + slot) * N * N];
+  A0[(long)s * S + tt] = v;
+}
+
+// y0 [S][16] = A0inv r0, r0[t][m] = r[t][0][m], on the matrix cores: one 16-row tile of A0inv per workgroup, sixteen waves split
+// K = S and keep eight k-steps of operands in flight (a load -> MFMA chain per k-step is one L2 round trip each: 25 us);
+// prc [S][16] = r0 . y0 (the coarse part of r.z)
+__global__ __launch_bounds__(1024) void k3b_coarse_apply(int S, int N, int nmu, const double* __restrict__ A0inv, const double* __restrict__ r,
+                                                         double* __restrict__ y0, double* __restrict__ prc) {
+  __shared__ double part[16][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * 16, row = row0 + li < S ? row0 + li : S - 1;
+  const double* arow = A0inv + (long)row * S;
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  const int ksteps = (S + 3) / 4;
+  for (int k0 = wave; k0 < ksteps; k0 += 16 * 8) {
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = 4 * (k0 + 16 * u) + lk, cc = c < S ? c : S - 1;
+      a[u] = arow[cc];
+      b[u] = r[((long)cc * N) * nmu + (li < nmu ? li : 0)];
+      if (c >= S || li >= nmu) b[u] = 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) part[wave][q][lane] = acc[q];
+  __syncthreads();
+  if (wave < 4) {                                     // wave q finishes accumulator register q: rows lk + 4 q, column li
+    double v = 0.0;
+    for (int w = 0; w < 16; ++w) v += part[w][wave][lane];
+    const int rr = row0 + lk + 4 * wave;
+    if (rr < S) {
+      const double r0 = li < nmu ? r[((long)rr * N) * nmu + li] : 0.0;
+      y0[rr * 16 + li] = li < nmu ? v : 0.0;
+      prc[rr * 16 + li] = li < nmu ? v * r0 : 0.0;
     }
   }
 }
@@ -2997,7 +3076,7 @@ int lrbms3_reduced_solve(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* th
 int64_t lrbms3_reduced_solve_batch_work_size(lrbms3_ctx* ctx, int32_t N, int32_t nmu) {
   if (!ctx || !ctx->has_mesh) return -1;
   const int64_t S = ctx->t.S;
-  return S * 7 * N * N + S * N * N + 5 * S * N * nmu + 4 * S * 16 + 5 * 16 + 16;
+  return S * 7 * N * N + S * N * N + 5 * S * N * nmu + 4 * S * 16 + 5 * 16 + 16 + 3 * S * 16;      // (+ y0, prc [2] of the coarse level)
 }
 
 int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* B_sys,
@@ -3021,6 +3100,9 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
   double* ppap = prz + 2 * S * 16;
   double* prr = ppap + S * 16;
   double* scal = prr + S * 16;        // [5][16]: only the residual norms ([3], [4]) are reduced by a kernel of their own
+  double* y0 = scal + 5 * 16 + 16;    // coarse level (lrbms3_reduced_precond_use): correction and its r.z contributions [2][S][16]
+  double* prc = y0 + S * 16;
+  const double* A0inv = ctx->user_pc_N == N ? ctx->user_pc : nullptr;
   TB th{};
   QV mean{};
   for (int m = 0; m < nmu; ++m)
@@ -3028,20 +3110,23 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
       th.v[m][q] = theta[m * Q + q];
       mean.v[q] += theta[m * Q + q] / nmu;
     }
-  hipLaunchKernelGGL(k3_combine, dim3((unsigned)((per_q + 255) / 256)), dim3(256), 0, st, per_q, Q, mean, B_sys, Amu);
-  hipLaunchKernelGGL(k3_block_inverse, dim3(S), dim3(256), sizeof(double) * N * (2 * N + 1), st, N, Amu, Dinv);
+  if (A0inv) {
+    Dinv = const_cast<double*>(A0inv) + S * S;        // the prebuilt preconditioner carries its inverse diagonal blocks (read only)
+  } else {
+    hipLaunchKernelGGL(k3_combine, dim3((unsigned)((per_q + 255) / 256)), dim3(256), 0, st, per_q, Q, mean, B_sys, Amu);
+    hipLaunchKernelGGL(k3_block_inverse, dim3(S), dim3(256), sizeof(double) * N * (2 * N + 1), st, N, Amu, Dinv);
+  }
   HIP3(ctx, hipMemsetAsync(scal, 0, sizeof(double) * 80, st));
   hipLaunchKernelGGL(k3b_init, dim3(S), dim3(512), sizeof(double) * (N + 32 * 16), st, N, nmu, rhs_red, Dinv, u, r, z, p0, prz, prr);
+  if (A0inv) hipLaunchKernelGGL(k3b_coarse_apply, dim3((unsigned)((S + 15) / 16)), dim3(1024), 0, st, (int)S, N, nmu, A0inv, r, y0, prc);
   hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prr, scal + 64);
   LAUNCH3(ctx);
-  double bb[16];
-  HIP3(ctx, hipMemcpyAsync(bb, scal + 64, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
-  HIP3(ctx, hipStreamSynchronize(st));
+  double bb[16];                       // |b|^2 per parameter: fetched with the first residual check (no host round trip of its own)
   if (info) info[0] = 0, info[1] = 0;
   double *po = p0, *pn = p1;
   int it = 0;
   double rel = 0.0;
-  const int check = 8;
+  const int check = A0inv ? 12 : 8;    // iterations between two looks at the residuals (a host synchronisation each)
   const size_t lds_mv = sizeof(double) * (7 * N * 16 + 32 * 16), lds_up = sizeof(double) * (N * 16 + 32 * 16);
   const size_t lds_mm = sizeof(double) * (7 * 32 * 16 + 4 * (N <= 16 ? 1 : 2) * 256 + 32 * 16);
   static const bool mfma_mv = !(getenv("LRBMS3_BMV") && getenv("LRBMS3_BMV")[0] == '0');      // A/B knob: 0 = the VALU panel matvec
@@ -3049,23 +3134,30 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
     for (int k = 0; k < check && it < max_iter; ++k, ++it) {
       double* rz_cur = prz + (it & 1) * S * 16;            // written by the previous update (or k3b_init)
       double* rz_nxt = prz + ((it + 1) & 1) * S * 16;      // holds the r.z of the update before that until this update overwrites it
+      double* rc_cur = prc + (it & 1) * S * 16;
+      double* rc_nxt = prc + ((it + 1) & 1) * S * 16;
+      const CoarseB cb{A0inv ? y0 : nullptr, rc_cur, rc_nxt};
       if (mfma_mv && N <= 16)
         hipLaunchKernelGGL(k3b_matvec_mfma<1>, dim3(S), dim3(256), lds_mm, st, t, Q, N, nmu, it == 0 ? 1 : 0, th, B_sys, z, po, pn, Ap,
-                           rz_cur, rz_nxt, ppap);
+                           rz_cur, rz_nxt, ppap, cb);
       else if (mfma_mv)
         hipLaunchKernelGGL(k3b_matvec_mfma<2>, dim3(S), dim3(256), lds_mm, st, t, Q, N, nmu, it == 0 ? 1 : 0, th, B_sys, z, po, pn, Ap,
-                           rz_cur, rz_nxt, ppap);
+                           rz_cur, rz_nxt, ppap, cb);
       else
         hipLaunchKernelGGL(k3b_matvec, dim3(S), dim3(512), lds_mv, st, t, Q, N, nmu, it == 0 ? 1 : 0, th, B_sys, z, po, pn, Ap, rz_cur,
-                           rz_nxt, ppap);
-      hipLaunchKernelGGL(k3b_update, dim3(S), dim3(512), lds_up, st, N, nmu, Dinv, pn, Ap, u, r, z, (int)S, rz_cur, ppap, rz_nxt, prr);
+                           rz_nxt, ppap, cb);
+      hipLaunchKernelGGL(k3b_update, dim3(S), dim3(512), lds_up, st, N, nmu, Dinv, pn, Ap, u, r, z, (int)S, rz_cur,
+                         A0inv ? rc_cur : nullptr, ppap, rz_nxt, prr);
+      if (A0inv)      // the coarse correction of the new residual: read by the next matvec (direction) and by the next update (r.z)
+        hipLaunchKernelGGL(k3b_coarse_apply, dim3((unsigned)((S + 15) / 16)), dim3(1024), 0, st, (int)S, N, nmu, A0inv, r, y0, rc_nxt);
       std::swap(po, pn);
     }
     hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prr, scal + 48);
     LAUNCH3(ctx);
-    double rr[16];
-    HIP3(ctx, hipMemcpyAsync(rr, scal + 48, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+    double rr[32];
+    HIP3(ctx, hipMemcpyAsync(rr, scal + 48, sizeof(double) * 32, hipMemcpyDeviceToHost, st));     // [3] residuals, [4] |b|^2
     HIP3(ctx, hipStreamSynchronize(st));
+    for (int m = 0; m < 16; ++m) bb[m] = rr[16 + m];
     rel = 0.0;
     for (int m = 0; m < nmu; ++m) {
       const double rm = bb[m] > 0.0 ? sqrt(rr[m] / bb[m]) : 0.0;
@@ -3076,6 +3168,64 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
   }
   if (info) info[0] = it, info[1] = rel;
   if (rel > rtol) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve_batch: not converged");
+  return LRBMS_OK;
+}
+
+int64_t lrbms3_reduced_precond_size(lrbms3_ctx* ctx, int32_t N) {
+  if (!ctx || !ctx->has_mesh || N < 1) return -1;
+  return (int64_t)ctx->t.S * ctx->t.S + (int64_t)ctx->t.S * N * N;          // coarse inverse | inverse diagonal blocks
+}
+
+int64_t lrbms3_reduced_precond_work_size(lrbms3_ctx* ctx, int32_t N) {
+  if (!ctx || !ctx->has_mesh || N < 1) return -1;
+  const int64_t S = ctx->t.S;
+  return std::max<int64_t>(2 * S * S + 2, S * 7 * N * N);
+}
+
+int lrbms3_reduced_precond_build(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* B_sys, double* work,
+                                 double* pc, void* stream) {
+  REQUIRE3(ctx);
+  const T3& t = ctx->t;
+  if (t.S_ext != t.S) return fail3(ctx, LRBMS_E_INVALID, "reduced_precond_build: needs all subdomains on this rank");
+  if (Q < 1 || Q > 8 || N < 1 || N > 32 || !theta || !B_sys || !work || !pc)
+    return fail3(ctx, LRBMS_E_INVALID, "reduced_precond_build: bad argument (the batched solve it serves takes N <= 32)");
+  hipStream_t st = (hipStream_t)stream;
+  const long S = t.S;
+  double* A0 = work;
+  double* Id = A0 + S * S;
+  rocblas_int* pinfo = (rocblas_int*)(Id + S * S);
+  if (!ctx->blas) {
+    rocblas_handle h = nullptr;
+    if (rocblas_create_handle(&h) != rocblas_status_success) return fail3(ctx, LRBMS_E_HIP, "rocblas_create_handle failed");
+    ctx->blas = h;
+  }
+  rocblas_handle h = (rocblas_handle)ctx->blas;
+  if (rocblas_set_stream(h, st) != rocblas_status_success) return fail3(ctx, LRBMS_E_HIP, "rocblas_set_stream failed");
+  HIP3(ctx, hipMemsetAsync(A0, 0, sizeof(double) * 2 * S * S, st));
+  hipLaunchKernelGGL(k3r_coarse_fill, dim3((unsigned)((S * 7 + 255) / 256)), dim3(256), 0, st, t, Q, N, make_theta(Q, theta), B_sys, A0, Id);
+  LAUNCH3(ctx);
+  if (rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)S, A0, (rocblas_int)S, pinfo) != rocblas_status_success)
+    return fail3(ctx, LRBMS_E_HIP, "rocsolver_dpotrf failed");
+  rocblas_int hinfo = 0;
+  HIP3(ctx, hipMemcpyAsync(&hinfo, pinfo, sizeof(rocblas_int), hipMemcpyDeviceToHost, st));
+  HIP3(ctx, hipStreamSynchronize(st));
+  if (hinfo != 0) return fail3(ctx, LRBMS_E_INVALID, "reduced_precond_build: the coarse matrix is not positive definite (first basis vectors)");
+  if (rocsolver_dpotrs(h, rocblas_fill_lower, (rocblas_int)S, (rocblas_int)S, A0, (rocblas_int)S, Id, (rocblas_int)S) !=
+      rocblas_status_success)
+    return fail3(ctx, LRBMS_E_HIP, "rocsolver_dpotrs failed");
+  HIP3(ctx, hipMemcpyAsync(pc, Id, sizeof(double) * S * S, hipMemcpyDeviceToDevice, st));
+  // the inverse diagonal blocks at the same reference parameter (the dense work is done: its space holds the combined blocks)
+  const long per_q = S * 7 * N * N;
+  hipLaunchKernelGGL(k3_combine, dim3((unsigned)((per_q + 255) / 256)), dim3(256), 0, st, per_q, Q, make_theta(Q, theta), B_sys, work);
+  hipLaunchKernelGGL(k3_block_inverse, dim3(S), dim3(256), sizeof(double) * N * (2 * N + 1), st, N, work, pc + S * S);
+  LAUNCH3(ctx);
+  return LRBMS_OK;
+}
+
+int lrbms3_reduced_precond_use(lrbms3_ctx* ctx, int32_t N, const double* pc) {
+  REQUIRE3(ctx);
+  ctx->user_pc = pc;
+  ctx->user_pc_N = pc ? N : 0;
   return LRBMS_OK;
 }
 

@@ -98,11 +98,24 @@ class ReducedDiscretization3D:
                 info = (max(info[0], inf[0]), max(info[1], inf[1]))
             U = torch.cat(out, dim=0).contiguous()
             return (U, info) if return_info else U
-        for b0 in range(0, len(mus), 16):
-            th = np.stack([self.d.theta(mu) for mu in mus[b0:b0 + 16]])
-            ub, inf = eng.ctx.reduced_solve_batch(self.d.Q, th, self.out['B_sys'], self.out['rhs_red'], rtol=rtol, max_iter=max_iter)
-            out.append(ub.permute(2, 0, 1))
-            info = (max(info[0], inf[0]), max(info[1], inf[1]))
+        # two-level preconditioner: inverse diagonal blocks + coarse level on the first local basis vectors, the coarse inverse built
+        # once per reduced model at the middle of the parameter range (mu_bar without one); any SPD preconditioner is admissible
+        if getattr(self, '_pc', None) is None:
+            pr = self.d.parameter_range
+            mu_ref = 0.5 * (pr[0] + pr[1]) if pr is not None else self.d.mu_bar
+            try:
+                self._pc = eng.ctx.reduced_precond_build(self.d.Q, self.d.theta(mu_ref), self.out['B_sys'])
+            except Exception:                  # first basis vectors that do not give an SPD coarse matrix (e.g. a zero vector)
+                self._pc = False
+        eng.ctx.reduced_precond_use(self._pc if self._pc is not False else None)
+        try:
+            for b0 in range(0, len(mus), 16):
+                th = np.stack([self.d.theta(mu) for mu in mus[b0:b0 + 16]])
+                ub, inf = eng.ctx.reduced_solve_batch(self.d.Q, th, self.out['B_sys'], self.out['rhs_red'], rtol=rtol, max_iter=max_iter)
+                out.append(ub.permute(2, 0, 1))
+                info = (max(info[0], inf[0]), max(info[1], inf[1]))
+        finally:
+            eng.ctx.reduced_precond_use(None)
         U = torch.cat(out, dim=0).contiguous()
         return (U, info) if return_info else U
 

@@ -161,6 +161,39 @@ def test_batched_reduced_solve_matches_single_solves_and_the_oracle(case):
         assert c3.rel(ub[:, :, m].cpu().numpy(), us.cpu().numpy()) < 1e-10
 
 
+def test_batched_solve_with_the_prebuilt_coarse_level(case):
+    """lrbms3_reduced_precond_build / _use: the Galerkin coarse problem on the first local basis vectors, inverted once at a
+    reference parameter, added to the inverse diagonal blocks -- the same solutions as the oracle for every parameter of the
+    batch (any SPD preconditioner is admissible); switched off again by use(None)."""
+    p, d, eng, rd, out = case['p'], case['d'], case['eng'], case['rd'], case['out']
+    if p['N'] > 32:
+        pytest.skip('batched solve takes N <= 32')
+    mus = [0.15, p['mu'], 0.55, 0.9, 1.2]
+    thetas = np.stack([c3.theta_of(p, mu) for mu in mus])
+    u0, (it0, _) = eng.ctx.reduced_solve_batch(d.Q, thetas, out['B_sys'], out['rhs_red'], rtol=1e-13)
+    pc = eng.ctx.reduced_precond_build(d.Q, c3.theta_of(p, 0.6), out['B_sys'])
+    A0 = np.zeros((eng.S, eng.S))                                   # the coarse matrix from the projected blocks, on the host
+    Bm = np.einsum('q,qsabc->sabc', c3.theta_of(p, 0.6), out['B_sys'].cpu().numpy())
+    for s_ in range(eng.S):
+        for slot in range(7):
+            t_ = s_ if slot == 3 else eng.nbr[s_, slot]
+            if t_ >= 0:
+                A0[s_, t_] = Bm[s_, slot, 0, 0]
+    assert c3.rel(pc[:eng.S * eng.S].cpu().numpy().reshape(eng.S, eng.S), np.linalg.inv(A0)) < 1e-9
+    eng.ctx.reduced_precond_use(pc)
+    try:
+        u1, (it1, res1) = eng.ctx.reduced_solve_batch(d.Q, thetas, out['B_sys'], out['rhs_red'], rtol=1e-13)
+    finally:
+        eng.ctx.reduced_precond_use(None)
+    # a preconditioner frozen at one parameter may cost iterations on a tiny problem whose parameters spread far (theta = mu^2
+    # here); it pays with the subdomain count (bench3d: 48 -> 24 at 8 x 8 x 8).  Counted in steps of 8 without, 12 with it.
+    assert res1 <= 1e-13 and 0 < it1 <= 2 * it0
+    for m, mu in enumerate(mus):
+        assert c3.rel(u1[:, :, m].cpu().numpy(), np.stack(rd.solve(mu))) < 1e-10
+    u2, (it2, _) = eng.ctx.reduced_solve_batch(d.Q, thetas, out['B_sys'], out['rhs_red'], rtol=1e-13)
+    assert it2 == it0 and np.array_equal(u2.cpu().numpy(), u0.cpu().numpy())
+
+
 def test_phased_pass_is_bit_identical_to_the_whole_pass(case):
     """lrbms3_project_estimate_phase: 1 (rank-local slabs only) followed by 2 (neighbour rows) == 0, bit for bit."""
     import torch
