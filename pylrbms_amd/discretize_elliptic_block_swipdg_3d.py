@@ -49,11 +49,38 @@ class BlockDiscretization3D:
 
     def solve(self, mu, rtol=1e-10, max_iter=50000, return_info=False):
         """``d.solve(mu)`` (:219-225): the full-order solution as a block DG vector [S, n] -- CG on the never-assembled block
-        operator with the 10 x 10 element blocks as preconditioner (``lrbms3_fom_solve``); snapshot generation."""
+        operator with a two-level preconditioner (10 x 10 element blocks + P1 per subdomain; ``lrbms3_fom_solve``); snapshot
+        generation.  Sharded (one tile of subdomains per rank): as in 2D every rank gathers the block operator once (1.6 GB at
+        config 5, against 288 GB of HBM) and solves redundantly through a second context that holds the GLOBAL neighbour table;
+        it keeps its own rows."""
         eng = self.engine
-        U, info = eng.ctx.fom_solve(self.Q, self.theta(mu), eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=rtol,
-                                    max_iter=max_iter)
+        if eng.S_ext == eng.S:
+            U, info = eng.ctx.fom_solve(self.Q, self.theta(mu), eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=rtol,
+                                        max_iter=max_iter)
+            return (U, info) if return_info else U
+        import torch
+        ctx, A_d, A_c, b = self._global_fom()
+        U, info = ctx.fom_solve(self.Q, self.theta(mu), A_d, A_c, b, rtol=rtol, max_iter=max_iter)
+        U = U[torch.as_tensor(eng.local, device=U.device)].contiguous()
         return (U, info) if return_info else U
+
+    def _global_fom(self):
+        """(context, A_diag [Q, S_total, n_T, 5, 100], A_cpl [Q, S_total, 6, ncf, 100], b [S_total, n]) in global subdomain order."""
+        if getattr(self, '_fom_global', None) is None:
+            from pylrbms_amd._native3d import Native3DContext
+            from pylrbms_amd.parallel import gather_subdomain_rows
+            eng, g = self.engine, self.grid
+            owned = [list(g._partition(r, g.world_size)) for r in range(g.world_size)]
+            total = g.num_subdomains
+            group = getattr(self, 'group', None)
+            A_d = gather_subdomain_rows(eng.ops['A_diag'].permute(1, 0, 2, 3, 4).contiguous(), owned, total, group)
+            A_c = gather_subdomain_rows(eng.ops['A_cpl'].permute(1, 0, 2, 3, 4).contiguous(), owned, total, group)
+            b = gather_subdomain_rows(eng.ops['b'], owned, total, group)
+            ctx = Native3DContext(eng.ctx.device.index)
+            nbr = np.asarray(g.neighbor_slots, dtype=np.int32).reshape(total, 7)
+            ctx.mesh_upload(eng.t, eng.spec, eng.t.tables(eng.spec), nbr, g.phys_mask, total, total)
+            self._fom_global = (ctx, A_d.permute(1, 0, 2, 3, 4).contiguous(), A_c.permute(1, 0, 2, 3, 4).contiguous(), b.contiguous())
+        return self._fom_global
 
     def apply(self, U, mu):
         """A(mu) U for a block DG array U [S, n, M] (BlockOperator.apply, :500-507)."""
