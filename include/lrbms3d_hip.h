@@ -184,7 +184,8 @@ int lrbms3_reduced_precond_use(lrbms3_ctx* ctx, int32_t N, const double* pc);
  *
  * lrbms3_fom_coarse_space: Phi [n][nc], the values of the nc <= 4 coarse functions at the local DoFs -- functions of the
  * subdomain-local coordinates, hence one table for all subdomains (the host mirror passes 1, x, y, z: P1 per subdomain);
- * nc = 0 switches the coarse level off.  Needs the mesh. */
+ * nc = 0 switches the coarse level off.  Needs the mesh.  The dense coarse problem is capped at 8 192 unknowns: beyond it only
+ * the first function is used, beyond 8 192 subdomains none. */
 int lrbms3_fom_coarse_space(lrbms3_ctx* ctx, int32_t nc, const double* Phi);
 int64_t lrbms3_fom_solve_work_size(lrbms3_ctx* ctx);
 int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const double* A_diag, const double* A_cpl, const double* b,

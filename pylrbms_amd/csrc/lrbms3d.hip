@@ -2302,6 +2302,7 @@ __global__ __launch_bounds__(256) void k3_fom_apply(T3 t, int Q, int M, QV th, c
 // operator is combined once per solve (Amu = sum_q theta_q A_q); an iteration is three kernels + three one-block reductions,
 // all scalars stay on the device.  EPB elements (10 rows each) per workgroup.
 constexpr int FOM_EPB = 24;
+constexpr int FOM_MAX_COARSE = 8192;      // largest dense coarse problem of the full-order solver (2 x 0.5 GB of work, ~0.1 s to invert)
 
 // inverse of the diagonal 10 x 10 blocks (SPD): Gauss-Jordan, one thread per element, the block in LDS
 __global__ __launch_bounds__(64) void k3f_block_inverse(T3 t, const double* __restrict__ Amu, double* __restrict__ Dinv) {
@@ -3251,7 +3252,7 @@ int lrbms3_fom_coarse_space(lrbms3_ctx* ctx, int32_t nc, const double* Phi) {
 int64_t lrbms3_fom_solve_work_size(lrbms3_ctx* ctx) {
   if (!ctx || !ctx->has_mesh) return -1;
   const T3& t = ctx->t;
-  const int64_t nblk = (int64_t)t.S * ((t.nT + FOM_EPB - 1) / FOM_EPB), M = 4 * (int64_t)t.S;
+  const int64_t nblk = (int64_t)t.S * ((t.nT + FOM_EPB - 1) / FOM_EPB), M = std::min<int64_t>(4 * (int64_t)t.S, FOM_MAX_COARSE);
   return (int64_t)t.S * t.nT * 500 + (int64_t)t.S * 6 * t.ncf * 100 + (int64_t)t.S * t.nT * 100 + 4 * (int64_t)t.S * t.n + 3 * nblk + 16 +
          M + 4 * nblk + 2 * M + (int64_t)t.S * 112 + 2 * M * M + 2;       // coarse level: prc, pr0, r0, y0, blocks, A1, A1inv, info
 }
@@ -3265,7 +3266,7 @@ int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const doub
   hipStream_t st = (hipStream_t)stream;
   const long S = t.S, nd = S * t.nT * 500, ncp = S * 6 * t.ncf * 100, total = S * t.n;
   const int nbx = (t.nT + FOM_EPB - 1) / FOM_EPB;
-  const long nblk = S * nbx, Mmax = 4 * S;
+  const long nblk = S * nbx, Mmax = std::min<long>(4 * S, FOM_MAX_COARSE);
   double* Amu = work;
   double* Cmu = Amu + nd;
   double* Dinv = Cmu + ncp;
@@ -3292,6 +3293,8 @@ int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const doub
   // ---- coarse level (LRBMS3_FOM_COARSE=0 switches it off: A/B knob)
   static const bool coarse_env = !(getenv("LRBMS3_FOM_COARSE") && getenv("LRBMS3_FOM_COARSE")[0] == '0');
   int nc = coarse_env ? ctx->fom_nc : 0;
+  if (nc > 1 && (long)nc * S > FOM_MAX_COARSE) nc = 1;       // the dense coarse inverse is capped: constants instead of P1, then none
+  if ((long)nc * S > FOM_MAX_COARSE) nc = 0;
   const double* Phi = ctx->fom_phi;
   const long M = (long)nc * S;
   if (nc > 0) {
