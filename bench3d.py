@@ -258,18 +258,25 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
         # snapshot generation: one full-order solve (two-level CG on the never-assembled block operator: element blocks + P1 per subdomain)
         try:
             fwork = eng.ctx.empty(int(eng.ctx.lib.lrbms3_fom_solve_work_size(eng.ctx.handle)))
-            for rep in range(2):                      # the first call creates the rocBLAS handle and loads rocSOLVER's kernels
+            fms = []
+            for rep, mu_s in enumerate((0.55, 0.55, 0.5)):
+                # 0: warm-up (creates the rocBLAS handle, loads rocSOLVER's kernels); 1: a solve that factorises its coarse matrix and
+                # keeps the inverse (d.solve does that for the first snapshot); 2: another parameter with the kept inverse
+                if rep == 1:
+                    eng.ctx.fom_precond_keep(True)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                _, finfo = eng.ctx.fom_solve(Q, np.array([1.0, 0.5]), eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=1e-8,
+                _, finfo = eng.ctx.fom_solve(Q, np.array([1.0, mu_s]), eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=1e-8,
                                              max_iter=20000, work=fwork)
                 torch.cuda.synchronize()
-                fms = 1e3 * (time.perf_counter() - t0)
+                fms.append(1e3 * (time.perf_counter() - t0))
+            eng.ctx.fom_precond_keep(False)
             del fwork
-            res['snapshot'] = {'metric': 'full-order solve (d.solve)', 'ms': fms, 'dofs': S * t.n,
+            res['snapshot'] = {'metric': 'full-order solve (d.solve)', 'ms': fms[2], 'first_snapshot_ms': fms[1], 'dofs': S * t.n,
                                'cg_iterations': finfo[0], 'relative_residual': finfo[1], 'rtol': 1e-8,
-                               'preconditioner': 'inverse 10x10 element blocks + Galerkin coarse level on P1 per subdomain '
-                                                 '(built inside the timed solve)'}
+                               'preconditioner': 'inverse 10x10 element blocks + Galerkin coarse level on P1 per subdomain; the dense '
+                                                 'coarse inverse is factorised by the first snapshot (first_snapshot_ms) and kept for '
+                                                 'the others (ms: another parameter)'}
         except Exception as exc:                      # reported, not fatal for the bench line
             res['snapshot'] = {'error': str(exc)}
     if base is not None:

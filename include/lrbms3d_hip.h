@@ -187,6 +187,10 @@ int lrbms3_reduced_precond_use(lrbms3_ctx* ctx, int32_t N, const double* pc);
  * nc = 0 switches the coarse level off.  Needs the mesh.  The dense coarse problem is capped at 8 192 unknowns: beyond it only
  * the first function is used, beyond 8 192 subdomains none. */
 int lrbms3_fom_coarse_space(lrbms3_ctx* ctx, int32_t nc, const double* Phi);
+/* keep != 0: the next lrbms3_fom_solve leaves its dense coarse inverse in the context and the following ones reuse it whatever
+ * their parameter (any SPD preconditioner is admissible; saves the ~10 ms factorisation per snapshot at config 5) until keep = 0
+ * frees it or the coarse space changes. */
+int lrbms3_fom_precond_keep(lrbms3_ctx* ctx, int32_t keep);
 int64_t lrbms3_fom_solve_work_size(lrbms3_ctx* ctx);
 int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const double* A_diag, const double* A_cpl, const double* b,
                      double* work, double* x, double rtol, int32_t max_iter, double* info, void* stream);

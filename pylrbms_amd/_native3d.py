@@ -40,6 +40,7 @@ SIGNATURES3 = {
     'lrbms3_reduced_solve_batch_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms3_reduced_solve_batch': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp, c_dbl, c_i32, _P_DBL, c_vp]),
     'lrbms3_fom_coarse_space': (ctypes.c_int, [c_vp, c_i32, _P_DBL]),
+    'lrbms3_fom_precond_keep': (ctypes.c_int, [c_vp, c_i32]),
     'lrbms3_reduced_precond_size': (c_i64, [c_vp, c_i32]),
     'lrbms3_reduced_precond_work_size': (c_i64, [c_vp, c_i32]),
     'lrbms3_reduced_precond_build': (ctypes.c_int, [c_vp, c_i32, c_i32, _P_DBL, c_vp, c_vp, c_vp, c_vp]),
@@ -153,6 +154,11 @@ class Native3DContext:
         x = np.asarray(t.node_coordinates(), dtype=np.float64)
         ext = x.max(axis=0) - x.min(axis=0)
         self.fom_coarse_space(np.concatenate([np.ones((t.n, 1)), (x - 0.5 * (x.max(axis=0) + x.min(axis=0))) / ext], axis=1))
+
+    def fom_precond_keep(self, keep=True):
+        """The next ``fom_solve`` leaves its coarse inverse in the context, the following ones reuse it for every parameter
+        (``False``: drop it, one factorisation per solve again)."""
+        self._check(self.lib.lrbms3_fom_precond_keep(self.handle, 1 if keep else 0), 'lrbms3_fom_precond_keep')
 
     def fom_coarse_space(self, Phi):
         """Phi [n, nc] (nc <= 4) values of the coarse functions of ``fom_solve``'s two-level preconditioner at the local DoFs,

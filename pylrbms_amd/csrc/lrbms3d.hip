@@ -54,6 +54,10 @@ struct lrbms3_ctx {
   // coarse space of the full-order solver (lrbms3_fom_coarse_space): nc functions per subdomain, values at the local DoFs
   int fom_nc = 0;
   double* fom_phi = nullptr;      // [n][4] device, zero-padded columns
+  bool fom_keep = false;          // lrbms3_fom_precond_keep: the coarse inverse of a solve stays in the context for the next ones
+  double* fom_pc = nullptr;       // [M][M] device (owned), valid for fom_pc_M = nc S unknowns of fom_pc_nc functions
+  long fom_pc_M = 0;
+  int fom_pc_nc = 0;
   void* blas = nullptr;           // rocBLAS handle (dense coarse inverses), created on first use
   const double* user_pc = nullptr;   // coarse inverse the batched reduced solve uses (lrbms3_reduced_precond_use), caller-owned
   int user_pc_N = 0;
@@ -2645,6 +2649,7 @@ int lrbms3_ctx_destroy(lrbms3_ctx* ctx) {
   for (void* p : ctx->owned) (void)hipFree(p);
   if (ctx->pg_part) (void)hipFree(ctx->pg_part);
   if (ctx->blas) (void)rocblas_destroy_handle((rocblas_handle)ctx->blas);
+  if (ctx->fom_pc) (void)hipFree(ctx->fom_pc);
   for (int i = 0; i < 2; ++i) {
     if (ctx->aux[i]) lrbms_side_stream_release(ctx->device, i);
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
@@ -3236,6 +3241,7 @@ int lrbms3_fom_coarse_space(lrbms3_ctx* ctx, int32_t nc, const double* Phi) {
   if (!ctx->has_mesh) return fail3(ctx, LRBMS_E_STATE, "fom_coarse_space: upload the mesh first");
   const T3& t = ctx->t;
   ctx->fom_nc = 0;
+  ctx->fom_pc_M = 0;                     // a kept coarse inverse belongs to the old space
   if (nc == 0) return LRBMS_OK;
   std::vector<double> padded((size_t)t.n * 4, 0.0);
   for (long d = 0; d < t.n; ++d)
@@ -3246,6 +3252,17 @@ int lrbms3_fom_coarse_space(lrbms3_ctx* ctx, int32_t nc, const double* Phi) {
   }
   HIP3(ctx, hipMemcpy(ctx->fom_phi, padded.data(), sizeof(double) * padded.size(), hipMemcpyHostToDevice));
   ctx->fom_nc = nc;
+  return LRBMS_OK;
+}
+
+int lrbms3_fom_precond_keep(lrbms3_ctx* ctx, int32_t keep) {
+  REQUIRE3(ctx);
+  ctx->fom_keep = keep != 0;
+  if (!keep) {
+    if (ctx->fom_pc) (void)hipFree(ctx->fom_pc);
+    ctx->fom_pc = nullptr;
+    ctx->fom_pc_M = 0;
+  }
   return LRBMS_OK;
 }
 
@@ -3297,7 +3314,9 @@ int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const doub
   if ((long)nc * S > FOM_MAX_COARSE) nc = 0;
   const double* Phi = ctx->fom_phi;
   const long M = (long)nc * S;
-  if (nc > 0) {
+  const bool kept = nc > 0 && ctx->fom_keep && ctx->fom_pc && ctx->fom_pc_M == M && ctx->fom_pc_nc == nc;
+  if (kept) A1inv = ctx->fom_pc;          // built by an earlier solve (another parameter: any SPD preconditioner is admissible)
+  if (nc > 0 && !kept) {
     if (!ctx->blas) {
       rocblas_handle h = nullptr;
       if (rocblas_create_handle(&h) != rocblas_status_success) return fail3(ctx, LRBMS_E_HIP, "rocblas_create_handle failed");
@@ -3320,6 +3339,17 @@ int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const doub
              rocblas_status_success)
       return fail3(ctx, LRBMS_E_HIP, "rocsolver_dpotrs failed");
     A1inv = Id;
+    if (nc > 0 && ctx->fom_keep) {
+      if (ctx->fom_pc && ctx->fom_pc_M != M) {
+        HIP3(ctx, hipFree(ctx->fom_pc));
+        ctx->fom_pc = nullptr;
+      }
+      ctx->fom_pc_M = 0;
+      if (!ctx->fom_pc) HIP3(ctx, hipMalloc((void**)&ctx->fom_pc, sizeof(double) * M * M));
+      HIP3(ctx, hipMemcpyAsync(ctx->fom_pc, Id, sizeof(double) * M * M, hipMemcpyDeviceToDevice, st));
+      ctx->fom_pc_M = M;
+      ctx->fom_pc_nc = nc;
+    }
   }
   const long nrz = nblk + (nc > 0 ? M : 0);
   auto coarse = [&]() {

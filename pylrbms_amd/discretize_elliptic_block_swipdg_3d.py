@@ -55,6 +55,9 @@ class BlockDiscretization3D:
         it keeps its own rows."""
         eng = self.engine
         if eng.S_ext == eng.S:
+            if not getattr(self, '_fom_kept', False):       # one dense coarse factorisation for all snapshots of this discretization
+                eng.ctx.fom_precond_keep(True)
+                self._fom_kept = True
             U, info = eng.ctx.fom_solve(self.Q, self.theta(mu), eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=rtol,
                                         max_iter=max_iter)
             return (U, info) if return_info else U
@@ -79,6 +82,7 @@ class BlockDiscretization3D:
             ctx = Native3DContext(eng.ctx.device.index)
             nbr = np.asarray(g.neighbor_slots, dtype=np.int32).reshape(total, 7)
             ctx.mesh_upload(eng.t, eng.spec, eng.t.tables(eng.spec), nbr, g.phys_mask, total, total)
+            ctx.fom_precond_keep(True)
             self._fom_global = (ctx, A_d.permute(1, 0, 2, 3, 4).contiguous(), A_c.permute(1, 0, 2, 3, 4).contiguous(), b.contiguous())
         return self._fom_global
 

@@ -99,6 +99,17 @@ def test_full_order_solver_with_every_coarse_space_matches_the_sparse_lu(name):
         assert c3.rel(U.cpu().numpy().ravel(), want) < 1e-9, key
         its[key] = info[0]
     assert its['P1'] <= its['constants'] <= its['none'] == its['deficient'] and its['P1'] < its['none'], its   # (counted in steps of 16)
+    # a kept coarse inverse (built at another parameter) is still a valid preconditioner: same solution
+    x = np.asarray(eng.t.node_coordinates())
+    ext = x.max(axis=0) - x.min(axis=0)
+    eng.ctx.fom_coarse_space(np.concatenate([np.ones((n, 1)), (x - 0.5 * (x.max(axis=0) + x.min(axis=0))) / ext], axis=1))
+    eng.ctx.fom_precond_keep(True)
+    try:
+        eng.ctx.fom_solve(eng.Q, c3.theta_of(p, 0.2), eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=1e-12)      # builds and keeps
+        U, info = eng.ctx.fom_solve(eng.Q, th, eng.ops['A_diag'], eng.ops['A_cpl'], eng.ops['b'], rtol=1e-12)             # reuses
+    finally:
+        eng.ctx.fom_precond_keep(False)
+    assert c3.rel(U.cpu().numpy().ravel(), want) < 1e-9 and info[0] <= its['none']
 
 
 def test_batched_online_phase_through_the_api():
