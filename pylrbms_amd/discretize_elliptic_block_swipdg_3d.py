@@ -114,6 +114,12 @@ class ReducedDiscretization3D:
         return expand_factored(self.d.engine, self.out, self.d.Q, self.N)
 
     def solve(self, mu, rtol=1e-12, max_iter=20000, return_info=False):
+        """``rd.solve(mu)`` (online_adaptive_lrbms.py:141).  N <= 32: the batched solver with one parameter -- it has the
+        two-level preconditioner of this reduced model and the matrix-core panel matvec; larger N: the single-parameter
+        block-Jacobi PCG."""
+        if self.N <= 32:
+            U, info = self.solve_batch([mu], rtol=rtol, max_iter=max_iter, return_info=True)
+            return (U[0], info) if return_info else U[0]
         u, info = self.d.engine.reduced_solve(self.d.theta(mu), self.out, rtol=rtol, max_iter=max_iter)
         return (u, info) if return_info else u
 
