@@ -1727,6 +1727,234 @@ __global__ __launch_bounds__(256) void k3_estimate_batch(T3 t, int Q, int N, int
   }
 }
 
+// ---- the same estimate for 16 parameters per pass on the matrix cores.  Every dense term is x^T (G y) with G a projected operator
+// or a factor (rows x cols, row-major in global memory) and x, y coefficient panels [.][16] in the LDS (one column per parameter):
+// a wave takes 16-row strips of G, T = G y is one accumulator tile (A operand: the strip straight from global memory, lane =
+// (row l & 15, k l >> 4), four k-steps of loads in flight; B operand: y rows from the LDS, lane = (parameter l & 15, k)), and the
+// lane sums its four rows of x . T for ITS parameter.  G is read once per pass for all 16 parameters with full-width loads (the
+// VALU kernel above: eight lanes per loaded entry).  The element-local quadratic terms and the node sums stay on the VALU.
+constexpr int EST16 = 16;
+struct TB16 { double v[EST16][8]; };
+
+// tile of T = G y for the 16-row strip at row0 (rows clamped into [0, rows)); y [cols][16] in the LDS; cols <= 64.  All loads of
+// the strip are issued before the first MFMA (a load -> MFMA chain per k-step exposes one memory round trip each).
+__device__ inline d4 est_strip(const double* __restrict__ G, int ld, int row0, int rows, int cols, const double* y, int li, int lk) {
+  const int row = row0 + li < rows ? row0 + li : rows - 1;
+  const double* g = G + (long)row * ld;
+  double av[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int c = 4 * u + lk;
+    av[u] = 4 * u < cols ? g[c < cols ? c : cols - 1] : 0.0;        // (4 u < cols: wave-uniform)
+  }
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    if (4 * u < cols) {
+      const int c = 4 * u + lk;
+      const double bv = c < cols ? y[c * 16 + li] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv, acc, 0, 0, 0);
+    }
+  return acc;
+}
+
+// sum_rows x[row][m] T[row][m] over the strip's valid rows for this lane's parameter
+__device__ inline double est_dot(const d4& T, const double* x, int row0, int rows, int li, int lk) {
+  double v = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + lk + 4 * r;
+    if (row < rows) v += x[row * 16 + li] * T[r];
+  }
+  return v;
+}
+
+// sum_j g[j] u[j * 16] for the 16 parameter lanes of a worker (consecutive lanes, same g, same control flow; n <= 64): lane m loads
+// entry 16 c + m of every chunk, the group passes the values around by lane shuffles (see dot_row8)
+__device__ inline double dot_row16(const double* __restrict__ g, const double* u, int n) {
+  const int lane = threadIdx.x & 63, m = lane & 15, base = lane & ~15;
+  double mine[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) mine[c] = (c * 16 < n && c * 16 + m < n) ? g[c * 16 + m] : 0.0;
+  double d = 0.0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c * 16 >= n) break;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double gk = __shfl(mine[c], base + k);
+      if (c * 16 + k < n) d += gk * u[(c * 16 + k) * 16];
+    }
+  }
+  return d;
+}
+
+constexpr int EST_NW = 8;      // waves per workgroup of k3_estimate_batch16
+
+__global__ __launch_bounds__(64 * EST_NW) void k3_estimate_batch16(T3 t, int Q, int N, int nmu, int m0, TB16 th, EA a) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4, QN = Q * N;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = tid >> 4, m = tid & 15, NWK = 4 * EST_NW;     // VALU parts: workers x 16 parameters
+  const int mb = nmu - m0 < EST16 ? nmu - m0 : EST16;
+  double* us = lds;                        // [7][N][16]  coefficients of the neighbourhood
+  double* ur = us + 7 * N * 16;            // [QN][16]    theta_q u_own
+  double* zf = ur + QN * 16;               // [nbf][16]   neighbours' flux traces at the side faces
+  double* z = zf + t.nbf * 16;             // [nb][16]    neighbours' node averages at the boundary nodes
+  double* red = z + t.nb * 16;             // [EST_NW][6][16] parts of the waves + [NWK][16] r_fd parts of the workers
+  for (int i = tid; i < 7 * N * 16; i += 64 * EST_NW) {
+    const int mm = i & 15, row = i >> 4, s2 = t.nbr[s * 7 + row / N];
+    us[i] = (s2 >= 0 && mm < mb) ? a.u[((long)s2 * N + row % N) * nmu + m0 + mm] : 0.0;
+  }
+  __syncthreads();
+  const double* u0p = us + 3 * N * 16;     // own coefficients [N][16]
+  for (int i = tid; i < QN * 16; i += 64 * EST_NW) {
+    const int mm = i & 15, c = i >> 4;
+    ur[i] = th.v[mm][c / N] * u0p[(c % N) * 16 + mm];
+  }
+  double thq[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) thq[q] = q < Q ? th.v[li][q] : 0.0;
+  // the strips of a term are dealt to the waves round-robin, every term starting one wave further (terms have 2 .. 25 strips)
+  int rot = 0;
+  auto first_strip = [&]() { return 16 * ((wave + EST_NW - (rot++ % EST_NW)) % EST_NW); };
+  // zf = sum_q theta_q Rb_q u_a, side by side (the rows of a side read the coefficients of ONE neighbour)
+  for (int side = 0; side < 6; ++side) {
+    const double* ua = us + side_slot(side) * N * 16;
+    for (int row0 = first_strip(); row0 < t.ncf; row0 += 16 * EST_NW) {
+      d4 zt = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int q = 0; q < Q; ++q) {
+        const d4 T = est_strip(a.Rb + ((long)s * t.nbf + side * t.ncf) * QN + q * N, QN, row0, t.ncf, N, ua, li, lk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zt[r] += thq[q] * T[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + lk + 4 * r;
+        if (row < t.ncf) zf[(side * t.ncf + row) * 16 + li] = zt[r];
+      }
+    }
+  }
+  for (int bn = w; bn < t.nb; bn += NWK) {
+    double acc = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      const int sp = t.bnode_sides[bn * 3 + k];
+      if (sp < 0) continue;
+      acc += dot_row16(a.As + ((long)s * 6 * t.nvs + sp) * N, us + side_slot(sp / t.nvs) * N * 16 + m, N);
+    }
+    z[bn * 16 + m] = acc;
+  }
+  __syncthreads();
+  double p_nc = 0.0, p_bb = 0.0, p_dd = 0.0, p_fd = 0.0, p_ab = 0.0, p_aa = 0.0;      // per lane: its parameter, part of the rows
+  // ---- dense terms on the matrix cores
+  for (int row0 = first_strip(); row0 < N; row0 += 16 * EST_NW) {
+    p_nc += est_dot(est_strip(a.G_nc + (long)s * N * N, N, row0, N, N, u0p, li, lk), u0p, row0, N, li, lk);
+    for (int q = 0; q < Q; ++q) {
+      p_ab += thq[q] * est_dot(est_strip(a.G_ab + ((long)q * t.S + s) * N * QN, QN, row0, N, QN, ur, li, lk), u0p, row0, N, li, lk);
+      for (int q2 = 0; q2 < Q; ++q2)
+        p_aa += thq[q] * thq[q2] *
+                est_dot(est_strip(a.G_aa + (((long)q * Q + q2) * t.S + s) * N * N, N, row0, N, N, u0p, li, lk), u0p, row0, N, li, lk);
+    }
+  }
+  for (int row0 = first_strip(); row0 < t.nb; row0 += 16 * EST_NW)
+    p_nc += 2.0 * est_dot(est_strip(a.Cn + (long)s * t.nb * N, N, row0, t.nb, N, u0p, li, lk), z, row0, t.nb, li, lk);
+  for (int row0 = first_strip(); row0 < QN; row0 += 16 * EST_NW) {
+    p_bb += est_dot(est_strip(a.G_bb + (long)s * QN * QN, QN, row0, QN, QN, ur, li, lk), ur, row0, QN, li, lk);
+    p_dd += est_dot(est_strip(a.G_rdd + (long)s * QN * QN, QN, row0, QN, QN, ur, li, lk), ur, row0, QN, li, lk);
+  }
+  for (int row0 = first_strip(); row0 < t.nbf; row0 += 16 * EST_NW) {
+    p_bb += 2.0 * est_dot(est_strip(a.Yb + (long)s * t.nbf * QN, QN, row0, t.nbf, QN, ur, li, lk), zf, row0, t.nbf, li, lk);
+    p_dd += 2.0 * est_dot(est_strip(a.Dp + (long)s * t.nbf * QN, QN, row0, t.nbf, QN, ur, li, lk), zf, row0, t.nbf, li, lk);
+    for (int q = 0; q < Q; ++q)
+      p_ab += thq[q] * est_dot(est_strip(a.Xab + ((long)q * t.S + s) * t.nbf * N, N, row0, t.nbf, N, u0p, li, lk), zf, row0, t.nbf, li, lk);
+  }
+  // ---- element-local quadratic terms, one element per wave at a time, on the matrix cores as well:
+  // boundary elements: ze^T E ze with ze = z at the element's boundary nodes (0 elsewhere); T = E ze is a 10 x 16 tile, K = 10
+  // (four elements per wave in flight: one at a time is a chain of memory round trips -- index, block, LDS -- per element)
+  constexpr int EU = 4;
+  for (int k0 = wave * EU; k0 < t.nbel; k0 += EST_NW * EU) {
+    double av[EU][3], bv[EU][3], xr[EU][3];
+#pragma unroll
+    for (int x = 0; x < EU; ++x) {
+      const int k = k0 + x < t.nbel ? k0 + x : t.nbel - 1;
+      const int e = t.bel_elem[k];
+      const double* E = a.ebar + ((long)s * t.nT + e) * 100 + (li < 10 ? li : 9) * 10;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int c = 4 * u + lk, cc = c < 10 ? c : 9;
+        av[x][u] = E[cc];
+        const int bn = t.bel_bnode[k * 10 + cc];
+        bv[x][u] = (c < 10 && bn >= 0 && k0 + x < t.nbel) ? z[bn * 16 + li] : 0.0;
+        xr[x][u] = bv[x][u];                                       // rows lk + 4 u of ze: the same entries as the B operand
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < EU; ++x) {
+      d4 T = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 3; ++u) T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x][u], bv[x][u], T, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) p_nc += xr[x][r] * T[r];       // (rows >= 10 and missing nodes carry ze = 0)
+    }
+  }
+  // side elements: ze^T B ze, the divergence of the side part and its pairings; ze = zf at the element's side faces (4 x 4 block)
+  for (int k0 = wave * EU; k0 < t.nsel; k0 += EST_NW * EU) {
+    double av[EU], ze[EU], cf[EU], bd[EU];
+#pragma unroll
+    for (int x = 0; x < EU; ++x) {
+      const bool on = k0 + x < t.nsel;
+      const int k = on ? k0 + x : t.nsel - 1;
+      const int e = t.sel_elem[k], ty = t.elem_type[e];
+      const int sf = t.sel_sf[k * 4 + lk];
+      ze[x] = (on && sf >= 0) ? zf[sf * 16 + li] : 0.0;            // face lk, parameter li
+      av[x] = a.Bbb[((long)s * t.nT + e) * 16 + (li < 4 ? li : 3) * 4 + lk];
+      cf[x] = sgn3(t, s, e, lk) * t.divc[ty * 4 + lk];
+      bd[x] = a.bdiv[(long)s * t.nT + e];
+    }
+#pragma unroll
+    for (int x = 0; x < EU; ++x) {
+      const d4 T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], ze[x], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+      p_bb += ze[x] * T[0];                                         // row lk of B ze (rows 0 .. 3 sit in register 0)
+      double dv = cf[x] * ze[x];
+      dv += __shfl_xor(dv, 16);
+      dv += __shfl_xor(dv, 32);
+      if (lk == 0) {
+        p_dd += t.volume * dv * dv;
+        p_fd += bd[x] * dv;
+      }
+    }
+  }
+  // sum over the four k lanes of a parameter
+  double part[6] = {p_nc, p_bb, p_dd, p_fd, p_ab, p_aa};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    part[k] += __shfl_xor(part[k], 16);
+    part[k] += __shfl_xor(part[k], 32);
+  }
+  double v_fd = 0.0;                       // r_fd . ur: thread = (worker w, parameter m)
+  for (int r = w; r < QN; r += NWK) v_fd += a.r_fd[(long)s * QN + r] * ur[r * 16 + m];
+  double* vred = red + EST_NW * 6 * 16;    // [NWK][16]
+  vred[w * 16 + m] = v_fd;
+  if (lk == 0)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[(wave * 6 + k) * 16 + li] = part[k];
+  __syncthreads();
+  if (tid < mb) {                          // totals per parameter, fixed order
+    double tot[6];
+    for (int k = 0; k < 6; ++k) {
+      double v = 0.0;
+      for (int ww = 0; ww < EST_NW; ++ww) v += red[(ww * 6 + k) * 16 + tid];
+      tot[k] = v;
+    }
+    for (int ww = 0; ww < NWK; ++ww) tot[3] += vred[ww * 16 + tid];
+    const double pi = 3.14159265358979323846;
+    const long o = (long)s * nmu + m0 + tid;
+    a.eta[o] = tot[0];
+    a.eta[(long)t.S * nmu + o] = (a.f2[s] - 2.0 * tot[3] + tot[2]) * (1.0 / (pi * pi)) / a.ceps[s] * a.hdiam * a.hdiam;
+    a.eta[2L * t.S * nmu + o] = tot[1] + 2.0 * tot[4] + tot[5];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------- online: reduced solve
 __global__ __launch_bounds__(256) void k3_combine(long per_q, int Q, QV th, const double* __restrict__ B, double* __restrict__ Amu) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -3004,6 +3232,20 @@ int lrbms3_reduced_estimate_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t
     return fail3(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: bad argument");
   const T3& t = ctx->t;
   EA a{u, G_nc, G_bb, G_rdd, G_ab, G_aa, r_fd, Rb, Yb, Dp, Xab, As, Cn, ebar, Bbb, bdiv, f2, ceps, hdiam, eta_loc};
+  static const bool est16_env = !(getenv("LRBMS3_EST16") && getenv("LRBMS3_EST16")[0] == '0');        // A/B knob
+  const size_t lds16 = sizeof(double) * ((size_t)(7 * N + Q * N + t.nbf + t.nb) * EST16 + EST_NW * 6 * 16 + 4 * EST_NW * 16);
+  if (est16_env && lds16 <= 160 * 1024 - 2048) {
+    if (lds16 > 64 * 1024)
+      HIP3(ctx, hipFuncSetAttribute((const void*)k3_estimate_batch16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+    for (int m0 = 0; m0 < nmu; m0 += EST16) {
+      TB16 th{};
+      for (int m = 0; m < EST16 && m0 + m < nmu; ++m)
+        for (int q = 0; q < Q; ++q) th.v[m][q] = theta[(m0 + m) * Q + q];
+      hipLaunchKernelGGL(k3_estimate_batch16, dim3(t.S), dim3(64 * EST_NW), lds16, (hipStream_t)stream, t, Q, N, nmu, m0, th, a);
+    }
+    LAUNCH3(ctx);
+    return LRBMS_OK;
+  }
   const size_t lds = sizeof(double) * ((size_t)(7 * N + Q * N + t.nbf + t.nb) * EST_MB + 256);
   if (lds > 64 * 1024) return fail3(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: template too large for the LDS");
   for (int m0 = 0; m0 < nmu; m0 += EST_MB) {
