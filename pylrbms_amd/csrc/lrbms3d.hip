@@ -1741,20 +1741,22 @@ struct TB16 { double v[EST16][8]; };
 __device__ inline d4 est_strip(const double* __restrict__ G, int ld, int row0, int rows, int cols, const double* y, int li, int lk) {
   const int row = row0 + li < rows ? row0 + li : rows - 1;
   const double* g = G + (long)row * ld;
-  double av[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int c = 4 * u + lk;
-    av[u] = 4 * u < cols ? g[c < cols ? c : cols - 1] : 0.0;        // (4 u < cols: wave-uniform)
-  }
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int c0 = 0; c0 < cols; c0 += 32) {                            // eight k-steps of loads in flight (sixteen spill at 128 VGPRs)
+    double av[8];
 #pragma unroll
-  for (int u = 0; u < 16; ++u)
-    if (4 * u < cols) {
-      const int c = 4 * u + lk;
-      const double bv = c < cols ? y[c * 16 + li] : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv, acc, 0, 0, 0);
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + 4 * u + lk;
+      av[u] = c0 + 4 * u < cols ? g[c < cols ? c : cols - 1] : 0.0;  // (c0 + 4 u < cols: wave-uniform)
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (c0 + 4 * u < cols) {
+        const int c = c0 + 4 * u + lk;
+        const double bv = c < cols ? y[c * 16 + li] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv, acc, 0, 0, 0);
+      }
+  }
   return acc;
 }
 
@@ -1789,7 +1791,7 @@ __device__ inline double dot_row16(const double* __restrict__ g, const double* u
   return d;
 }
 
-constexpr int EST_NW = 8;      // waves per workgroup of k3_estimate_batch16
+constexpr int EST_NW = 16;     // waves per workgroup of k3_estimate_batch16 (<= 128 VGPRs: sixteen k-steps of loads per strip would spill)
 
 __global__ __launch_bounds__(64 * EST_NW) void k3_estimate_batch16(T3 t, int Q, int N, int nmu, int m0, TB16 th, EA a) {
   extern __shared__ double lds[];
@@ -1835,16 +1837,32 @@ __global__ __launch_bounds__(64 * EST_NW) void k3_estimate_batch16(T3 t, int Q, 
       }
     }
   }
-  for (int bn = w; bn < t.nb; bn += NWK) {
-    double acc = 0.0;
-    for (int k = 0; k < 3; ++k) {
-      const int sp = t.bnode_sides[bn * 3 + k];
-      if (sp < 0) continue;
-      acc += dot_row16(a.As + ((long)s * 6 * t.nvs + sp) * N, us + side_slot(sp / t.nvs) * N * 16 + m, N);
-    }
-    z[bn * 16 + m] = acc;
+  // z = sum over the (<= 3) sides of a boundary node of As u_a: side by side as MFMA strips over the side's nodes, each tile added to
+  // the rows of its boundary nodes (a side holds a node once: no two lanes meet; the sides follow each other, so the order of the
+  // additions is fixed).  (One worker per node with its rows loaded cooperatively: 78 us of 246 -- chains of index -> row -> 30
+  // shuffles per node.)
+  int* sp2bn = reinterpret_cast<int*>(red + EST_NW * 6 * 16 + 4 * EST_NW * 16);      // [6 nvs] side node -> boundary node
+  for (int i = tid; i < 6 * t.nvs; i += 64 * EST_NW) sp2bn[i] = -1;
+  for (int i = tid; i < t.nb * 16; i += 64 * EST_NW) z[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < 3 * t.nb; i += 64 * EST_NW) {
+    const int sp = t.bnode_sides[i];
+    if (sp >= 0) sp2bn[sp] = i / 3;
   }
   __syncthreads();
+  for (int side = 0; side < 6; ++side) {
+    const double* ua = us + side_slot(side) * N * 16;
+    for (int row0 = first_strip(); row0 < t.nvs; row0 += 16 * EST_NW) {
+      const d4 T = est_strip(a.As + ((long)s * 6 * t.nvs + side * t.nvs) * N, N, row0, t.nvs, N, ua, li, lk);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + lk + 4 * r;
+        const int bn = row < t.nvs ? sp2bn[side * t.nvs + row] : -1;
+        if (bn >= 0) z[bn * 16 + li] += T[r];
+      }
+    }
+    __syncthreads();
+  }
   double p_nc = 0.0, p_bb = 0.0, p_dd = 0.0, p_fd = 0.0, p_ab = 0.0, p_aa = 0.0;      // per lane: its parameter, part of the rows
   // ---- dense terms on the matrix cores
   for (int row0 = first_strip(); row0 < N; row0 += 16 * EST_NW) {
@@ -3233,7 +3251,7 @@ int lrbms3_reduced_estimate_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t
   const T3& t = ctx->t;
   EA a{u, G_nc, G_bb, G_rdd, G_ab, G_aa, r_fd, Rb, Yb, Dp, Xab, As, Cn, ebar, Bbb, bdiv, f2, ceps, hdiam, eta_loc};
   static const bool est16_env = !(getenv("LRBMS3_EST16") && getenv("LRBMS3_EST16")[0] == '0');        // A/B knob
-  const size_t lds16 = sizeof(double) * ((size_t)(7 * N + Q * N + t.nbf + t.nb) * EST16 + EST_NW * 6 * 16 + 4 * EST_NW * 16);
+  const size_t lds16 = sizeof(double) * ((size_t)(7 * N + Q * N + t.nbf + t.nb) * EST16 + EST_NW * 6 * 16 + 4 * EST_NW * 16 + 3 * t.nvs + 1);
   if (est16_env && lds16 <= 160 * 1024 - 2048) {
     if (lds16 > 64 * 1024)
       HIP3(ctx, hipFuncSetAttribute((const void*)k3_estimate_batch16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
