@@ -2196,7 +2196,8 @@ __global__ __launch_bounds__(256) void k3b_reduce(int S, int nmu, const double* 
   if (tid < 16) out[tid] = red[tid];
 }
 
-__global__ __launch_bounds__(512) void k3b_init(int N, int nmu, const double* __restrict__ rhs, const double* __restrict__ Dinv,
+//   x: this group's columns of the caller's solution array, x[(s N + i) ldx + m]
+__global__ __launch_bounds__(512) void k3b_init(int N, int nmu, int ldx, const double* __restrict__ rhs, const double* __restrict__ Dinv,
                                                 double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
                                                 double* __restrict__ p, double* __restrict__ prz, double* __restrict__ prr) {
   extern __shared__ double lds[];      // [N] rhs + [N][16] products
@@ -2210,7 +2211,8 @@ __global__ __launch_bounds__(512) void k3b_init(int N, int nmu, const double* __
     const double* D = Dinv + ((long)s * N + i) * N;
     for (int j = 0; j < N; ++j) zi += D[j] * lds[j];
     const long d = ((long)s * N + i) * nmu + m;
-    x[d] = 0.0; r[d] = ri; z[d] = zi; p[d] = 0.0;
+    x[((long)s * N + i) * ldx + m] = 0.0;
+    r[d] = ri; z[d] = zi; p[d] = 0.0;
   }
   double* pr = lds + N;
   for (int pass = 0; pass < 2; ++pass) {
@@ -2420,7 +2422,7 @@ __global__ __launch_bounds__(512) void k3b_matvec(T3 t, int Q, int N, int nmu, i
   }
 }
 
-__global__ __launch_bounds__(512) void k3b_update(int N, int nmu, const double* __restrict__ Dinv, const double* __restrict__ p,
+__global__ __launch_bounds__(512) void k3b_update(int N, int nmu, int ldx, const double* __restrict__ Dinv, const double* __restrict__ p,
                                                   const double* __restrict__ Ap, double* __restrict__ x, double* __restrict__ r,
                                                   double* __restrict__ z, int S, const double* __restrict__ prz_cur,
                                                   const double* __restrict__ prc_cur, const double* __restrict__ ppap,
@@ -2435,7 +2437,7 @@ __global__ __launch_bounds__(512) void k3b_update(int N, int nmu, const double* 
   if (on) {
     const double alpha = pap != 0.0 ? rz / pap : 0.0;               // a converged parameter (r = 0) stays put
     const long d = ((long)s * N + i) * nmu + m;
-    x[d] += alpha * p[d];
+    x[((long)s * N + i) * ldx + m] += alpha * p[d];
     ri = r[d] - alpha * Ap[d];
     r[d] = ri;
   }
@@ -3339,10 +3341,14 @@ int lrbms3_reduced_solve(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* th
   return LRBMS_OK;
 }
 
+// doubles of work per group of <= 16 parameters of the batched reduced solve
+static long reduced_batch_group_size(long S, int N) {
+  return S * 7 * N * N + S * N * N + 5 * S * N * 16 + 4 * S * 16 + 5 * 16 + 16 + 3 * S * 16;      // (+ y0, prc [2] of the coarse level)
+}
+
 int64_t lrbms3_reduced_solve_batch_work_size(lrbms3_ctx* ctx, int32_t N, int32_t nmu) {
-  if (!ctx || !ctx->has_mesh) return -1;
-  const int64_t S = ctx->t.S;
-  return S * 7 * N * N + S * N * N + 5 * S * N * nmu + 4 * S * 16 + 5 * 16 + 16 + 3 * S * 16;      // (+ y0, prc [2] of the coarse level)
+  if (!ctx || !ctx->has_mesh || nmu < 1) return -1;
+  return (int64_t)((nmu + 15) / 16) * reduced_batch_group_size(ctx->t.S, N);
 }
 
 int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* B_sys,
@@ -3351,88 +3357,147 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
   REQUIRE3(ctx);
   const T3& t = ctx->t;
   if (t.S_ext != t.S) return fail3(ctx, LRBMS_E_INVALID, "reduced_solve_batch: needs all subdomains on this rank");
-  if (Q < 1 || Q > 8 || N < 1 || N > 32 || nmu < 1 || nmu > 16 || !theta || !B_sys || !rhs_red || !work || !u)
-    return fail3(ctx, LRBMS_E_INVALID, "reduced_solve_batch: needs N <= 32 and nmu <= 16");
+  if (Q < 1 || Q > 8 || N < 1 || N > 32 || nmu < 1 || nmu > 48 || !theta || !B_sys || !rhs_red || !work || !u)
+    return fail3(ctx, LRBMS_E_INVALID, "reduced_solve_batch: needs N <= 32 and nmu <= 48");
   hipStream_t st = (hipStream_t)stream;
-  const long S = t.S, per_q = S * 7 * N * N, nv = S * N * nmu;
-  double* Amu = work;                 // blocks at the batch-mean theta: only its diagonal blocks are used (preconditioner)
-  double* Dinv = Amu + per_q;
-  double* r = Dinv + S * N * N;
-  double* z = r + nv;
-  double* p0 = z + nv;
-  double* p1 = p0 + nv;
-  double* Ap = p1 + nv;
-  double* prz = Ap + nv;              // [2][S][16]: r.z partials of the last two updates (beta needs both)
-  double* ppap = prz + 2 * S * 16;
-  double* prr = ppap + S * 16;
-  double* scal = prr + S * 16;        // [5][16]: only the residual norms ([3], [4]) are reduced by a kernel of their own
-  double* y0 = scal + 5 * 16 + 16;    // coarse level (lrbms3_reduced_precond_use): correction and its r.z contributions [2][S][16]
-  double* prc = y0 + S * 16;
+  const long S = t.S, per_q = S * 7 * N * N;
+  // Up to three groups of <= 16 parameters, each an independent CG on its own stream (the caller's and the library's two side
+  // streams): a group's kernels are 512 small workgroups that wait on memory most of the time, so two or three groups share the
+  // chip at little cost to each other.  Launches are interleaved iteration by iteration; residuals are looked at together.
+  const int ng = (nmu + 15) / 16;
+  const long gsize = reduced_batch_group_size(S, N);
+  struct Group {
+    int nm, m0;
+    TB th;
+    double *Amu, *Dinv, *r, *z, *po, *pn, *Ap, *prz, *ppap, *prr, *scal, *y0, *prc;
+    hipStream_t st;
+    bool done;
+    double rel;
+    int it;
+  } g[3];
   const double* A0inv = ctx->user_pc_N == N ? ctx->user_pc : nullptr;
-  TB th{};
-  QV mean{};
-  for (int m = 0; m < nmu; ++m)
-    for (int q = 0; q < Q; ++q) {
-      th.v[m][q] = theta[m * Q + q];
-      mean.v[q] += theta[m * Q + q] / nmu;
-    }
-  if (A0inv) {
-    Dinv = const_cast<double*>(A0inv) + S * S;        // the prebuilt preconditioner carries its inverse diagonal blocks (read only)
-  } else {
-    hipLaunchKernelGGL(k3_combine, dim3((unsigned)((per_q + 255) / 256)), dim3(256), 0, st, per_q, Q, mean, B_sys, Amu);
-    hipLaunchKernelGGL(k3_block_inverse, dim3(S), dim3(256), sizeof(double) * N * (2 * N + 1), st, N, Amu, Dinv);
+  for (int k = 0; k < ng; ++k) {
+    Group& G = g[k];
+    G.m0 = 16 * k;
+    G.nm = nmu - G.m0 < 16 ? nmu - G.m0 : 16;
+    G.st = k == 0 ? st : ctx->aux[k - 1];
+    G.done = false;
+    G.rel = 0.0;
+    G.it = 0;
+    const long nv = S * N * 16;
+    double* w = work + k * gsize;
+    G.Amu = w;                        // blocks at the group-mean theta: only its diagonal blocks are used (preconditioner)
+    G.Dinv = G.Amu + per_q;
+    G.r = G.Dinv + S * N * N;
+    G.z = G.r + nv;
+    G.po = G.z + nv;
+    G.pn = G.po + nv;
+    G.Ap = G.pn + nv;
+    G.prz = G.Ap + nv;                // [2][S][16]: r.z partials of the last two updates (beta needs both)
+    G.ppap = G.prz + 2 * S * 16;
+    G.prr = G.ppap + S * 16;
+    G.scal = G.prr + S * 16;          // [5][16]: only the residual norms ([3], [4]) are reduced by a kernel of their own
+    G.y0 = G.scal + 5 * 16 + 16;      // coarse level (lrbms3_reduced_precond_use): correction and its r.z contributions [2][S][16]
+    G.prc = G.y0 + S * 16;
+    G.th = TB{};
   }
-  HIP3(ctx, hipMemsetAsync(scal, 0, sizeof(double) * 80, st));
-  hipLaunchKernelGGL(k3b_init, dim3(S), dim3(512), sizeof(double) * (N + 32 * 16), st, N, nmu, rhs_red, Dinv, u, r, z, p0, prz, prr);
-  if (A0inv) hipLaunchKernelGGL(k3b_coarse_apply, dim3((unsigned)((S + 15) / 16)), dim3(1024), 0, st, (int)S, N, nmu, A0inv, r, y0, prc);
-  hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prr, scal + 64);
+  if (ng > 1) {
+    HIP3(ctx, hipEventRecord(ctx->ev_fork, st));
+    for (int k = 1; k < ng; ++k) HIP3(ctx, hipStreamWaitEvent(g[k].st, ctx->ev_fork, 0));
+  }
+  for (int k = 0; k < ng; ++k) {
+    Group& G = g[k];
+    QV mean{};
+    for (int m = 0; m < G.nm; ++m)
+      for (int q = 0; q < Q; ++q) {
+        G.th.v[m][q] = theta[(G.m0 + m) * Q + q];
+        mean.v[q] += theta[(G.m0 + m) * Q + q] / G.nm;
+      }
+    if (A0inv) {
+      G.Dinv = const_cast<double*>(A0inv) + S * S;      // the prebuilt preconditioner carries its inverse diagonal blocks (read only)
+    } else {
+      hipLaunchKernelGGL(k3_combine, dim3((unsigned)((per_q + 255) / 256)), dim3(256), 0, G.st, per_q, Q, mean, B_sys, G.Amu);
+      hipLaunchKernelGGL(k3_block_inverse, dim3(S), dim3(256), sizeof(double) * N * (2 * N + 1), G.st, N, G.Amu, G.Dinv);
+    }
+    HIP3(ctx, hipMemsetAsync(G.scal, 0, sizeof(double) * 80, G.st));
+    hipLaunchKernelGGL(k3b_init, dim3(S), dim3(512), sizeof(double) * (N + 32 * 16), G.st, N, G.nm, nmu, rhs_red, G.Dinv, u + G.m0, G.r,
+                       G.z, G.po, G.prz, G.prr);
+    if (A0inv)
+      hipLaunchKernelGGL(k3b_coarse_apply, dim3((unsigned)((S + 15) / 16)), dim3(1024), 0, G.st, (int)S, N, G.nm, A0inv, G.r, G.y0, G.prc);
+    hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, G.st, (int)S, G.nm, G.prr, G.scal + 64);
+  }
   LAUNCH3(ctx);
-  double bb[16];                       // |b|^2 per parameter: fetched with the first residual check (no host round trip of its own)
   if (info) info[0] = 0, info[1] = 0;
-  double *po = p0, *pn = p1;
-  int it = 0;
-  double rel = 0.0;
   const int check = A0inv ? 12 : 8;    // iterations between two looks at the residuals (a host synchronisation each)
   const size_t lds_mv = sizeof(double) * (7 * N * 16 + 32 * 16), lds_up = sizeof(double) * (N * 16 + 32 * 16);
   const size_t lds_mm = sizeof(double) * (7 * 32 * 16 + 4 * (N <= 16 ? 1 : 2) * 256 + 32 * 16);
   static const bool mfma_mv = !(getenv("LRBMS3_BMV") && getenv("LRBMS3_BMV")[0] == '0');      // A/B knob: 0 = the VALU panel matvec
-  while (it < max_iter) {
-    for (int k = 0; k < check && it < max_iter; ++k, ++it) {
-      double* rz_cur = prz + (it & 1) * S * 16;            // written by the previous update (or k3b_init)
-      double* rz_nxt = prz + ((it + 1) & 1) * S * 16;      // holds the r.z of the update before that until this update overwrites it
-      double* rc_cur = prc + (it & 1) * S * 16;
-      double* rc_nxt = prc + ((it + 1) & 1) * S * 16;
-      const CoarseB cb{A0inv ? y0 : nullptr, rc_cur, rc_nxt};
-      if (mfma_mv && N <= 16)
-        hipLaunchKernelGGL(k3b_matvec_mfma<1>, dim3(S), dim3(256), lds_mm, st, t, Q, N, nmu, it == 0 ? 1 : 0, th, B_sys, z, po, pn, Ap,
-                           rz_cur, rz_nxt, ppap, cb);
-      else if (mfma_mv)
-        hipLaunchKernelGGL(k3b_matvec_mfma<2>, dim3(S), dim3(256), lds_mm, st, t, Q, N, nmu, it == 0 ? 1 : 0, th, B_sys, z, po, pn, Ap,
-                           rz_cur, rz_nxt, ppap, cb);
-      else
-        hipLaunchKernelGGL(k3b_matvec, dim3(S), dim3(512), lds_mv, st, t, Q, N, nmu, it == 0 ? 1 : 0, th, B_sys, z, po, pn, Ap, rz_cur,
-                           rz_nxt, ppap, cb);
-      hipLaunchKernelGGL(k3b_update, dim3(S), dim3(512), lds_up, st, N, nmu, Dinv, pn, Ap, u, r, z, (int)S, rz_cur,
-                         A0inv ? rc_cur : nullptr, ppap, rz_nxt, prr);
-      if (A0inv)      // the coarse correction of the new residual: read by the next matvec (direction) and by the next update (r.z)
-        hipLaunchKernelGGL(k3b_coarse_apply, dim3((unsigned)((S + 15) / 16)), dim3(1024), 0, st, (int)S, N, nmu, A0inv, r, y0, rc_nxt);
-      std::swap(po, pn);
+  int rc = LRBMS_OK;
+  bool all_done = false;
+  while (!all_done) {
+    for (int c = 0; c < check; ++c)
+      for (int k = 0; k < ng; ++k) {
+        Group& G = g[k];
+        if (G.done || G.it >= max_iter) continue;
+        const int it = G.it;
+        double* rz_cur = G.prz + (it & 1) * S * 16;          // written by the previous update (or k3b_init)
+        double* rz_nxt = G.prz + ((it + 1) & 1) * S * 16;    // holds the r.z of the update before that until this update overwrites it
+        double* rc_cur = G.prc + (it & 1) * S * 16;
+        double* rc_nxt = G.prc + ((it + 1) & 1) * S * 16;
+        const CoarseB cb{A0inv ? G.y0 : nullptr, rc_cur, rc_nxt};
+        if (mfma_mv && N <= 16)
+          hipLaunchKernelGGL(k3b_matvec_mfma<1>, dim3(S), dim3(256), lds_mm, G.st, t, Q, N, G.nm, it == 0 ? 1 : 0, G.th, B_sys, G.z, G.po,
+                             G.pn, G.Ap, rz_cur, rz_nxt, G.ppap, cb);
+        else if (mfma_mv)
+          hipLaunchKernelGGL(k3b_matvec_mfma<2>, dim3(S), dim3(256), lds_mm, G.st, t, Q, N, G.nm, it == 0 ? 1 : 0, G.th, B_sys, G.z, G.po,
+                             G.pn, G.Ap, rz_cur, rz_nxt, G.ppap, cb);
+        else
+          hipLaunchKernelGGL(k3b_matvec, dim3(S), dim3(512), lds_mv, G.st, t, Q, N, G.nm, it == 0 ? 1 : 0, G.th, B_sys, G.z, G.po, G.pn,
+                             G.Ap, rz_cur, rz_nxt, G.ppap, cb);
+        hipLaunchKernelGGL(k3b_update, dim3(S), dim3(512), lds_up, G.st, N, G.nm, nmu, G.Dinv, G.pn, G.Ap, u + G.m0, G.r, G.z, (int)S,
+                           rz_cur, A0inv ? rc_cur : nullptr, G.ppap, rz_nxt, G.prr);
+        if (A0inv)    // the coarse correction of the new residual: read by the next matvec (direction) and by the next update (r.z)
+          hipLaunchKernelGGL(k3b_coarse_apply, dim3((unsigned)((S + 15) / 16)), dim3(1024), 0, G.st, (int)S, N, G.nm, A0inv, G.r, G.y0,
+                             rc_nxt);
+        std::swap(G.po, G.pn);
+        ++G.it;
+      }
+    double rr[3][32];
+    for (int k = 0; k < ng; ++k) {
+      Group& G = g[k];
+      if (G.done) continue;
+      hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, G.st, (int)S, G.nm, G.prr, G.scal + 48);
+      HIP3(ctx, hipMemcpyAsync(rr[k], G.scal + 48, sizeof(double) * 32, hipMemcpyDeviceToHost, G.st));   // [3] residuals, [4] |b|^2
     }
-    hipLaunchKernelGGL(k3b_reduce, dim3(1), dim3(256), 0, st, (int)S, nmu, prr, scal + 48);
     LAUNCH3(ctx);
-    double rr[32];
-    HIP3(ctx, hipMemcpyAsync(rr, scal + 48, sizeof(double) * 32, hipMemcpyDeviceToHost, st));     // [3] residuals, [4] |b|^2
-    HIP3(ctx, hipStreamSynchronize(st));
-    for (int m = 0; m < 16; ++m) bb[m] = rr[16 + m];
-    rel = 0.0;
-    for (int m = 0; m < nmu; ++m) {
-      const double rm = bb[m] > 0.0 ? sqrt(rr[m] / bb[m]) : 0.0;
-      if (!(rm == rm)) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve_batch: NaN residual");
-      rel = rm > rel ? rm : rel;
+    all_done = true;
+    for (int k = 0; k < ng; ++k) {
+      Group& G = g[k];
+      if (G.done) continue;
+      HIP3(ctx, hipStreamSynchronize(G.st));
+      G.rel = 0.0;
+      for (int m = 0; m < G.nm; ++m) {
+        const double bbm = rr[k][16 + m], rm = bbm > 0.0 ? sqrt(rr[k][m] / bbm) : 0.0;
+        if (!(rm == rm)) rc = LRBMS_E_NOT_CONVERGED;
+        G.rel = rm > G.rel ? rm : G.rel;
+      }
+      if (G.rel <= rtol || G.it >= max_iter || rc != LRBMS_OK) G.done = true;
+      if (!G.done) all_done = false;
     }
-    if (rel <= rtol) break;
+  }
+  if (ng > 1)
+    for (int k = 1; k < ng; ++k) {
+      HIP3(ctx, hipEventRecord(ctx->ev_join[k - 1], g[k].st));
+      HIP3(ctx, hipStreamWaitEvent(st, ctx->ev_join[k - 1], 0));
+    }
+  int it = 0;
+  double rel = 0.0;
+  for (int k = 0; k < ng; ++k) {
+    it = g[k].it > it ? g[k].it : it;
+    rel = g[k].rel > rel ? g[k].rel : rel;
   }
   if (info) info[0] = it, info[1] = rel;
+  if (rc != LRBMS_OK) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve_batch: NaN residual");
   if (rel > rtol) return fail3(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve_batch: not converged");
   return LRBMS_OK;
 }

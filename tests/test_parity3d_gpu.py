@@ -161,6 +161,31 @@ def test_batched_reduced_solve_matches_single_solves_and_the_oracle(case):
         assert c3.rel(ub[:, :, m].cpu().numpy(), us.cpu().numpy()) < 1e-10
 
 
+def test_batched_solve_of_three_groups_on_three_streams(case):
+    """nmu > 16: groups of 16 parameters as independent CG runs on the caller's stream and the library's two side streams, launches
+    interleaved, each group writing its own columns of u [S, N, nmu] -- every column equals the oracle's solution, with and
+    without the prebuilt preconditioner; 17 and 48 parameters cover a one-column last group and three full groups."""
+    p, d, eng, rd, out = case['p'], case['d'], case['eng'], case['rd'], case['out']
+    if p['N'] > 32:
+        pytest.skip('batched solve takes N <= 32')
+    for nmu in (17, 48):
+        mus = list(np.linspace(0.15, 1.2, nmu))
+        thetas = np.stack([c3.theta_of(p, mu) for mu in mus])
+        ub, (it, res) = eng.ctx.reduced_solve_batch(d.Q, thetas, out['B_sys'], out['rhs_red'], rtol=1e-13)
+        assert tuple(ub.shape) == (eng.S, p['N'], nmu) and res <= 1e-13 and it > 0
+        ref = [np.stack(rd.solve(mu)) for mu in mus]
+        for m in range(nmu):
+            assert c3.rel(ub[:, :, m].cpu().numpy(), ref[m]) < 1e-10, (nmu, m)
+        eng.ctx.reduced_precond_use(eng.ctx.reduced_precond_build(d.Q, c3.theta_of(p, 0.6), out['B_sys']))
+        try:
+            u2, (_, res2) = eng.ctx.reduced_solve_batch(d.Q, thetas, out['B_sys'], out['rhs_red'], rtol=1e-13)
+        finally:
+            eng.ctx.reduced_precond_use(None)
+        assert res2 <= 1e-13
+        for m in range(nmu):
+            assert c3.rel(u2[:, :, m].cpu().numpy(), ref[m]) < 1e-10, (nmu, m, 'pc')
+
+
 def test_batched_solve_with_the_prebuilt_coarse_level(case):
     """lrbms3_reduced_precond_build / _use: the Galerkin coarse problem on the first local basis vectors, inverted once at a
     reference parameter, added to the inverse diagonal blocks -- the same solutions as the oracle for every parameter of the
