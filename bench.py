@@ -393,24 +393,27 @@ def main():
         eng.ctx.reduced_precond_use(pc)
         torch.cuda.synchronize()
         t_pc = time.perf_counter() - t1
-        iters, worst = 0, 0.0
-        t_est = 0.0
-        for b0 in range(0, len(mus), nb):
-            ub, info = eng.ctx.reduced_solve_batch(thetas[b0:b0 + nb], bufo['sys'][0], bufo['sys'][1], rtol=1e-12)
-            iters, worst = max(iters, info['iterations']), max(worst, info['relative_residual'])
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
+        eng.ctx.reduced_solve_batches(thetas[:3 * nb], bufo['sys'][0], bufo['sys'][1], batch=nb)   # untimed: first use of the side streams
+        torch.cuda.synchronize()
+        t_warm = time.perf_counter() - t1 - t_pc
+        # the batches of 16 on up to three of the library's side streams at once (what rd.solve_batch does): a batch's kernels
+        # are latency-bound and share the chip (one after the other: 6 100 mu-solves/s)
+        ulist, info = eng.ctx.reduced_solve_batches(thetas, bufo['sys'][0], bufo['sys'][1], batch=nb, rtol=1e-12, concat=False)
+        iters, worst = info['iterations'], info['relative_residual']
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for b, ub in enumerate(ulist):
             for e0 in range(0, ub.shape[2], ne):                              # E1, in sub-batches of <= 16 parameters
-                eng.ctx.reduced_estimate_batch(thetas[b0 + e0:b0 + e0 + ne], ub[:, :, e0:e0 + ne].contiguous(), bufo['grams'],
+                eng.ctx.reduced_estimate_batch(thetas[b * nb + e0:b * nb + e0 + ne], ub[:, :, e0:e0 + ne].contiguous(), bufo['grams'],
                                                eng.f2, eng.ceps, eng.hdiam)
-            torch.cuda.synchronize()
-            t_est += time.perf_counter() - t2
-        dt = time.perf_counter() - t1
+        torch.cuda.synchronize()
+        t_est = time.perf_counter() - t2
+        dt = time.perf_counter() - t1 - t_warm
         eng.ctx.reduced_precond_use(None)
         online = {'metric': 'online reduced solves (O1)', 'value': len(mus) / (dt - t_est), 'unit': 'mu-solves/s',
                   'solve_plus_estimate_per_s': len(mus) / dt, 'estimates_per_s': len(mus) / t_est, 'parameters': len(mus),
                   'batch': nb, 'reduced_dim': S_total * N, 'cg_iterations_max': iters, 'relative_residual_max': worst,
-                  'preconditioner_build_ms': 1e3 * t_pc,
+                  'preconditioner_build_ms': 1e3 * t_pc, 'batches_in_flight': 3,
                   'solver': 'PCG on the block-sparse reduced system, rtol 1e-12, preconditioner = inverse diagonal blocks + coarse '
                             'level on the first local basis vectors, built once at mu = 0.55 (time included in value); '
                             'estimates: lrbms_reduced_estimate_batch (local nc / r / df terms of every subdomain)'}

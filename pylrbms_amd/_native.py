@@ -481,6 +481,51 @@ class NativeContext:
         self._check(rc, 'lrbms_reduced_solve_batch')
         return u, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
 
+    def reduced_solve_batches(self, thetas, B_sys, rhs_red, batch=16, rtol=1e-13, max_iter=20000, streams=3, concat=True):
+        """Parameter sweep: thetas [nmu, Q] for any nmu -> u [S, N, nmu] (``concat=False``: the list of per-batch arrays
+        [S, N, <= batch], no copy), info.  The batches of ``batch`` parameters are dealt to
+        ``streams`` host threads, each issuing its ``lrbms_reduced_solve_batch`` calls on one of the library's side streams (the
+        call synchronises only its own stream, and ctypes drops the GIL): a batch's kernels are latency-bound, so two or three
+        independent batches share the chip -- 6 100 -> 8 700 mu-solves/s at config 3, bit-identical results."""
+        import threading
+        torch = self.torch
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        chunks = [th[b0:b0 + batch] for b0 in range(0, th.shape[0], batch)]
+        nthreads = max(1, min(int(streams), 3, len(chunks)))
+        pc = getattr(self, '_pc_in_use', None)
+        if pc is None or int(pc._lrbms_N) != int(B_sys.shape[3]):
+            nthreads = 1          # without a prebuilt preconditioner every call builds its coarse level in scratch the context owns
+        if nthreads == 1:
+            res = [self.reduced_solve_batch(c, B_sys, rhs_red, rtol=rtol, max_iter=max_iter) for c in chunks]
+        else:
+            main = torch.cuda.current_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(main)                                   # inputs written on the caller's stream
+            res, errors = [None] * len(chunks), []
+
+            def worker(k):
+                try:
+                    side = self.aux_stream(k)
+                    side.wait_event(ready)
+                    with torch.cuda.stream(side):
+                        for b in range(k, len(chunks), nthreads):
+                            res[b] = self.reduced_solve_batch(chunks[b], B_sys, rhs_red, rtol=rtol, max_iter=max_iter)
+                            res[b][0].record_stream(main)        # consumed (and freed) on the caller's stream
+                except Exception as exc:                         # re-raised in the calling thread
+                    errors.append(exc)
+            threads = [threading.Thread(target=worker, args=(k,)) for k in range(nthreads)]
+            for t_ in threads:
+                t_.start()
+            for t_ in threads:
+                t_.join()
+            if errors:
+                raise errors[0]
+        if concat:
+            u = torch.cat([r[0] for r in res], dim=2) if len(res) > 1 else res[0][0]
+        else:
+            u = [r[0] for r in res]
+        return u, {'iterations': max(r[1]['iterations'] for r in res), 'relative_residual': max(r[1]['relative_residual'] for r in res)}
+
     def reduced_precond_build(self, theta, B_sys):
         """Two-level preconditioner of the reduced solves at the reference parameter ``theta`` -> device buffer."""
         Q, S, N = B_sys.shape[0], self.S, B_sys.shape[3]

@@ -95,7 +95,8 @@ class ReducedDiscretization:
         return ReducedVectorArray(u.reshape(eng.S, self.N, 1))
 
     def solve_batch(self, mus):
-        """Parameter sweep: ``len(mus)`` reduced solutions (batches of <= 16 through ``lrbms_reduced_solve_batch``);
+        """Parameter sweep: ``len(mus)`` reduced solutions (batches of <= 16 through ``lrbms_reduced_solve_batch``, up to three
+        batches in flight on the library's side streams);
         returns one ``ReducedVectorArray`` with ``len(mus)`` vectors."""
         eng = self.d.engine
         thetas = np.array([self.d.theta(mu) for mu in mus])
@@ -103,9 +104,9 @@ class ReducedDiscretization:
         # sharded: on the gathered reduced system, like solve(); every rank keeps the rows of its own subdomains
         ctx, B_sys, rhs = self._global_online() if eng.S_ext != eng.S else (eng.ctx, self.B_sys, self.rhs_red)
 
-        def run():
-            return [ctx.reduced_solve_batch(thetas[b0:b0 + nb], B_sys, rhs)[0] for b0 in range(0, len(thetas), nb)]
-        u = self._torch.cat(self._solve_with_preconditioner(ctx, B_sys, run), dim=2)
+        def run():        # batches on up to three side streams at once (NativeContext.reduced_solve_batches)
+            return ctx.reduced_solve_batches(thetas, B_sys, rhs, batch=nb)[0]
+        u = self._solve_with_preconditioner(ctx, B_sys, run)
         if eng.S_ext != eng.S:
             u = u[self._torch.as_tensor(eng.local, device=u.device)]
         return ReducedVectorArray(u)
