@@ -2581,8 +2581,13 @@ __global__ __launch_bounds__(64) void k3f_block_inverse(T3 t, const double* __re
       }
     }
   }
-  double* dst = Dinv + ((long)s * t.nT + e) * 100;
-  for (int i = 0; i < 100; ++i) dst[i] = inv[i];
+  // the inverse of an SPD block is symmetric: its upper triangle is stored, packed row by row (56 doubles per block) -- the update
+  // kernel of the CG streams these blocks every iteration and is bound by their bytes
+  double* dst = Dinv + ((long)s * t.nT + e) * 56;
+  int k = 0;
+  for (int i = 0; i < 10; ++i)
+    for (int j = i; j < 10; ++j) dst[k++] = inv[i * 10 + j];
+  dst[55] = 0.0;
 }
 
 // scal: [0], [1] r.z of the last two updates (alternating)  [2] pAp  [3] rr  [4] bb
@@ -2713,9 +2718,12 @@ __global__ __launch_bounds__(256) void k3f_update(T3 t, int init, int cur, const
   __syncthreads();
   double zi = 0.0;
   if (on) {
-    const double* D = Dinv + ((long)s * t.nT + e) * 100 + i * 10;
+    const double* D = Dinv + ((long)s * t.nT + e) * 56;          // packed upper triangle: entry (a, b), a <= b, at a (21 - a) / 2 + b - a
 #pragma unroll
-    for (int j = 0; j < 10; ++j) zi += D[j] * rs[el * 10 + j];
+    for (int j = 0; j < 10; ++j) {
+      const int a = i < j ? i : j, b = i < j ? j : i;
+      zi += D[a * (21 - a) / 2 + b - a] * rs[el * 10 + j];
+    }
     z[d] = zi;
   }
   red[tid] = ri * zi;
