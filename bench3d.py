@@ -178,6 +178,29 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
                 'compulsory_GBps': (inputs + outputs) / (dev_ms * 1e-3) / 1e9,
                 'compulsory_frac_of_hbm_peak': (inputs + outputs) / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 'device_ms_per_step': dev_ms, 'kernels': table, 'kernels_sum_us': sum(r['us'] for r in table)}
+    # measured HBM traffic per launch from the committed rocprofv3 PMC passes of this configuration (FETCH_SIZE x 2 + WRITE_SIZE as the
+    # guide prescribes for gfx950; separate --pmc runs, tools/cfg5_pmc.sh): profiles/rNN_cfg5_pmc_traffic.json
+    if world == 1:
+        import glob
+        import json as _json
+        for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+            try:
+                doc = _json.load(open(path))
+            except (OSError, ValueError):
+                continue
+            if doc.get('config') != config:
+                continue
+            for r in table:
+                if r['name'] in doc['per_kernel']:
+                    r['pmc_bytes'] = doc['per_kernel'][r['name']]['bytes']
+            if dom['name'] in doc['per_kernel']:
+                roofline['traffic'] = doc['per_kernel'][dom['name']]['bytes']
+                roofline['traffic_GBps'] = roofline['traffic'] / (dom['us'] * 1e-6) / 1e9
+                roofline['traffic_frac_of_hbm_peak'] = roofline['traffic_GBps'] / PEAK_HBM_GBS
+            roofline['traffic_per_pass'] = doc['per_pass_bytes']
+            roofline['traffic_over_compulsory'] = doc['per_pass_bytes'] / (inputs + outputs)
+            roofline['traffic_source'] = os.path.join('profiles', os.path.basename(path))
+            break
     mine = [float(S), float(len(eng.halo)), float(halo.send_bytes if halo is not None else 0), float(halo.recv_bytes if halo is not None else 0)]
     if world > 1:
         gathered = [torch.zeros(4, dtype=torch.float64, device=V.device) for _ in range(world)]
