@@ -150,11 +150,11 @@ int64_t lrbms3_reduced_solve_work_size(lrbms3_ctx* ctx, int32_t N);
 int lrbms3_reduced_solve(lrbms3_ctx* ctx, int32_t Q, int32_t N, const double* theta, const double* B_sys, const double* rhs_red,
                          double* work, double* u, double rtol, int32_t max_iter, double* info, void* stream);
 
-/* Throughput form of the reduced solve: nmu <= 48 parameters at once (N <= 32), in groups of <= 16.  theta [nmu][Q] host;
+/* Throughput form of the reduced solve: nmu <= 64 parameters at once (N <= 32), in groups of <= 16.  theta [nmu][Q] host;
  * u [S][N][nmu] (parameter fastest).  Inside a group every projected block is read once per CG iteration for all its parameters
  * (panel matvec on the matrix cores), independent CG scalars per parameter; preconditioner: the inverse diagonal blocks at the
- * group-mean theta, or the prebuilt two-level one (lrbms3_reduced_precond_use).  The (<= 3) groups run on the caller's stream and
- * the library's two side streams, launches interleaved: their kernels are latency-bound and share the chip.  info[0] =
+ * group-mean theta, or the prebuilt two-level one (lrbms3_reduced_precond_use).  The (<= 4) groups run on the caller's stream and
+ * the library's three side streams, launches interleaved: their kernels are latency-bound and share the chip.  info[0] =
  * iterations (of the slowest group), info[1] = worst relative residual.  2D: lrbms_reduced_solve_batch. */
 int64_t lrbms3_reduced_solve_batch_work_size(lrbms3_ctx* ctx, int32_t N, int32_t nmu);
 int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* B_sys,

@@ -296,7 +296,7 @@ class Native3DContext:
         return u, (int(info[0]), float(info[1]))
 
     def reduced_solve_batch(self, Q, thetas, B_sys, rhs_red, rtol=1e-13, max_iter=5000, work=None):
-        """thetas [nmu, Q] (nmu <= 48: up to three groups of 16 on three streams) -> u [S, N, nmu] (parameter fastest),
+        """thetas [nmu, Q] (nmu <= 64: up to four groups of 16 on four streams) -> u [S, N, nmu] (parameter fastest),
         (iterations, worst relative residual)."""
         N, S = rhs_red.shape[1], self.S
         th = np.ascontiguousarray(thetas, dtype=np.float64)

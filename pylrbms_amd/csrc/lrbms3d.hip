@@ -61,8 +61,9 @@ struct lrbms3_ctx {
   void* blas = nullptr;           // rocBLAS handle (dense coarse inverses), created on first use
   const double* user_pc = nullptr;   // coarse inverse the batched reduced solve uses (lrbms3_reduced_precond_use), caller-owned
   int user_pc_N = 0;
-  hipStream_t aux[2] = {nullptr, nullptr};          // library-owned streams: the flux chain and the Oswald chain of the pass
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr}; // library-owned streams: the flux chain and the Oswald chain of the pass; the
+                                                    // groups of the batched reduced solve (all three)
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   double* pg_part = nullptr;       // K-split partial results of the k3_pg kernels (library-owned, grown on demand)
   long pg_part_cap = 0;
   bool side_padding = false;       // some side has fewer faces than ncf (unequal cubes per direction): padded factor rows exist
@@ -2890,7 +2891,7 @@ int lrbms3_ctx_create(int device, lrbms3_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return LRBMS_E_HIP;
   lrbms3_ctx* c = new lrbms3_ctx();
   c->device = device;
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 3; ++i)
     if ((c->aux[i] = lrbms_side_stream_acquire(device, i)) == nullptr ||
         hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
       return lrbms3_ctx_destroy(c), LRBMS_E_HIP;
@@ -2906,7 +2907,7 @@ int lrbms3_ctx_destroy(lrbms3_ctx* ctx) {
   if (ctx->pg_part) (void)hipFree(ctx->pg_part);
   if (ctx->blas) (void)rocblas_destroy_handle((rocblas_handle)ctx->blas);
   if (ctx->fom_pc) (void)hipFree(ctx->fom_pc);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 3; ++i) {
     if (ctx->aux[i]) lrbms_side_stream_release(ctx->device, i);
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
@@ -3365,11 +3366,11 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
   REQUIRE3(ctx);
   const T3& t = ctx->t;
   if (t.S_ext != t.S) return fail3(ctx, LRBMS_E_INVALID, "reduced_solve_batch: needs all subdomains on this rank");
-  if (Q < 1 || Q > 8 || N < 1 || N > 32 || nmu < 1 || nmu > 48 || !theta || !B_sys || !rhs_red || !work || !u)
-    return fail3(ctx, LRBMS_E_INVALID, "reduced_solve_batch: needs N <= 32 and nmu <= 48");
+  if (Q < 1 || Q > 8 || N < 1 || N > 32 || nmu < 1 || nmu > 64 || !theta || !B_sys || !rhs_red || !work || !u)
+    return fail3(ctx, LRBMS_E_INVALID, "reduced_solve_batch: needs N <= 32 and nmu <= 64");
   hipStream_t st = (hipStream_t)stream;
   const long S = t.S, per_q = S * 7 * N * N;
-  // Up to three groups of <= 16 parameters, each an independent CG on its own stream (the caller's and the library's two side
+  // Up to four groups of <= 16 parameters, each an independent CG on its own stream (the caller's and the library's three side
   // streams): a group's kernels are 512 small workgroups that wait on memory most of the time, so two or three groups share the
   // chip at little cost to each other.  Launches are interleaved iteration by iteration; residuals are looked at together.
   const int ng = (nmu + 15) / 16;
@@ -3382,7 +3383,7 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
     bool done;
     double rel;
     int it;
-  } g[3];
+  } g[4];
   const double* A0inv = ctx->user_pc_N == N ? ctx->user_pc : nullptr;
   for (int k = 0; k < ng; ++k) {
     Group& G = g[k];
@@ -3470,7 +3471,7 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
         std::swap(G.po, G.pn);
         ++G.it;
       }
-    double rr[3][32];
+    double rr[4][32];
     for (int k = 0; k < ng; ++k) {
       Group& G = g[k];
       if (G.done) continue;

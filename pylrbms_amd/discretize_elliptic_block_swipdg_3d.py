@@ -124,7 +124,7 @@ class ReducedDiscretization3D:
         return (u, info) if return_info else u
 
     def solve_batch(self, mus, rtol=1e-12, max_iter=20000, return_info=False):
-        """Reduced solutions for a list of parameters, <= 48 per native call: [len(mus), S, N]."""
+        """Reduced solutions for a list of parameters, <= 64 per native call: [len(mus), S, N]."""
         import torch
         eng, out = self.d.engine, []
         info = (0, 0.0)
@@ -146,8 +146,8 @@ class ReducedDiscretization3D:
                 self._pc = False
         eng.ctx.reduced_precond_use(self._pc if self._pc is not False else None)
         try:
-            for b0 in range(0, len(mus), 48):          # 48 per native call: three groups of 16 on three streams
-                th = np.stack([self.d.theta(mu) for mu in mus[b0:b0 + 48]])
+            for b0 in range(0, len(mus), 64):          # 64 per native call: four groups of 16 on four streams
+                th = np.stack([self.d.theta(mu) for mu in mus[b0:b0 + 64]])
                 ub, inf = eng.ctx.reduced_solve_batch(self.d.Q, th, self.out['B_sys'], self.out['rhs_red'], rtol=rtol, max_iter=max_iter)
                 out.append(ub.permute(2, 0, 1))
                 info = (max(info[0], inf[0]), max(info[1], inf[1]))

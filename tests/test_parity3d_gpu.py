@@ -161,14 +161,14 @@ def test_batched_reduced_solve_matches_single_solves_and_the_oracle(case):
         assert c3.rel(ub[:, :, m].cpu().numpy(), us.cpu().numpy()) < 1e-10
 
 
-def test_batched_solve_of_three_groups_on_three_streams(case):
-    """nmu > 16: groups of 16 parameters as independent CG runs on the caller's stream and the library's two side streams, launches
+def test_batched_solve_of_several_groups_on_their_streams(case):
+    """nmu > 16: groups of 16 parameters as independent CG runs on the caller's stream and the library's side streams, launches
     interleaved, each group writing its own columns of u [S, N, nmu] -- every column equals the oracle's solution, with and
-    without the prebuilt preconditioner; 17 and 48 parameters cover a one-column last group and three full groups."""
+    without the prebuilt preconditioner; 17 and 64 parameters cover a one-column last group and four full groups."""
     p, d, eng, rd, out = case['p'], case['d'], case['eng'], case['rd'], case['out']
     if p['N'] > 32:
         pytest.skip('batched solve takes N <= 32')
-    for nmu in (17, 48):
+    for nmu in (17, 64):
         mus = list(np.linspace(0.15, 1.2, nmu))
         thetas = np.stack([c3.theta_of(p, mu) for mu in mus])
         ub, (it, res) = eng.ctx.reduced_solve_batch(d.Q, thetas, out['B_sys'], out['rhs_red'], rtol=1e-13)
