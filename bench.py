@@ -230,7 +230,13 @@ def main():
     ap.add_argument('--no-config5', action='store_true', help='skip the config-5 (3D, P2) leg of the default run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-online', action='store_true')
+    ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE',
+                    help='launch-policy option of the 2D context (NativeContext.OPTIONS), e.g. --opt streams=0; measurement only')
+    ap.add_argument('--opt3', action='append', default=[], metavar='NAME=VALUE',
+                    help='the same for the 3D context (Native3DContext.OPTIONS), e.g. --opt3 serial=1')
     args = ap.parse_args()
+    opts = {k: int(v) for k, v in (o.split('=') for o in args.opt)}
+    opts3 = {k: int(v) for k, v in (o.split('=') for o in args.opt3)}
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -240,7 +246,7 @@ def main():
         import bench3d
         line = bench3d.run(args.config, args.steps, args.warmup, device_index=int(os.environ.get('LRBMS_BENCH_DEVICE', local_rank)),
                            cpu=not args.no_cpu_baseline, online=not args.no_online, world=world, rank=rank,
-                           backend=os.environ.get('LRBMS_BENCH_BACKEND', 'nccl'))
+                           backend=os.environ.get('LRBMS_BENCH_BACKEND', 'nccl'), options=opts3)
         if line is not None:
             print(json.dumps(line), flush=True)
         return
@@ -289,6 +295,8 @@ def main():
     theta_bar = np.array([c.evaluate(p['mu_bar']) for c in lam['coefficients']])
     eng = Engine(grid, lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], theta_bar,
                  device_index=local_rank)
+    for name, value in opts.items():
+        eng.ctx.set_option(name, value)
     eng.assemble()
     torch.cuda.synchronize()
     ta0, ta1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -560,7 +568,7 @@ def main():
             torch.cuda.empty_cache()
             try:
                 out['config5'] = bench3d.run('cfg5', steps=args.steps, warmup=args.warmup, device_index=local_rank, cpu=False,
-                                             online=not args.no_online)
+                                             online=not args.no_online, options=opts3)
                 if cpu5 is not None:
                     out['config5']['cpu_baseline'] = cpu5
             except Exception as exc:           # the config-3 line must not depend on the second leg: report, do not fail

@@ -76,7 +76,7 @@ def cpu_baseline3d(N):
             'os_cpu_count': os.cpu_count()}
 
 
-def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True, world=1, rank=0, backend='nccl'):
+def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True, world=1, rank=0, backend='nccl', options=None):
     """One rank of the config-5 bench.  world > 1 (launched by torch.distributed.run): the 8 x 8 x 8 subdomains are cut into
     one 3D tile per rank (strong scaling, as BASELINE.json config 5 asks for 8 GPUs), every step = one halo exchange of the
     neighbour rows (all_to_all_single over RCCL, point to point) + one pass; rank 0 returns the line, the others None."""
@@ -102,6 +102,8 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
     eng = Engine3D(p['grid'], lam['functions'], p['f'], p['lambda_bar'], p['lambda_hat'], data_degree=p['data_degree'],
                    device_index=device_index)
     setup_s = time.perf_counter() - t0
+    for name, value in (options or {}).items():
+        eng.ctx.set_option(name, value)
     eng.assemble()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -147,6 +149,12 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
         tt = torch.tensor([elapsed], dtype=torch.float64, device=V.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # the timed passes left their results in `out`: every array finite, one checksum per run on record (same seed => same value)
+    bad = [k for k, v in out.items() if not bool(torch.isfinite(v).all())]
+    if bad:
+        raise RuntimeError('config-5 pass produced non-finite values in {}'.format(bad))
+    checksum = {k: float(v.sum()) for k, v in out.items()}
+    checksum['all'] = float(sum(checksum.values()))
     eng.ctx.kernel_timing(True)
     for _ in range(steps):
         eng.project_and_estimate(V, out, work)
@@ -224,14 +232,14 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
                                       cfg['cubes_per_subdomain'], t.n, t.n_rt, Q, N),
                       'subdomains': S_total, 'N': N, 'Q': Q,
                       'parallelism': 'one rank holds every subdomain' if world == 1 else '3D subdomain tiles x{}'.format(world)},
-           'roofline': roofline, 'distributed': dist_info,
+           'roofline': roofline, 'distributed': dist_info, 'output_checksum': checksum,
            'assemble': {'ms': assemble_ms, 'value': S / (1e-3 * assemble_ms), 'unit': 'subdomains/s',
                         'host_sampling_and_upload_s': setup_s}}
     if online:
         # online phase on the same reduced model: 256 parameters in batches of 16, then their estimates one by one
         mus = np.random.default_rng(7).uniform(0.1, 1.0, size=256)
         thetas = np.stack([np.array([1.0, float(m)]) for m in mus])
-        nper = int(os.environ.get('LRBMS3_NPER', 64))      # parameters per native call (groups of 16 on the caller's + the side streams)
+        nper = 64      # parameters per native call (groups of 16 on the caller's + the side streams)
         eng.ctx.reduced_precond_use(eng.ctx.reduced_precond_build(Q, np.array([1.0, 0.55]), out['B_sys']))    # warm-up (rocSOLVER, too)
         eng.ctx.reduced_solve_batch(Q, thetas[:nper], out['B_sys'], out['rhs_red'], rtol=1e-12)
         torch.cuda.synchronize()

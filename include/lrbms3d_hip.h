@@ -68,6 +68,24 @@ int lrbms3_ctx_create(int device, lrbms3_ctx** out);
 int lrbms3_ctx_destroy(lrbms3_ctx* ctx);
 const char* lrbms3_last_error(lrbms3_ctx* ctx);
 
+/* Launch policy of the library (no numerical convention).  The library reads no environment variable: these options are the
+ * only switches; tests use them to reach every kernel path at small sizes.  2D: lrbms_ctx_set_option.
+ *   LRBMS3_OPT_KSPLIT          0 (default): workgroups per (subdomain, operator) of the projection kernels chosen from the launch
+ *                              size (1 from ~400 workgroups per kernel on, i.e. at config 5's 512 subdomains); 1 .. 8: forced
+ *                              (1 = the in-kernel epilogues, > 1 = partial tiles + k3_pg_combine)
+ *   LRBMS3_OPT_SERIAL          1: every kernel of the pass on the caller's stream (kernel statistics of a serial pass)
+ *   LRBMS3_OPT_WAVES           0 (default): 4 / 8 waves per workgroup of the projection kernels; else that many
+ *   LRBMS3_OPT_ESTIMATE_VALU   1: VALU form of the batched estimate (cross-check of the matrix-core form)
+ *   LRBMS3_OPT_SOLVE_VALU      1: VALU form of the batched solver's panel matvec (cross-check)
+ *   LRBMS3_OPT_FOM_COARSE      0: full-order solves without the coarse level whatever lrbms3_fom_coarse_space set */
+#define LRBMS3_OPT_KSPLIT 1
+#define LRBMS3_OPT_SERIAL 2
+#define LRBMS3_OPT_WAVES 3
+#define LRBMS3_OPT_ESTIMATE_VALU 4
+#define LRBMS3_OPT_SOLVE_VALU 5
+#define LRBMS3_OPT_FOM_COARSE 6
+int lrbms3_ctx_set_option(lrbms3_ctx* ctx, int32_t option, int32_t value);
+
 /* Template, tables, neighbour table nbr [S][7] (index into the S_ext ordering per slot, -1 = none, nbr[s][3] == s) and
  * phys [S_ext] (bit a set: side a lies on the physical boundary).   2D: lrbms_mesh_upload. */
 int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* desc, int32_t S, int32_t S_ext, const int32_t* nbr,

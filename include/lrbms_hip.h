@@ -228,6 +228,22 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
  *       allocated once) with :581-583 (assembled into for every lambda) would if the assembler does not zero them */
 #define LRBMS_OPT_OSWALD_ZERO_ON_SUBDOMAIN_BOUNDARY 1
 #define LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q 2
+/* Launch policy of the library (no numerical convention; every setting gives the same results up to the summation order the
+ * parity tests bound).  The library reads no environment variable: these options are the only switches.
+ *   LRBMS_OPT_STREAMS          -1 (default): the fused pass forks its small kernels over the library streams below 192
+ *                              subdomains per rank; 0: never; 1: always
+ *   LRBMS_OPT_F1_KSPLIT        0 (default): workgroups per subdomain of the dense projection kernel chosen from S; 1, 2, 4: forced
+ *   LRBMS_OPT_F1_PRODUCER_CONSUMER  1: the producer / consumer form of that kernel (the only form for N > 48) for every N
+ *   LRBMS_OPT_COARSE           coarse level of the reduced solvers' preconditioner: 1 (default) hand-written block-tridiagonal
+ *                              factorisation where the band allows it; 0: none (block-Jacobi); 2: rocSOLVER always
+ *   LRBMS_OPT_SOLVE_VALU       1: VALU form of the batched solver's panel matvec (cross-check of the matrix-core form)
+ *   LRBMS_OPT_ESTIMATE_VALU    1: VALU form of the batched estimate (dense layout only; cross-check) */
+#define LRBMS_OPT_STREAMS 3
+#define LRBMS_OPT_F1_KSPLIT 4
+#define LRBMS_OPT_F1_PRODUCER_CONSUMER 5
+#define LRBMS_OPT_COARSE 6
+#define LRBMS_OPT_SOLVE_VALU 7
+#define LRBMS_OPT_ESTIMATE_VALU 8
 int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value);
 
 /* Per-kernel device timing of the fused pass (measurement only; the reference has wall-clock prints around

@@ -546,13 +546,16 @@ class NativeContext:
                                                 c_vp(pc.data_ptr()) if pc is not None else None)
         self._check(rc, 'lrbms_reduced_precond_use')
 
-    OPTIONS = {'oswald_zero_on_subdomain_boundary': 1, 'accumulate_coupling_across_q': 2}
+    OPTIONS = {'oswald_zero_on_subdomain_boundary': 1, 'accumulate_coupling_across_q': 2,
+               # launch policy (no numerical convention): the library reads no environment variable
+               'streams': 3, 'f1_ksplit': 4, 'f1_producer_consumer': 5, 'coarse': 6, 'solve_valu': 7, 'estimate_valu': 8}
 
     def set_option(self, name, value):
-        """Switch one of the conventions the reference tree leaves open (include/lrbms_hip.h, LRBMS_OPT_*)."""
+        """Switch one of the conventions the reference tree leaves open, or the launch policy of the library
+        (include/lrbms_hip.h, LRBMS_OPT_*)."""
         if name not in self.OPTIONS:
             raise NativeError('unknown option {!r}; known: {}'.format(name, sorted(self.OPTIONS)))
-        self._check(self.lib.lrbms_ctx_set_option(self.handle, self.OPTIONS[name], 1 if value else 0), 'lrbms_ctx_set_option')
+        self._check(self.lib.lrbms_ctx_set_option(self.handle, self.OPTIONS[name], int(value)), 'lrbms_ctx_set_option')
 
     def kernel_timing(self, enable):
         """Bracket every kernel of the fused pass by HIP events on its own stream (measurement only)."""

@@ -23,6 +23,7 @@ SIGNATURES3 = {
     'lrbms3_ctx_create': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_vp)]),
     'lrbms3_ctx_destroy': (ctypes.c_int, [c_vp]),
     'lrbms3_last_error': (ctypes.c_char_p, [c_vp]),
+    'lrbms3_ctx_set_option': (ctypes.c_int, [c_vp, c_i32, c_i32]),
     'lrbms3_mesh_upload': (ctypes.c_int, [c_vp, ctypes.POINTER(MeshDesc3D), c_i32, c_i32, _P_I32, _P_I32]),
     'lrbms3_assemble_system': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'lrbms3_assemble_rhs': (ctypes.c_int, [c_vp] + [c_vp] * 7),
@@ -101,6 +102,14 @@ class Native3DContext:
 
     def _stream(self):
         return c_vp(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    OPTIONS = {'ksplit': 1, 'serial': 2, 'waves': 3, 'estimate_valu': 4, 'solve_valu': 5, 'fom_coarse': 6}
+
+    def set_option(self, name, value):
+        """Launch policy of the library (include/lrbms3d_hip.h, LRBMS3_OPT_*); the library reads no environment variable."""
+        if name not in self.OPTIONS:
+            raise NativeError('unknown option {!r} (known: {})'.format(name, sorted(self.OPTIONS)))
+        self._check(self.lib.lrbms3_ctx_set_option(self.handle, self.OPTIONS[name], int(value)), 'lrbms3_ctx_set_option')
 
     def _ptr(self, t, shape, name):
         torch = self.torch

@@ -158,10 +158,21 @@ const char* lrbms_last_error(lrbms_ctx* ctx) { return ctx ? ctx->err.c_str() : "
 
 int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value) {
   if (!ctx) return LRBMS_E_INVALID;
-  if (value != 0 && value != 1) return lrbms_fail(ctx, LRBMS_E_INVALID, "set_option: value must be 0 or 1");
+  int lo = 0, hi = 1;
+  if (option == LRBMS_OPT_STREAMS) lo = -1;
+  if (option == LRBMS_OPT_F1_KSPLIT) hi = 4;
+  if (option == LRBMS_OPT_COARSE) hi = 2;
+  if (value < lo || value > hi || (option == LRBMS_OPT_F1_KSPLIT && value == 3))
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "set_option: value out of range for this option");
   switch (option) {
     case LRBMS_OPT_OSWALD_ZERO_ON_SUBDOMAIN_BOUNDARY: ctx->t.opt_oswald_subdomain = value; break;
     case LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q: ctx->t.opt_accumulate_coupling = value; break;
+    case LRBMS_OPT_STREAMS: ctx->opt_streams = value; break;
+    case LRBMS_OPT_F1_KSPLIT: ctx->opt_f1_ksplit = value; break;
+    case LRBMS_OPT_F1_PRODUCER_CONSUMER: ctx->opt_f1_legacy = value; break;
+    case LRBMS_OPT_COARSE: ctx->opt_coarse = value; break;
+    case LRBMS_OPT_SOLVE_VALU: ctx->opt_solve_valu = value; break;
+    case LRBMS_OPT_ESTIMATE_VALU: ctx->opt_estimate_valu = value; break;
     default: return lrbms_fail(ctx, LRBMS_E_INVALID, "set_option: unknown option");
   }
   return LRBMS_OK;

@@ -2416,8 +2416,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // k_prep_side), the three thin kernels as ONE launch (k_thin) on a library stream, k_f2 and k_f3 on two more, k_f1 on
   // the caller's stream: five launches and one fork / join instead of twelve launches and two forks (config 2: 86 us of
   // host enqueue per pass for 104 us of device time before).
-  const char* env_streams0 = getenv("LRBMS_STREAMS");
-  const bool forked = env_streams0 ? env_streams0[0] != '0' : S < 192;
+  const bool forked = ctx->opt_streams >= 0 ? ctx->opt_streams != 0 : S < 192;      // LRBMS_OPT_STREAMS
   const int gy_flux = (t.nrt * N + 255) / 256, gy_vtx = (t.nv * N + 255) / 256;   // (2 - 8 items per thread instead: no faster)
   // (k_prep only there: at 1 024 subdomains it takes 182 us against 113 + 59 us for the two sweeps on their own)
   // factored layout: the three thin kernels are 256-thread workgroups and always share one launch (k_thin3: 141 us at
@@ -2455,7 +2454,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // hides the latencies each of them exposes when it runs alone (they are latency-, not throughput-bound)
   // Measured on MI355X / ROCm 7.2 (config 3 tiles): S = 128: 0.32 ms forked vs 0.41 ms serial (no kernel fills 256 CUs alone);
   // S = 256: 0.53 vs 0.51; S = 512: 0.97 vs 0.93; S = 1024: 1.92 vs 1.81 -> fork only below 192 subdomains per rank.
-  // LRBMS_STREAMS=0 / 1 overrides.
+  // LRBMS_OPT_STREAMS 0 / 1 overrides.
   const bool multi = (do_a || do_b) && forked;
   // forked: caller's stream k_f1 | aux0 k_thin (nonconformity side blocks, coupling projection, flux side factors), k_f3 |
   // aux1 k_f2.  k_f3 goes behind k_thin on library stream 0, not on a stream of its own: one join less, and k_f2 (one long
@@ -2505,7 +2504,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
         nsl = sl + 1;
       }
       F1Args a{V, A_diag, P_diag, caa, Aab, Rself, b, g0 == 0 ? rhs_red : nullptr, Q, N, S, nullptr, nullptr};
-      const bool legacy = getenv("LRBMS_F1_LEGACY") != nullptr;   // A/B: the producer / consumer form of the same kernel
+      const bool legacy = ctx->opt_f1_legacy != 0;   // LRBMS_OPT_F1_PRODUCER_CONSUMER: the producer / consumer form of the same kernel
       const bool unified = (Q == 1 || Q == 2) && one_slice && ntx <= 3 && !legacy;
       // K-split: a rank with few subdomains spreads the element range of a subdomain over up to four workgroups (k_f1u:
       // partial tiles + "last one sums in fixed order"; the producer / consumer kernel: two halves that meet by atomic
@@ -2514,19 +2513,17 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       const int nch = t.nT / EC;
       int ksplit = 1;
       if (unified) {
-        const char* env_ks = getenv("LRBMS_F1_KSPLIT");
         // (measured, one MI355X: 64 subdomains 98 / 102 us per pass split in 2 / 4, 110 unsplit; 128 subdomains 171 unsplit, 185 / 199 split)
         // (an UNEVEN two-way split at 128 subdomains -- long parts first, short parts beside the other kernels -- was measured
         // too: 160 - 190 us per pass for 28 .. 16 of the 32 chunks in the long part, against 150 unsplit)
-        const int want = env_ks ? atoi(env_ks) : (S <= 64 ? 2 : 1);
+        const int want = ctx->opt_f1_ksplit > 0 ? ctx->opt_f1_ksplit : (S <= 64 ? 2 : 1);      // LRBMS_OPT_F1_KSPLIT
         while (ksplit < want && nch % (4 * ksplit) == 0) ksplit *= 2;
         while (72 * (size_t)(t.nT / ksplit) > 56 * 1024 && nch % (4 * ksplit) == 0) ksplit *= 2;
         if (72 * (size_t)(t.nT / ksplit) > 56 * 1024)
           return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: template too large for k_f1u");
       } else {
-        const char* env_ks = getenv("LRBMS_F1_KSPLIT");
         const bool split_ok = nch % 4 == 0;
-        ksplit = split_ok && (env_ks ? env_ks[0] == '2' : 4 * S * nsl <= 256) ? 2 : 1;
+        ksplit = split_ok && (ctx->opt_f1_ksplit > 0 ? ctx->opt_f1_ksplit == 2 : 4 * S * nsl <= 256) ? 2 : 1;
       }
       if (ksplit > 1 && unified) {
         const long need = (long)S * ksplit * f1u_part_size(ntx);

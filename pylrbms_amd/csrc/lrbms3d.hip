@@ -66,6 +66,8 @@ struct lrbms3_ctx {
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   double* pg_part = nullptr;       // K-split partial results of the k3_pg kernels (library-owned, grown on demand)
   long pg_part_cap = 0;
+  // launch policy (lrbms3_ctx_set_option): the library reads no environment variable
+  int opt_ksplit = 0, opt_serial = 0, opt_waves = 0, opt_estimate_valu = 0, opt_solve_valu = 0, opt_fom_coarse = 1;
   bool side_padding = false;       // some side has fewer faces than ncf (unequal cubes per direction): padded factor rows exist
   bool ktime = false;
   struct KTimer { const char* name; hipEvent_t e0, e1; };
@@ -2922,6 +2924,24 @@ int lrbms3_ctx_destroy(lrbms3_ctx* ctx) {
 
 const char* lrbms3_last_error(lrbms3_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int lrbms3_ctx_set_option(lrbms3_ctx* ctx, int32_t option, int32_t value) {
+  if (!ctx) return LRBMS_E_INVALID;
+  int hi = 1;
+  if (option == LRBMS3_OPT_KSPLIT) hi = 8;
+  if (option == LRBMS3_OPT_WAVES) hi = 16;
+  if (value < 0 || value > hi) return fail3(ctx, LRBMS_E_INVALID, "set_option: value out of range for this option");
+  switch (option) {
+    case LRBMS3_OPT_KSPLIT: ctx->opt_ksplit = value; break;
+    case LRBMS3_OPT_SERIAL: ctx->opt_serial = value; break;
+    case LRBMS3_OPT_WAVES: ctx->opt_waves = value; break;
+    case LRBMS3_OPT_ESTIMATE_VALU: ctx->opt_estimate_valu = value; break;
+    case LRBMS3_OPT_SOLVE_VALU: ctx->opt_solve_valu = value; break;
+    case LRBMS3_OPT_FOM_COARSE: ctx->opt_fom_coarse = value; break;
+    default: return fail3(ctx, LRBMS_E_INVALID, "set_option: unknown option");
+  }
+  return LRBMS_OK;
+}
+
 int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, int32_t S_ext, const int32_t* nbr,
                        const int32_t* phys) {
   if (!ctx || !d || !nbr || !phys) return LRBMS_E_INVALID;
@@ -3089,8 +3109,7 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
   //   aux 1            node averages  ->  G_nc, side-node factors
   // (while per-kernel timing is on, everything runs on the caller's stream: overlapping kernels would stretch each other's
   // event intervals)
-  static const bool serial_env = getenv("LRBMS3_SERIAL") != nullptr;      // profiling knob: rocprofv3 kernel statistics of a serial pass
-  const bool serial = ctx->ktime || serial_env;
+  const bool serial = ctx->ktime || ctx->opt_serial != 0;      // LRBMS3_OPT_SERIAL: rocprofv3 kernel statistics of a serial pass
   hipStream_t sf = serial ? st : ctx->aux[0], sn = serial ? st : ctx->aux[1];
   HIP3(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP3(ctx, hipStreamWaitEvent(sf, ctx->ev_fork, 0));
@@ -3102,7 +3121,7 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
     HIP3(ctx, hipMemsetAsync(Xab, 0, sizeof(double) * (size_t)Q * t.S * t.nbf * N, sf));
   }
   const int tn = (N + 15) / 16, tq = (Q * N + 15) / 16;
-  static const int nw_env = getenv("LRBMS3_NW") ? atoi(getenv("LRBMS3_NW")) : 0;   // experiment knob: waves per workgroup
+  const int nw_env = ctx->opt_waves;      // LRBMS3_OPT_WAVES
   const int nw = nw_env > 0 ? nw_env : 4;
   const int nw_s = nw_env > 0 ? nw_env : 8;      // kernels with one workgroup per subdomain only: more waves each
   int bad = 0;
@@ -3120,7 +3139,7 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
   // K-split for small per-rank subdomain counts (the 4 x 4 x 4 tile of an 8-GPU run has 64): one workgroup per (subdomain,
   // operator) would leave most of the 256 CUs idle, so the element range is dealt to ksplit workgroups and k3_pg_combine sums
   // their partial results in a fixed order.  Off (ksplit = 1, no extra launch) from ~400 workgroups per kernel on.
-  static const int ks_env = getenv("LRBMS3_KSPLIT") ? atoi(getenv("LRBMS3_KSPLIT")) : 0;          // experiment knob
+  const int ks_env = ctx->opt_ksplit;      // LRBMS3_OPT_KSPLIT
   auto ksplit_of = [&](int nblocks) {
     if (ks_env > 0) return ks_env < 8 ? ks_env : 8;
     if (nblocks >= 384) return 1;
@@ -3261,7 +3280,7 @@ int lrbms3_reduced_estimate_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t
     return fail3(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: bad argument");
   const T3& t = ctx->t;
   EA a{u, G_nc, G_bb, G_rdd, G_ab, G_aa, r_fd, Rb, Yb, Dp, Xab, As, Cn, ebar, Bbb, bdiv, f2, ceps, hdiam, eta_loc};
-  static const bool est16_env = !(getenv("LRBMS3_EST16") && getenv("LRBMS3_EST16")[0] == '0');        // A/B knob
+  const bool est16_env = ctx->opt_estimate_valu == 0;      // LRBMS3_OPT_ESTIMATE_VALU
   const size_t lds16 = sizeof(double) * ((size_t)(7 * N + Q * N + t.nbf + t.nb) * EST16 + EST_NW * 6 * 16 + 4 * EST_NW * 16 + 3 * t.nvs + 1);
   if (est16_env && lds16 <= 160 * 1024 - 2048) {
     if (lds16 > 64 * 1024)
@@ -3440,7 +3459,7 @@ int lrbms3_reduced_solve_batch(lrbms3_ctx* ctx, int32_t Q, int32_t N, int32_t nm
   const int check = A0inv ? 12 : 8;    // iterations between two looks at the residuals (a host synchronisation each)
   const size_t lds_mv = sizeof(double) * (7 * N * 16 + 32 * 16), lds_up = sizeof(double) * (N * 16 + 32 * 16);
   const size_t lds_mm = sizeof(double) * (7 * 32 * 16 + 4 * (N <= 16 ? 1 : 2) * 256 + 32 * 16);
-  static const bool mfma_mv = !(getenv("LRBMS3_BMV") && getenv("LRBMS3_BMV")[0] == '0');      // A/B knob: 0 = the VALU panel matvec
+  const bool mfma_mv = ctx->opt_solve_valu == 0;      // LRBMS3_OPT_SOLVE_VALU: the VALU panel matvec
   int rc = LRBMS_OK;
   bool all_done = false;
   while (!all_done) {
@@ -3641,8 +3660,8 @@ int lrbms3_fom_solve(lrbms3_ctx* ctx, int32_t Q, const double* theta, const doub
   hipLaunchKernelGGL(k3_combine, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, nd, Q, th, A_diag, Amu);
   hipLaunchKernelGGL(k3_combine, dim3((unsigned)((ncp + 255) / 256)), dim3(256), 0, st, ncp, Q, th, A_cpl, Cmu);
   hipLaunchKernelGGL(k3f_block_inverse, dim3((t.nT + 63) / 64, S), dim3(64), 0, st, t, Amu, Dinv);
-  // ---- coarse level (LRBMS3_FOM_COARSE=0 switches it off: A/B knob)
-  static const bool coarse_env = !(getenv("LRBMS3_FOM_COARSE") && getenv("LRBMS3_FOM_COARSE")[0] == '0');
+  // ---- coarse level (LRBMS3_OPT_FOM_COARSE 0 switches it off)
+  const bool coarse_env = ctx->opt_fom_coarse != 0;
   int nc = coarse_env ? ctx->fom_nc : 0;
   if (nc > 1 && (long)nc * S > FOM_MAX_COARSE) nc = 1;       // the dense coarse inverse is capped: constants instead of P1, then none
   if ((long)nc * S > FOM_MAX_COARSE) nc = 0;

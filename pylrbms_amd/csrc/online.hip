@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) void k_bt_inverse(int S, int b, int nb, const 
 int coarse_begin(lrbms_ctx* ctx, double** A0_out, hipStream_t st) {
   *A0_out = nullptr;
   const long S = ctx->S;
-  if (getenv("LRBMS_NO_COARSE") != nullptr || S < 4 || S > 4096) return LRBMS_OK;
+  if (ctx->opt_coarse == 0 || S < 4 || S > 4096) return LRBMS_OK;      // LRBMS_OPT_COARSE
   const long need = 2 * S * S + 16 + 2 * (S + 64) * 65;     // A0, A0inv, info / flag, block factor
   if (ctx->coarse_cap < need) {
     if (ctx->coarse) (void)hipFree(ctx->coarse);
@@ -940,7 +940,7 @@ int coarse_finish(lrbms_ctx* ctx, const double** A0inv_out, hipStream_t st) {
         bw = dist > bw ? dist : bw;
       }
     }
-    if (bw <= 64 && getenv("LRBMS_COARSE_ROCSOLVER") == nullptr) {
+    if (bw <= 64 && ctx->opt_coarse != 2) {
       const int b = bw, nb = (int)((S + b - 1) / b);
       double* A0 = ctx->coarse;
       double* A0inv = A0 + S * S;
@@ -1042,7 +1042,7 @@ static int user_precond(lrbms_ctx* ctx, int N, const double** Dinv, const double
   LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
   if ((int)head[1] != N) return lrbms_fail(ctx, LRBMS_E_INVALID, "the preconditioner in use was built for another basis size");
   *Dinv = ctx->user_pc + 2;
-  if (head[0] != 0.0 && getenv("LRBMS_NO_COARSE") == nullptr) *A0inv = *Dinv + (long)ctx->S * N * N;
+  if (head[0] != 0.0 && ctx->opt_coarse != 0) *A0inv = *Dinv + (long)ctx->S * N * N;
   return LRBMS_OK;
 }
 
@@ -1668,133 +1668,211 @@ __global__ __launch_bounds__(256) void k_bcg_init(long total, int nmu, const dou
 
 }  // namespace
 
+// doubles of work per group of <= 16 parameters of the batched reduced solve: u (groups of a multi-group call solve into their
+// own [S][N][nm] array), r, z, p0, p1, y, two partial arrays, scalars
+static long reduced_batch_group_size(long S, int N) { return 6 * S * N * 16 + 2 * S * 16 + 4 * BMAX; }
+
 int64_t reduced_solve_batch_work_size(lrbms_ctx* ctx, int N, int nmu) {
   const long S = ctx->S;
-  return S * 5 * N * N + S * N * N + 5 * S * N * nmu + 2 * S * nmu + 4 * BMAX + 16;
+  return S * 5 * N * N + S * N * N + (long)((nmu + 15) / 16) * reduced_batch_group_size(S, N) + 16;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void k_bcg_scatter(long rows, int nm, int nmu, const double* __restrict__ ug, double* __restrict__ u) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * nm; i += (long)gridDim.x * blockDim.x)
+    u[(i / nm) * nmu + i % nm] = ug[i];
+}
+}  // namespace
+
+// nmu <= 64 parameters per call in groups of <= 16, each group an independent CG on its own stream (the caller's and the
+// library's three side streams), launches interleaved iteration by iteration, residuals looked at together: a group's kernels
+// are S latency-bound workgroups, so the groups share the chip at little cost to each other (config 3: 6 100 mu-solves/s with
+// one group at a time, 8 700 with three in flight).  One preconditioner per call, read-only while the groups run: the prebuilt
+// one (lrbms_reduced_precond_use) or the inverse diagonal blocks + coarse level at the mean theta of the call.
 int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const double* theta, const double* B_sys,
                                const double* rhs_red, double* work, double* u, double rtol, int max_iter, double* info,
                                hipStream_t st) {
   if (ctx->S_ext != ctx->S) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve_batch needs all subdomains on one rank");
-  if (N > 64 || nmu < 1 || nmu > BMAX || N * nmu > 256 * BCG_KMAX)
-    return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve_batch: need N <= 64, nmu <= 32, N * nmu <= 1280");
+  if (N > 64 || nmu < 1 || nmu > 64)
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve_batch: need N <= 64, nmu <= 64");
   const int S = ctx->S;
-  const long NM = (long)N * nmu, vec = (long)S * NM;
-  ThetaBatch th;
+  const int ng = (nmu + 15) / 16;
+  const long per_q = (long)S * 5 * N * N;
   QVec mean;
   for (int q = 0; q < 8; ++q) mean.v[q] = 0.0;
-  for (int m = 0; m < BMAX; ++m)
-    for (int q = 0; q < 8; ++q) {
-      const double v = (m < nmu && q < Q) ? theta[m * Q + q] : 0.0;
-      th.v[m * 8 + q] = v;
-      mean.v[q] += v / nmu;
-    }
-  double* Amu = work;                                   // blocks at the batch-mean theta (only the diagonal is inverted)
-  double* Dinv = Amu + (long)S * 5 * N * N;
-  double* r = Dinv + (long)S * N * N;
-  double* z = r + vec;
-  double* p0 = z + vec;
-  double* p1 = p0 + vec;
-  double* y = p1 + vec;
-  double* partial = y + vec;
-  double* partial2 = partial + (long)S * nmu;
-  double* scal = partial2 + (long)S * nmu;              // rz, alpha, beta, rr (BMAX each)
-  const long per_q = (long)S * 5 * N * N;
-  hipLaunchKernelGGL(k_bcg_init, dim3((unsigned)((vec + 255) / 256 > 4096 ? 4096 : (vec + 255) / 256)), dim3(256), 0, st, vec, nmu,
-                     rhs_red, u, r);
-  LRBMS_LAUNCH_CHECK(ctx);
+  for (int m = 0; m < nmu; ++m)
+    for (int q = 0; q < Q; ++q) mean.v[q] += theta[m * Q + q] / nmu;
+  double* Amu = work;                                   // blocks at the mean theta of the call (only the diagonal is inverted)
+  double* Dinv = Amu + per_q;
+  double* gwork = Dinv + (long)S * N * N;
+  const long gsize = reduced_batch_group_size(S, N);
+  struct Group {
+    int nm, m0, it;
+    ThetaBatch th;
+    double *ug, *r, *z, *pin, *pout, *y, *partial, *partial2, *scal;
+    hipStream_t st;
+    bool done;
+    double rel, rr0[16];
+  } g[4];
+  for (int k = 0; k < ng; ++k) {
+    Group& G = g[k];
+    G.m0 = 16 * k;
+    G.nm = nmu - G.m0 < 16 ? nmu - G.m0 : 16;
+    G.st = k == 0 ? st : ctx->aux[k - 1];
+    G.it = 0;
+    G.done = false;
+    G.rel = 0.0;
+    const long vec = (long)S * N * G.nm;
+    double* w = gwork + k * gsize;
+    G.ug = ng == 1 ? u : w;                             // a single group solves straight into the caller's array
+    G.r = w + (long)S * N * 16;
+    G.z = G.r + vec;
+    G.pin = G.z + vec;
+    G.pout = G.pin + vec;
+    G.y = G.pout + vec;
+    G.partial = w + 6L * S * N * 16;
+    G.partial2 = G.partial + (long)S * 16;
+    G.scal = G.partial2 + (long)S * 16;                 // rz, alpha, beta, rr (BMAX each)
+    for (int m = 0; m < BMAX; ++m)
+      for (int q = 0; q < 8; ++q) G.th.v[m * 8 + q] = (m < G.nm && q < Q) ? theta[(G.m0 + m) * Q + q] : 0.0;
+  }
+  // ---- the preconditioner of the call, on the caller's stream, before the groups fork
   const double* A0inv = nullptr;
   const double* pcD = nullptr;
   if (int rc = user_precond(ctx, N, &pcD, &A0inv, st)) return rc;
   if (pcD) {
     Dinv = const_cast<double*>(pcD);                     // prebuilt (lrbms_reduced_precond_build / _use): read only below
-  } else {                                               // block inverses and coarse level at the batch-mean theta
+  } else {
     hipLaunchKernelGGL(k_assemble_mu, dim3((unsigned)((per_q + 255) / 256 > 8192 ? 8192 : (per_q + 255) / 256)), dim3(256), 0, st,
                        per_q, Q, mean, B_sys, Amu);
     if (int rc = launch_block_inverse(ctx, (int)S, N, Amu, Dinv, 5, 2, st)) return rc;
     LRBMS_LAUNCH_CHECK(ctx);
     if (int rc = coarse_setup(ctx, N, Amu, &A0inv, st)) return rc;
   }
-  if (nmu > 16) A0inv = nullptr;                         // k_coarse_apply handles at most 16 columns
-  const size_t lds_upd = sizeof(double) * 3 * NM;
-  // matrix-core form for batches of at most 16 parameters (LRBMS_BCG_VALU=1 forces the VALU form)
+  // matrix-core form of the panel matvec and of the preconditioner (LRBMS_OPT_SOLVE_VALU forces the VALU form)
   const int kp = (N + 3) & ~3, ldb = N + ((4 - N % 8) + 8) % 8;
   const size_t bs_lds = (size_t)(N + 1) * ldb > (size_t)N * 16 ? (size_t)(N + 1) * ldb : (size_t)N * 16;   // block, later the products
   const size_t lds_mfma = sizeof(double) * ((size_t)5 * kp * 16 + bs_lds);
-  const bool use_mfma = nmu <= 16 && getenv("LRBMS_BCG_VALU") == nullptr;
+  const bool use_mfma = ctx->opt_solve_valu == 0;
   if (use_mfma && lds_mfma > 64 * 1024)
     LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
-  const size_t lds_mv = sizeof(double) * (5 * NM + (size_t)N * N + 256);
-  if (lds_mv > 64 * 1024)
+  const size_t lds_mv = sizeof(double) * (5 * (size_t)N * 16 + (size_t)N * N + 256);
+  if (!use_mfma && lds_mv > 64 * 1024)
     LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec<BCG_KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mv));
   const size_t lds_upd_mfma = sizeof(double) * ((size_t)kp * 16 + (size_t)2 * N * 16);
-  if (use_mfma)
-    hipLaunchKernelGGL(k_bcg_update_mfma, dim3(S), dim3(256), lds_upd_mfma, st, N, nmu, Dinv, scal, 1, u, r, p0, y, z, partial, partial2);
-  else
-    hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, st, N, nmu, Dinv, scal, 1, u, r, p0, y, z, partial, partial2);
-  if (A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16), dim3(1024), 0, st, S, N, nmu, A0inv, r, z, partial);
-  hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, st, S, nmu, partial, partial2, scal, 0);
-  LRBMS_LAUNCH_CHECK(ctx);
-  double host[4 * BMAX];
-  LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(host, scal, sizeof(double) * 4 * BMAX, hipMemcpyDeviceToHost, st));
-  LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  double rr0[BMAX];
-  bool all_zero = true;
-  for (int m = 0; m < nmu; ++m) {
-    rr0[m] = host[3 * BMAX + m];
-    all_zero &= rr0[m] == 0.0;
+  if (ng > 1) {
+    LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
+    for (int k = 1; k < ng; ++k) LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(g[k].st, ctx->ev_fork, 0));
   }
-  if (all_zero) {
-    if (info) { info[0] = 0; info[1] = 0.0; }
+  auto join = [&]() -> int {                             // every return below leaves the side streams joined into the caller's
+    for (int k = 1; k < ng; ++k) {
+      LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[k - 1], g[k].st));
+      LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_join[k - 1], 0));
+    }
     return LRBMS_OK;
+  };
+  auto update = [&](Group& G, int first) {
+    const size_t lds_upd = sizeof(double) * 3 * (size_t)N * G.nm;
+    if (use_mfma)
+      hipLaunchKernelGGL(k_bcg_update_mfma, dim3(S), dim3(256), lds_upd_mfma, G.st, N, G.nm, Dinv, G.scal, first, G.ug, G.r,
+                         first ? G.pin : G.pout, G.y, G.z, G.partial, G.partial2);
+    else
+      hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, G.st, N, G.nm, Dinv, G.scal, first, G.ug, G.r,
+                         first ? G.pin : G.pout, G.y, G.z, G.partial, G.partial2);
+    if (A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16), dim3(1024), 0, G.st, S, N, G.nm, A0inv, G.r, G.z, G.partial);
+    hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, G.st, S, G.nm, G.partial, G.partial2, G.scal, first ? 0 : 2);
+  };
+  double host[4][4 * BMAX];
+  for (int k = 0; k < ng; ++k) {
+    Group& G = g[k];
+    const long vec = (long)S * N * G.nm;
+    hipLaunchKernelGGL(k_bcg_init, dim3((unsigned)((vec + 255) / 256 > 4096 ? 4096 : (vec + 255) / 256)), dim3(256), 0, G.st, vec, G.nm,
+                       rhs_red, G.ug, G.r);
+    update(G, 1);
+    LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(host[k], G.scal, sizeof(double) * 4 * BMAX, hipMemcpyDeviceToHost, G.st));
   }
-  double rel = 1.0;
-  int it = 0;
+  LRBMS_LAUNCH_CHECK(ctx);
+  bool all_done = true;
+  for (int k = 0; k < ng; ++k) {
+    Group& G = g[k];
+    LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(G.st));
+    bool all_zero = true;
+    for (int m = 0; m < G.nm; ++m) {
+      G.rr0[m] = host[k][3 * BMAX + m];
+      all_zero &= G.rr0[m] == 0.0;
+    }
+    G.done = all_zero;                                   // zero right-hand side: x = 0 is the solution
+    all_done &= G.done;
+  }
   int block = 10;                                        // iterations until the next look at the residuals (see red_cg_run)
-  double* pin = p0;
-  double* pout = p1;
-  while (it < max_iter) {
-    for (int k = 0; k < block && it < max_iter; ++k, ++it) {
-      if (use_mfma)
-        hipLaunchKernelGGL(k_bcg_matvec_mfma, dim3(S), dim3(256), lds_mfma, st, S, ctx->nbr, Q, N, nmu, th, B_sys, z, pin,
-                           scal + 2 * BMAX, it == 0 ? 1 : 0, pout, y, partial);
-      else if (NM <= 768)   // three outputs per thread: fewer registers, measurably faster for the usual batch of 16
-        hipLaunchKernelGGL(k_bcg_matvec<3>, dim3(S), dim3(256), lds_mv, st, S, ctx->nbr, Q, N, nmu, th, B_sys, z, pin,
-                           scal + 2 * BMAX, it == 0 ? 1 : 0, pout, y, partial);
-      else
-        hipLaunchKernelGGL(k_bcg_matvec<BCG_KMAX>, dim3(S), dim3(256), lds_mv, st, S, ctx->nbr, Q, N, nmu, th, B_sys, z, pin,
-                           scal + 2 * BMAX, it == 0 ? 1 : 0, pout, y, partial);
-      hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, st, S, nmu, partial, (const double*)nullptr, scal, 1);
-      if (use_mfma)
-        hipLaunchKernelGGL(k_bcg_update_mfma, dim3(S), dim3(256), lds_upd_mfma, st, N, nmu, Dinv, scal, 0, u, r, pout, y, z, partial,
-                           partial2);
-      else
-        hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, st, N, nmu, Dinv, scal, 0, u, r, pout, y, z, partial, partial2);
-      if (A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16), dim3(1024), 0, st, S, N, nmu, A0inv, r, z, partial);
-      hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, st, S, nmu, partial, partial2, scal, 2);
-      double* tmp = pin; pin = pout; pout = tmp;
-    }
+  int rc = LRBMS_OK;
+  while (!all_done) {
+    for (int c = 0; c < block; ++c)
+      for (int k = 0; k < ng; ++k) {
+        Group& G = g[k];
+        if (G.done || G.it >= max_iter) continue;
+        const int first = G.it == 0 ? 1 : 0;
+        const long NM = (long)N * G.nm;
+        if (use_mfma)
+          hipLaunchKernelGGL(k_bcg_matvec_mfma, dim3(S), dim3(256), lds_mfma, G.st, S, ctx->nbr, Q, N, G.nm, G.th, B_sys, G.z, G.pin,
+                             G.scal + 2 * BMAX, first, G.pout, G.y, G.partial);
+        else if (NM <= 768)   // three outputs per thread: fewer registers, measurably faster for the usual batch of 16
+          hipLaunchKernelGGL(k_bcg_matvec<3>, dim3(S), dim3(256), lds_mv, G.st, S, ctx->nbr, Q, N, G.nm, G.th, B_sys, G.z, G.pin,
+                             G.scal + 2 * BMAX, first, G.pout, G.y, G.partial);
+        else
+          hipLaunchKernelGGL(k_bcg_matvec<BCG_KMAX>, dim3(S), dim3(256), lds_mv, G.st, S, ctx->nbr, Q, N, G.nm, G.th, B_sys, G.z, G.pin,
+                             G.scal + 2 * BMAX, first, G.pout, G.y, G.partial);
+        hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, G.st, S, G.nm, G.partial, (const double*)nullptr, G.scal, 1);
+        update(G, 0);
+        double* tmp = G.pin; G.pin = G.pout; G.pout = tmp;
+        ++G.it;
+      }
     LRBMS_LAUNCH_CHECK(ctx);
-    LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(host, scal, sizeof(double) * 4 * BMAX, hipMemcpyDeviceToHost, st));
-    LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    rel = 0.0;
-    for (int m = 0; m < nmu; ++m) {
-      const double rm = rr0[m] > 0.0 ? sqrt(host[3 * BMAX + m] / rr0[m]) : 0.0;
-      if (!(rm == rm)) return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve_batch: NaN residual (system not SPD?)");
-      rel = rm > rel ? rm : rel;
+    for (int k = 0; k < ng; ++k)
+      if (!g[k].done)
+        LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(host[k], g[k].scal, sizeof(double) * 4 * BMAX, hipMemcpyDeviceToHost, g[k].st));
+    all_done = true;
+    double need_max = 0.0;
+    for (int k = 0; k < ng; ++k) {
+      Group& G = g[k];
+      if (G.done) continue;
+      LRBMS_HIP_CHECK(ctx, hipStreamSynchronize(G.st));
+      G.rel = 0.0;
+      for (int m = 0; m < G.nm; ++m) {
+        const double rm = G.rr0[m] > 0.0 ? sqrt(host[k][3 * BMAX + m] / G.rr0[m]) : 0.0;
+        if (!(rm == rm)) rc = LRBMS_E_NOT_CONVERGED;
+        G.rel = rm > G.rel ? rm : G.rel;
+      }
+      if (G.rel <= rtol || G.it >= max_iter || rc != LRBMS_OK) {
+        G.done = true;
+        continue;
+      }
+      all_done = false;
+      // CG converges superlinearly, so the average rate so far overestimates what is left: aim a little short (a further
+      // look costs one host round trip, a wasted iteration three to four kernels)
+      const double rate = log(G.rel) / G.it;
+      double need = 10.0;
+      if (rate < 0.0) need = 0.8 * (log(rtol) - log(G.rel)) / rate;
+      need_max = need > need_max ? need : need_max;
     }
-    if (rel <= rtol) break;
-    // CG converges superlinearly, so the average rate so far overestimates what is left: aim a little short (a further
-    // look costs one host round trip, a wasted iteration three to four kernels)
-    const double rate = log(rel) / it;
-    block = 10;
-    if (rate < 0.0) {
-      const double need = 0.8 * (log(rtol) - log(rel)) / rate;
-      block = need < 2.0 ? 2 : need > 40.0 ? 40 : (int)need;
+    block = need_max < 2.0 ? 2 : need_max > 40.0 ? 40 : (int)need_max;
+  }
+  if (ng > 1)
+    for (int k = 0; k < ng; ++k) {
+      const long rows = (long)S * N;
+      hipLaunchKernelGGL(k_bcg_scatter, dim3((unsigned)((rows * g[k].nm + 255) / 256 > 4096 ? 4096 : (rows * g[k].nm + 255) / 256)),
+                         dim3(256), 0, g[k].st, rows, g[k].nm, nmu, g[k].ug, u + g[k].m0);
     }
+  LRBMS_LAUNCH_CHECK(ctx);
+  if (int jrc = join()) return jrc;
+  int it = 0;
+  double rel = 0.0;
+  for (int k = 0; k < ng; ++k) {
+    it = g[k].it > it ? g[k].it : it;
+    rel = g[k].rel > rel ? g[k].rel : rel;
   }
   if (info) { info[0] = it; info[1] = rel; }
+  if (rc != LRBMS_OK) return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve_batch: NaN residual (system not SPD?)");
   if (rel > rtol) return lrbms_fail(ctx, LRBMS_E_NOT_CONVERGED, "reduced_solve_batch: CG did not reach rtol");
   return LRBMS_OK;
 }
@@ -2198,7 +2276,7 @@ int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const d
   ThetaBatch th;
   for (int m = 0; m < BMAX; ++m)
     for (int q = 0; q < 8; ++q) th.v[m * 8 + q] = (m < nmu && q < Q) ? theta[m * Q + q] : 0.0;
-  if (Fside != nullptr || getenv("LRBMS_EST_VALU") == nullptr) {   // matrix-core form (default; the only one for the factored layout)
+  if (Fside != nullptr || ctx->opt_estimate_valu == 0) {   // matrix-core form (default; the only one for the factored layout)
     const size_t ldm = sizeof(double) * ((size_t)(((5 * N + 3) & ~3) + (Fside ? ((Q * N + 3) & ~3) + ((4 * nvs + 3) & ~3) : (5 * Q * N + 3) & ~3)) * 16 +
                                          EST_NW * 3 * 16);
     if (ldm > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");

@@ -163,7 +163,7 @@ class HaloExchange:
     ``mode='alltoall'`` (default): ``all_to_all_single`` with per-peer row splits -- every rank sends each packed row
     only to the one peer that reads it (point-to-point over xGMI, no traffic to non-neighbours; at the 8-GPU tile of
     config 3 this is 1.3 MB per rank instead of the 10 MB an all-gather delivers to everyone).
-    ``mode='allgather'`` (or env ``LRBMS_HALO=allgather``): the same rows through one ``all_gather_into_tensor``."""
+    ``mode='allgather'``: the same rows through one ``all_gather_into_tensor``."""
 
     def __init__(self, plan, N, device, dtype=None, group=None, mode=None, loopback=False):
         """``loopback=True`` (alltoall mode, test use): run the collective on a one-rank process group, every packed row
@@ -173,7 +173,7 @@ class HaloExchange:
         import torch
         self.torch, self.plan, self.group = torch, plan, group
         self.loopback = bool(loopback)
-        self.mode = mode or os.environ.get('LRBMS_HALO', 'alltoall')
+        self.mode = mode or 'alltoall'
         if self.mode not in ('alltoall', 'allgather'):
             raise ValueError('halo mode must be alltoall or allgather')
         dtype = dtype or torch.float64

@@ -37,6 +37,9 @@ PROBLEMS = {
     'wide_basis': ([2, 1, 1], 2, [_one, _lam1], [lambda mu: 1.0, lambda mu: mu], np.eye(3), 30, 0.4),
     # unequal cubes per direction: sides with fewer faces / nodes than the padded tables hold, odd cube counts in the traversal
     'kc_3x1x2': ([2, 2, 2], (3, 1, 2), [_one, _lam1], [lambda mu: 1.0, lambda mu: mu], KAPPA_ANISO, 4, 0.8),
+    # the template and basis size of BASELINE.json config 5 itself (k_c = 4: n = 3 840, n_bf = 192, n_b = 386; Q = 2, N = 30), on
+    # four subdomains: the kernel instantiations the benchmark times
+    'cfg5_template': ([2, 1, 2], 4, [_one, _lam1], [lambda mu: 1.0, lambda mu: mu], np.eye(3), 30, 0.45),
 }
 
 

@@ -62,6 +62,54 @@ def test_projected_operators_match_the_oracle(case):
     assert all(v < TOL for v in worst.values()), worst
 
 
+def test_every_k_split_of_the_projection_kernels_matches_the_oracle(case):
+    """LRBMS3_OPT_KSPLIT: 1 = one workgroup per (subdomain, operator) with the in-kernel epilogues (H + H^T through the LDS, mirrored
+    G_aa store, G_bb / G_rdd / r_fd epilogue, direct rhs_red) -- the path BASELINE.json config 5 runs at its 512 subdomains, which the
+    automatic choice never takes at test sizes; 2, 5, 8 = partial tiles + k3_pg_combine.  Every setting against the oracle at the
+    parity tolerance, against the automatic choice to summation-order rounding, and the estimate from the ksplit = 1 operators."""
+    import torch
+    p, d, eng, rd, out, Vd = case['p'], case['d'], case['eng'], case['rd'], case['out'], case['Vd']
+    from pylrbms_amd.engine3d import expand_factored
+    N = p['N']
+    refs = [c3.oracle_dense_blocks(p, d, rd, ii) for ii in range(d.S)]
+    work = eng.alloc_work(N)
+    try:
+        for ks in (1, 2, 5, 8):
+            eng.ctx.set_option('ksplit', ks)
+            o2 = eng.alloc_outputs(N)
+            for v in o2.values():
+                v.fill_(float('nan'))
+            eng.project_and_estimate(Vd, o2, work)
+            torch.cuda.synchronize()
+            for k in out:
+                scale = float(out[k].abs().max())
+                assert float((out[k] - o2[k]).abs().max()) <= 1e-12 * max(scale, 1e-300), (ks, k)
+            got = {k: v.cpu().numpy() for k, v in expand_factored(eng, o2, d.Q, N).items()}
+            worst = 0.0
+            for ii, ref in enumerate(refs):
+                for k in ('G_nc', 'G_bb', 'G_rdd', 'r_fd'):
+                    worst = max(worst, c3.rel(got[k][ii], ref[k]))
+                worst = max(worst, c3.rel(got['G_ab'][:, ii], ref['G_ab']), c3.rel(got['G_aa'][:, :, ii], ref['G_aa']),
+                            c3.rel(got['B_sys'][:, ii], ref['B_sys']), c3.rel(got['rhs_red'][ii], rd.rhs[ii]))
+            assert worst < TOL, (ks, worst)
+            if ks == 1:
+                u = np.random.default_rng(5).standard_normal((d.S, N))
+                th = c3.theta_of(p, p['mu'])
+                eta = eng.reduced_estimate(th, eng.ctx.from_numpy(u), o2).cpu().numpy()
+                for got_, ref_ in zip(eta, rd.local_terms([u[ii] for ii in range(d.S)], p['mu'])):
+                    assert c3.rel(got_, ref_) < 1e-10
+                us, (it, res) = eng.reduced_solve(th, o2, rtol=1e-13)
+                assert c3.rel(us.cpu().numpy(), np.stack(rd.solve(p['mu']))) < 1e-10
+                # repeated passes are bit-identical (fixed summation order)
+                o3 = eng.alloc_outputs(N)
+                eng.project_and_estimate(Vd, o3, work)
+                torch.cuda.synchronize()
+                for k in o2:
+                    assert torch.equal(o2[k], o3[k]), k
+    finally:
+        eng.ctx.set_option('ksplit', 0)
+
+
 def test_estimator_terms_match_the_oracle(case):
     p, d, eng, rd, out = case['p'], case['d'], case['eng'], case['rd'], case['out']
     rng = np.random.default_rng(5)

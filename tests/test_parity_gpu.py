@@ -187,7 +187,7 @@ def test_k_split_of_the_projection_kernel_is_order_independent(monkeypatch, shap
     V2 = eng.ctx.from_numpy(make_bases(S, n, N, seed=9))
     outs = {}
     for ks in ('1', '2', '4'):
-        monkeypatch.setenv('LRBMS_F1_KSPLIT', ks)
+        eng.ctx.set_option('f1_ksplit', int(ks))
         buf = eng.project_and_estimate(V)
         first = [x.clone() for x in buf['sys']] + [x.clone() for x in buf['grams']]
         for rep in range(4):
@@ -213,15 +213,15 @@ def test_full_size_properties_config3(monkeypatch):
     S, n, N = eng.S, eng.t.n, 40
     assert eng.ctx.fused_supported(eng.Q, N)
     V = eng.ctx.from_numpy(make_bases(S, n, N, seed=4))
-    monkeypatch.setenv('LRBMS_STREAMS', '0')
+    eng.ctx.set_option('streams', 0)
     buf = eng.project_and_estimate(V)
     serial = [x.clone() for x in buf['sys']] + [x.clone() for x in buf['grams']]
-    monkeypatch.setenv('LRBMS_STREAMS', '1')
+    eng.ctx.set_option('streams', 1)
     buf = eng.project_and_estimate(V, buf)
     forked = list(buf['sys']) + list(buf['grams'])
     for a, b in zip(serial, forked):
         assert torch.equal(a, b)
-    monkeypatch.delenv('LRBMS_STREAMS')
+    eng.ctx.set_option('streams', -1)
     # the two halves of the pass (halo-independent / halo-dependent) give the same bits as the whole
     for x in list(buf['sys']) + list(buf['grams']):
         x.fill_(float('nan'))
@@ -315,7 +315,7 @@ def test_batched_reduced_solve_matches_single_and_oracle():
 
 def test_two_level_preconditioner_and_prebuilt_form(monkeypatch):
     """The coarse level of the reduced solvers: same solutions as the oracle's dense solves with it, without it
-    (LRBMS_NO_COARSE) and with a preconditioner prebuilt at ANOTHER parameter (lrbms_reduced_precond_build / _use);
+    (LRBMS_OPT_COARSE 0) and with a preconditioner prebuilt at ANOTHER parameter (lrbms_reduced_precond_build / _use);
     fewer iterations with it; basis size mismatch of a prebuilt preconditioner falls back to per-call ones."""
     from pylrbms_amd import multiscale_problem
     from oracle.lrbms import OracleReductor
@@ -342,16 +342,16 @@ def test_two_level_preconditioner_and_prebuilt_form(monkeypatch):
         return its
 
     with_coarse = check('per-call two-level')
-    monkeypatch.setenv('LRBMS_NO_COARSE', '1')
+    eng.ctx.set_option('coarse', 0)
     jacobi_only = check('block-Jacobi only')
-    monkeypatch.delenv('LRBMS_NO_COARSE')
+    eng.ctx.set_option('coarse', 1)
     assert max(with_coarse) < min(jacobi_only)
     pc = eng.ctx.reduced_precond_build(theta_of(p, 0.55), B)
     # the hand-written block-tridiagonal coarse inverse against rocSOLVER's dense one, and against numpy on the 5-point
     # coarse matrix itself (entries (0, 0) of the combined blocks)
-    monkeypatch.setenv('LRBMS_COARSE_ROCSOLVER', '1')
+    eng.ctx.set_option('coarse', 2)
     pc_lib = eng.ctx.reduced_precond_build(theta_of(p, 0.55), B)
-    monkeypatch.delenv('LRBMS_COARSE_ROCSOLVER')
+    eng.ctx.set_option('coarse', 1)
     S = d.S
     A0inv, A0inv_lib = (x[2 + S * N * N:].reshape(S, S).cpu().numpy() for x in (pc, pc_lib))
     assert float(pc[0]) == 1.0 and float(pc_lib[0]) == 1.0

@@ -21,6 +21,8 @@ eng = Engine(p['grid'], lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p
 N = cfg['N']
 V = eng.ctx.from_numpy(make_bases_host(eng.local, eng.t.n, N))
 buf = eng.alloc_reduce_buffers(N)
+if os.environ.get('F1_PRODUCER_CONSUMER'):      # tool-side switch -> context option
+    eng.ctx.set_option('f1_producer_consumer', 1)
 for _ in range(3):
     eng.project_and_estimate(V, buf)
 torch.cuda.synchronize()
@@ -33,7 +35,7 @@ nch = eng.t.n_T // 4
 A, B = out[0, :nch].astype(np.int64), out[1, :nch].astype(np.int64)
 t0 = min(A[0, 0], B[0, 0])
 names = 'stage_start loads_issued wait_done staged barrier_passed mfma_done'
-if os.environ.get('LRBMS_F1_LEGACY'):
+if os.environ.get('F1_PRODUCER_CONSUMER'):
     print('legacy producer/consumer kernel: stamps of producer wave 0 (6) and consumer wave 4 (3: at_barrier, barrier_passed, mfma_done)')
 print('chunk | wave 0 (role A): ' + names + ' | wave 4 (role B): ' + names)
 for c in range(nch):

@@ -1,5 +1,5 @@
 """Host enqueue time vs. device time of one fused pass at a small per-rank subdomain count.
-usage: python tools/small_s.py CONFIG   (environment switches of the launcher apply: LRBMS_STREAMS, LRBMS_F1_KSPLIT)"""
+usage: python tools/small_s.py CONFIG [streams=0|1] [f1_ksplit=1|2|4]   (launch-policy options of the context)"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -12,6 +12,8 @@ p = multiscale_problem.init_grid_and_problem({'num_subdomains': cfg['num_subdoma
 lam = p['lambda']
 tb = np.array([c.evaluate(p['mu_bar']) for c in lam['coefficients']])
 eng = Engine(p['grid'], lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], tb).assemble()
+for o in sys.argv[2:]:
+    eng.ctx.set_option(o.split('=')[0], int(o.split('=')[1]))
 N = cfg['N']
 V = eng.ctx.from_numpy(bench.make_bases_host(eng.local, eng.t.n, N))
 buf = eng.alloc_reduce_buffers(N)

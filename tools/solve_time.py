@@ -1,5 +1,5 @@
 """Times the launch-bound Krylov loops on a bench config (single-parameter reduced solve, full-order solve, parabolic
-trajectories).  usage: solve_time.py PX PY N [NT]   (env LRBMS_NO_GRAPH=1: kernel-by-kernel launches)"""
+trajectories).  usage: solve_time.py PX PY N [NT]"""
 import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np
@@ -21,7 +21,7 @@ V = torch.bmm(V, LinvT).contiguous()
 buf = eng.project_and_estimate(V)
 B_sys, rhs_red, E_red, M_red = buf['sys']
 theta = d.theta(d.parse_parameter(0.5))
-tag = 'nograph' if os.environ.get('LRBMS_NO_GRAPH') else 'graph'
+tag = 'launches'
 
 
 def timed(fn, reps=3):

@@ -1,4 +1,5 @@
-"""Per-kernel timing of the 3D / P2 pass (config 5 by default): python tools/time3d.py [P] [kc] [N] [steps] [degree]."""
+"""Per-kernel timing of the 3D / P2 pass (config 5 by default): python tools/time3d.py [P] [kc] [N] [steps] [degree] [opt=value ...]
+(launch-policy options of the 3D context, e.g. waves=8 ksplit=1)."""
 import sys
 import time
 
@@ -9,6 +10,8 @@ sys.path.insert(0, '.')
 from pylrbms_amd import multiscale_problem3d  # noqa: E402
 from pylrbms_amd.engine3d import Engine3D  # noqa: E402
 
+OPTS = [a for a in sys.argv[1:] if '=' in a]
+sys.argv = [a for a in sys.argv if '=' not in a]
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 kc = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 30
@@ -18,6 +21,8 @@ t0 = time.time()
 p = multiscale_problem3d.init_grid_and_problem({'num_subdomains': (P, P, P), 'cubes_per_subdomain': kc, 'data_degree': deg})
 lam = p['lambda']
 eng = Engine3D(p['grid'], lam['functions'], p['f'], p['lambda_bar'], p['lambda_hat'], data_degree=deg)
+for o in OPTS:
+    eng.ctx.set_option(o.split('=')[0], int(o.split('=')[1]))
 t1 = time.time()
 eng.assemble()
 torch.cuda.synchronize()
