@@ -217,6 +217,9 @@ def load_pmc_traffic(config):
             continue
         if doc.get('config') == config:
             doc['file'] = os.path.relpath(path, ROOT)
+            # a profile speaks for the kernels it was taken from: same kernel sources, or the traffic figures are withheld
+            from pylrbms_amd._build import source_sha
+            doc['stale'] = doc.get('csrc_sha') != source_sha()
             return doc
     return None
 
@@ -389,10 +392,8 @@ def main():
         mus = np.random.default_rng(7).uniform(0.1, 1.0, size=256)
         coeffs = lam['coefficients']
         thetas = np.array([[c.evaluate(float(m)) for c in coeffs] for m in mus])
-        nb = min(16, 1280 // N)            # lrbms_reduced_solve_batch takes N * nmu <= 1280; measured at config 3: batches of
-                                           # 16 give 760 mu-solves/s, batches of 32 only 577 (the panel matvec turns VALU-bound)
-        ne = min(16, nb)                                                     # lrbms_reduced_estimate_batch: <= 16 per call
-        eng.ctx.reduced_solve_batch(thetas[:nb], bufo['sys'][0], bufo['sys'][1])      # warm-up (also creates the rocBLAS handle)
+        nb = 64                            # parameters per lrbms_reduced_solve_batch call: four groups of 16 on four streams, inside the library
+        eng.ctx.reduced_solve_batch(thetas[:16], bufo['sys'][0], bufo['sys'][1])      # warm-up (also creates the rocBLAS handle)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         # the two-level preconditioner of the reduced model, built ONCE at the middle of the parameter range and used by
@@ -401,19 +402,15 @@ def main():
         eng.ctx.reduced_precond_use(pc)
         torch.cuda.synchronize()
         t_pc = time.perf_counter() - t1
-        eng.ctx.reduced_solve_batches(thetas[:3 * nb], bufo['sys'][0], bufo['sys'][1], batch=nb)   # untimed: first use of the side streams
+        eng.ctx.reduced_solve_batches(thetas[:nb], bufo['sys'][0], bufo['sys'][1], per_call=nb)   # untimed: first use of the side streams
         torch.cuda.synchronize()
         t_warm = time.perf_counter() - t1 - t_pc
-        # the batches of 16 on up to three of the library's side streams at once (what rd.solve_batch does): a batch's kernels
-        # are latency-bound and share the chip (one after the other: 6 100 mu-solves/s)
-        ulist, info = eng.ctx.reduced_solve_batches(thetas, bufo['sys'][0], bufo['sys'][1], batch=nb, rtol=1e-12, concat=False)
+        ulist, info = eng.ctx.reduced_solve_batches(thetas, bufo['sys'][0], bufo['sys'][1], per_call=nb, rtol=1e-12, concat=False)
         iters, worst = info['iterations'], info['relative_residual']
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        for b, ub in enumerate(ulist):
-            for e0 in range(0, ub.shape[2], ne):                              # E1, in sub-batches of <= 16 parameters
-                eng.ctx.reduced_estimate_batch(thetas[b * nb + e0:b * nb + e0 + ne], ub[:, :, e0:e0 + ne].contiguous(), bufo['grams'],
-                                               eng.f2, eng.ceps, eng.hdiam)
+        for b, ub in enumerate(ulist):                                        # E1: the arrays of a solve call as they are (passes of 16 inside)
+            eng.ctx.reduced_estimate_batch(thetas[b * nb:b * nb + ub.shape[2]], ub, bufo['grams'], eng.f2, eng.ceps, eng.hdiam)
         torch.cuda.synchronize()
         t_est = time.perf_counter() - t2
         dt = time.perf_counter() - t1 - t_warm
@@ -421,8 +418,9 @@ def main():
         online = {'metric': 'online reduced solves (O1)', 'value': len(mus) / (dt - t_est), 'unit': 'mu-solves/s',
                   'solve_plus_estimate_per_s': len(mus) / dt, 'estimates_per_s': len(mus) / t_est, 'parameters': len(mus),
                   'batch': nb, 'reduced_dim': S_total * N, 'cg_iterations_max': iters, 'relative_residual_max': worst,
-                  'preconditioner_build_ms': 1e3 * t_pc, 'batches_in_flight': 3,
-                  'solver': 'PCG on the block-sparse reduced system, rtol 1e-12, preconditioner = inverse diagonal blocks + coarse '
+                  'preconditioner_build_ms': 1e3 * t_pc, 'groups_in_flight': 4,
+                  'solver': 'PCG on the block-sparse reduced system, rtol 1e-12, 64 parameters per call (four groups of 16 on four streams, '
+                            'inside the library), preconditioner = inverse diagonal blocks + coarse '
                             'level on the first local basis vectors, built once at mu = 0.55 (time included in value); '
                             'estimates: lrbms_reduced_estimate_batch (local nc / r / df terms of every subdomain)'}
 
@@ -498,6 +496,10 @@ def main():
         compulsory = inputs + outputs
         ach_gbs = compulsory / dev_s_per_step / 1e9
         pmc = load_pmc_traffic(args.config) if world == 1 else None
+        pmc_note = None
+        if pmc and pmc['stale']:
+            pmc_note = '{} (withheld: the kernel sources changed since that profile was taken)'.format(pmc['file'])
+            pmc = None
         traffic = pmc['per_pass_bytes'] if pmc else None
         roofline = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': ach_gbs / PEAK_HBM_GBS, 'traffic': traffic,
@@ -505,7 +507,7 @@ def main():
                     'compulsory_bytes': compulsory, 'compulsory_input_bytes': inputs, 'compulsory_output_bytes': outputs,
                     'traffic_over_compulsory': (traffic / compulsory) if traffic else None,
                     'traffic_frac_of_peak': (traffic / dev_s_per_step / 1e9 / PEAK_HBM_GBS) if traffic else None,
-                    'traffic_source': pmc['file'] if pmc else None,
+                    'traffic_source': pmc['file'] if pmc else pmc_note,
                     'kernel': 'fused project+estimate pass: k_flux_compact, k_vertex_avg, k_f1, k_f2, k_f3, k_thin3 (= k_coupling, '
                               'k_thin_rt, k_thin_ncf in one launch) (HIP events around the pass on the launch stream)',
                     'device_ms_per_step': 1e3 * dev_s_per_step,

@@ -306,8 +306,9 @@ int lrbms_reduced_estimate(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* t
                            const double* G_ab, const double* G_aa, const double* f2, const double* ceps, double hdiam,
                            double* eta_loc, void* stream);
 
-/* E1, throughput form: nmu <= 16 reduced solutions at once; theta [nmu][Q] host, u [S_ext][N][nmu] (mu fastest, the
- * layout lrbms_reduced_solve_batch returns), eta_loc [3][S][nmu].  Every projected operator is read once per batch. */
+/* E1, throughput form: nmu <= 64 reduced solutions per call, in passes of <= 16 over the same arrays; theta [nmu][Q] host,
+ * u [S_ext][N][nmu] (mu fastest, the layout lrbms_reduced_solve_batch returns), eta_loc [3][S][nmu].  Every projected
+ * operator is read once per pass of 16. */
 int lrbms_reduced_estimate_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* u,
                                  const double* G_nc, const double* r_fd, const double* G_rdd, const double* G_bb,
                                  const double* G_ab, const double* G_aa, const double* f2, const double* ceps, double hdiam,
@@ -323,9 +324,13 @@ int lrbms_reduced_solve(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* thet
                         const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
                         void* stream);
 
-/* O1, throughput form: nmu <= 32 parameters at once (N * nmu <= 1280).  theta [nmu][Q] host; u [S][N][nmu] (mu fastest).
- * Every projected block is read once per CG iteration for the whole batch; one block-Jacobi preconditioner at the
- * batch-mean theta.  info[0] = iterations, info[1] = worst relative residual. */
+/* O1, throughput form: nmu <= 64 parameters per call, in groups of <= 16.  theta [nmu][Q] host; u [S][N][nmu] (mu fastest).
+ * Inside a group every projected block is read once per CG iteration for all its parameters (panel matvec on the matrix
+ * cores), independent CG scalars per parameter.  The (<= 4) groups run on the caller's stream and the library's three side
+ * streams, launches interleaved iteration by iteration: their kernels are latency-bound and share the chip (the host does
+ * not thread: one call, one caller -- a ctx is not re-entrant).  One preconditioner per call: the prebuilt one
+ * (lrbms_reduced_precond_use) or inverse diagonal blocks + coarse level at the mean theta of the call.
+ * info[0] = iterations (of the slowest group), info[1] = worst relative residual. */
 int64_t lrbms_reduced_solve_batch_work_size(lrbms_ctx* ctx, int32_t N, int32_t nmu);
 int lrbms_reduced_solve_batch(lrbms_ctx* ctx, int32_t Q, int32_t N, int32_t nmu, const double* theta, const double* B_sys,
                               const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,

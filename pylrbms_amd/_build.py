@@ -18,6 +18,19 @@ def _hipcc():
     raise RuntimeError('hipcc not found')
 
 
+def source_sha():
+    """sha256 over the kernel sources and the two headers, in a fixed order: the identity of the build a profile was taken from
+    (tools/pmc_traffic.py records it, bench.py reports measured HBM traffic only for the same sources)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.h'))]
+    files += [os.path.join(HERE, '..', 'include', 'lrbms_hip.h'), os.path.join(HERE, '..', 'include', 'lrbms3d_hip.h')]
+    for f in files:
+        with open(f, 'rb') as fh:
+            h.update(os.path.basename(f).encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

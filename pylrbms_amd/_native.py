@@ -481,45 +481,17 @@ class NativeContext:
         self._check(rc, 'lrbms_reduced_solve_batch')
         return u, {'iterations': int(info[0]), 'relative_residual': float(info[1])}
 
-    def reduced_solve_batches(self, thetas, B_sys, rhs_red, batch=16, rtol=1e-13, max_iter=20000, streams=3, concat=True):
-        """Parameter sweep: thetas [nmu, Q] for any nmu -> u [S, N, nmu] (``concat=False``: the list of per-batch arrays
-        [S, N, <= batch], no copy), info.  The batches of ``batch`` parameters are dealt to
-        ``streams`` host threads, each issuing its ``lrbms_reduced_solve_batch`` calls on one of the library's side streams (the
-        call synchronises only its own stream, and ctypes drops the GIL): a batch's kernels are latency-bound, so two or three
-        independent batches share the chip -- 6 100 -> 8 700 mu-solves/s at config 3, bit-identical results."""
-        import threading
+    def reduced_solve_batches(self, thetas, B_sys, rhs_red, per_call=64, rtol=1e-13, max_iter=20000, concat=True):
+        """Parameter sweep: thetas [nmu, Q] for any nmu -> u [S, N, nmu] (``concat=False``: the list of per-call arrays
+        [S, N, <= per_call], no copy), info.  ``lrbms_reduced_solve_batch`` takes up to 64 parameters per call and runs them as
+        (<= 4) groups of 16 on the caller's stream and the library's side streams itself -- no host threads, one caller per
+        context (include/lrbms_hip.h: a ctx is not re-entrant)."""
         torch = self.torch
         th = np.ascontiguousarray(thetas, dtype=np.float64)
-        chunks = [th[b0:b0 + batch] for b0 in range(0, th.shape[0], batch)]
-        nthreads = max(1, min(int(streams), 3, len(chunks)))
-        pc = getattr(self, '_pc_in_use', None)
-        if pc is None or int(pc._lrbms_N) != int(B_sys.shape[3]):
-            nthreads = 1          # without a prebuilt preconditioner every call builds its coarse level in scratch the context owns
-        if nthreads == 1:
-            res = [self.reduced_solve_batch(c, B_sys, rhs_red, rtol=rtol, max_iter=max_iter) for c in chunks]
-        else:
-            main = torch.cuda.current_stream(self.device)
-            ready = torch.cuda.Event()
-            ready.record(main)                                   # inputs written on the caller's stream
-            res, errors = [None] * len(chunks), []
-
-            def worker(k):
-                try:
-                    side = self.aux_stream(k)
-                    side.wait_event(ready)
-                    with torch.cuda.stream(side):
-                        for b in range(k, len(chunks), nthreads):
-                            res[b] = self.reduced_solve_batch(chunks[b], B_sys, rhs_red, rtol=rtol, max_iter=max_iter)
-                            res[b][0].record_stream(main)        # consumed (and freed) on the caller's stream
-                except Exception as exc:                         # re-raised in the calling thread
-                    errors.append(exc)
-            threads = [threading.Thread(target=worker, args=(k,)) for k in range(nthreads)]
-            for t_ in threads:
-                t_.start()
-            for t_ in threads:
-                t_.join()
-            if errors:
-                raise errors[0]
+        per_call = max(1, min(int(per_call), 64))
+        work = self.empty(int(self.lib.lrbms_reduced_solve_batch_work_size(self.handle, int(B_sys.shape[3]), min(per_call, th.shape[0]))))
+        res = [self.reduced_solve_batch(th[b0:b0 + per_call], B_sys, rhs_red, rtol=rtol, max_iter=max_iter, work=work)
+               for b0 in range(0, th.shape[0], per_call)]
         if concat:
             u = torch.cat([r[0] for r in res], dim=2) if len(res) > 1 else res[0][0]
         else:

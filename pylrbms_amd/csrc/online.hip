@@ -1910,7 +1910,8 @@ __global__ __launch_bounds__(256) void k_reduced_estimate_batch(int S, const int
                                                                 const double* __restrict__ G_rdd, const double* __restrict__ G_bb,
                                                                 const double* __restrict__ G_ab, const double* __restrict__ G_aa,
                                                                 const double* __restrict__ f2, const double* __restrict__ ceps,
-                                                                double hdiam, double* __restrict__ eta_loc) {
+                                                                double hdiam, double* __restrict__ eta_loc, int ldu, int m0) {
+  // (u, eta_loc: arrays of ldu columns; this launch handles the nmu <= 16 columns from m0 on)
   extern __shared__ double lds[];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = 5 * N, QN = Q * N, C = 5 * QN;
@@ -1921,7 +1922,7 @@ __global__ __launch_bounds__(256) void k_reduced_estimate_batch(int S, const int
   for (int i = tid; i < W * nmu; i += 256) {
     const int row = i / nmu, m = i - row * nmu, slot = row / N, j = row - slot * N;
     const int s2 = nbr[s * 5 + slot];
-    const double val = s2 >= 0 ? u[((long)s2 * N + j) * nmu + m] : 0.0;
+    const double val = s2 >= 0 ? u[((long)s2 * N + j) * ldu + m0 + m] : 0.0;
     uo[i] = val;
     for (int q = 0; q < Q; ++q) ur[((slot * Q + q) * N + j) * nmu + m] = th.v[m * 8 + q] * val;
   }
@@ -1985,9 +1986,9 @@ __global__ __launch_bounds__(256) void k_reduced_estimate_batch(int S, const int
       rr += red[(w * 3 + 1) * EB + tid];
       df += red[(w * 3 + 2) * EB + tid];
     }
-    eta_loc[((long)0 * S + s) * nmu + tid] = nc;
-    eta_loc[((long)1 * S + s) * nmu + tid] = (f2[s] + rr) * ((1.0 / (pi * pi)) / ceps[s]) * hdiam * hdiam;   // estimators.py:88-91
-    eta_loc[((long)2 * S + s) * nmu + tid] = df;
+    eta_loc[((long)0 * S + s) * ldu + m0 + tid] = nc;
+    eta_loc[((long)1 * S + s) * ldu + m0 + tid] = (f2[s] + rr) * ((1.0 / (pi * pi)) / ceps[s]) * hdiam * hdiam;   // estimators.py:88-91
+    eta_loc[((long)2 * S + s) * ldu + m0 + tid] = df;
   }
 }
 
@@ -2114,7 +2115,7 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
                                                                      const double* __restrict__ Fside, const double* __restrict__ Fnc,
                                                                      int ncf, int nvs, const double* __restrict__ f2,
                                                                      const double* __restrict__ ceps, double hdiam,
-                                                                     double* __restrict__ eta_loc) {
+                                                                     double* __restrict__ eta_loc, int ldu, int m0) {
   extern __shared__ double lds[];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4, wave = tid >> 6;
   const int W = 5 * N, QN = Q * N, C = 5 * QN;
@@ -2132,7 +2133,7 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
   for (int i = tid; i < W * nmu; i += 64 * EST_NW) {
     const int row = i / nmu, m = i - row * nmu, slot = row / N, j = row - slot * N;
     const int s2 = nbr[s * 5 + slot];
-    const double val = s2 >= 0 ? u[((long)s2 * N + j) * nmu + m] : 0.0;
+    const double val = s2 >= 0 ? u[((long)s2 * N + j) * ldu + m0 + m] : 0.0;
     uo[row * 16 + m] = val;
     if (!factored) {
       for (int q = 0; q < Q; ++q) ur[((slot * Q + q) * N + j) * 16 + m] = th.v[m * 8 + q] * val;
@@ -2256,9 +2257,9 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
       rr += red[(w * 3 + 1) * 16 + tid];
       df += red[(w * 3 + 2) * 16 + tid];
     }
-    eta_loc[((long)0 * S + s) * nmu + tid] = nc;
-    eta_loc[((long)1 * S + s) * nmu + tid] = (f2[s] + rr) * ((1.0 / (pi * pi)) / ceps[s]) * hdiam * hdiam;   // estimators.py:88-91
-    eta_loc[((long)2 * S + s) * nmu + tid] = df;
+    eta_loc[((long)0 * S + s) * ldu + m0 + tid] = nc;
+    eta_loc[((long)1 * S + s) * ldu + m0 + tid] = (f2[s] + rr) * ((1.0 / (pi * pi)) / ceps[s]) * hdiam * hdiam;   // estimators.py:88-91
+    eta_loc[((long)2 * S + s) * ldu + m0 + tid] = df;
   }
 }
 
@@ -2270,28 +2271,32 @@ int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const d
                                   double hdiam, double* eta_loc, hipStream_t st) {
   if ((Fside != nullptr) != (Fnc != nullptr)) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: F_side and F_nc go together");
   const int nvs = ctx->t.nvx > ctx->t.nvy ? ctx->t.nvx : ctx->t.nvy;
-  if (nmu < 1 || nmu > EB) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: need 1 <= nmu <= 16");
-  const size_t lds = sizeof(double) * ((size_t)(5 * N + 5 * Q * N) * nmu + 8 * EB + 4 * 3 * EB);
-  if (lds > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
-  ThetaBatch th;
-  for (int m = 0; m < BMAX; ++m)
-    for (int q = 0; q < 8; ++q) th.v[m * 8 + q] = (m < nmu && q < Q) ? theta[m * Q + q] : 0.0;
-  if (Fside != nullptr || ctx->opt_estimate_valu == 0) {   // matrix-core form (default; the only one for the factored layout)
-    const size_t ldm = sizeof(double) * ((size_t)(((5 * N + 3) & ~3) + (Fside ? ((Q * N + 3) & ~3) + ((4 * nvs + 3) & ~3) : (5 * Q * N + 3) & ~3)) * 16 +
-                                         EST_NW * 3 * 16);
-    if (ldm > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
-    if (ldm > 64 * 1024)
-      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)ldm));
-    hipLaunchKernelGGL(k_reduced_estimate_batch_mfma, dim3(ctx->S), dim3(64 * EST_NW), ldm, st, ctx->S, ctx->nbr, Q, N, nmu, th, u, G_nc, r_fd,
-                       G_rdd, G_bb, G_ab, G_aa, Fside, Fnc, ctx->t.ncf, nvs, f2, ceps, hdiam, eta_loc);
-    LRBMS_LAUNCH_CHECK(ctx);
-    return LRBMS_OK;
+  if (nmu < 1 || nmu > 64) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: need 1 <= nmu <= 64");
+  // passes of <= 16 parameters over the same u / eta_loc arrays (column offset m0): the layout lrbms_reduced_solve_batch returns
+  // is consumed as it is, no repacking
+  for (int m0 = 0; m0 < nmu; m0 += EB) {
+    const int nm = nmu - m0 < EB ? nmu - m0 : EB;
+    const size_t lds = sizeof(double) * ((size_t)(5 * N + 5 * Q * N) * nm + 8 * EB + 4 * 3 * EB);
+    if (lds > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
+    ThetaBatch th;
+    for (int m = 0; m < BMAX; ++m)
+      for (int q = 0; q < 8; ++q) th.v[m * 8 + q] = (m < nm && q < Q) ? theta[(m0 + m) * Q + q] : 0.0;
+    if (Fside != nullptr || ctx->opt_estimate_valu == 0) {   // matrix-core form (default; the only one for the factored layout)
+      const size_t ldm = sizeof(double) * ((size_t)(((5 * N + 3) & ~3) + (Fside ? ((Q * N + 3) & ~3) + ((4 * nvs + 3) & ~3) : (5 * Q * N + 3) & ~3)) * 16 +
+                                           EST_NW * 3 * 16);
+      if (ldm > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
+      if (ldm > 64 * 1024)
+        LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)ldm));
+      hipLaunchKernelGGL(k_reduced_estimate_batch_mfma, dim3(ctx->S), dim3(64 * EST_NW), ldm, st, ctx->S, ctx->nbr, Q, N, nm, th, u, G_nc, r_fd,
+                         G_rdd, G_bb, G_ab, G_aa, Fside, Fnc, ctx->t.ncf, nvs, f2, ceps, hdiam, eta_loc, nmu, m0);
+    } else {
+      if (lds > 64 * 1024)
+        LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_reduced_estimate_batch, dim3(ctx->S), dim3(256), lds, st, ctx->S, ctx->nbr, Q, N, nm, th, u, G_nc, r_fd, G_rdd,
+                         G_bb, G_ab, G_aa, f2, ceps, hdiam, eta_loc, nmu, m0);
+    }
   }
-  if (lds > 64 * 1024)
-    LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_reduced_estimate_batch, dim3(ctx->S), dim3(256), lds, st, ctx->S, ctx->nbr, Q, N, nmu, th, u, G_nc, r_fd, G_rdd,
-                     G_bb, G_ab, G_aa, f2, ceps, hdiam, eta_loc);
   LRBMS_LAUNCH_CHECK(ctx);
   return LRBMS_OK;
 }

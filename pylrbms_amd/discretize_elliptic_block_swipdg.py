@@ -291,7 +291,7 @@ class DuneDiscretization:
         return out
 
 
-def discretize(grid_and_problem_data, solver_options=None, mpi_comm=None, device_index=None, conventions=None):
+def discretize(grid_and_problem_data, solver_options=None, mpi_comm=None, device_index=None, conventions=None, quadrature=None):
     """Reference block_swipdg.py:530-811.  Returns ``(d, data)`` with ``data`` keys as at :631-637."""
     p = grid_and_problem_data
     grid = p['grid']
@@ -315,7 +315,7 @@ def discretize(grid_and_problem_data, solver_options=None, mpi_comm=None, device
     # ``conventions``: switches for what the reference tree leaves open (include/lrbms_hip.h
     # LRBMS_OPT_*), e.g. {'oswald_zero_on_subdomain_boundary': True, 'accumulate_coupling_across_q': True}
     engine = Engine(grid, lambda_funcs, kappa, f, p['lambda_bar'], p['lambda_hat'], theta_bar, device_index=device_index,
-                    conventions=conventions)
+                    conventions=conventions, quadrature=quadrature)     # quadrature: a QuadratureSpec (default: the reference's orders)
     engine.assemble()
 
     d = DuneDiscretization(engine, p, solver_options, mpi_comm)

@@ -13,6 +13,7 @@ only (:22-23); this module gives the 3D / P2 path the same surface for the calls
 coefficient functionals, lambda_bar / lambda_hat, f, mu_bar / mu_hat).  ``d.solve(mu)`` generates snapshots (block-Jacobi CG)."""
 import numpy as np
 
+from pylrbms_amd._native import NativeError
 from pylrbms_amd.engine3d import Engine3D
 
 
@@ -42,7 +43,17 @@ class BlockDiscretization3D:
         """EstimatorBase._estimate_elliptic (estimators.py:99-112) from the local terms [3, S]."""
         nc, r, df = (np.asarray(x, dtype=np.float64) for x in eta_loc)
         a_bar, a_hat, g_bar = self.alpha(mu, self.mu_bar), self.alpha(mu, self.mu_hat), self.gamma(mu, self.mu_bar)
-        eta = (1.0 / np.sqrt(a_bar)) * (np.sqrt(g_bar) * np.linalg.norm(nc) + (1.0 / np.sqrt(a_hat)) * np.linalg.norm(r + df))
+        if getattr(self.grid, 'world_size', 1) > 1:
+            # sharded: eta_loc holds this rank's subdomains only; the two mpi_norm of estimators.py:100-101 as one all-reduce of the
+            # sums of squares (parallel.global_norms, as in 2D) -- on the device, RCCL has no host collectives
+            import torch
+            from pylrbms_amd.parallel import global_norms
+            dev = self.engine.ctx.device
+            norms = global_norms(torch.as_tensor(nc, device=dev), torch.as_tensor(r + df, device=dev), getattr(self, 'group', None))
+            n_nc, n_rdf = float(norms[0]), float(norms[1])
+        else:
+            n_nc, n_rdf = np.linalg.norm(nc), np.linalg.norm(r + df)
+        eta = (1.0 / np.sqrt(a_bar)) * (np.sqrt(g_bar) * n_nc + (1.0 / np.sqrt(a_hat)) * n_rdf)
         if not decompose:
             return eta
         return eta, (nc, r, df), (2.0 / a_bar) * (g_bar * nc ** 2 + (1.0 / a_hat) * (r + df) ** 2)
@@ -142,7 +153,9 @@ class ReducedDiscretization3D:
             mu_ref = 0.5 * (pr[0] + pr[1]) if pr is not None else self.d.mu_bar
             try:
                 self._pc = eng.ctx.reduced_precond_build(self.d.Q, self.d.theta(mu_ref), self.out['B_sys'])
-            except Exception:                  # first basis vectors that do not give an SPD coarse matrix (e.g. a zero vector)
+            except NativeError as exc:         # first basis vectors that do not give an SPD coarse matrix (e.g. a zero vector):
+                if 'not positive definite' not in str(exc):      # block-Jacobi alone; anything else (HIP errors, bad arguments) is raised
+                    raise
                 self._pc = False
         eng.ctx.reduced_precond_use(self._pc if self._pc is not False else None)
         try:

@@ -95,17 +95,15 @@ class ReducedDiscretization:
         return ReducedVectorArray(u.reshape(eng.S, self.N, 1))
 
     def solve_batch(self, mus):
-        """Parameter sweep: ``len(mus)`` reduced solutions (batches of <= 16 through ``lrbms_reduced_solve_batch``, up to three
-        batches in flight on the library's side streams);
-        returns one ``ReducedVectorArray`` with ``len(mus)`` vectors."""
+        """Parameter sweep: ``len(mus)`` reduced solutions, <= 64 per ``lrbms_reduced_solve_batch`` call (the library runs them as
+        groups of 16 on its own streams); returns one ``ReducedVectorArray`` with ``len(mus)`` vectors."""
         eng = self.d.engine
         thetas = np.array([self.d.theta(mu) for mu in mus])
-        nb = max(1, min(16, 1280 // self.N))
         # sharded: on the gathered reduced system, like solve(); every rank keeps the rows of its own subdomains
         ctx, B_sys, rhs = self._global_online() if eng.S_ext != eng.S else (eng.ctx, self.B_sys, self.rhs_red)
 
-        def run():        # batches on up to three side streams at once (NativeContext.reduced_solve_batches)
-            return ctx.reduced_solve_batches(thetas, B_sys, rhs, batch=nb)[0]
+        def run():
+            return ctx.reduced_solve_batches(thetas, B_sys, rhs)[0]
         u = self._solve_with_preconditioner(ctx, B_sys, run)
         if eng.S_ext != eng.S:
             u = u[self._torch.as_tensor(eng.local, device=u.device)]

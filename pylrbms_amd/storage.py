@@ -16,7 +16,8 @@ import json
 
 import numpy as np
 
-FORMAT_VERSION = '1'
+FORMAT_VERSION = '2'      # 2: the header also pins the quadrature orders and the open conventions the stored arrays were computed with
+CONVENTION_NAMES = ('oswald_zero_on_subdomain_boundary', 'accumulate_coupling_across_q')
 _GRAMS = ('G_nc', 'r_fd', 'G_rdd', 'G_bb', 'G_ab', 'G_aa')
 _SYS = ('B_sys', 'rhs_red', 'E_red', 'M_red')
 
@@ -26,10 +27,17 @@ def _signature(d, N):
     g, t = d.grid, eng.t
     return {'format': FORMAT_VERSION, 'K': json.dumps([int(k) for k in g.K]), 'P': json.dumps([int(p) for p in g.P]),
             'lower_left': json.dumps([float(v) for v in g.lower_left]), 'upper_right': json.dumps([float(v) for v in g.upper_right]),
-            'local_subdomains': json.dumps([int(i) for i in eng.local]), 'n': str(int(t.n)), 'Q': str(int(eng.Q)), 'N': str(int(N))}
+            'local_subdomains': json.dumps([int(i) for i in eng.local]), 'n': str(int(t.n)), 'Q': str(int(eng.Q)), 'N': str(int(N)),
+            # what the numbers mean: a reduced model stored under other quadrature orders or conventions would be combined with
+            # this discretization's f2 / c_eps / operators into inconsistent estimates -- rejected on load like a wrong grid
+            'quadrature': json.dumps({k: int(v) for k, v in sorted(eng.quadrature.as_dict().items())}),
+            'conventions': json.dumps({k: bool(eng.conventions.get(k, False)) for k in CONVENTION_NAMES})}
 
 
 def _check(meta, want, what):
+    if (meta or {}).get('format') != FORMAT_VERSION:
+        raise ValueError('{}: format version {!r}, this build reads {!r} (older files do not record the quadrature orders and '
+                         'conventions their arrays were computed with)'.format(what, (meta or {}).get('format'), FORMAT_VERSION))
     for k, v in want.items():
         if meta.get(k) != v:
             raise ValueError('{}: stored {} = {} does not match this discretization ({})'.format(what, k, meta.get(k), v))

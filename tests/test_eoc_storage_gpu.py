@@ -93,6 +93,25 @@ def test_bases_and_reduced_model_round_trip_through_disk(tmp_path):
     d_other, _ = discretize(p_other)
     with pytest.raises(ValueError):
         load_bases(d_other, fb)
+    # ... or by the same grid under another convention or other quadrature orders (the stored numbers mean something else there)
+    from pylrbms_amd.quadrature import QuadratureSpec
+    for kw in ({'conventions': {'oswald_zero_on_subdomain_boundary': True}}, {'quadrature': QuadratureSpec.uniform(5)}):
+        d_conv, _ = discretize(p, **kw)
+        with pytest.raises(ValueError, match='conventions|quadrature'):
+            load_reduced(LRBMSReductor(d_conv, order=0), fr)
+        with pytest.raises(ValueError, match='conventions|quadrature'):
+            load_bases(d_conv, fb)
+    # ... and a file without the version-2 header fields (what round 1 / 2 wrote) is refused, not silently combined
+    from safetensors import safe_open
+    from safetensors.torch import save_file
+    with safe_open(fb, framework='pt', device='cpu') as f:
+        meta, tens = dict(f.metadata()), {k: f.get_tensor(k) for k in f.keys()}
+    meta['format'] = '1'
+    del meta['quadrature'], meta['conventions']
+    f_old = str(tmp_path / 'old.safetensors')
+    save_file(tens, f_old, metadata=meta)
+    with pytest.raises(ValueError, match='format version'):
+        load_bases(d, f_old)
     # VTK output of the reconstruction (one file per vector)
     files = d.visualize(reductor.reconstruct(u), filename=str(tmp_path / 'u_red'))
     assert len(files) == 1 and open(files[0]).readline().startswith('# vtk DataFile')

@@ -313,6 +313,66 @@ def test_batched_reduced_solve_matches_single_and_oracle():
             assert np.abs(eta_s[row] - ref_row).max() < 1e-9 * scale
 
 
+@pytest.mark.parametrize('shape, N', [((4, 3), 6), ((6, 6), 40), ((3, 2), 64)])
+def test_batched_solve_of_several_groups_on_the_library_streams(shape, N):
+    """lrbms_reduced_solve_batch with nmu > 16: groups of 16 parameters as independent CG runs on the caller's stream and the
+    library's side streams, launches interleaved, every group scattering its columns into u [S, N, nmu] -- every column equals
+    the oracle's dense solve (1e-10), with the per-call preconditioner, with a prebuilt one and with the VALU panel matvec
+    (LRBMS_OPT_SOLVE_VALU); 17 and 64 parameters cover a one-column last group and four full groups; N = 40 is the basis size of
+    config 3, N = 64 the limit.  No host threads: one call, one caller."""
+    from pylrbms_amd import multiscale_problem
+    from oracle.lrbms import OracleReductor
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(shape), 'coarse_per_subdomain': 2})
+    eng = _engine(p)
+    d = oracle_from_problem(p)
+    V = energy_orthonormalize(make_bases(d.S, d.n, N, seed=9), d)
+    buf = eng.project_and_estimate(eng.ctx.from_numpy(V))
+    B, rhs = buf['sys'][0], buf['sys'][1]
+    rd = OracleReductor(d, [V[ii] for ii in range(d.S)]).reduce()
+    for nmu in (17, 64):
+        mus = list(np.linspace(0.1, 1.0, nmu))
+        thetas = np.stack([theta_of(p, mu) for mu in mus])
+        refs = [np.stack(rd.solve(mu)) for mu in mus]
+
+        def check(tag):
+            ub, info = eng.ctx.reduced_solve_batch(thetas, B, rhs)
+            assert tuple(ub.shape) == (eng.S, N, nmu) and info['iterations'] > 0 and info['relative_residual'] <= 1e-13, tag
+            ub = ub.cpu().numpy()
+            for m in range(nmu):
+                assert np.linalg.norm(ub[:, :, m] - refs[m]) < 1e-10 * np.linalg.norm(refs[m]), (tag, nmu, m)
+            return ub
+        u0 = check('per-call preconditioner')
+        eng.ctx.reduced_precond_use(eng.ctx.reduced_precond_build(theta_of(p, 0.55), B))
+        try:
+            check('prebuilt preconditioner')
+            if nmu == 17:
+                eng.ctx.set_option('solve_valu', 1)
+                check('VALU panel matvec')
+        finally:
+            eng.ctx.set_option('solve_valu', 0)
+            eng.ctx.reduced_precond_use(None)
+        u1 = check('per-call preconditioner again')
+        assert np.array_equal(u0, u1)                  # nothing left behind in the work buffers or on the side streams
+    # the sweep wrapper: any number of parameters, 64 per call
+    mus = list(np.linspace(0.1, 1.0, 70))
+    thetas = np.stack([theta_of(p, mu) for mu in mus])
+    ub, info = eng.ctx.reduced_solve_batches(thetas, B, rhs)
+    assert tuple(ub.shape) == (eng.S, N, 70)
+    for m in (0, 63, 64, 69):
+        ref = np.stack(rd.solve(mus[m]))
+        assert np.linalg.norm(ub[:, :, m].cpu().numpy() - ref) < 1e-10 * np.linalg.norm(ref)
+    # the batched estimate takes the arrays of a 64-parameter call as they are (passes of 16 over the same arrays)
+    ub64 = ub[:, :, :64].contiguous()
+    eta64 = eng.ctx.reduced_estimate_batch(thetas[:64], ub64, buf['grams'], eng.f2, eng.ceps, eng.hdiam).cpu().numpy()
+    for m in (0, 15, 16, 40, 63):
+        um = ub64[:, :, m].contiguous()
+        one = eng.reduced_estimate(thetas[m], um, buf['grams']).cpu().numpy()
+        assert np.abs(eta64[:, :, m] - one).max() <= 1e-11 * np.abs(one).max(), m
+    from pylrbms_amd._native import NativeError
+    with pytest.raises(NativeError):
+        eng.ctx.reduced_solve_batch(np.tile(thetas[:1], (65, 1)), B, rhs)          # more than 64 per call
+
+
 def test_two_level_preconditioner_and_prebuilt_form(monkeypatch):
     """The coarse level of the reduced solvers: same solutions as the oracle's dense solves with it, without it
     (LRBMS_OPT_COARSE 0) and with a preconditioner prebuilt at ANOTHER parameter (lrbms_reduced_precond_build / _use);

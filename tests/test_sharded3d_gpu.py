@@ -38,9 +38,11 @@ def _worker(rank, world, port, ref_path, outdir):
     try:
         from pylrbms_amd.grid3d import DDSubdomainsGrid3D
         from pylrbms_amd.parallel import HaloExchange, HaloPlan, global_norms
+        from pylrbms_amd.discretize_elliptic_block_swipdg_3d import BlockDiscretization3D
         p = _problem(rank, world)
         grid = p['grid']
-        eng = _engine(p)
+        d = BlockDiscretization3D(p)
+        eng = d.engine
         n = grid.template.n
         Vg = _bases(grid.num_subdomains, n)
         V = eng.ctx.zeros(eng.S_ext, n, N)
@@ -69,22 +71,32 @@ def _worker(rank, world, port, ref_path, outdir):
         worst_eta = float(np.abs(eta - ref['eta'][:, eng.local]).max() / np.abs(ref['eta']).max())
         norms = global_norms(torch.from_numpy(eta[0]), torch.from_numpy(eta[1] + eta[2]))
         want_n = np.array([np.linalg.norm(ref['eta'][0]), np.linalg.norm(ref['eta'][1] + ref['eta'][2])])
+        # the combined estimate of the sharded discretization is the GLOBAL one (estimators.py:100-101 are mpi_norm), and the
+        # decomposition keeps this rank's local indicators
+        eta_c, _, ind = d.combine(eta, 0.4, decompose=True)
+        err_c = abs(eta_c - ref['eta_combined']) / ref['eta_combined']
+        err_i = float(np.abs(ind - ref['indicators'][eng.local]).max() / np.abs(ref['indicators']).max())
         with open(os.path.join(outdir, 'result_{}.pkl'.format(rank)), 'wb') as fh:
-            pickle.dump((worst, worst_eta, float(np.abs(norms.numpy() - want_n).max() / want_n.max()), eng.S, eng.S_ext), fh)
+            pickle.dump((worst, worst_eta, float(np.abs(norms.numpy() - want_n).max() / want_n.max()), eng.S, eng.S_ext,
+                         max(err_c, err_i)), fh)
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize('world', [2, 4])
 def test_sharded_3d_pass_matches_the_single_rank_pass(world, tmp_path):
+    from pylrbms_amd.discretize_elliptic_block_swipdg_3d import BlockDiscretization3D
     p = _problem()
-    eng = _engine(p)
+    d = BlockDiscretization3D(p)
+    eng = d.engine
     Vg = _bases(p['grid'].num_subdomains, p['grid'].template.n)
     out = eng.project_and_estimate(eng.ctx.from_numpy(Vg))
     u = np.random.default_rng(3).standard_normal((eng.S, N))
     eta = eng.reduced_estimate(np.array([1.0, 0.4]), eng.ctx.from_numpy(u), out).cpu().numpy()
     ref = {k: v.cpu().numpy() for k, v in out.items()}
-    ref.update(u=u, eta=eta)
+    eta_c, _, ind = d.combine(eta, 0.4, decompose=True)
+    ref.update(u=u, eta=eta, eta_combined=float(eta_c), indicators=ind)
+    del d
     ref_path = str(tmp_path / 'ref.pkl')
     pickle.dump(ref, open(ref_path, 'wb'))
     del eng, out
@@ -94,9 +106,9 @@ def test_sharded_3d_pass_matches_the_single_rank_pass(world, tmp_path):
     port = 29300 + (os.getpid() % 500) + world
     mp.spawn(_worker, args=(world, port, ref_path, outdir), nprocs=world, join=True)
     for r in range(world):
-        worst, worst_eta, wn, S, S_ext = pickle.load(open(os.path.join(outdir, 'result_{}.pkl'.format(r)), 'rb'))
+        worst, worst_eta, wn, S, S_ext, wc = pickle.load(open(os.path.join(outdir, 'result_{}.pkl'.format(r)), 'rb'))
         assert S_ext > S == 8 // world
-        assert worst < 1e-12 and worst_eta < 1e-11 and wn < 1e-12, (r, worst, worst_eta, wn)
+        assert worst < 1e-12 and worst_eta < 1e-11 and wn < 1e-12 and wc < 1e-11, (r, worst, worst_eta, wn, wc)
 
 
 def _solve_worker(rank, world, port, ref_path, outdir):

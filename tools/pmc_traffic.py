@@ -9,8 +9,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from pylrbms_amd._build import source_sha  # noqa: E402
 
 config, out_json = sys.argv[1], sys.argv[2]
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -41,7 +45,7 @@ for k, v in sorted(tot.items()):
 print('per pass (hot-path kernels): FETCH_SIZE {:.1f} MiB (x2 correction for wide coalesced reads on gfx950: {:.1f} MiB), '
       'WRITE_SIZE {:.1f} MiB'.format(sf, 2 * sf, sw))
 with open(out_json, 'w') as fh:
-    json.dump({'config': config, 'per_kernel': per_kernel, 'per_pass_bytes': (2 * sf + sw) * 2 ** 20,
+    json.dump({'config': config, 'csrc_sha': source_sha(), 'per_kernel': per_kernel, 'per_pass_bytes': (2 * sf + sw) * 2 ** 20,
                'fetch_correction': 'FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported',
                'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py'}, fh,
               indent=1)
