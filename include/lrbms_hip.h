@@ -197,6 +197,9 @@ int lrbms_estimator_grams(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V,
  * lrbms_fused_factored_supported for the factored one (lrbms_project_estimate_fused_factored below), which needs less
  * LDS and also takes large templates (k_c = 16).  work >= lrbms_fused_work_size doubles. */
 int lrbms_fused_supported(lrbms_ctx* ctx, int32_t Q, int32_t N);
+/* v_mfma_f64_16x16x4_f64 instructions (2 048 flops each, padding included) the dense projection kernel of the fused pass
+ * executes per subdomain for this shape under the context's launch options (measurement only: roofline of bench.py). */
+int64_t lrbms_fused_mfma_per_subdomain(lrbms_ctx* ctx, int32_t Q, int32_t N);
 int lrbms_fused_factored_supported(lrbms_ctx* ctx, int32_t Q, int32_t N);
 int64_t lrbms_fused_work_size(lrbms_ctx* ctx, int32_t Q, int32_t N);
 int lrbms_project_estimate_fused(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V, const double* F,
@@ -233,14 +236,16 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
  *   LRBMS_OPT_STREAMS          -1 (default): the fused pass forks its small kernels over the library streams below 192
  *                              subdomains per rank; 0: never; 1: always
  *   LRBMS_OPT_F1_KSPLIT        0 (default): workgroups per subdomain of the dense projection kernel chosen from S; 1, 2, 4: forced
- *   LRBMS_OPT_F1_PRODUCER_CONSUMER  1: the producer / consumer form of that kernel (the only form for N > 48) for every N
+ *   LRBMS_OPT_F1_FORM          0 (default): the leanest form of that kernel the shape allows (k_f1v: even N <= 40 at Q = 2;
+ *                              else k_f1u; N > 48 or Q > 2: k_f1); 1: the producer / consumer form k_f1 for every shape;
+ *                              2: no k_f1v (cross-check of the forms against each other)
  *   LRBMS_OPT_COARSE           coarse level of the reduced solvers' preconditioner: 1 (default) hand-written block-tridiagonal
  *                              factorisation where the band allows it; 0: none (block-Jacobi); 2: rocSOLVER always
  *   LRBMS_OPT_SOLVE_VALU       1: VALU form of the batched solver's panel matvec (cross-check of the matrix-core form)
  *   LRBMS_OPT_ESTIMATE_VALU    1: VALU form of the batched estimate (dense layout only; cross-check) */
 #define LRBMS_OPT_STREAMS 3
 #define LRBMS_OPT_F1_KSPLIT 4
-#define LRBMS_OPT_F1_PRODUCER_CONSUMER 5
+#define LRBMS_OPT_F1_FORM 5
 #define LRBMS_OPT_COARSE 6
 #define LRBMS_OPT_SOLVE_VALU 7
 #define LRBMS_OPT_ESTIMATE_VALU 8

@@ -88,6 +88,110 @@ def _producer_loops(lines):
     return out, tags
 
 
+def _regs(tok):
+    """VGPR numbers named by one operand token ('v12', 'v[12:15]'); empty for anything else."""
+    m = re.fullmatch(r'v(\d+)', tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r'v\[(\d+):(\d+)\]', tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def _operands(line):
+    body = line.split(';')[0].strip()
+    parts = body.split(None, 1)
+    if len(parts) < 2:
+        return parts[0] if parts else '', []
+    return parts[0], [t.strip() for t in re.split(r'[,\s]+', parts[1]) if t.strip()]
+
+
+def _inflight_register_hazards(lines, tags, region=None, max_states=400000):
+    """An asm-managed load writes its destination VGPRs some hundred cycles after it was issued, and the compiler does not know:
+    between the load and the ``s_waitcnt vmcnt(n)`` that completes it, no instruction the COMPILER emitted may read or write
+    those registers (a copy, a live-range split, an early use would see stale data).  Exact, path-sensitive walk
+    over the control-flow graph (basic blocks = label to label; the layout order is NOT the execution order: hipcc places the cold
+    sides of wave-uniform branches out of line): a state is the ordered list of loads in flight (loads complete in order: after
+    ``vmcnt(n)`` only the n youngest are pending), every (block, state) pair is visited once.  ``region``: the line indices of ONE
+    loop (as _producer_loops returns them) -- the walk starts at its header with nothing in flight and never leaves it; the
+    straight-line tail rounds behind the unrolled loops are copies of its rounds guarded by correlated branches (c < nchunks, ++c)
+    that a CFG walk cannot correlate, so they are not walked.  Returns a sorted list of offending instructions."""
+    inside = set(region) if region is not None else None
+    starts = sorted({0} | {i for i, ln in enumerate(lines) if re.match(r'^\.LBB\d+_\d+:', ln)})
+    label_at = {}
+    for i in starts:
+        m = re.match(r'^(\.LBB\d+_\d+):', lines[i])
+        if m:
+            label_at[m.group(1)] = i
+    nxt = {a: b for a, b in zip(starts, starts[1:] + [len(lines)])}
+    # every block once: events ('L', regs) asm load, ('W', n) wait, ('T', regs, text) compiler instruction naming VGPRs; successors
+    blocks = {}
+    for b in starts:
+        ev, succ, fall = [], [], True
+        for k in range(b, nxt[b]):
+            ln = lines[k]
+            st = ln.strip()
+            if not ln.startswith('\t') or st.startswith((';', '.')):
+                continue
+            op, toks = _operands(ln)
+            if op == 's_waitcnt':
+                m = re.search(r'vmcnt\((\d+)\)', ln)
+                if m:
+                    ev.append(('W', int(m.group(1))))
+                continue
+            if tags[k]:
+                if op.startswith('global_load') and toks:
+                    ev.append(('L', frozenset(_regs(toks[0]))))
+                continue
+            if op == 's_endpgm':
+                fall = False
+                break
+            if op == 's_branch':
+                if toks and toks[0] in label_at:
+                    succ.append(label_at[toks[0]])
+                fall = False
+                break
+            if op.startswith('s_cbranch') and toks and toks[-1] in label_at:
+                succ.append(label_at[toks[-1]])
+                continue
+            touched = frozenset().union(*[_regs(t) for t in toks]) if toks else frozenset()
+            if touched:
+                ev.append(('T', touched, st))
+        if fall and nxt[b] < len(lines):
+            succ.append(nxt[b])
+        blocks[b] = (ev, succ)
+    bad, seen = set(), set()
+    first = 0 if inside is None else max(b for b in starts if b <= min(inside))
+    work = [(first, ())]
+    while work:
+        b, state = work.pop()
+        if inside is not None and b not in inside and b != first:
+            continue
+        if (b, state) in seen:
+            continue
+        seen.add((b, state))
+        if len(seen) > max_states:
+            raise IsaCheckError('in-flight register analysis: more than {} (block, state) pairs'.format(max_states))
+        pending = list(state)
+        ev, succ = blocks[b]
+        live = frozenset().union(*pending) if pending else frozenset()
+        for e in ev:
+            if e[0] == 'W':
+                pending = pending[len(pending) - e[1]:] if e[1] else []
+                live = frozenset().union(*pending) if pending else frozenset()
+            elif e[0] == 'L':
+                pending = (pending + [e[1]])[-63:]      # vmcnt is a 6-bit counter
+                live = live | e[1]
+            elif live and e[1] & live:
+                bad.add(e[2])
+        out = tuple(pending)
+        for t in succ:
+            if (t, out) not in seen:
+                work.append((t, out))
+    return sorted(bad)
+
+
 def check_fused_isa(asm_path):
     """Raises IsaCheckError when the emitted code breaks an assumption of the asm-managed prefetch; returns a report."""
     fns = _functions(asm_path)
@@ -95,7 +199,7 @@ def check_fused_isa(asm_path):
     report, problems = [], []
     seen = 0
     for name, lines in fns.items():
-        m = re.search(r'\dk_f(1u|1|2)I((?:Li\d+E)+)E', name)
+        m = re.search(r'\dk_f(1u|1v|1|2)I((?:Li\d+E)+)E', name)
         if not m:
             continue
         kernel = 'k_f{}<{}>'.format(m.group(1), ','.join(re.findall(r'Li(\d+)E', m.group(2))))
@@ -125,9 +229,10 @@ def check_fused_isa(asm_path):
         if scratch_lines and first_asm_load is not None and max(scratch_lines) >= first_asm_load:
             problems.append('{}: scratch instruction behind the first asm-managed load (line {} >= {})'.format(
                 kernel, max(scratch_lines), first_asm_load))
+        lean = m.group(1) == '1v'      # k_f1v: ONE register set per wave, completed by an asm vmcnt(0) at the start of a stage
         uses_asm_prefetch = any(';;#ASMSTART' in ln for ln in lines) and \
             any('global_load' in ln for ln in lines if True) and \
-            any(re.search(r'^\s+s_waitcnt vmcnt\((?!0\))\d+\)\s*$', ln) for ln in lines)
+            any(re.search(r'^\s+s_waitcnt vmcnt\((?!0\))\d+\)\s*$' if not lean else r'^\s+s_waitcnt vmcnt\(0\)\s*$', ln) for ln in lines)
         loops, tags = _producer_loops(lines)
         if m.group(1) == '1' and kernel.endswith(',0>'):
             # the generic-Q instantiation of k_f1 loads with ordinary (compiler-tracked) loads: nothing to guard
@@ -138,20 +243,27 @@ def check_fused_isa(asm_path):
             continue
         seen += 1
         for idx in loops:
+            hazards = _inflight_register_hazards(lines, tags, region=idx)
+            if hazards:
+                problems.append('{}: compiler-emitted instruction touches the destination of an asm load still in flight: {}'.format(
+                    kernel, hazards[:3]))
             a, b = idx[0], idx[-1]
             asm_waits = sorted({lines[k].strip() for k in idx if tags[k] and 'vmcnt' in lines[k]})
             counts = [int(x) for w in asm_waits for x in re.findall(r'vmcnt\((\d+)\)', w)]
             own_waits = [lines[k].strip() for k in idx if not tags[k] and re.search(r's_waitcnt.*vmcnt', lines[k])]
             own_vmem = [lines[k].strip() for k in idx
                         if not tags[k] and re.match(r'\s+(global_|buffer_|scratch_|flat_)', lines[k])]
-            if not counts or min(counts) == 0:
+            if not counts or (min(counts) == 0 and not lean):
                 problems.append('{}: producer loop waits {} (expected one vmcnt(n), n > 0)'.format(kernel, asm_waits))
+            if lean and counts and max(counts) != 0:
+                problems.append('{}: staging loop waits {} (expected vmcnt(0) only)'.format(kernel, asm_waits))
             if max(counts or [0]) > 63:
                 problems.append('{}: vmcnt({}) exceeds the 6-bit counter'.format(kernel, max(counts)))
             if own_waits:
                 problems.append('{}: compiler-emitted vmcnt wait inside the producer loop: {}'.format(kernel, own_waits[:2]))
             if own_vmem:
                 problems.append('{}: compiler-emitted vector-memory instruction inside the producer loop: {}'.format(kernel, own_vmem[:2]))
+
             report.append('{}: producer loop [{}..{}] waits {}, VGPRs {}, scratch {}'.format(
                 kernel, a, b, asm_waits, md.get('vgpr_count'), md.get('private_segment_fixed_size')))
     if seen == 0:

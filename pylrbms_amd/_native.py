@@ -49,6 +49,7 @@ SIGNATURES = {
     'lrbms_estimator_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_estimator_grams': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 16),
     'lrbms_fused_supported': (ctypes.c_int, [c_vp, c_i32, c_i32]),
+    'lrbms_fused_mfma_per_subdomain': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_fused_factored_supported': (ctypes.c_int, [c_vp, c_i32, c_i32]),
     'lrbms_fused_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_project_estimate_fused': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 22),
@@ -520,7 +521,7 @@ class NativeContext:
 
     OPTIONS = {'oswald_zero_on_subdomain_boundary': 1, 'accumulate_coupling_across_q': 2,
                # launch policy (no numerical convention): the library reads no environment variable
-               'streams': 3, 'f1_ksplit': 4, 'f1_producer_consumer': 5, 'coarse': 6, 'solve_valu': 7, 'estimate_valu': 8}
+               'streams': 3, 'f1_ksplit': 4, 'f1_form': 5, 'coarse': 6, 'solve_valu': 7, 'estimate_valu': 8}
 
     def set_option(self, name, value):
         """Switch one of the conventions the reference tree leaves open, or the launch policy of the library
@@ -528,6 +529,10 @@ class NativeContext:
         if name not in self.OPTIONS:
             raise NativeError('unknown option {!r}; known: {}'.format(name, sorted(self.OPTIONS)))
         self._check(self.lib.lrbms_ctx_set_option(self.handle, self.OPTIONS[name], int(value)), 'lrbms_ctx_set_option')
+
+    def fused_mfma_per_subdomain(self, Q, N):
+        """fp64 MFMA instructions the dense projection kernel executes per subdomain (bench.py's roofline)."""
+        return int(self.lib.lrbms_fused_mfma_per_subdomain(self.handle, int(Q), int(N)))
 
     def kernel_timing(self, enable):
         """Bracket every kernel of the fused pass by HIP events on its own stream (measurement only)."""

@@ -161,7 +161,7 @@ int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value) {
   int lo = 0, hi = 1;
   if (option == LRBMS_OPT_STREAMS) lo = -1;
   if (option == LRBMS_OPT_F1_KSPLIT) hi = 4;
-  if (option == LRBMS_OPT_COARSE) hi = 2;
+  if (option == LRBMS_OPT_COARSE || option == LRBMS_OPT_F1_FORM) hi = 2;
   if (value < lo || value > hi || (option == LRBMS_OPT_F1_KSPLIT && value == 3))
     return lrbms_fail(ctx, LRBMS_E_INVALID, "set_option: value out of range for this option");
   switch (option) {
@@ -169,7 +169,7 @@ int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value) {
     case LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q: ctx->t.opt_accumulate_coupling = value; break;
     case LRBMS_OPT_STREAMS: ctx->opt_streams = value; break;
     case LRBMS_OPT_F1_KSPLIT: ctx->opt_f1_ksplit = value; break;
-    case LRBMS_OPT_F1_PRODUCER_CONSUMER: ctx->opt_f1_legacy = value; break;
+    case LRBMS_OPT_F1_FORM: ctx->opt_f1_legacy = value; break;
     case LRBMS_OPT_COARSE: ctx->opt_coarse = value; break;
     case LRBMS_OPT_SOLVE_VALU: ctx->opt_solve_valu = value; break;
     case LRBMS_OPT_ESTIMATE_VALU: ctx->opt_estimate_valu = value; break;
@@ -386,6 +386,11 @@ int lrbms_estimator_grams(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V,
   CHECK_PTR(ctx, r_fd); CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa);
   return launch_estimator_grams(ctx, Q, N, V, Wt, Rt, ebar, caa, Aab, Bbb, b, work, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa,
                                 (hipStream_t)stream);
+}
+
+int64_t lrbms_fused_mfma_per_subdomain(lrbms_ctx* ctx, int32_t Q, int32_t N) {
+  if (!ctx || !ctx->has_mesh) return -1;
+  return f1_mfma_per_subdomain(ctx, Q, N);
 }
 
 int lrbms_fused_supported(lrbms_ctx* ctx, int32_t Q, int32_t N) {

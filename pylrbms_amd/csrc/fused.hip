@@ -353,6 +353,10 @@ struct Grp {
   double* dst;
   double* dst_t;   // optional transposed copy (symmetric pair of G_aa), same strides
   long sstride;
+  // k_f1v only: LDS column of local column c of this group = cb[c / 16] + c % 16; sym: the group's operator is symmetric
+  // (only the entries row <= column are taken from the tiles, the others are their mirror images)
+  int cb[4];
+  int sym;
 };
 struct GrpTable {
   Grp g[F1_MAXG];
@@ -1285,6 +1289,514 @@ __global__ __launch_bounds__(512, 2) void k_f1u(Tmpl t, F1Args a, GrpTable gt) {
   else
     f1u_body<NTX, QP, 1>(t, a, Xs, Ys, Kl, red, &flag, grp, ng);
   if (gridDim.z == 1 && a.rhs_red != nullptr) {   // fixed-order sum over the EC role-A waves (K-split: done in f1u_body)
+    __syncthreads();
+    if (tid < a.N) {
+      double sum = 0.0;
+      for (int w = 0; w < EC; ++w) sum += red[w * 64 + tid];
+      a.rhs_red[(long)blockIdx.x * a.N + tid] = sum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F1, lean form (k_f1v; round 3).  Same workgroup shape, LDS layout, tile ownership, K-split and epilogue as k_f1u; what changed
+// is the number of non-MFMA instructions of a chunk.  On gfx950 a SIMD's time is (f64 MFMA issue) + (every other instruction of
+// its two waves) (tools/ubench/overlap64.hip), and tools/ubench/interleave64.hip shows that the vector-memory loads themselves
+// are cheap (~4 cycles per instruction and CU when all eight waves issue them in one burst; one load BETWEEN two MFMAs costs a
+// whole MFMA slot): the ~3 050 cycles a chunk of k_f1u spends outside the matrix pipe are instruction count -- 64-bit address
+// arithmetic, v_readlane broadcasts, f64 FMAs on 40 of 64 lanes, a wave-uniform liveness test in front of every MFMA.  Hence:
+//   * the mass, stiffness and right-hand-side rows ride on the apply MFMA of role A: its A operand has 16 rows, of which the
+//     stacked blocks A_q, P use 3 (Q + 1); rows 3 (Q + 1) .. hold M_T = |T|/12 (I + J), K_T and b_T (self block only, the other
+//     k read zeros), so M V, K V and b . V leave the matrix pipe with the system rows -- no v0 loads, no FMAs; the c^{qq'} K V
+//     groups are K V times a scalar that comes through the scalar cache (one v_mul per tile);
+//   * every load of the neighbours' rows has a wave-uniform base (SGPR pair) and a 32-bit lane offset: el * 24 N + lane constant;
+//     a lane owns ADJACENT basis columns (tile 2p: column 32 p + 2 l, tile 2p + 1: column 32 p + 2 l + 1), so one 16-byte load
+//     feeds two column tiles (9 -> 6 loads per element at N = 40; the permutation is undone by the LDS addresses, which are
+//     lane constants anyway);
+//   * role B reads a flux row of both components with ONE 16-byte load (lanes 0-31: component 0, lanes 32-63: component 1, two
+//     adjacent columns each) and writes its Y rows as 16-byte LDS stores: 3 + 1 loads and 6 stores per element instead of 7 and 12;
+//   * the number of column tiles per SIMD is a template parameter chosen on the host from Q N: no liveness test in the MFMA loop
+//     (at most three tiles beyond the last column multiply zeros).
+// Needs even N (adjacent-column pairs).  Everything else (odd N, N > 48 ...) runs k_f1u / k_f1.
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ inline double gload_s64(const double* base, unsigned off) {      // base: wave-uniform (SGPR pair); off: bytes
+  double v;
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+  return v;
+}
+__device__ inline d2 gload_s128(const double* base, unsigned off) {
+  d2 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+  return v;
+}
+
+constexpr int F1V_SLOTS = 16;      // most accumulator tiles one wave of k_f1v owns
+constexpr long f1v_part_size(int) { return 8L * F1V_SLOTS * 4 * 64 + 64; }
+
+// Column tiles of k_f1v ("levels": level l = the four column tiles 4 l + e of the SIMDs e = 0 .. 3).  The launcher orders the
+// columns of Y so that the tiles come in ascending order of the number of row tiles they need (see f1v_layout): a symmetric
+// group is cut into blocks of 16 columns, block j needs the row tiles 0 .. j only (the entries below the diagonal are mirror
+// images), the short last blocks of all symmetric groups are packed into shared tiles.  L1 / L2 / L3 levels need 1 / 2 / 3 row
+// tiles -- compile-time, the same for every SIMD: no liveness test in the MFMA loop and no MFMA on a dead tile
+// (N = 40, Q = 2: 17 instead of 21 MFMAs per SIMD and k-step).
+template <int L1, int L2, int L3>
+struct F1vLevels {
+  static constexpr int NL = L1 + L2 + L3;
+  static constexpr int cls(int l) { return l < L1 ? 1 : l < L1 + L2 ? 2 : 3; }
+  // role A (whose staging holds more registers) takes the first LA levels: the cheap ones
+  static constexpr int LA = NL >= 6 ? 2 : NL >= 3 ? 1 : 0;
+  static constexpr int first(int role) { return role == 0 ? 0 : LA; }
+  static constexpr int count(int role) { return role == 0 ? LA : NL - LA; }
+  static constexpr int slots_before(int role, int jt) {      // accumulator slot of (owned level jt, row tile 0)
+    int n = 0;
+    for (int k = 0; k < jt; ++k) n += cls(first(role) + k);
+    return n;
+  }
+  static constexpr int slots(int role) { return slots_before(role, count(role)); }
+};
+
+template <int NTX, int QP, int L1, int L2, int L3, int ROLE>
+__device__ __forceinline__ void f1v_body(const Tmpl& t, const F1Args& a, double* __restrict__ Xs, double* __restrict__ Ys,
+                                         double* __restrict__ red, int* __restrict__ flag, const int* __restrict__ colmap,
+                                         const Grp* grp) {
+  static_assert(QP == 1 || QP == 2, "rows of the stacked apply: 3 (Q + 3) + 1 <= 16");
+  using LV = F1vLevels<L1, L2, L3>;
+  constexpr int NTYS = LV::NL;
+  static_assert((L3 == 0 || NTX >= 3) && (L2 == 0 || NTX >= 2), "a level cannot need more row tiles than there are");
+  constexpr int LDX = padded_ld(NTX);
+  constexpr int LDY = 4 * NTYS * 16 + 16;
+  constexpr int NT = LV::count(ROLE), LV0 = LV::first(ROLE);
+  constexpr int NS = LV::slots(ROLE) > 0 ? LV::slots(ROLE) : 1;
+  static_assert(LV::slots(ROLE) <= F1V_SLOTS, "K-split partial layout");
+  constexpr int NP = QP * (QP + 1) / 2;                  // pairs q <= q' of the c^{qq'} K V groups
+  constexpr int NPAIR = NTX / 2, NSING = NTX % 2;        // 16-byte loads (two column tiles each), one 8-byte load for an odd last tile
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = uniform(tid >> 6), e = wave & 3;
+  const int N = a.N, S = a.S, QN = QP * N;
+  const int ksplit = gridDim.z;
+  const int nchunks = t.nT / EC / ksplit;
+  const int T0 = blockIdx.z * nchunks * EC;
+  // LDS column of local column c of group g
+  auto pos = [&](int g, int c) { return grp[g].cb[c >> 4] + (c & 15); };
+  // the basis column a lane holds in column tile ct of an apply operand: tile 2p: 32 p + 2 li, tile 2p + 1: 32 p + 2 li + 1 (one
+  // 16-byte load feeds both), an odd last tile: 16 ct + li; beyond N: a duplicate of a column < N (clamped loads)
+  auto colc = [&](int ct) {
+    return ct < 2 * NPAIR ? (32 * (ct >> 1) + 2 * li + 1 < N ? 32 * (ct >> 1) + 2 * li : N - 2) + (ct & 1) : (16 * ct + li < N ? 16 * ct + li : N - 1);
+  };
+  const double* Vs = (const double*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(a.V + (long)s * t.n * N) >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)(a.V + (long)s * t.n * N)));
+
+  d4 acc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  auto mfma_phase = [&](int c) {
+    const double* Xb = Xs + (c & 1) * 3 * EC * LDX;
+    const double* Yb = Ys + (c & 1) * 3 * EC * LDY;
+#pragma unroll
+    for (int kk = 0; kk < 3 * EC; kk += 4) {
+      double av[NTX];
+#pragma unroll
+      for (int i = 0; i < NTX; ++i) av[i] = Xb[(kk + lk) * LDX + i * 16 + li];
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const double bv = Yb[(kk + lk) * LDY + (4 * (LV0 + jt) + e) * 16 + li];
+#pragma unroll
+        for (int i = 0; i < LV::cls(LV0 + jt); ++i)
+          acc[LV::slots_before(ROLE, jt) + i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[LV::slots_before(ROLE, jt) + i], 0, 0, 0);
+      }
+    }
+  };
+  auto tie = [](double& v) { asm volatile("" : "+v"(v)); };
+  auto tie2 = [](d2& v) { asm volatile("" : "+v"(v)); };
+  double rhs_part[NTX];
+#pragma unroll
+  for (int ct = 0; ct < NTX; ++ct) rhs_part[ct] = 0.0;
+  constexpr int R_GRP = 3 * (QP + 2);                   // rows 0 .. R_GRP - 1: A_q V, P V, M V  (column groups 0 .. Q + 1)
+  constexpr int RRK = R_GRP / 4;                        // accumulator register that holds the three K V rows
+  constexpr int R_B = 3 * (QP + 3), RRB = R_B / 4, KQB = R_B % 4;      // row of b . V
+  static_assert((R_GRP + 2) / 4 == RRK && R_B < 16, "K rows in one accumulator register");
+
+  if constexpr (ROLE == 0) {
+    // ------------------------------------------------------------- role A: the stacked apply, X rows
+    struct Set {
+      double A[3];
+      d2 Bp[3][NPAIR > 0 ? NPAIR : 1];
+      double Bs[3];
+    };
+    const int r16 = li, kq = lk;
+    const double* ap[3];                               // per-lane source of A[r16][4 ks + kq] for the wave's first element
+    unsigned ainc = 0;                                 // its advance per chunk (bytes): the same for the three k-steps of a lane (lanes that
+                                                       // must read zeros walk through a zero table with the stride of their row)
+    int bbk[3];
+    unsigned lcp[3][NPAIR > 0 ? NPAIR : 1], lcs[3];    // lane constants of the B operand offsets (bytes)
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const int k = 4 * ks + kq, bb = k / 3, cc = k - 3 * bb;
+      bbk[ks] = bb;
+      const double* src = t.zero64;
+      unsigned stride = r16 < R_B ? 9 : r16 == R_B ? 3 : 0;
+      if (r16 < 3 * (QP + 1)) {
+        const int g = r16 / 3, i = r16 % 3;
+        src = (g < QP ? a.A_diag + ((long)g * S + s) * t.nT * 36 : a.P_diag + (long)s * t.nT * 36) + bb * 9 + i * 3 + cc;
+        stride = 36;
+      } else if (bb == 0 && r16 < R_GRP) {
+        src = t.mass9 + (r16 - 3 * (QP + 1)) * 3 + cc;
+        stride = 9;
+      } else if (bb == 0 && r16 < R_B) {
+        src = t.stiff + (r16 - R_GRP) * 3 + cc;
+        stride = 9;
+      } else if (bb == 0 && r16 == R_B) {
+        src = a.b + (long)s * t.n + cc;
+        stride = 3;
+      }
+      ap[ks] = src + (long)(T0 + e) * stride;
+      ainc = 8u * EC * stride;
+#pragma unroll
+      for (int pp = 0; pp < NPAIR; ++pp) {
+        const int col = 32 * pp + 2 * li + 1 < N ? 32 * pp + 2 * li : N - 2;
+        lcp[ks][pp] = 8u * (unsigned)(cc * N + col);
+      }
+      const int cs = 16 * (NTX - 1) + li < N ? 16 * (NTX - 1) + li : N - 1;
+      lcs[ks] = 8u * (unsigned)(cc * N + cs);
+    }
+    const unsigned rs3 = 24u * (unsigned)N;              // bytes of the three rows of an element
+    // LDS offsets (doubles) of the apply's outputs: lane (kq, r16) holds row kq + 4 rr, basis column colc(ct) of tile ct.
+    // A lane whose natural column lies beyond N holds a duplicate of a column < N (the clamped loads above), hence the SAME
+    // apply results as the lane that owns that column: it stores them to the same LDS address (a benign same-value write), and
+    // the X / Y columns >= N keep their initial zeros.  Only lanes without a row of the kind being stored need a dump slot.
+    int xoff[NTX], yoff[4][NTX], koff[NP][NTX];
+    const int dump = (3 * e) * LDY + 4 * NTYS * 16 + r16;
+    const int rk = kq + 4 * RRK - R_GRP;                 // 0 .. 2 on the lanes that hold a K V row
+    const bool krow = rk >= 0 && rk < 3;
+#pragma unroll
+    for (int ct = 0; ct < NTX; ++ct) {
+      const int col = colc(ct);
+      xoff[ct] = (3 * e + (kq < 3 ? kq : 0)) * LDX + col;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = kq + 4 * rr;
+        yoff[rr][ct] = r < R_GRP ? (3 * e + r % 3) * LDY + pos(r / 3, col) : dump;
+      }
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) koff[pr][ct] = (3 * e + (krow ? rk : 0)) * LDY + pos(QP + 2 + pr, col);
+    }
+    const cint_p nbc = (cint_p)t.nb_elem;
+    struct Sc {
+      int nb[3];
+      double cc[NP];
+    };
+    auto load_sc = [&](int T, Sc& x) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) x.nb[f] = nbc[T * 3 + f];
+      int pr = 0;
+#pragma unroll
+      for (int q = 0; q < QP; ++q)
+#pragma unroll
+        for (int q2 = q; q2 < QP; ++q2) x.cc[pr++] = ((cdbl_p)(a.caa + ((long)(q * QP + q2) * S + s) * t.nT))[T];
+    };
+    auto load_set = [&](int T, const Sc& sc, Set& x) {
+      // a face without an in-subdomain neighbour has an all-zero block: its rows may be any finite values (the element's own)
+      unsigned eo[4];
+      eo[0] = (unsigned)T * rs3;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) eo[1 + f] = (unsigned)(sc.nb[f] >= 0 ? sc.nb[f] : T) * rs3;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) x.A[ks] = gload_f64(ap[ks]);
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const unsigned eoff = bbk[ks] == 0 ? eo[0] : bbk[ks] == 1 ? eo[1] : bbk[ks] == 2 ? eo[2] : eo[3];
+#pragma unroll
+        for (int pp = 0; pp < NPAIR; ++pp) x.Bp[ks][pp] = gload_s128(Vs, eoff + lcp[ks][pp]);
+        if (NSING) x.Bs[ks] = gload_s64(Vs, eoff + lcs[ks]);
+      }
+    };
+    auto tie_set = [&](Set& x) {
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        tie(x.A[ks]);
+#pragma unroll
+        for (int pp = 0; pp < NPAIR; ++pp) tie2(x.Bp[ks][pp]);
+        if (NSING) tie(x.Bs[ks]);
+      }
+    };
+    auto bop = [&](const Set& x, int ks, int ct) { return ct < 2 * NPAIR ? x.Bp[ks][ct >> 1][ct & 1] : x.Bs[ks]; };
+    // ONE register set: stage c waits for it, consumes it (apply MFMAs, stores) and then requests the rows of chunk c + 1 into
+    // the same registers -- they land during the MFMA phase in between (interleave64: a burst of loads is cheap, and the second
+    // set of the ping-pong form cost 24 VGPRs that this role does not have).  The element's scalars (neighbours for the address
+    // arithmetic of the loads, c^{qq'}) are requested at the START of the previous stage: sc_nxt is read at its end and in the next.
+    auto stage = [&](int c, Set& cur, const Sc& sc_cur, Sc& sc_nxt) {
+      const int T = T0 + c * EC + e;               // wave-uniform element
+      const bool more = c + 1 < nchunks;
+      double* Xb = Xs + (c & 1) * 3 * EC * LDX;
+      double* Yb = Ys + (c & 1) * 3 * EC * LDY;
+      if (e == 0) F1_STAMP(0, c, 0);
+      load_sc(more ? T + EC : T, sc_nxt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tie_set(cur);
+      if (e == 0) F1_STAMP(0, c, 1);
+      d4 D[NTX];
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) D[ct] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) D[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.A[ks], bop(cur, ks, ct), D[ct], 0, 0, 0);
+      // X rows: the own rows sit in the B operand of k-step 0 (lanes kq < 3 hold row kq)
+      if (kq < 3) {
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) Xb[xoff[ct]] = bop(cur, 0, ct);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        if (4 * rr < R_GRP) {                      // compile time: this register holds rows of the column groups 0 .. Q + 1
+#pragma unroll
+          for (int ct = 0; ct < NTX; ++ct) Yb[yoff[rr][ct]] = D[ct][rr];
+        }
+      }
+      if (krow) {                                  // lane constant: one exec region for all c^{qq'} K V stores
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+          for (int ct = 0; ct < NTX; ++ct) Yb[koff[pr][ct]] = sc_cur.cc[pr] * D[ct][RRK];
+      }
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) rhs_part[ct] += D[ct][RRB];      // meaningful on the lanes kq == KQB
+      if (e == 0) F1_STAMP(0, c, 2);
+      if (more) {                                  // wave-uniform; the last stage requests nothing
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) ap[ks] = (const double*)((const char*)ap[ks] + ainc);
+        load_set(T + EC, sc_nxt, cur);
+      }
+      if (e == 0) F1_STAMP(0, c, 3);
+    };
+    Set s0;
+    Sc c0, c1;
+    load_sc(T0 + e, c0);
+    load_set(T0 + e, c0, s0);
+    auto round = [&](int c, Sc& x0, Sc& x1) {
+      stage(c, s0, x0, x1);
+      lds_barrier();
+      if (e == 0) F1_STAMP(0, c, 4);
+      mfma_phase(c);
+      if (e == 0) F1_STAMP(0, c, 5);
+    };
+    for (int c = 0; c < nchunks; c += 2) {                   // nT is a multiple of 8, so nchunks is even
+      round(c, c0, c1);
+      round(c + 1, c1, c0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie_set(s0);
+    if (a.rhs_red != nullptr && kq == KQB) {
+      // every basis column once: the lane that owns it naturally (lanes beyond N hold duplicates)
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) {
+        const int nat = ct < 2 * NPAIR ? 32 * (ct >> 1) + 2 * li + (ct & 1) : 16 * ct + li;
+        if (nat < N) red[e * 64 + nat] = rhs_part[ct];
+      }
+    }
+  } else {
+    // ------------------------------------------------------------- role B: the A_ab R groups, on the matrix pipe as well
+    // Y^{q,q2}[i][col] = sum_f A_ab^q[i][f] R[rt_f][q2 N + col]: one MFMA per (q2, column tile) with the 3 Q rows (q, i) of the
+    // element's A_ab blocks as the A operand (k = face f, the fourth k reads zeros) and the three flux rows as the B operand
+    // (lane: column, k: face).  (The VALU form of k_f1u -- 18 broadcasts = 36 v_readlane, 36 f64 FMAs per element -- takes as
+    // long as the Q NTX MFMAs, tools/f1_trace.py; this form needs fewer registers.)
+    struct Set {
+      double A;
+      d2 Bp[QP][NPAIR > 0 ? NPAIR : 1];
+      double Bs[QP];
+    };
+    const double* Rs = (const double*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(a.Rself + (long)s * t.nrt * QN) >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)(a.Rself + (long)s * t.nrt * QN)));
+    const int r16 = li, kq = lk;
+    const double* ap = t.zero64;                        // lanes without an entry walk through the zero table with the same stride
+    if (r16 < 3 * QP && kq < 3) ap = a.Aab + ((long)(r16 / 3) * S + s) * t.nT * 9 + (r16 % 3) * 3 + kq;
+    ap += (long)(T0 + e) * 9;
+    unsigned lcp[QP][NPAIR > 0 ? NPAIR : 1], lcs[QP];  // lane constants of the B operand offsets (bytes)
+    int yo0[QP][NTX], yo1[QP][NTX];                    // LDS offsets (doubles) of accumulator registers 0 / 1 (rows kq, 4 + kq)
+    const bool v0 = kq < 3 * QP, v1 = 4 + kq < 3 * QP;
+#pragma unroll
+    for (int q2 = 0; q2 < QP; ++q2) {
+#pragma unroll
+      for (int pp = 0; pp < NPAIR; ++pp) lcp[q2][pp] = 8u * (unsigned)(q2 * N + (32 * pp + 2 * li + 1 < N ? 32 * pp + 2 * li : N - 2));
+      lcs[q2] = 8u * (unsigned)(q2 * N + (16 * (NTX - 1) + li < N ? 16 * (NTX - 1) + li : N - 1));
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) {
+        const int col = colc(ct);
+        const int ra = v0 ? kq : 0, rb = v1 ? 4 + kq : 0;
+        yo0[q2][ct] = (3 * e + ra % 3) * LDY + pos(QP + 2 + NP + (ra / 3) * QP + q2, col);
+        yo1[q2][ct] = (3 * e + rb % 3) * LDY + pos(QP + 2 + NP + (rb / 3) * QP + q2, col);
+      }
+    }
+    const unsigned rsr = 8u * (unsigned)QN;
+    const cint_p rtc = (cint_p)t.elem_rt;
+    struct Sc {
+      int rt[3];
+    };
+    auto load_sc = [&](int T, Sc& x) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) x.rt[f] = rtc[T * 3 + f];
+    };
+    auto load_set = [&](const Sc& sc, Set& x) {
+      const unsigned ro = (unsigned)(kq == 1 ? sc.rt[1] : kq == 2 ? sc.rt[2] : sc.rt[0]) * rsr;      // k = 3 meets zeros of A: any finite row
+      x.A = gload_f64(ap);
+#pragma unroll
+      for (int q2 = 0; q2 < QP; ++q2) {
+#pragma unroll
+        for (int pp = 0; pp < NPAIR; ++pp) x.Bp[q2][pp] = gload_s128(Rs, ro + lcp[q2][pp]);
+        if (NSING) x.Bs[q2] = gload_s64(Rs, ro + lcs[q2]);
+      }
+    };
+    auto tie_set = [&](Set& x) {
+      tie(x.A);
+#pragma unroll
+      for (int q2 = 0; q2 < QP; ++q2) {
+#pragma unroll
+        for (int pp = 0; pp < NPAIR; ++pp) tie2(x.Bp[q2][pp]);
+        if (NSING) tie(x.Bs[q2]);
+      }
+    };
+    auto bop = [&](const Set& x, int q2, int ct) { return ct < 2 * NPAIR ? x.Bp[q2][ct >> 1][ct & 1] : x.Bs[q2]; };
+    auto stage = [&](int c, Set& cur, Sc& sc_nxt) {
+      const int T = T0 + c * EC + e;
+      const bool more = c + 1 < nchunks;
+      double* Yb = Ys + (c & 1) * 3 * EC * LDY;
+      if (e == 0) F1_STAMP(1, c, 0);
+      load_sc(more ? T + EC : T, sc_nxt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tie_set(cur);
+      if (e == 0) F1_STAMP(1, c, 1);
+#pragma unroll
+      for (int q2 = 0; q2 < QP; ++q2) {
+        d4 D[NTX];
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct)
+          D[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.A, bop(cur, q2, ct), (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        if (v0) {
+#pragma unroll
+          for (int ct = 0; ct < NTX; ++ct) Yb[yo0[q2][ct]] = D[ct][0];
+        }
+        if (3 * QP > 4 && v1) {
+#pragma unroll
+          for (int ct = 0; ct < NTX; ++ct) Yb[yo1[q2][ct]] = D[ct][1];
+        }
+      }
+      if (e == 0) F1_STAMP(1, c, 2);
+      if (more) {
+        ap += 9 * EC;
+        load_set(sc_nxt, cur);
+      }
+      if (e == 0) F1_STAMP(1, c, 3);
+    };
+    Set s0;
+    Sc c0;
+    load_sc(T0 + e, c0);
+    load_set(c0, s0);
+    for (int c = 0; c < nchunks; ++c) {
+      stage(c, s0, c0);
+      lds_barrier();
+      if (e == 0) F1_STAMP(1, c, 4);
+      mfma_phase(c);
+      if (e == 0) F1_STAMP(1, c, 5);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie_set(s0);
+  }
+  // ---- K-split (see f1u_body: partial tiles written through, the last arriver sums them in the fixed order of the parts)
+  if (ksplit > 1) {
+    constexpr int PW = F1V_SLOTS * 4 * 64;             // doubles per wave: [slot][r / 2][lane][r % 2]
+    const long wg = 8L * PW + 64;                      // + the partial rhs_red
+    double* mine = a.part + ((long)s * ksplit + blockIdx.z) * wg;
+    double* pw = mine + (long)wave * PW + 2 * lane;
+#pragma unroll
+    for (int i = 0; i < LV::slots(ROLE); ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) store_sc1_b128(pw + (i * 2 + h) * 128, acc[i][2 * h], acc[i][2 * h + 1]);
+    __syncthreads();                                   // red[] of the role-A waves is complete
+    if (a.rhs_red != nullptr && tid < N) {
+      double sum = 0.0;
+      for (int w = 0; w < EC; ++w) sum += red[w * 64 + tid];
+      store_sc1_b64(mine + 8L * PW + tid, sum);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier in front of the arrival
+    __syncthreads();
+    if (tid == 0) *flag = __hip_atomic_fetch_add(a.ticket + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != ksplit - 1) return;                   // workgroup-uniform
+    if (tid == 0) __hip_atomic_store(a.ticket + s, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    const double* all = a.part + (long)s * ksplit * wg;
+#pragma unroll
+    for (int i = 0; i < LV::slots(ROLE); ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int z = 0; z < ksplit; ++z) {
+      const double* pz = all + z * wg + (long)wave * PW + 2 * lane;
+#pragma unroll
+      for (int i = 0; i < LV::slots(ROLE); ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] += load_sc1_b64(pz + (i * 2 + r / 2) * 128 + r % 2);
+    }
+    if (a.rhs_red != nullptr && tid < N) {
+      double sum = 0.0;
+      for (int z = 0; z < ksplit; ++z) sum += load_sc1_b64(all + z * wg + 8L * PW + tid);
+      a.rhs_red[(long)s * N + tid] = sum;
+    }
+  }
+  // ---- epilogue: scatter the tiles to their destination arrays (static accumulator indices only).  colmap: LDS column ->
+  // (group << 8 | local column) or -1.  Symmetric groups: a tile delivers the entries row <= column and their mirror images.
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int m = colmap[(4 * (LV0 + jt) + e) * 16 + li];
+    const bool live = m >= 0;
+    const int g = live ? m >> 8 : 0, jj = m & 255;
+    const int ld = grp[g].ld;
+    const bool sym = grp[g].sym != 0;
+    double* base = grp[g].dst + (long)s * grp[g].sstride;
+    double* base_t = grp[g].dst_t ? grp[g].dst_t + (long)s * grp[g].sstride : nullptr;
+#pragma unroll
+    for (int i = 0; i < LV::cls(LV0 + jt); ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + lk + 4 * r;
+        const double val = acc[LV::slots_before(ROLE, jt) + i][r];
+        if (live && row < N && (!sym || row <= jj)) {
+          base[(long)row * ld + jj] = val;
+          if (sym && row < jj) base[(long)jj * ld + row] = val;
+          if (base_t) base_t[(long)jj * ld + row] = val;
+        }
+      }
+    }
+  }
+}
+
+template <int NTX, int QP, int L1, int L2, int L3>
+__global__ __launch_bounds__(512, 2) void k_f1v(Tmpl t, F1Args a, GrpTable gt) {
+  constexpr int NTYS = L1 + L2 + L3;
+  constexpr int LDX = padded_ld(NTX);
+  constexpr int LDY = 4 * NTYS * 16 + 16;
+  __shared__ double Xs[2 * 3 * EC * LDX];
+  __shared__ double Ys[2 * 3 * EC * LDY];
+  __shared__ double red[EC * 64];
+  __shared__ int colmap[4 * NTYS * 16];
+  __shared__ Grp grp[F1_MAXG];
+  __shared__ int flag;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int g = 0; g < F1_MAXG; ++g)
+    if (tid == g) grp[g] = gt.g[g];
+  for (int i = tid; i < 2 * 3 * EC * LDX; i += 512) Xs[i] = 0.0;
+  for (int i = tid; i < 2 * 3 * EC * LDY; i += 512) Ys[i] = 0.0;
+  for (int i = tid; i < 4 * NTYS * 16; i += 512) colmap[i] = -1;
+  if (tid < EC * 64) red[tid] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < gt.n * a.N; i += 512) {
+    const int g = i / a.N, c = i - g * a.N;
+    colmap[grp[g].cb[c >> 4] + (c & 15)] = (g << 8) | c;
+  }
+  __syncthreads();
+  if (uniform(tid >> 6) < EC)
+    f1v_body<NTX, QP, L1, L2, L3, 0>(t, a, Xs, Ys, red, &flag, colmap, grp);
+  else
+    f1v_body<NTX, QP, L1, L2, L3, 1>(t, a, Xs, Ys, red, &flag, colmap, grp);
+  if (gridDim.z == 1 && a.rhs_red != nullptr) {   // fixed-order sum over the EC role-A waves (K-split: done in f1v_body)
     __syncthreads();
     if (tid < a.N) {
       double sum = 0.0;
@@ -2292,7 +2804,11 @@ __global__ __launch_bounds__(256) void k_build_tables(Tmpl t, double* __restrict
     double K[9];
     stiffness3(t, i, K);
     for (int k = 0; k < 9; ++k) stiff[i * 9 + k] = K[k];
+    double* mass9 = stiff + 9 * t.nT;
+    const double m = t.area[i] * (1.0 / 12.0);
+    for (int k = 0; k < 9; ++k) mass9[i * 9 + k] = (k % 4 == 0) ? m + m : m;
   }
+  for (int k = i; k < 9 * t.nT + 64; k += gridDim.x * blockDim.x) stiff[18 * t.nT + k] = 0.0;
   if (i < 4 * t.ntouch) {
     const int sd = i / t.ntouch, p = i - sd * t.ntouch;
     int m = 0;
@@ -2322,7 +2838,7 @@ int build_template_tables(lrbms_ctx* ctx) {
   Tmpl& t = ctx->t;
   double* stiff = nullptr;
   int *tvtx = nullptr, *tpos = nullptr, *tmask = nullptr;
-  LRBMS_HIP_CHECK(ctx, hipMalloc(&stiff, sizeof(double) * 9 * (size_t)t.nT));
+  LRBMS_HIP_CHECK(ctx, hipMalloc(&stiff, sizeof(double) * (27 * (size_t)t.nT + 64)));   // stiff | mass9 | zeros [9 nT + 64]
   ctx->owned.push_back(stiff);
   LRBMS_HIP_CHECK(ctx, hipMalloc(&tvtx, sizeof(int) * 12 * (size_t)t.ntouch));
   ctx->owned.push_back(tvtx);
@@ -2330,15 +2846,83 @@ int build_template_tables(lrbms_ctx* ctx) {
   ctx->owned.push_back(tpos);
   LRBMS_HIP_CHECK(ctx, hipMalloc(&tmask, sizeof(int) * 4 * (size_t)t.ntouch));
   ctx->owned.push_back(tmask);
-  const int total = t.nT > 4 * t.ntouch ? t.nT : 4 * t.ntouch;
+  const int total = std::max(64, t.nT > 4 * t.ntouch ? t.nT : 4 * t.ntouch);
   hipLaunchKernelGGL(k_build_tables, dim3((total + 255) / 256), dim3(256), 0, nullptr, t, stiff, tvtx, tpos, tmask);
   LRBMS_LAUNCH_CHECK(ctx);
   LRBMS_HIP_CHECK(ctx, hipDeviceSynchronize());
   t.stiff = stiff;
+  t.mass9 = stiff + 9 * (size_t)t.nT;
+  t.zero64 = stiff + 18 * (size_t)t.nT;
   t.touch_vtx = tvtx;
   t.touch_pos = tpos;
   t.touch_mask = tmask;
   return LRBMS_OK;
+}
+
+// (row tiles, Q, levels with 1 / 2 / 3 live row tiles) combinations of the lean projection kernel k_f1v that are compiled in;
+// everything else runs k_f1u.  Q = 2: N = 36 .. 40 (config 3), N = 34, N = 20 (config 2).
+#define LRBMS_F1V_LIST(X) X(3, 2, 1, 2, 4) X(3, 2, 1, 2, 3) X(2, 2, 1, 3, 0)
+static bool f1v_instantiated(int ntx, int Q, const int lv[3]) {
+#define LRBMS_F1V_HAS(A, B, C, D, E) if (ntx == A && Q == B && lv[0] == C && lv[1] == D && lv[2] == E) return true;
+  LRBMS_F1V_LIST(LRBMS_F1V_HAS)
+#undef LRBMS_F1V_HAS
+  return false;
+}
+
+// Column layout of Y for k_f1v.  A symmetric group (B_sys diagonal, E_red, M_red, G_aa[q][q]) is cut into blocks of 16 columns;
+// block j needs the row tiles 0 .. j only (entries below the diagonal are mirror images), so its tile has "class" j + 1; the
+// short last blocks (N - 16 (ntx - 1) columns) of all symmetric groups are packed back to back into shared tiles of class ntx,
+// the unsymmetric groups follow contiguously (class ntx).  Tiles in ascending class, four per level (one per SIMD); a level's
+// class is that of its last tile.  Fills Grp::cb / sym and lv = levels of class 1 / 2 / 3; false if the columns do not fit.
+static bool f1v_layout(std::vector<Grp>& groups, int N, int ntx, int lv[3]) {
+  int ns = 0, nu = 0;
+  for (Grp& g : groups) {
+    g.sym = (g.kind == G_SYS || g.kind == G_ENERGY || g.kind == G_MASS || (g.kind == G_AA && g.q == g.q2)) ? 1 : 0;
+    (g.sym ? ns : nu) += 1;
+  }
+  const int tail = N - 16 * (ntx - 1);
+  const int ntail = (ns * tail + 15) / 16, nuns = (nu * N + 15) / 16;
+  const int nblock = ns * (ntx - 1), T = nblock + ntail + nuns;
+  if (T > 4 * F1_NTY || ntx > 3) return false;
+  int si = 0, ui = 0;
+  for (Grp& g : groups) {
+    if (g.sym) {
+      for (int j = 0; j < 4; ++j) g.cb[j] = j < ntx - 1 ? 16 * (j * ns + si) : 16 * nblock + si * tail;
+      ++si;
+    } else {
+      for (int j = 0; j < 4; ++j) g.cb[j] = 16 * (nblock + ntail) + ui * N + 16 * j;
+      ++ui;
+    }
+  }
+  lv[0] = lv[1] = lv[2] = 0;
+  for (int l = 0; 4 * l < T; ++l) {
+    const int k = std::min(4 * l + 3, T - 1);
+    lv[(k < nblock ? k / ns + 1 : ntx) - 1] += 1;
+  }
+  return true;
+}
+
+// v_mfma_f64_16x16x4_f64 instructions the dense projection kernel (k_f1v / k_f1u / k_f1, whichever the launcher takes for this
+// shape and these options) executes per subdomain; 0 if the fused pass does not support the shape.  For the roofline of bench.py.
+long f1_mfma_per_subdomain(lrbms_ctx* ctx, int Q, int N) {
+  const Tmpl& t = ctx->t;
+  if (N < 1 || N > 64 || Q < 1 || Q > 4) return 0;
+  const int ntx = (N + 15) / 16, ng = Q + 2 + Q * (Q + 1) / 2 + Q * Q, nch = t.nT / EC;
+  std::vector<Grp> groups;
+  for (int q = 0; q < Q; ++q) groups.push_back({G_SYS, q, 0});
+  groups.push_back({G_ENERGY, 0, 0});
+  groups.push_back({G_MASS, 0, 0});
+  for (int q = 0; q < Q; ++q)
+    for (int q2 = q; q2 < Q; ++q2) groups.push_back({G_AA, q, q2});
+  for (int q = 0; q < Q; ++q)
+    for (int q2 = 0; q2 < Q; ++q2) groups.push_back({G_AB, q, q2});
+  const bool one_slice = ng <= std::min(F1_MAXG, (4 * F1_NTY * 16) / N);
+  const bool unified = (Q == 1 || Q == 2) && one_slice && ntx <= 3 && ctx->opt_f1_legacy != 1;
+  int lv[3] = {0, 0, 0};
+  if (unified && ctx->opt_f1_legacy != 2 && N % 2 == 0 && N >= 2 && f1v_layout(groups, N, ntx, lv) && f1v_instantiated(ntx, Q, lv))
+    return (long)nch * 3 * 4 * (lv[0] + 2 * lv[1] + 3 * lv[2]) + (long)t.nT * (3 * ntx + Q * ntx);      // projection + the two applies
+  const int tiles = (ng * N + 15) / 16;                         // k_f1u skips the column tiles beyond the last column
+  return (long)nch * 3 * ntx * tiles + (long)t.nT * 3 * ntx;
 }
 
 static size_t thin_nc_lds_bytes(const Tmpl& t, int ntx) {   // Wa, Yc, Ksc, ttab / vtab / ptab / side_mask of k_thin_nc
@@ -2504,15 +3088,24 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
         nsl = sl + 1;
       }
       F1Args a{V, A_diag, P_diag, caa, Aab, Rself, b, g0 == 0 ? rhs_red : nullptr, Q, N, S, nullptr, nullptr};
-      const bool legacy = ctx->opt_f1_legacy != 0;   // LRBMS_OPT_F1_PRODUCER_CONSUMER: the producer / consumer form of the same kernel
+      const bool legacy = ctx->opt_f1_legacy == 1;   // LRBMS_OPT_F1_FORM 1: the producer / consumer form of the same kernel
       const bool unified = (Q == 1 || Q == 2) && one_slice && ntx <= 3 && !legacy;
+      // the lean form (k_f1v): even N, and one of the instantiated (row tiles, Q, column tiles per SIMD) combinations
+      int lv[3] = {0, 0, 0};
+      const bool lean = unified && ctx->opt_f1_legacy != 2 && N % 2 == 0 && N >= 2 && f1v_layout(groups, N, ntx, lv) &&
+                        f1v_instantiated(ntx, Q, lv);
+      if (lean)
+        for (int i = 0; i < gt[0].n; ++i) gt[0].g[i] = groups[g0 + i];      // with the column map filled in
       // K-split: a rank with few subdomains spreads the element range of a subdomain over up to four workgroups (k_f1u:
       // partial tiles + "last one sums in fixed order"; the producer / consumer kernel: two halves that meet by atomic
       // add on zeroed outputs).  Every part keeps an even number of chunks (the stage loops are unrolled by two).  A
       // template whose stiffness table does not fit beside the staging buffers in LDS is split for that reason alone.
       const int nch = t.nT / EC;
       int ksplit = 1;
-      if (unified) {
+      if (lean) {
+        const int want = ctx->opt_f1_ksplit > 0 ? ctx->opt_f1_ksplit : (S <= 64 ? 2 : 1);      // LRBMS_OPT_F1_KSPLIT
+        while (ksplit < want && nch % (4 * ksplit) == 0) ksplit *= 2;
+      } else if (unified) {
         // (measured, one MI355X: 64 subdomains 98 / 102 us per pass split in 2 / 4, 110 unsplit; 128 subdomains 171 unsplit, 185 / 199 split)
         // (an UNEVEN two-way split at 128 subdomains -- long parts first, short parts beside the other kernels -- was measured
         // too: 160 - 190 us per pass for 28 .. 16 of the 32 chunks in the long part, against 150 unsplit)
@@ -2526,7 +3119,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
         ksplit = split_ok && (ctx->opt_f1_ksplit > 0 ? ctx->opt_f1_ksplit == 2 : 4 * S * nsl <= 256) ? 2 : 1;
       }
       if (ksplit > 1 && unified) {
-        const long need = (long)S * ksplit * f1u_part_size(ntx);
+        const long need = (long)S * ksplit * (lean ? f1v_part_size(ntx) : f1u_part_size(ntx));
         if (ctx->ksp_part_cap < need) {
           if (ctx->ksp_part) LRBMS_HIP_CHECK(ctx, hipFree(ctx->ksp_part));
           ctx->ksp_part = nullptr;
@@ -2551,6 +3144,15 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       }
       const dim3 grid(S, nsl, ksplit);
       KScope ks(ctx, "k_f1", st);
+      if (lean) {
+#define LRBMS_F1V(A, B, C, D, E)                                               \
+  if (ntx == A && Q == B && lv[0] == C && lv[1] == D && lv[2] == E)            \
+    hipLaunchKernelGGL((k_f1v<A, B, C, D, E>), grid, dim3(512), 0, st, t, a, gt[0]);
+        LRBMS_F1V_LIST(LRBMS_F1V)
+#undef LRBMS_F1V
+        LRBMS_LAUNCH_CHECK(ctx);
+        continue;
+      }
       const size_t ldsf1u = sizeof(double) * 9 * (t.nT / ksplit);
 #define LRBMS_F1(NTXV)                                                                                              \
   do {                                                                                                              \

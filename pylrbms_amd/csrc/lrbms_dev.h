@@ -21,6 +21,8 @@ struct Tmpl {
   const double *grad, *area, *normal, *face_len, *points;
   // derived on the device at mesh upload (build_template_tables, fused.hip): template data every subdomain shares
   const double* stiff;       // [nT][9]            K_T[i][j] = grad phi_i . kappa grad phi_j
+  const double* mass9;       // [nT][9]            M_T[i][j] = |T| / 12 (1 + delta_ij)   (P1 mass block)
+  const double* zero64;      // [9 nT + 64] zeros: operand lanes of k_f1v that must read 0.0 walk through here
   const int* touch_vtx;      // [4][ntouch][3]     lattice vertex of local DoF i of the p-th element touching side sd
   const int* touch_pos;      // [4][ntouch][3][4]  its position along side sd', or -1 if it is not on that side
   const int* touch_mask;     // [4][ntouch]        bit sd' set if the element has a vertex on side sd'
@@ -122,6 +124,7 @@ struct KScope {
 };
 
 int build_template_tables(lrbms_ctx* ctx);
+long f1_mfma_per_subdomain(lrbms_ctx* ctx, int Q, int N);   // fused.hip: executed MFMAs of the dense projection kernel
 // dense coarse level of the Krylov preconditioners (online.hip)
 int coarse_begin(lrbms_ctx* ctx, double** A0_out, hipStream_t st);
 int coarse_finish(lrbms_ctx* ctx, const double** A0inv_out, hipStream_t st);

@@ -44,6 +44,10 @@ def _problems():
         # BASELINE.json config 2 geometry (k_c = 4, N = 20) on a smaller subdomain grid
         'multiscale_4x3_kc4_N20': (lambda: multiscale_problem.init_grid_and_problem(
             {'num_subdomains': [4, 3], 'coarse_per_subdomain': 4}), 20, 0.7),
+        # N = 34: the second instantiation of the lean projection kernel for three row tiles (k_f1v<3,2,1,2,3>: six levels of
+        # column tiles), with short packed tails of the symmetric groups (2 columns each)
+        'multiscale_3x2_kc4_N34': (lambda: multiscale_problem.init_grid_and_problem(
+            {'num_subdomains': [3, 2], 'coarse_per_subdomain': 4}), 34, 0.55),
         # the widest supported basis (N = 64, QN = 128): k_f1 needs two column slices -> its generic (runtime-Q) producer
         'multiscale_2x2_kc4_N64': (lambda: multiscale_problem.init_grid_and_problem(
             {'num_subdomains': [2, 2], 'coarse_per_subdomain': 4}), 64, 0.8),
@@ -199,6 +203,37 @@ def test_k_split_of_the_projection_kernel_is_order_independent(monkeypatch, shap
     for ks in ('2', '4'):
         for a, b in zip(outs['1'], outs[ks]):
             assert float((a - b).abs().max()) <= 1e-13 * float(a.abs().max())
+
+
+@pytest.mark.parametrize('shape, kc, N', [((6, 5), 4, 40), ((3, 3), 4, 36), ((4, 4), 2, 20), ((3, 2), 4, 38)])
+def test_forms_of_the_projection_kernel_agree(shape, kc, N):
+    """LRBMS_OPT_F1_FORM: the lean kernel k_f1v (symmetric groups cut into column blocks, mirror entries stored from the upper
+    triangle, mass / stiffness / rhs rows on the apply MFMA), the unified kernel k_f1u and the producer / consumer kernel k_f1
+    compute the same projected operators to summation-order rounding; the symmetric outputs of k_f1v are EXACTLY symmetric (both
+    halves come from one accumulator entry)."""
+    import torch
+    from pylrbms_amd import multiscale_problem
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(shape), 'coarse_per_subdomain': kc})
+    eng = _engine(p)
+    V = eng.ctx.from_numpy(make_bases(eng.S, eng.t.n, N, seed=6))
+    outs = {}
+    try:
+        for form in (0, 2, 1):
+            eng.ctx.set_option('f1_form', form)
+            buf = eng.project_and_estimate(V)
+            outs[form] = [x.clone() for x in buf['sys']] + [x.clone() for x in buf['grams']]
+    finally:
+        eng.ctx.set_option('f1_form', 0)
+    for form in (2, 1):
+        for a, b in zip(outs[0], outs[form]):
+            assert float((a - b).abs().max()) <= 1e-12 * float(a.abs().max()), form
+    B_sys, rhs_red, E_red, M_red = outs[0][:4]
+    assert torch.equal(B_sys[:, :, 2], B_sys[:, :, 2].transpose(2, 3))
+    assert torch.equal(E_red, E_red.transpose(1, 2)) and torch.equal(M_red, M_red.transpose(1, 2))
+    G_aa = outs[0][4 + 5]
+    for q in range(eng.Q):
+        for q2 in range(eng.Q):
+            assert torch.equal(G_aa[q, q2], G_aa[q2, q].transpose(1, 2))
 
 
 def test_full_size_properties_config3(monkeypatch):

@@ -8,6 +8,6 @@ python3 -c "import sys; sys.path.insert(0, '$ROOT'); from pylrbms_amd._build imp
 mkdir -p $ROOT/pylrbms_amd/_variants /tmp/var_$NAME
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DLRBMS_EXPERIMENT_BUILD "$@" -I$ROOT/pylrbms_amd/csrc -c ${SRC:-$ROOT/pylrbms_amd/csrc/fused.hip} -o /tmp/var_$NAME/fused.o
 OBJS=""
-for f in capi assemble apply gemm online enrich fom; do OBJS="$OBJS $ROOT/pylrbms_amd/csrc/_obj/$f.o"; done
+for f in capi assemble apply gemm online enrich fom lrbms3d; do OBJS="$OBJS $ROOT/pylrbms_amd/csrc/_obj/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/pylrbms_amd/_variants/$NAME.so $OBJS /tmp/var_$NAME/fused.o -L/opt/rocm/lib -lrocsolver -lrocblas
 echo built $ROOT/pylrbms_amd/_variants/$NAME.so
