@@ -51,9 +51,24 @@ def compulsory_bytes(t, S, N, Q):
     return inputs, outputs
 
 
+_POOL3 = {}
+
+
+def _pool_reduce3(chunk):
+    from oracle.lrbms3d import Reductor3D
+    Reductor3D(_POOL3['d'], _POOL3['V']).reduce(subdomains=chunk)
+    return len(chunk)
+
+
 def cpu_baseline3d(N):
-    """The 3D oracle's Reductor3D.reduce() (NumPy / SciPy, one core) on a 2 x 2 x 2 sample of the same problem, timed before
-    the process touches the GPU."""
+    """The 3D oracle's Reductor3D.reduce() (NumPy / SciPy) on a 2 x 2 x 2 sample of the same problem (k_c = 4, N as config 5),
+    timed before the process touches the GPU: one process, and the target subdomains farmed over a fork()ed pool on the host cores
+    the process may use (as bench.py does for config 3).  Why not 4 x 4 x 4: the oracle ASSEMBLES its global sparse operators in
+    Python (21 s for 2 x 2 x 2, 76 s for 3 x 3 x 3, ~3 min for 4 x 4 x 4: untimed, but inside the default bench run), and its
+    rate per target subdomain barely depends on the sample (1.4 / s at 2 x 2 x 2, 1.0 / s at 3 x 3 x 3 on one core here)."""
+    import multiprocessing as mp
+    from threadpoolctl import threadpool_limits
+    from bench import host_cores
     from oracle.lrbms3d import Discretization3D, Reductor3D
     from oracle.mesh3d import KuhnMesh3D
     from pylrbms_amd import multiscale_problem3d
@@ -66,14 +81,28 @@ def cpu_baseline3d(N):
     t_asm = time.perf_counter() - t0
     rng = np.random.default_rng(0)
     V = [np.hstack([np.ones((d.n, 1)), rng.standard_normal((d.n, N - 1))]) for _ in range(d.S)]
-    t0 = time.perf_counter()
-    Reductor3D(d, V).reduce()
-    dt = time.perf_counter() - t0
-    return {'value': d.S / dt, 'unit': 'subdomains/s', 'cores': 1, 'kind': 'port',
+    hc = host_cores()
+    workers = max(1, min(hc['cores'], d.S))
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        Reductor3D(d, V).reduce()
+        one = d.S / (time.perf_counter() - t0)
+        _POOL3['d'], _POOL3['V'] = d, V
+        chunks = [[ii] for ii in range(d.S)]
+        with mp.get_context('fork').Pool(workers) as pool:
+            pool.map(_pool_reduce3, chunks[:workers])                     # start-up of the workers is not timed
+            t0 = time.perf_counter()
+            pool.map(_pool_reduce3, chunks)
+            allc = d.S / (time.perf_counter() - t0)
+    _POOL3.clear()
+    return {'value': allc, 'unit': 'subdomains/s', 'cores': workers, 'kind': 'port', 'value_1core': one,
             'assemble_subdomains_per_s_1core': d.S / t_asm,
-            'sample': 'oracle.lrbms3d.Reductor3D.reduce() (NumPy/SciPy fp64, one process, one thread) on 2x2x2 subdomains of the '
-                      'same synthetic 3D problem (k_c = 4, n = 3840, N = {}); timed before the GPU is touched'.format(N),
-            'os_cpu_count': os.cpu_count()}
+            'sample': 'oracle.lrbms3d.Reductor3D.reduce() (NumPy/SciPy fp64) on 2x2x2 subdomains of the same synthetic 3D problem '
+                      '(k_c = 4, n = 3840, N = {}): value = the 8 target subdomains farmed over a {}-process pool (1 BLAS thread '
+                      'each), value_1core = one process; timed before the GPU is touched.  A 4x4x4 sample would add ~3 min of '
+                      'untimed oracle assembly (Python) to the default bench run; the per-subdomain rate barely depends on the '
+                      'sample size'.format(N, workers),
+            'os_cpu_count': hc['os_cpu_count'], 'affinity': hc['affinity'], 'cgroup_quota': hc['cgroup_quota']}
 
 
 def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True, world=1, rank=0, backend='nccl', options=None):

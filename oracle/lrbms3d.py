@@ -464,20 +464,24 @@ class Reductor3D:
         out[self.d.dofs_of(ii)] = self.bases[ii]
         return out
 
-    def reduce(self):
+    def reduce(self, subdomains=None):
+        """``subdomains``: only these TARGET subdomains (bench.py farms them over a process pool to time the oracle on all host
+        cores; the result then holds their entries only, in that order, and cannot be solved) -- default: all."""
         d, m = self.d, self.d.mesh
         S, Q = d.S, d.Q
-        emb = [self._embed(ii) for ii in range(S)]
-        W = [d.oswald_error(emb[ii]) for ii in range(S)]                                   # [ndof, N_ii]
-        R = [[d.F_q[q] @ emb[ii] for q in range(Q)] for ii in range(S)]                    # [num_faces, N_ii] per q
+        targets = list(range(S)) if subdomains is None else [int(ii) for ii in subdomains]
+        need = sorted({kk for ii in targets for kk in m.neighborhood_of(ii)})
+        emb = {ii: self._embed(ii) for ii in need}
+        W = {ii: d.oswald_error(emb[ii]) for ii in need}                                   # [ndof, N_ii]
+        R = {ii: [d.F_q[q] @ emb[ii] for q in range(Q)] for ii in need}                    # [num_faces, N_ii] per q
         rd = ReducedModel3D(self)
         rd.op = [{jj: [self.bases[ii].T @ (d.A_q[q][d.dofs_of(ii)][:, d.dofs_of(jj)] @ self.bases[jj]) for q in range(Q)]
-                  for jj in m.neighborhood_of(ii)} for ii in range(S)]
-        rd.rhs = [self.bases[ii].T @ d.b[d.dofs_of(ii)] for ii in range(S)]
-        rd.hood = [m.neighborhood_of(ii) for ii in range(S)]
+                  for jj in m.neighborhood_of(ii)} for ii in targets]
+        rd.rhs = [self.bases[ii].T @ d.b[d.dofs_of(ii)] for ii in targets]
+        rd.hood = [m.neighborhood_of(ii) for ii in targets]
         rd.nc, rd.r_fd, rd.r_dd, rd.df_bb, rd.df_ab, rd.df_aa = [], [], [], [], [], []
-        for ii in range(S):
-            hood, dof, el = rd.hood[ii], d.dofs_of(ii), m.elements_of(ii)
+        for k, ii in enumerate(targets):
+            hood, dof, el = rd.hood[k], d.dofs_of(ii), m.elements_of(ii)
             Wi = np.hstack([W[kk][dof] for kk in hood])                                    # images on ii, slot-major columns
             rd.nc.append(Wi.T @ (d.E[dof][:, dof] @ Wi))
             # flux images on ii: columns (slot, q, j)
