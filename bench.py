@@ -369,6 +369,25 @@ def main():
             kernel_ms.setdefault(name, []).append(ms)
         kernel_ms = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
 
+    # the same pass writing the DENSE block-compact layout (G_rdd / G_bb [S][9][QN][QN], G_nc [S][5N][5N]: what rd.operators hands a
+    # caller of the reference's API; the timed region above writes the factored layout the reduced estimate consumes)
+    dense_layout_ms = None
+    if world == 1 and eng.ctx.fused_supported(eng.Q, N, factored=False):
+        bufd = eng.alloc_reduce_buffers(N, factored=False)
+        eng.__dict__.pop('_bound_pass', None)
+        eng.project_and_estimate(V, bufd)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            eng.project_and_estimate(V, bufd)
+        e1.record()
+        torch.cuda.synchronize()
+        dense_layout_ms = e0.elapsed_time(e1) / args.steps
+        del bufd
+        eng.__dict__.pop('_bound_pass', None)
+        torch.cuda.empty_cache()
+
     online = None
     if world == 1 and not args.no_online:
         # online phase (O1) on the same problem: energy-orthonormalise the local bases (B1) with the projected energy
@@ -491,16 +510,24 @@ def main():
             pmc_note = '{} (withheld: the kernel sources changed since that profile was taken)'.format(pmc['file'])
             pmc = None
         traffic = pmc['per_pass_bytes'] if pmc else None
-        roofline = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': ach_gbs / PEAK_HBM_GBS, 'traffic': traffic,
-                    'basis': 'compulsory bytes per pass (inputs once + outputs once, compact layouts) / device time of the pass',
-                    'compulsory_bytes': compulsory, 'compulsory_input_bytes': inputs, 'compulsory_output_bytes': outputs,
-                    'traffic_over_compulsory': (traffic / compulsory) if traffic else None,
-                    'traffic_frac_of_peak': (traffic / dev_s_per_step / 1e9 / PEAK_HBM_GBS) if traffic else None,
-                    'traffic_source': pmc['file'] if pmc else pmc_note,
+        # The pass is bound by the fp64 matrix pipe, not by HBM: its dominant kernel (k_f1, ~45 % of the pass) and the dense
+        # kernels together run at > 0.5 of the MFMA peak while the compulsory bytes need 0.12 of the HBM peak.  Top level = the
+        # time-weighted bound: executed fp64-MFMA flops of the dense kernels (k_f1 + k_f2 + k_f3, padding included, as the
+        # library counts them) over their measured time; the HBM view of the whole pass stays beside it under `hbm`.
+        hbm = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach_gbs / PEAK_HBM_GBS,
+               'basis': 'compulsory bytes per pass (inputs once + outputs once, compact layouts) / device time of the pass',
+               'compulsory_bytes': compulsory, 'compulsory_input_bytes': inputs, 'compulsory_output_bytes': outputs,
+               'traffic': traffic, 'traffic_over_compulsory': (traffic / compulsory) if traffic else None,
+               'traffic_frac_of_peak': (traffic / dev_s_per_step / 1e9 / PEAK_HBM_GBS) if traffic else None,
+               'traffic_source': pmc['file'] if pmc else pmc_note}
+        roofline = {'bound': 'mfma', 'achieved': None, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
+                    'traffic': traffic, 'traffic_source': pmc['file'] if pmc else pmc_note, 'hbm': hbm,
+                    'basis': 'executed fp64-MFMA flops (padding included) of the dense kernels k_f1 + k_f2 + k_f3 / their measured '
+                             'time (phase 4 of the pass, HIP events on the launch stream); the dominant kernel alone: dominant_kernel',
                     'kernel': 'fused project+estimate pass: k_flux_compact, k_vertex_avg, k_f1, k_f2, k_f3, k_thin3 (= k_coupling, '
-                              'k_thin_rt, k_thin_ncf in one launch) (HIP events around the pass on the launch stream)',
+                              'k_thin_rt, k_thin_ncf in one launch)',
                     'device_ms_per_step': 1e3 * dev_s_per_step,
+                    'dense_layout_ms_per_step': dense_layout_ms,
                     'survey_8d_algorithmic': {'bytes_per_subdomain': byts, 'flops_per_subdomain': flops,
                                               'note': 'canonical counts of SURVEY 8(d); ~90 % of the flops are structural zeros the pass '
                                                       'skips and the bytes include intermediates it keeps on chip: not executed, not moved',
@@ -532,6 +559,10 @@ def main():
                                          'ms': dense_ms, 'executed_mfma_flops': mf,
                                          'kernel': 'k_f1 + k_f2 + k_f3 (phase 4 of the pass; executed fp64 MFMA flops, padding '
                                                    'included, over their measured time)'}
+            roofline['achieved'], roofline['frac'] = roofline['dense_kernels']['achieved'], roofline['dense_kernels']['frac']
+        elif kernel_ms and roofline.get('dominant_kernel', {}).get('mfma_TFLOPs'):
+            roofline['achieved'] = roofline['dominant_kernel']['mfma_TFLOPs']
+            roofline['frac'] = roofline['dominant_kernel']['mfma_frac']
         out = {'metric': 'offline project+estimate throughput', 'value': value, 'unit': 'subdomains/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',

@@ -58,6 +58,7 @@ typedef struct {
   const double *divc;                             /* [6][4] |f| / |T| */
   const double *TV, *TE, *TAA;                    /* [6][nA|nB|nC][100]  w |T| grad phi_i . kappa grad phi_j */
   const double *TFo, *TFn, *TFb;                  /* [6][4][nFs][100]    inner face (own, own) / (own, neighbour); Dirichlet face */
+  const double *TPo, *TPn, *TPb;                  /* [6][4][nFs][100]    their penalty parts alone (local energy product) */
   const double *TC, *TCb;                         /* [6][4][nFf][10]     flux coefficients: inner / Dirichlet face */
   const double *TPH, *TM;                         /* [6][nB][10] w |T| phi_i;  [6][100] mass */
   const double *TB, *TAB;                         /* [6][nC][16] w |T| psi_f . kappa^-1 psi_g;  [6][nC][40] w |T| grad phi_i . psi_f */
@@ -104,6 +105,18 @@ int lrbms3_assemble_rhs(lrbms3_ctx* ctx, const double* f_smp, const double* lhat
  * Bbb [S][n_T][4][4] (RT0 orientation signs folded in).  2D: lrbms_assemble_products. */
 int lrbms3_assemble_products(lrbms3_ctx* ctx, int32_t Q, const double* lam, const double* lbar, const double* lhat, double* ebar,
                              double* Aaa, double* Aab, double* Bbb, void* stream);
+/* Local energy product of every subdomain (reference: local_energy_dg_product_i, discretize_elliptic_block_swipdg.py:651-677, the
+ * product the local bases are orthonormalised in, reductor.py:19-31): sum_q theta_bar_q [volume term of lambda_q + the PENALTY
+ * terms of the faces inside the subdomain + the Dirichlet penalty, with the inside coefficient, on every face of the subdomain
+ * boundary (coupling or physical: all-Dirichlet boundary info on the subdomain layer, :658)].  theta_bar [Q] host;
+ * P_diag [S][n_T][5][100] block-ELL like A_diag (no coupling blocks: the product is local).  2D: P_diag of lrbms_assemble_products. */
+int lrbms3_assemble_energy_product(lrbms3_ctx* ctx, int32_t Q, const double* theta_bar, const double* lam, double* P_diag,
+                                   void* stream);
+
+/* Y [S][n][M] = P_diag X (the local energy product applied to M vectors per subdomain): Gram-Schmidt of the reductor.
+ * 2D: lrbms_blockell_apply. */
+int lrbms3_energy_product_apply(lrbms3_ctx* ctx, int32_t M, const double* P_diag, const double* X, double* Y, void* stream);
+
 /* Cf [Q][S_ext][n_T][4][10]: contribution of the element's own DoFs to the RT0 DoF of its face f (unsigned; the kernels
  * apply the orientation).  2D: lrbms_assemble_flux. */
 int lrbms3_assemble_flux(lrbms3_ctx* ctx, int32_t Q, const double* lam, double* Cf, void* stream);

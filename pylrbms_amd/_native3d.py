@@ -11,7 +11,7 @@ _INT_FIELDS = ('n_T', 'n_rt', 'ncf', 'nvs', 'n_nodes', 'nb', 'nbel', 'nsel', 'nb
 _I32_TABLES = ('elem_type', 'up_face', 'order', 'nb_elem', 'nb_out', 'face_pos', 'tsign', 'elem_rt', 'rt_e0', 'rt_f0', 'rt_e1', 'rt_f1', 'side_elem',
                'side_face', 'side_elem_out', 'side_face_out', 'dof_node', 'node_ptr', 'node_dofs', 'node_mask', 'node_count',
                'side_nodes', 'sn_ptr', 'sn_dofs', 'dof_bslot', 'bn_ptr', 'bn_slots', 'bnodes', 'bnode_sides', 'bel_elem', 'bel_bnode', 'sel_elem', 'sel_sf')
-_DBL_TABLES = ('divc', 'TV', 'TE', 'TAA', 'TFo', 'TFn', 'TFb', 'TC', 'TCb', 'TPH', 'TM', 'TB', 'TAB', 'WB', 'WC')
+_DBL_TABLES = ('divc', 'TV', 'TE', 'TAA', 'TFo', 'TFn', 'TFb', 'TPo', 'TPn', 'TPb', 'TC', 'TCb', 'TPH', 'TM', 'TB', 'TAB', 'WB', 'WC')
 
 
 class MeshDesc3D(ctypes.Structure):
@@ -29,6 +29,8 @@ SIGNATURES3 = {
     'lrbms3_assemble_rhs': (ctypes.c_int, [c_vp] + [c_vp] * 7),
     'lrbms3_assemble_products': (ctypes.c_int, [c_vp, c_i32] + [c_vp] * 8),
     'lrbms3_assemble_flux': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'lrbms3_assemble_energy_product': (ctypes.c_int, [c_vp, c_i32, _P_DBL, c_vp, c_vp, c_vp]),
+    'lrbms3_energy_product_apply': (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'lrbms3_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms3_project_estimate': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 26),
     'lrbms3_project_estimate_phase': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32] + [c_vp] * 26),
@@ -215,6 +217,27 @@ class Native3DContext:
                                            c_vp(Cf.data_ptr()), self._stream())
         self._check(rc, 'lrbms3_assemble_flux')
         return Cf
+
+    def assemble_energy_product(self, theta_bar, lam):
+        """P_diag [S, n_T, 5, 100]: the local energy product at mu_bar (block-ELL, local to every subdomain)."""
+        Q, sp = lam.shape[0], self.spec
+        th = np.ascontiguousarray(theta_bar, dtype=np.float64)
+        assert th.shape == (Q,)
+        P = self.empty(self.S, self.n_T, 5, 100)
+        rc = self.lib.lrbms3_assemble_energy_product(self.handle, Q, th.ctypes.data_as(_P_DBL),
+                                                     self._ptr(lam, (Q, self.S_ext, self.n_T, sp.lam_stride), 'lam'),
+                                                     c_vp(P.data_ptr()), self._stream())
+        self._check(rc, 'lrbms3_assemble_energy_product')
+        return P
+
+    def energy_product_apply(self, P_diag, X):
+        """P X for X [S, n, M] (M vectors per subdomain)."""
+        M = X.shape[2]
+        Y = self.empty(self.S, self.n, M)
+        rc = self.lib.lrbms3_energy_product_apply(self.handle, M, self._ptr(P_diag, (self.S, self.n_T, 5, 100), 'P_diag'),
+                                                  self._ptr(X, (self.S, self.n, M), 'X'), c_vp(Y.data_ptr()), self._stream())
+        self._check(rc, 'lrbms3_energy_product_apply')
+        return Y
 
     # ------------------------------------------------------------------ pass
     OUT_NAMES = ('B_sys', 'rhs_red', 'G_nc', 'G_bb', 'G_rdd', 'G_ab', 'G_aa', 'r_fd', 'Rb', 'Yb', 'Dp', 'Xab', 'As', 'Cn')

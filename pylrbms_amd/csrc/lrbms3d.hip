@@ -38,7 +38,8 @@ struct T3 {
   const int *side_elem, *side_face, *side_elem_out, *side_face_out;
   const int *dof_node, *node_ptr, *node_dofs, *node_mask, *node_count, *side_nodes, *sn_ptr, *sn_dofs;
   const int *dof_bslot, *bn_ptr, *bn_slots, *bnodes, *bnode_sides, *bel_elem, *bel_bnode, *sel_elem, *sel_sf;
-  const double *divc, *TV, *TE, *TAA, *TFo, *TFn, *TFb, *TC, *TCb, *TPH, *TM, *TB, *TAB, *WB, *WC;
+  const double *divc, *TV, *TE, *TAA, *TFo, *TFn, *TFb, *TPo, *TPn, *TPb, *TC, *TCb, *TPH, *TM, *TB, *TAB, *WB, *WC;
+  const double* TSP;     // [6][nA + 8 nFs][100] diagonal block of the local energy product: TV | per face (TPo | TPb)
   const double* TSD;     // [6][nA + 8 nFs][100] system diagonal block: TV | per face (TFo | TFb)  (built at mesh upload)
   const double* zeros;   // [64] zeros: target of the loads of padding lanes
 };
@@ -64,6 +65,7 @@ struct lrbms3_ctx {
   hipStream_t aux[3] = {nullptr, nullptr, nullptr}; // library-owned streams: the flux chain and the Oswald chain of the pass; the
                                                     // groups of the batched reduced solve (all three)
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  double* thbar = nullptr;         // [8] device: theta(mu_bar) of lrbms3_assemble_energy_product
   double* pg_part = nullptr;       // K-split partial results of the k3_pg kernels (library-owned, grown on demand)
   long pg_part_cap = 0;
   // launch policy (lrbms3_ctx_set_option): the library reads no environment variable
@@ -173,6 +175,9 @@ constexpr int ASM_KC = 32;        // quadrature points per staged table chunk
 //   4 rhs b (W = f at rule B, table w |T| phi_i), 5 int_T f (W = f at rule C, table = the weights), 6 diagonal block of the SWIPDG
 //   system (K = volume rule + 4 faces x (inner-face table | Dirichlet table), the weight of the table that does not apply to the
 //   face set to zero), 7 block towards the neighbour across face `fq2` (inner: A_diag slot 1 + f; coupling face: A_cpl; zero else).
+//   8 / 9 the same two for the LOCAL ENERGY PRODUCT (block_swipdg.py:651-677): penalty parts of the face tables only, every face of
+//   the subdomain boundary (coupling or physical) a Dirichlet face with the inside coefficient, no coupling blocks; the sample is
+//   sum_q theta_bar_q lambda_q (every term is linear in lambda; theta_bar [Q] on the device through `lhat`).
 template <int OP, int NCT>
 __global__ __launch_bounds__(256) void k3_asm(T3 t, int Q, int q, int q2, const double* __restrict__ lam, const double* __restrict__ lbar,
                                               const double* __restrict__ lhat, double* __restrict__ out, double* __restrict__ out_mirror) {
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void k3_asm(T3 t, int Q, int q, int q2, const 
   const int cube = grp * 64 + wave * 16 + li;                        // this lane's element (A operand row)
   const int e = (cube < ncube ? cube : ncube - 1) * 6 + ty;
   const int fq = q2;                                                 // OP 7: the face
-  const int K = OP == 0 || OP == 4 ? t.nB : (OP == 6 ? t.nA + 8 * t.nFs : (OP == 7 ? t.nFs : t.nC));
+  const int K = OP == 0 || OP == 4 ? t.nB : (OP == 6 || OP == 8 ? t.nA + 8 * t.nFs : (OP == 7 || OP == 9 ? t.nFs : t.nC));
   const double* tab;
   if (OP == 0) tab = t.TE + (long)ty * K * C;
   if (OP == 1) tab = t.TAA + (long)ty * K * C;
@@ -194,6 +199,8 @@ __global__ __launch_bounds__(256) void k3_asm(T3 t, int Q, int q, int q2, const 
   if (OP == 5) tab = t.WC;
   if (OP == 6) tab = t.TSD + (long)ty * K * C;
   if (OP == 7) tab = t.TFn + ((long)(ty * 4 + fq) * K) * C;
+  if (OP == 8) tab = t.TSP + (long)ty * K * C;
+  if (OP == 9) tab = t.TPn + ((long)(ty * 4 + fq) * K) * C;
   const long se = (long)s * t.nT + e;
   // OP 0: lambda_bar; 1-3: lambda_hat at rule C; 4 / 5: f at rule B / C (passed as lbar)
   const double* w0 = OP == 0 ? lbar + se * t.nB : (OP == 4 ? lbar + se * t.f_stride : (OP == 5 ? lbar + se * t.f_stride + t.nB
@@ -209,6 +216,16 @@ __global__ __launch_bounds__(256) void k3_asm(T3 t, int Q, int q, int q2, const 
       bnd[f] = nb < 0 && ((t.phys[s] >> (-(nb + 1))) & 1);
     }
   }
+  if (OP == 8 || OP == 9) {          // local product: every face of the subdomain boundary is a Dirichlet face
+#pragma unroll
+    for (int f = 0; f < 4; ++f) bnd[f] = t.nb_elem[e * 4 + f] < 0;
+  }
+  // OP 8 / 9: lambda at mu_bar = sum_q theta_bar_q lambda_q at point `off` of the element's records
+  auto lam_bar = [&](int off) {
+    double v = 0.0;
+    for (int qq = 0; qq < Q; ++qq) v += lhat[qq] * lam[(((long)qq * t.S_ext + s) * t.nT + e) * t.lam_stride + off];
+    return v;
+  };
   d4 acc[NCT];
 #pragma unroll
   for (int j = 0; j < NCT; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -236,6 +253,17 @@ __global__ __launch_bounds__(256) void k3_asm(T3 t, int Q, int q, int q2, const 
             const bool bf = f == 0 ? bnd[0] : (f == 1 ? bnd[1] : (f == 2 ? bnd[2] : bnd[3]));
             w = (bf == (dir != 0)) ? rec[t.o_fs + f * t.nFs + pt] : 0.0;
           }
+        } else if (OP == 8) {
+          if (k < t.nA) {
+            w = lam_bar(k);
+          } else {
+            const int kf = k - t.nA, f = kf / (2 * t.nFs), r2 = kf - f * 2 * t.nFs, dir = r2 >= t.nFs, pt = dir ? r2 - t.nFs : r2;
+            const bool bf = f == 0 ? bnd[0] : (f == 1 ? bnd[1] : (f == 2 ? bnd[2] : bnd[3]));
+            w = (bf == (dir != 0)) ? lam_bar(t.o_fs + f * t.nFs + pt) : 0.0;
+          }
+        } else if (OP == 9) {
+          const bool bf = fq == 0 ? bnd[0] : (fq == 1 ? bnd[1] : (fq == 2 ? bnd[2] : bnd[3]));
+          w = bf ? 0.0 : lam_bar(t.o_fs + fq * t.nFs + k);
         } else {
           const bool bf = fq == 0 ? bnd[0] : (fq == 1 ? bnd[1] : (fq == 2 ? bnd[2] : bnd[3]));
           w = bf ? 0.0 : rec[t.o_fs + fq * t.nFs + k];
@@ -261,6 +289,10 @@ __global__ __launch_bounds__(256) void k3_asm(T3 t, int Q, int q, int q2, const 
       if (OP == 3) v *= (double)(sgn3(t, s, eo, c >> 2) * sgn3(t, s, eo, c & 3));
       if (OP == 6) {
         out[(((long)q * t.S + s) * t.nT + eo) * 500 + c] = v;
+      } else if (OP == 8) {
+        out[((long)s * t.nT + eo) * 500 + c] = v;
+      } else if (OP == 9) {
+        out[((long)s * t.nT + eo) * 500 + (1 + fq) * 100 + c] = t.nb_elem[eo * 4 + fq] >= 0 ? v : 0.0;
       } else if (OP == 7) {
         const int nb = t.nb_elem[eo * 4 + fq];
         out[(((long)q * t.S + s) * t.nT + eo) * 500 + (1 + fq) * 100 + c] = nb >= 0 ? v : 0.0;
@@ -1992,7 +2024,9 @@ __global__ __launch_bounds__(256) void k3_block_inverse(int N, const double* __r
   const double* A = Amu + ((long)s * 7 + 3) * N * N;
   for (int i = tid; i < N * 2 * N; i += 256) {
     const int r = i / (2 * N), c = i - r * 2 * N;
-    lds[r * ld + c] = c < N ? A[r * N + c] : (c - N == r ? 1.0 : 0.0);
+    // a zero diagonal entry = a zero-padded basis column (ragged local bases: its whole row and column are zero): identity there,
+    // the padded unknown stays exactly 0 (2D: k_block_inverse)
+    lds[r * ld + c] = c < N ? ((c == r && A[r * N + c] == 0.0) ? 1.0 : A[r * N + c]) : (c - N == r ? 1.0 : 0.0);
   }
   __syncthreads();
   for (int p = 0; p < N; ++p) {
@@ -2536,6 +2570,7 @@ __global__ __launch_bounds__(256) void k3_fom_apply(T3 t, int Q, int M, QV th, c
         if (slot > 0) {
           ee = t.nb_elem[e * 4 + slot - 1];
           if (ee < 0) {
+            if (A_cpl == nullptr) continue;      // local operator (energy product): no coupling blocks
             const int side = -(ee + 1);
             ss = t.nbr[s * 7 + side_slot(side)];
             if (ss < 0) continue;
@@ -2975,6 +3010,7 @@ int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, in
   UP(divc, 24);
   UP(TV, 6L * t.nA * 100); UP(TE, 6L * t.nB * 100); UP(TAA, 6L * t.nC * 100);
   UP(TFo, 24L * t.nFs * 100); UP(TFn, 24L * t.nFs * 100); UP(TFb, 24L * t.nFs * 100);
+  UP(TPo, 24L * t.nFs * 100); UP(TPn, 24L * t.nFs * 100); UP(TPb, 24L * t.nFs * 100);
   UP(TC, 24L * t.nFf * 10); UP(TCb, 24L * t.nFf * 10);
   UP(TPH, 6L * t.nB * 10); UP(TM, 600); UP(TB, 6L * t.nC * 16); UP(TAB, 6L * t.nC * 40); UP(WB, t.nB); UP(WC, t.nC);
 #undef UP
@@ -2996,6 +3032,14 @@ int lrbms3_mesh_upload(lrbms3_ctx* ctx, const lrbms3_mesh_desc* d, int32_t S, in
       }
     }
     if ((rc = upload(ctx, tsd.data(), (long)tsd.size(), &t.TSD)) != LRBMS_OK) return rc;
+    for (int ty = 0; ty < 6; ++ty) {      // the same layout with the penalty parts of the face tables: local energy product
+      double* dst = tsd.data() + (size_t)ty * KD * 100;
+      for (int f = 0; f < 4; ++f) {
+        memcpy(dst + ((size_t)t.nA + (size_t)f * 2 * t.nFs) * 100, d->TPo + ((size_t)(ty * 4 + f) * t.nFs) * 100, sizeof(double) * t.nFs * 100);
+        memcpy(dst + ((size_t)t.nA + (size_t)f * 2 * t.nFs + t.nFs) * 100, d->TPb + ((size_t)(ty * 4 + f) * t.nFs) * 100, sizeof(double) * t.nFs * 100);
+      }
+    }
+    if ((rc = upload(ctx, tsd.data(), (long)tsd.size(), &t.TSP)) != LRBMS_OK) return rc;
   }
   ctx->nbr_host.assign(nbr, nbr + (long)S * 7);
   ctx->side_padding = false;
@@ -3056,6 +3100,41 @@ int lrbms3_assemble_products(lrbms3_ctx* ctx, int32_t Q, const double* lam, cons
     hipLaunchKernelGGL((k3_asm<2, 3>), grid, dim3(256), 0, st, t, Q, q, q, lam, lbar, lhat, Aab + (long)q * t.S * t.nT * 40,
                        (double*)nullptr);
   hipLaunchKernelGGL((k3_asm<3, 1>), grid, dim3(256), 0, st, t, Q, 0, 0, lam, lbar, lhat, Bbb, (double*)nullptr);
+  LAUNCH3(ctx);
+  return LRBMS_OK;
+}
+
+int lrbms3_assemble_energy_product(lrbms3_ctx* ctx, int32_t Q, const double* theta_bar, const double* lam, double* P_diag,
+                                   void* stream) {
+  REQUIRE3(ctx);
+  if (Q < 1 || Q > 8 || !theta_bar || !lam || !P_diag) return fail3(ctx, LRBMS_E_INVALID, "assemble_energy_product: bad argument");
+  const T3& t = ctx->t;
+  if (t.nT % 6) return fail3(ctx, LRBMS_E_INVALID, "assemble_energy_product: template is not made of whole cubes");
+  hipStream_t st = (hipStream_t)stream;
+  if (!ctx->thbar) {
+    HIP3(ctx, hipMalloc((void**)&ctx->thbar, sizeof(double) * 8));
+    ctx->owned.push_back(ctx->thbar);
+  }
+  double* thb = ctx->thbar;
+  HIP3(ctx, hipMemcpyAsync(thb, theta_bar, sizeof(double) * Q, hipMemcpyHostToDevice, st));
+  const dim3 grid(6 * ((t.nT / 6 + 63) / 64), t.S);
+  hipLaunchKernelGGL((k3_asm<8, 7>), grid, dim3(256), 0, st, t, Q, 0, 0, lam, (const double*)nullptr, (const double*)thb, P_diag,
+                     (double*)nullptr);
+  for (int f = 0; f < 4; ++f)
+    hipLaunchKernelGGL((k3_asm<9, 7>), grid, dim3(256), 0, st, t, Q, 0, f, lam, (const double*)nullptr, (const double*)thb, P_diag,
+                       (double*)nullptr);
+  LAUNCH3(ctx);
+  HIP3(ctx, hipStreamSynchronize(st));          // theta_bar is a host buffer of the caller
+  return LRBMS_OK;
+}
+
+int lrbms3_energy_product_apply(lrbms3_ctx* ctx, int32_t M, const double* P_diag, const double* X, double* Y, void* stream) {
+  REQUIRE3(ctx);
+  if (M < 1 || !P_diag || !X || !Y) return fail3(ctx, LRBMS_E_INVALID, "energy_product_apply: bad argument");
+  const T3& t = ctx->t;
+  const double one = 1.0;
+  hipLaunchKernelGGL(k3_fom_apply, dim3(t.nT, t.S), dim3(256), 0, (hipStream_t)stream, t, 1, M, make_theta(1, &one), P_diag,
+                     (const double*)nullptr, X, Y);
   LAUNCH3(ctx);
   return LRBMS_OK;
 }

@@ -24,12 +24,27 @@ class BlockDiscretization3D:
         self.coefficients = list(lam['coefficients'])
         self.mu_bar, self.mu_hat = p['mu_bar'], p['mu_hat']
         self.engine = Engine3D(self.grid, lam['functions'], p['f'], p['lambda_bar'], p['lambda_hat'],
-                               data_degree=p.get('data_degree', 2), device_index=device_index).assemble()
+                               data_degree=p.get('data_degree', 2), device_index=device_index,
+                               theta_bar=[float(c(self.mu_bar)) for c in self.coefficients]).assemble()
         self.Q = self.engine.Q
         self.parameter_range = p.get('parameter_range')
 
     def theta(self, mu):
         return np.array([float(c(mu)) for c in self.coefficients], dtype=np.float64)
+
+    def shape_functions(self, subdomain, order=0):
+        """``d.shape_functions(subdomain, order)`` (discretize_elliptic_block_swipdg.py:190-203 in 2D): the constant (order 0)
+        and, for order 1, the three coordinate functions relative to the subdomain centre, as P2 nodal vectors [n, 1 or 4]
+        (device).  The reductor starts every local basis with them (reductor.py:29-31)."""
+        if order not in (0, 1):
+            raise NotImplementedError('shape functions of order 0 and 1')
+        eng = self.engine
+        x = np.asarray(eng.t.node_coordinates(), dtype=np.float64)
+        cols = [np.ones(eng.t.n)]
+        if order == 1:
+            centre = 0.5 * (x.max(axis=0) + x.min(axis=0))
+            cols += [x[:, a] - centre[a] for a in range(3)]
+        return eng.ctx.from_numpy(np.stack(cols, axis=1))
 
     def alpha(self, mu, mu2):
         """min_q theta_q(mu) / theta_q(mu2) as written in the reference: the loop returns in its first pass
@@ -181,21 +196,169 @@ class ReducedDiscretization3D:
         return self.d.combine(eta_loc.cpu().numpy(), mu, decompose)
 
 
+class ExtensionError3D(Exception):
+    """A vector handed to ``extend_basis`` is (numerically) in the span of a local basis (pyMOR's ExtensionError)."""
+
+
 class LRBMSReductor3D:
-    """``LRBMSReductor`` (reference reductor.py:17-78) for the 3D path: local bases as one device slab [S, n, N]."""
+    """``LRBMSReductor`` (reference reductor.py:17-78) for the 3D path: the same constructor and methods, local bases as ONE
+    device slab [S, n, N_max] (ragged bases: zero columns behind the ``local_sizes()[s]`` vectors of a subdomain).
 
-    def __init__(self, d, bases):
-        self.d = d
+        LRBMSReductor3D(d, bases=None, products=None, order=None)
+            bases      ready-made local bases: a slab [S or S_ext, n, N] / list of [n, N_s] arrays (reductor.py:22-27), or None
+            products   {'domain_i': ...} of the reference is the local energy product of every subdomain (reductor.py:19,
+                       online_adaptive_lrbms.py:107); here it is ``d.engine.ops['P_diag']`` (lrbms3_assemble_energy_product) and
+                       the argument only switches it: None / anything = the energy product, 'euclidean' = plain dot products
+            order      0 / 1: start every local basis with the shape functions of that order (reductor.py:29-31)
+        extend_basis(U)            restrict a block DG function [S, n(, L)] to every subdomain, Gram-Schmidt it into the bases
+        extend_basis_local(ii, U)  the same for ONE subdomain (reductor.py:31,78)
+        reduce()                   one pass of the hot path (reductor.py:33-73)
+        reconstruct(u), reconstruct_local(u, ii)
+
+    Gram-Schmidt runs on the device: the product is applied by ``lrbms3_energy_product_apply``, the rest are batched products.
+    ``enrich_local`` (reductor.py:75-78) needs the neighbourhood corrector solves, which exist in 2D only."""
+
+    def __init__(self, d, bases=None, products=None, order=None):
+        import torch
+        self.d, self._torch = d, torch
         eng = d.engine
-        self.bases = bases if isinstance(bases, eng.ctx.torch.Tensor) else eng.ctx.from_numpy(np.asarray(bases))
-        assert tuple(self.bases.shape[:2]) == (eng.S_ext, eng.t.n)
+        self.euclidean = products == 'euclidean'
+        self._V, self._nloc = None, None
+        if bases is not None:
+            if isinstance(bases, (list, tuple)):
+                blocks = [b if isinstance(b, torch.Tensor) else eng.ctx.from_numpy(np.asarray(b)) for b in bases]
+                nmax = max(int(b.shape[1]) for b in blocks)
+                self._nloc = np.array([int(b.shape[1]) for b in blocks], dtype=np.int64)
+                V = torch.stack([torch.nn.functional.pad(b, (0, nmax - int(b.shape[1]))) for b in blocks])
+            else:
+                V = bases if isinstance(bases, torch.Tensor) else eng.ctx.from_numpy(np.asarray(bases))
+                self._nloc = np.full(V.shape[0], int(V.shape[2]), dtype=np.int64)
+            assert V.shape[0] in (eng.S, eng.S_ext) and V.shape[1] == eng.t.n
+            self._V = V.contiguous()
+        if order is not None:
+            if self._V is not None and self._V.shape[0] != eng.S:
+                raise NotImplementedError('order= with ready-made bases that already carry their halo')
+            sf = d.shape_functions(0, order)                            # the same template for every subdomain
+            self._gram_schmidt_extend(sf[None].expand(eng.S, -1, -1).contiguous())
 
+    # ------------------------------------------------------------------ bases
+    @property
+    def bases(self):
+        """The basis slab [S (or S_ext), n, N_max] (device); columns >= local_sizes()[s] of subdomain s are zero."""
+        return self._V
+
+    def basis_size(self):
+        return 0 if self._V is None else int(self._V.shape[2])
+
+    def local_sizes(self):
+        return [] if self._nloc is None else [int(v) for v in self._nloc[:self.d.engine.S]]
+
+    def _product_apply(self, X):
+        eng = self.d.engine
+        if self.euclidean:
+            return X
+        return eng.ctx.energy_product_apply(eng.ops['P_diag'], X.contiguous())
+
+    def gram(self):
+        """V^T P V per subdomain [S, N_max, N_max]: the identity on the filled columns after Gram-Schmidt (what the 2D pass returns
+        as E_red)."""
+        V = self._V[:self.d.engine.S].contiguous()
+        return self._torch.einsum('snk,snl->skl', V, self._product_apply(V))
+
+    def _orthonormalize(self, v, atol=1e-13, rtol=1e-10):
+        """Gram-Schmidt with one re-orthogonalisation of the single-column slab ``v`` [S, n, 1] against the local bases; returns the
+        normalised slab and the mask of subdomains whose block was NOT (numerically) in the span of their basis."""
+        torch = self._torch
+        S = self.d.engine.S
+        V = self._V[:S] if self._V is not None and self._V.shape[2] > 0 else None
+        v = v.clone()
+        norm0 = torch.sqrt(torch.clamp((v * self._product_apply(v)).sum(dim=(1, 2)), min=0.0))
+        for _ in range(2):
+            if V is not None:
+                coef = torch.einsum('snk,snl->skl', V, self._product_apply(v))
+                v = v - torch.einsum('snk,skl->snl', V, coef)
+        norm = torch.sqrt(torch.clamp((v * self._product_apply(v)).sum(dim=(1, 2)), min=0.0))
+        ok = (norm > atol) & (norm > rtol * norm0)
+        v = torch.where(ok[:, None, None], v / torch.where(ok, norm, torch.ones_like(norm))[:, None, None], torch.zeros_like(v))
+        return v, ok
+
+    def _append(self, v, ok):
+        torch = self._torch
+        eng = self.d.engine
+        ok_host = ok.cpu().numpy().astype(bool)
+        if self._V is None:
+            self._V = eng.ctx.zeros(eng.S, eng.t.n, 0)
+            self._nloc = np.zeros(eng.S, dtype=np.int64)
+        if self._V.shape[0] != eng.S:
+            raise NotImplementedError('extending bases that carry their halo: extend the local slab and exchange afterwards')
+        idx = np.where(ok_host)[0]
+        if len(idx) == 0:
+            return ok_host
+        if int(self._nloc[idx].max()) + 1 > self._V.shape[2]:
+            self._V = torch.cat([self._V, eng.ctx.zeros(eng.S, eng.t.n, 1)], dim=2).contiguous()
+        rows = torch.as_tensor(idx, device=self._V.device)
+        cols = torch.as_tensor(self._nloc[idx], device=self._V.device)
+        self._V[rows, :, cols] = v[rows, :, 0]
+        self._nloc[idx] += 1
+        return ok_host
+
+    def _gram_schmidt_extend(self, U):
+        """Extend EVERY local basis by the columns of U [S, n, L], one after the other (all-or-nothing per column)."""
+        for k in range(U.shape[2]):
+            v, ok = self._orthonormalize(U[:, :, k:k + 1])
+            if not bool(ok.all()):
+                raise ExtensionError3D('snapshot block is (numerically) in the span of its local basis')
+            self._append(v, ok)
+
+    def _as_slab(self, U):
+        eng = self.d.engine
+        U = U if isinstance(U, self._torch.Tensor) else eng.ctx.from_numpy(np.asarray(U))
+        if U.dim() == 2:
+            U = U[:, :, None]
+        assert tuple(U.shape[:2]) == (eng.S, eng.t.n), 'a block DG function [S, n] or [S, n, L]'
+        return U.contiguous()
+
+    def extend_basis(self, U):
+        """Restrict the block DG function(s) ``U`` [S, n] / [S, n, L] (e.g. ``d.solve(mu)``) to every subdomain and extend all
+        local bases (the fork's ``extend_basis``; online_adaptive_lrbms.py:117-121)."""
+        self._gram_schmidt_extend(self._as_slab(U))
+
+    def extend_basis_local(self, subdomain, U):
+        """Extend the basis of ONE subdomain by the vector(s) ``U`` [n] / [n, L] (reductor.py:31,78)."""
+        eng = self.d.engine
+        i = eng.local.index(int(subdomain))
+        U = U if isinstance(U, self._torch.Tensor) else eng.ctx.from_numpy(np.asarray(U))
+        U = U[:, None] if U.dim() == 1 else U
+        mask = self._torch.zeros(eng.S, dtype=self._torch.bool, device=U.device)
+        mask[i] = True
+        for k in range(U.shape[1]):
+            full = eng.ctx.zeros(eng.S, eng.t.n, 1)
+            full[i, :, 0] = U[:, k]
+            v, ok = self._orthonormalize(full)
+            if not bool(ok[i]):
+                raise ExtensionError3D('local vector is (numerically) in the span of the local basis')
+            self._append(v, ok & mask)
+
+    def enrich_local(self, subdomain, U, mu=None):
+        raise NotImplementedError('online enrichment (reductor.py:75-78: neighbourhood corrector solves) is built for the 2D path only')
+
+    # ------------------------------------------------------------------ reduce / reconstruct
     def reduce(self):
-        return ReducedDiscretization3D(self, self.d.engine.project_and_estimate(self.bases.contiguous()))
+        eng = self.d.engine
+        if self._V is None or self._V.shape[2] == 0:
+            raise RuntimeError('no basis')
+        V = self._V
+        if V.shape[0] != eng.S_ext:
+            raise NotImplementedError('sharded discretization: hand in bases [S_ext, n, N] with the halo filled (HaloExchange)')
+        return ReducedDiscretization3D(self, eng.project_and_estimate(V.contiguous()))
 
     def reconstruct(self, u):
-        import torch
-        return torch.einsum('snj,sj->sn', self.bases, u)
+        return self._torch.einsum('snj,sj->sn', self._V, u)
+
+    def reconstruct_local(self, u, subdomain):
+        """The block of ``reconstruct(u)`` on ONE subdomain [n] (reductor.py:76)."""
+        i = self.d.engine.ext.index(int(subdomain))
+        return self._V[i] @ u[i]
 
 
 def discretize(grid_and_problem_data, device_index=0):

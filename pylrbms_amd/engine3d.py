@@ -5,6 +5,7 @@ Data layout in HBM (fp64, C-contiguous; S local subdomains, S_ext = S + halo):
 
     lam    [Q][S_ext][n_T][LS]    coefficient samples at the points of the rules (grid3d.QuadratureSpec3D)
     A_diag [Q][S][n_T][5][100]    SWIPDG blocks, block-ELL over the element adjacency template (10 x 10 blocks, P2)
+    P_diag [S][n_T][5][100]       local energy product at mu_bar (the same pattern; local to every subdomain)
     A_cpl  [Q][S][6][ncf][100]    coupling blocks per side face
     V      [S_ext][n][N]          local reduced bases, DoF-major
     outputs of a pass: Native3DContext.out_shapes (factored layout, include/lrbms3d_hip.h)
@@ -21,8 +22,11 @@ def sample(fn, x):
 
 
 class Engine3D:
-    def __init__(self, grid, lambda_funcs, f, lambda_bar, lambda_hat, data_degree=2, device_index=0):
+    def __init__(self, grid, lambda_funcs, f, lambda_bar, lambda_hat, data_degree=2, device_index=0, theta_bar=None):
+        """``theta_bar`` [Q]: theta_q(mu_bar), the weights of the local energy product (reference: assembled at mu_bar,
+        discretize_elliptic_block_swipdg.py:676); default: all ones."""
         self.grid, self.t = grid, grid.template
+        self.theta_bar = np.ones(len(lambda_funcs)) if theta_bar is None else np.asarray(theta_bar, dtype=np.float64).reshape(-1)
         t = self.t
         self.spec = QuadratureSpec3D(data_degree)
         local = list(grid.subdomains_on_rank)
@@ -58,7 +62,9 @@ class Engine3D:
         b, f2, ceps, bdiv = c.assemble_rhs(self.f_smp, self.lhat)
         ebar, Aaa, Aab, Bbb = c.assemble_products(self.lam, self.lbar, self.lhat)
         Cf = c.assemble_flux(self.lam)
-        self.ops = dict(A_diag=A_diag, A_cpl=A_cpl, b=b, f2=f2, ceps=ceps, bdiv=bdiv, ebar=ebar, Aaa=Aaa, Aab=Aab, Bbb=Bbb, Cf=Cf)
+        P_diag = c.assemble_energy_product(self.theta_bar, self.lam)          # K6: local energy product at mu_bar
+        self.ops = dict(A_diag=A_diag, A_cpl=A_cpl, b=b, f2=f2, ceps=ceps, bdiv=bdiv, ebar=ebar, Aaa=Aaa, Aab=Aab, Bbb=Bbb, Cf=Cf,
+                        P_diag=P_diag)
         return self
 
     def alloc_outputs(self, N):

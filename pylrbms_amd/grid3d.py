@@ -394,6 +394,7 @@ class SubdomainTemplate3D:
           TE   [6][nB][100]          the same at rule B                                       (lambda_bar product E)
           TAA  [6][nC][100]          the same at rule C                                       (df_aa)
           TFo  [6][4][nFs][100]      inner face, (own, own) block      TFn: (own, neighbour) block      TFb: Dirichlet face
+          TPo, TPn, TPb              the PENALTY parts of TFo, TFn, TFb alone (local energy product, block_swipdg.py:651-677)
           TC   [6][4][nFf][10]       flux coefficients of the own element on an inner face   TCb: on a Dirichlet face
           TPH  [6][nB][10]           w |T| phi_i   (rhs)               TM [6][100]  mass
           TB   [6][nC][16]           w |T| psi_f . kappa^-1 psi_g   (unsigned)               TAB [6][nC][40]  w |T| grad phi_i . psi_f
@@ -432,6 +433,7 @@ class SubdomainTemplate3D:
 
         nFs, nFf = spec.nFs, spec.nFf
         TFo, TFn, TFb = (np.empty((6, 4, nFs, NLOC, NLOC)) for _ in range(3))
+        TPo, TPn, TPb = (np.empty((6, 4, nFs, NLOC, NLOC)) for _ in range(3))
         TC, TCb = np.empty((6, 4, nFf, NLOC)), np.empty((6, 4, nFf, NLOC))
         for t in range(6):
             for f in range(4):
@@ -454,10 +456,14 @@ class SubdomainTemplate3D:
                                           - s_in * po[:, :, None] * pn[:, None, :])
                         TFb[t, f] = ww * (-po[:, :, None] * d_o[:, None, :] - d_o[:, :, None] * po[:, None, :]
                                           + s_bd * po[:, :, None] * po[:, None, :])
+                        TPo[t, f] = ww * (s_in * po[:, :, None] * po[:, None, :])
+                        TPn[t, f] = ww * (-s_in * po[:, :, None] * pn[:, None, :])
+                        TPb[t, f] = ww * (s_bd * po[:, :, None] * po[:, None, :])
                     else:
                         TC[t, f] = w[:, None] * (-0.5 * d_o + s_in * po)
                         TCb[t, f] = w[:, None] * (-d_o + s_bd * po)
         out['TFo'], out['TFn'], out['TFb'] = (x.reshape(6, 4, nFs, 100) for x in (TFo, TFn, TFb))
+        out['TPo'], out['TPn'], out['TPb'] = (x.reshape(6, 4, nFs, 100) for x in (TPo, TPn, TPb))
         out['TC'], out['TCb'] = TC, TCb
         return out
 

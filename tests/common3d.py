@@ -82,7 +82,21 @@ def oracle_assembled(p, d):
     S, nT, Q = grid.num_subdomains, t.n_T, d.Q
     from pylrbms_amd.grid3d import SIDE_TO_SLOT
     out = dict(A_diag=np.zeros((Q, S, nT, 5, 10, 10)), A_cpl=np.zeros((Q, S, 6, t.ncf, 10, 10)), Cf=np.zeros((Q, S, nT, 4, 10)),
-               ebar=np.zeros((S, nT, 10, 10)), Aaa=np.zeros((Q, Q, S, nT, 10, 10)))
+               ebar=np.zeros((S, nT, 10, 10)), Aaa=np.zeros((Q, Q, S, nT, 10, 10)), P_diag=np.zeros((S, nT, 5, 10, 10)))
+    Pm = d.P.tocsr()                  # local energy product at mu_bar: block diagonal over the subdomains
+    for s in range(S):
+        dofs = d.dofs_of(s)
+        own = Pm[dofs][:, dofs].toarray().reshape(nT, 10, nT, 10)
+        off = Pm[dofs].copy()
+        off = off.tolil()
+        off[:, dofs] = 0.0
+        assert abs(off.tocsr()).max() == 0.0, 'the local energy product couples subdomains'
+        for e in range(nT):
+            out['P_diag'][s, e, 0] = own[e, :, e, :]
+            for f in range(4):
+                nb = t.nb_elem[e, f]
+                if nb >= 0:
+                    out['P_diag'][s, e, 1 + f] = own[e, :, nb, :]
     for q in range(Q):
         A = d.A_q[q].tocsr()
         F = d.F_q[q].tocsr()

@@ -77,6 +77,77 @@ def test_snapshots_bases_reduced_model_workflow():
     assert abs(rd.estimate(u, mu) - d.estimate(Ur, mu)) < 1e-8 * rd.estimate(u, mu)
 
 
+@pytest.mark.parametrize('name', ['aniso_2x2x1', 'kc_3x1x2'])
+def test_reference_reductor_surface_in_3d(name):
+    """``LRBMSReductor(d, products=..., order=0)`` + ``extend_basis(d.solve(mu))`` + ``reduce()`` (reference reductor.py:17-73, driver
+    online_adaptive_lrbms.py:105-123) in 3D: the local energy product is assembled on the device (lrbms3_assemble_energy_product,
+    checked entry by entry against the oracle in tests/test_parity3d_gpu.py), Gram-Schmidt runs on the device, the bases are
+    orthonormal in that product (V^T P V = I to 1e-9 against the ORACLE's product matrix), and the reduced model is the Galerkin
+    model on the same span as the oracle's reductor fed with the same snapshots (same reconstruction, same estimate)."""
+    import torch
+    from pylrbms_amd.discretize_elliptic_block_swipdg_3d import ExtensionError3D, LRBMSReductor3D, discretize
+    p = c3.make_problem(name)
+    o = c3.oracle_of(p)
+    pd = {'grid': p['grid'], 'lambda': {'functions': p['lambdas'], 'coefficients': p['thetas']}, 'lambda_bar': p['lambda_bar'],
+          'lambda_hat': p['lambda_hat'], 'f': p['f'], 'mu_bar': p['mu_bar'], 'mu_hat': p['mu_hat']}
+    d, _ = discretize(pd)
+    red = LRBMSReductor3D(d, products=None, order=0)                      # reductor.py:29-31: the constant starts every basis
+    assert red.local_sizes() == [1] * o.S
+    snaps = []
+    for mu in (0.2, 0.9):
+        U = d.solve(mu, rtol=1e-12)
+        snaps.append(U.cpu().numpy())
+        red.extend_basis(U)                                                # online_adaptive_lrbms.py:117-121
+    assert red.local_sizes() == [3] * o.S and red.basis_size() == 3
+    with pytest.raises(ExtensionError3D):
+        red.extend_basis(snaps[0])                                         # already in the span
+    assert red.local_sizes() == [3] * o.S
+    # orthonormal in the local energy product -- of the oracle
+    Vh = red.bases.cpu().numpy()
+    Pm = o.P.tocsr()
+    for ii in range(o.S):
+        dofs = o.dofs_of(ii)
+        G = Vh[ii].T @ (Pm[dofs][:, dofs] @ Vh[ii])
+        assert np.abs(G - np.eye(3)).max() < 1e-9
+        span = np.stack([np.ones(o.n)] + [sn[ii] for sn in snaps], axis=1)
+        coef = np.linalg.lstsq(span, Vh[ii], rcond=None)[0]
+        assert np.abs(span @ coef - Vh[ii]).max() < 1e-9 * np.abs(Vh[ii]).max()       # the same span
+    assert float((red.gram() - torch.eye(3, dtype=torch.float64, device='cuda')[None]).abs().max()) < 1e-9
+    rd = red.reduce()
+    # the oracle's reductor on the un-orthonormalised span: same Galerkin solution (reconstruction) and the same estimate
+    bases_o = [np.stack([np.ones(o.n)] + [sn[ii] for sn in snaps], axis=1) for ii in range(o.S)]
+    from oracle.lrbms3d import Reductor3D
+    ored = Reductor3D(o, bases_o)
+    ord_ = ored.reduce()
+    for mu in (0.5, 0.9):
+        u = rd.solve(mu, rtol=1e-13)
+        rec = red.reconstruct(u).cpu().numpy().ravel()
+        uo = ord_.solve(mu)
+        ref = ored.reconstruct(uo)
+        assert c3.rel(rec, ref) < 1e-8
+        assert abs(rd.estimate(u, mu) - ord_.estimate(uo, mu)) < 1e-7 * ord_.estimate(uo, mu)
+        assert c3.rel(red.reconstruct_local(u, 1).cpu().numpy(), ref[o.dofs_of(1)]) < 1e-8
+    # one subdomain alone (reductor.py:31,78): a new local vector, the others keep their size
+    w = np.random.default_rng(4).standard_normal(o.n)
+    red.extend_basis_local(1, w)
+    assert red.local_sizes() == [3, 4] + [3] * (o.S - 2) and red.basis_size() == 4
+    G = red.gram().cpu().numpy()
+    want = np.stack([np.diag([1.0] * nl + [0.0] * (4 - nl)) for nl in red.local_sizes()])
+    assert np.abs(G - want).max() < 1e-9                                   # zero-padded columns stay zero
+    rd2 = red.reduce()                                                     # ragged bases through the uniform kernels
+    u2 = rd2.solve(0.5, rtol=1e-13)
+    assert float(u2[[i for i in range(o.S) if i != 1], 3].abs().max()) == 0.0
+    bases_o[1] = np.concatenate([bases_o[1], w[:, None]], axis=1)
+    ored2 = Reductor3D(o, bases_o)
+    assert c3.rel(red.reconstruct(u2).cpu().numpy().ravel(), ored2.reconstruct(ored2.reduce().solve(0.5))) < 1e-8
+    # order = 1: the constant and the three coordinate functions, orthonormalised
+    red1 = LRBMSReductor3D(d, order=1)
+    assert red1.local_sizes() == [4] * o.S
+    assert float((red1.gram() - torch.eye(4, dtype=torch.float64, device='cuda')[None]).abs().max()) < 1e-9
+    with pytest.raises(NotImplementedError):
+        red.enrich_local(0, None, mu=0.5)
+
+
 @pytest.mark.parametrize('name', ['interior_3x3x3', 'kc_3x1x2'])
 def test_full_order_solver_with_every_coarse_space_matches_the_sparse_lu(name):
     """lrbms3_fom_solve with its two-level preconditioner: no coarse level, subdomain constants (nc = 1), P1 per subdomain

@@ -71,8 +71,19 @@ def test_table_contraction_reproduces_the_oracle_assembly(name):
         lams = [fn(xl + org) for fn in p['lambdas']]
         lh, fs, lbs = p['lambda_hat'](xh + org), p['f'](xh + org), p['lambda_bar'](xb + org)
         sg = np.where((t.nb_elem < 0) & (((phys >> np.maximum(-(t.nb_elem + 1), 0)) & 1) == 1), 1, t.tsign)     # [nT, 4]
+        th_bar = c3.theta_of(p, p['mu_bar'])
         for e in range(nT):
             ty = t.elem_type[e]
+            # local energy product (block_swipdg.py:651-677): lambda at mu_bar, penalty parts of the face tables, every face of the
+            # subdomain boundary a Dirichlet face, no coupling
+            lamb = sum(th_bar[q] * lams[q][e] for q in range(Q))
+            pblk = lamb[:spec.nA] @ T['TV'][ty]
+            for f in range(4):
+                lf = lamb[spec.o_fs + f * spec.nFs:spec.o_fs + (f + 1) * spec.nFs]
+                nb = t.nb_elem[e, f]
+                pblk = pblk + lf @ (T['TPb'] if nb < 0 else T['TPo'])[ty, f]
+                upd('P_nb', (lf @ T['TPn'][ty, f]).reshape(10, 10) if nb >= 0 else np.zeros((10, 10)), ref['P_diag'][s, e, 1 + f])
+            upd('P_diag', pblk.reshape(10, 10), ref['P_diag'][s, e, 0])
             for q in range(Q):
                 lam = lams[q][e]
                 blk = lam[:spec.nA] @ T['TV'][ty]

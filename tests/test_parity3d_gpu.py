@@ -20,7 +20,7 @@ def case(request):
     from pylrbms_amd.engine3d import Engine3D, expand_factored
     p = c3.make_problem(request.param)
     d = c3.oracle_of(p)
-    eng = Engine3D(p['grid'], p['lambdas'], p['f'], p['lambda_bar'], p['lambda_hat']).assemble()
+    eng = Engine3D(p['grid'], p['lambdas'], p['f'], p['lambda_bar'], p['lambda_hat'], theta_bar=c3.theta_of(p, p['mu_bar'])).assemble()
     V = c3.make_bases3d(d.S, d.n, p['N'], seed=3)
     Vd = eng.ctx.from_numpy(V)
     out = eng.project_and_estimate(Vd)
@@ -32,7 +32,7 @@ def case(request):
 def test_assembled_operators_match_the_oracle(case):
     p, d, eng = case['p'], case['d'], case['eng']
     ref = c3.oracle_assembled(p, d)
-    for k in ('A_diag', 'A_cpl', 'b', 'f2', 'ceps', 'bdiv', 'ebar', 'Aaa', 'Aab', 'Bbb', 'Cf'):
+    for k in ('A_diag', 'A_cpl', 'b', 'f2', 'ceps', 'bdiv', 'ebar', 'Aaa', 'Aab', 'Bbb', 'Cf', 'P_diag'):
         got = eng.ops[k].cpu().numpy().reshape(ref[k].shape)
         assert c3.rel(got, ref[k]) < TOL, (k, c3.rel(got, ref[k]))
 
