@@ -7,8 +7,17 @@ and the derived MFMA-busy and wait fractions."""
 import collections
 import csv
 import glob
+import json
+import os
 import re
 import sys
+
+# optional: --json OUT CONFIG  -> {config, csrc_sha, per_kernel: {name: {fetch_bytes_raw, write_bytes, bytes}}, per_pass_bytes} for bench3d.py
+JSON_OUT = None
+if '--json' in sys.argv:
+    i = sys.argv.index('--json')
+    JSON_OUT, JSON_CFG = sys.argv[i + 1], sys.argv[i + 2]
+    del sys.argv[i:i + 3]
 
 KINDS = {'0': 'SYS', '1': 'AAA', '2': 'NC', '3': 'AB', '4': 'BB', '5': 'RDD', '6': 'CPL'}
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -42,3 +51,20 @@ for k in sorted(tot):
             if c in avg:
                 extra.append('{}/wave_cycles={:.3f}'.format(c[3:].lower(), avg[c] / avg['SQ_WAVE_CYCLES']))
     print(row + '  ' + ' '.join(extra))
+if JSON_OUT:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from pylrbms_amd._build import source_sha
+    per, total = {}, 0.0
+    for k in sorted(tot):
+        if 'FETCH_SIZE' not in tot[k] or 'WRITE_SIZE' not in tot[k]:
+            continue
+        f = tot[k]['FETCH_SIZE'] / calls[k]['FETCH_SIZE'] * 1024.0
+        w = tot[k]['WRITE_SIZE'] / calls[k]['WRITE_SIZE'] * 1024.0
+        per[k] = {'fetch_bytes_raw': f, 'write_bytes': w, 'bytes': 2 * f + w}
+        if k.startswith(('k3_pg<', 'k3_flux', 'k3_node_avg', 'k3_side_nc')) and 'combine' not in k:
+            total += 2 * f + w
+    with open(JSON_OUT, 'w') as fh:
+        json.dump({'config': JSON_CFG, 'csrc_sha': source_sha(), 'per_kernel': per, 'per_pass_bytes': total,
+                   'fetch_correction': 'FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported',
+                   'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --config ' + JSON_CFG},
+                  fh, indent=1)
