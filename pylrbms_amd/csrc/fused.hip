@@ -1956,7 +1956,9 @@ __global__ __launch_bounds__(64 * (F2_NCW + EC)) void k_f2(Tmpl t, F2Args a) {
     int ti[TPW], tj[TPW];
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
-      int idx = cw + k * NCW, i = 0;                           // idx-th upper-triangular tile, row-major
+      int idx = ((cw + s) & (NCW - 1)) + k * NCW, i = 0;       // idx-th upper-triangular tile, row-major; rotated by the subdomain so
+                                                               // that the waves with one tile more are not always on the same SIMD
+                                                               // (a SIMD's time is the sum of its waves' MFMA streams: 125.7 -> 120.8 us)
       if (idx >= NTRI) idx = -1;
       int rem = idx;
       while (rem >= NR - i && idx >= 0) {
@@ -2044,6 +2046,10 @@ __global__ __launch_bounds__(256) void k_f3(Tmpl t, F3Args a) {
   const int N = a.N;
   for (int i = tid; i < 3 * ECH * LD; i += 256) Xs[i] = Ys[i] = 0.0;
   int ti[NT], tj[NT];
+  // (Measured and dropped, round 3: rotating the tile dealing by the subdomain index so that the waves with the extra tile of the
+  // workgroups sharing a CU sit on different SIMDs -- no change, 58 us: the kernel waits on its loads, not on the matrix pipe; a
+  // register double buffer for the next chunk's rows behind LDS-only barriers -- hipcc drains it with vmcnt(0) at the dependent
+  // index loads and the 144 VGPRs cost occupancy: 89 us.)
 #pragma unroll
   for (int k = 0; k < NT; ++k) {                 // (wave + 4 k)-th upper-triangular tile, row-major
     int idx = wave + 4 * k, i = 0;
