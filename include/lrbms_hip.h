@@ -197,6 +197,9 @@ int lrbms_estimator_grams(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V,
  * lrbms_fused_factored_supported for the factored one (lrbms_project_estimate_fused_factored below), which needs less
  * LDS and also takes large templates (k_c = 16).  work >= lrbms_fused_work_size doubles. */
 int lrbms_fused_supported(lrbms_ctx* ctx, int32_t Q, int32_t N);
+/* Row length (doubles) of F_nc [S][4][nvs][.]: 2 N + 4 nvs, plus N with LRBMS_OPT_OSWALD_VERTEX_PATCH (the diagonal subdomain's
+ * share of the vertex average at the two corner vertices a side carries: A_a | C_a | M_a0 .. M_a3 | A_diag). */
+int32_t lrbms_fused_fnc_ld(lrbms_ctx* ctx, int32_t N);
 /* v_mfma_f64_16x16x4_f64 instructions (2 048 flops each, padding included) the dense projection kernel of the fused pass
  * executes per subdomain for this shape under the context's launch options (measurement only: roofline of bench.py). */
 int64_t lrbms_fused_mfma_per_subdomain(lrbms_ctx* ctx, int32_t Q, int32_t N);
@@ -228,7 +231,14 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
  *       boundary info on the subdomain layer to apply_oswald_interpolation_operator
  *   LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q       0 (default): one coupling matrix per affine component; 1: component q
  *       carries the coupling terms of all components q' <= q, as discretize_elliptic_block_swipdg.py:551-565 (matrices
- *       allocated once) with :581-583 (assembled into for every lambda) would if the assembler does not zero them */
+ *       allocated once) with :581-583 (assembled into for every lambda) would if the assembler does not zero them
+ *   LRBMS_OPT_OSWALD_VERTEX_PATCH                0 (default): the Oswald average at a vertex runs over the elements of the
+ *       subdomain and of its FACE neighbours (HEAD: grid.neighborhood_of, discretize_elliptic_block_swipdg.py:78-113); 1: over
+ *       every element at the vertex -- at a cross point also the elements of the diagonal subdomain -- the reading that
+ *       reproduces the nonconformity value the reference prints (linearelliptic_block_swipdg_decomp.py:41: 1.66e-01).
+ *       Factored layout of the fused pass only (rows of F_nc grow by N columns, lrbms_fused_fnc_ld), all subdomains on one
+ *       rank (S_ext == S); the dense layout and the unfused kernels have five slots per neighbourhood and refuse it */
+#define LRBMS_OPT_OSWALD_VERTEX_PATCH 9
 #define LRBMS_OPT_OSWALD_ZERO_ON_SUBDOMAIN_BOUNDARY 1
 #define LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q 2
 /* Launch policy of the library (no numerical convention; every setting gives the same results up to the summation order the

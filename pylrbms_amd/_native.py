@@ -50,6 +50,7 @@ SIGNATURES = {
     'lrbms_estimator_grams': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 16),
     'lrbms_fused_supported': (ctypes.c_int, [c_vp, c_i32, c_i32]),
     'lrbms_fused_mfma_per_subdomain': (c_i64, [c_vp, c_i32, c_i32]),
+    'lrbms_fused_fnc_ld': (c_i32, [c_vp, c_i32]),
     'lrbms_fused_factored_supported': (ctypes.c_int, [c_vp, c_i32, c_i32]),
     'lrbms_fused_work_size': (c_i64, [c_vp, c_i32, c_i32]),
     'lrbms_project_estimate_fused': (ctypes.c_int, [c_vp, c_i32, c_i32] + [c_vp] * 22),
@@ -354,8 +355,8 @@ class NativeContext:
         return 4 * Q * N + 4
 
     def fnc_ld(self, N):
-        """Row length of F_nc [S, 4, nvs, .]: A_a | C_a | M_a0 .. M_a3 (include/lrbms_hip.h)."""
-        return 2 * N + 4 * self.nvs
+        """Row length of F_nc [S, 4, nvs, .]: A_a | C_a | M_a0 .. M_a3 (| A_diag with the vertex-patch option) (include/lrbms_hip.h)."""
+        return int(self.lib.lrbms_fused_fnc_ld(self.handle, int(N)))
 
     def _gram_ptrs(self, grams, Q, N):
         """Pointers of the projected estimator operators in either layout: 6 tensors = dense (G_rdd / G_bb block-compact
@@ -519,7 +520,7 @@ class NativeContext:
                                                 c_vp(pc.data_ptr()) if pc is not None else None)
         self._check(rc, 'lrbms_reduced_precond_use')
 
-    OPTIONS = {'oswald_zero_on_subdomain_boundary': 1, 'accumulate_coupling_across_q': 2,
+    OPTIONS = {'oswald_zero_on_subdomain_boundary': 1, 'accumulate_coupling_across_q': 2, 'oswald_vertex_patch': 9,
                # launch policy (no numerical convention): the library reads no environment variable
                'streams': 3, 'f1_ksplit': 4, 'f1_form': 5, 'coarse': 6, 'solve_valu': 7, 'estimate_valu': 8}
 

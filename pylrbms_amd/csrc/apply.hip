@@ -360,6 +360,9 @@ inline unsigned grid_for(long total) {
 
 int launch_oswald(lrbms_ctx* ctx, int N, const double* V, double* Wt, hipStream_t st) {
   const Tmpl& t = ctx->t;
+  if (t.opt_oswald_vertex)
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "LRBMS_OPT_OSWALD_VERTEX_PATCH: the image basis Wt has five slots per subdomain, the "
+                                            "diagonal subdomains enter through the factored layout of the fused pass only");
   hipLaunchKernelGGL(k_oswald, dim3(grid_for((long)ctx->S * t.n * N)), dim3(256), 0, st, t, ctx->S, ctx->nbr, N, V, Wt);
   LRBMS_LAUNCH_CHECK(ctx);
   return LRBMS_OK;

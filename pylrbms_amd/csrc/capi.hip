@@ -167,6 +167,7 @@ int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value) {
   switch (option) {
     case LRBMS_OPT_OSWALD_ZERO_ON_SUBDOMAIN_BOUNDARY: ctx->t.opt_oswald_subdomain = value; break;
     case LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q: ctx->t.opt_accumulate_coupling = value; break;
+    case LRBMS_OPT_OSWALD_VERTEX_PATCH: ctx->t.opt_oswald_vertex = value; break;
     case LRBMS_OPT_STREAMS: ctx->opt_streams = value; break;
     case LRBMS_OPT_F1_KSPLIT: ctx->opt_f1_ksplit = value; break;
     case LRBMS_OPT_F1_FORM: ctx->opt_f1_legacy = value; break;
@@ -386,6 +387,12 @@ int lrbms_estimator_grams(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* V,
   CHECK_PTR(ctx, r_fd); CHECK_PTR(ctx, G_rdd); CHECK_PTR(ctx, G_bb); CHECK_PTR(ctx, G_ab); CHECK_PTR(ctx, G_aa);
   return launch_estimator_grams(ctx, Q, N, V, Wt, Rt, ebar, caa, Aab, Bbb, b, work, G_nc, r_fd, G_rdd, G_bb, G_ab, G_aa,
                                 (hipStream_t)stream);
+}
+
+int32_t lrbms_fused_fnc_ld(lrbms_ctx* ctx, int32_t N) {
+  if (!ctx || !ctx->has_mesh || N < 1) return -1;
+  const int nvs = ctx->t.nvx > ctx->t.nvy ? ctx->t.nvx : ctx->t.nvy;
+  return 2 * N + 4 * nvs + (ctx->t.opt_oswald_vertex ? N : 0);
 }
 
 int64_t lrbms_fused_mfma_per_subdomain(lrbms_ctx* ctx, int32_t Q, int32_t N) {

@@ -119,6 +119,9 @@ struct OsInfo {
   double inv;
   int vside[4];
   int pos[4];   // position of the vertex along the side
+  // LRBMS_OPT_OSWALD_VERTEX_PATCH: at a cross point (a corner vertex whose two side neighbours exist) the matching corner vertex
+  // of the DIAGONAL subdomain, the corner id (0 SW, 1 SE, 2 NW, 3 NE) and the two sides that meet there; -1 otherwise
+  int vdiag, corner, sda, sdb;
 };
 
 __device__ inline OsInfo oswald_vertex(const Tmpl& t, const int* nbr_s, int v) {
@@ -138,6 +141,17 @@ __device__ inline OsInfo oswald_vertex(const Tmpl& t, const int* nbr_s, int v) {
       dirichlet = true;
     else
       cnt += t.vdof_ptr[o.vside[sd] + 1] - t.vdof_ptr[o.vside[sd]];
+  }
+  o.vdiag = o.corner = o.sda = o.sdb = -1;
+  const bool cx = lx == 0 || lx == t.nvx - 1, cy = ly == 0 || ly == t.nvy - 1;
+  if (t.opt_oswald_vertex && cx && cy && !dirichlet) {
+    // a corner vertex whose two sides both have a neighbour: on the Cartesian subdomain grid the diagonal subdomain exists, and
+    // its elements at the opposite corner belong to the patch
+    o.corner = (ly == 0 ? 0 : 2) + (lx == 0 ? 0 : 1);
+    o.sda = ly == 0 ? 0 : 3;
+    o.sdb = lx == 0 ? 1 : 2;
+    o.vdiag = (lx == 0 ? t.nvx - 1 : 0) + t.nvx * (ly == 0 ? t.nvy - 1 : 0);
+    cnt += t.vdof_ptr[o.vdiag + 1] - t.vdof_ptr[o.vdiag];
   }
   o.inv = dirichlet ? 0.0 : 1.0 / (double)cnt;
   return o;
@@ -265,6 +279,22 @@ __device__ __forceinline__ void vertex_avg_body(const Tmpl& t, int S, const int*
         a2 *= o.inv;
       }
       AvgSide[(((long)s * 4 + sd) * nvs + o.pos[sd]) * N + j] = a2;
+    }
+    if (t.opt_oswald_vertex) {
+      // the diagonal subdomain's share at the four corner vertices: Avg_corner [S][4][N], behind Avg_side in the work buffer
+      const int lx = v % t.nvx, ly = v / t.nvx;
+      if ((lx == 0 || lx == t.nvx - 1) && (ly == 0 || ly == t.nvy - 1)) {
+        double a3 = 0.0;
+        if (o.vdiag >= 0) {
+          const int sd1 = nbr[s * 5 + side_to_slot(o.sda)];                      // exists: the vertex is not on a Dirichlet side
+          const int sdg = nbr[sd1 * 5 + side_to_slot(o.sdb)];                    // one rank holds every subdomain (checked by the launcher)
+          const int q0 = t.vdof_ptr[o.vdiag], q1 = t.vdof_ptr[o.vdiag + 1];
+          for (int pb = q0; pb < q1; ++pb) a3 += V[((long)sdg * t.n + t.vdof_idx[pb]) * N + j];
+          a3 *= o.inv;
+        }
+        const int corner = (ly == 0 ? 0 : 2) + (lx == 0 ? 0 : 1);
+        (AvgSide + (long)S * 4 * nvs * N)[((long)s * 4 + corner) * N + j] = a3;
+      }
     }
   }
 }
@@ -2323,7 +2353,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 
 // and the factored layout stores one row per (side, side vertex):  F_nc [S][4][nvs][2 N + 4 nvs] = A_a | C_a | M_a0 .. M_a3
 // (26 KB per subdomain at config 3 instead of the 115 KB of the nine N x N blocks; the estimate kernels contract the rows
 // with the coefficient vectors directly).  Rows of vertices a side does not have, and of sides without neighbour, are zero.
-__host__ __device__ inline int fnc_ld(int nvs, int N) { return 2 * N + 4 * nvs; }
+__host__ __device__ inline int fnc_ld(int nvs, int N, int vertex_patch = 0) { return 2 * N + 4 * nvs + (vertex_patch ? N : 0); }
 constexpr int NCF_ROWS = 8;   // rows listed per side vertex in k_thin_ncf (4 in the 8-triangle pattern)
 
 struct ThinNcfArgs {
@@ -2336,7 +2366,7 @@ struct ThinNcfArgs {
 __device__ __forceinline__ void thin_ncf_body(const Tmpl& t, const ThinNcfArgs& a, int side, int s) {
   extern __shared__ double lds[];
   const int slot = side_to_slot(side), tid = threadIdx.x, N = a.N;
-  const int nvs = nvs_of(t), LD = fnc_ld(nvs, N);
+  const int nvs = nvs_of(t), LD = fnc_ld(nvs, N, t.opt_oswald_vertex);
   double* Fs = a.Fnc + ((long)s * 4 + side) * nvs * LD;
   const int s2 = a.nbr[s * 5 + slot];
   if (s2 < 0) {
@@ -2403,6 +2433,15 @@ __device__ __forceinline__ void thin_ncf_body(const Tmpl& t, const ThinNcfArgs& 
     }
     Fs[(long)pos * LD + j] = pos < nside ? Aa[(long)pos * N + j] : 0.0;
     Fs[(long)pos * LD + N + j] = c;
+    if (t.opt_oswald_vertex) {
+      // A_diag: the diagonal subdomain's share of the vertex average at a cross point, carried by the sides 0 (S) and 3 (N) at
+      // their end vertices (corner 0 SW / 1 SE on side 0, 2 NW / 3 NE on side 3); it multiplies the DIAGONAL subdomain's
+      // coefficients in the estimate (z_a[pos] += A_diag . u_diag)
+      const bool carries = (side == 0 || side == 3) && (pos == 0 || pos == t.nvx - 1);
+      const int corner = (side == 0 ? 0 : 2) + (pos == 0 ? 0 : 1);
+      const double* Ac = a.AvgSide + (long)a.S * 4 * nvs * N;
+      Fs[(long)pos * LD + 2 * N + 4 * nvs + j] = carries ? Ac[((long)s * 4 + corner) * N + j] : 0.0;
+    }
   }
   // M_ab: one item per (side vertex, other side b, vertex of b)
   for (int it = tid; it < nvs * 4 * nvs; it += 256) {
@@ -2799,7 +2838,7 @@ int64_t fused_fside_size(lrbms_ctx* ctx, int Q, int N) { return (long)ctx->S * 4
 
 int64_t fused_fnc_size(lrbms_ctx* ctx, int N) {
   const int nvs = ctx->t.nvx > ctx->t.nvy ? ctx->t.nvx : ctx->t.nvy;
-  return (long)ctx->S * 4 * nvs * fnc_ld(nvs, N);
+  return (long)ctx->S * 4 * nvs * fnc_ld(nvs, N, ctx->t.opt_oswald_vertex);
 }
 
 namespace {
@@ -2997,6 +3036,9 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   double* AvgSide = AvgSelf + (long)S * t.nv * N;
   const bool factored = Fside != nullptr;
   if (factored != (Fnc != nullptr)) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: F_side and F_nc go together");
+  if (t.opt_oswald_vertex && (!factored || phase != 0 || ctx->S_ext != ctx->S))
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "LRBMS_OPT_OSWALD_VERTEX_PATCH: the diagonal subdomains enter through the factored layout "
+                                            "only (F_nc), whole pass, all subdomains on one rank");
   if (!factored) Fside = AvgSide + (long)S * 4 * nvs * N;
   const long gstride = factored ? (long)QN * QN : (long)9 * QN * QN;      // self blocks of G_bb / G_rdd
   const int abld = factored ? QN : C;                                     // row length of G_ab

@@ -29,6 +29,10 @@ struct Tmpl {
   // conventions the reference tree leaves open (lrbms_ctx_set_option; defaults = DESIGN.md section 3)
   int opt_oswald_subdomain;      // 1: the Oswald interpolant vanishes on the WHOLE subdomain boundary (block_swipdg.py:108-113 read
                                  //    literally: all-Dirichlet boundary info on the subdomain layer), 0: on the physical boundary only
+  int opt_oswald_vertex;         // 1: the Oswald vertex patch is every element at the vertex (at a cross point also the elements of the
+                                 //    DIAGONAL subdomain), the reading that reproduces the reference's printed nonconformity value
+                                 //    (linearelliptic_block_swipdg_decomp.py:41); 0: the elements of the subdomain and its FACE neighbours
+                                 //    (HEAD: grid.neighborhood_of, block_swipdg.py:78-113).  Factored layout, one rank only.
   int opt_accumulate_coupling;   // 1: coupling matrices accumulate across the affine components q (block_swipdg.py:551-565 vs
                                  //    :581-583), 0: one coupling matrix per component
 };

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
                                                           const double* __restrict__ G_aa, const double* __restrict__ Fside,
                                                           const double* __restrict__ Fnc, int ncf, int nvs,
                                                           const double* __restrict__ f2, const double* __restrict__ ceps,
-                                                          double hdiam, double* __restrict__ eta_loc) {
+                                                          double hdiam, double* __restrict__ eta_loc, int nvx_patch) {
+  // nvx_patch > 0: LRBMS_OPT_OSWALD_VERTEX_PATCH (value: vertices per x-side) -- rows of F_nc carry A_diag, see k_thin_ncf
   extern __shared__ double lds[];
   const int s = blockIdx.x;
   const int W = 5 * N, C = 5 * Q * N;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
       for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
       if (lane == 0) fac[it] = d;
     }
-    const int LDn = 2 * N + 4 * nvs;
+    const int LDn = 2 * N + 4 * nvs + (nvx_patch > 0 ? N : 0);
     for (int it = wave; it < 4 * nvs * 2; it += nw) {
       const int row = it >> 1, k = it & 1, side = row / nvs;
       const double* x = Fnc + ((long)s * 4 * nvs + row) * LDn + k * N;
@@ -126,6 +127,25 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
       if (lane == 0) facn[it] = d;
     }
     __syncthreads();
+    if (nvx_patch > 0) {
+      // cross points: the diagonal subdomain's share of the vertex average joins z of the side that carries the corner
+      // (z_a[pos] += A_diag . u_diag); corners 0 SW / 1 SE on side 0, 2 NW / 3 NE on side 3
+      if (wave < 4) {
+        const int corner = wave, side = corner < 2 ? 0 : 3, pos = (corner & 1) ? nvx_patch - 1 : 0;
+        const int sa = nbr[s * 5 + (corner < 2 ? 0 : 4)];                     // S / N neighbour
+        const int sd = sa >= 0 ? nbr[sa * 5 + ((corner & 1) ? 3 : 1)] : -1;   // ... and its E / W neighbour: the diagonal subdomain
+        const int row = side * nvs + pos;
+        double d = 0.0;
+        if (sd >= 0) {
+          const double* x = Fnc + ((long)s * 4 * nvs + row) * LDn + 2 * N + 4 * nvs;
+          const double* y = u + (long)sd * N;
+          for (int c = lane; c < N; c += 64) d += x[c] * y[c];
+        }
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+        if (lane == 0) facn[2 * row] += d;
+      }
+      __syncthreads();
+    }
     for (int row = threadIdx.x; row < 4 * nvs; row += blockDim.x) {
       const double* m = Fnc + ((long)s * 4 * nvs + row) * LDn + 2 * N;
       double mz = 0.0;
@@ -504,10 +524,13 @@ int launch_reduced_estimate(lrbms_ctx* ctx, int Q, int N, const double* theta, c
   QVec th;
   for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
   if ((Fside != nullptr) != (Fnc != nullptr)) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate: F_side and F_nc go together");
+  if (ctx->t.opt_oswald_vertex && (Fnc == nullptr || ctx->S_ext != ctx->S))
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "LRBMS_OPT_OSWALD_VERTEX_PATCH: factored layout, all subdomains on one rank");
   const int nvs = ctx->t.nvx > ctx->t.nvy ? ctx->t.nvx : ctx->t.nvy;
   const size_t lds = sizeof(double) * (5 * N + 5 * Q * N + 256 + 4 * ctx->t.ncf * (3 + Q) + 8 * nvs);
   hipLaunchKernelGGL(k_reduced_estimate, dim3(ctx->S), dim3(256), lds, st, ctx->S, ctx->nbr, Q, N, th, u, G_nc, r_fd,
-                     G_rdd, G_bb, G_ab, G_aa, Fside, Fnc, ctx->t.ncf, nvs, f2, ceps, hdiam, eta_loc);
+                     G_rdd, G_bb, G_ab, G_aa, Fside, Fnc, ctx->t.ncf, nvs, f2, ceps, hdiam, eta_loc,
+                     ctx->t.opt_oswald_vertex ? ctx->t.nvx : 0);
   LRBMS_LAUNCH_CHECK(ctx);
   return LRBMS_OK;
 }
@@ -2115,7 +2138,7 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
                                                                      const double* __restrict__ Fside, const double* __restrict__ Fnc,
                                                                      int ncf, int nvs, const double* __restrict__ f2,
                                                                      const double* __restrict__ ceps, double hdiam,
-                                                                     double* __restrict__ eta_loc, int ldu, int m0) {
+                                                                     double* __restrict__ eta_loc, int ldu, int m0, int nvx_patch) {
   extern __shared__ double lds[];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4, wave = tid >> 6;
   const int W = 5 * N, QN = Q * N, C = 5 * QN;
@@ -2127,8 +2150,21 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
   double* ur = uo + Wp * 16;        // [Cp][16]  theta_q(mu_m) * coefficient: row order (slot, q, j), factored: (q, j) of the own slot
   double* red = ur + Cp * 16;       // [EST_NW][3][16]
   double* zn = red + EST_NW * 3 * 16;   // [Zp][16]  (factored layout) z_a = A_a u_a per side vertex, rows (side, vertex)
+  double* dcn = zn + Zp * 16;           // [4][16]   LRBMS_OPT_OSWALD_VERTEX_PATCH: A_diag . u_diag per corner and parameter
   for (int i = tid; i < (Wp + Cp) * 16; i += 64 * EST_NW) lds[i] = 0.0;
   for (int i = tid; i < Zp * 16; i += 64 * EST_NW) zn[i] = 0.0;
+  if (nvx_patch > 0 && tid < 64) {
+    // cross points (see k_reduced_estimate): thread = (corner, parameter)
+    const int corner = tid >> 4, m = tid & 15, side = corner < 2 ? 0 : 3, pos = (corner & 1) ? nvx_patch - 1 : 0;
+    const int sa = nbr[s * 5 + (corner < 2 ? 0 : 4)];
+    const int sd = sa >= 0 ? nbr[sa * 5 + ((corner & 1) ? 3 : 1)] : -1;
+    double d = 0.0;
+    if (sd >= 0 && m < nmu) {
+      const double* x = Fnc + ((long)s * 4 * nvs + side * nvs + pos) * (3 * N + 4 * nvs) + 2 * N + 4 * nvs;
+      for (int c = 0; c < N; ++c) d += x[c] * u[((long)sd * N + c) * ldu + m0 + m];
+    }
+    dcn[tid] = d;
+  }
   __syncthreads();
   for (int i = tid; i < W * nmu; i += 64 * EST_NW) {
     const int row = i / nmu, m = i - row * nmu, slot = row / N, j = row - slot * N;
@@ -2155,7 +2191,7 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
   if (factored) {
     // nonconformity side terms from F_nc (k_thin_ncf): z_a = A_a u_a, then sum_a z_a^T (2 C_a u_s + sum_b M_ab z_b); the
     // z panel of all four sides goes through LDS (every side needs every other side's)
-    const int LDn = 2 * N + 4 * nvs;
+    const int LDn = 2 * N + 4 * nvs + (nvx_patch > 0 ? N : 0);
     for (int side = wave; side < 4; side += EST_NW) {
       const double* ua = uo + (side < 2 ? side : side + 1) * N * 16;
       side_factored(Fside + ((long)s * 4 + side) * ncf * (4 * QN + 4), ncf, Q, N, ua, zs, ui, thl, a_r, a_df);
@@ -2168,8 +2204,11 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
         for (int rr = 0; rr < 4; ++rr) {
           const int row = tile * 16 + lk + 4 * rr;
           if (row < nvs) {
-            zn[(side * nvs + row) * 16 + li] = Tz[rr];
-            a_nc += 2.0 * Tz[rr] * Tc[rr];
+            double zz = Tz[rr];
+            if (nvx_patch > 0 && (side == 0 || side == 3) && (row == 0 || row == nvx_patch - 1))
+              zz += dcn[((side == 0 ? 0 : 2) + (row == 0 ? 0 : 1)) * 16 + li];      // the diagonal subdomain's share at a cross point
+            zn[(side * nvs + row) * 16 + li] = zz;
+            a_nc += 2.0 * zz * Tc[rr];
           }
         }
       }
@@ -2222,7 +2261,7 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
     // second half of the nonconformity side terms, z_a^T M_ab z_b: needs the z panel of every side, so it comes behind a
     // barrier -- placed here, after the tiles of the self operators, so that no wave waits for the side waves' first half
     __syncthreads();
-    const int LDn = 2 * N + 4 * nvs;
+    const int LDn = 2 * N + 4 * nvs + (nvx_patch > 0 ? N : 0);
     for (int side = wave - 4; side >= 0 && side < 4; side += EST_NW) {
       const double* Fn = Fnc + ((long)s * 4 + side) * nvs * LDn + 2 * N;
       for (int tile = 0; tile * 16 < nvs; ++tile) {
@@ -2270,6 +2309,8 @@ int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const d
                                   const double* G_aa, const double* Fside, const double* Fnc, const double* f2, const double* ceps,
                                   double hdiam, double* eta_loc, hipStream_t st) {
   if ((Fside != nullptr) != (Fnc != nullptr)) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: F_side and F_nc go together");
+  if (ctx->t.opt_oswald_vertex && (Fnc == nullptr || ctx->S_ext != ctx->S))
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "LRBMS_OPT_OSWALD_VERTEX_PATCH: factored layout, all subdomains on one rank");
   const int nvs = ctx->t.nvx > ctx->t.nvy ? ctx->t.nvx : ctx->t.nvy;
   if (nmu < 1 || nmu > 64) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: need 1 <= nmu <= 64");
   // passes of <= 16 parameters over the same u / eta_loc arrays (column offset m0): the layout lrbms_reduced_solve_batch returns
@@ -2283,13 +2324,14 @@ int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const d
       for (int q = 0; q < 8; ++q) th.v[m * 8 + q] = (m < nm && q < Q) ? theta[(m0 + m) * Q + q] : 0.0;
     if (Fside != nullptr || ctx->opt_estimate_valu == 0) {   // matrix-core form (default; the only one for the factored layout)
       const size_t ldm = sizeof(double) * ((size_t)(((5 * N + 3) & ~3) + (Fside ? ((Q * N + 3) & ~3) + ((4 * nvs + 3) & ~3) : (5 * Q * N + 3) & ~3)) * 16 +
-                                           EST_NW * 3 * 16);
+                                           EST_NW * 3 * 16 + 64);
       if (ldm > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
       if (ldm > 64 * 1024)
         LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)ldm));
       hipLaunchKernelGGL(k_reduced_estimate_batch_mfma, dim3(ctx->S), dim3(64 * EST_NW), ldm, st, ctx->S, ctx->nbr, Q, N, nm, th, u, G_nc, r_fd,
-                         G_rdd, G_bb, G_ab, G_aa, Fside, Fnc, ctx->t.ncf, nvs, f2, ceps, hdiam, eta_loc, nmu, m0);
+                         G_rdd, G_bb, G_ab, G_aa, Fside, Fnc, ctx->t.ncf, nvs, f2, ceps, hdiam, eta_loc, nmu, m0,
+                         ctx->t.opt_oswald_vertex ? ctx->t.nvx : 0);
     } else {
       if (lds > 64 * 1024)
         LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

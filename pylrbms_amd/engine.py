@@ -285,6 +285,9 @@ def expand_factored_grams(grams, ncf=None):
     Gnc_s, r_fd, Gd_s, Gb_s, Gab_s, G_aa, Fs, Fn = grams
     Q, S, N, QN = Gab_s.shape[0], Gab_s.shape[1], Gab_s.shape[2], Gab_s.shape[3]
     nvs = Fn.shape[2]
+    if Fn.shape[3] != 2 * N + 4 * nvs:
+        raise NotImplementedError('F_nc carries the diagonal subdomains (conventions={"oswald_vertex_patch": True}): the dense '
+                                  'block layout has five slots per neighbourhood and cannot hold them -- use the estimates')
     A, Cn, M = Fn[..., :N], Fn[..., N:2 * N], Fn[..., 2 * N:].reshape(S, 4, nvs, 4, nvs)
     G_nc = torch.zeros(S, 5 * N, 5 * N, dtype=Fs.dtype, device=Fs.device)
     G_nc[:, 2 * N:3 * N, 2 * N:3 * N] = Gnc_s

@@ -17,7 +17,7 @@ import json
 import numpy as np
 
 FORMAT_VERSION = '2'      # 2: the header also pins the quadrature orders and the open conventions the stored arrays were computed with
-CONVENTION_NAMES = ('oswald_zero_on_subdomain_boundary', 'accumulate_coupling_across_q')
+CONVENTION_NAMES = ('oswald_zero_on_subdomain_boundary', 'accumulate_coupling_across_q', 'oswald_vertex_patch')
 _GRAMS = ('G_nc', 'r_fd', 'G_rdd', 'G_bb', 'G_ab', 'G_aa')
 _SYS = ('B_sys', 'rhs_red', 'E_red', 'M_red')
 

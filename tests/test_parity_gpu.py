@@ -236,6 +236,58 @@ def test_forms_of_the_projection_kernel_agree(shape, kc, N):
             assert torch.equal(G_aa[q, q2], G_aa[q2, q].transpose(1, 2))
 
 
+@pytest.mark.parametrize('shape, kc, N', [((3, 3), 2, 5), ((4, 3), 1, 2), ((2, 2), 2, 40)])
+def test_vertex_patch_of_the_oswald_interpolation(shape, kc, N):
+    """LRBMS_OPT_OSWALD_VERTEX_PATCH (conventions={'oswald_vertex_patch': True}): the Oswald average at a cross point runs over
+    the elements of ALL four subdomains that meet there -- the reading that reproduces the reference's printed nonconformity value
+    (tests/test_reference_pin.py) -- instead of HEAD's subdomain + face neighbours.  The diagonal subdomains enter through the
+    factored layout (one more column block A_diag in F_nc, added to z at the corner vertices by the estimate kernels): local
+    nonconformity terms of a reduced model against the oracle's reductor with ``oswald_patch='vertex'`` (1e-10), single and
+    batched; residual and diffusive-flux terms are untouched; the dense five-slot layout refuses the option."""
+    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd._native import NativeError
+    from pylrbms_amd.engine import Engine
+    from oracle.lrbms import OracleReductor
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(shape), 'coarse_per_subdomain': kc})
+    lam = p['lambda']
+    eng = Engine(p['grid'], lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], theta_bar_of(p),
+                 conventions={'oswald_vertex_patch': True}).assemble()
+    head = _engine(p)
+    d = oracle_from_problem(p, oswald_patch='vertex')
+    V = energy_orthonormalize(make_bases(d.S, d.n, N, seed=12), d)
+    Vd = eng.ctx.from_numpy(V)
+    buf = eng.project_and_estimate(Vd)
+    assert buf['grams'][7].shape[3] == 3 * N + 4 * eng.ctx.nvs          # A_a | C_a | M | A_diag
+    rd = OracleReductor(d, [V[ii] for ii in range(d.S)]).reduce()
+    rng = np.random.default_rng(3)
+    mus = [0.15, 0.6, 1.0]
+    U = rng.standard_normal((d.S, N, len(mus)))
+    thetas = np.stack([theta_of(p, mu) for mu in mus])
+    eta_b = eng.ctx.reduced_estimate_batch(thetas, eng.ctx.from_numpy(U), buf['grams'], eng.f2, eng.ceps, eng.hdiam).cpu().numpy()
+    buf_h = head.project_and_estimate(head.ctx.from_numpy(V))
+    differs = 0.0
+    for m, mu in enumerate(mus):
+        um = np.ascontiguousarray(U[:, :, m])
+        eta_s = eng.reduced_estimate(thetas[m], eng.ctx.from_numpy(um), buf['grams']).cpu().numpy()
+        _, (nc, r, df), _ = rd.estimate([um[ii] for ii in range(d.S)], mu, decompose=True)
+        for row, ref_row in enumerate((nc, r, df)):
+            scale = max(np.abs(ref_row).max(), 1e-300)
+            assert np.abs(eta_s[row] - ref_row).max() < 1e-10 * scale, (m, row)
+            assert np.abs(eta_b[row, :, m] - ref_row).max() < 1e-10 * scale, (m, row)
+        eta_h = head.reduced_estimate(thetas[m], head.ctx.from_numpy(um), buf_h['grams']).cpu().numpy()
+        assert np.abs(eta_h[1] - eta_s[1]).max() < 1e-12 * np.abs(eta_s[1]).max()          # residual, diffusive flux: the same
+        assert np.abs(eta_h[2] - eta_s[2]).max() < 1e-12 * np.abs(eta_s[2]).max()
+        differs = max(differs, float(np.abs(eta_h[0] - eta_s[0]).max() / np.abs(eta_s[0]).max()))
+    assert differs > 1e-4                                                # the two readings are different operators (cross points exist)
+    with pytest.raises(NativeError, match='VERTEX_PATCH'):
+        eng.project_and_estimate(Vd, eng.alloc_reduce_buffers(N, factored=False))            # dense five-slot layout
+    with pytest.raises(NativeError, match='VERTEX_PATCH'):
+        eng.ctx.oswald_apply(Vd)                                                              # five-slot image basis
+    from pylrbms_amd.engine import expand_factored_grams
+    with pytest.raises(NotImplementedError):
+        expand_factored_grams(buf['grams'])
+
+
 def test_full_size_properties_config3(monkeypatch):
     """BASELINE.json config 3 at full size (32x32 subdomains, N = 40: the benchmark workload).  Size-independent
     properties: the fused pass gives bit-identical results with its kernels serial or forked over the library's

@@ -140,6 +140,23 @@ def test_product_reproduces_the_three_printed_indicators():
 
 
 @pytest.mark.gpu
+def test_product_with_the_vertex_patch_reproduces_all_three_printed_indicators():
+    """``discretize(..., conventions={'oswald_vertex_patch': True})``: the product's full-order estimate with the Oswald patch over
+    every element at a vertex -- all three printed values of linearelliptic_block_swipdg_decomp.py:41-43 to their three digits,
+    and the oracle's vertex reading to 1e-9."""
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    p = OS2015_academic_problem.init_grid_and_problem(CONFIG_4x4)
+    d, _ = discretize(p, conventions={'oswald_vertex_patch': True})
+    d.estimator = d.estimator.with_(sqrt_local=True)
+    mu = d.parse_parameter(1.)
+    _, (nc, r, df), _ = d.estimate(d.solve(mu), mu=mu, decompose=True)
+    got = {'nc': np.linalg.norm(nc), 'r': np.linalg.norm(r), 'df': np.linalg.norm(df)}
+    for k, v in OBSERVED_4x4['vertex'].items():
+        assert abs(got[k] - v) < 1e-9 * v, (k, got[k])
+        assert abs(got[k] - PRINTED[k]) < 0.5e-3, (k, got[k])
+
+
+@pytest.mark.gpu
 def test_product_reproduces_the_reference_estimate():
     """The same number through the product: init_grid_and_problem -> discretize -> d.solve -> d.estimate
     (online_adaptive_lrbms.py:67-95), HIP kernels end to end."""
