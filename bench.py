@@ -338,6 +338,12 @@ def main():
     elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = S_total * args.steps / elapsed
+    # the timed passes left their results in `buf`: every output finite, one checksum on record (same seed => same value)
+    outs = {'{}[{}]'.format(k, i): v for k in ('sys', 'grams') for i, v in enumerate(buf[k])}
+    bad = [k for k, v in outs.items() if not bool(torch.isfinite(v).all())]
+    if bad:
+        raise RuntimeError('non-finite outputs of the timed pass: ' + ', '.join(bad))
+    output_checksum = float(sum(float(v.sum()) for v in outs.values()))
 
     # the dense (fp64-MFMA) kernels of the pass on their own: phase 4 = k_f1, k_f2, k_f3 (HIP events on the launch stream)
     dense_ms = None
@@ -573,7 +579,7 @@ def main():
                                               cfg['num_subdomains'][0], cfg['num_subdomains'][1],
                                               cfg['coarse_per_subdomain'], t.n, t.n_rt, Q, N),
                           'subdomains': S_total, 'N': N, 'Q': Q, 'parallelism': 'subdomain tiles x{}'.format(world)},
-               'roofline': roofline, 'distributed': dist_info}
+               'roofline': roofline, 'distributed': dist_info, 'output_checksum': output_checksum}
         out['assemble'] = {'metric': 'offline assembly K1-K6, K9 (+ flux coefficients)', 'ms': assemble_ms,
                            'value': eng.S / (1e-3 * assemble_ms), 'unit': 'subdomains/s (this rank)'}
         if online is not None:
