@@ -252,13 +252,16 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
  *   LRBMS_OPT_COARSE           coarse level of the reduced solvers' preconditioner: 1 (default) hand-written block-tridiagonal
  *                              factorisation where the band allows it; 0: none (block-Jacobi); 2: rocSOLVER always
  *   LRBMS_OPT_SOLVE_VALU       1: VALU form of the batched solver's panel matvec (cross-check of the matrix-core form)
- *   LRBMS_OPT_ESTIMATE_VALU    1: VALU form of the batched estimate (dense layout only; cross-check) */
+ *   LRBMS_OPT_ESTIMATE_VALU    1: VALU form of the batched estimate (dense layout only; cross-check)
+ *   LRBMS_OPT_PREP_LDS         1 (default): the preparation sweeps of the fused pass (flux image, vertex averages) run from one copy of
+ *                              the subdomain's basis slab in LDS whenever it fits (k_prep_lds); 0: the two streaming sweeps */
 #define LRBMS_OPT_STREAMS 3
 #define LRBMS_OPT_F1_KSPLIT 4
 #define LRBMS_OPT_F1_FORM 5
 #define LRBMS_OPT_COARSE 6
 #define LRBMS_OPT_SOLVE_VALU 7
 #define LRBMS_OPT_ESTIMATE_VALU 8
+#define LRBMS_OPT_PREP_LDS 10
 int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value);
 
 /* Per-kernel device timing of the fused pass (measurement only; the reference has wall-clock prints around

@@ -520,7 +520,7 @@ class NativeContext:
                                                 c_vp(pc.data_ptr()) if pc is not None else None)
         self._check(rc, 'lrbms_reduced_precond_use')
 
-    OPTIONS = {'oswald_zero_on_subdomain_boundary': 1, 'accumulate_coupling_across_q': 2, 'oswald_vertex_patch': 9,
+    OPTIONS = {'oswald_zero_on_subdomain_boundary': 1, 'accumulate_coupling_across_q': 2, 'oswald_vertex_patch': 9, 'prep_lds': 10,
                # launch policy (no numerical convention): the library reads no environment variable
                'streams': 3, 'f1_ksplit': 4, 'f1_form': 5, 'coarse': 6, 'solve_valu': 7, 'estimate_valu': 8}
 

@@ -174,6 +174,7 @@ int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value) {
     case LRBMS_OPT_COARSE: ctx->opt_coarse = value; break;
     case LRBMS_OPT_SOLVE_VALU: ctx->opt_solve_valu = value; break;
     case LRBMS_OPT_ESTIMATE_VALU: ctx->opt_estimate_valu = value; break;
+    case LRBMS_OPT_PREP_LDS: ctx->opt_prep_lds = value; break;
     default: return lrbms_fail(ctx, LRBMS_E_INVALID, "set_option: unknown option");
   }
   return LRBMS_OK;

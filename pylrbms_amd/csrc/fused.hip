@@ -39,13 +39,14 @@
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 // Experiment switches (tools/build_variant.sh builds A/B variants with them) change what the kernels compute or skip.
 // A product build must define none of them: a stray -D would silently produce wrong results.
 #if !defined(LRBMS_EXPERIMENT_BUILD) &&                                                                               \
     (defined(F1_NO_STAGE) || defined(F1_NO_APPLY) || defined(F1_NO_VALU_STAGE) || defined(F1_NO_MFMA) ||             \
      defined(F1_LDS_FILL) || defined(F1_PRODUCER_PRIO) || defined(F1_SPLIT_SIMD) || defined(F1_PF) ||                \
-     defined(F2_NO_STAGE) || defined(F2_NO_MFMA) || defined(F1_TRACE))
+     defined(F2_NO_STAGE) || defined(F2_NO_MFMA) || defined(F1_TRACE) || defined(F1V_NO_STORE) || defined(F1V_NO_MIRROR) || defined(PREP_X))
 #error "experiment switch defined in a product build of fused.hip (use tools/build_variant.sh, which sets LRBMS_EXPERIMENT_BUILD)"
 #endif
 #ifndef F1_SPLIT_SIMD
@@ -170,19 +171,21 @@ __device__ inline int nvs_of(const Tmpl& t) { return t.nvx > t.nvy ? t.nvx : t.n
 // sharded pass); write_side = 1: R_self and R_side in one sweep.
 // (`by` of `gy` workgroups share subdomain `s`: the bodies below are launched on their own for large subdomain counts and
 // merged into one launch -- k_prep, k_prep_side, k_thin -- for small ones, where the pass is bound by launches, not work)
+template <int NTHR = 256, typename VP = const double*>
 __device__ __forceinline__ void flux_compact_body(const Tmpl& t, int S, const int* __restrict__ nbr, int Q, int N,
                                                   const double* __restrict__ F, const double* __restrict__ V,
                                                   double* __restrict__ Rself, double* __restrict__ Rside, int write_side,
-                                                  int s, int by, int gy) {
+                                                  int s, int by, int gy, VP Vown) {
+  // Vown: the basis rows of subdomain s itself, [n][N] (V + s n N, or the workgroup's copy of that slab in LDS: k_prep_lds)
   const int QN = Q * N;
-  for (int it = by * 256 + threadIdx.x; it < t.nrt * N; it += gy * 256) {   // 32-bit index arithmetic only
+  for (int it = by * NTHR + threadIdx.x; it < t.nrt * N; it += gy * NTHR) {   // 32-bit index arithmetic only
     const int r = it / N, j = it - r * N;
     const int e0 = t.rt_e0[r], e1 = t.rt_e1[r], side = t.rt_side[r];
     const int s2 = (side >= 0 && write_side) ? nbr[s * 5 + side_to_slot(side)] : -1;
     double v0[3], v1[3] = {0, 0, 0};
-    for (int i = 0; i < 3; ++i) v0[i] = V[((long)s * t.n + 3 * e0 + i) * N + j];
+    for (int i = 0; i < 3; ++i) v0[i] = Vown[(3 * e0 + i) * N + j];
     if (side < 0)
-      for (int i = 0; i < 3; ++i) v1[i] = V[((long)s * t.n + 3 * e1 + i) * N + j];
+      for (int i = 0; i < 3; ++i) v1[i] = Vown[(3 * e1 + i) * N + j];
     else if (s2 >= 0)
       for (int i = 0; i < 3; ++i) v1[i] = V[((long)s2 * t.n + 3 * e1 + i) * N + j];
     for (int q = 0; q < Q; ++q) {
@@ -199,7 +202,8 @@ __device__ __forceinline__ void flux_compact_body(const Tmpl& t, int S, const in
 __global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
                                                       const double* __restrict__ F, const double* __restrict__ V,
                                                       double* __restrict__ Rself, double* __restrict__ Rside, int write_side) {
-  flux_compact_body(t, S, nbr, Q, N, F, V, Rself, Rside, write_side, blockIdx.x, blockIdx.y, gridDim.y);   // grid (S, chunks of n_rt * N)
+  flux_compact_body(t, S, nbr, Q, N, F, V, Rself, Rside, write_side, blockIdx.x, blockIdx.y, gridDim.y,
+                    V + (long)blockIdx.x * t.n * N);   // grid (S, chunks of n_rt * N)
 }
 
 // R_side alone (the halo-dependent phase of a sharded pass): one item per (subdomain, side, side face, column).
@@ -240,11 +244,12 @@ __global__ __launch_bounds__(256) void k_flux_side(Tmpl t, int S, const int* __r
 
 // Oswald vertex averages: Avg_self[s][v][j] = inv(v) sum_{star_s(v)} V_s ;  Avg_side[s][sd][pos][j] = inv(v) sum over
 // the star of the matching vertex in the neighbour across side sd (0 if there is none).
+template <int NTHR = 256, typename VP = const double*>
 __device__ __forceinline__ void vertex_avg_body(const Tmpl& t, int S, const int* __restrict__ nbr, int N,
                                                 const double* __restrict__ V, double* __restrict__ AvgSelf,
-                                                double* __restrict__ AvgSide, int write_side, int s, int by, int gy) {
+                                                double* __restrict__ AvgSide, int write_side, int s, int by, int gy, VP Vown) {
   const int nvs = nvs_of(t);
-  for (int it = by * 256 + threadIdx.x; it < t.nv * N; it += gy * 256) {
+  for (int it = by * NTHR + threadIdx.x; it < t.nv * N; it += gy * NTHR) {
     const int v = it / N, j = it - v * N;
     const OsInfo o = oswald_vertex(t, nbr + s * 5, v);
     // the (at most 8) values at the vertex are loaded together and summed in the same order (an `acc += V[...]` loop
@@ -254,7 +259,7 @@ __device__ __forceinline__ void vertex_avg_body(const Tmpl& t, int S, const int*
     for (int pb = p0; pb < p1; pb += 8) {
       double val[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) val[k] = pb + k < p1 ? V[((long)s * t.n + t.vdof_idx[pb + k]) * N + j] : 0.0;
+      for (int k = 0; k < 8; ++k) val[k] = pb + k < p1 ? Vown[t.vdof_idx[pb + k] * N + j] : 0.0;
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         if (pb + k < p1) acc += val[k];
@@ -302,7 +307,8 @@ __device__ __forceinline__ void vertex_avg_body(const Tmpl& t, int S, const int*
 __global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __restrict__ nbr, int N,
                                                     const double* __restrict__ V, double* __restrict__ AvgSelf,
                                                     double* __restrict__ AvgSide, int write_side) {
-  vertex_avg_body(t, S, nbr, N, V, AvgSelf, AvgSide, write_side, blockIdx.x, blockIdx.y, gridDim.y);   // grid (S, chunks of n_v * N)
+  vertex_avg_body(t, S, nbr, N, V, AvgSelf, AvgSide, write_side, blockIdx.x, blockIdx.y, gridDim.y,
+                  V + (long)blockIdx.x * t.n * N);   // grid (S, chunks of n_v * N)
 }
 
 // both preparation sweeps in one launch: grid (S, gy_flux + gy_vtx)
@@ -312,9 +318,245 @@ __global__ __launch_bounds__(256) void k_prep(Tmpl t, int S, const int* __restri
                                               double* __restrict__ AvgSelf, double* __restrict__ AvgSide, int write_side,
                                               int gy_flux) {
   if ((int)blockIdx.y < gy_flux)
-    flux_compact_body(t, S, nbr, Q, N, F, V, Rself, Rside, write_side, blockIdx.x, blockIdx.y, gy_flux);
+    flux_compact_body(t, S, nbr, Q, N, F, V, Rself, Rside, write_side, blockIdx.x, blockIdx.y, gy_flux, V + (long)blockIdx.x * t.n * N);
   else
-    vertex_avg_body(t, S, nbr, N, V, AvgSelf, AvgSide, write_side, blockIdx.x, blockIdx.y - gy_flux, gridDim.y - gy_flux);
+    vertex_avg_body(t, S, nbr, N, V, AvgSelf, AvgSide, write_side, blockIdx.x, blockIdx.y - gy_flux, gridDim.y - gy_flux,
+                    V + (long)blockIdx.x * t.n * N);
+}
+
+// Both preparation sweeps from ONE copy of the subdomain's basis slab in LDS (round 3).  The streaming sweeps above are bound by
+// memory latency, not bandwidth: every item waits for a chain of dependent loads (row tables -> coefficients / basis rows), and
+// every basis row is fetched ~3 times by the flux sweep and ~twice by the vertex averages through L1 / L2.  Here one workgroup
+// per subdomain issues ALL its global loads at once -- the n x N slab (fully coalesced 16-byte loads), the subdomain's flux
+// coefficients, the row and vertex tables -- parks them in LDS, and the sweeps then read LDS only and write their results with
+// 16-byte stores (two basis columns per item).  With write_side the last four waves compute the neighbours' shares (R_side,
+// Avg_side, Avg_corner: the only items that still wait for global loads) while the other twelve do the own rows.
+// Needs even N and prep_lds_bytes() of LDS (148 KB at config 3); the launcher falls back to the sweeps above otherwise.
+constexpr int PREP_LDS_THREADS = 1024, PREP_SIDE_THREADS = 512;
+static size_t prep_lds_bytes(const Tmpl& t, int Q, int N) {   // Vl [n][N] | Fl [Q][nrt][6] | rinfo [nrt] int4 | srow [4 ncf] | vptr [nv + 1] | vidx [n]
+  return sizeof(double) * ((size_t)t.n * N + (size_t)Q * t.nrt * 6) + sizeof(int) * (4 * (size_t)t.nrt + 4 * t.ncf + (t.nv + 1) + t.n);
+}
+
+template <typename IP>
+__device__ inline OsInfo oswald_vertex_from(const Tmpl& t, IP vptr, const int* nbr_s, int v) {   // oswald_vertex with its own copy of vdof_ptr
+  OsInfo o;
+  const int lx = v % t.nvx, ly = v / t.nvx;
+  o.vside[0] = (ly == 0) ? lx + t.nvx * (t.nvy - 1) : -1;
+  o.vside[1] = (lx == 0) ? (t.nvx - 1) + t.nvx * ly : -1;
+  o.vside[2] = (lx == t.nvx - 1) ? t.nvx * ly : -1;
+  o.vside[3] = (ly == t.nvy - 1) ? lx : -1;
+  o.pos[0] = o.pos[3] = lx;
+  o.pos[1] = o.pos[2] = ly;
+  int cnt = vptr[v + 1] - vptr[v];
+  bool dirichlet = false;
+  for (int sd = 0; sd < 4; ++sd) {
+    if (o.vside[sd] < 0) continue;
+    if (nbr_s[side_to_slot(sd)] < 0 || t.opt_oswald_subdomain)
+      dirichlet = true;
+    else
+      cnt += vptr[o.vside[sd] + 1] - vptr[o.vside[sd]];
+  }
+  o.vdiag = o.corner = o.sda = o.sdb = -1;
+  const bool cx = lx == 0 || lx == t.nvx - 1, cy = ly == 0 || ly == t.nvy - 1;
+  if (t.opt_oswald_vertex && cx && cy && !dirichlet) {
+    o.corner = (ly == 0 ? 0 : 2) + (lx == 0 ? 0 : 1);
+    o.sda = ly == 0 ? 0 : 3;
+    o.sdb = lx == 0 ? 1 : 2;
+    o.vdiag = (lx == 0 ? t.nvx - 1 : 0) + t.nvx * (ly == 0 ? t.nvy - 1 : 0);
+    cnt += vptr[o.vdiag + 1] - vptr[o.vdiag];
+  }
+  o.inv = dirichlet ? 0.0 : 1.0 / (double)cnt;
+  return o;
+}
+
+__global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
+                                                               const double* __restrict__ F, const double* __restrict__ V,
+                                                               double* __restrict__ Rself, double* __restrict__ Rside,
+                                                               double* __restrict__ AvgSelf, double* __restrict__ AvgSide,
+                                                               int write_side) {
+  extern __shared__ double Vl[];
+  const int s = blockIdx.x, tid = threadIdx.x, N2 = N / 2, QN = Q * N, nvs = nvs_of(t);
+  double* Fl = Vl + t.n * N;
+  int4* rinfo = reinterpret_cast<int4*>(Fl + Q * t.nrt * 6);
+  int* srow = reinterpret_cast<int*>(rinfo + t.nrt);
+  int* vptr = srow + 4 * t.ncf;
+  int* vidx = vptr + t.nv + 1;
+  // ---- every global load of the own-rows work, issued together: the row tables first (a chain of two dependent loads whose
+  // second step is requested while the slab is in flight), then the slab, the coefficients and the vertex tables
+  const int nb0 = nbr[s * 5], nb1 = nbr[s * 5 + 1], nb3 = nbr[s * 5 + 3], nb4 = nbr[s * 5 + 4];      // wave-uniform: scalar loads
+  auto nbr_slot = [&](int slot) { return slot == 0 ? nb0 : slot == 1 ? nb1 : slot == 3 ? nb3 : nb4; };
+  const int sc0 = t.side_count[0], sc1 = t.side_count[1], sc2 = t.side_count[2], sc3 = t.side_count[3];
+  {
+    const d2* src = reinterpret_cast<const d2*>(V + (long)s * t.n * N);
+    d2* dst = reinterpret_cast<d2*>(Vl);
+    const int total2 = t.n * N2;
+    int e0 = 0, e1 = 0, side = -1, f0 = 0;
+    if (tid < t.nrt) e0 = t.rt_e0[tid], e1 = t.rt_e1[tid], side = t.rt_side[tid], f0 = t.rt_f0[tid];
+    constexpr int U = 8;
+    static_assert(PREP_LDS_THREADS * U * 2 >= 384 * 40, "config 3: the slab in one round of loads");
+    for (int base = 0; base < total2; base += U * PREP_LDS_THREADS) {
+      d2 tmp[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * PREP_LDS_THREADS + tid;
+        tmp[u] = src[i < total2 ? i : total2 - 1];
+      }
+      if (base == 0) {
+        for (int i = tid; i <= t.nv; i += PREP_LDS_THREADS) vptr[i] = t.vdof_ptr[i];
+        for (int i = tid; i < t.n; i += PREP_LDS_THREADS) vidx[i] = t.vdof_idx[i];
+        const int f2 = t.nrt * 3;                    // 16-byte pieces of one component's coefficient rows
+        for (int i = tid; i < Q * f2; i += PREP_LDS_THREADS) {
+          const int q = i / f2, k = i - q * f2;
+          reinterpret_cast<d2*>(Fl)[i] = reinterpret_cast<const d2*>(F + ((long)q * S + s) * t.nrt * 6)[k];
+        }
+        for (int r = tid; r < t.nrt; r += PREP_LDS_THREADS) {
+          if (r != tid) e0 = t.rt_e0[r], e1 = t.rt_e1[r], side = t.rt_side[r], f0 = t.rt_f0[r];      // (templates with n_rt > 1024)
+          const int pos = side >= 0 ? t.elem_side_pos[e0 * 3 + f0] : 0;
+          rinfo[r] = make_int4(e0, e1, side, pos);
+          if (side >= 0) srow[side * t.ncf + pos] = r;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * PREP_LDS_THREADS + tid;
+        if (i < total2) dst[i] = tmp[u];
+      }
+    }
+  }
+  __syncthreads();
+#if defined(PREP_X) && PREP_X == 3
+  return;
+#endif
+  const d2* Vl2 = reinterpret_cast<const d2*>(Vl);
+  const int nmain = write_side ? PREP_LDS_THREADS - PREP_SIDE_THREADS : PREP_LDS_THREADS;
+  if (tid < nmain) {
+#if defined(PREP_X) && PREP_X == 1
+    return;
+#endif
+    // ---- R_self: one item per (RT0 row, pair of columns)
+    d2* R2 = reinterpret_cast<d2*>(Rself + (long)s * t.nrt * QN);
+    for (int it = tid; it < t.nrt * N2; it += nmain) {
+      const int r = it / N2, j2 = it - r * N2;
+      const int4 ri = rinfo[r];
+      d2 v0[3], v1[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        v0[i] = Vl2[(3 * ri.x + i) * N2 + j2];
+        v1[i] = ri.z < 0 ? Vl2[(3 * ri.y + i) * N2 + j2] : (d2){0.0, 0.0};
+      }
+      for (int q = 0; q < Q; ++q) {
+        const double* f = Fl + (q * t.nrt + r) * 6;
+        d2 o;
+        {
+          const double self = f[0] * v0[0].x + f[1] * v0[1].x + f[2] * v0[2].x;
+          const double other = f[3] * v1[0].x + f[4] * v1[1].x + f[5] * v1[2].x;
+          o.x = ri.z < 0 ? self + other : self;
+        }
+        {
+          const double self = f[0] * v0[0].y + f[1] * v0[1].y + f[2] * v0[2].y;
+          const double other = f[3] * v1[0].y + f[4] * v1[1].y + f[5] * v1[2].y;
+          o.y = ri.z < 0 ? self + other : self;
+        }
+        R2[(r * QN + q * N) / 2 + j2] = o;
+      }
+    }
+#if defined(PREP_X) && PREP_X == 4
+    return;
+#endif
+    // ---- Avg_self: one item per (lattice vertex, pair of columns); the values at a vertex summed in the order of its DoF list
+    d2* A2 = reinterpret_cast<d2*>(AvgSelf + (long)s * t.nv * N);
+    for (int it = tid; it < t.nv * N2; it += nmain) {
+      const int v = it / N2, j2 = it - v * N2;
+      const OsInfo o = oswald_vertex_from(t, vptr, nbr + s * 5, v);
+      d2 acc = {0.0, 0.0};
+      const int p0 = vptr[v], p1 = vptr[v + 1];
+      for (int pb = p0; pb < p1; pb += 8) {
+        d2 val[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) val[k] = pb + k < p1 ? Vl2[vidx[pb + k] * N2 + j2] : (d2){0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (pb + k < p1) acc.x += val[k].x, acc.y += val[k].y;
+      }
+      A2[v * N2 + j2] = (d2){o.inv * acc.x, o.inv * acc.y};
+    }
+    return;
+  }
+  // ---- the neighbours' shares (write_side only): the last PREP_SIDE_THREADS threads
+#if defined(PREP_X) && PREP_X == 2
+  return;
+#endif
+  const int ts = tid - nmain;
+  const d2* V2 = reinterpret_cast<const d2*>(V);
+  {
+    d2* Rs2 = reinterpret_cast<d2*>(Rside + (long)s * 4 * t.ncf * QN);
+    for (int it = ts; it < 4 * t.ncf * N2; it += PREP_SIDE_THREADS) {
+      const int sp = it / N2, j2 = it - sp * N2;
+      const int sd = sp / t.ncf;
+      if (sp - sd * t.ncf >= (sd == 0 ? sc0 : sd == 1 ? sc1 : sd == 2 ? sc2 : sc3)) continue;      // a side with fewer than ncf faces
+      const int r = srow[sp];
+      const int4 ri = rinfo[r];
+      const int s2 = nbr_slot(side_to_slot(sd));
+      d2 v1[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+      if (s2 >= 0)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v1[i] = V2[((long)s2 * t.n + 3 * ri.y + i) * N2 + j2];
+      for (int q = 0; q < Q; ++q) {
+        const double* f = Fl + (q * t.nrt + r) * 6;
+        const double ox = f[3] * v1[0].x + f[4] * v1[1].x + f[5] * v1[2].x;
+        const double oy = f[3] * v1[0].y + f[4] * v1[1].y + f[5] * v1[2].y;
+        Rs2[(sp * QN + q * N) / 2 + j2] = s2 >= 0 ? (d2){ox, oy} : (d2){0.0, 0.0};
+      }
+    }
+  }
+  {
+    d2* As2 = reinterpret_cast<d2*>(AvgSide + (long)s * 4 * nvs * N);
+    for (int it = ts; it < 4 * nvs * N2; it += PREP_SIDE_THREADS) {
+      const int sp = it / N2, j2 = it - sp * N2;
+      const int sd = sp / nvs, pos = sp - sd * nvs;
+      if (pos >= ((sd == 0 || sd == 3) ? t.nvx : t.nvy)) continue;
+      const int v = sd == 0 ? pos : sd == 1 ? pos * t.nvx : sd == 2 ? pos * t.nvx + t.nvx - 1 : (t.nvy - 1) * t.nvx + pos;
+      const OsInfo o = oswald_vertex_from(t, vptr, nbr + s * 5, v);
+      const int s2 = nbr_slot(side_to_slot(sd));
+      d2 a2 = {0.0, 0.0};
+      if (s2 >= 0 && o.inv != 0.0) {
+        const int v2 = o.vside[sd];
+        const int q0 = vptr[v2], q1 = vptr[v2 + 1];
+        for (int pb = q0; pb < q1; pb += 8) {
+          d2 val[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) val[k] = pb + k < q1 ? V2[((long)s2 * t.n + vidx[pb + k]) * N2 + j2] : (d2){0.0, 0.0};
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (pb + k < q1) a2.x += val[k].x, a2.y += val[k].y;
+        }
+        a2.x *= o.inv;
+        a2.y *= o.inv;
+      }
+      As2[sp * N2 + j2] = a2;
+    }
+    if (t.opt_oswald_vertex) {                   // the diagonal subdomains' shares at the four corners: Avg_corner [S][4][N]
+      d2* Ac2 = reinterpret_cast<d2*>(AvgSide + (long)S * 4 * nvs * N + (long)s * 4 * N);
+      for (int it = ts; it < 4 * N2; it += PREP_SIDE_THREADS) {
+        const int corner = it / N2, j2 = it - corner * N2;
+        const int v = ((corner & 1) ? t.nvx - 1 : 0) + t.nvx * ((corner & 2) ? t.nvy - 1 : 0);
+        const OsInfo o = oswald_vertex_from(t, vptr, nbr + s * 5, v);
+        d2 a3 = {0.0, 0.0};
+        if (o.vdiag >= 0) {
+          const int sd1 = nbr[s * 5 + side_to_slot(o.sda)];
+          const int sdg = nbr[sd1 * 5 + side_to_slot(o.sdb)];
+          for (int pb = vptr[o.vdiag]; pb < vptr[o.vdiag + 1]; ++pb) {
+            const d2 x = V2[((long)sdg * t.n + vidx[pb]) * N2 + j2];
+            a3.x += x.x;
+            a3.y += x.y;
+          }
+          a3.x *= o.inv;
+          a3.y *= o.inv;
+        }
+        Ac2[corner * N2 + j2] = a3;
+      }
+    }
+  }
 }
 
 // Avg_side alone (the halo-dependent phase of a sharded pass): one item per (subdomain, side, side vertex, column).
@@ -1348,7 +1590,6 @@ __global__ __launch_bounds__(512, 2) void k_f1u(Tmpl t, F1Args a, GrpTable gt) {
 //   * the number of column tiles per SIMD is a template parameter chosen on the host from Q N: no liveness test in the MFMA loop
 //     (at most three tiles beyond the last column multiply zeros).
 // Needs even N (adjacent-column pairs).  Everything else (odd N, N > 48 ...) runs k_f1u / k_f1.
-typedef double d2 __attribute__((ext_vector_type(2)));
 __device__ inline double gload_s64(const double* base, unsigned off) {      // base: wave-uniform (SGPR pair); off: bytes
   double v;
   asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
@@ -1788,9 +2029,15 @@ __device__ __forceinline__ void f1v_body(const Tmpl& t, const F1Args& a, double*
         const int row = i * 16 + lk + 4 * r;
         const double val = acc[LV::slots_before(ROLE, jt) + i][r];
         if (live && row < N && (!sym || row <= jj)) {
+#ifndef F1V_NO_STORE
           base[(long)row * ld + jj] = val;
+#ifndef F1V_NO_MIRROR
           if (sym && row < jj) base[(long)jj * ld + row] = val;
           if (base_t) base_t[(long)jj * ld + row] = val;
+#endif
+#else
+          if (val == 1.2345e300) base[(long)row * ld + jj] = val;
+#endif
         }
       }
     }
@@ -2783,10 +3030,11 @@ __global__ __launch_bounds__(256) void k_coupling(Tmpl t, int S, const int* __re
 template <int NTX>
 __global__ __launch_bounds__(256) void k_thin3(Tmpl t, ThinRtArgs a, ThinNcfArgs f, const double* __restrict__ A_cpl,
                                                double* __restrict__ B_sys) {
-  const int side = blockIdx.x, s = blockIdx.y;
-  if (blockIdx.z == 0)
+  // (an XCD-aware 1-D grid -- the twelve workgroups of a subdomain on one XCD, kinds interleaved -- was measured: no change)
+  const int side = blockIdx.x, s = blockIdx.y, z = blockIdx.z;
+  if (z == 0)
     coupling_body<NTX>(t, a.S, a.nbr, a.Q, a.N, a.V, A_cpl, B_sys, side, s);
-  else if (blockIdx.z == 1)
+  else if (z == 1)
     thin_rt_body(t, a, side, s);
   else
     thin_ncf_body(t, f, side, s);
@@ -3054,8 +3302,15 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // factored layout: the three thin kernels are 256-thread workgroups and always share one launch (k_thin3: 141 us at
   // 1 024 subdomains against 65 + 49 + 41 us one after the other -- they are latency-bound and fill each other's gaps)
   const bool merge_prep = forked, merge_thin = forked || factored;
+  const size_t prep_lds = prep_lds_bytes(t, Q, N);
+  const bool prep_from_lds = ctx->opt_prep_lds != 0 && prep_lds <= 160 * 1024 && N % 2 == 0;      // LRBMS_OPT_PREP_LDS
   if (do_prep) {
-    if (merge_prep) {
+    if (prep_from_lds) {
+      KScope ks(ctx, "k_prep_lds", st);
+      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_prep_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
+      hipLaunchKernelGGL(k_prep_lds, dim3(S), dim3(PREP_LDS_THREADS), prep_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
+                         AvgSide, phase == 0 ? 1 : 0);
+    } else if (merge_prep) {
       KScope ks(ctx, "k_prep", st);
       hipLaunchKernelGGL(k_prep, dim3(S, gy_flux + gy_vtx), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
                          AvgSide, phase == 0 ? 1 : 0, gy_flux);

@@ -325,7 +325,15 @@ __global__ __launch_bounds__(64) void k3_assemble_flux(T3 t, const double* __res
 // One wave per row: the row's elements, orientation and the ten flux coefficients per (element, q) are wave-uniform and come
 // through the scalar cache; the only vector-memory instructions are the loads of the basis rows (the address unit, not the
 // HBM, bounds these kernels).
-constexpr int FLUX_R = 1;     // rows per wave (4 rows with their loads grouped was measured: slower)
+constexpr int FLUX_R = 1;     // rows per wave and step (4 rows with their loads grouped was measured: slower)
+// rows a wave handles one after the other (measured at config 5, FLUX_LOOP 1 / 4 / 8 / 16: k3_flux 362 / 381 / 387 / 398 us -- it is bound
+// by L2 traffic, every element's rows are read by its four faces; NODE_LOOP 1 / 4 / 8 / 16: k3_node_avg 232 / 192 / 192 / 198 us)
+#ifndef FLUX_LOOP
+#define FLUX_LOOP 1
+#endif
+#ifndef NODE_LOOP
+#define NODE_LOOP 4
+#endif
 
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The row blocks of one subdomain read overlapping basis
 // rows, so a 1D grid is decoded such that all blocks of a subdomain get ids that are equal modulo 8 (one XCD) and close in time:
@@ -342,9 +350,10 @@ __global__ __launch_bounds__(256) void k3_flux(T3 t, int Q, int N, int rbeg, int
                                                const double* __restrict__ Cf, double* __restrict__ Rs, double* __restrict__ Rb) {
   const int QN = Q * N, nrows = rend;          // rows [rbeg, rend) of [own faces | side faces]
   int s, xblk;
-  if (!xcd_block((rend - rbeg + 4 * FLUX_R - 1) / (4 * FLUX_R), t.S, xblk, s)) return;
+  if (!xcd_block((rend - rbeg + 4 * FLUX_R * FLUX_LOOP - 1) / (4 * FLUX_R * FLUX_LOOP), t.S, xblk, s)) return;
   const int lane = threadIdx.x & 63, half = lane >> 5, jl = lane & 31;
-  const int row0 = __builtin_amdgcn_readfirstlane(rbeg + (xblk * 4 + (threadIdx.x >> 6)) * FLUX_R);
+  for (int rep = 0; rep < FLUX_LOOP; ++rep) {      // a wave lives for FLUX_LOOP rows: these sweeps are bound by the wave launch rate
+  const int row0 = __builtin_amdgcn_readfirstlane(rbeg + ((xblk * FLUX_LOOP + rep) * 4 + (threadIdx.x >> 6)) * FLUX_R);
   if (row0 >= nrows) return;
   // The (<= 2) elements of a face are dealt to the two halves of the wave: lanes 0..31 take the first, lanes 32..63 the second,
   // lane = basis column.  Every basis row is loaded once per face (ten instead of twenty vector-memory instructions), both affine
@@ -408,6 +417,7 @@ __global__ __launch_bounds__(256) void k3_flux(T3 t, int Q, int N, int rbeg, int
         if (half == 0 && j < N && on[r]) dst[r][q * N + j] = acc + other;
       }
   }
+  }
 }
 
 // Avg [S][n_nodes][N]: own share of the Oswald node average (0 on the physical boundary: the interpolant vanishes there);
@@ -415,12 +425,13 @@ __global__ __launch_bounds__(256) void k3_flux(T3 t, int Q, int N, int rbeg, int
 __global__ __launch_bounds__(256) void k3_node_avg(T3 t, int N, int rbeg, int rend, const double* __restrict__ V,
                                                    double* __restrict__ Avg, double* __restrict__ As) {
   int s, xblk;
-  if (!xcd_block((rend - rbeg + 3) / 4, t.S, xblk, s)) return;          // rows [rbeg, rend) of [own nodes | side nodes]
+  if (!xcd_block((rend - rbeg + 4 * NODE_LOOP - 1) / (4 * NODE_LOOP), t.S, xblk, s)) return;          // rows [rbeg, rend) of [own nodes | side nodes]
   const int j = threadIdx.x & 63;
-  const int row = __builtin_amdgcn_readfirstlane(rbeg + xblk * 4 + (threadIdx.x >> 6));
-  if (row >= rend) return;
   const int jc = j < N ? j : N - 1;
   const int phys = t.phys[s];
+  for (int rep = 0; rep < NODE_LOOP; ++rep) {
+  const int row = __builtin_amdgcn_readfirstlane(rbeg + (xblk * NODE_LOOP + rep) * 4 + (threadIdx.x >> 6));
+  if (row >= rend) return;
   int p0 = 0, p1 = 0, node, src = s;
   const int* list;
   if (row < t.nnodes) {
@@ -450,6 +461,7 @@ __global__ __launch_bounds__(256) void k3_node_avg(T3 t, int N, int rbeg, int re
   if (j < N) {
     if (row < t.nnodes) Avg[((long)s * t.nnodes + row) * N + j] = a0;
     else As[((long)s * 6 * t.nvs + row - t.nnodes) * N + j] = a0;
+  }
   }
 }
 
@@ -3207,12 +3219,12 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
   {
     const int r0 = own ? 0 : t.nrt, r1 = side ? t.nrt + t.nbf : t.nrt;      // own faces | side faces (the neighbours' share: halo)
     KScope3 k(ctx, own ? "k3_flux" : "k3_flux<side>", sf);
-    hipLaunchKernelGGL(k3_flux, dim3(xcd_grid((r1 - r0 + 4 * FLUX_R - 1) / (4 * FLUX_R), t.S)), dim3(256), 0, sf, t, Q, N, r0, r1, V, Cf, Rs, Rb);
+    hipLaunchKernelGGL(k3_flux, dim3(xcd_grid((r1 - r0 + 4 * FLUX_R * FLUX_LOOP - 1) / (4 * FLUX_R * FLUX_LOOP), t.S)), dim3(256), 0, sf, t, Q, N, r0, r1, V, Cf, Rs, Rb);
   }
   {
     const int r0 = own ? 0 : t.nnodes, r1 = side ? t.nnodes + 6 * t.nvs : t.nnodes;
     KScope3 k(ctx, own ? "k3_node_avg" : "k3_node_avg<side>", sn);
-    hipLaunchKernelGGL(k3_node_avg, dim3(xcd_grid((r1 - r0 + 3) / 4, t.S)), dim3(256), 0, sn, t, N, r0, r1, V, Avg, As);
+    hipLaunchKernelGGL(k3_node_avg, dim3(xcd_grid((r1 - r0 + 4 * NODE_LOOP - 1) / (4 * NODE_LOOP), t.S)), dim3(256), 0, sn, t, N, r0, r1, V, Avg, As);
   }
   const int npair = Q * (Q + 1) / 2;       // A_aa: pairs q <= q', the transposed blocks are written from the same accumulators
   // K-split for small per-rank subdomain counts (the 4 x 4 x 4 tile of an 8-GPU run has 64): one workgroup per (subdomain,

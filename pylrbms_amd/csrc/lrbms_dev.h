@@ -71,7 +71,7 @@ struct lrbms_ctx {
   long ksp_ticket_cap = 0;
   lrbms_quadrature* qdev = nullptr;   // device copy of the quadrature (lrbms_set_quadrature), read by the assembly kernels
   // launch policy (lrbms_ctx_set_option, LRBMS_OPT_STREAMS ...): the library reads no environment variable
-  int opt_streams = -1, opt_f1_ksplit = 0, opt_f1_legacy = 0, opt_coarse = 1, opt_solve_valu = 0, opt_estimate_valu = 0;
+  int opt_streams = -1, opt_f1_ksplit = 0, opt_f1_legacy = 0, opt_coarse = 1, opt_solve_valu = 0, opt_estimate_valu = 0, opt_prep_lds = 1;
   const double* user_pc = nullptr;   // prebuilt preconditioner the reduced solves use (lrbms_reduced_precond_use), caller-owned
   int user_pc_N = 0;
   std::string err;
