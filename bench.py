@@ -175,6 +175,9 @@ def kernel_model(t, N, Q, S):
     m = {
         'k_flux_compact': (V_self + d8 * 4 * 3 * ncf * N + d8 * Q * nrt * 6, R_self + R_side, 0),
         'k_vertex_avg': (V_self + V_halo, A_self + A_side, 0),
+        # both sweeps from one copy of the slab in LDS, and G_nc[self, self] (rank-2 form: 2 K rows per element) from the same copy
+        'k_prep_lds': (V_self + V_halo + d8 * 4 * 3 * ncf * N + d8 * Q * nrt * 6 + d8 * nT, R_self + R_side + A_self + A_side + d8 * N * N,
+                       (nT // 2) * (ntx * (ntx + 1) // 2) * 2048),
         'k_f1': (V_self + d8 * nT * (36 * Q + 36 + Q * Q + 9 * Q) + R_self + d8 * n,
                  d8 * (Q * N * N + 2 * N * N + Q * Q * N * N + Q * N * QN + N),
                  (chunks * 3 * ntx * 28 + nT * 3 * ntx) * 2048),
@@ -507,7 +510,7 @@ def main():
         # it is NOT a utilisation figure (it exceeds what HBM can stream).
         inputs = 8 * (t.n * N + 4 * 3 * t.ntouch * N + t.n_T * (36 * Q + 36 + 1 + Q * Q + 9 * Q + 9) + Q * 4 * t.ncf * 9 +
                       Q * t.n_rt * 6 + t.n) * s_rank
-        outputs = sum(w for k, (r, w, f) in model.items() if k not in ('k_flux_compact', 'k_vertex_avg', 'k_thin3'))
+        outputs = sum(w for k, (r, w, f) in model.items() if k not in ('k_flux_compact', 'k_vertex_avg', 'k_thin3', 'k_prep_lds'))
         compulsory = inputs + outputs
         ach_gbs = compulsory / dev_s_per_step / 1e9
         pmc = load_pmc_traffic(args.config) if world == 1 else None
@@ -528,10 +531,11 @@ def main():
                'traffic_source': pmc['file'] if pmc else pmc_note}
         roofline = {'bound': 'mfma', 'achieved': None, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
                     'traffic': traffic, 'traffic_source': pmc['file'] if pmc else pmc_note, 'hbm': hbm,
-                    'basis': 'executed fp64-MFMA flops (padding included) of the dense kernels k_f1 + k_f2 + k_f3 / their measured '
-                             'time (phase 4 of the pass, HIP events on the launch stream); the dominant kernel alone: dominant_kernel',
-                    'kernel': 'fused project+estimate pass: k_flux_compact, k_vertex_avg, k_f1, k_f2, k_f3, k_thin3 (= k_coupling, '
-                              'k_thin_rt, k_thin_ncf in one launch)',
+                    'basis': 'executed fp64-MFMA flops (padding included) of the dense kernels k_f1 + k_f2 (+ k_f3 when it runs) / their '
+                             'measured time (phase 4 of the pass, HIP events on the launch stream); the dominant kernel alone: dominant_kernel',
+                    'kernel': 'fused project+estimate pass: k_prep_lds (flux image, vertex averages and G_nc[self,self] from one copy of '
+                              'the basis slab in LDS; without LRBMS_OPT_PREP_LDS: k_flux_compact, k_vertex_avg, k_f3), k_f1, k_f2, k_thin3 '
+                              '(= k_coupling, k_thin_rt, k_thin_ncf in one launch)',
                     'device_ms_per_step': 1e3 * dev_s_per_step,
                     'dense_layout_ms_per_step': dense_layout_ms,
                     'survey_8d_algorithmic': {'bytes_per_subdomain': byts, 'flops_per_subdomain': flops,
@@ -559,11 +563,13 @@ def main():
             roofline['dominant_kernel'] = dict(dom, bound='mfma' if dom.get('mfma_frac', 0) >= dom.get('hbm_frac', 0) else 'hbm',
                                                frac=max(dom.get('mfma_frac', 0), dom.get('hbm_frac', 0)))
         if dense_ms is not None:
-            mf = sum(model[k][2] for k in ('k_f1', 'k_f2', 'k_f3'))
+            # (with LRBMS_OPT_PREP_LDS, the default, G_nc[self, self] is produced by k_prep_lds and k_f3 is not launched)
+            dense_names = [k for k in ('k_f1', 'k_f2', 'k_f3') if kernel_ms is None or k in kernel_ms]
+            mf = sum(model[k][2] for k in dense_names)
             roofline['dense_kernels'] = {'bound': 'mfma', 'achieved': mf / (1e-3 * dense_ms) / 1e12, 'peak': PEAK_FP64_MFMA_TFLOPS,
                                          'unit': 'TFLOP/s', 'frac': mf / (1e-3 * dense_ms) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
                                          'ms': dense_ms, 'executed_mfma_flops': mf,
-                                         'kernel': 'k_f1 + k_f2 + k_f3 (phase 4 of the pass; executed fp64 MFMA flops, padding '
+                                         'kernel': ' + '.join(dense_names) + ' (phase 4 of the pass; executed fp64 MFMA flops, padding '
                                                    'included, over their measured time)'}
             roofline['achieved'], roofline['frac'] = roofline['dense_kernels']['achieved'], roofline['dense_kernels']['frac']
         elif kernel_ms and roofline.get('dominant_kernel', {}).get('mfma_TFLOPs'):

@@ -46,7 +46,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #if !defined(LRBMS_EXPERIMENT_BUILD) &&                                                                               \
     (defined(F1_NO_STAGE) || defined(F1_NO_APPLY) || defined(F1_NO_VALU_STAGE) || defined(F1_NO_MFMA) ||             \
      defined(F1_LDS_FILL) || defined(F1_PRODUCER_PRIO) || defined(F1_SPLIT_SIMD) || defined(F1_PF) ||                \
-     defined(F2_NO_STAGE) || defined(F2_NO_MFMA) || defined(F1_TRACE) || defined(F1V_NO_STORE) || defined(F1V_NO_MIRROR) || defined(PREP_X))
+     defined(F2_NO_STAGE) || defined(F2_NO_MFMA) || defined(F1_TRACE) || defined(F1V_NO_STORE) || defined(F1V_NO_MIRROR) || defined(F3_EW_X) || defined(PREP_TRACE))
 #error "experiment switch defined in a product build of fused.hip (use tools/build_variant.sh, which sets LRBMS_EXPERIMENT_BUILD)"
 #endif
 #ifndef F1_SPLIT_SIMD
@@ -67,6 +67,19 @@ extern "C" int lrbms_debug_f1_trace(unsigned long long* host) {
 }
 #else
 #define F1_STAMP(role, c, k) do {} while (0)
+#endif
+#ifdef PREP_TRACE   // experiment build: cycle stamps of wave 0 (own rows) and the last wave (neighbours' shares) of workgroup 5 of k_prep_lds
+__device__ unsigned long long g_prep_trace[2][16];
+#define PREP_STAMP(k)                                                                                          \
+  do {                                                                                                         \
+    if (blockIdx.x == 5 && (threadIdx.x == 0 || threadIdx.x == PREP_LDS_THREADS - 64))                         \
+      g_prep_trace[threadIdx.x == 0 ? 0 : 1][k] = __builtin_amdgcn_s_memtime();                               \
+  } while (0)
+extern "C" int lrbms_debug_prep_trace(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prep_trace), sizeof(g_prep_trace));
+}
+#else
+#define PREP_STAMP(k) do {} while (0)
 #endif
 constexpr int EC = 4;               // elements per K-chunk (12 DG rows = 3 MFMA k-steps) = staging waves
 constexpr int F1_NTY = 7;           // Y column tiles per wave in k_f1
@@ -329,58 +342,74 @@ __global__ __launch_bounds__(256) void k_prep(Tmpl t, int S, const int* __restri
 // every basis row is fetched ~3 times by the flux sweep and ~twice by the vertex averages through L1 / L2.  Here one workgroup
 // per subdomain issues ALL its global loads at once -- the n x N slab (fully coalesced 16-byte loads), the subdomain's flux
 // coefficients, the row and vertex tables -- parks them in LDS, and the sweeps then read LDS only and write their results with
-// 16-byte stores (two basis columns per item).  With write_side the last four waves compute the neighbours' shares (R_side,
-// Avg_side, Avg_corner: the only items that still wait for global loads) while the other twelve do the own rows.
-// Needs even N and prep_lds_bytes() of LDS (148 KB at config 3); the launcher falls back to the sweeps above otherwise.
+// 16-byte stores (two basis columns per item).  With write_side the last eight waves compute the neighbours' shares (R_side,
+// Avg_side, Avg_corner: the only items that still wait for global loads) while the other eight do the own rows.
+// With the fold (GncArgs) the same workgroup goes on to G_nc[self, self] -- the whole of k_f3, which would read the slab and the
+// averages again -- from the slab and the averages it has in LDS.  164 us (two sweeps) -> 82 us; + G_nc: 120 us against 82 + 57.
+// Where a workgroup's time goes at config 3 (tools/prep_trace.py, cycles): loads 22 k (all 256 workgroups of a round fetch their
+// 150 KB at the same time: HBM-bound), flux rows 11 k, averages 7 k, Z rows 5 k, MFMA 9 k, reduction 3 k.
+// Needs even N and prep_lds_bytes() of LDS (156 KB at config 3 with the fold); the launcher falls back to the sweeps above otherwise.
 constexpr int PREP_LDS_THREADS = 1024, PREP_SIDE_THREADS = 512;
-static size_t prep_lds_bytes(const Tmpl& t, int Q, int N) {   // Vl [n][N] | Fl [Q][nrt][6] | rinfo [nrt] int4 | srow [4 ncf] | vptr [nv + 1] | vidx [n]
-  return sizeof(double) * ((size_t)t.n * N + (size_t)Q * t.nrt * 6) + sizeof(int) * (4 * (size_t)t.nrt + 4 * t.ncf + (t.nv + 1) + t.n);
+// LDS layout (bytes): Vl [n][N] (at least PREP_GNC_PART with the G_nc fold) | vinfo [nv] | Lg [nT][6] (fold) | vptr [nv + 1], vidx [n],
+// dvt [n] (ints, padded to 16) | region B = max(Fl [Q][nrt][6] + rinfo [nrt] int4 + srow [4 ncf],  Al [nv][N] with the fold: it
+// overlays Fl / rinfo / srow once the flux rows are done)
+constexpr size_t PREP_GNC_PART = sizeof(double) * 16 * 3 * 256;      // partial tiles of the G_nc fold: 16 waves x 3 tiles
+__host__ __device__ inline size_t prep_lds_tab_bytes(const Tmpl& t, bool gnc) {      // vinfo [nv] | Lg [nT][6] (fold only) | the ints
+  return 16 * (size_t)t.nv + (gnc ? sizeof(double) * 6 * (size_t)t.nT : 0) + ((sizeof(int) * ((size_t)t.nv + 1 + 2 * t.n) + 15) & ~(size_t)15);
+}
+__host__ __device__ inline size_t prep_lds_slab_bytes(const Tmpl& t, int N, bool gnc) {
+  const size_t slab = sizeof(double) * (size_t)t.n * N;
+  return gnc && slab < PREP_GNC_PART ? PREP_GNC_PART : slab;
+}
+static size_t prep_lds_bytes(const Tmpl& t, int Q, int N, bool gnc) {
+  const size_t flux = sizeof(double) * (size_t)Q * t.nrt * 6 + sizeof(int) * (4 * (size_t)t.nrt + 4 * t.ncf);
+  const size_t avg = gnc ? sizeof(double) * (size_t)t.nv * N : 0;
+  return prep_lds_slab_bytes(t, N, gnc) + prep_lds_tab_bytes(t, gnc) + (flux > avg ? flux : avg);
 }
 
-template <typename IP>
-__device__ inline OsInfo oswald_vertex_from(const Tmpl& t, IP vptr, const int* nbr_s, int v) {   // oswald_vertex with its own copy of vdof_ptr
-  OsInfo o;
-  const int lx = v % t.nvx, ly = v / t.nvx;
-  o.vside[0] = (ly == 0) ? lx + t.nvx * (t.nvy - 1) : -1;
-  o.vside[1] = (lx == 0) ? (t.nvx - 1) + t.nvx * ly : -1;
-  o.vside[2] = (lx == t.nvx - 1) ? t.nvx * ly : -1;
-  o.vside[3] = (ly == t.nvy - 1) ? lx : -1;
-  o.pos[0] = o.pos[3] = lx;
-  o.pos[1] = o.pos[2] = ly;
-  int cnt = vptr[v + 1] - vptr[v];
-  bool dirichlet = false;
-  for (int sd = 0; sd < 4; ++sd) {
-    if (o.vside[sd] < 0) continue;
-    if (nbr_s[side_to_slot(sd)] < 0 || t.opt_oswald_subdomain)
-      dirichlet = true;
-    else
-      cnt += vptr[o.vside[sd] + 1] - vptr[o.vside[sd]];
+// G_nc[self, self] folded into k_prep_lds (below): the tiles a wave owns.  Even waves: the first row of tiles, odd waves: the rest.
+template <int NTX>
+__device__ inline void gnc_tile(int half, int k, int& ti, int& tj) {      // k-th tile (row, column) of a wave of that parity
+  if (NTX == 1) {
+    ti = tj = 0;
+  } else if (NTX == 2) {
+    ti = half ? 1 : 0;
+    tj = half ? 1 : k;
+  } else {
+    ti = half ? (k < 2 ? 1 : 2) : 0;
+    tj = half ? (k == 0 ? 1 : 2) : k;
   }
-  o.vdiag = o.corner = o.sda = o.sdb = -1;
-  const bool cx = lx == 0 || lx == t.nvx - 1, cy = ly == 0 || ly == t.nvy - 1;
-  if (t.opt_oswald_vertex && cx && cy && !dirichlet) {
-    o.corner = (ly == 0 ? 0 : 2) + (lx == 0 ? 0 : 1);
-    o.sda = ly == 0 ? 0 : 3;
-    o.sdb = lx == 0 ? 1 : 2;
-    o.vdiag = (lx == 0 ? t.nvx - 1 : 0) + t.nvx * (ly == 0 ? t.nvy - 1 : 0);
-    cnt += vptr[o.vdiag + 1] - vptr[o.vdiag];
-  }
-  o.inv = dirichlet ? 0.0 : 1.0 / (double)cnt;
-  return o;
 }
+template <int NTX>
+__host__ __device__ constexpr int gnc_count(int half) { return NTX == 1 ? (half ? 0 : 1) : NTX == 2 ? (half ? 1 : 2) : 3; }
 
+struct GncArgs {           // G_nc != nullptr: the fold runs (the launcher then skips k_f3)
+  const double* ebar;
+  double* G_nc;
+  long gsub;
+  int gld, goff;
+};
+
+template <int NTX>
 __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
                                                                const double* __restrict__ F, const double* __restrict__ V,
                                                                double* __restrict__ Rself, double* __restrict__ Rside,
                                                                double* __restrict__ AvgSelf, double* __restrict__ AvgSide,
-                                                               int write_side) {
+                                                               int write_side, GncArgs ga) {
   extern __shared__ double Vl[];
   const int s = blockIdx.x, tid = threadIdx.x, N2 = N / 2, QN = Q * N, nvs = nvs_of(t);
-  double* Fl = Vl + t.n * N;
+  const bool gnc = ga.G_nc != nullptr;           // workgroup-uniform
+  PREP_STAMP(0);
+  struct VInfo { double inv; int p0, cnt; };     // per lattice vertex: inverse patch size (0 on a Dirichlet vertex), its DoF list
+  VInfo* vinfo = reinterpret_cast<VInfo*>(reinterpret_cast<char*>(Vl) + prep_lds_slab_bytes(t, N, gnc));
+  double* Lg = reinterpret_cast<double*>(vinfo + t.nv);                                                       // [nT][2][3]: L^T G_T (fold only)
+  int* vptr = reinterpret_cast<int*>(Lg + (gnc ? 6 * t.nT : 0));
+  int* vidx = vptr + t.nv + 1;
+  int* dvt = vidx + t.n;
+  double* Fl = reinterpret_cast<double*>(reinterpret_cast<char*>(vinfo) + prep_lds_tab_bytes(t, gnc));
+  double* Al = Fl;                               // with the fold: the vertex averages, once the flux rows are done
   int4* rinfo = reinterpret_cast<int4*>(Fl + Q * t.nrt * 6);
   int* srow = reinterpret_cast<int*>(rinfo + t.nrt);
-  int* vptr = srow + 4 * t.ncf;
-  int* vidx = vptr + t.nv + 1;
   // ---- every global load of the own-rows work, issued together: the row tables first (a chain of two dependent loads whose
   // second step is requested while the slab is in flight), then the slab, the coefficients and the vertex tables
   const int nb0 = nbr[s * 5], nb1 = nbr[s * 5 + 1], nb3 = nbr[s * 5 + 3], nb4 = nbr[s * 5 + 4];      // wave-uniform: scalar loads
@@ -404,6 +433,22 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
       if (base == 0) {
         for (int i = tid; i <= t.nv; i += PREP_LDS_THREADS) vptr[i] = t.vdof_ptr[i];
         for (int i = tid; i < t.n; i += PREP_LDS_THREADS) vidx[i] = t.vdof_idx[i];
+        for (int v = tid; v < t.nv; v += PREP_LDS_THREADS) {          // (integer divisions, a chain of table reads and an fp64 division:
+          const OsInfo o = oswald_vertex(t, nbr + s * 5, v);          //  once per vertex, not once per item)
+          const int p0 = t.vdof_ptr[v];
+          vinfo[v] = VInfo{o.inv, p0, t.vdof_ptr[v + 1] - p0};
+        }
+        if (gnc) {
+          for (int i = tid; i < t.n; i += PREP_LDS_THREADS) dvt[i] = t.dof_vertex[i];
+          const double ksym = 0.5 * (t.kappa[1] + t.kappa[2]);
+          const double l00 = sqrt(t.kappa[0]), l10 = ksym / l00, l11 = sqrt(t.kappa[3] - l10 * l10);
+          for (int i = tid; i < 3 * t.nT; i += PREP_LDS_THREADS) {      // (element, shape function): rows of L^T applied to its gradient
+            const int T = i / 3, k = i - 3 * T;
+            const double gx = t.grad[i * 2], gy = t.grad[i * 2 + 1];
+            Lg[T * 6 + k] = l00 * gx + l10 * gy;
+            Lg[T * 6 + 3 + k] = l11 * gy;
+          }
+        }
         const int f2 = t.nrt * 3;                    // 16-byte pieces of one component's coefficient rows
         for (int i = tid; i < Q * f2; i += PREP_LDS_THREADS) {
           const int q = i / f2, k = i - q * f2;
@@ -423,16 +468,14 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
       }
     }
   }
+  PREP_STAMP(1);
   __syncthreads();
-#if defined(PREP_X) && PREP_X == 3
-  return;
-#endif
+  PREP_STAMP(2);
   const d2* Vl2 = reinterpret_cast<const d2*>(Vl);
   const int nmain = write_side ? PREP_LDS_THREADS - PREP_SIDE_THREADS : PREP_LDS_THREADS;
+  const int ts = tid - nmain;
+  const d2* V2 = reinterpret_cast<const d2*>(V);
   if (tid < nmain) {
-#if defined(PREP_X) && PREP_X == 1
-    return;
-#endif
     // ---- R_self: one item per (RT0 row, pair of columns)
     d2* R2 = reinterpret_cast<d2*>(Rself + (long)s * t.nrt * QN);
     for (int it = tid; it < t.nrt * N2; it += nmain) {
@@ -460,35 +503,9 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
         R2[(r * QN + q * N) / 2 + j2] = o;
       }
     }
-#if defined(PREP_X) && PREP_X == 4
-    return;
-#endif
-    // ---- Avg_self: one item per (lattice vertex, pair of columns); the values at a vertex summed in the order of its DoF list
-    d2* A2 = reinterpret_cast<d2*>(AvgSelf + (long)s * t.nv * N);
-    for (int it = tid; it < t.nv * N2; it += nmain) {
-      const int v = it / N2, j2 = it - v * N2;
-      const OsInfo o = oswald_vertex_from(t, vptr, nbr + s * 5, v);
-      d2 acc = {0.0, 0.0};
-      const int p0 = vptr[v], p1 = vptr[v + 1];
-      for (int pb = p0; pb < p1; pb += 8) {
-        d2 val[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) val[k] = pb + k < p1 ? Vl2[vidx[pb + k] * N2 + j2] : (d2){0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (pb + k < p1) acc.x += val[k].x, acc.y += val[k].y;
-      }
-      A2[v * N2 + j2] = (d2){o.inv * acc.x, o.inv * acc.y};
-    }
-    return;
-  }
-  // ---- the neighbours' shares (write_side only): the last PREP_SIDE_THREADS threads
-#if defined(PREP_X) && PREP_X == 2
-  return;
-#endif
-  const int ts = tid - nmain;
-  const d2* V2 = reinterpret_cast<const d2*>(V);
-  {
+  } else {
+    // ---- the neighbours' share of the flux image (write_side only): the last PREP_SIDE_THREADS threads.  Every item of theirs waits
+    // for global loads (the neighbours' rows)
     d2* Rs2 = reinterpret_cast<d2*>(Rside + (long)s * 4 * t.ncf * QN);
     for (int it = ts; it < 4 * t.ncf * N2; it += PREP_SIDE_THREADS) {
       const int sp = it / N2, j2 = it - sp * N2;
@@ -509,26 +526,56 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
       }
     }
   }
-  {
+  PREP_STAMP(3);
+  // (the barriers of the fold order LDS traffic only: __syncthreads() would also wait for the global stores of the rows just written)
+  if (gnc) lds_barrier();                        // Fl, rinfo, srow are dead: the averages may overwrite them
+  PREP_STAMP(4);
+  if (tid < nmain) {
+    // ---- Avg_self: one item per (lattice vertex, pair of columns); the values at a vertex summed in the order of its DoF list
+    d2* A2 = reinterpret_cast<d2*>(AvgSelf + (long)s * t.nv * N);
+    for (int it = tid; it < t.nv * N2; it += nmain) {
+      const int v = it / N2, j2 = it - v * N2;
+      const VInfo o = vinfo[v];
+      d2 acc = {0.0, 0.0};
+      const int p0 = o.p0, p1 = o.p0 + o.cnt;
+      for (int pb = p0; pb < p1; pb += 8) {
+        d2 val[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) val[k] = Vl2[vidx[pb + k < p1 ? pb + k : p1 - 1] * N2 + j2];      // unconditional reads (clamped index):
+#pragma unroll                                                                                    // no branch between the LDS round trips
+        for (int k = 0; k < 8; ++k) {
+          acc.x += pb + k < p1 ? val[k].x : 0.0;
+          acc.y += pb + k < p1 ? val[k].y : 0.0;
+        }
+      }
+      const d2 av = {o.inv * acc.x, o.inv * acc.y};
+      A2[v * N2 + j2] = av;
+      if (gnc) reinterpret_cast<d2*>(Al)[v * N2 + j2] = av;
+    }
+  } else {
+    // ---- the neighbours' shares of the vertex averages, beside the own ones
     d2* As2 = reinterpret_cast<d2*>(AvgSide + (long)s * 4 * nvs * N);
     for (int it = ts; it < 4 * nvs * N2; it += PREP_SIDE_THREADS) {
       const int sp = it / N2, j2 = it - sp * N2;
       const int sd = sp / nvs, pos = sp - sd * nvs;
       if (pos >= ((sd == 0 || sd == 3) ? t.nvx : t.nvy)) continue;
       const int v = sd == 0 ? pos : sd == 1 ? pos * t.nvx : sd == 2 ? pos * t.nvx + t.nvx - 1 : (t.nvy - 1) * t.nvx + pos;
-      const OsInfo o = oswald_vertex_from(t, vptr, nbr + s * 5, v);
+      const VInfo o = vinfo[v];
       const int s2 = nbr_slot(side_to_slot(sd));
       d2 a2 = {0.0, 0.0};
       if (s2 >= 0 && o.inv != 0.0) {
-        const int v2 = o.vside[sd];
-        const int q0 = vptr[v2], q1 = vptr[v2 + 1];
+        // the matching lattice vertex of the neighbour across side sd (oswald_vertex: vside)
+        const int v2 = sd == 0 ? pos + t.nvx * (t.nvy - 1) : sd == 1 ? (t.nvx - 1) + t.nvx * pos : sd == 2 ? t.nvx * pos : pos;
+        const int q0 = vinfo[v2].p0, q1 = q0 + vinfo[v2].cnt;
         for (int pb = q0; pb < q1; pb += 8) {
           d2 val[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) val[k] = pb + k < q1 ? V2[((long)s2 * t.n + vidx[pb + k]) * N2 + j2] : (d2){0.0, 0.0};
+          for (int k = 0; k < 8; ++k) val[k] = V2[((long)s2 * t.n + vidx[pb + k < q1 ? pb + k : q1 - 1]) * N2 + j2];
 #pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (pb + k < q1) a2.x += val[k].x, a2.y += val[k].y;
+          for (int k = 0; k < 8; ++k) {
+            a2.x += pb + k < q1 ? val[k].x : 0.0;
+            a2.y += pb + k < q1 ? val[k].y : 0.0;
+          }
         }
         a2.x *= o.inv;
         a2.y *= o.inv;
@@ -540,7 +587,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
       for (int it = ts; it < 4 * N2; it += PREP_SIDE_THREADS) {
         const int corner = it / N2, j2 = it - corner * N2;
         const int v = ((corner & 1) ? t.nvx - 1 : 0) + t.nvx * ((corner & 2) ? t.nvy - 1 : 0);
-        const OsInfo o = oswald_vertex_from(t, vptr, nbr + s * 5, v);
+        const OsInfo o = oswald_vertex(t, nbr + s * 5, v);
         d2 a3 = {0.0, 0.0};
         if (o.vdiag >= 0) {
           const int sd1 = nbr[s * 5 + side_to_slot(o.sda)];
@@ -556,7 +603,96 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
         Ac2[corner * N2 + j2] = a3;
       }
     }
+    }
+  PREP_STAMP(5);
+  if (!gnc) return;
+  // ---- G_nc[self, self] = W^T E W, W = V - P Avg (the Oswald interpolation error of the own basis), E_T = ebar_T K_T.
+  // K_T = G_T^T kappa G_T has rank 2 (G_T: the gradients of the three P1 shape functions): with kappa = L L^T,
+  //   G_nc = sum_T ebar_T Z_T^T Z_T,   Z_T = L^T G_T W_T   (2 rows per element instead of 3),
+  // and Z_T overwrites the first two of the element's three rows of the slab IN PLACE, so the product needs no staging: both MFMA
+  // operands of a k-step are plain LDS rows (the B operand scaled by ebar_T).
+  lds_barrier();                                 // Al complete
+  PREP_STAMP(6);
+  {
+    d2* Vw = reinterpret_cast<d2*>(Vl);
+    const d2* Al2 = reinterpret_cast<const d2*>(Al);
+    for (int it = tid; it < t.nT * N2; it += PREP_LDS_THREADS) {
+      const int T = it / N2, j2 = it - T * N2;
+      d2 w[3];
+      double g0[3], g1[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const d2 v = Vw[(3 * T + i) * N2 + j2], av = Al2[dvt[3 * T + i] * N2 + j2];
+        w[i] = (d2){v.x - av.x, v.y - av.y};
+        g0[i] = Lg[T * 6 + i];
+        g1[i] = Lg[T * 6 + 3 + i];
+      }
+      Vw[(3 * T) * N2 + j2] = (d2){g0[0] * w[0].x + g0[1] * w[1].x + g0[2] * w[2].x, g0[0] * w[0].y + g0[1] * w[1].y + g0[2] * w[2].y};
+      Vw[(3 * T + 1) * N2 + j2] = (d2){g1[0] * w[0].x + g1[1] * w[1].x + g1[2] * w[2].x, g1[0] * w[0].y + g1[1] * w[1].y + g1[2] * w[2].y};
+      if (j2 == 0) Vl[(3 * T + 2) * N] = ga.ebar[(long)s * t.nT + T];      // the element's third row is free now: its first entry carries ebar_T
+    }
   }
+  PREP_STAMP(7);
+  lds_barrier();  
+  PREP_STAMP(8);
+  {
+    const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wave = uniform(tid >> 6), half = wave & 1, kp = wave >> 1;
+    const int nsteps = t.nT / 2, per = (nsteps + 7) / 8;
+    const int st0 = kp * per, st1 = st0 + per < nsteps ? st0 + per : nsteps;
+    d4 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int ntile = half ? gnc_count<NTX>(1) : gnc_count<NTX>(0);
+    for (int st = st0; st < st1; ++st) {
+      const int T = 2 * st + (lk >> 1), row = 3 * T + (lk & 1);
+      const double eb = Vl[(3 * T + 2) * N];
+      double x[NTX];
+#pragma unroll
+      for (int c = 0; c < NTX; ++c) x[c] = Vl[row * N + 16 * c + li];      // columns >= N: finite garbage in entries that are not stored
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < gnc_count<NTX>(0)) {
+          int ti, tj;
+          gnc_tile<NTX>(half, k, ti, tj);
+          double av = x[0], bv = x[0];
+#pragma unroll
+          for (int c = 1; c < NTX; ++c) {
+            av = ti == c ? x[c] : av;
+            bv = tj == c ? x[c] : bv;
+          }
+          if (k < ntile) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, eb * bv, acc[k], 0, 0, 0);
+        }
+    }
+    PREP_STAMP(9);
+    lds_barrier();                               // every wave is done with the Z rows: the slab region takes the partial tiles
+    PREP_STAMP(10);
+    double* part = Vl + (long)wave * 3 * 256;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(k * 4 + r) * 64 + lane] = acc[k][r];
+    lds_barrier();  
+    PREP_STAMP(11);
+    // fixed-order sum over the eight K parts; one item per (tile, accumulator register, lane)
+    double* g = ga.G_nc + (long)s * ga.gsub + ga.goff;
+    constexpr int NTRI = NTX * (NTX + 1) / 2;
+    for (int it = tid; it < NTRI * 256; it += PREP_LDS_THREADS) {
+      const int tile = it >> 8, r = (it >> 6) & 3, ln = it & 63;
+      const int hf = tile < gnc_count<NTX>(0) ? 0 : 1, k = hf ? tile - gnc_count<NTX>(0) : tile;
+      double sum = 0.0;
+#pragma unroll
+      for (int p8 = 0; p8 < 8; ++p8) sum += Vl[(long)(2 * p8 + hf) * 3 * 256 + (k * 4 + r) * 64 + ln];
+      int ti, tj;
+      gnc_tile<NTX>(hf, k, ti, tj);
+      const int row = 16 * ti + (ln >> 4) + 4 * r, col = 16 * tj + (ln & 15);
+      if (row < N && col < N) {
+        g[(long)row * ga.gld + col] = sum;
+        if (ti != tj) g[(long)col * ga.gld + row] = sum;      // mirror: the stored operator is exactly symmetric
+      }
+    }
+  }
+  PREP_STAMP(12);
 }
 
 // Avg_side alone (the halo-dependent phase of a sharded pass): one item per (subdomain, side, side vertex, column).
@@ -2309,7 +2445,10 @@ struct F3Args {
   int gld, goff;  // their row length and first entry: 5 N, 10 N^2 + 2 N (dense) or N, 0 (factored)
 };
 
-constexpr int F3_EW = 4;   // elements staged per wave and chunk: 16 elements (48 K-rows) per barrier pair
+#ifndef F3_EW_X
+#define F3_EW_X 4
+#endif
+constexpr int F3_EW = F3_EW_X;   // elements staged per wave and chunk: 16 elements (48 K-rows) per barrier pair
 
 template <int NTX>
 __global__ __launch_bounds__(256) void k_f3(Tmpl t, F3Args a) {
@@ -3302,14 +3441,28 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // factored layout: the three thin kernels are 256-thread workgroups and always share one launch (k_thin3: 141 us at
   // 1 024 subdomains against 65 + 49 + 41 us one after the other -- they are latency-bound and fill each other's gaps)
   const bool merge_prep = forked, merge_thin = forked || factored;
-  const size_t prep_lds = prep_lds_bytes(t, Q, N);
-  const bool prep_from_lds = ctx->opt_prep_lds != 0 && prep_lds <= 160 * 1024 && N % 2 == 0;      // LRBMS_OPT_PREP_LDS
+  // LRBMS_OPT_PREP_LDS: the preparation sweeps from one copy of the basis slab in LDS; with it G_nc[self, self] is folded into the same
+  // kernel (k_f3 is not launched) whenever N <= 48 and the call covers both the preparation and the dense kernels
+  const int ntx_p = (N + 15) / 16;
+  const bool prep_ok = ctx->opt_prep_lds != 0 && N % 2 == 0;
+  const bool gnc_fold = prep_ok && ctx->opt_prep_lds != 2 && ntx_p <= 3 && prep_lds_bytes(t, Q, N, true) <= 160 * 1024;
+  const size_t prep_lds = prep_lds_bytes(t, Q, N, gnc_fold);
+  const bool prep_from_lds = prep_ok && prep_lds <= 160 * 1024;
   if (do_prep) {
     if (prep_from_lds) {
       KScope ks(ctx, "k_prep_lds", st);
-      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_prep_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
-      hipLaunchKernelGGL(k_prep_lds, dim3(S), dim3(PREP_LDS_THREADS), prep_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
-                         AvgSide, phase == 0 ? 1 : 0);
+      const GncArgs ga{ebar, gnc_fold ? G_nc : nullptr, factored ? (long)N * N : (long)25 * N * N, factored ? N : 5 * N,
+                       factored ? 0 : 10 * N * N + 2 * N};
+#define LRBMS_PREP(NTXV)                                                                                                              \
+  do {                                                                                                                                \
+    LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_prep_lds<NTXV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds)); \
+    hipLaunchKernelGGL(k_prep_lds<NTXV>, dim3(S), dim3(PREP_LDS_THREADS), prep_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf, \
+                       AvgSide, phase == 0 ? 1 : 0, ga);                                                                              \
+  } while (0)
+      if (ntx_p == 1) LRBMS_PREP(1);
+      else if (ntx_p == 2) LRBMS_PREP(2);
+      else LRBMS_PREP(3);
+#undef LRBMS_PREP
     } else if (merge_prep) {
       KScope ks(ctx, "k_prep", st);
       hipLaunchKernelGGL(k_prep, dim3(S, gy_flux + gy_vtx), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
@@ -3607,8 +3760,8 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
 #undef LRBMS_F2
     LRBMS_LAUNCH_CHECK(ctx);
   }
-  // ---- F3
-  if (do_a) {
+  // ---- F3 (unless k_prep_lds has produced G_nc[self, self] from its copy of the slab)
+  if (do_a && !(prep_from_lds && gnc_fold)) {
     F3Args a{V, ebar, AvgSelf, AvgSide, G_nc, N, S, factored ? (long)N * N : 25L * N * N, factored ? N : 5 * N,
              factored ? 0 : 10 * N * N + 2 * N};
     const int ntx = (N + 15) / 16;
