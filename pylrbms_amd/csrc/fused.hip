@@ -33,6 +33,7 @@
 // written exactly once (zeros included); all reductions have a fixed order (the 2-way K-split meets by atomic add, which
 // is order-independent for two contributions).
 #include <cstdlib>
+#include <type_traits>
 
 #include "lrbms_dev.h"
 
@@ -40,13 +41,22 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+// One or two adjacent basis columns per lane (W = 2 whenever N is even).  A CU moves ~50 GB/s with 8-byte and ~70 GB/s with 16-byte
+// lane loads (MI355X_MICROARCH.md, indexed rows), and the thin kernels are bound by exactly that rate (tools/thin_trace.py).
+template <int W> struct VecT { using T = double; };
+template <> struct VecT<2> { using T = d2; };
+template <int W> __device__ inline typename VecT<W>::T ldv(const double* p) { return *reinterpret_cast<const typename VecT<W>::T*>(p); }
+template <int W> __device__ inline void stv(double* p, typename VecT<W>::T v) { *reinterpret_cast<typename VecT<W>::T*>(p) = v; }
+template <int W> __device__ inline typename VecT<W>::T zerov() { return typename VecT<W>::T(0.0); }
+using W1 = std::integral_constant<int, 1>;
+using W2 = std::integral_constant<int, 2>;
 
 // Experiment switches (tools/build_variant.sh builds A/B variants with them) change what the kernels compute or skip.
 // A product build must define none of them: a stray -D would silently produce wrong results.
 #if !defined(LRBMS_EXPERIMENT_BUILD) &&                                                                               \
     (defined(F1_NO_STAGE) || defined(F1_NO_APPLY) || defined(F1_NO_VALU_STAGE) || defined(F1_NO_MFMA) ||             \
      defined(F1_LDS_FILL) || defined(F1_PRODUCER_PRIO) || defined(F1_SPLIT_SIMD) || defined(F1_PF) ||                \
-     defined(F2_NO_STAGE) || defined(F2_NO_MFMA) || defined(F1_TRACE) || defined(F1V_NO_STORE) || defined(F1V_NO_MIRROR) || defined(F3_EW_X) || defined(PREP_TRACE))
+     defined(F2_NO_STAGE) || defined(F2_NO_MFMA) || defined(F1_TRACE) || defined(F1V_NO_STORE) || defined(F1V_NO_MIRROR) || defined(F3_EW_X) || defined(PREP_TRACE) || defined(THIN_TRACE))
 #error "experiment switch defined in a product build of fused.hip (use tools/build_variant.sh, which sets LRBMS_EXPERIMENT_BUILD)"
 #endif
 #ifndef F1_SPLIT_SIMD
@@ -67,6 +77,18 @@ extern "C" int lrbms_debug_f1_trace(unsigned long long* host) {
 }
 #else
 #define F1_STAMP(role, c, k) do {} while (0)
+#endif
+#ifdef THIN_TRACE   // experiment build: cycle stamps of thread 0 of the three workgroups (side 1, subdomain 500) of k_thin3
+__device__ unsigned long long g_thin_trace[3][8];
+#define THIN_STAMP(z, k)                                                                                       \
+  do {                                                                                                         \
+    if (side == 1 && s == 500 && threadIdx.x == 0) g_thin_trace[z][k] = __builtin_amdgcn_s_memtime();          \
+  } while (0)
+extern "C" int lrbms_debug_thin_trace(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_thin_trace), sizeof(g_thin_trace));
+}
+#else
+#define THIN_STAMP(z, k) do {} while (0)
 #endif
 #ifdef PREP_TRACE   // experiment build: cycle stamps of wave 0 (own rows) and the last wave (neighbours' shares) of workgroup 5 of k_prep_lds
 __device__ unsigned long long g_prep_trace[2][16];
@@ -2759,6 +2781,7 @@ __device__ __forceinline__ void thin_ncf_body(const Tmpl& t, const ThinNcfArgs& 
     for (int i = tid; i < nvs * LD; i += 256) Fs[i] = 0.0;
     return;
   }
+  THIN_STAMP(2, 0);
   const int ne = t.touch_count[side];
   double* Y = lds;                                                // [3 ne][N]  rows of E W_self of the touching elements
   double* Ksc = Y + 3 * t.ntouch * N;                            // [ne][9]    ebar_T K_T
@@ -2772,40 +2795,70 @@ __device__ __forceinline__ void thin_ncf_body(const Tmpl& t, const ThinNcfArgs& 
     ttab[i] = t.touch_elem[side * t.ntouch + i];
     side_mask[i] = t.touch_mask[side * t.ntouch + i];
   }
+  // the rows that meet in a side vertex, in table order: t.touch_rlist (built at mesh upload; a vertex with more than NCF_ROWS rows has
+  // count -1 and is scanned where it is used)
+  static_assert(NCF_ROWS == 8, "layout of t.touch_rlist");
+  for (int i = tid; i < nvs * (NCF_ROWS + 1); i += 256) rlist[i] = t.touch_rlist[side * nvs * (NCF_ROWS + 1) + i];
   for (int i = tid; i < 3 * ne; i += 256) vtab[i] = t.touch_vtx[side * t.ntouch * 3 + i];
   for (int i = tid; i < 12 * ne; i += 256) ptab[i] = t.touch_pos[side * t.ntouch * 12 + i];
   for (int i = tid; i < 9 * ne; i += 256) {
     const int T = t.touch_elem[side * t.ntouch + i / 9];
     Ksc[i] = ebs[T] * t.stiff[9 * T + i % 9];
   }
+  THIN_STAMP(2, 1);
   __syncthreads();
-  // the rows that meet in a side vertex, in table order (one scan per vertex instead of one per output entry); a vertex
-  // with more than NCF_ROWS rows keeps count -1 and is scanned where it is used
-  for (int pos = tid; pos < nvs; pos += 256) {
-    int cnt = 0;
-    for (int r = 0; r < 3 * ne; ++r)
-      if (ptab[r * 4 + side] == pos) {
-        if (cnt < NCF_ROWS) rlist[pos * (NCF_ROWS + 1) + 1 + cnt] = r;
-        ++cnt;
-      }
-    rlist[pos * (NCF_ROWS + 1)] = cnt <= NCF_ROWS ? cnt : -1;
-  }
+  THIN_STAMP(2, 2);
   const double* Vs = a.V + (long)s * t.n * N;
   const double* As = a.AvgSelf + (long)s * t.nv * N;
-  for (int it = tid; it < ne * N; it += 256) {
-    const int p = it / N, j = it - p * N, T = ttab[p];
-    double ws[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ws[i] = Vs[(long)(3 * T + i) * N + j] - As[(long)vtab[3 * p + i] * N + j];
-    const double* K = Ksc + 9 * p;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) Y[(3 * p + k) * N + j] = K[k * 3] * ws[0] + K[k * 3 + 1] * ws[1] + K[k * 3 + 2] * ws[2];
-  }
-  __syncthreads();
+  // (round 3) every thread requests the rows of a batch of items before it uses the first one: one memory round trip per batch
+  // instead of one per item; the neighbour's vertex averages of the output sweep are requested here as well
   const int nside = (side == 0 || side == 3) ? t.nvx : t.nvy;
   const double* Aa = a.AvgSide + ((long)s * 4 + side) * nvs * N;
+  constexpr int OT = 2;                             // output items per thread held across the barrier (nvs N <= 512: checked below)
+  double aav[OT];
+#pragma unroll
+  for (int u = 0; u < OT; ++u) {
+    const int it = u * 256 + tid, pos = it / N, j = it - pos * N;
+    aav[u] = it < nvs * N && pos < nside ? Aa[(long)pos * N + j] : 0.0;
+  }
+  auto stage_y = [&](auto wtag) {
+    constexpr int W = decltype(wtag)::value;
+    using VT = typename VecT<W>::T;
+    constexpr int IT = W == 2 ? 3 : 5;              // (config 3: all items of a thread in one batch)
+    const int NW = N / W;
+    for (int base = 0; base < ne * NW; base += IT * 256) {
+      VT vv[IT][3], av[IT][3];
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        const int it = base + u * 256 + tid, itc = it < ne * NW ? it : ne * NW - 1;
+        const int p = itc / NW, j = (itc - p * NW) * W, T = ttab[p];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          vv[u][i] = ldv<W>(Vs + (long)(3 * T + i) * N + j);
+          av[u][i] = ldv<W>(As + (long)vtab[3 * p + i] * N + j);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        const int it = base + u * 256 + tid;
+        if (it >= ne * NW) continue;
+        const int p = it / NW, j = (it - p * NW) * W;
+        VT ws[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ws[i] = vv[u][i] - av[u][i];
+        const double* K = Ksc + 9 * p;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) stv<W>(Y + (3 * p + k) * N + j, K[k * 3] * ws[0] + K[k * 3 + 1] * ws[1] + K[k * 3 + 2] * ws[2]);
+      }
+    }
+  };
+  if (N & 1) stage_y(W1{});
+  else stage_y(W2{});
+  THIN_STAMP(2, 3);
+  __syncthreads();
+  THIN_STAMP(2, 4);
   // A_a | C_a: one item per (side vertex, column); the rows that meet in a vertex are summed in table order
-  for (int it = tid; it < nvs * N; it += 256) {
+  for (int it = tid, u = 0; it < nvs * N; it += 256, ++u) {
     const int pos = it / N, j = it - pos * N;
     double c = 0.0;
     if (pos < nside) {
@@ -2817,7 +2870,7 @@ __device__ __forceinline__ void thin_ncf_body(const Tmpl& t, const ThinNcfArgs& 
           if (ptab[r * 4 + side] == pos) c -= Y[r * N + j];
       }
     }
-    Fs[(long)pos * LD + j] = pos < nside ? Aa[(long)pos * N + j] : 0.0;
+    Fs[(long)pos * LD + j] = u < OT ? (u == 0 ? aav[0] : aav[1]) : (pos < nside ? Aa[(long)pos * N + j] : 0.0);
     Fs[(long)pos * LD + N + j] = c;
     if (t.opt_oswald_vertex) {
       // A_diag: the diagonal subdomain's share of the vertex average at a cross point, carried by the sides 0 (S) and 3 (N) at
@@ -2833,7 +2886,12 @@ __device__ __forceinline__ void thin_ncf_body(const Tmpl& t, const ThinNcfArgs& 
   for (int it = tid; it < nvs * 4 * nvs; it += 256) {
     const int pos = it / (4 * nvs), rem = it - pos * 4 * nvs, sb = rem / nvs, pos2 = rem - sb * nvs;
     double m = 0.0;
-    if (pos < nside) {
+    // two lattice vertices share an element only if they are lattice neighbours (every triangle of the template spans one lattice
+    // step): everything else is zero without a look at the tables
+    const int ax = side == 0 || side == 3 ? pos : (side == 1 ? 0 : t.nvx - 1), ay = side == 1 || side == 2 ? pos : (side == 0 ? 0 : t.nvy - 1);
+    const int bx = sb == 0 || sb == 3 ? pos2 : (sb == 1 ? 0 : t.nvx - 1), by = sb == 1 || sb == 2 ? pos2 : (sb == 0 ? 0 : t.nvy - 1);
+    const bool near = ax - bx <= 1 && bx - ax <= 1 && ay - by <= 1 && by - ay <= 1;
+    if (pos < nside && near) {
       const int bit = 1 << sb;
       const int* rl = rlist + pos * (NCF_ROWS + 1);
       const int nr = rl[0] >= 0 ? rl[0] : 3 * ne;
@@ -2847,6 +2905,7 @@ __device__ __forceinline__ void thin_ncf_body(const Tmpl& t, const ThinNcfArgs& 
     }
     Fs[(long)pos * LD + 2 * N + rem] = m;
   }
+  THIN_STAMP(2, 5);
 }
 
 __global__ __launch_bounds__(256) void k_thin_ncf(Tmpl t, ThinNcfArgs a) { thin_ncf_body(t, a, blockIdx.x, blockIdx.y); }
@@ -2879,6 +2938,10 @@ struct ThinRtArgs {
 
 __host__ __device__ inline int fside_ld(int Q, int N) { return 4 * Q * N + 4; }
 
+static size_t thin_rt_lds_bytes(const Tmpl& t, int Q, int N) {      // fco [ncf][4], sc2 [ncf], Bl [ncf][3], Aq [ncf][Q][3], pad, Rl [ncf][QN], fidx [ncf][5] ints
+  return sizeof(double) * ((size_t)(8 + 3 * Q) * t.ncf + 1 + (size_t)t.ncf * Q * N + 3 * (size_t)t.ncf);
+}
+
 __device__ __forceinline__ void thin_rt_body(const Tmpl& t, const ThinRtArgs& a, int side, int s) {
   extern __shared__ double lds[];
   const int slot = side_to_slot(side), tid = threadIdx.x;
@@ -2894,65 +2957,129 @@ __device__ __forceinline__ void thin_rt_body(const Tmpl& t, const ThinRtArgs& a,
   }
   // per side face p: element, its face on the side, its three RT0 rows and divergence coefficients -- resolved ONCE by
   // np threads into LDS (the index chains side_elem -> nb_elem -> elem_rt / face_len / area are three dependent round trips)
+  THIN_STAMP(1, 0);
   double* fco = lds;                                  // [np][4]: sign |e_g| / |T| (g = 0..2), |T|
   double* sc2 = fco + 4 * np;                         // [np]    (b_T . 1) c_p
-  int* fidx = reinterpret_cast<int*>(sc2 + np);       // [np][5]: T, fp, rt row of face 0..2
+  double* Bl = sc2 + np;                              // [np][3]    row f_p of B_T
+  double* Aq = Bl + 3 * np;                           // [np][Q][3] column f_p of (A_ab^q)_T
+  double* Rl = Aq + 3 * Q * np + ((np * (8 + 3 * Q)) & 1);   // [np][QN]   the neighbour's flux image on the side faces (Ra), 16-byte aligned
+  int* fidx = reinterpret_cast<int*>(Rl + np * QN);   // [np][5]: T, fp, rt row of face 0..2
   const int* nbr_s = a.nbr + s * 5;
   const double* Rs = a.Rself + (long)s * t.nrt * QN;
+  const double* Rsd = a.Rside + ((long)s * 4 + side) * t.ncf * QN;
+  // Ra (np QN contiguous doubles) is requested first and parked in LDS: the factor rows and r_fd both read it there
+  constexpr int RT_IT = 3;
+  double rr[RT_IT];
+#pragma unroll
+  for (int u = 0; u < RT_IT; ++u) rr[u] = Rsd[u * 256 + tid < np * QN ? u * 256 + tid : 0];
   if (tid < np) {
-    const int p = tid, T = t.side_elem[side * t.ncf + p];
-    int fp = 0;
-    for (int f = 0; f < 3; ++f)
-      if (t.nb_elem[T * 3 + f] == -(1 + side)) fp = f;
+    // template data of the side face from ONE table row (t.sface_i / t.sface_d, built at mesh upload), then the subdomain's data
+    // of that element: two round trips (was a chain of five: side_elem -> nb_elem -> elem_rt / face_len / area -> b, B)
+    const int p = tid;
+    const int4* ti4 = reinterpret_cast<const int4*>(t.sface_i + (side * t.ncf + p) * 12);
+    const int4 i0 = ti4[0], i1 = ti4[1], i2 = ti4[2];      // T fp rt0 rt1 | rt2 sg0 sg1 sg2 | bs0 bs1 bs2 -
+    const double* td = t.sface_d + (side * t.ncf + p) * 4;
+    const double len[3] = {td[0], td[1], td[2]}, area = td[3];
+    const int T = i0.x, fp = i0.y;
+    const int rt[3] = {i0.z, i0.w, i1.x}, sg[3] = {i1.y, i1.z, i1.w}, bs[3] = {i2.x, i2.y, i2.z};
+    const double* be = a.b + (long)s * t.n + 3 * T;
+    const double* B = a.Bbb + ((long)s * t.nT + T) * 9 + fp * 3;
+    const double b0 = be[0], b1 = be[1], b2 = be[2], B0 = B[0], B1 = B[1], B2 = B[2];
+    double Aqv[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < Q) {
+        const double* A = a.Aab + (((long)q * S + s) * t.nT + T) * 9;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Aqv[q][k] = A[k * 3 + fp];
+      }
     fidx[p * 5] = T;
     fidx[p * 5 + 1] = fp;
-    const double area = t.area[T];
+#pragma unroll
     for (int g = 0; g < 3; ++g) {
-      fidx[p * 5 + 2 + g] = t.elem_rt[T * 3 + g];
-      fco[p * 4 + g] = face_sign_at(t, nbr_s, T, g) * t.face_len[T * 3 + g] / area;
+      fidx[p * 5 + 2 + g] = rt[g];
+      const int sign = (bs[g] >= 0 && nbr_s[side_to_slot(bs[g] >= 0 ? bs[g] : 0)] < 0) ? 1 : sg[g];      // face_sign_at
+      fco[p * 4 + g] = sign * len[g] / area;
     }
     fco[p * 4 + 3] = area;
     const double cp = fco[p * 4 + fp];
-    const double* be = a.b + (long)s * t.n + 3 * T;
-    const double* B = a.Bbb + ((long)s * t.nT + T) * 9 + fp * 3;
-    sc2[p] = (be[0] + be[1] + be[2]) * cp;
+    sc2[p] = (b0 + b1 + b2) * cp;
     double* row = Fs + (long)p * LD + 4 * QN;
-    row[0] = B[fp];
+    row[0] = fp == 0 ? B0 : fp == 1 ? B1 : B2;
     row[1] = area * cp * cp;
     row[2] = sc2[p];
     row[3] = 0.0;
+    Bl[p * 3] = B0;
+    Bl[p * 3 + 1] = B1;
+    Bl[p * 3 + 2] = B2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < Q)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Aq[(p * Q + q) * 3 + k] = Aqv[q][k];
   }
+#pragma unroll
+  for (int u = 0; u < RT_IT; ++u)
+    if (u * 256 + tid < np * QN) Rl[u * 256 + tid] = rr[u];
+  for (int i = RT_IT * 256 + tid; i < np * QN; i += 256) Rl[i] = Rsd[i];      // (larger templates)
+  THIN_STAMP(1, 1);
   __syncthreads();
-  for (int it = tid; it < np * QN; it += 256) {
-    const int p = it / QN, c = it - p * QN;
-    const int T = fidx[p * 5], fp = fidx[p * 5 + 1];
-    const double ra = a.Rside[(((long)s * 4 + side) * t.ncf + p) * QN + c];
-    const double* B = a.Bbb + ((long)s * t.nT + T) * 9 + fp * 3;
-    const double area = fco[p * 4 + 3];
-    double yb = 0.0, d = 0.0;
-    for (int g = 0; g < 3; ++g) {
-      const double rv = Rs[(long)fidx[p * 5 + 2 + g] * QN + c];
-      yb += B[g] * rv;
-      d += fco[p * 4 + g] * rv;
+  THIN_STAMP(1, 2);
+  // The three sweeps below are latency-bound (a workgroup has a few items per thread, every item a handful of global loads), so each
+  // thread requests the loads of ALL its items of a sweep before it uses the first one: one memory round trip per sweep instead
+  // of one per item (round 3; the expressions, and with them the results, are unchanged).
+  auto factor_rows = [&](auto wtag) {
+    constexpr int W = decltype(wtag)::value;
+    using VT = typename VecT<W>::T;
+    constexpr int IT = W == 2 ? 2 : 3;                // items per thread and batch (7 loads each: the kernel stays below 96 VGPRs)
+    const int QW = QN / W;
+    for (int base = 0; base < np * QW; base += IT * 256) {
+      VT ra[IT], rv[IT][3], xv[IT][3];
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        const int it = base + u * 256 + tid, itc = it < np * QW ? it : np * QW - 1;
+        const int p = itc / QW, c = (itc - p * QW) * W, q = c / N, i = c - q * N;
+        const int T = fidx[p * 5];
+        ra[u] = ldv<W>(Rl + p * QN + c);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          rv[u][g] = ldv<W>(Rs + (long)fidx[p * 5 + 2 + g] * QN + c);
+          xv[u][g] = ldv<W>(a.V + ((long)s * t.n + 3 * T + g) * N + i);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        const int it = base + u * 256 + tid;
+        if (it >= np * QW) continue;
+        const int p = it / QW, c = (it - p * QW) * W, q = c / N;
+        const int fp = fidx[p * 5 + 1];
+        const double area = fco[p * 4 + 3];
+        VT yb = zerov<W>(), d = zerov<W>();
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          yb += Bl[p * 3 + g] * rv[u][g];
+          d += fco[p * 4 + g] * rv[u][g];
+        }
+        VT x = zerov<W>();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x += xv[u][k] * Aq[(p * Q + q) * 3 + k];
+        double* row = Fs + (long)p * LD;
+        stv<W>(row + c, ra[u]);
+        stv<W>(row + QN + c, yb);
+        stv<W>(row + 2 * QN + c, area * fco[p * 4 + fp] * d);
+        stv<W>(row + 3 * QN + c, x);
+      }
     }
-    double* row = Fs + (long)p * LD;
-    row[c] = ra;
-    row[QN + c] = yb;
-    row[2 * QN + c] = area * fco[p * 4 + fp] * d;
-  }
-  for (int it = tid; it < np * QN; it += 256) {
-    const int p = it / QN, qi = it - p * QN, q = qi / N, i = qi - q * N;
-    const int T = fidx[p * 5], fp = fidx[p * 5 + 1];
-    const double* A = a.Aab + (((long)q * S + s) * t.nT + T) * 9;
-    double x = 0.0;
-    for (int k = 0; k < 3; ++k) x += a.V[((long)s * t.n + 3 * T + k) * N + i] * A[k * 3 + fp];
-    Fs[(long)p * LD + 3 * QN + qi] = x;
-  }
+  };
+  if (N & 1) factor_rows(W1{});
+  else factor_rows(W2{});
+  THIN_STAMP(1, 3);
   for (int c = tid; c < QN; c += 256) {
     double v = 0.0;
-    for (int p = 0; p < np; ++p) v += sc2[p] * a.Rside[(((long)s * 4 + side) * t.ncf + p) * QN + c];
+    for (int p = 0; p < np; ++p) v += sc2[p] * Rl[p * QN + c];
     a.r_fd[(long)s * C + slot * QN + c] = v;
   }
+  THIN_STAMP(1, 4);
 }
 
 __global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) { thin_rt_body(t, a, blockIdx.x, blockIdx.y); }
@@ -3102,6 +3229,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 // side).  One workgroup per (side, subdomain) handles every q: the rows of V_s at the side are staged once, C_q V_nbr per
 // q, and the N x N product is a handful of MFMAs (the VALU version re-read two LDS operands per multiply-add and was
 // bound by the LDS pipe: 76 us at config 3 for 105 MB of output).
+static size_t coupling_lds_bytes(const Tmpl& t, int ntx, int Q) {      // Xin [KP][LD], Tm [Q][KP][LD]; Cl [Q][ncf][9]
+  return sizeof(double) * ((1 + (size_t)Q) * (size_t)((3 * t.ncf + 3) & ~3) * padded_ld(ntx) + (size_t)Q * t.ncf * 9);
+}
+
 template <int NTX>
 __device__ __forceinline__ void coupling_body(const Tmpl& t, int S, const int* __restrict__ nbr, int Q, int N,
                                               const double* __restrict__ V, const double* __restrict__ A_cpl,
@@ -3121,32 +3252,97 @@ __device__ __forceinline__ void coupling_body(const Tmpl& t, int S, const int* _
     }
     return;
   }
+  THIN_STAMP(0, 0);
   const int K = 3 * cnt, KP = (K + 3) & ~3;
   double* Xin = lds;             // [KP][LD]  rows of V_s at the side
-  double* Tm = lds + KP * LD;    // [KP][LD]  C_q * rows of V_nbr
-  for (int i = tid; i < 2 * KP * LD; i += 256) lds[i] = 0.0;
-  __syncthreads();
-  for (int i = tid; i < K * N; i += 256) {
-    const int row = i / N, col = i - row * N, pos = row / 3, ii = row - 3 * pos;
-    Xin[row * LD + col] = V[((long)s * t.n + 3 * t.side_elem[side * t.ncf + pos] + ii) * N + col];
+  double* Tm = lds + KP * LD;    // [Q][KP][LD]  rows of V_nbr at the side (raw, in Tm[0]), then C_q * (those rows)
+  double* Cl = Tm + Q * KP * LD; // [Q][cnt][9]
+  // One memory round trip (behind the element tables) per workgroup (round 3): every thread requests all its rows before it stores
+  // the first one, and both components share the neighbour's rows: they are parked raw in Tm[0], then one LDS pass per side face
+  // replaces them by C_q V_nbr for every q -- the expression of the former per-component staging, so the results are unchanged.
+  // (Before: rows of V_s, then per component the coupling blocks and the neighbour's rows: six round trips, five barriers.)
+  // Columns >= N of the LDS rows are never written: they only reach output entries that are not stored.
+  double clv[2];                                    // the coupling blocks: the first 512 entries requested first, stored behind the rows' requests
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = u * 256 + tid, ic = i < Q * cnt * 9 ? i : 0, q = ic / (cnt * 9), r = ic - q * cnt * 9;
+    clv[u] = A_cpl[((((long)q * S + s) * 4 + side) * t.ncf) * 9 + r];
   }
-  for (int q = 0; q < Q; ++q) {
-    for (int i = tid; i < K * N; i += 256) {
-      const int row = i / N, col = i - row * N, pos = row / 3, ii = row - 3 * pos;
-      const double* C = A_cpl + ((((long)q * S + s) * 4 + side) * t.ncf + pos) * 9 + ii * 3;
-      const double* v2 = V + ((long)s2 * t.n + 3 * t.side_elem_out[side * t.ncf + pos]) * N + col;
-      Tm[row * LD + col] = C[0] * v2[0] + C[1] * v2[N] + C[2] * v2[2 * N];
+  auto stage = [&](auto wtag) {
+    constexpr int W = decltype(wtag)::value;
+    using VT = typename VecT<W>::T;
+    constexpr int IT = W == 2 ? 2 : 4;
+    const int NW = N / W;
+    for (int base = 0; base < KP * NW; base += IT * 256) {
+      VT xv[IT], vv[IT];
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        const int i = base + u * 256 + tid, ic = i < K * NW ? i : 0;
+        const int row = ic / NW, col = (ic - row * NW) * W, pos = row / 3, ii = row - 3 * pos;
+        xv[u] = ldv<W>(V + ((long)s * t.n + 3 * t.side_elem[side * t.ncf + pos] + ii) * N + col);
+        vv[u] = ldv<W>(V + ((long)s2 * t.n + 3 * t.side_elem_out[side * t.ncf + pos] + ii) * N + col);
+      }
+      if (base == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (u * 256 + tid < Q * cnt * 9) Cl[u * 256 + tid] = clv[u];
+        for (int i = 512 + tid; i < Q * cnt * 9; i += 256) {      // (large templates: the rest of the blocks)
+          const int q = i / (cnt * 9), r = i - q * cnt * 9;
+          Cl[i] = A_cpl[((((long)q * S + s) * 4 + side) * t.ncf) * 9 + r];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        const int i = base + u * 256 + tid;
+        if (i >= KP * NW) continue;
+        const int row = i / NW, col = (i - row * NW) * W;
+        stv<W>(Xin + row * LD + col, i < K * NW ? xv[u] : zerov<W>());      // the padding rows K .. KP - 1 multiply every entry: zeros
+        stv<W>(Tm + row * LD + col, i < K * NW ? vv[u] : zerov<W>());
+        for (int q = 1; q < Q; ++q)
+          if (i >= K * NW) stv<W>(Tm + (q * KP + row) * LD + col, zerov<W>());
+      }
     }
+    THIN_STAMP(0, 1);
     __syncthreads();
+    for (int i = tid; i < cnt * NW; i += 256) {          // (side face, columns): the three rows of the neighbour's element -> C_q * rows
+      const int pos = i / NW, col = (i - pos * NW) * W;
+      VT v2[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v2[k] = ldv<W>(Tm + (3 * pos + k) * LD + col);
+      for (int q = 0; q < Q; ++q) {
+        const double* C = Cl + (q * cnt + pos) * 9;
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii)
+          stv<W>(Tm + (q * KP + 3 * pos + ii) * LD + col, C[ii * 3] * v2[0] + C[ii * 3 + 1] * v2[1] + C[ii * 3 + 2] * v2[2]);
+      }
+    }
+  };
+  if (N & 1) stage(W1{});
+  else stage(W2{});
+  __syncthreads();
+  THIN_STAMP(0, 2);
+  for (int q = 0; q < Q; ++q) {
     double* out = B_sys + ((((long)q * S + s) * 5 + slot) * N) * N;
+    const double* Tq = Tm + q * KP * LD;
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
       const int tile = wave + 4 * k;
       if (tile >= NTX * NTX) continue;           // wave-uniform
       const int ti = tile / NTX, tj = tile - ti * NTX;
       d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-      for (int kk = 0; kk < KP; kk += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xin[(kk + lk) * LD + ti * 16 + li], Tm[(kk + lk) * LD + tj * 16 + li], acc, 0, 0, 0);
+      // (unrolled by 8 k-steps with the operands of all of them requested first: a rolled loop pays one LDS round trip per MFMA)
+      for (int k0 = 0; k0 < KP; k0 += 32) {
+        double xa[8], yb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int kr = k0 + 4 * u + lk < KP ? k0 + 4 * u + lk : KP - 1;
+          xa[u] = Xin[kr * LD + ti * 16 + li];
+          yb[u] = Tq[kr * LD + tj * 16 + li];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + 4 * u < KP) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], yb[u], acc, 0, 0, 0);      // wave-uniform
+      }
       const int col = tj * 16 + li;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -3154,8 +3350,8 @@ __device__ __forceinline__ void coupling_body(const Tmpl& t, int S, const int* _
         if (row < N && col < N) out[(long)row * N + col] = acc[r];
       }
     }
-    __syncthreads();                             // Tm is restaged for the next q
   }
+  THIN_STAMP(0, 3);
 }
 
 template <int NTX>
@@ -3188,7 +3384,7 @@ struct ThinNcArgs {
   double* Fnc;   // factored layout: the side factors of G_nc instead of its side blocks
 };
 template <int NTX>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 8 : 6, 8))) void k_thin(Tmpl t, ThinRtArgs a, ThinNcArgs c) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 5 : 4, 8))) void k_thin(Tmpl t, ThinRtArgs a, ThinNcArgs c) {
   const int side = blockIdx.x, s = blockIdx.y;
   if (blockIdx.z == 0 && c.Fnc == nullptr) {
     thin_nc_body<NTX>(t, a.S, a.nbr, a.N, a.V, c.ebar, c.AvgSelf, c.AvgSide, c.G_nc, side, s);
@@ -3230,8 +3426,48 @@ int64_t fused_fnc_size(lrbms_ctx* ctx, int N) {
 
 namespace {
 __global__ __launch_bounds__(256) void k_build_tables(Tmpl t, double* __restrict__ stiff, int* __restrict__ tvtx,
-                                                      int* __restrict__ tpos, int* __restrict__ tmask) {
+                                                      int* __restrict__ tpos, int* __restrict__ tmask, int* __restrict__ sfi,
+                                                      double* __restrict__ sfd, int* __restrict__ trl) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nvs_b = t.nvx > t.nvy ? t.nvx : t.nvy;
+  if (i < 4 * nvs_b) {                            // the rows that meet in a side vertex, in table order (k_thin_ncf scanned them per workgroup)
+    const int sd = i / nvs_b, pos = i - sd * nvs_b;
+    int cnt = 0;
+    for (int r = 0; r < 3 * t.touch_count[sd]; ++r) {
+      const int T = t.touch_elem[sd * t.ntouch + r / 3];
+      const int v = t.dof_vertex[3 * T + r % 3], lx = v % t.nvx, ly = v / t.nvx;
+      const int ps = sd == 0 ? (ly == 0 ? lx : -1) : sd == 1 ? (lx == 0 ? ly : -1) : sd == 2 ? (lx == t.nvx - 1 ? ly : -1) : (ly == t.nvy - 1 ? lx : -1);
+      if (ps == pos) {
+        if (cnt < 8) trl[i * 9 + 1 + cnt] = r;
+        ++cnt;
+      }
+    }
+    for (int k = cnt; k < 8; ++k) trl[i * 9 + 1 + k] = 0;
+    trl[i * 9] = cnt <= 8 ? cnt : -1;
+  }
+  if (i < 4 * t.ncf) {                            // side faces: what k_thin_rt resolved by three dependent index chains per workgroup
+    const int sd = i / t.ncf, p = i - sd * t.ncf;
+    int* o = sfi + i * 12;
+    double* d = sfd + i * 4;
+    for (int k = 0; k < 12; ++k) o[k] = 0;
+    for (int k = 0; k < 4; ++k) d[k] = 0.0;
+    if (p < t.side_count[sd]) {
+      const int T = t.side_elem[i];
+      int fp = 0;
+      for (int f = 0; f < 3; ++f)
+        if (t.nb_elem[T * 3 + f] == -(1 + sd)) fp = f;
+      o[0] = T;
+      o[1] = fp;
+      for (int g = 0; g < 3; ++g) {
+        const int nb = t.nb_elem[T * 3 + g];
+        o[2 + g] = t.elem_rt[T * 3 + g];
+        o[5 + g] = t.face_sign[T * 3 + g];
+        o[8 + g] = nb < 0 ? -1 - nb : -1;
+        d[g] = t.face_len[T * 3 + g];
+      }
+      d[3] = t.area[T];
+    }
+  }
   if (i < t.nT) {
     double K[9];
     stiffness3(t, i, K);
@@ -3278,8 +3514,18 @@ int build_template_tables(lrbms_ctx* ctx) {
   ctx->owned.push_back(tpos);
   LRBMS_HIP_CHECK(ctx, hipMalloc(&tmask, sizeof(int) * 4 * (size_t)t.ntouch));
   ctx->owned.push_back(tmask);
-  const int total = std::max(64, t.nT > 4 * t.ntouch ? t.nT : 4 * t.ntouch);
-  hipLaunchKernelGGL(k_build_tables, dim3((total + 255) / 256), dim3(256), 0, nullptr, t, stiff, tvtx, tpos, tmask);
+  int* sfi = nullptr;
+  double* sfd = nullptr;
+  LRBMS_HIP_CHECK(ctx, hipMalloc(&sfi, sizeof(int) * 48 * (size_t)t.ncf));
+  ctx->owned.push_back(sfi);
+  LRBMS_HIP_CHECK(ctx, hipMalloc(&sfd, sizeof(double) * 16 * (size_t)t.ncf));
+  ctx->owned.push_back(sfd);
+  const int nvs_b = t.nvx > t.nvy ? t.nvx : t.nvy;
+  int* trl = nullptr;
+  LRBMS_HIP_CHECK(ctx, hipMalloc(&trl, sizeof(int) * 36 * (size_t)nvs_b));
+  ctx->owned.push_back(trl);
+  const int total = std::max(std::max(64, std::max(4 * t.ncf, 4 * nvs_b)), t.nT > 4 * t.ntouch ? t.nT : 4 * t.ntouch);
+  hipLaunchKernelGGL(k_build_tables, dim3((total + 255) / 256), dim3(256), 0, nullptr, t, stiff, tvtx, tpos, tmask, sfi, sfd, trl);
   LRBMS_LAUNCH_CHECK(ctx);
   LRBMS_HIP_CHECK(ctx, hipDeviceSynchronize());
   t.stiff = stiff;
@@ -3288,6 +3534,9 @@ int build_template_tables(lrbms_ctx* ctx) {
   t.touch_vtx = tvtx;
   t.touch_pos = tpos;
   t.touch_mask = tmask;
+  t.sface_i = sfi;
+  t.sface_d = sfd;
+  t.touch_rlist = trl;
   return LRBMS_OK;
 }
 
@@ -3383,7 +3632,7 @@ bool fused_supported(lrbms_ctx* ctx, int Q, int N, bool factored) {
   }
   static const size_t f2_static[8] = {12288, 28672, 28672, 45056, 45056, 61440, 61440, 77824};   // k_f2<NR> (see the .s)
   if (44 * (size_t)t.nT + f2_static[nr - 1] > LDS_MAX) return false;
-  if ((size_t)2 * ((3 * t.ncf + 3) & ~3) * padded_ld(ntx) * sizeof(double) > LDS_MAX) return false;   // k_coupling
+  if (coupling_lds_bytes(t, ntx, Q) > LDS_MAX) return false;
   if (factored) return thin_ncf_lds_bytes(t, N) <= LDS_MAX;
   if (thin_nc_lds_bytes(t, ntx) > LDS_MAX || t.ntouch * N > 3 * 512) return false;   // k_thin_nc: LDS, items per thread
   if ((size_t)t.ncf * fside_ld(Q, N) * sizeof(double) > LDS_MAX) return false;       // k_thin_expand
@@ -3639,8 +3888,8 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, Fside, r_fd, Q, N, S};
     ThinNcArgs c{ebar, AvgSelf, AvgSide, A_cpl, G_nc, B_sys, Fnc};
     size_t lds = factored ? thin_ncf_lds_bytes(t, N) : thin_nc_lds_bytes(t, ntx);
-    lds = std::max(lds, sizeof(double) * (5 * t.ncf + 3 * t.ncf));
-    lds = std::max(lds, sizeof(double) * 2 * (size_t)((3 * t.ncf + 3) & ~3) * padded_ld(ntx));
+    lds = std::max(lds, thin_rt_lds_bytes(t, Q, N));
+    lds = std::max(lds, coupling_lds_bytes(t, ntx, Q));
 #define LRBMS_THIN(NTX)                                                                                                      \
   do {                                                                                                                       \
     if (lds > 64 * 1024)                                                                                                     \
@@ -3718,7 +3967,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     }
     LRBMS_LAUNCH_CHECK(ctx);
     ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, Fside, r_fd, Q, N, S};
-    const size_t lds2 = sizeof(double) * (5 * t.ncf + 3 * t.ncf);   // fco [ncf][4], sc2 [ncf], fidx [ncf][5] ints
+    const size_t lds2 = thin_rt_lds_bytes(t, Q, N);
     {
       KScope ks(ctx, "k_thin_rt", s_rt);
       hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, s_rt, t, a);
@@ -3776,7 +4025,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   }
   if (do_b && !merge_thin) {   // off-diagonal blocks of B_sys
     const int ntx = (N + 15) / 16;
-    const size_t ldsc = sizeof(double) * 2 * (size_t)((3 * t.ncf + 3) & ~3) * padded_ld(ntx);
+    const size_t ldsc = coupling_lds_bytes(t, ntx, Q);
     KScope ks(ctx, "k_coupling", s_rt);
 #define LRBMS_CPL(NTXV)                                                                                                      \
   do {                                                                                                                       \

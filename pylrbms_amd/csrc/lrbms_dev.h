@@ -26,6 +26,10 @@ struct Tmpl {
   const int* touch_vtx;      // [4][ntouch][3]     lattice vertex of local DoF i of the p-th element touching side sd
   const int* touch_pos;      // [4][ntouch][3][4]  its position along side sd', or -1 if it is not on that side
   const int* touch_mask;     // [4][ntouch]        bit sd' set if the element has a vertex on side sd'
+  const int* touch_rlist;    // [4][nvs][9]        count, then the rows 3 p + k (p-th touching element, DoF k) that sit on side vertex pos (count -1: > 8 rows)
+  const int* sface_i;        // [4][ncf][12]       side face p of side sd: element T, its face f_p on the side, RT0 rows of its faces 0..2,
+                             //                    template signs of those faces, the side a face lies on (or -1); 0-padded
+  const double* sface_d;     // [4][ncf][4]        |e_g| (g = 0..2), |T|
   // conventions the reference tree leaves open (lrbms_ctx_set_option; defaults = DESIGN.md section 3)
   int opt_oswald_subdomain;      // 1: the Oswald interpolant vanishes on the WHOLE subdomain boundary (block_swipdg.py:108-113 read
                                  //    literally: all-Dirichlet boundary info on the subdomain layer), 0: on the physical boundary only
