@@ -420,6 +420,11 @@ __global__ __launch_bounds__(256) void k3_flux(T3 t, int Q, int N, int rbeg, int
   }
 }
 
+// (Measured and dropped, round 3: the own faces from element chunks staged in LDS -- 24 elements per workgroup, rows and flux
+// coefficients loaded once with 16-byte loads, only the faces towards a later chunk read their second element from global memory:
+// 268 + 70 us (side faces) against 363 us for this kernel, but the PASS went from 2.19 to 2.29 ms: with 73 KB of LDS and 128 VGPRs
+// per workgroup the sweep no longer fits beside the MFMA kernels of the other two chains, and hiding under them is worth more than
+// the 25 us.)
 // Avg [S][n_nodes][N]: own share of the Oswald node average (0 on the physical boundary: the interpolant vanishes there);
 // As [S][6][nvs][N]: the neighbours' shares at the side nodes.  One wave per node, DoF lists through the scalar cache.
 __global__ __launch_bounds__(256) void k3_node_avg(T3 t, int N, int rbeg, int rend, const double* __restrict__ V,

@@ -236,6 +236,37 @@ def test_forms_of_the_projection_kernel_agree(shape, kc, N):
             assert torch.equal(G_aa[q, q2], G_aa[q2, q].transpose(1, 2))
 
 
+@pytest.mark.parametrize('shape, kc, N', [((6, 5), 4, 40), ((3, 3), 4, 36), ((4, 4), 2, 20), ((3, 2), 1, 6), ((2, 3), 4, 48)])
+def test_forms_of_the_preparation_agree(shape, kc, N):
+    """LRBMS_OPT_PREP_LDS: the preparation from one copy of the basis slab in LDS (k_prep_lds: flux image, vertex averages and --
+    folded in -- G_nc[self, self] in its rank-2 form), the same without the fold (k_f3 runs) and the two streaming sweeps
+    (k_flux_compact, k_vertex_avg) give the same outputs: flux image and vertex averages feed every estimator operator, so all of
+    them are compared -- bit for bit where the arithmetic is the same expression (everything but G_nc), to rounding for G_nc (the
+    fold sums 2 rows per element, Z = L^T G W, where k_f3 sums 3); G_nc is symmetric (off-diagonal tiles are mirrored: exactly; inside
+    a diagonal tile the two halves are separate sums: to rounding)."""
+    import torch
+    from pylrbms_amd import multiscale_problem
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(shape), 'coarse_per_subdomain': kc})
+    eng = _engine(p)
+    V = eng.ctx.from_numpy(make_bases(eng.S, eng.t.n, N, seed=8))
+    outs = {}
+    try:
+        for form in (1, 2, 0):
+            eng.ctx.set_option('prep_lds', form)
+            buf = eng.project_and_estimate(V)
+            outs[form] = [x.clone() for x in buf['sys']] + [x.clone() for x in buf['grams']]
+    finally:
+        eng.ctx.set_option('prep_lds', 1)
+    G_nc = outs[1][4]
+    assert float((G_nc - G_nc.transpose(1, 2)).abs().max()) <= 1e-14 * float(G_nc.abs().max())
+    for form in (2, 0):
+        for i, (a, b) in enumerate(zip(outs[1], outs[form])):
+            if i == 4:          # G_nc [S][N][N]: another summation
+                assert float((a - b).abs().max()) <= 1e-12 * float(a.abs().max()), form
+            else:
+                assert torch.equal(a, b), (form, i)
+
+
 @pytest.mark.parametrize('shape, kc, N', [((3, 3), 2, 5), ((4, 3), 1, 2), ((2, 2), 2, 40)])
 def test_vertex_patch_of_the_oswald_interpolation(shape, kc, N):
     """LRBMS_OPT_OSWALD_VERTEX_PATCH (conventions={'oswald_vertex_patch': True}): the Oswald average at a cross point runs over
