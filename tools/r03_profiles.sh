@@ -22,6 +22,11 @@ python3 tools/pmc_sq.py $O/cfg3_sq1 $O/cfg3_sq2 > $O/cfg3_pmc_sq.txt 2>&1
 python3 tools/pmc3d.py --json $O/cfg5_pmc_traffic.json cfg5 $O/cfg5_fetch $O/cfg5_write > $O/cfg5_pmc_traffic.txt 2>&1
 python3 tools/pmc3d.py $O/cfg5_sq1 $O/cfg5_sq2 > $O/cfg5_pmc_sq.txt 2>&1
 rm -rf $O/*_stats $O/*_fetch $O/*_write $O/*_sq1 $O/*_sq2
+# cycle stamps inside k_prep_lds / k_thin3 (experiment builds made by tools/build_variant.sh ptrace -DPREP_TRACE, ttrace -DTHIN_TRACE)
+for v in ptrace:prep_trace ttrace:thin_trace; do
+  so=pylrbms_amd/_variants/${v%%:*}.so
+  if [ -f $so ]; then LRBMS_HIP_LIB=$GRAFT_REPO_ROOT/$so python3 tools/${v##*:}.py 2> /dev/null > $O/${v##*:}.txt; fi
+done
 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 bench.py --config cfg5 --no-cpu-baseline > $O/bench_cfg5.json 2> $O/bench_cfg5.err
 tail -n 12 $O/cfg3_pmc_traffic.txt; tail -c 300 $O/bench.json
