@@ -370,6 +370,10 @@ __global__ __launch_bounds__(256) void k_prep(Tmpl t, int S, const int* __restri
 // averages again -- from the slab and the averages it has in LDS.  164 us (two sweeps) -> 82 us; + G_nc: 120 us against 82 + 57.
 // Where a workgroup's time goes at config 3 (tools/prep_trace.py, cycles): loads 22 k (all 256 workgroups of a round fetch their
 // 150 KB at the same time: HBM-bound), flux rows 11 k, averages 7 k, Z rows 5 k, MFMA 9 k, reduction 3 k.
+// (Measured and dropped: PERSISTENT workgroups, one per CU, that request the next subdomain's slab into registers in front of the
+// MFMA phase -- the trace shows the load phase shrink from 22 k to 10 k cycles, but with 1 024 threads the kernel has 128 VGPRs:
+// half a slab in registers is all that fits without spilling the prefetched values -- a spill waits for the load -- and the
+// kernel went from 120 to 117 us; the whole slab in registers, spilled: 169 us.)
 // Needs even N and prep_lds_bytes() of LDS (156 KB at config 3 with the fold); the launcher falls back to the sweeps above otherwise.
 constexpr int PREP_LDS_THREADS = 1024, PREP_SIDE_THREADS = 512;
 // LDS layout (bytes): Vl [n][N] (at least PREP_GNC_PART with the G_nc fold) | vinfo [nv] | Lg [nT][6] (fold) | vptr [nv + 1], vidx [n],

@@ -5,8 +5,8 @@
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
-B3="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-online --no-config5"
-B5="python3 bench.py --config cfg5 --opt3 serial=1 --steps 5 --warmup 1 --no-cpu-baseline --no-online"
+B3="python3 bench.py --no-cpu-baseline --no-online --no-config5"      # the default 20 steps + 3 warm-up passes: steady-state averages
+B5="python3 bench.py --config cfg5 --opt3 serial=1 --no-cpu-baseline --no-online"
 SQ1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES"
 for cfg in cfg3 cfg5; do
