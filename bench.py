@@ -200,6 +200,8 @@ def load_pmc_traffic(config):
     profiles/rNN_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950).  None when no profile of this configuration is on file."""
     import glob
+    from pylrbms_amd._build import source_sha
+    stale = None
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
         try:
             with open(path) as fh:
@@ -208,11 +210,13 @@ def load_pmc_traffic(config):
             continue
         if doc.get('config') == config:
             doc['file'] = os.path.relpath(path, ROOT)
-            # a profile speaks for the kernels it was taken from: same kernel sources, or the traffic figures are withheld
-            from pylrbms_amd._build import source_sha
+            # a profile speaks for the kernels it was taken from: same kernel sources, or the traffic figures are withheld.
+            # Several sets are on file (earlier rounds, mid-round): the one of THIS build wins.
             doc['stale'] = doc.get('csrc_sha') != source_sha()
-            return doc
-    return None
+            if not doc['stale']:
+                return doc
+            stale = stale or doc
+    return stale
 
 
 def main():

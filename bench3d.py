@@ -228,10 +228,10 @@ def run(config='cfg5', steps=10, warmup=2, device_index=0, cpu=True, online=True
             if doc.get('config') != config:
                 continue
             from pylrbms_amd._build import source_sha
-            if doc.get('csrc_sha') != source_sha():       # a profile speaks for the kernels it was taken from
-                roofline['traffic_source'] = '{} (withheld: the kernel sources changed since that profile was taken)'.format(
-                    os.path.join('profiles', os.path.basename(path)))
-                break
+            if doc.get('csrc_sha') != source_sha():       # a profile speaks for the kernels it was taken from: look for this build's
+                roofline.setdefault('traffic_source', '{} (withheld: the kernel sources changed since that profile was taken)'.format(
+                    os.path.join('profiles', os.path.basename(path))))
+                continue
             for r in table:
                 if r['name'] in doc['per_kernel']:
                     r['pmc_bytes'] = doc['per_kernel'][r['name']]['bytes']
