@@ -3236,15 +3236,18 @@ int lrbms3_project_estimate_phase(lrbms3_ctx* ctx, int32_t phase, int32_t Q, int
   // operator) would leave most of the 256 CUs idle, so the element range is dealt to ksplit workgroups and k3_pg_combine sums
   // their partial results in a fixed order.  Off (ksplit = 1, no extra launch) from ~400 workgroups per kernel on.
   const int ks_env = ctx->opt_ksplit;      // LRBMS3_OPT_KSPLIT
-  auto ksplit_of = [&](int nblocks) {
+  // target workgroups per launch, measured on the 4 x 4 x 4 tile of an 8-GPU run (64 subdomains; LRBMS3_OPT_KSPLIT 2 / 4 / 6 / auto):
+  // the kernels with ONE workgroup per subdomain and ~240 VGPRs (BB: 4 waves, NC: 8 waves) want one workgroup per CU (k3_pg<BB>
+  // 104 us at 256 workgroups, 124 at 512; <NC> 44 vs 51), G_aa three per CU (70 us at 768, 85 at 576), the others two
+  auto ksplit_of = [&](int nblocks, int target) {
     if (ks_env > 0) return ks_env < 8 ? ks_env : 8;
     if (nblocks >= 384) return 1;
-    const int k = (512 + nblocks - 1) / nblocks;
-    return k < 8 ? k : 8;
+    const int k = (target + nblocks - 1) / nblocks;
+    return k < 1 ? 1 : (k < 8 ? k : 8);
   };
   const int QNl = Q * N;
-  const int ks_sys = ksplit_of(Q * t.S), ks_aaa = ksplit_of(npair * t.S), ks_nc = ksplit_of(t.S), ks_ab = ksplit_of(Q * t.S),
-            ks_bb = ksplit_of(t.S), ks_cpl = ksplit_of(Q * t.S * 6);
+  const int ks_sys = ksplit_of(Q * t.S, 512), ks_aaa = ksplit_of(npair * t.S, 768), ks_nc = ksplit_of(t.S, 256), ks_ab = ksplit_of(Q * t.S, 512),
+            ks_bb = ksplit_of(t.S, 256), ks_cpl = ksplit_of(Q * t.S * 6, 512);
   const long need_sys = ks_sys > 1 ? (long)Q * t.S * ks_sys * pg_part_size<G_SYS>(N, QNl) : 0,
              need_aaa = ks_aaa > 1 ? (long)npair * t.S * ks_aaa * pg_part_size<G_AAA>(N, QNl) : 0,
              need_nc = ks_nc > 1 ? (long)t.S * ks_nc * pg_part_size<G_NC>(N, QNl) : 0,
