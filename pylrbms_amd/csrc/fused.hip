@@ -424,7 +424,10 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
                                                                int write_side, GncArgs ga) {
   extern __shared__ double Vl[];
   const int s = blockIdx.x, tid = threadIdx.x, N2 = N / 2, QN = Q * N, nvs = nvs_of(t);
-  const bool gnc = ga.G_nc != nullptr;           // workgroup-uniform
+  // gridDim.y == 2 (ranks with at most half as many subdomains as the chip has CUs): the work of a subdomain is dealt to TWO workgroups
+  // that each load the slab -- part 0 the flux image, part 1 the vertex averages and G_nc -- instead of leaving half of the CUs idle
+  const bool do_flux = gridDim.y == 1 || blockIdx.y == 0, do_avg = gridDim.y == 1 || blockIdx.y == 1;      // workgroup-uniform
+  const bool gnc = ga.G_nc != nullptr && do_avg;
   PREP_STAMP(0);
   struct VInfo { double inv; int p0, cnt; };     // per lattice vertex: inverse patch size (0 on a Dirichlet vertex), its DoF list
   VInfo* vinfo = reinterpret_cast<VInfo*>(reinterpret_cast<char*>(Vl) + prep_lds_slab_bytes(t, N, gnc));
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
     d2* dst = reinterpret_cast<d2*>(Vl);
     const int total2 = t.n * N2;
     int e0 = 0, e1 = 0, side = -1, f0 = 0;
-    if (tid < t.nrt) e0 = t.rt_e0[tid], e1 = t.rt_e1[tid], side = t.rt_side[tid], f0 = t.rt_f0[tid];
+    if (do_flux && tid < t.nrt) e0 = t.rt_e0[tid], e1 = t.rt_e1[tid], side = t.rt_side[tid], f0 = t.rt_f0[tid];
     constexpr int U = 8;
     static_assert(PREP_LDS_THREADS * U * 2 >= 384 * 40, "config 3: the slab in one round of loads");
     for (int base = 0; base < total2; base += U * PREP_LDS_THREADS) {
@@ -476,11 +479,11 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
           }
         }
         const int f2 = t.nrt * 3;                    // 16-byte pieces of one component's coefficient rows
-        for (int i = tid; i < Q * f2; i += PREP_LDS_THREADS) {
+        for (int i = tid; do_flux && i < Q * f2; i += PREP_LDS_THREADS) {
           const int q = i / f2, k = i - q * f2;
           reinterpret_cast<d2*>(Fl)[i] = reinterpret_cast<const d2*>(F + ((long)q * S + s) * t.nrt * 6)[k];
         }
-        for (int r = tid; r < t.nrt; r += PREP_LDS_THREADS) {
+        for (int r = tid; do_flux && r < t.nrt; r += PREP_LDS_THREADS) {
           if (r != tid) e0 = t.rt_e0[r], e1 = t.rt_e1[r], side = t.rt_side[r], f0 = t.rt_f0[r];      // (templates with n_rt > 1024)
           const int pos = side >= 0 ? t.elem_side_pos[e0 * 3 + f0] : 0;
           rinfo[r] = make_int4(e0, e1, side, pos);
@@ -501,7 +504,8 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
   const int nmain = write_side ? PREP_LDS_THREADS - PREP_SIDE_THREADS : PREP_LDS_THREADS;
   const int ts = tid - nmain;
   const d2* V2 = reinterpret_cast<const d2*>(V);
-  if (tid < nmain) {
+  if (!do_flux) {
+  } else if (tid < nmain) {
     // ---- R_self: one item per (RT0 row, pair of columns)
     d2* R2 = reinterpret_cast<d2*>(Rself + (long)s * t.nrt * QN);
     for (int it = tid; it < t.nrt * N2; it += nmain) {
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
   }
   PREP_STAMP(3);
   // (the barriers of the fold order LDS traffic only: __syncthreads() would also wait for the global stores of the rows just written)
+  if (!do_avg) return;
   if (gnc) lds_barrier();                        // Fl, rinfo, srow are dead: the averages may overwrite them
   PREP_STAMP(4);
   if (tid < nmain) {
@@ -3704,12 +3709,18 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   if (do_prep) {
     if (prep_from_lds) {
       KScope ks(ctx, "k_prep_lds", st);
+      if (ctx->num_cus == 0) {
+        int ncu = 0;
+        LRBMS_HIP_CHECK(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        ctx->num_cus = ncu > 0 ? ncu : 256;
+      }
+      const int prep_parts = 2 * S <= ctx->num_cus ? 2 : 1;      // one workgroup per CU: two per subdomain while that leaves none waiting
       const GncArgs ga{ebar, gnc_fold ? G_nc : nullptr, factored ? (long)N * N : (long)25 * N * N, factored ? N : 5 * N,
                        factored ? 0 : 10 * N * N + 2 * N};
 #define LRBMS_PREP(NTXV)                                                                                                              \
   do {                                                                                                                                \
     LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_prep_lds<NTXV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds)); \
-    hipLaunchKernelGGL(k_prep_lds<NTXV>, dim3(S), dim3(PREP_LDS_THREADS), prep_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf, \
+    hipLaunchKernelGGL(k_prep_lds<NTXV>, dim3(S, prep_parts), dim3(PREP_LDS_THREADS), prep_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf, \
                        AvgSide, phase == 0 ? 1 : 0, ga);                                                                              \
   } while (0)
       if (ntx_p == 1) LRBMS_PREP(1);

@@ -51,6 +51,7 @@ void lrbms_side_stream_release(int device, int i);
 
 struct lrbms_ctx {
   int device = 0;
+  int num_cus = 0;                // compute units of the device (queried on first use)
   bool has_mesh = false;
   Tmpl t{};
   int S = 0, S_ext = 0;
