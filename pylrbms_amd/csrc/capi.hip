@@ -123,7 +123,8 @@ int lrbms_ctx_create(int device, lrbms_ctx** out) {
   lrbms_ctx* ctx = new (std::nothrow) lrbms_ctx();
   if (!ctx) return LRBMS_E_INVALID;
   ctx->device = device;
-  bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+  bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; i < 3 && ok; ++i)
     ok = (ctx->aux[i] = lrbms_side_stream_acquire(device, i)) != nullptr &&
          hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
@@ -144,6 +145,7 @@ int lrbms_ctx_destroy(lrbms_ctx* ctx) {
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
   for (auto& k : ctx->ktimers) {
     if (k.e0) (void)hipEventDestroy(k.e0);
     if (k.e1) (void)hipEventDestroy(k.e1);

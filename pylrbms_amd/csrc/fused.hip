@@ -3741,7 +3741,11 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       hipLaunchKernelGGL(k_vertex_avg, dim3(S, gy_vtx), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
                          phase == 0 ? 1 : 0);
     }
+    // sharded pass: phase 2 (on another stream, once the halo is there) reads what the preparation wrote; the library orders
+    // the two itself, so that the host needs neither a call boundary nor an event of its own between preparation and dense kernels
+    // (recorded below, where the fork event of a forked call -- the same point of the stream -- serves as well)
   } else if (do_b) {
+    LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->prep_done ? ctx->prep_done : ctx->ev_prep, 0));      // (a no-op if never recorded / same stream)
     if (merge_prep) {
       const unsigned gxf = grid_for((long)S * 4 * t.ncf * N), gxv = grid_for((long)S * 4 * nvs * N);
       KScope ks(ctx, "k_prep_side", st);
@@ -3770,11 +3774,17 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // sharded choreography runs phase 2 on stream 0) needs neither.
   // (Replaying the phases as captured hipGraphs instead was measured too: one graph launch costs ~35 us of host time and
   // the replay loses the overlap between the branches, 272 us per step.)
-  const bool use_aux[3] = {multi && ctx->aux[0] != st, multi && do_a && ctx->aux[1] != st, false};
-  if (use_aux[0] || use_aux[1] || use_aux[2]) {
+  const bool f3_runs = do_a && !(prep_from_lds && gnc_fold);      // library stream 0 carries the thin kernels and k_f3
+  const bool use_aux[3] = {multi && (do_b || f3_runs) && ctx->aux[0] != st, multi && do_a && ctx->aux[1] != st, false};
+  const bool forks = use_aux[0] || use_aux[1] || use_aux[2];
+  if (forks) {
     LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
     for (int i = 0; i < 3; ++i)
       if (use_aux[i]) LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+  }
+  if (phase == 1 || phase == 3) {      // what phase 2 waits for: the point behind the preparation (one event packet, not two)
+    if (!forks) LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_prep, st));
+    ctx->prep_done = forks ? ctx->ev_fork : ctx->ev_prep;
   }
 
   // ---- F1: build the column-group list and launch in slices of at most 4 * F1_NTY * 16 / N groups

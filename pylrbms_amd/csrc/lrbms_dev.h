@@ -60,6 +60,8 @@ struct lrbms_ctx {
   std::vector<void*> owned;       // device allocations to free
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // library-owned streams: independent small kernels run concurrently
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_prep = nullptr;   // fused pass, phases 1 / 3: recorded behind the preparation of the own basis; phase 2 waits for it
+  hipEvent_t prep_done = nullptr; // ... or for the fork event of that call, recorded at the same point (whichever the last call used)
   // coarse level of the reduced solvers' preconditioner (online.hip): rocBLAS handle and S x S scratch, created on first use
   void* blas = nullptr;
   double* coarse = nullptr;       // [2][S][S] + info

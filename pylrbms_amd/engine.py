@@ -214,18 +214,16 @@ class Engine:
                 main = torch.cuda.current_stream()
                 side = c.aux_stream(0)     # a library stream, not a fresh one: HIP maps streams onto few hardware queues
                 if '_step_events' not in self.__dict__:
-                    self._step_events = (torch.cuda.Event(), torch.cuda.Event())
-                prepared, done = self._step_events
+                    self._step_events = (torch.cuda.Event(),)
+                done, = self._step_events
                 finish = halo.start(V)                      # pack on the main stream + asynchronous collective
-                run(3)                                      # R_self, Avg_self (local slabs only)
-                prepared.record(main)
-                run(4)                                      # k_f1, k_f2, k_f3 on the main stream (local slabs only)
+                run(1)                                      # preparation of the own basis + the dense kernels (local slabs only), ONE
+                                                            # call: the library records its own event behind the preparation
                 torch.cuda.set_stream(side)                 # beside them, as soon as the halo is there (set_stream pair and
                 try:                                        # persistent events: the context manager + wait_stream cost 20 us)
-                    side.wait_event(prepared)
                     finish()                                # side stream waits for the collective, unpacks into V[S:]
-                    run(2)                                  # R_side, Avg_side, thin kernels, coupling blocks
-                    done.record(side)
+                    run(2)                                  # R_side, Avg_side, thin kernels, coupling blocks (the library makes
+                    done.record(side)                       # this stream wait for the preparation)
                 finally:
                     torch.cuda.set_stream(main)
                 main.wait_event(done)

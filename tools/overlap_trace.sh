@@ -10,7 +10,7 @@ rows=[r for r in rows if 'assemble' not in r['Kernel_Name'] and 'build_tables' n
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # last pass: last 8-12 kernels
 import re
-last=rows[-11:] if '$m'=='overlap' else rows[-8:]
+last=rows[-7:] if '$m'=='overlap' else rows[-4:]
 t0=int(last[0]['Start_Timestamp'])
 print('$m')
 for r in last:
