@@ -427,10 +427,14 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
   // gridDim.y == 2 (ranks with at most half as many subdomains as the chip has CUs): the work of a subdomain is dealt to TWO workgroups
   // that each load the slab -- part 0 the flux image, part 1 the vertex averages and G_nc -- instead of leaving half of the CUs idle
   const bool do_flux = gridDim.y == 1 || blockIdx.y == 0, do_avg = gridDim.y == 1 || blockIdx.y == 1;      // workgroup-uniform
-  const bool gnc = ga.G_nc != nullptr && do_avg;
+  // write_side: 0 the own rows only (halo-independent phase of a sharded pass), 1 own rows and the neighbours' shares, 2 the
+  // neighbours' shares only (the halo-dependent phase: no slab, every thread takes side items -- the same code, hence the same bits,
+  // as the whole pass)
+  const bool side_only = write_side == 2;
+  const bool gnc = ga.G_nc != nullptr && do_avg && !side_only;
   PREP_STAMP(0);
   struct VInfo { double inv; int p0, cnt; };     // per lattice vertex: inverse patch size (0 on a Dirichlet vertex), its DoF list
-  VInfo* vinfo = reinterpret_cast<VInfo*>(reinterpret_cast<char*>(Vl) + prep_lds_slab_bytes(t, N, gnc));
+  VInfo* vinfo = reinterpret_cast<VInfo*>(reinterpret_cast<char*>(Vl) + (write_side == 2 ? 0 : prep_lds_slab_bytes(t, N, gnc)));      // (side only: no slab)
   double* Lg = reinterpret_cast<double*>(vinfo + t.nv);                                                       // [nT][2][3]: L^T G_T (fold only)
   int* vptr = reinterpret_cast<int*>(Lg + (gnc ? 6 * t.nT : 0));
   int* vidx = vptr + t.nv + 1;
@@ -452,12 +456,12 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
     if (do_flux && tid < t.nrt) e0 = t.rt_e0[tid], e1 = t.rt_e1[tid], side = t.rt_side[tid], f0 = t.rt_f0[tid];
     constexpr int U = 8;
     static_assert(PREP_LDS_THREADS * U * 2 >= 384 * 40, "config 3: the slab in one round of loads");
-    for (int base = 0; base < total2; base += U * PREP_LDS_THREADS) {
+    for (int base = 0; base < (side_only ? 1 : total2); base += U * PREP_LDS_THREADS) {
       d2 tmp[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int i = base + u * PREP_LDS_THREADS + tid;
-        tmp[u] = src[i < total2 ? i : total2 - 1];
+        tmp[u] = side_only ? (d2){0.0, 0.0} : src[i < total2 ? i : total2 - 1];
       }
       if (base == 0) {
         for (int i = tid; i <= t.nv; i += PREP_LDS_THREADS) vptr[i] = t.vdof_ptr[i];
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int i = base + u * PREP_LDS_THREADS + tid;
-        if (i < total2) dst[i] = tmp[u];
+        if (i < total2 && !side_only) dst[i] = tmp[u];
       }
     }
   }
@@ -501,8 +505,8 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
   __syncthreads();
   PREP_STAMP(2);
   const d2* Vl2 = reinterpret_cast<const d2*>(Vl);
-  const int nmain = write_side ? PREP_LDS_THREADS - PREP_SIDE_THREADS : PREP_LDS_THREADS;
-  const int ts = tid - nmain;
+  const int nmain = side_only ? 0 : (write_side ? PREP_LDS_THREADS - PREP_SIDE_THREADS : PREP_LDS_THREADS);
+  const int ts = tid - nmain, nst = PREP_LDS_THREADS - nmain;      // side threads: index, count
   const d2* V2 = reinterpret_cast<const d2*>(V);
   if (!do_flux) {
   } else if (tid < nmain) {
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
     // ---- the neighbours' share of the flux image (write_side only): the last PREP_SIDE_THREADS threads.  Every item of theirs waits
     // for global loads (the neighbours' rows)
     d2* Rs2 = reinterpret_cast<d2*>(Rside + (long)s * 4 * t.ncf * QN);
-    for (int it = ts; it < 4 * t.ncf * N2; it += PREP_SIDE_THREADS) {
+    for (int it = ts; it < 4 * t.ncf * N2; it += nst) {
       const int sp = it / N2, j2 = it - sp * N2;
       const int sd = sp / t.ncf;
       if (sp - sd * t.ncf >= (sd == 0 ? sc0 : sd == 1 ? sc1 : sd == 2 ? sc2 : sc3)) continue;      // a side with fewer than ncf faces
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
   } else {
     // ---- the neighbours' shares of the vertex averages, beside the own ones
     d2* As2 = reinterpret_cast<d2*>(AvgSide + (long)s * 4 * nvs * N);
-    for (int it = ts; it < 4 * nvs * N2; it += PREP_SIDE_THREADS) {
+    for (int it = ts; it < 4 * nvs * N2; it += nst) {
       const int sp = it / N2, j2 = it - sp * N2;
       const int sd = sp / nvs, pos = sp - sd * nvs;
       if (pos >= ((sd == 0 || sd == 3) ? t.nvx : t.nvy)) continue;
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
     }
     if (t.opt_oswald_vertex) {                   // the diagonal subdomains' shares at the four corners: Avg_corner [S][4][N]
       d2* Ac2 = reinterpret_cast<d2*>(AvgSide + (long)S * 4 * nvs * N + (long)s * 4 * N);
-      for (int it = ts; it < 4 * N2; it += PREP_SIDE_THREADS) {
+      for (int it = ts; it < 4 * N2; it += nst) {
         const int corner = it / N2, j2 = it - corner * N2;
         const int v = ((corner & 1) ? t.nvx - 1 : 0) + t.nvx * ((corner & 2) ? t.nvy - 1 : 0);
         const OsInfo o = oswald_vertex(t, nbr + s * 5, v);
@@ -3746,7 +3750,17 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     // (recorded below, where the fork event of a forked call -- the same point of the stream -- serves as well)
   } else if (do_b) {
     LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->prep_done ? ctx->prep_done : ctx->ev_prep, 0));      // (a no-op if never recorded / same stream)
-    if (merge_prep) {
+    if (merge_prep && prep_from_lds) {
+      // the neighbours' shares by the side threads' code of k_prep_lds (one workgroup per subdomain, per-vertex data and row tables
+      // resolved once per workgroup): 31 -> 10 us at 128 subdomains, and bit-identical to the whole pass by construction
+      KScope ks(ctx, "k_prep_lds<side>", st);
+      const GncArgs ga{ebar, nullptr, 0, 0, 0};
+      const size_t side_lds = prep_lds_bytes(t, Q, N, false) - prep_lds_slab_bytes(t, N, false);      // tables + coefficients: no slab
+      if (side_lds > 64 * 1024)
+        LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_prep_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)side_lds));
+      hipLaunchKernelGGL(k_prep_lds<1>, dim3(S, 1), dim3(PREP_LDS_THREADS), side_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
+                         AvgSide, 2, ga);
+    } else if (merge_prep) {
       const unsigned gxf = grid_for((long)S * 4 * t.ncf * N), gxv = grid_for((long)S * 4 * nvs * N);
       KScope ks(ctx, "k_prep_side", st);
       hipLaunchKernelGGL(k_prep_side, dim3(gxf + gxv), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside, AvgSide, (int)gxf);
