@@ -3750,7 +3750,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     // (recorded below, where the fork event of a forked call -- the same point of the stream -- serves as well)
   } else if (do_b) {
     LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->prep_done ? ctx->prep_done : ctx->ev_prep, 0));      // (a no-op if never recorded / same stream)
-    if (merge_prep && prep_from_lds) {
+    if (prep_from_lds) {
       // the neighbours' shares by the side threads' code of k_prep_lds (one workgroup per subdomain, per-vertex data and row tables
       // resolved once per workgroup): 31 -> 10 us at 128 subdomains, and bit-identical to the whole pass by construction
       KScope ks(ctx, "k_prep_lds<side>", st);
@@ -3765,9 +3765,18 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       KScope ks(ctx, "k_prep_side", st);
       hipLaunchKernelGGL(k_prep_side, dim3(gxf + gxv), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside, AvgSide, (int)gxf);
     } else {
-      KScope ks(ctx, "k_flux_side", st);
-      hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)S * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
-      // Avg_side is read by k_thin_nc only: k_vertex_side is launched right in front of it
+      {
+        KScope ks(ctx, "k_flux_side", st);
+        hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)S * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
+      }
+      // Avg_side: the dense layout launches k_vertex_side right in front of its only reader, k_thin_nc (below); in the factored
+      // layout the reader is k_thin3, which is launched from the merged branch -- so it goes out here.  (Round 3: it went out
+      // NOWHERE in that combination -- factored layout, >= 192 subdomains per rank, phase 2 -- and the phased-vs-whole test did not
+      // see it because it reused a work buffer that still held the averages of the whole pass.)
+      if (merge_thin) {
+        KScope ks(ctx, "k_vertex_side", st);
+        hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)S * 4 * nvs * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSide);
+      }
     }
   }
   LRBMS_LAUNCH_CHECK(ctx);

@@ -69,6 +69,7 @@ def test_phased_pass_is_bit_identical(cfg5):
     o2, work = eng.alloc_outputs(N), eng.alloc_work(N)
     for v in o2.values():
         v.fill_(float('nan'))
+    work.fill_(float('nan'))      # a recycled allocation may still hold the intermediates of the whole pass
     eng.ctx.project_estimate(eng.Q, V, eng.ops, work, o2, phase=1)
     eng.ctx.project_estimate(eng.Q, V, eng.ops, work, o2, phase=2)
     torch.cuda.synchronize()
