@@ -75,7 +75,12 @@ def _worker(rank, world, port, ref_path, results):
         ref = np.load(ref_path)
         ok = True
         worst = 0.0
-        for fused in (False, True, 'phased', 'overlap'):
+        for fused in (False, True, 'phased', 'overlap', 'phased/unforked', 'phased/unforked/streaming', 'overlap/unforked'):
+            # '/unforked': the launch policy of a rank with >= 192 subdomains (every kernel its own launch on one stream), forced
+            # here at a small count; '/streaming': the preparation by the streaming sweeps (k_flux_side + k_vertex_side in phase 2)
+            eng.ctx.set_option('streams', 0 if 'unforked' in str(fused) else -1)
+            eng.ctx.set_option('prep_lds', 0 if 'streaming' in str(fused) else 1)
+            fused = str(fused).split('/')[0] if isinstance(fused, str) else fused
             if fused == 'overlap':
                 # the production form of a sharded pass: Engine drives the exchange (gloo here: staged through the host)
                 # and the stream choreography -- dense kernels on the main stream, halo-dependent ones on a side stream
