@@ -3750,7 +3750,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     // (recorded below, where the fork event of a forked call -- the same point of the stream -- serves as well)
   } else if (do_b) {
     LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->prep_done ? ctx->prep_done : ctx->ev_prep, 0));      // (a no-op if never recorded / same stream)
-    if (prep_from_lds) {
+    if (prep_from_lds && S <= (ctx->num_cus > 0 ? ctx->num_cus : 256)) {      // (more subdomains than CUs: the streaming pair is faster)
       // the neighbours' shares by the side threads' code of k_prep_lds (one workgroup per subdomain, per-vertex data and row tables
       // resolved once per workgroup): 31 -> 10 us at 128 subdomains, and bit-identical to the whole pass by construction
       KScope ks(ctx, "k_prep_lds<side>", st);
