@@ -416,8 +416,10 @@ struct GncArgs {           // G_nc != nullptr: the fold runs (the launcher then 
   int gld, goff;
 };
 
-template <int NTX>
-__global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
+// NTHR: 1 024 threads (everything), or 256 for the slab-less launch of the halo-dependent phase (write_side == 2 only: small workgroups,
+// several per CU, beside the dense kernels)
+template <int NTX, int NTHR = PREP_LDS_THREADS>
+__global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
                                                                const double* __restrict__ F, const double* __restrict__ V,
                                                                double* __restrict__ Rself, double* __restrict__ Rside,
                                                                double* __restrict__ AvgSelf, double* __restrict__ AvgSide,
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
   // neighbours' shares only (the halo-dependent phase: no slab, every thread takes side items -- the same code, hence the same bits,
   // as the whole pass)
   const bool side_only = write_side == 2;
-  const bool gnc = ga.G_nc != nullptr && do_avg && !side_only;
+  const bool gnc = NTHR == 1024 && ga.G_nc != nullptr && do_avg && !side_only;      // (the fold deals its tiles to 16 waves)
   PREP_STAMP(0);
   struct VInfo { double inv; int p0, cnt; };     // per lattice vertex: inverse patch size (0 on a Dirichlet vertex), its DoF list
   VInfo* vinfo = reinterpret_cast<VInfo*>(reinterpret_cast<char*>(Vl) + (write_side == 2 ? 0 : prep_lds_slab_bytes(t, N, gnc)));      // (side only: no slab)
@@ -455,27 +457,27 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
     int e0 = 0, e1 = 0, side = -1, f0 = 0;
     if (do_flux && tid < t.nrt) e0 = t.rt_e0[tid], e1 = t.rt_e1[tid], side = t.rt_side[tid], f0 = t.rt_f0[tid];
     constexpr int U = 8;
-    static_assert(PREP_LDS_THREADS * U * 2 >= 384 * 40, "config 3: the slab in one round of loads");
-    for (int base = 0; base < (side_only ? 1 : total2); base += U * PREP_LDS_THREADS) {
+    static_assert(NTHR != 1024 || NTHR * U * 2 >= 384 * 40, "config 3: the slab in one round of loads");
+    for (int base = 0; base < (side_only ? 1 : total2); base += U * NTHR) {
       d2 tmp[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int i = base + u * PREP_LDS_THREADS + tid;
+        const int i = base + u * NTHR + tid;
         tmp[u] = side_only ? (d2){0.0, 0.0} : src[i < total2 ? i : total2 - 1];
       }
       if (base == 0) {
-        for (int i = tid; i <= t.nv; i += PREP_LDS_THREADS) vptr[i] = t.vdof_ptr[i];
-        for (int i = tid; i < t.n; i += PREP_LDS_THREADS) vidx[i] = t.vdof_idx[i];
-        for (int v = tid; v < t.nv; v += PREP_LDS_THREADS) {          // (integer divisions, a chain of table reads and an fp64 division:
+        for (int i = tid; i <= t.nv; i += NTHR) vptr[i] = t.vdof_ptr[i];
+        for (int i = tid; i < t.n; i += NTHR) vidx[i] = t.vdof_idx[i];
+        for (int v = tid; v < t.nv; v += NTHR) {          // (integer divisions, a chain of table reads and an fp64 division:
           const OsInfo o = oswald_vertex(t, nbr + s * 5, v);          //  once per vertex, not once per item)
           const int p0 = t.vdof_ptr[v];
           vinfo[v] = VInfo{o.inv, p0, t.vdof_ptr[v + 1] - p0};
         }
         if (gnc) {
-          for (int i = tid; i < t.n; i += PREP_LDS_THREADS) dvt[i] = t.dof_vertex[i];
+          for (int i = tid; i < t.n; i += NTHR) dvt[i] = t.dof_vertex[i];
           const double ksym = 0.5 * (t.kappa[1] + t.kappa[2]);
           const double l00 = sqrt(t.kappa[0]), l10 = ksym / l00, l11 = sqrt(t.kappa[3] - l10 * l10);
-          for (int i = tid; i < 3 * t.nT; i += PREP_LDS_THREADS) {      // (element, shape function): rows of L^T applied to its gradient
+          for (int i = tid; i < 3 * t.nT; i += NTHR) {      // (element, shape function): rows of L^T applied to its gradient
             const int T = i / 3, k = i - 3 * T;
             const double gx = t.grad[i * 2], gy = t.grad[i * 2 + 1];
             Lg[T * 6 + k] = l00 * gx + l10 * gy;
@@ -483,11 +485,11 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
           }
         }
         const int f2 = t.nrt * 3;                    // 16-byte pieces of one component's coefficient rows
-        for (int i = tid; do_flux && i < Q * f2; i += PREP_LDS_THREADS) {
+        for (int i = tid; do_flux && i < Q * f2; i += NTHR) {
           const int q = i / f2, k = i - q * f2;
           reinterpret_cast<d2*>(Fl)[i] = reinterpret_cast<const d2*>(F + ((long)q * S + s) * t.nrt * 6)[k];
         }
-        for (int r = tid; do_flux && r < t.nrt; r += PREP_LDS_THREADS) {
+        for (int r = tid; do_flux && r < t.nrt; r += NTHR) {
           if (r != tid) e0 = t.rt_e0[r], e1 = t.rt_e1[r], side = t.rt_side[r], f0 = t.rt_f0[r];      // (templates with n_rt > 1024)
           const int pos = side >= 0 ? t.elem_side_pos[e0 * 3 + f0] : 0;
           rinfo[r] = make_int4(e0, e1, side, pos);
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int i = base + u * PREP_LDS_THREADS + tid;
+        const int i = base + u * NTHR + tid;
         if (i < total2 && !side_only) dst[i] = tmp[u];
       }
     }
@@ -505,8 +507,8 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
   __syncthreads();
   PREP_STAMP(2);
   const d2* Vl2 = reinterpret_cast<const d2*>(Vl);
-  const int nmain = side_only ? 0 : (write_side ? PREP_LDS_THREADS - PREP_SIDE_THREADS : PREP_LDS_THREADS);
-  const int ts = tid - nmain, nst = PREP_LDS_THREADS - nmain;      // side threads: index, count
+  const int nmain = side_only ? 0 : (write_side ? NTHR - NTHR / 2 : NTHR);
+  const int ts = tid - nmain, nst = NTHR - nmain;      // side threads: index, count
   const d2* V2 = reinterpret_cast<const d2*>(V);
   if (!do_flux) {
   } else if (tid < nmain) {
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
       }
     }
   } else {
-    // ---- the neighbours' share of the flux image (write_side only): the last PREP_SIDE_THREADS threads.  Every item of theirs waits
+    // ---- the neighbours' share of the flux image (write_side only): the last NTHR / 2 threads.  Every item of theirs waits
     // for global loads (the neighbours' rows)
     d2* Rs2 = reinterpret_cast<d2*>(Rside + (long)s * 4 * t.ncf * QN);
     for (int it = ts; it < 4 * t.ncf * N2; it += nst) {
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
   {
     d2* Vw = reinterpret_cast<d2*>(Vl);
     const d2* Al2 = reinterpret_cast<const d2*>(Al);
-    for (int it = tid; it < t.nT * N2; it += PREP_LDS_THREADS) {
+    for (int it = tid; it < t.nT * N2; it += NTHR) {
       const int T = it / N2, j2 = it - T * N2;
       d2 w[3];
       double g0[3], g1[3];
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(PREP_LDS_THREADS) void k_prep_lds(Tmpl t, int S, co
     // fixed-order sum over the eight K parts; one item per (tile, accumulator register, lane)
     double* g = ga.G_nc + (long)s * ga.gsub + ga.goff;
     constexpr int NTRI = NTX * (NTX + 1) / 2;
-    for (int it = tid; it < NTRI * 256; it += PREP_LDS_THREADS) {
+    for (int it = tid; it < NTRI * 256; it += NTHR) {
       const int tile = it >> 8, r = (it >> 6) & 3, ln = it & 63;
       const int hf = tile < gnc_count<NTX>(0) ? 0 : 1, k = hf ? tile - gnc_count<NTX>(0) : tile;
       double sum = 0.0;
@@ -3750,15 +3752,14 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     // (recorded below, where the fork event of a forked call -- the same point of the stream -- serves as well)
   } else if (do_b) {
     LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->prep_done ? ctx->prep_done : ctx->ev_prep, 0));      // (a no-op if never recorded / same stream)
-    if (prep_from_lds && S <= (ctx->num_cus > 0 ? ctx->num_cus : 256)) {      // (more subdomains than CUs: the streaming pair is faster)
-      // the neighbours' shares by the side threads' code of k_prep_lds (one workgroup per subdomain, per-vertex data and row tables
-      // resolved once per workgroup): 31 -> 10 us at 128 subdomains, and bit-identical to the whole pass by construction
+    if (prep_ok && prep_lds_bytes(t, Q, N, false) - prep_lds_slab_bytes(t, N, false) <= 64 * 1024) {
+      // the neighbours' shares by the side threads' code of k_prep_lds in its slab-less form (one 256-thread workgroup per subdomain,
+      // per-vertex data and row tables resolved once per workgroup; several workgroups per CU, so it also fits beside the dense
+      // kernels) -- bit-identical to the whole pass by construction
       KScope ks(ctx, "k_prep_lds<side>", st);
       const GncArgs ga{ebar, nullptr, 0, 0, 0};
       const size_t side_lds = prep_lds_bytes(t, Q, N, false) - prep_lds_slab_bytes(t, N, false);      // tables + coefficients: no slab
-      if (side_lds > 64 * 1024)
-        LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_prep_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)side_lds));
-      hipLaunchKernelGGL(k_prep_lds<1>, dim3(S, 1), dim3(PREP_LDS_THREADS), side_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
+      hipLaunchKernelGGL((k_prep_lds<1, 256>), dim3(S, 1), dim3(256), side_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
                          AvgSide, 2, ga);
     } else if (merge_prep) {
       const unsigned gxf = grid_for((long)S * 4 * t.ncf * N), gxv = grid_for((long)S * 4 * nvs * N);
