@@ -350,7 +350,11 @@ def main():
     bad = [k for k, v in outs.items() if not bool(torch.isfinite(v).all())]
     if bad:
         raise RuntimeError('non-finite outputs of the timed pass: ' + ', '.join(bad))
-    output_checksum = float(sum(float(v.sum()) for v in outs.values()))
+    # (sum and sum of absolute values over ALL ranks: a sharded run must reproduce the single-rank figures, tests/test_sharded_gpu.py)
+    cs = torch.stack([sum(v.sum() for v in outs.values()), sum(v.abs().sum() for v in outs.values())])
+    if world > 1:
+        dist.all_reduce(cs, op=dist.ReduceOp.SUM)
+    output_checksum, output_abs_checksum = float(cs[0]), float(cs[1])
 
     # the dense (fp64-MFMA) kernels of the pass on their own: phase 4 = k_f1, k_f2, k_f3 (HIP events on the launch stream)
     dense_ms = None
@@ -379,7 +383,7 @@ def main():
         eng.ctx.kernel_timing(False)
         kernel_ms = {}
         for name, ms in rows:
-            kernel_ms.setdefault(name, []).append(ms)
+            kernel_ms.setdefault({'k_f1v': 'k_f1', 'k_f1u': 'k_f1'}.get(name, name), []).append(ms)   # the forms of one step
         kernel_ms = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
 
     # the same pass writing the DENSE block-compact layout (G_rdd / G_bb [S][9][QN][QN], G_nc [S][5N][5N]: what rd.operators hands a
@@ -589,7 +593,7 @@ def main():
                                               cfg['num_subdomains'][0], cfg['num_subdomains'][1],
                                               cfg['coarse_per_subdomain'], t.n, t.n_rt, Q, N),
                           'subdomains': S_total, 'N': N, 'Q': Q, 'parallelism': 'subdomain tiles x{}'.format(world)},
-               'roofline': roofline, 'distributed': dist_info, 'output_checksum': output_checksum}
+               'roofline': roofline, 'distributed': dist_info, 'output_checksum': output_checksum, 'output_abs_checksum': output_abs_checksum}
         out['assemble'] = {'metric': 'offline assembly K1-K6, K9 (+ flux coefficients)', 'ms': assemble_ms,
                            'value': eng.S / (1e-3 * assemble_ms), 'unit': 'subdomains/s (this rank)'}
         if online is not None:

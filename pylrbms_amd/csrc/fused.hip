@@ -3897,7 +3897,8 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
           hipLaunchKernelGGL(k_f1_zero, dim3(S), dim3(256), 0, st, gt[sl], S, N, sl == 0 ? a.rhs_red : nullptr);
       }
       const dim3 grid(S, nsl, ksplit);
-      KScope ks(ctx, "k_f1", st);
+      // the timing name tells the form that ran (tests assert it; bench.py files all three under k_f1)
+      KScope ks(ctx, lean ? "k_f1v" : unified ? "k_f1u" : "k_f1", st);
       if (lean) {
 #define LRBMS_F1V(A, B, C, D, E)                                               \
   if (ntx == A && Q == B && lv[0] == C && lv[1] == D && lv[2] == E)            \

@@ -209,7 +209,12 @@ class LRBMSReductor3D:
             products   {'domain_i': ...} of the reference is the local energy product of every subdomain (reductor.py:19,
                        online_adaptive_lrbms.py:107); here it is ``d.engine.ops['P_diag']`` (lrbms3_assemble_energy_product) and
                        the argument only switches it: None / anything = the energy product, 'euclidean' = plain dot products
-            order      0 / 1: start every local basis with the shape functions of that order (reductor.py:29-31)
+            order      0 / 1: start every local basis with the shape functions of that order (reductor.py:29-31); with neither
+                       ``bases`` nor ``order`` given: order 0, the reference's default (reductor.py:23-24) -- every local basis then
+                       starts with the constant, which the coarse level of the reduced solver's preconditioner builds on.
+                       Order 1 deviates from the reference (block_swipdg.py:195: uncentred x0, x1, x0*x1, a 2D list whose
+                       projection call is undefined at HEAD): here the constant plus the three coordinates relative to the
+                       subdomain centre, the 3D counterpart of "all polynomials of degree <= 1"
         extend_basis(U)            restrict a block DG function [S, n(, L)] to every subdomain, Gram-Schmidt it into the bases
         extend_basis_local(ii, U)  the same for ONE subdomain (reductor.py:31,78)
         reduce()                   one pass of the hot path (reductor.py:33-73)
@@ -224,6 +229,8 @@ class LRBMSReductor3D:
         eng = d.engine
         self.euclidean = products == 'euclidean'
         self._V, self._nloc = None, None
+        if order is None and bases is None:
+            order = 0                                                    # reductor.py:23-24
         if bases is not None:
             if isinstance(bases, (list, tuple)):
                 blocks = [b if isinstance(b, torch.Tensor) else eng.ctx.from_numpy(np.asarray(b)) for b in bases]

@@ -93,6 +93,8 @@ def test_reference_reductor_surface_in_3d(name):
     d, _ = discretize(pd)
     red = LRBMSReductor3D(d, products=None, order=0)                      # reductor.py:29-31: the constant starts every basis
     assert red.local_sizes() == [1] * o.S
+    dflt = LRBMSReductor3D(d)                                              # reductor.py:23-24: neither bases nor order => order 0
+    assert dflt.local_sizes() == [1] * o.S and torch.equal(dflt.bases, red.bases)
     snaps = []
     for mu in (0.2, 0.9):
         U = d.solve(mu, rtol=1e-12)

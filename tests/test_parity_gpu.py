@@ -44,6 +44,10 @@ def _problems():
         # BASELINE.json config 2 geometry (k_c = 4, N = 20) on a smaller subdomain grid
         'multiscale_4x3_kc4_N20': (lambda: multiscale_problem.init_grid_and_problem(
             {'num_subdomains': [4, 3], 'coarse_per_subdomain': 4}), 20, 0.7),
+        # BASELINE.json config 3's exact kernel shapes (k_c = 4, N = 40, Q = 2: k_f1v<3,2,1,2,4>, k_prep_lds<3> with the G_nc fold,
+        # k_f2<5>, k_thin3<3>) on a 3 x 3 grid (one interior subdomain, every boundary kind) directly against the oracle
+        'multiscale_3x3_kc4_N40': (lambda: multiscale_problem.init_grid_and_problem(
+            {'num_subdomains': [3, 3], 'coarse_per_subdomain': 4}), 40, 0.3),
         # N = 34: the second instantiation of the lean projection kernel for three row tiles (k_f1v<3,2,1,2,3>: six levels of
         # column tiles), with short packed tails of the symmetric groups (2 columns each)
         'multiscale_3x2_kc4_N34': (lambda: multiscale_problem.init_grid_and_problem(
@@ -317,6 +321,65 @@ def test_vertex_patch_of_the_oswald_interpolation(shape, kc, N):
     from pylrbms_amd.engine import expand_factored_grams
     with pytest.raises(NotImplementedError):
         expand_factored_grams(buf['grams'])
+
+
+def test_launch_matrix_against_one_oracle_checked_result():
+    """Every launch combination of the fused pass against ONE result that is itself compared with the oracle: layout {factored,
+    dense} x launch policy {one stream, forked over the library streams} x preparation {streaming sweeps + k_f3, LDS slab with the
+    G_nc fold, LDS slab without it} x projection kernel {k_f1v, k_f1 (producer / consumer), k_f1u} x {whole pass, phase 1 then
+    phase 2}: 72 cells on a 5 x 4 grid of the config-3 template (k_c = 4, N = 40).  Outputs AND the work buffer are poisoned with NaN
+    in front of every cell, so a cell that forgets a launch (round 3: k_vertex_side in factored x unforked x phase 2) cannot pass on
+    what the cell before left behind.  Reference: the unfused kernels' result, compared with the oracle's reductor at 1e-11; every
+    cell against it at 1e-12 (dense-layout arrays; factored cells expanded)."""
+    import itertools
+    import torch
+    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd.engine import expand_factored_grams
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': [5, 4], 'coarse_per_subdomain': 4})
+    eng = _engine(p)
+    d = oracle_from_problem(p)
+    N = 40
+    V = energy_orthonormalize(make_bases(d.S, d.n, N, seed=21), d)
+    res = compare_all(p, eng, V, 0.4, oracle=d, do_solve=False)
+    bad = {k: v for k, v in res.items() if not v < TOL}
+    assert not bad, bad
+    Vd = eng.ctx.from_numpy(V)
+    ref = eng.project_and_estimate(Vd, fused=False)
+    names = ('B_sys', 'rhs_red', 'E_red', 'M_red', 'G_nc', 'r_fd', 'G_rdd', 'G_bb', 'G_ab', 'G_aa')
+    ref = dict(zip(names, [x.clone() for x in list(ref['sys']) + list(ref['grams'])]))
+    scale = {k: float(v.abs().max()) for k, v in ref.items()}
+    bufs = {True: eng.alloc_reduce_buffers(N, factored=True), False: eng.alloc_reduce_buffers(N, factored=False)}
+    failures, seen = [], set()
+    try:
+        for factored, streams, prep, form, phased in itertools.product((True, False), (0, 1), (0, 1, 2), (0, 1, 2), (False, True)):
+            eng.ctx.set_option('streams', streams)
+            eng.ctx.set_option('prep_lds', prep)
+            eng.ctx.set_option('f1_form', form)
+            buf = bufs[factored]
+            for x in list(buf['sys']) + list(buf['grams']) + [buf['work']]:
+                x.fill_(float('nan'))
+            args = (Vd, eng.F, eng.A_diag, eng.A_cpl, eng.P_diag, eng.b, eng.ebar, eng.caa, eng.Aab, eng.Bbb, buf['work'], buf['sys'],
+                    buf['grams'])
+            eng.ctx.kernel_timing(True)
+            if phased:
+                eng.ctx.project_estimate_fused(*args, phase=1)
+                eng.ctx.project_estimate_fused(*args, phase=2)
+            else:
+                eng.ctx.project_estimate_fused(*args, phase=0)
+            seen.update(k for k, _ in eng.ctx.kernel_timing_read())
+            eng.ctx.kernel_timing(False)
+            for name, got in zip(names, list(buf['sys']) + list(expand_factored_grams(buf['grams']))):
+                err = float((got - ref[name]).abs().max()) / scale[name]
+                if not err <= 1e-12:          # (NaN fails too)
+                    failures.append(((factored, streams, prep, form, phased), name, err))
+    finally:
+        for k, v in (('streams', -1), ('prep_lds', 1), ('f1_form', 0)):
+            eng.ctx.set_option(k, v)
+    assert not failures, failures[:12]
+    # the matrix did reach every kernel variant it is meant to enumerate
+    for k in ('k_f1v', 'k_f1u', 'k_f1', 'k_prep_lds', 'k_prep_lds<side>', 'k_prep', 'k_prep_side', 'k_flux_compact', 'k_vertex_avg',
+              'k_flux_side', 'k_vertex_side', 'k_f2', 'k_f3', 'k_thin3', 'k_thin', 'k_thin_nc', 'k_thin_rt', 'k_coupling', 'k_thin_expand'):
+        assert k in seen, (k, sorted(seen))
 
 
 def test_full_size_properties_config3(monkeypatch):

@@ -12,11 +12,16 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 PX, PY, KC, N = 4, 3, 2, 5
+# (subdomains x, y, coarse squares per subdomain and direction, local basis size): 'small' exercises odd N (k_f1u, the streaming
+# sweeps); 'cfg3' is the template of BASELINE.json config 3 / 4 (k_c = 4, N = 40) on a 6 x 4 grid -- the kernels a sharded run of
+# config 4 launches (k_f1v<3,2,1,2,4>, k_prep_lds<3> with the G_nc fold, its slab-less 256-thread phase-2 instance, k_thin3<3>)
+SHAPES = {'small': (PX, PY, KC, N), 'cfg3': (6, 4, 4, 40)}
 
 
-def _problem(comm=None):
+def _problem(comm=None, shape='small'):
     from pylrbms_amd import multiscale_problem
-    return multiscale_problem.init_grid_and_problem({'num_subdomains': [PX, PY], 'coarse_per_subdomain': KC}, mpi_comm=comm)
+    px, py, kc, _ = SHAPES[shape]
+    return multiscale_problem.init_grid_and_problem({'num_subdomains': [px, py], 'coarse_per_subdomain': kc}, mpi_comm=comm)
 
 
 def _engine(p):
@@ -26,7 +31,7 @@ def _engine(p):
     return Engine(p['grid'], lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], theta_bar).assemble()
 
 
-def _bases(S, n):
+def _bases(S, n, N=N):
     rng = np.random.default_rng(77)
     return rng.standard_normal((S, n, N))
 
@@ -53,18 +58,20 @@ def _spawn_and_collect(fn, args, world, tmp_path):
     return out
 
 
-def _worker(rank, world, port, ref_path, results):
+def _worker(rank, world, port, ref_path, shape, results):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
+        from pylrbms_amd.engine import Engine
         from pylrbms_amd.grid import DDSubdomainsGrid
         from pylrbms_amd.parallel import Communicator, HaloExchange, HaloPlan
-        p = _problem(Communicator(rank, world))
+        N = SHAPES[shape][3]
+        p = _problem(Communicator(rank, world), shape)
         grid = p['grid']
         eng = _engine(p)
         n = grid.template.n
-        Vg = _bases(grid.num_subdomains, n)
+        Vg = _bases(grid.num_subdomains, n, N)
         # halo exchange on CPU tensors (gloo), then upload
         Vh = torch.zeros(eng.S_ext, n, N, dtype=torch.float64)
         Vh[:eng.S] = torch.from_numpy(Vg[eng.local])
@@ -75,12 +82,19 @@ def _worker(rank, world, port, ref_path, results):
         ref = np.load(ref_path)
         ok = True
         worst = 0.0
-        for fused in (False, True, 'phased', 'overlap', 'phased/unforked', 'phased/unforked/streaming', 'overlap/unforked'):
+        ran = {}
+        modes = (False, True, 'phased', 'overlap', 'phased/unforked', 'phased/unforked/streaming', 'overlap/unforked',
+                 'overlap/serial', 'overlap/unforked/serial')
+        for mode in modes:
             # '/unforked': the launch policy of a rank with >= 192 subdomains (every kernel its own launch on one stream), forced
-            # here at a small count; '/streaming': the preparation by the streaming sweeps (k_flux_side + k_vertex_side in phase 2)
-            eng.ctx.set_option('streams', 0 if 'unforked' in str(fused) else -1)
-            eng.ctx.set_option('prep_lds', 0 if 'streaming' in str(fused) else 1)
-            fused = str(fused).split('/')[0] if isinstance(fused, str) else fused
+            # here at a small count; '/streaming': the preparation by the streaming sweeps (k_flux_side + k_vertex_side in phase 2);
+            # '/serial': Engine.SERIAL_PHASES_FROM reached -- the two halves one after the other on ONE stream, the branch a rank
+            # with >= 384 subdomains takes (2 GPUs at config 4), halo slabs poisoned until the exchange has finished
+            eng.ctx.set_option('streams', 0 if 'unforked' in str(mode) else -1)
+            eng.ctx.set_option('prep_lds', 0 if 'streaming' in str(mode) else 1)
+            Engine.SERIAL_PHASES_FROM = 1 if 'serial' in str(mode) else 384
+            fused = str(mode).split('/')[0] if isinstance(mode, str) else mode
+            eng.ctx.kernel_timing(True)
             if fused == 'overlap':
                 # the production form of a sharded pass: Engine drives the exchange (gloo here: staged through the host)
                 # and the stream choreography -- dense kernels on the main stream, halo-dependent ones on a side stream
@@ -103,6 +117,8 @@ def _worker(rank, world, port, ref_path, results):
                 eng.ctx.project_estimate_fused(*args, phase=2)
             else:
                 buf = eng.project_and_estimate(V, eng.alloc_reduce_buffers(N, factored=bool(fused)), fused=fused)
+            ran[str(mode)] = sorted({k for k, _ in eng.ctx.kernel_timing_read()})
+            eng.ctx.kernel_timing(False)
             from pylrbms_amd.engine import expand_factored_grams
             names = ('B_sys', 'rhs_red', 'E_red', 'M_red', 'G_nc', 'r_fd', 'G_rdd', 'G_bb', 'G_ab', 'G_aa')
             for name, arr in zip(names, list(buf['sys']) + list(expand_factored_grams(buf['grams']))):
@@ -117,6 +133,22 @@ def _worker(rank, world, port, ref_path, results):
                 err = np.abs(a - r).max() / max(np.abs(r).max(), 1e-300)
                 worst = max(worst, err)
                 ok &= bool(err < 1e-12)
+        Engine.SERIAL_PHASES_FROM = 384
+        eng.ctx.set_option('streams', -1)
+        if shape == 'cfg3':
+            # the kernels config 4 launches did run, in every mode that is meant to take them: the lean projection kernel, the
+            # preparation from the LDS copy of the slab, and in the phased forms its slab-less instance for the neighbours' shares
+            for mode, names_ran in ran.items():
+                if mode == 'False':
+                    continue
+                ok &= 'k_f1v' in names_ran and 'k_f1u' not in names_ran and 'k_f1' not in names_ran
+                if 'streaming' in mode:
+                    ok &= 'k_prep_lds' not in names_ran and ('k_flux_side' in names_ran or 'k_prep_side' in names_ran)
+                else:
+                    ok &= 'k_prep_lds' in names_ran and 'k_f3' not in names_ran
+                    if mode != 'True':
+                        ok &= 'k_prep_lds<side>' in names_ran
+                ok &= 'k_thin3' in names_ran and 'k_f2' in names_ran
         # sharded estimate: local indicators + fused norms
         theta = np.array([1.0, 0.4])
         u_g = np.random.default_rng(5).standard_normal((grid.num_subdomains, N))
@@ -128,7 +160,7 @@ def _worker(rank, world, port, ref_path, results):
         from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
         from pylrbms_amd.reductor import LRBMSReductor
         del eng, buf, V
-        d, _ = discretize(_problem(Communicator(rank, world)), mpi_comm=Communicator(rank, world))
+        d, _ = discretize(_problem(Communicator(rank, world), shape), mpi_comm=Communicator(rank, world))
         red = LRBMSReductor(d, bases={'domain_{}'.format(ii): Vg[ii].T for ii in d.engine.local})
         rd = red.reduce()
         u_loc = rd.solve(0.4).tensor[:, :, 0].cpu().numpy()
@@ -138,17 +170,18 @@ def _worker(rank, world, port, ref_path, results):
         ub = rd.solve_batch([0.9, 0.4, 0.15]).tensor.cpu().numpy()
         ok &= bool(ub.shape == (d.engine.S, Vg.shape[2], 3))
         ok &= bool(np.abs(ub[:, :, 1] - u_loc).max() < 1e-9 * np.abs(u_loc).max())
-        _put(results, rank, (ok, max(worst, err_u), d.engine.S, d.engine.S_ext))
+        _put(results, rank, (ok, max(worst, err_u), d.engine.S, d.engine.S_ext, ran))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 4])
-def test_sharded_projection_matches_single_rank(world, tmp_path):
-    p = _problem()
+@pytest.mark.parametrize('world, shape', [(2, 'small'), (4, 'small'), (2, 'cfg3'), (4, 'cfg3')])
+def test_sharded_projection_matches_single_rank(world, shape, tmp_path):
+    N = SHAPES[shape][3]
+    p = _problem(shape=shape)
     eng = _engine(p)
     grid = p['grid']
-    V = eng.ctx.from_numpy(_bases(grid.num_subdomains, grid.template.n))
+    V = eng.ctx.from_numpy(_bases(grid.num_subdomains, grid.template.n, N))
     buf = eng.project_and_estimate(V, fused=False)
     names = ('B_sys', 'rhs_red', 'E_red', 'M_red', 'G_nc', 'r_fd', 'G_rdd', 'G_bb', 'G_ab', 'G_aa')
     out = {k: v.cpu().numpy() for k, v in zip(names, list(buf['sys']) + list(buf['grams']))}
@@ -159,33 +192,46 @@ def test_sharded_projection_matches_single_rank(world, tmp_path):
     np.savez(ref_path, **out)
     del eng, buf, V
     torch.cuda.empty_cache()
-    port = 29500 + 2 * (os.getpid() % 100) + world        # disjoint port ranges per test of this file
-    results = _spawn_and_collect(_worker, (world, port, ref_path), world, tmp_path)
+    port = 29500 + 2 * (os.getpid() % 100) + world + (10 if shape == 'cfg3' else 0)        # disjoint port ranges per test of this file
+    results = _spawn_and_collect(_worker, (world, port, ref_path, shape), world, tmp_path)
     assert len(results) == world
     for r in range(world):
-        ok, worst, S, S_ext = results[r]
-        assert ok, (r, worst)
+        ok, worst, S, S_ext, ran = results[r]
+        assert ok, (r, worst, ran)
         assert S_ext > S
 
 
-def test_bench_two_rank_rehearsal():
-    """bench.py's N > 1 code path (sharded engine, asynchronous halo exchange under phase 1, max-over-ranks timing) with
-    two ranks sharing cuda:0 over gloo (halo rows staged through host memory); the driver's runs use RCCL."""
+def _bench_line(nranks, port):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LRBMS_BENCH_BACKEND='gloo', LRBMS_BENCH_DEVICE='0')
-    port = 29900 + (os.getpid() % 90)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-           '--config', 'cfg2']
+    tail = [os.path.join(root, 'bench.py'), '--gpus', str(nranks), '--steps', '3', '--warmup', '1', '--config', 'cfg2',
+            '--no-cpu-baseline', '--no-online']
+    if nranks > 1:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nranks), '--master-addr',
+               '127.0.0.1', '--master-port', str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1                                   # ONE JSON line, from rank 0
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's N > 1 code path (sharded engine, asynchronous halo exchange under phase 1, max-over-ranks timing) with
+    two ranks sharing cuda:0 over gloo (halo rows staged through host memory); the driver's runs use RCCL.  The two ranks
+    together must have computed what one rank computes: sum and sum of absolute values of every output of the timed pass,
+    all-reduced over the ranks, against the single-rank run of the same config (same seeded bases by global subdomain index)."""
+    out = _bench_line(2, 29900 + (os.getpid() % 90))
     assert out['n_gpus'] == 2 and out['value'] > 0 and out['scaling'] == 'strong' and 'cpu_baseline' not in out
+    one = _bench_line(1, 0)
+    assert one['n_gpus'] == 1 and one['output_abs_checksum'] > 0
+    assert abs(out['output_abs_checksum'] - one['output_abs_checksum']) <= 1e-10 * one['output_abs_checksum']
+    assert abs(out['output_checksum'] - one['output_checksum']) <= 1e-10 * one['output_abs_checksum']
 
 
 def _enrichment_run(p, comm=None):
