@@ -464,6 +464,21 @@ def main():
                       'unit': 'local solves/s', 'problems': len(marked), 'unknowns_per_problem': 5 * t.n, 'ms': 1e3 * dt,
                       'cg_iterations_max': int(cinfo[:, 0].max()), 'cg_iterations_mean': float(cinfo[:, 0].mean()),
                       'relative_residual_max': float(cinfo[:, 1].max())}
+        # incremental re-projection after a round that marked m subdomains (lrbms_fused_set_subset): the fused pass over the marked
+        # subdomains and their neighbours only, into the buffers of the whole pass; 1 024 marked = the whole pass through the same path
+        rng_m = np.random.default_rng(11)
+        reproj = {}
+        for m in (16, 128, eng.S):
+            mk = sorted(rng_m.choice(eng.S, size=m, replace=False).tolist())
+            subset = eng.touched_targets([eng.local[i] for i in mk])
+            eng.project_and_estimate(Vo, buf, subset=subset)          # (Vo: the bases `buf` was projected from -- its rows stay valid)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.project_and_estimate(Vo, buf, subset=subset)
+            torch.cuda.synchronize()
+            reproj[str(m)] = {'marked': m, 'subdomains_projected': len(subset), 'ms': 1e3 * (time.perf_counter() - t1) / args.steps}
+        enrichment['incremental_reprojection'] = reproj
 
     parabolic = None
     if world == 1 and not args.no_online:

@@ -256,7 +256,9 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
  *   LRBMS_OPT_SOLVE_VALU       1: VALU form of the batched solver's panel matvec (cross-check of the matrix-core form)
  *   LRBMS_OPT_ESTIMATE_VALU    1: VALU form of the batched estimate (dense layout only; cross-check)
  *   LRBMS_OPT_PREP_LDS         1 (default): the preparation sweeps of the fused pass (flux image, vertex averages) run from one copy of
- *                              the subdomain's basis slab in LDS whenever it fits (k_prep_lds); 0: the two streaming sweeps */
+ *                              the subdomain's basis slab in LDS whenever it fits (k_prep_lds), with G_nc[self, self] folded into the
+ *                              same kernel; 2: the LDS form without that fold (k_f3 computes G_nc[self, self]); 0: the two streaming
+ *                              sweeps */
 #define LRBMS_OPT_STREAMS 3
 #define LRBMS_OPT_F1_KSPLIT 4
 #define LRBMS_OPT_F1_FORM 5
@@ -265,6 +267,16 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
 #define LRBMS_OPT_ESTIMATE_VALU 8
 #define LRBMS_OPT_PREP_LDS 10
 int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value);
+
+/* Incremental re-projection after online enrichment.  The reference re-reduces everything after a round of local enrichment
+ * (online_enrichment.py:49-58 calls reductor.reduce() after reductor.py:75-78 enrich_local); but the projected operators of target
+ * subdomain ii depend on the bases of ii and of its neighbours only, so after a round that changed the bases of the subdomains M
+ * only the targets M + neighbours(M) change.  lrbms_fused_set_subset restricts every following call of the fused pass
+ * (lrbms_project_estimate_fused, _factored, _phase) to the `count` LOCAL subdomains listed in `subset` (host array, strictly
+ * ascending, each in [0, S)); the pass then writes the rows of exactly those subdomains into the SAME output buffers (strides as
+ * for all S subdomains) and leaves every other row untouched -- bit-identical to what the whole pass writes there.  The list is
+ * copied (ordered on the library's copy stream before it returns); count == 0 (subset may be NULL) lifts the restriction. */
+int lrbms_fused_set_subset(lrbms_ctx* ctx, const int32_t* subset, int32_t count);
 
 /* Per-kernel device timing of the fused pass (measurement only; the reference has wall-clock prints around
  * rd.solve / rd.estimate, python/scripts/linearelliptic_block_swipdg_decomp.py:67-75).  While enabled, every kernel of

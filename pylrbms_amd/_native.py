@@ -35,6 +35,7 @@ SIGNATURES = {
     'lrbms_ctx_aux_stream': (c_vp, [c_vp, c_i32]),
     'lrbms_ctx_set_option': (ctypes.c_int, [c_vp, c_i32, c_i32]),
     'lrbms_set_quadrature': (ctypes.c_int, [c_vp, c_vp]),
+    'lrbms_fused_set_subset': (ctypes.c_int, [c_vp, _P_I32, c_i32]),
     'lrbms_kernel_timing': (ctypes.c_int, [c_vp, c_i32]),
     'lrbms_kernel_timing_read': (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), c_i32,
                                                 ctypes.POINTER(c_i32)]),
@@ -530,6 +531,15 @@ class NativeContext:
         if name not in self.OPTIONS:
             raise NativeError('unknown option {!r}; known: {}'.format(name, sorted(self.OPTIONS)))
         self._check(self.lib.lrbms_ctx_set_option(self.handle, self.OPTIONS[name], int(value)), 'lrbms_ctx_set_option')
+
+    def fused_set_subset(self, subset):
+        """Restrict the following fused passes to the local subdomains ``subset`` (strictly ascending local indices; ``None`` or
+        empty: all) -- incremental re-projection after online enrichment (include/lrbms_hip.h: lrbms_fused_set_subset)."""
+        if subset is None or len(subset) == 0:
+            self._check(self.lib.lrbms_fused_set_subset(self.handle, None, 0), 'lrbms_fused_set_subset')
+            return
+        arr = np.ascontiguousarray(np.asarray(subset, dtype=np.int32))
+        self._check(self.lib.lrbms_fused_set_subset(self.handle, arr.ctypes.data_as(_P_I32), int(arr.size)), 'lrbms_fused_set_subset')
 
     def fused_mfma_per_subdomain(self, Q, N):
         """fp64 MFMA instructions the dense projection kernel executes per subdomain (bench.py's roofline)."""

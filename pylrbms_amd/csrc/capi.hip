@@ -140,6 +140,7 @@ int lrbms_ctx_destroy(lrbms_ctx* ctx) {
   free_owned(ctx);
   if (ctx->ksp_part) (void)hipFree(ctx->ksp_part);
   if (ctx->ksp_ticket) (void)hipFree(ctx->ksp_ticket);
+  if (ctx->subset) (void)hipFree(ctx->subset);
   for (int i = 0; i < 3; ++i) {
     if (ctx->aux[i]) lrbms_side_stream_release(ctx->device, i);
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
@@ -179,6 +180,29 @@ int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value) {
     case LRBMS_OPT_PREP_LDS: ctx->opt_prep_lds = value; break;
     default: return lrbms_fail(ctx, LRBMS_E_INVALID, "set_option: unknown option");
   }
+  return LRBMS_OK;
+}
+
+int lrbms_fused_set_subset(lrbms_ctx* ctx, const int32_t* subset, int32_t count) {
+  LRBMS_REQUIRE_MESH(ctx);
+  if (count < 0 || count > ctx->S || (count > 0 && subset == nullptr))
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "fused_set_subset: count must be in [0, S] and the list non-null");
+  for (int i = 0; i < count; ++i)
+    if (subset[i] < 0 || subset[i] >= ctx->S || (i > 0 && subset[i] <= subset[i - 1]))
+      return lrbms_fail(ctx, LRBMS_E_INVALID, "fused_set_subset: the list must be strictly ascending local subdomain indices in [0, S)");
+  if (count > ctx->subset_cap) {
+    if (ctx->subset) LRBMS_HIP_CHECK(ctx, hipFree(ctx->subset));
+    ctx->subset = nullptr;
+    ctx->subset_cap = 0;
+    LRBMS_HIP_CHECK(ctx, hipMalloc(&ctx->subset, sizeof(int) * (size_t)ctx->S));
+    ctx->subset_cap = ctx->S;
+  }
+  // a synchronous copy: the list a pass still in flight reads must not change under it, and the host array may go away after return
+  if (count > 0) {
+    LRBMS_HIP_CHECK(ctx, hipDeviceSynchronize());
+    LRBMS_HIP_CHECK(ctx, hipMemcpy(ctx->subset, subset, sizeof(int) * (size_t)count, hipMemcpyHostToDevice));
+  }
+  ctx->subset_n = count;
   return LRBMS_OK;
 }
 

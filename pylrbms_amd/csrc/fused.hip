@@ -237,22 +237,23 @@ __device__ __forceinline__ void flux_compact_body(const Tmpl& t, int S, const in
 __global__ __launch_bounds__(256) void k_flux_compact(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
                                                       const double* __restrict__ F, const double* __restrict__ V,
                                                       double* __restrict__ Rself, double* __restrict__ Rside, int write_side) {
-  flux_compact_body(t, S, nbr, Q, N, F, V, Rself, Rside, write_side, blockIdx.x, blockIdx.y, gridDim.y,
-                    V + (long)blockIdx.x * t.n * N);   // grid (S, chunks of n_rt * N)
+  const int s = subdomain_of(t, blockIdx.x);
+  flux_compact_body(t, S, nbr, Q, N, F, V, Rself, Rside, write_side, s, blockIdx.y, gridDim.y,
+                    V + (long)s * t.n * N);   // grid (S, chunks of n_rt * N)
 }
 
 // R_side alone (the halo-dependent phase of a sharded pass): one item per (subdomain, side, side face, column).
 __device__ __forceinline__ void flux_side_body(const Tmpl& t, int S, const int* __restrict__ nbr, int Q, int N,
                                                const double* __restrict__ F, const double* __restrict__ V,
                                                double* __restrict__ Rside, int bx, int gx) {
-  const long total = (long)S * 4 * t.ncf * N;
+  const long total = (long)(t.sub_list ? t.sub_count : S) * 4 * t.ncf * N;
   const int QN = Q * N;
   for (long idx = (long)bx * 256 + threadIdx.x; idx < total; idx += (long)gx * 256) {
     const int j = (int)(idx % N);
     long rem = idx / N;
     const int pos = (int)(rem % t.ncf);
     rem /= t.ncf;
-    const int side = (int)(rem % 4), s = (int)(rem / 4);
+    const int side = (int)(rem % 4), s = subdomain_of(t, (int)(rem / 4));
     if (pos >= t.side_count[side]) continue;
     const int e0 = t.side_elem[side * t.ncf + pos], e1 = t.side_elem_out[side * t.ncf + pos];
     int f0 = 0;
@@ -342,8 +343,9 @@ __device__ __forceinline__ void vertex_avg_body(const Tmpl& t, int S, const int*
 __global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __restrict__ nbr, int N,
                                                     const double* __restrict__ V, double* __restrict__ AvgSelf,
                                                     double* __restrict__ AvgSide, int write_side) {
-  vertex_avg_body(t, S, nbr, N, V, AvgSelf, AvgSide, write_side, blockIdx.x, blockIdx.y, gridDim.y,
-                  V + (long)blockIdx.x * t.n * N);   // grid (S, chunks of n_v * N)
+  const int s = subdomain_of(t, blockIdx.x);
+  vertex_avg_body(t, S, nbr, N, V, AvgSelf, AvgSide, write_side, s, blockIdx.y, gridDim.y,
+                  V + (long)s * t.n * N);   // grid (S, chunks of n_v * N)
 }
 
 // both preparation sweeps in one launch: grid (S, gy_flux + gy_vtx)
@@ -352,11 +354,12 @@ __global__ __launch_bounds__(256) void k_prep(Tmpl t, int S, const int* __restri
                                               double* __restrict__ Rself, double* __restrict__ Rside,
                                               double* __restrict__ AvgSelf, double* __restrict__ AvgSide, int write_side,
                                               int gy_flux) {
+  const int s = subdomain_of(t, blockIdx.x);
   if ((int)blockIdx.y < gy_flux)
-    flux_compact_body(t, S, nbr, Q, N, F, V, Rself, Rside, write_side, blockIdx.x, blockIdx.y, gy_flux, V + (long)blockIdx.x * t.n * N);
+    flux_compact_body(t, S, nbr, Q, N, F, V, Rself, Rside, write_side, s, blockIdx.y, gy_flux, V + (long)s * t.n * N);
   else
-    vertex_avg_body(t, S, nbr, N, V, AvgSelf, AvgSide, write_side, blockIdx.x, blockIdx.y - gy_flux, gridDim.y - gy_flux,
-                    V + (long)blockIdx.x * t.n * N);
+    vertex_avg_body(t, S, nbr, N, V, AvgSelf, AvgSide, write_side, s, blockIdx.y - gy_flux, gridDim.y - gy_flux,
+                    V + (long)s * t.n * N);
 }
 
 // Both preparation sweeps from ONE copy of the subdomain's basis slab in LDS (round 3).  The streaming sweeps above are bound by
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
                                                                double* __restrict__ AvgSelf, double* __restrict__ AvgSide,
                                                                int write_side, GncArgs ga) {
   extern __shared__ double Vl[];
-  const int s = blockIdx.x, tid = threadIdx.x, N2 = N / 2, QN = Q * N, nvs = nvs_of(t);
+  const int s = subdomain_of(t, blockIdx.x), tid = threadIdx.x, N2 = N / 2, QN = Q * N, nvs = nvs_of(t);
   // gridDim.y == 2 (ranks with at most half as many subdomains as the chip has CUs): the work of a subdomain is dealt to TWO workgroups
   // that each load the slab -- part 0 the flux image, part 1 the vertex averages and G_nc -- instead of leaving half of the CUs idle
   const bool do_flux = gridDim.y == 1 || blockIdx.y == 0, do_avg = gridDim.y == 1 || blockIdx.y == 1;      // workgroup-uniform
@@ -736,13 +739,13 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
 __device__ __forceinline__ void vertex_side_body(const Tmpl& t, int S, const int* __restrict__ nbr, int N,
                                                  const double* __restrict__ V, double* __restrict__ AvgSide, int bx, int gx) {
   const int nvs = nvs_of(t);
-  const long total = (long)S * 4 * nvs * N;
+  const long total = (long)(t.sub_list ? t.sub_count : S) * 4 * nvs * N;
   for (long idx = (long)bx * 256 + threadIdx.x; idx < total; idx += (long)gx * 256) {
     const int j = (int)(idx % N);
     long rem = idx / N;
     const int pos = (int)(rem % nvs);
     rem /= nvs;
-    const int sd = (int)(rem % 4), s = (int)(rem / 4);
+    const int sd = (int)(rem % 4), s = subdomain_of(t, (int)(rem / 4));
     if (pos >= ((sd == 0 || sd == 3) ? t.nvx : t.nvy)) continue;
     const int v = sd == 0 ? pos : sd == 1 ? pos * t.nvx : sd == 2 ? pos * t.nvx + t.nvx - 1 : (t.nvy - 1) * t.nvx + pos;
     const OsInfo o = oswald_vertex(t, nbr + s * 5, v);
@@ -753,7 +756,7 @@ __device__ __forceinline__ void vertex_side_body(const Tmpl& t, int S, const int
       for (int p = t.vdof_ptr[v2]; p < t.vdof_ptr[v2 + 1]; ++p) a2 += V[((long)s2 * t.n + t.vdof_idx[p]) * N + j];
       a2 *= o.inv;
     }
-    AvgSide[idx] = a2;
+    AvgSide[(((long)s * 4 + sd) * nvs + pos) * N + j] = a2;
   }
 }
 
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(512, 2) void k_f1(Tmpl t, F1Args a, GrpTable gt0, G
   __shared__ double red[EC * 64];
   __shared__ Grp grp[F1_MAXG];
   __shared__ int grp_n;
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int s = subdomain_of(t, blockIdx.x), tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
 #if F1_SPLIT_SIMD   // experiment: producers on SIMDs 0 / 2, consumers on SIMDs 1 / 3 (hardware wave w runs on SIMD w % 4)
   const int hw_wave = uniform(tid >> 6);
   const int wave = (hw_wave & 1) ? EC + (hw_wave >> 1) : (hw_wave >> 1);
@@ -1325,7 +1328,7 @@ __device__ __forceinline__ void f1u_body(const Tmpl& t, const F1Args& a, double*
   constexpr int NTYS = F1_NTY;                         // column tiles per SIMD (waves w and w + 4)
   constexpr int LDY = 4 * NTYS * 16 + 16;
   constexpr int NT = ROLE == 0 ? NTYS / 2 : (NTYS + 1) / 2;   // role A stages more (below), so role B takes the odd tile
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int s = subdomain_of(t, blockIdx.x), tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6), e = wave & 3;    // e: element of the chunk this wave stages, SIMD it runs on
   // column tiles are dealt round-robin over the SIMDs (tile 4 k + e belongs to SIMD e; role A takes the even k, role B the
   // odd ones), so that basis sizes whose groups fill only part of the 4 NTYS tiles still load every SIMD evenly; tiles
@@ -1738,7 +1741,7 @@ __global__ __launch_bounds__(512, 2) void k_f1u(Tmpl t, F1Args a, GrpTable gt) {
     if (tid < a.N) {
       double sum = 0.0;
       for (int w = 0; w < EC; ++w) sum += red[w * 64 + tid];
-      a.rhs_red[(long)blockIdx.x * a.N + tid] = sum;
+      a.rhs_red[(long)subdomain_of(t, blockIdx.x) * a.N + tid] = sum;
     }
   }
 }
@@ -1814,7 +1817,7 @@ __device__ __forceinline__ void f1v_body(const Tmpl& t, const F1Args& a, double*
   static_assert(LV::slots(ROLE) <= F1V_SLOTS, "K-split partial layout");
   constexpr int NP = QP * (QP + 1) / 2;                  // pairs q <= q' of the c^{qq'} K V groups
   constexpr int NPAIR = NTX / 2, NSING = NTX % 2;        // 16-byte loads (two column tiles each), one 8-byte load for an odd last tile
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int s = subdomain_of(t, blockIdx.x), tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6), e = wave & 3;
   const int N = a.N, S = a.S, QN = QP * N;
   const int ksplit = gridDim.z;
@@ -2251,14 +2254,14 @@ __global__ __launch_bounds__(512, 2) void k_f1v(Tmpl t, F1Args a, GrpTable gt) {
     if (tid < a.N) {
       double sum = 0.0;
       for (int w = 0; w < EC; ++w) sum += red[w * 64 + tid];
-      a.rhs_red[(long)blockIdx.x * a.N + tid] = sum;
+      a.rhs_red[(long)subdomain_of(t, blockIdx.x) * a.N + tid] = sum;
     }
   }
 }
 
 // Zeroes every output of k_f1 (the destination blocks of its column groups and rhs_red) before a K-split launch.
-__global__ __launch_bounds__(256) void k_f1_zero(GrpTable gt, int S, int N, double* __restrict__ rhs_red) {
-  const int s = blockIdx.x;
+__global__ __launch_bounds__(256) void k_f1_zero(GrpTable gt, int S, int N, double* __restrict__ rhs_red, const int* __restrict__ sub_list) {
+  const int s = sub_list ? sub_list[blockIdx.x] : blockIdx.x;
   for (int g = 0; g < gt.n; ++g) {
     double* dst = gt.g[g].dst + (long)s * gt.g[g].sstride;
     double* dst_t = gt.g[g].dst_t ? gt.g[g].dst_t + (long)s * gt.g[g].sstride : nullptr;
@@ -2294,7 +2297,7 @@ __global__ __launch_bounds__(64 * (F2_NCW + EC)) void k_f2(Tmpl t, F2Args a) {
   extern __shared__ double dyn[];             // per-element scalars cached once: coef [nT][3], bsum [nT], rt [nT][3] (int)
   __shared__ double Xb[2][3 * EC * LD], Yb[2][3 * EC * LD], Xd[2][EC * LD], Yd[2][EC * LD];
   __shared__ double red[EC * 128];
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int s = subdomain_of(t, blockIdx.x), tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
   const int nthreads = 64 * (F2_NCW + EC);
   const int QN = a.Q * a.N, C = 5 * QN;
@@ -2494,7 +2497,7 @@ __global__ __launch_bounds__(256) void k_f3(Tmpl t, F3Args a) {
   constexpr int NTRI = NTX * (NTX + 1) / 2;      // G_nc[self,self] = W^T E W is symmetric: tiles on / above the diagonal
   constexpr int NT = (NTRI + 3) / 4;
   __shared__ double Xs[3 * ECH * LD], Ys[3 * ECH * LD];
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int s = subdomain_of(t, blockIdx.x), tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int wave = uniform(tid >> 6);
   const int N = a.N;
   for (int i = tid; i < 3 * ECH * LD; i += 256) Xs[i] = Ys[i] = 0.0;
@@ -2764,7 +2767,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 
                                                  const double* __restrict__ V, const double* __restrict__ ebar,
                                                  const double* __restrict__ AvgSelf, const double* __restrict__ AvgSide,
                                                  double* __restrict__ G_nc) {
-  thin_nc_body<NTX>(t, S, nbr, N, V, ebar, AvgSelf, AvgSide, G_nc, blockIdx.x, blockIdx.y);
+  thin_nc_body<NTX>(t, S, nbr, N, V, ebar, AvgSelf, AvgSide, G_nc, blockIdx.x, subdomain_of(t, blockIdx.y));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2923,7 +2926,7 @@ __device__ __forceinline__ void thin_ncf_body(const Tmpl& t, const ThinNcfArgs& 
   THIN_STAMP(2, 5);
 }
 
-__global__ __launch_bounds__(256) void k_thin_ncf(Tmpl t, ThinNcfArgs a) { thin_ncf_body(t, a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_thin_ncf(Tmpl t, ThinNcfArgs a) { thin_ncf_body(t, a, blockIdx.x, subdomain_of(t, blockIdx.y)); }
 
 static size_t thin_ncf_lds_bytes(const Tmpl& t, int N) {
   const size_t nvs = (size_t)(t.nvx > t.nvy ? t.nvx : t.nvy);
@@ -3097,7 +3100,7 @@ __device__ __forceinline__ void thin_rt_body(const Tmpl& t, const ThinRtArgs& a,
   THIN_STAMP(1, 4);
 }
 
-__global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) { thin_rt_body(t, a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_thin_rt(Tmpl t, ThinRtArgs a) { thin_rt_body(t, a, blockIdx.x, subdomain_of(t, blockIdx.y)); }
 
 // Dense block-compact form of the side blocks from the factors (callers that want the blocks themselves: the reference
 // keeps such operators as BlockOperators, block_swipdg.py:336-338): G_bb / G_rdd [S][9][QN][QN] blocks 1 + side = [a, self],
@@ -3111,7 +3114,7 @@ struct ThinExpandArgs {
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_thin_expand(Tmpl t, ThinExpandArgs a) {
   extern __shared__ double lds[];
-  const int side = blockIdx.x, s = blockIdx.y, slot = side_to_slot(side), tid = threadIdx.x;
+  const int side = blockIdx.x, s = subdomain_of(t, blockIdx.y), slot = side_to_slot(side), tid = threadIdx.x;
   const int Q = a.Q, N = a.N, QN = Q * N, C = 5 * QN, S = a.S, LD = fside_ld(Q, N);
   double* Gb_as = a.G_bb + ((long)s * 9 + 1 + side) * QN * QN;
   double* Gb_aa = a.G_bb + ((long)s * 9 + 5 + side) * QN * QN;
@@ -3373,7 +3376,7 @@ template <int NTX>
 __global__ __launch_bounds__(256) void k_coupling(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
                                                   const double* __restrict__ V, const double* __restrict__ A_cpl,
                                                   double* __restrict__ B_sys) {
-  coupling_body<NTX>(t, S, nbr, Q, N, V, A_cpl, B_sys, blockIdx.x, blockIdx.y);
+  coupling_body<NTX>(t, S, nbr, Q, N, V, A_cpl, B_sys, blockIdx.x, subdomain_of(t, blockIdx.y));
 }
 
 // Factored layout: all three thin kernels are 256-thread workgroups -- one launch, grid (4, S, 3).
@@ -3381,7 +3384,7 @@ template <int NTX>
 __global__ __launch_bounds__(256) void k_thin3(Tmpl t, ThinRtArgs a, ThinNcfArgs f, const double* __restrict__ A_cpl,
                                                double* __restrict__ B_sys) {
   // (an XCD-aware 1-D grid -- the twelve workgroups of a subdomain on one XCD, kinds interleaved -- was measured: no change)
-  const int side = blockIdx.x, s = blockIdx.y, z = blockIdx.z;
+  const int side = blockIdx.x, s = subdomain_of(t, blockIdx.y), z = blockIdx.z;
   if (z == 0)
     coupling_body<NTX>(t, a.S, a.nbr, a.Q, a.N, a.V, A_cpl, B_sys, side, s);
   else if (z == 1)
@@ -3400,7 +3403,7 @@ struct ThinNcArgs {
 };
 template <int NTX>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NTX <= 3 ? 5 : 4, 8))) void k_thin(Tmpl t, ThinRtArgs a, ThinNcArgs c) {
-  const int side = blockIdx.x, s = blockIdx.y;
+  const int side = blockIdx.x, s = subdomain_of(t, blockIdx.y);
   if (blockIdx.z == 0 && c.Fnc == nullptr) {
     thin_nc_body<NTX>(t, a.S, a.nbr, a.N, a.V, c.ebar, c.AvgSelf, c.AvgSide, c.G_nc, side, s);
     return;
@@ -3678,8 +3681,15 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   const bool do_prep = phase == 0 || phase == 1 || phase == 3;
   const bool do_a = phase == 0 || phase == 1 || phase == 4;      // the dense, halo-independent kernels
   const bool do_b = phase == 0 || phase == 2;
-  const Tmpl& t = ctx->t;
+  // incremental re-projection (lrbms_fused_set_subset): Sg workgroup rows for the listed subdomains; S stays the stride of every
+  // array.  Launch POLICY (forked launches, two preparation workgroups per subdomain) follows Sg -- every policy gives the same
+  // bits --, the K-split of the projection kernel follows S: a split changes the summation order, and a subset pass must
+  // reproduce the bits of the whole pass.
+  Tmpl t = ctx->t;
+  t.sub_list = ctx->subset_n > 0 ? ctx->subset : nullptr;
+  t.sub_count = ctx->subset_n;
   const int S = ctx->S, QN = Q * N, C = 5 * QN;
+  const int Sg = t.sub_list ? t.sub_count : S;
   const long nvs = t.nvx > t.nvy ? t.nvx : t.nvy;
   double* Rself = work;
   double* Rside = Rself + (long)S * t.nrt * QN;
@@ -3699,7 +3709,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // k_prep_side), the three thin kernels as ONE launch (k_thin) on a library stream, k_f2 and k_f3 on two more, k_f1 on
   // the caller's stream: five launches and one fork / join instead of twelve launches and two forks (config 2: 86 us of
   // host enqueue per pass for 104 us of device time before).
-  const bool forked = ctx->opt_streams >= 0 ? ctx->opt_streams != 0 : S < 192;      // LRBMS_OPT_STREAMS
+  const bool forked = ctx->opt_streams >= 0 ? ctx->opt_streams != 0 : Sg < 192;      // LRBMS_OPT_STREAMS
   const int gy_flux = (t.nrt * N + 255) / 256, gy_vtx = (t.nv * N + 255) / 256;   // (2 - 8 items per thread instead: no faster)
   // (k_prep only there: at 1 024 subdomains it takes 182 us against 113 + 59 us for the two sweeps on their own)
   // factored layout: the three thin kernels are 256-thread workgroups and always share one launch (k_thin3: 141 us at
@@ -3720,13 +3730,13 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
         LRBMS_HIP_CHECK(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
         ctx->num_cus = ncu > 0 ? ncu : 256;
       }
-      const int prep_parts = 2 * S <= ctx->num_cus ? 2 : 1;      // one workgroup per CU: two per subdomain while that leaves none waiting
+      const int prep_parts = 2 * Sg <= ctx->num_cus ? 2 : 1;      // one workgroup per CU: two per subdomain while that leaves none waiting
       const GncArgs ga{ebar, gnc_fold ? G_nc : nullptr, factored ? (long)N * N : (long)25 * N * N, factored ? N : 5 * N,
                        factored ? 0 : 10 * N * N + 2 * N};
 #define LRBMS_PREP(NTXV)                                                                                                              \
   do {                                                                                                                                \
     LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_prep_lds<NTXV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds)); \
-    hipLaunchKernelGGL(k_prep_lds<NTXV>, dim3(S, prep_parts), dim3(PREP_LDS_THREADS), prep_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf, \
+    hipLaunchKernelGGL(k_prep_lds<NTXV>, dim3(Sg, prep_parts), dim3(PREP_LDS_THREADS), prep_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf, \
                        AvgSide, phase == 0 ? 1 : 0, ga);                                                                              \
   } while (0)
       if (ntx_p == 1) LRBMS_PREP(1);
@@ -3735,16 +3745,16 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
 #undef LRBMS_PREP
     } else if (merge_prep) {
       KScope ks(ctx, "k_prep", st);
-      hipLaunchKernelGGL(k_prep, dim3(S, gy_flux + gy_vtx), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
+      hipLaunchKernelGGL(k_prep, dim3(Sg, gy_flux + gy_vtx), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
                          AvgSide, phase == 0 ? 1 : 0, gy_flux);
     } else {
       {
         KScope ks(ctx, "k_flux_compact", st);
-        hipLaunchKernelGGL(k_flux_compact, dim3(S, gy_flux), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
+        hipLaunchKernelGGL(k_flux_compact, dim3(Sg, gy_flux), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
                            phase == 0 ? 1 : 0);
       }
       KScope ks(ctx, "k_vertex_avg", st);
-      hipLaunchKernelGGL(k_vertex_avg, dim3(S, gy_vtx), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
+      hipLaunchKernelGGL(k_vertex_avg, dim3(Sg, gy_vtx), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSelf, AvgSide,
                          phase == 0 ? 1 : 0);
     }
     // sharded pass: phase 2 (on another stream, once the halo is there) reads what the preparation wrote; the library orders
@@ -3759,16 +3769,16 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       KScope ks(ctx, "k_prep_lds<side>", st);
       const GncArgs ga{ebar, nullptr, 0, 0, 0};
       const size_t side_lds = prep_lds_bytes(t, Q, N, false) - prep_lds_slab_bytes(t, N, false);      // tables + coefficients: no slab
-      hipLaunchKernelGGL((k_prep_lds<1, 256>), dim3(S, 1), dim3(256), side_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
+      hipLaunchKernelGGL((k_prep_lds<1, 256>), dim3(Sg, 1), dim3(256), side_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
                          AvgSide, 2, ga);
     } else if (merge_prep) {
-      const unsigned gxf = grid_for((long)S * 4 * t.ncf * N), gxv = grid_for((long)S * 4 * nvs * N);
+      const unsigned gxf = grid_for((long)Sg * 4 * t.ncf * N), gxv = grid_for((long)Sg * 4 * nvs * N);
       KScope ks(ctx, "k_prep_side", st);
       hipLaunchKernelGGL(k_prep_side, dim3(gxf + gxv), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside, AvgSide, (int)gxf);
     } else {
       {
         KScope ks(ctx, "k_flux_side", st);
-        hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)S * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
+        hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)Sg * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
       }
       // Avg_side: the dense layout launches k_vertex_side right in front of its only reader, k_thin_nc (below); in the factored
       // layout the reader is k_thin3, which is launched from the merged branch -- so it goes out here.  (Round 3: it went out
@@ -3776,7 +3786,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       // see it because it reused a work buffer that still held the averages of the whole pass.)
       if (merge_thin) {
         KScope ks(ctx, "k_vertex_side", st);
-        hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)S * 4 * nvs * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSide);
+        hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)Sg * 4 * nvs * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSide);
       }
     }
   }
@@ -3894,9 +3904,9 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       }
       if (ksplit > 1 && !unified) {
         for (int sl = 0; sl < nsl; ++sl)
-          hipLaunchKernelGGL(k_f1_zero, dim3(S), dim3(256), 0, st, gt[sl], S, N, sl == 0 ? a.rhs_red : nullptr);
+          hipLaunchKernelGGL(k_f1_zero, dim3(Sg), dim3(256), 0, st, gt[sl], S, N, sl == 0 ? a.rhs_red : nullptr, t.sub_list);
       }
-      const dim3 grid(S, nsl, ksplit);
+      const dim3 grid(Sg, nsl, ksplit);
       // the timing name tells the form that ran (tests assert it; bench.py files all three under k_f1)
       KScope ks(ctx, lean ? "k_f1v" : unified ? "k_f1u" : "k_f1", st);
       if (lean) {
@@ -3944,13 +3954,13 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   do {                                                                                                                       \
     if (lds > 64 * 1024)                                                                                                     \
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_thin<NTX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(k_thin<NTX>, dim3(4, S, 3), dim3(512), lds, s_rt, t, a, c);                                           \
+    hipLaunchKernelGGL(k_thin<NTX>, dim3(4, Sg, 3), dim3(512), lds, s_rt, t, a, c);                                           \
   } while (0)
 #define LRBMS_THIN3(NTX)                                                                                                     \
   do {                                                                                                                       \
     if (lds > 64 * 1024)                                                                                                     \
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_thin3<NTX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(k_thin3<NTX>, dim3(4, S, 3), dim3(256), lds, s_rt, t, a, f, A_cpl, B_sys);                            \
+    hipLaunchKernelGGL(k_thin3<NTX>, dim3(4, Sg, 3), dim3(256), lds, s_rt, t, a, f, A_cpl, B_sys);                            \
   } while (0)
     if (factored) {
       const ThinNcfArgs f{V, ebar, AvgSelf, AvgSide, ctx->nbr, Fnc, N, S};
@@ -3977,7 +3987,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       ThinExpandArgs e{Fside, ctx->nbr, G_bb, G_rdd, G_ab, Q, N, S};
       const size_t lds3 = sizeof(double) * (size_t)t.ncf * fside_ld(Q, N);
       KScope ks(ctx, "k_thin_expand", s_rt);
-      hipLaunchKernelGGL(k_thin_expand, dim3(4, S), dim3(256), lds3, s_rt, t, e);
+      hipLaunchKernelGGL(k_thin_expand, dim3(4, Sg), dim3(256), lds3, s_rt, t, e);
       LRBMS_LAUNCH_CHECK(ctx);
     }
   }
@@ -3985,7 +3995,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     hipStream_t side = s_nc;
     if (!do_prep && !merge_prep) {
       KScope ks(ctx, "k_vertex_side", side);
-      hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)S * 4 * nvs * N)), dim3(256), 0, side, t, S, ctx->nbr, N, V, AvgSide);
+      hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)Sg * 4 * nvs * N)), dim3(256), 0, side, t, S, ctx->nbr, N, V, AvgSide);
     }
     const int ntx = (N + 15) / 16;
     if (factored) {
@@ -3994,7 +4004,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       if (ldsf > 64 * 1024)
         LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_thin_ncf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
       KScope ks(ctx, "k_thin_ncf", side);
-      hipLaunchKernelGGL(k_thin_ncf, dim3(4, S), dim3(256), ldsf, side, t, f);
+      hipLaunchKernelGGL(k_thin_ncf, dim3(4, Sg), dim3(256), ldsf, side, t, f);
     } else {
     const size_t lds = thin_nc_lds_bytes(t, ntx);
     // templates with more than ~24 touching elements per side (k_c = 8: 78 KB at N = 40) need the opt-in for > 64 KB of LDS
@@ -4002,7 +4012,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   do {                                                                                                                           \
     if (lds > 64 * 1024)                                                                                                         \
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_thin_nc<NTX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(k_thin_nc<NTX>, dim3(4, S), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);    \
+    hipLaunchKernelGGL(k_thin_nc<NTX>, dim3(4, Sg), dim3(512), lds, side, t, S, ctx->nbr, N, V, ebar, AvgSelf, AvgSide, G_nc);    \
   } while (0)
     {
     KScope ks(ctx, "k_thin_nc", side);
@@ -4020,14 +4030,14 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     const size_t lds2 = thin_rt_lds_bytes(t, Q, N);
     {
       KScope ks(ctx, "k_thin_rt", s_rt);
-      hipLaunchKernelGGL(k_thin_rt, dim3(4, S), dim3(256), lds2, s_rt, t, a);
+      hipLaunchKernelGGL(k_thin_rt, dim3(4, Sg), dim3(256), lds2, s_rt, t, a);
     }
     LRBMS_LAUNCH_CHECK(ctx);
     if (!factored) {
       ThinExpandArgs e{Fside, ctx->nbr, G_bb, G_rdd, G_ab, Q, N, S};
       const size_t lds3 = sizeof(double) * (size_t)t.ncf * fside_ld(Q, N);
       KScope ks(ctx, "k_thin_expand", s_rt);
-      hipLaunchKernelGGL(k_thin_expand, dim3(4, S), dim3(256), lds3, s_rt, t, e);
+      hipLaunchKernelGGL(k_thin_expand, dim3(4, Sg), dim3(256), lds3, s_rt, t, e);
       LRBMS_LAUNCH_CHECK(ctx);
     }
   }
@@ -4040,7 +4050,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   do {                                                                                                                       \
     if (ldsf2 > 64 * 1024)                                                                                                   \
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_f2<NRV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf2)); \
-    hipLaunchKernelGGL(k_f2<NRV>, dim3(S), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a);                                    \
+    hipLaunchKernelGGL(k_f2<NRV>, dim3(Sg), dim3(64 * (F2_NCW + EC)), ldsf2, s_f23, t, a);                                    \
   } while (0)
     // (A unified-role form of this kernel as for k_f1 -- all eight waves stage, chunks of eight elements -- was measured
     // and dropped: its 98 KB of LDS leave one workgroup per CU, 136 us against 126 us for three co-resident workgroups of
@@ -4066,10 +4076,10 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     const int ntx = (N + 15) / 16;
     KScope ks(ctx, "k_f3", s_nc);
     switch (ntx) {
-      case 1: hipLaunchKernelGGL(k_f3<1>, dim3(S), dim3(256), 0, s_nc, t, a); break;
-      case 2: hipLaunchKernelGGL(k_f3<2>, dim3(S), dim3(256), 0, s_nc, t, a); break;
-      case 3: hipLaunchKernelGGL(k_f3<3>, dim3(S), dim3(256), 0, s_nc, t, a); break;
-      default: hipLaunchKernelGGL(k_f3<4>, dim3(S), dim3(256), 0, s_nc, t, a); break;
+      case 1: hipLaunchKernelGGL(k_f3<1>, dim3(Sg), dim3(256), 0, s_nc, t, a); break;
+      case 2: hipLaunchKernelGGL(k_f3<2>, dim3(Sg), dim3(256), 0, s_nc, t, a); break;
+      case 3: hipLaunchKernelGGL(k_f3<3>, dim3(Sg), dim3(256), 0, s_nc, t, a); break;
+      default: hipLaunchKernelGGL(k_f3<4>, dim3(Sg), dim3(256), 0, s_nc, t, a); break;
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }
@@ -4081,7 +4091,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   do {                                                                                                                       \
     if (ldsc > 64 * 1024)                                                                                                    \
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_coupling<NTXV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc)); \
-    hipLaunchKernelGGL(k_coupling<NTXV>, dim3(4, S), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys);          \
+    hipLaunchKernelGGL(k_coupling<NTXV>, dim3(4, Sg), dim3(256), ldsc, s_rt, t, S, ctx->nbr, Q, N, V, A_cpl, B_sys);          \
   } while (0)
     switch (ntx) {
       case 1: LRBMS_CPL(1); break;

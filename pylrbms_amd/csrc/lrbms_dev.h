@@ -39,7 +39,15 @@ struct Tmpl {
                                  //    (HEAD: grid.neighborhood_of, block_swipdg.py:78-113).  Factored layout, one rank only.
   int opt_accumulate_coupling;   // 1: coupling matrices accumulate across the affine components q (block_swipdg.py:551-565 vs
                                  //    :581-583), 0: one coupling matrix per component
+  // incremental re-projection (lrbms_fused_set_subset): the fused pass runs over the sub_count local subdomains sub_list[0 ..] only --
+  // one int32 indirection in front of "workgroup index -> subdomain"; array strides and the neighbour table are untouched.
+  // nullptr: every subdomain (workgroup b works on subdomain b).  Set in the launcher's COPY of the template, never in ctx->t.
+  const int* sub_list;
+  int sub_count;
 };
+
+// the subdomain workgroup-index b of a fused-pass kernel works on
+__device__ inline int subdomain_of(const Tmpl& t, int b) { return t.sub_list ? t.sub_list[b] : b; }
 
 // Library-owned side streams, one set per device, shared by every context of the process (2D and 3D alike).  HIP maps streams
 // round-robin onto a few hardware queues (4 by default); a second context with side streams of its own lands on queues the
@@ -76,6 +84,8 @@ struct lrbms_ctx {
   long ksp_part_cap = 0;
   int* ksp_ticket = nullptr;
   long ksp_ticket_cap = 0;
+  int* subset = nullptr;              // lrbms_fused_set_subset: device copy of the list (ctx-owned), subset_n == 0: no restriction
+  int subset_n = 0, subset_cap = 0;
   lrbms_quadrature* qdev = nullptr;   // device copy of the quadrature (lrbms_set_quadrature), read by the assembly kernels
   // launch policy (lrbms_ctx_set_option, LRBMS_OPT_STREAMS ...): the library reads no environment variable
   int opt_streams = -1, opt_f1_ksplit = 0, opt_f1_legacy = 0, opt_coarse = 1, opt_solve_valu = 0, opt_estimate_valu = 0, opt_prep_lds = 1;

@@ -177,8 +177,28 @@ class Engine:
         buf.update(self.alloc_outputs(N, factored=factored))
         return buf
 
-    def project_and_estimate(self, V, buffers=None, project_system=True, fused=None, halo=None):
-        """One pass of the hot path over all local subdomains.  ``V`` [S_ext, n, N] must already hold the halo -- or
+    def touched_targets(self, changed_global):
+        """Local indices (ascending) of the target subdomains whose projected operators depend on the basis of one of the
+        subdomains ``changed_global`` (global ids, on any rank): the changed subdomains themselves and their face neighbours --
+        the operators of target ii are built from the bases of ii and of its neighbourhood (reductor.py:40-60, block_swipdg.py:78)
+        -- plus the diagonal neighbours when the Oswald patch is the whole vertex star (conventions oswald_vertex_patch)."""
+        g = self.grid
+        hit = set()
+        for m in changed_global:
+            m = int(m)
+            hit.add(m)
+            nbrs = [int(j) for j in g.neighbor_slots[m] if j >= 0]
+            hit.update(nbrs)
+            if self.conventions.get('oswald_vertex_patch'):
+                for j in nbrs:                                            # diagonal = neighbour of a neighbour across the other axis
+                    hit.update(int(k) for k in g.neighbor_slots[j] if k >= 0)
+        pos = {gid: i for i, gid in enumerate(self.local)}
+        return sorted(pos[gid] for gid in hit if gid in pos)
+
+    def project_and_estimate(self, V, buffers=None, project_system=True, fused=None, halo=None, subset=None):
+        """One pass of the hot path over all local subdomains -- or, with ``subset`` (ascending local indices, fused pass only), over
+        those subdomains only, writing their rows into ``buffers`` and leaving every other row as it is (incremental
+        re-projection after online enrichment: ``touched_targets``; bit-identical to the rows a whole pass writes).  ``V`` [S_ext, n, N] must already hold the halo -- or
         ``halo`` (a ``pylrbms_amd.parallel.HaloExchange``) is given and fills it: with the fused pass the exchange then
         runs on the communication stream while the halo-independent kernels (more than half of the pass) are computed on
         the main stream; the kernels that read neighbour rows start on a side stream as soon as the halo has arrived.
@@ -198,6 +218,18 @@ class Engine:
             raise NativeError('buffers were allocated for N={}'.format(buf['N']))
         if not fused and len(buf['grams']) == 8:
             raise NativeError('the unfused kernels write the dense layout: allocate the buffers with factored=False')
+        if subset is not None:
+            if not fused or buffers is None:
+                raise NativeError('subset= needs the fused pass and the buffers of an earlier whole pass')
+            if len(subset) == 0:
+                if halo is not None:
+                    halo(V)
+                return buf
+            c.fused_set_subset(subset)
+            try:
+                return self.project_and_estimate(V, buffers, project_system=project_system, fused=fused, halo=halo)
+            finally:
+                c.fused_set_subset(None)
         if fused:
             args = (V, self.F, self.A_diag, self.A_cpl, self.P_diag, self.b, self.ebar, self.caa, self.Aab, self.Bbb,
                     buf['work'], buf['sys'], buf['grams'])

@@ -4,7 +4,8 @@
 and ``solve`` loop.  The enrichment step differs in how it is executed, not in what it computes: the reference calls
 ``reductor.enrich_local`` for one marked subdomain after the other (:49-50); here all corrector problems of a round are
 solved by ONE kernel launch (one workgroup per marked neighbourhood, ``lrbms_local_correction_solve``) and the bases
-are extended by one masked Gram-Schmidt step, then ``reductor.reduce()`` re-runs the fused project+estimate pass."""
+are extended by one masked Gram-Schmidt step, then ``reductor.reduce(touched=marked)`` re-runs the fused project+estimate pass
+over the marked subdomains and their neighbours only (pylrbms_amd/reductor.py: incremental re-projection)."""
 import numpy as np
 
 
@@ -62,7 +63,12 @@ class AdaptiveEnrichment:
         else:
             for ii in mine:
                 self.reductor.enrich_local(ii, U, mu)
-        self.rd = self.reductor.reduce()
+        # re-projection (online_enrichment.py:52 calls reductor.reduce()): only the marked subdomains' bases changed, so only they
+        # and their neighbours are projected again -- into the arrays of self.rd -- unless the basis slab had to grow
+        try:
+            self.rd = self.reductor.reduce(touched=sorted(marked_subdomains))
+        except TypeError:                                     # a reductor without the incremental form
+            self.rd = self.reductor.reduce()
         for ii in range(self.block_space.num_blocks):
             age_count[ii] = 1 if ii in marked_subdomains else age_count[ii] + 1
         return len(marked_subdomains)
@@ -72,6 +78,12 @@ class AdaptiveEnrichment:
 
     def solve(self, mu, enrichment_steps=np.inf, callback=None):
         mu = self.discretization.parse_parameter(mu)
+        if hasattr(self.reductor, 'reserve') and np.isfinite(enrichment_steps) and enrichment_steps > 0:
+            # room for the vectors this loop can add (one per subdomain and round): the slab keeps its width, every round after
+            # the first re-projects marked + neighbours only.  (Zero columns change no result; an unbounded loop grows on demand.)
+            width = self.reductor.basis_size()
+            if self.reductor.reserve(width + int(min(enrichment_steps, 16))) != width:
+                self.rd = self.reductor.reduce()
         enrichment_step = 1
         age_count = np.ones(self.block_space.num_blocks)
         local_problem_solves = 0

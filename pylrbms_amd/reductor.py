@@ -14,6 +14,13 @@ columns project to exactly zero rows / columns of every reduced operator, the re
 entries (``k_block_inverse``), so the padded unknowns stay 0 and every kernel keeps its uniform shape.
 A global ``extend_basis`` is all-or-nothing and raises ``ExtensionError`` if any block of the snapshot is numerically
 in the span of its basis.
+
+Incremental re-projection (``reduce(touched=...)``): the reference re-reduces everything after a round of local enrichment
+(online_enrichment.py:49-58 after reductor.py:75-78).  The projected operators of a target subdomain depend on the bases of
+its neighbourhood only, so ``reduce(touched=marked)`` re-runs the fused pass over ``marked + neighbours(marked)`` and writes
+their rows into the buffers of the previous reduced model -- as long as the slab width is unchanged (``reserve(width)`` pads the
+slab with zero columns ahead of an enrichment loop: an enriched subdomain then fills one of its own zero columns and nobody
+else pays for it).  The rows written are bit-identical to those of a whole pass.
 """
 import numpy as np
 
@@ -238,6 +245,16 @@ class LRBMSReductor:
                         torch.zeros_like(v))
         return v, ok
 
+    def reserve(self, width):
+        """Room for local bases of up to ``width`` vectors: pads the slab with zero columns (to an even width: the lean kernels
+        of the fused pass take even N).  Zero columns project to zero rows / columns, so every result is unchanged; what changes is
+        that later extensions fill existing columns, the slab keeps its width and ``reduce(touched=...)`` can update in place."""
+        import torch
+        width = int(width) + (int(width) & 1)
+        if self._V is not None and width > self._V.shape[2]:
+            self._V = torch.nn.functional.pad(self._V, (0, width - self._V.shape[2])).contiguous()
+        return self.basis_size()
+
     def _append_columns(self, v, ok):
         """Write block s of ``v`` behind the ``nloc[s]`` vectors of subdomain s for every s with ``ok[s]``."""
         import torch
@@ -255,6 +272,7 @@ class LRBMSReductor:
         cols = torch.as_tensor(self._nloc[idx], device=self._V.device)
         self._V[rows, :, cols] = v[rows, :, 0]
         self._nloc[idx] += 1
+        self._dirty = getattr(self, '_dirty', set()) | {int(eng.local[i]) for i in idx}      # bases changed since the last reduce()
         return ok_host
 
     def _gram_schmidt_extend(self, U):
@@ -308,10 +326,15 @@ class LRBMSReductor:
             self._pending = []
 
     # ------------------------------------------------------------------ reduce
-    def reduce(self):
-        return self._reduce()
+    def reduce(self, touched=None):
+        """``reductor.reduce()`` (reductor.py:33-73).  ``touched``: global ids of the subdomains whose local bases changed since the
+        previous ``reduce()`` -- on ANY rank of a sharded discretization (the marking of online_enrichment.py:38-47 is global) --:
+        only they and their neighbours are re-projected, into the arrays of the previous reduced model, which the returned model
+        shares (the previous one is superseded, as in the reference's loop, online_enrichment.py:52).  Falls back to the whole pass
+        when there is no previous model of the same width or the fused pass does not support the shape."""
+        return self._reduce(touched=touched)
 
-    def _reduce(self):
+    def _reduce(self, touched=None):
         d = self.d
         eng = d.engine
         if self._V is None:
@@ -332,6 +355,16 @@ class LRBMSReductor:
             if N > self._V.shape[2]:
                 self._V = torch.nn.functional.pad(self._V, (0, N - self._V.shape[2])).contiguous()
         V = d._with_halo(self._V)
+        dirty = getattr(self, '_dirty', set())
+        self._dirty = set()
+        last = getattr(self, '_last_reduce', None)
+        if (touched is not None and last is not None and last['N'] == N and len(last['grams']) == 8
+                and eng.ctx.fused_supported(eng.Q, N, factored=True)):
+            # incremental: the targets whose neighbourhood holds a changed basis, written into the previous model's arrays
+            subset = eng.touched_targets(set(int(g) for g in touched) | dirty)
+            eng.project_and_estimate(V, last, subset=subset)
+            self.last_reduce_info = {'incremental': True, 'subdomains': len(subset)}
+            return ReducedDiscretization(self, last, N)
         if getattr(self, '_buffers', None) is None or self._buffers['N'] != N:
             self._buffers = eng.alloc_reduce_buffers(N)                   # scratch (and image bases if unfused): reused
         buf = dict(self._buffers)
@@ -340,6 +373,8 @@ class LRBMSReductor:
         self._buffers['Wt'], self._buffers['Rt'] = buf['Wt'], buf['Rt']
         if buf['Wt'] is not None:                                         # only the unfused kernels materialise them
             self._image_bases = {'OI': buf['Wt'], 'RT': buf['Rt']}      # target-major image bases (device tensors)
+        self._last_reduce = buf
+        self.last_reduce_info = {'incremental': False, 'subdomains': eng.S}
         return ReducedDiscretization(self, buf, N)
 
     def image_bases(self):
@@ -475,7 +510,7 @@ class ParabolicLRBMSReductor(LRBMSReductor):
         if added == 0:
             raise ExtensionError('no snapshot block extends its local basis')
 
-    def _reduce(self):
-        rd = super()._reduce()
+    def _reduce(self, touched=None):
+        rd = super()._reduce(touched=touched)
         return InstationaryReducedDiscretization(self, {'sys': (rd.B_sys, rd.rhs_red, rd.E_red, rd.M_red), 'grams': rd.grams},
                                                  rd.N)

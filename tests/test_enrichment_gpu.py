@@ -169,6 +169,63 @@ def test_adaptive_enrichment_loop():
     assert np.abs(reductor.reconstruct(U).data.reshape(o.S, o.n) - rec_o).max() < 1e-7 * np.abs(rec_o).max()
 
 
+@pytest.mark.parametrize('shape, kc, N0, conv', [((6, 5), 4, 38, None), ((9, 8), 2, 18, None), ((5, 5), 2, 5, None),
+                                                   ((5, 4), 2, 6, {'oswald_vertex_patch': True})])
+def test_incremental_reprojection_equals_the_whole_pass_bitwise(shape, kc, N0, conv):
+    """``reduce(touched=marked)`` (reference: online_enrichment.py:52 re-reduces everything after reductor.py:75-78): after the bases
+    of a few subdomains grew inside a reserved slab, the fused pass over marked + neighbours -- one int32 indirection in front of
+    the workgroup -> subdomain map (lrbms_fused_set_subset) -- leaves EVERY array of the reduced model bit-identical to a whole
+    ``reduce()`` on the same bases: the rows it rewrites and the rows it does not touch (which therefore cannot depend on a changed
+    basis).  Shapes: the config-3 template at N = 40 (k_f1v, k_prep_lds; 30 subdomains, so the whole pass K-splits the projection
+    kernel and the subset pass must do the same), 72 subdomains (no split), odd N (k_f1u, streaming sweeps), and the Oswald vertex
+    patch, where the diagonal neighbours of a marked subdomain change too."""
+    import torch
+    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+    from pylrbms_amd.reductor import LRBMSReductor
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(shape), 'coarse_per_subdomain': kc})
+    d, _ = discretize(p, conventions=conv) if conv else discretize(p)
+    eng = d.engine
+    S, n = eng.S, eng.t.n
+    rng = np.random.default_rng(5)
+    if N0 % 2 == 0:
+        reductor = LRBMSReductor(d, bases={'domain_{}'.format(ii): rng.standard_normal((N0, n)) for ii in range(S)})
+        width = reductor.reserve(N0 + 2)
+    else:      # an odd slab width (reserve() pads to even ones): ragged bases, subdomain 1 holds the widest and is never marked
+        reductor = LRBMSReductor(d, bases={'domain_{}'.format(ii): rng.standard_normal((N0 if ii == 1 else N0 - 2, n))
+                                           for ii in range(S)})
+        width = reductor.basis_size()
+        assert width == N0
+    rd0 = reductor.reduce()
+    assert reductor.last_reduce_info == {'incremental': False, 'subdomains': S} and rd0.N == width
+    names = ('B_sys', 'rhs_red', 'E_red', 'M_red') + tuple('gram{}'.format(i) for i in range(len(rd0.grams)))
+    before = [x.clone() for x in (rd0.B_sys, rd0.rhs_red, rd0.E_red, rd0.M_red) + rd0.grams]
+    for rnd, marked in enumerate(([0, S // 2, S - 1], sorted(rng.choice(np.arange(2, S), size=max(2, S // 6), replace=False).tolist()))):
+        vecs = eng.ctx.from_numpy(rng.standard_normal((len(marked), n, 1)))
+        assert all(reductor._extend_marked(marked, vecs))
+        rd1 = reductor.reduce(touched=marked)
+        info = reductor.last_reduce_info
+        assert info['incremental'] and len(marked) <= info['subdomains'] < S
+        assert rd1.B_sys.data_ptr() == rd0.B_sys.data_ptr()                # in place: the previous model's arrays
+        inc = [x.clone() for x in (rd1.B_sys, rd1.rhs_red, rd1.E_red, rd1.M_red) + rd1.grams]
+        rd2 = reductor.reduce()                                             # the whole pass, fresh arrays
+        assert not reductor.last_reduce_info['incremental'] and rd2.B_sys.data_ptr() != rd0.B_sys.data_ptr()
+        changed = 0
+        for name, a, b, c in zip(names, inc, (rd2.B_sys, rd2.rhs_red, rd2.E_red, rd2.M_red) + rd2.grams, before):
+            assert torch.equal(a, b), (rnd, name)
+            changed += int(not torch.equal(a, c))
+        assert changed >= 10                                                # the round did change the model
+        rd0, before = rd2, [x.clone() for x in (rd2.B_sys, rd2.rhs_red, rd2.E_red, rd2.M_red) + rd2.grams]
+    # an empty round and a round that outgrows the slab
+    rd3 = reductor.reduce(touched=[])
+    assert reductor.last_reduce_info == {'incremental': True, 'subdomains': 0} and torch.equal(rd3.B_sys, before[0])
+    while reductor.basis_size() == width:
+        assert reductor._extend_marked([1], eng.ctx.from_numpy(rng.standard_normal((1, n, 1)))) == [True]
+    assert reductor.basis_size() == width + 1                               # grown on demand: no previous model of this width
+    rd4 = reductor.reduce(touched=[1])
+    assert not reductor.last_reduce_info['incremental'] and rd4.N == width + 1
+
+
 def test_corrector_solves_on_a_sharded_discretization_match_the_single_rank_ones():
     """A rank of a sharded discretization solves the neighbourhood problems of ITS subdomains on a second engine whose
     local set is local + halo (assembled on the rank, no communication): same correctors as the single-rank run."""
