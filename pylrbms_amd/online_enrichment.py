@@ -58,6 +58,9 @@ class AdaptiveEnrichment:
         for ii in np.where(age_count > self.marking_max_age)[0]:
             marked_subdomains.add(ii)
         mine = sorted(ii for ii in marked_subdomains if ii in set(self.discretization.engine.local))   # this rank's share
+        if getattr(self, '_reserve', 0) and hasattr(self.reductor, 'reserve'):
+            self.reductor.reserve(self.reductor.basis_size() + self._reserve)      # (every rank: the widths agree in reduce())
+            self._reserve = 0
         if hasattr(self.reductor, 'enrich_local_batch'):
             self.reductor.enrich_local_batch(mine, U, mu)
         else:
@@ -78,12 +81,9 @@ class AdaptiveEnrichment:
 
     def solve(self, mu, enrichment_steps=np.inf, callback=None):
         mu = self.discretization.parse_parameter(mu)
-        if hasattr(self.reductor, 'reserve') and np.isfinite(enrichment_steps) and enrichment_steps > 0:
-            # room for the vectors this loop can add (one per subdomain and round): the slab keeps its width, every round after
-            # the first re-projects marked + neighbours only.  (Zero columns change no result; an unbounded loop grows on demand.)
-            width = self.reductor.basis_size()
-            if self.reductor.reserve(width + int(min(enrichment_steps, 16))) != width:
-                self.rd = self.reductor.reduce()
+        # room for the vectors this loop can add (one per subdomain and round), reserved in front of the FIRST enrichment: the slab
+        # then keeps its width and every later round re-projects marked + neighbours only (zero columns change no result)
+        self._reserve = int(min(enrichment_steps, 16)) if np.isfinite(enrichment_steps) else 8
         enrichment_step = 1
         age_count = np.ones(self.block_space.num_blocks)
         local_problem_solves = 0
