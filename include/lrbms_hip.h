@@ -238,8 +238,9 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
  *       subdomain and of its FACE neighbours (HEAD: grid.neighborhood_of, discretize_elliptic_block_swipdg.py:78-113); 1: over
  *       every element at the vertex -- at a cross point also the elements of the diagonal subdomain -- the reading that
  *       reproduces the nonconformity value the reference prints (linearelliptic_block_swipdg_decomp.py:41: 1.66e-01).
- *       Factored layout of the fused pass only (rows of F_nc grow by N columns, lrbms_fused_fnc_ld), all subdomains on one
- *       rank (S_ext == S); the dense layout and the unfused kernels have five slots per neighbourhood and refuse it */
+ *       Factored layout of the fused pass only (rows of F_nc grow by N columns, lrbms_fused_fnc_ld); the dense layout and the
+ *       unfused kernels have five slots per neighbourhood and refuse it.  Sharded grids (S_ext > S): the diagonal subdomains must
+ *       be halo slabs and lrbms_set_diagonal_neighbours must name them */
 #define LRBMS_OPT_OSWALD_VERTEX_PATCH 9
 #define LRBMS_OPT_OSWALD_ZERO_ON_SUBDOMAIN_BOUNDARY 1
 #define LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q 2
@@ -267,6 +268,12 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
 #define LRBMS_OPT_ESTIMATE_VALU 8
 #define LRBMS_OPT_PREP_LDS 10
 int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value);
+
+/* LRBMS_OPT_OSWALD_VERTEX_PATCH on sharded grids: nbr_diag [S][4] (host) = index into the S_ext slabs of the diagonal neighbour
+ * at corner 0 SW, 1 SE, 2 NW, 3 NE of every local subdomain, or -1.  lrbms_mesh_upload derives the table from nbr where the side
+ * neighbour in between is local; a rank of a sharded grid whose diagonal neighbours are halo slabs of their own (they then need
+ * the rows of the elements at the shared cross point only) hands it over here.  Must follow lrbms_mesh_upload. */
+int lrbms_set_diagonal_neighbours(lrbms_ctx* ctx, const int32_t* nbr_diag);
 
 /* Incremental re-projection after online enrichment.  The reference re-reduces everything after a round of local enrichment
  * (online_enrichment.py:49-58 calls reductor.reduce() after reductor.py:75-78 enrich_local); but the projected operators of target

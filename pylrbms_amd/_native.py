@@ -36,6 +36,7 @@ SIGNATURES = {
     'lrbms_ctx_set_option': (ctypes.c_int, [c_vp, c_i32, c_i32]),
     'lrbms_set_quadrature': (ctypes.c_int, [c_vp, c_vp]),
     'lrbms_fused_set_subset': (ctypes.c_int, [c_vp, _P_I32, c_i32]),
+    'lrbms_set_diagonal_neighbours': (ctypes.c_int, [c_vp, _P_I32]),
     'lrbms_kernel_timing': (ctypes.c_int, [c_vp, c_i32]),
     'lrbms_kernel_timing_read': (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), c_i32,
                                                 ctypes.POINTER(c_i32)]),
@@ -531,6 +532,12 @@ class NativeContext:
         if name not in self.OPTIONS:
             raise NativeError('unknown option {!r}; known: {}'.format(name, sorted(self.OPTIONS)))
         self._check(self.lib.lrbms_ctx_set_option(self.handle, self.OPTIONS[name], int(value)), 'lrbms_ctx_set_option')
+
+    def set_diagonal_neighbours(self, nbr_diag):
+        """[S, 4] int32: index into the S_ext slabs of the diagonal neighbour at corner SW, SE, NW, NE of every local subdomain
+        (or -1) -- read by the Oswald vertex patch (include/lrbms_hip.h: lrbms_set_diagonal_neighbours)."""
+        arr = np.ascontiguousarray(np.asarray(nbr_diag, dtype=np.int32))
+        self._check(self.lib.lrbms_set_diagonal_neighbours(self.handle, arr.ctypes.data_as(_P_I32)), 'lrbms_set_diagonal_neighbours')
 
     def fused_set_subset(self, subset):
         """Restrict the following fused passes to the local subdomains ``subset`` (strictly ascending local indices; ``None`` or

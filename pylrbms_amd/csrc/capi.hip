@@ -183,6 +183,18 @@ int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value) {
   return LRBMS_OK;
 }
 
+int lrbms_set_diagonal_neighbours(lrbms_ctx* ctx, const int32_t* nbr_diag) {
+  LRBMS_REQUIRE_MESH(ctx);
+  if (!nbr_diag) return lrbms_fail(ctx, LRBMS_E_INVALID, "set_diagonal_neighbours: null table");
+  for (long i = 0; i < (long)ctx->S * 4; ++i)
+    if (nbr_diag[i] < -1 || nbr_diag[i] >= ctx->S_ext)
+      return lrbms_fail(ctx, LRBMS_E_INVALID, "set_diagonal_neighbours: index out of range [-1, S_ext)");
+  LRBMS_HIP_CHECK(ctx, hipDeviceSynchronize());      // no pass in flight reads the table while it changes
+  LRBMS_HIP_CHECK(ctx, hipMemcpy(const_cast<int*>(ctx->t.nbr_diag), nbr_diag, sizeof(int) * (size_t)ctx->S * 4, hipMemcpyHostToDevice));
+  ctx->diag_explicit = true;
+  return LRBMS_OK;
+}
+
 int lrbms_fused_set_subset(lrbms_ctx* ctx, const int32_t* subset, int32_t count) {
   LRBMS_REQUIRE_MESH(ctx);
   if (count < 0 || count > ctx->S || (count > 0 && subset == nullptr))
@@ -309,6 +321,20 @@ int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* d, int32_t S, int32
   if ((rc = upload(ctx, nbr, (size_t)S * 5, &nbr_dev))) return rc;
   ctx->nbr = const_cast<int*>(nbr_dev);
   ctx->nbr_host.assign(nbr, nbr + (size_t)S * 5);
+  {
+    // diagonal neighbours as far as nbr determines them: the E / W neighbour of the S / N neighbour, if that one is local
+    std::vector<int32_t> dg((size_t)S * 4, -1);
+    for (int i = 0; i < S; ++i)
+      for (int c = 0; c < 4; ++c) {
+        const int sa = nbr[i * 5 + (c < 2 ? 0 : 4)];
+        if (sa >= 0 && sa < S) dg[(size_t)i * 4 + c] = nbr[sa * 5 + ((c & 1) ? 3 : 1)];
+      }
+    const int* dg_dev = nullptr;
+    if ((rc = upload(ctx, dg.data(), dg.size(), &dg_dev))) return rc;
+    t.nbr_diag = dg_dev;
+    ctx->diag_explicit = false;
+  }
+  ctx->subset_n = 0;
   ctx->S = S;
   ctx->S_ext = S_ext;
   if ((rc = build_template_tables(ctx))) return rc;

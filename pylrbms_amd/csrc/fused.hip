@@ -327,8 +327,7 @@ __device__ __forceinline__ void vertex_avg_body(const Tmpl& t, int S, const int*
       if ((lx == 0 || lx == t.nvx - 1) && (ly == 0 || ly == t.nvy - 1)) {
         double a3 = 0.0;
         if (o.vdiag >= 0) {
-          const int sd1 = nbr[s * 5 + side_to_slot(o.sda)];                      // exists: the vertex is not on a Dirichlet side
-          const int sdg = nbr[sd1 * 5 + side_to_slot(o.sdb)];                    // one rank holds every subdomain (checked by the launcher)
+          const int sdg = t.nbr_diag[s * 4 + o.corner];                          // exists (checked by the launcher for sharded grids)
           const int q0 = t.vdof_ptr[o.vdiag], q1 = t.vdof_ptr[o.vdiag + 1];
           for (int pb = q0; pb < q1; ++pb) a3 += V[((long)sdg * t.n + t.vdof_idx[pb]) * N + j];
           a3 *= o.inv;
@@ -630,8 +629,7 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
         const OsInfo o = oswald_vertex(t, nbr + s * 5, v);
         d2 a3 = {0.0, 0.0};
         if (o.vdiag >= 0) {
-          const int sd1 = nbr[s * 5 + side_to_slot(o.sda)];
-          const int sdg = nbr[sd1 * 5 + side_to_slot(o.sdb)];
+          const int sdg = t.nbr_diag[s * 4 + corner];
           for (int pb = vptr[o.vdiag]; pb < vptr[o.vdiag + 1]; ++pb) {
             const d2 x = V2[((long)sdg * t.n + vidx[pb]) * N2 + j2];
             a3.x += x.x;
@@ -757,6 +755,21 @@ __device__ __forceinline__ void vertex_side_body(const Tmpl& t, int S, const int
       a2 *= o.inv;
     }
     AvgSide[(((long)s * 4 + sd) * nvs + pos) * N + j] = a2;
+  }
+  if (t.opt_oswald_vertex) {      // the diagonal subdomains' shares at the four corners: Avg_corner [S][4][N] behind Avg_side
+    const long totc = (long)(t.sub_list ? t.sub_count : S) * 4 * N;
+    for (long idx = (long)bx * 256 + threadIdx.x; idx < totc; idx += (long)gx * 256) {
+      const int j = (int)(idx % N), corner = (int)((idx / N) % 4), s = subdomain_of(t, (int)(idx / N / 4));
+      const int v = ((corner & 1) ? t.nvx - 1 : 0) + t.nvx * ((corner & 2) ? t.nvy - 1 : 0);
+      const OsInfo o = oswald_vertex(t, nbr + s * 5, v);
+      double a3 = 0.0;
+      if (o.vdiag >= 0) {
+        const int sdg = t.nbr_diag[s * 4 + corner];
+        for (int p = t.vdof_ptr[o.vdiag]; p < t.vdof_ptr[o.vdiag + 1]; ++p) a3 += V[((long)sdg * t.n + t.vdof_idx[p]) * N + j];
+        a3 *= o.inv;
+      }
+      (AvgSide + (long)S * 4 * nvs * N)[((long)s * 4 + corner) * N + j] = a3;
+    }
   }
 }
 
@@ -3697,9 +3710,12 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   double* AvgSide = AvgSelf + (long)S * t.nv * N;
   const bool factored = Fside != nullptr;
   if (factored != (Fnc != nullptr)) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: F_side and F_nc go together");
-  if (t.opt_oswald_vertex && (!factored || phase != 0 || ctx->S_ext != ctx->S))
+  if (t.opt_oswald_vertex && !factored)
     return lrbms_fail(ctx, LRBMS_E_INVALID, "LRBMS_OPT_OSWALD_VERTEX_PATCH: the diagonal subdomains enter through the factored layout "
-                                            "only (F_nc), whole pass, all subdomains on one rank");
+                                            "only (F_nc)");
+  if (t.opt_oswald_vertex && ctx->S_ext != ctx->S && !ctx->diag_explicit)
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "LRBMS_OPT_OSWALD_VERTEX_PATCH on a sharded grid: the diagonal subdomains must be halo "
+                                            "slabs named by lrbms_set_diagonal_neighbours");
   if (!factored) Fside = AvgSide + (long)S * 4 * nvs * N;
   const long gstride = factored ? (long)QN * QN : (long)9 * QN * QN;      // self blocks of G_bb / G_rdd
   const int abld = factored ? QN : C;                                     // row length of G_ab

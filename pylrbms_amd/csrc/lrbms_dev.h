@@ -44,6 +44,10 @@ struct Tmpl {
   // nullptr: every subdomain (workgroup b works on subdomain b).  Set in the launcher's COPY of the template, never in ctx->t.
   const int* sub_list;
   int sub_count;
+  // diagonal neighbours [S][4] (corner 0 SW, 1 SE, 2 NW, 3 NE; index into the S_ext slabs or -1): read with
+  // LRBMS_OPT_OSWALD_VERTEX_PATCH only.  mesh_upload derives it from nbr where that is possible (side neighbour local);
+  // lrbms_set_diagonal_neighbours replaces it (sharded grids: the diagonal subdomain is a halo slab of its own).
+  const int* nbr_diag;
 };
 
 // the subdomain workgroup-index b of a fused-pass kernel works on
@@ -84,6 +88,7 @@ struct lrbms_ctx {
   long ksp_part_cap = 0;
   int* ksp_ticket = nullptr;
   long ksp_ticket_cap = 0;
+  bool diag_explicit = false;         // lrbms_set_diagonal_neighbours was called (needed with the vertex patch when S_ext > S)
   int* subset = nullptr;              // lrbms_fused_set_subset: device copy of the list (ctx-owned), subset_n == 0: no restriction
   int subset_n = 0, subset_cap = 0;
   lrbms_quadrature* qdev = nullptr;   // device copy of the quadrature (lrbms_set_quadrature), read by the assembly kernels

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
                                                           const double* __restrict__ G_aa, const double* __restrict__ Fside,
                                                           const double* __restrict__ Fnc, int ncf, int nvs,
                                                           const double* __restrict__ f2, const double* __restrict__ ceps,
-                                                          double hdiam, double* __restrict__ eta_loc, int nvx_patch) {
+                                                          double hdiam, double* __restrict__ eta_loc, int nvx_patch,
+                                                         const int* __restrict__ nbr_diag) {
   // nvx_patch > 0: LRBMS_OPT_OSWALD_VERTEX_PATCH (value: vertices per x-side) -- rows of F_nc carry A_diag, see k_thin_ncf
   extern __shared__ double lds[];
   const int s = blockIdx.x;
@@ -132,8 +133,7 @@ __global__ __launch_bounds__(256) void k_reduced_estimate(int S, const int* __re
       // (z_a[pos] += A_diag . u_diag); corners 0 SW / 1 SE on side 0, 2 NW / 3 NE on side 3
       if (wave < 4) {
         const int corner = wave, side = corner < 2 ? 0 : 3, pos = (corner & 1) ? nvx_patch - 1 : 0;
-        const int sa = nbr[s * 5 + (corner < 2 ? 0 : 4)];                     // S / N neighbour
-        const int sd = sa >= 0 ? nbr[sa * 5 + ((corner & 1) ? 3 : 1)] : -1;   // ... and its E / W neighbour: the diagonal subdomain
+        const int sd = nbr[s * 5 + (corner < 2 ? 0 : 4)] >= 0 ? nbr_diag[s * 4 + corner] : -1;   // the diagonal subdomain (Tmpl::nbr_diag)
         const int row = side * nvs + pos;
         double d = 0.0;
         if (sd >= 0) {
@@ -524,13 +524,13 @@ int launch_reduced_estimate(lrbms_ctx* ctx, int Q, int N, const double* theta, c
   QVec th;
   for (int q = 0; q < 8; ++q) th.v[q] = q < Q ? theta[q] : 0.0;
   if ((Fside != nullptr) != (Fnc != nullptr)) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate: F_side and F_nc go together");
-  if (ctx->t.opt_oswald_vertex && (Fnc == nullptr || ctx->S_ext != ctx->S))
-    return lrbms_fail(ctx, LRBMS_E_INVALID, "LRBMS_OPT_OSWALD_VERTEX_PATCH: factored layout, all subdomains on one rank");
+  if (ctx->t.opt_oswald_vertex && (Fnc == nullptr || (ctx->S_ext != ctx->S && !ctx->diag_explicit)))
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "LRBMS_OPT_OSWALD_VERTEX_PATCH: factored layout; sharded grids need lrbms_set_diagonal_neighbours");
   const int nvs = ctx->t.nvx > ctx->t.nvy ? ctx->t.nvx : ctx->t.nvy;
   const size_t lds = sizeof(double) * (5 * N + 5 * Q * N + 256 + 4 * ctx->t.ncf * (3 + Q) + 8 * nvs);
   hipLaunchKernelGGL(k_reduced_estimate, dim3(ctx->S), dim3(256), lds, st, ctx->S, ctx->nbr, Q, N, th, u, G_nc, r_fd,
                      G_rdd, G_bb, G_ab, G_aa, Fside, Fnc, ctx->t.ncf, nvs, f2, ceps, hdiam, eta_loc,
-                     ctx->t.opt_oswald_vertex ? ctx->t.nvx : 0);
+                     ctx->t.opt_oswald_vertex ? ctx->t.nvx : 0, ctx->t.nbr_diag);
   LRBMS_LAUNCH_CHECK(ctx);
   return LRBMS_OK;
 }
@@ -2138,7 +2138,8 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
                                                                      const double* __restrict__ Fside, const double* __restrict__ Fnc,
                                                                      int ncf, int nvs, const double* __restrict__ f2,
                                                                      const double* __restrict__ ceps, double hdiam,
-                                                                     double* __restrict__ eta_loc, int ldu, int m0, int nvx_patch) {
+                                                                     double* __restrict__ eta_loc, int ldu, int m0, int nvx_patch,
+                                                                     const int* __restrict__ nbr_diag) {
   extern __shared__ double lds[];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4, wave = tid >> 6;
   const int W = 5 * N, QN = Q * N, C = 5 * QN;
@@ -2156,8 +2157,7 @@ __global__ __launch_bounds__(64 * EST_NW) void k_reduced_estimate_batch_mfma(int
   if (nvx_patch > 0 && tid < 64) {
     // cross points (see k_reduced_estimate): thread = (corner, parameter)
     const int corner = tid >> 4, m = tid & 15, side = corner < 2 ? 0 : 3, pos = (corner & 1) ? nvx_patch - 1 : 0;
-    const int sa = nbr[s * 5 + (corner < 2 ? 0 : 4)];
-    const int sd = sa >= 0 ? nbr[sa * 5 + ((corner & 1) ? 3 : 1)] : -1;
+    const int sd = nbr[s * 5 + (corner < 2 ? 0 : 4)] >= 0 ? nbr_diag[s * 4 + corner] : -1;
     double d = 0.0;
     if (sd >= 0 && m < nmu) {
       const double* x = Fnc + ((long)s * 4 * nvs + side * nvs + pos) * (3 * N + 4 * nvs) + 2 * N + 4 * nvs;
@@ -2309,8 +2309,8 @@ int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const d
                                   const double* G_aa, const double* Fside, const double* Fnc, const double* f2, const double* ceps,
                                   double hdiam, double* eta_loc, hipStream_t st) {
   if ((Fside != nullptr) != (Fnc != nullptr)) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: F_side and F_nc go together");
-  if (ctx->t.opt_oswald_vertex && (Fnc == nullptr || ctx->S_ext != ctx->S))
-    return lrbms_fail(ctx, LRBMS_E_INVALID, "LRBMS_OPT_OSWALD_VERTEX_PATCH: factored layout, all subdomains on one rank");
+  if (ctx->t.opt_oswald_vertex && (Fnc == nullptr || (ctx->S_ext != ctx->S && !ctx->diag_explicit)))
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "LRBMS_OPT_OSWALD_VERTEX_PATCH: factored layout; sharded grids need lrbms_set_diagonal_neighbours");
   const int nvs = ctx->t.nvx > ctx->t.nvy ? ctx->t.nvx : ctx->t.nvy;
   if (nmu < 1 || nmu > 64) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: need 1 <= nmu <= 64");
   // passes of <= 16 parameters over the same u / eta_loc arrays (column offset m0): the layout lrbms_reduced_solve_batch returns
@@ -2331,7 +2331,7 @@ int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const d
                                                  (int)ldm));
       hipLaunchKernelGGL(k_reduced_estimate_batch_mfma, dim3(ctx->S), dim3(64 * EST_NW), ldm, st, ctx->S, ctx->nbr, Q, N, nm, th, u, G_nc, r_fd,
                          G_rdd, G_bb, G_ab, G_aa, Fside, Fnc, ctx->t.ncf, nvs, f2, ceps, hdiam, eta_loc, nmu, m0,
-                         ctx->t.opt_oswald_vertex ? ctx->t.nvx : 0);
+                         ctx->t.opt_oswald_vertex ? ctx->t.nvx : 0, ctx->t.nbr_diag);
     } else {
       if (lds > 64 * 1024)
         LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_reduced_estimate_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -152,7 +152,8 @@ class DuneDiscretization:
             g = self.grid
             from pylrbms_amd.grid import DDSubdomainsGrid
             plan = HaloPlan(lambda r: DDSubdomainsGrid(g.lower_left, g.upper_right, g.K, g.P, rank=r,
-                                                       world_size=g.world_size), g.world_size, g.rank)
+                                                       world_size=g.world_size), g.world_size, g.rank,
+                            diagonal=bool(eng.conventions.get('oswald_vertex_patch')))
             self._halo[L] = HaloExchange(plan, L, V.device, group=getattr(self.mpi_comm, 'group', None))
         return self._halo[L](V)
 

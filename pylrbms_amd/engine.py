@@ -96,7 +96,12 @@ class Engine:
         self.t = t
         local = list(grid.subdomains_on_rank)
         lset = set(local)
-        halo = sorted({j for s in local for j in grid.neighboring_subdomains(s)} - lset)
+        # (with the Oswald vertex patch the diagonal neighbours are read too -- one DoF row per element at the shared cross point)
+        diagonal = bool(self.conventions.get('oswald_vertex_patch'))
+        if hasattr(grid, 'halo_subdomains'):
+            halo = grid.halo_subdomains(diagonal=diagonal)
+        else:
+            halo = sorted({j for s in local for j in grid.neighboring_subdomains(s)} - lset)
         self.local, self.halo = local, halo
         self.ext = local + halo
         pos = {g: i for i, g in enumerate(self.ext)}
@@ -116,6 +121,10 @@ class Engine:
         self.ctx.mesh_upload(t, kap, nbr, self.S, self.S_ext)
         for name, value in self.conventions.items():          # conventions the reference leaves open (LRBMS_OPT_*)
             self.ctx.set_option(name, value)
+        if diagonal and hasattr(grid, 'diagonal_neighbors'):
+            self.nbr_diag = np.array([[pos.get(g, -1) if g >= 0 else -1 for g in grid.diagonal_neighbors(s)] for s in local],
+                                     dtype=np.int32).reshape(len(local), 4)
+            self.ctx.set_diagonal_neighbours(self.nbr_diag)
         self.ctx.set_quadrature(self.quadrature)
         self.hdiam = grid.subdomain_diameter(0)
 

@@ -235,6 +235,28 @@ class DDSubdomainsGrid:
     def neighborhood_of(self, ii):
         return [int(j) for j in self.neighbor_slots[ii] if j >= 0]
 
+    def diagonal_neighbors(self, ii):
+        """Global ids of the subdomains that touch ``ii`` in ONE vertex, by corner 0 SW, 1 SE, 2 NW, 3 NE (-1: none).  Not part of
+        ``neighborhood_of`` (HEAD's grid.neighborhood_of returns face neighbours); the Oswald vertex patch reads them
+        (conventions={'oswald_vertex_patch': True})."""
+        Px, Py = self.P
+        sx, sy = int(ii) % Px, int(ii) // Px
+        out = []
+        for dy in (-1, 1):
+            for dx in (-1, 1):
+                x, y = sx + dx, sy + dy
+                out.append(int(x + Px * y) if 0 <= x < Px and 0 <= y < Py else -1)
+        return out
+
+    def halo_subdomains(self, diagonal=False):
+        """Sorted global ids of the subdomains other ranks own whose basis rows this rank's subdomains read: the face neighbours
+        and, with ``diagonal`` (Oswald vertex patch), the diagonal ones.  Engine and HaloPlan order the halo slabs this way."""
+        local = set(self.subdomains_on_rank)
+        halo = {j for s in local for j in self.neighboring_subdomains(s)}
+        if diagonal:
+            halo |= {j for s in local for j in self.diagonal_neighbors(s) if j >= 0}
+        return sorted(int(j) for j in halo - local)
+
     def boundary_subdomains(self):
         return [int(i) for i in np.nonzero((self.neighbor_slots < 0).any(axis=1))[0]]
 

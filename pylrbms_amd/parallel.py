@@ -72,12 +72,25 @@ def side_rows3d(template):
     return rows
 
 
+def corner_rows(template):
+    """2D: for each corner 0 SW, 1 SE, 2 NW, 3 NE of the subdomain the sorted DoF rows sitting AT that lattice vertex (one per
+    element of its star) -- all the Oswald vertex patch reads of a diagonal neighbour's basis."""
+    t = template
+    rows = []
+    for c in range(4):
+        v = ((c & 1) and t.nvx - 1) + t.nvx * ((c & 2) and t.nvy - 1)
+        rows.append(np.sort(np.asarray(t.vdof_idx[t.vdof_ptr[v]:t.vdof_ptr[v + 1]], dtype=np.int64)))
+    return rows
+
+
 class HaloPlan:
     """Who sends which rows of which subdomain: derived by every rank from the grid partition alone (no handshake)."""
 
-    def __init__(self, grid_factory, world_size, rank):
+    def __init__(self, grid_factory, world_size, rank, diagonal=False):
         """``grid_factory(rank)`` returns the DDSubdomainsGrid (2D) or DDSubdomainsGrid3D as seen by ``rank`` (same global
-        grid, other tile)."""
+        grid, other tile).  ``diagonal`` (2D, conventions oswald_vertex_patch): the halo also holds the diagonal neighbours, and a
+        diagonal neighbour whose corner rows do not already travel with a side item sends them as an item of their own
+        (kinds 4 .. 7 = corner 0 .. 3 behind the four sides): at a cross point of four ranks' tiles, two DoF rows per corner."""
         grids = [grid_factory(r) for r in range(world_size)]
         g = grids[rank]
         self.rank, self.world_size = rank, world_size
@@ -94,6 +107,17 @@ class HaloPlan:
         for r, gr in enumerate(grids):
             for s in gr.subdomains_on_rank:
                 owner[s] = r
+        diagonal = bool(diagonal) and getattr(g, 'dim', 2) == 2
+        if diagonal:
+            rows = list(rows) + corner_rows(t)
+            corner_sides = ((0, 1), (0, 2), (3, 1), (3, 2))       # the two sides that meet in corner SW, SE, NW, NE
+
+        def peer_of(s, kind):
+            """Global id of the subdomain that reads item (s, kind): the face neighbour across side ``kind`` or the diagonal
+            neighbour at corner ``kind - nsides``."""
+            if kind < nsides:
+                return int(g.neighbor_slots[s, slot_of_side[kind]])
+            return int(g.diagonal_neighbors(s)[kind - nsides])
         # send list of rank r: for each owned subdomain s and each side whose neighbour lives elsewhere,
         # the rows of s touching that side.  Deterministic order: (s ascending, side ascending).
         self.send_items = []      # per rank: list of (subdomain, side)
@@ -104,6 +128,15 @@ class HaloPlan:
                     j = g.neighbor_slots[s, slot_of_side[sd]]
                     if j >= 0 and owner[int(j)] != r:
                         items.append((s, sd))
+                if diagonal:
+                    for c, dgn in enumerate(g.diagonal_neighbors(s)):
+                        if dgn < 0 or owner[dgn] == r:
+                            continue
+                        # the corner rows are part of the side rows of both sides that meet there: they already reach owner[dgn] if
+                        # that rank also owns the face neighbour of s across one of the two
+                        if any(owner.get(int(g.neighbor_slots[s, slot_of_side[sd]]), -1) == owner[dgn] for sd in corner_sides[c]):
+                            continue
+                        items.append((s, nsides + c))
             self.send_items.append(items)
         self.row_counts = [len(rw) for rw in rows]
         self.rows = rows
@@ -112,7 +145,10 @@ class HaloPlan:
         # local gather index (into the flattened [S_ext * n] row space of the local V) for my own send buffer
         local = list(g.subdomains_on_rank)
         lpos = {s: i for i, s in enumerate(local)}
-        halo = sorted({int(j) for s in local for j in g.neighboring_subdomains(s)} - set(local))
+        if diagonal:
+            halo = g.halo_subdomains(diagonal=True)
+        else:
+            halo = sorted({int(j) for s in local for j in g.neighboring_subdomains(s)} - set(local))
         hpos = {s: len(local) + i for i, s in enumerate(halo)}
         self.S, self.S_ext, self.n = len(local), len(local) + len(halo), t.n
         idx = []
@@ -127,7 +163,7 @@ class HaloPlan:
             off = 0
             for (s, sd) in self.send_items[r]:
                 cnt = self.row_counts[sd]
-                j = int(g.neighbor_slots[s, slot_of_side[sd]])
+                j = peer_of(s, sd)
                 if s in hpos and j in lpos:          # s is my halo because its neighbour j on that side is mine
                     src.append(r * self.max_rows + off + np.arange(cnt))
                     dst.append(hpos[s] * t.n + rows[sd])
@@ -138,7 +174,7 @@ class HaloPlan:
         # point-to-point form of the same exchange (one all_to_all with per-peer splits): every (s, side) item goes
         # to exactly one peer, the owner of the neighbour across that side.  Send buffer ordered by (peer, s, side).
         def dest(s, sd):
-            return owner[int(g.neighbor_slots[s, slot_of_side[sd]])]
+            return owner[peer_of(s, sd)]
         self.a2a_send_splits = [0] * world_size
         self.a2a_recv_splits = [0] * world_size
         pidx, udst = [], []

@@ -74,6 +74,54 @@ def test_halo_exchange_gloo(world, mode):
         assert ok and checked > 0
 
 
+def _diag_worker(rank, world, port, results):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pylrbms_amd.parallel import corner_rows
+        mk = lambda r: DDSubdomainsGrid([0, 0], [1, 1], (P[0] * KC, P[1] * KC), P, rank=r, world_size=world)  # noqa: E731
+        grid = mk(rank)
+        Vg = _global_V(grid)
+        local = grid.subdomains_on_rank
+        halo = grid.halo_subdomains(diagonal=True)
+        crow = corner_rows(grid.template)
+        ok, checked, corner_items = True, 0, 0
+        for mode in ('alltoall', 'allgather'):
+            plan = HaloPlan(mk, world, rank, diagonal=True)
+            assert plan.S_ext == len(local) + len(halo)
+            corner_items = sum(1 for (_, kind) in plan.send_items[rank] if kind >= 4)
+            V = torch.full((len(local) + len(halo), grid.template.n, N), float('nan'), dtype=torch.float64)
+            V[:len(local)] = torch.from_numpy(Vg[local])
+            HaloExchange(plan, N, V.device, mode=mode)(V)
+            hpos = {g: len(local) + i for i, g in enumerate(halo)}
+            for s in local:                                           # what the vertex patch reads of a diagonal neighbour
+                for c, dgn in enumerate(grid.diagonal_neighbors(s)):
+                    if dgn >= 0 and dgn not in local:
+                        rows = crow[3 - c]                            # the opposite corner of the diagonal subdomain
+                        ok &= bool(np.array_equal(V[hpos[dgn], rows].numpy(), Vg[dgn][rows]))
+                        checked += 1
+        results[rank] = (ok, checked, corner_items)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_halo_exchange_with_diagonal_neighbours_gloo(world):
+    """conventions oswald_vertex_patch on a sharded grid: the halo also holds the diagonal neighbours, and their DoF rows at the
+    shared cross point arrive -- with a side item where one passes by anyway, as a corner item of their own (two rows) where four
+    tiles meet (world 4: 2 x 2 tiles of the 4 x 4 grid have one such cross point, every rank sends exactly one corner item)."""
+    port = 27200 + (os.getpid() % 1000) + world
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_diag_worker, args=(world, port, results), nprocs=world, join=True)
+    assert len(results) == world
+    for r in range(world):
+        ok, checked, corner_items = results[r]
+        assert ok and checked > 0
+        assert corner_items == (1 if world == 4 else 0)
+
+
 def test_side_rows_cover_what_the_kernels_read():
     t = DDSubdomainsGrid([0, 0], [1, 1], (8, 8), (2, 2)).template
     rows = side_rows(t)

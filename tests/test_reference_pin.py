@@ -104,9 +104,12 @@ def test_three_printed_indicators_of_the_4x4_configuration(patch):
     readings of the Oswald vertex patch -- unlike the 2 x 2 configuration above, this one has cross points and unsymmetric
     interfaces, so it does see the coupling-face conventions.  The nonconformity indicator tells the two readings apart: the printed
     1.66e-01 is matched by the patch over ALL elements at a vertex (0.16561), the face-neighbour patch of HEAD's
-    ``grid.neighborhood_of`` gives 0.16801 (1.2 % off, bounded here).  The product implements HEAD's reading; the vertex patch lives
-    in the oracle only (it needs the diagonal subdomains in every neighbourhood: 9 slots instead of 5 in every kernel and halo
-    plan).  Stated tolerance of the pin: 3 digits on r and df, 1.2 % on nc."""
+    ``grid.neighborhood_of`` gives 0.16801 (1.2 % off, bounded here).  The product's default is HEAD's reading; the vertex patch is
+    the switch ``conventions={'oswald_vertex_patch': True}`` (through the factored layout: one more column block per corner row
+    of F_nc, the diagonal subdomains' corner rows in the halo exchange on sharded grids) -- the product-side counterpart of this
+    test is ``test_product_with_the_vertex_patch_reproduces_all_three_printed_indicators`` below, the sharded one
+    ``tests/test_sharded_gpu.py::test_vertex_patch_on_a_sharded_grid_matches_the_oracle``.  Stated tolerance of the pin: 3 digits
+    on r and df, 1.2 % on nc with HEAD's patch, 3 digits with the vertex patch."""
     p = OS2015_academic_problem.init_grid_and_problem(CONFIG_4x4)
     kw = {'oswald_patch': 'vertex'} if patch == 'vertex' else {}
     d = oracle_from_problem(p, quad=QuadratureSpec.dune(), **kw)

@@ -15,7 +15,7 @@ PX, PY, KC, N = 4, 3, 2, 5
 # (subdomains x, y, coarse squares per subdomain and direction, local basis size): 'small' exercises odd N (k_f1u, the streaming
 # sweeps); 'cfg3' is the template of BASELINE.json config 3 / 4 (k_c = 4, N = 40) on a 6 x 4 grid -- the kernels a sharded run of
 # config 4 launches (k_f1v<3,2,1,2,4>, k_prep_lds<3> with the G_nc fold, its slab-less 256-thread phase-2 instance, k_thin3<3>)
-SHAPES = {'small': (PX, PY, KC, N), 'cfg3': (6, 4, 4, 40)}
+SHAPES = {'small': (PX, PY, KC, N), 'cfg3': (6, 4, 4, 40), 'vp': (4, 4, 2, 6)}
 
 
 def _problem(comm=None, shape='small'):
@@ -199,6 +199,102 @@ def test_sharded_projection_matches_single_rank(world, shape, tmp_path):
         ok, worst, S, S_ext, ran = results[r]
         assert ok, (r, worst, ran)
         assert S_ext > S
+
+
+def _vertex_patch_worker(rank, world, port, ref_path, results):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pylrbms_amd.engine import Engine
+        from pylrbms_amd.grid import DDSubdomainsGrid
+        from pylrbms_amd.parallel import Communicator, HaloExchange, HaloPlan
+        N = SHAPES['vp'][3]
+        comm = Communicator(rank, world)
+        p = _problem(comm, 'vp')
+        grid, lam = p['grid'], p['lambda']
+        theta_bar = np.array([c.evaluate(p['mu_bar']) for c in lam['coefficients']])
+        eng = Engine(grid, lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], theta_bar,
+                     conventions={'oswald_vertex_patch': True}).assemble()
+        ref = np.load(ref_path)
+        Vg, U, thetas = ref['V'], ref['U'], ref['thetas']
+        plan = HaloPlan(lambda r: DDSubdomainsGrid(grid.lower_left, grid.upper_right, grid.K, grid.P, rank=r, world_size=world),
+                        world, rank, diagonal=True)
+        assert plan.S_ext == eng.S_ext > eng.S
+        ok, worst = True, 0.0
+        for mode in ('overlap', 'overlap/serial', 'whole', 'whole/streaming'):
+            eng.ctx.set_option('prep_lds', 0 if 'streaming' in mode else 1)
+            Engine.SERIAL_PHASES_FROM = 1 if 'serial' in mode else 384
+            V = torch.full((eng.S_ext, grid.template.n, N), float('nan'), dtype=torch.float64, device=eng.ctx.device)
+            V[:eng.S] = eng.ctx.from_numpy(Vg[eng.local])
+            hx = HaloExchange(plan, N, V.device)
+            if mode.startswith('overlap'):       # the production choreography: exchange under the halo-independent half
+                buf = eng.project_and_estimate(V, eng.alloc_reduce_buffers(N), halo=hx)
+            else:
+                # rows of the halo slabs nobody reads stay NaN; the pass must not touch them
+                buf = eng.project_and_estimate(hx(V), eng.alloc_reduce_buffers(N))
+            torch.cuda.synchronize()
+            for m in range(U.shape[2]):
+                u = eng.ctx.from_numpy(np.ascontiguousarray(U[eng.ext, :, m]))
+                eta = eng.reduced_estimate(thetas[m], u, buf['grams']).cpu().numpy()
+                for row in range(3):
+                    want = ref['eta'][m, row][eng.local]
+                    err = np.abs(eta[row] - want).max() / np.abs(ref['eta'][m, row]).max()
+                    worst = max(worst, float(err))
+                    ok &= bool(err < 1e-10)
+            ub = eng.ctx.from_numpy(np.ascontiguousarray(U[eng.ext]))
+            eta_b = eng.ctx.reduced_estimate_batch(thetas, ub, buf['grams'], eng.f2, eng.ceps, eng.hdiam).cpu().numpy()
+            for m in range(U.shape[2]):
+                for row in range(3):
+                    ok &= bool(np.abs(eta_b[row, :, m] - ref['eta'][m, row][eng.local]).max() < 1e-10 * np.abs(ref['eta'][m, row]).max())
+        Engine.SERIAL_PHASES_FROM = 384
+        del eng, buf, V
+        # API level: the same through discretize(conventions=) -> reductor -> rd.estimate (global norms all-reduced)
+        from pylrbms_amd.discretize_elliptic_block_swipdg import discretize
+        from pylrbms_amd.reductor import LRBMSReductor
+        from pylrbms_amd.vectorarrays import ReducedVectorArray
+        d, _ = discretize(_problem(comm, 'vp'), mpi_comm=comm, conventions={'oswald_vertex_patch': True})
+        rd = LRBMSReductor(d, bases={'domain_{}'.format(ii): Vg[ii].T for ii in d.engine.local}).reduce()
+        u0 = ReducedVectorArray(d.engine.ctx.from_numpy(np.ascontiguousarray(U[d.engine.local, :, :1])))
+        est = float(rd.estimate(u0, mu=float(ref['mus'][0])))
+        ok &= bool(abs(est - float(ref['est0'])) < 1e-9 * float(ref['est0']))
+        _put(results, rank, (ok, worst, est))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_vertex_patch_on_a_sharded_grid_matches_the_oracle(world, tmp_path):
+    """conventions={'oswald_vertex_patch': True} (the reading that reproduces the reference's printed nonconformity value,
+    linearelliptic_block_swipdg_decomp.py:41) on 2 and 4 ranks: the diagonal neighbours are halo slabs of their own
+    (lrbms_set_diagonal_neighbours), their corner rows travel with the one halo exchange (HaloPlan(diagonal=True); 4 ranks: the
+    cross point of the four tiles needs corner items), and every rank's local estimator terms equal the ORACLE's with
+    ``oswald_patch='vertex'`` (1e-10) -- whole pass, streaming preparation, and the overlapped / serial-phase choreography with
+    the halo poisoned until the exchange has filled it; rd.estimate through the API equals the single-rank oracle value."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from common import energy_orthonormalize, make_bases, oracle_from_problem, theta_of
+    from oracle.lrbms import OracleReductor
+    N = SHAPES['vp'][3]
+    p = _problem(shape='vp')
+    d = oracle_from_problem(p, oswald_patch='vertex')
+    V = energy_orthonormalize(make_bases(d.S, d.n, N, seed=31), d)
+    rd = OracleReductor(d, [V[ii] for ii in range(d.S)]).reduce()
+    mus = [0.2, 0.9]
+    U = np.random.default_rng(9).standard_normal((d.S, N, len(mus)))
+    eta = np.zeros((len(mus), 3, d.S))
+    for m, mu in enumerate(mus):
+        _, (nc, r, df), _ = rd.estimate([U[ii, :, m] for ii in range(d.S)], mu, decompose=True)
+        eta[m] = np.stack([nc, r, df])
+    est0 = rd.estimate([U[ii, :, 0] for ii in range(d.S)], mus[0])
+    ref_path = str(tmp_path / 'ref.npz')
+    np.savez(ref_path, V=V, U=U, thetas=np.stack([theta_of(p, mu) for mu in mus]), eta=eta, mus=np.array(mus), est0=float(est0))
+    port = 29400 + (os.getpid() % 90) + world
+    results = _spawn_and_collect(_vertex_patch_worker, (world, port, ref_path), world, tmp_path)
+    assert len(results) == world
+    for r in range(world):
+        ok, worst, est = results[r]
+        assert ok, (r, worst, est, float(est0))
 
 
 def _bench_line(nranks, port):
