@@ -363,10 +363,11 @@ int lrbms_reduced_solve(lrbms_ctx* ctx, int32_t Q, int32_t N, const double* thet
                         const double* rhs_red, double* work, double* u, double rtol, int32_t max_iter, double* info,
                         void* stream);
 
-/* O1, throughput form: nmu <= 64 parameters per call, in groups of <= 16.  theta [nmu][Q] host; u [S][N][nmu] (mu fastest).
+/* O1, throughput form: nmu <= 64 parameters per call, in groups of <= 32 (calls of <= 16 parameters: one group of <= 16; with
+ * LRBMS_OPT_SOLVE_VALU: groups of <= 16).  theta [nmu][Q] host; u [S][N][nmu] (mu fastest).
  * Inside a group every projected block is read once per CG iteration for all its parameters (panel matvec on the matrix
- * cores), independent CG scalars per parameter.  The (<= 4) groups run on the caller's stream and the library's three side
- * streams, launches interleaved iteration by iteration: their kernels are latency-bound and share the chip (the host does
+ * cores: a 16- or 32-column panel), independent CG scalars per parameter.  The groups run on the caller's stream and the library's
+ * side streams, launches interleaved iteration by iteration: their kernels are latency-bound and share the chip (the host does
  * not thread: one call, one caller -- a ctx is not re-entrant).  One preconditioner per call: the prebuilt one
  * (lrbms_reduced_precond_use) or inverse diagonal blocks + coarse level at the mean theta of the call.
  * info[0] = iterations (of the slowest group), info[1] = worst relative residual. */

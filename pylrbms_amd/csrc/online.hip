@@ -583,6 +583,7 @@ __global__ __launch_bounds__(1024) void k_coarse_apply(int S, int N, int nmu, co
   const long NM = (long)N * nmu;
   const int nsteps = (S + 3) / 4;
   const int row = row0 + li;
+  const int col = blockIdx.y * 16 + li;                  // panels of 32 parameters: grid.y = 2, one column half each
   d4c acc = (d4c){0.0, 0.0, 0.0, 0.0};
   for (int i0 = 0; wave + 16 * i0 < nsteps; i0 += 8) {   // 8 steps = 16 loads per lane in flight (16 steps spill at 1024 threads)
     double a[8], b[8];
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(1024) void k_coarse_apply(int S, int N, int nmu, co
       const int k = 4 * (wave + 16 * (i0 + u)) + lk;
       const bool in = k < S;
       a[u] = (in && row < S) ? A0inv[(long)k * S + row] : 0.0;
-      b[u] = (in && li < nmu) ? r[(long)k * NM + li] : 0.0;
+      b[u] = (in && col < nmu) ? r[(long)k * NM + col] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
@@ -605,10 +606,10 @@ __global__ __launch_bounds__(1024) void k_coarse_apply(int S, int N, int nmu, co
 #pragma unroll
     for (int w = 0; w < 16; ++w) c += red[(w * 4 + q) * 64 + lane];
     const int s = row0 + lk + 4 * q;
-    if (s < S && li < nmu) {
-      const long g = (long)s * NM + li;
+    if (s < S && col < nmu) {
+      const long g = (long)s * NM + col;
       z[g] += c;
-      prz[(long)li * S + s] += r[g] * c;
+      prz[(long)col * S + s] += r[g] * c;
     }
   }
 }
@@ -1011,7 +1012,7 @@ int launch_coarse_apply(lrbms_ctx* ctx, int N, int nmu, const double* A0inv, con
   if (nmu == 1)
     hipLaunchKernelGGL(k_coarse_apply1, dim3((ctx->S + 3) / 4), dim3(256), 0, st, ctx->S, (long)N, A0inv, r, z, prz);
   else
-    hipLaunchKernelGGL(k_coarse_apply, dim3((ctx->S + 15) / 16), dim3(1024), 0, st, ctx->S, N, nmu, A0inv, r, z, prz);
+    hipLaunchKernelGGL(k_coarse_apply, dim3((ctx->S + 15) / 16, (nmu + 15) / 16), dim3(1024), 0, st, ctx->S, N, nmu, A0inv, r, z, prz);
   LRBMS_LAUNCH_CHECK(ctx);
   return LRBMS_OK;
 }
@@ -1453,25 +1454,29 @@ __global__ __launch_bounds__(256) void k_bcg_matvec(int S, const int* __restrict
 // (inline-asm loads, 70 per lane, consumed block by block behind exact s_waitcnt vmcnt(n)): 1 030 vs 1 190 mu-solves/s --
 // 176 VGPRs leave two workgroups per CU instead of three, and the kernel is not short of loads in flight but of
 // bandwidth: 131 MB per launch stream at 2.5 TB/s here, 3.8 TB/s is the most any kernel of this library reaches.)
+// NC = 32 (round 4): panels of 32 parameters -- every block read serves twice as many solves; eight waves: wave & 3 = row tile,
+// wave >> 2 = column half (the same per-wave work as the 16-column form, twice the waves to hide the block loads behind).
 typedef double d4m __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_bcg_matvec_mfma(int S, const int* __restrict__ nbr, int Q, int N, int nmu, ThetaBatch th,
+template <int NC>
+__global__ __launch_bounds__(16 * NC) void k_bcg_matvec_mfma(int S, const int* __restrict__ nbr, int Q, int N, int nmu, ThetaBatch th,
                                                          const double* __restrict__ B_sys, const double* __restrict__ z,
                                                          const double* __restrict__ p_old, const double* __restrict__ beta,
                                                          int first, double* __restrict__ p_out, double* __restrict__ y,
                                                          double* __restrict__ partial) {
   extern __shared__ double lds[];
+  constexpr int NTH = 16 * NC;                         // threads: 256 / 512
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int wave = tid >> 6;
+  const int wave = tid >> 6, rt = wave & 3, ch = wave >> 2;      // row tile, column half
   const int NM = N * nmu;
   const int KP = (N + 3) & ~3;                         // K padded to a multiple of 4 (zero rows / columns)
   const int LDB = N + ((4 - N % 8) + 8) % 8;           // row stride == 4 (mod 8) doubles: conflict-free A-operand reads
-  // LDS: 40 032 B at N = 40, so that FOUR workgroups fit a CU and all 1 024 of config 3 are resident at once (with the
+  // LDS (NC = 16): 40 032 B at N = 40, so that FOUR workgroups fit a CU and all 1 024 of config 3 are resident at once (with the
   // 47.6 KB of a tile-padded block and a separate product buffer only three fit: a second, third-full round of workgroups)
-  double* Pt = lds;                                    // [5][KP][16]
-  double* Bs = Pt + 5 * KP * 16;                       // [N + 1][LDB]: the block, row N stays zero (rows of a partial tile)
-  double* prod = Bs;                                   // [N][16], after the last block has been multiplied
-  for (int i = tid; i < 5 * KP * 16; i += 256) {
-    const int slot = i / (KP * 16), rem = i - slot * KP * 16, c = rem >> 4, m = rem & 15;
+  double* Pt = lds;                                    // [5][KP][NC]
+  double* Bs = Pt + 5 * KP * NC;                       // [N + 1][LDB]: the block, row N stays zero (rows of a partial tile)
+  double* prod = Bs;                                   // [N][NC], after the last block has been multiplied
+  for (int i = tid; i < 5 * KP * NC; i += NTH) {
+    const int slot = i / (KP * NC), rem = i - slot * KP * NC, c = rem / NC, m = rem % NC;
     const int s2 = nbr[s * 5 + slot];
     double v = 0.0;
     if (s2 >= 0 && c < N && m < nmu) {
@@ -1481,18 +1486,19 @@ __global__ __launch_bounds__(256) void k_bcg_matvec_mfma(int S, const int* __res
     }
     Pt[i] = v;
   }
-  for (int i = tid; i < (N + 1) * LDB; i += 256) Bs[i] = 0.0;
+  for (int i = tid; i < (N + 1) * LDB; i += NTH) Bs[i] = 0.0;
+  const int col = ch * 16 + li;                        // this lane's parameter
   double thq[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) thq[q] = li < nmu ? th.v[li * 8 + q] : 0.0;
+  for (int q = 0; q < 8; ++q) thq[q] = col < nmu ? th.v[col * 8 + q] : 0.0;
   // block list of this subdomain: (slot, q) for every existing neighbour slot; register prefetch of the next block
-  constexpr int PF = 16;                               // N * N <= 4096 = 256 threads x 16
+  constexpr int PF = 4096 / NTH;                       // N * N <= 4096 = NTH threads x PF
   double pf[PF];
   auto load_block = [&](int slot, int q) {
     const double* B = B_sys + ((((long)q * S + s) * 5 + slot) * N) * N;
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
-      const int i = tid + 256 * k;
+      const int i = tid + NTH * k;
       pf[k] = i < N * N ? B[i] : 0.0;
     }
   };
@@ -1501,28 +1507,28 @@ __global__ __launch_bounds__(256) void k_bcg_matvec_mfma(int S, const int* __res
     if (nbr[s * 5 + slot] >= 0) slots[ns++] = slot;
   const int nblk = ns * Q;
   d4m acc = (d4m){0.0, 0.0, 0.0, 0.0};
-  const bool active = wave * 16 < N;                   // this wave's row tile exists
+  const bool active = rt * 16 < N;                     // this wave's row tile exists
   if (nblk > 0) load_block(slots[0], 0);
   for (int b = 0; b < nblk; ++b) {
     const int slot = slots[b / Q], q = b - (b / Q) * Q;
     __syncthreads();                                   // previous block's MFMAs are done reading Bs (and Pt is complete)
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
-      const int i = tid + 256 * k;
+      const int i = tid + NTH * k;
       if (i < N * N) Bs[(i / N) * LDB + i % N] = pf[k];
     }
     if (b + 1 < nblk) load_block(slots[(b + 1) / Q], (b + 1) - ((b + 1) / Q) * Q);
     __syncthreads();
     if (active) {
-      const double* pslot = Pt + slot * KP * 16;
+      const double* pslot = Pt + slot * KP * NC;
       double thv = thq[0];
 #pragma unroll
       for (int qq = 1; qq < 8; ++qq)
         if (q == qq) thv = thq[qq];
-      const int ra = wave * 16 + li < N ? wave * 16 + li : N;
+      const int ra = rt * 16 + li < N ? rt * 16 + li : N;
       for (int kk = 0; kk < KP; kk += 4) {
         const double a = Bs[ra * LDB + kk + lk];
-        const double bv = thv * pslot[(kk + lk) * 16 + li];
+        const double bv = thv * pslot[(kk + lk) * NC + col];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
       }
     }
@@ -1531,16 +1537,16 @@ __global__ __launch_bounds__(256) void k_bcg_matvec_mfma(int S, const int* __res
   // D layout: lane holds rows lk + 4 r of its tile, column li
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = wave * 16 + lk + 4 * r;
-    if (active && row < N && li < nmu) {
-      y[(long)s * NM + row * nmu + li] = acc[r];
-      prod[row * 16 + li] = acc[r] * Pt[2 * KP * 16 + row * 16 + li];
+    const int row = rt * 16 + lk + 4 * r;
+    if (active && row < N && col < nmu) {
+      y[(long)s * NM + row * nmu + col] = acc[r];
+      prod[row * NC + col] = acc[r] * Pt[2 * KP * NC + row * NC + col];
     }
   }
   __syncthreads();
   if (tid < nmu) {
     double sum = 0.0;
-    for (int r = 0; r < N; ++r) sum += prod[r * 16 + tid];
+    for (int r = 0; r < N; ++r) sum += prod[r * NC + tid];
     partial[(long)tid * gridDim.x + s] = sum;          // [m][S]: the reduce reads contiguous runs
   }
 }
@@ -1628,44 +1634,47 @@ __global__ __launch_bounds__(256) void k_bcg_update(int N, int nmu, const double
 
 // The same update with z = Dinv r as a 16-column MFMA product (batches of at most 16 parameters): wave w owns row tile w,
 // the inverse diagonal block is the A operand straight from global memory, r (padded to 16 columns) the B operand in LDS.
-__global__ __launch_bounds__(256) void k_bcg_update_mfma(int N, int nmu, const double* __restrict__ Dinv, const double* __restrict__ scal,
+template <int NC>
+__global__ __launch_bounds__(16 * NC) void k_bcg_update_mfma(int N, int nmu, const double* __restrict__ Dinv, const double* __restrict__ scal,
                                                          int first, double* __restrict__ x, double* __restrict__ r,
                                                          const double* __restrict__ p, const double* __restrict__ y,
                                                          double* __restrict__ z, double* __restrict__ partial,
                                                          double* __restrict__ partial2) {
   extern __shared__ double lds[];
+  constexpr int NTH = 16 * NC;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4, wave = tid >> 6;
+  const int rt = wave & 3, col = (wave >> 2) * 16 + li;      // row tile, this lane's parameter
   const int NM = N * nmu, KP = (N + 3) & ~3;
-  double* rs = lds;              // [KP][16]  (columns >= nmu and rows >= N zero)
-  double* prod = rs + KP * 16;   // [2][N][16]
-  for (int i = tid; i < KP * 16; i += 256) rs[i] = 0.0;
+  double* rs = lds;              // [KP][NC]  (columns >= nmu and rows >= N zero)
+  double* prod = rs + KP * NC;   // [2][N][NC]
+  for (int i = tid; i < KP * NC; i += NTH) rs[i] = 0.0;
   __syncthreads();
-  for (int i = tid; i < NM; i += 256) {
+  for (int i = tid; i < NM; i += NTH) {
     const long g = (long)s * NM + i;
     const int row = i / nmu, m = i - row * nmu;
     const double alpha = first ? 0.0 : scal[BMAX + m];
     if (!first) x[g] += alpha * p[g];
     const double rv = first ? r[g] : r[g] - alpha * y[g];
     r[g] = rv;
-    rs[row * 16 + m] = rv;
+    rs[row * NC + m] = rv;
   }
   __syncthreads();
-  if (wave * 16 < N) {
-    const int ra = wave * 16 + li < N ? wave * 16 + li : N - 1;
+  if (rt * 16 < N) {
+    const int ra = rt * 16 + li < N ? rt * 16 + li : N - 1;
     const double* D = Dinv + ((long)s * N + ra) * N;
     d4m T = (d4m){0.0, 0.0, 0.0, 0.0};
     for (int kk = 0; kk < KP; kk += 4) {
       const bool in = kk + lk < N;
-      T = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? D[kk + lk] : 0.0, rs[(kk + lk) * 16 + li], T, 0, 0, 0);
+      T = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? D[kk + lk] : 0.0, rs[(kk + lk) * NC + col], T, 0, 0, 0);
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const int row = wave * 16 + lk + 4 * rr;
+      const int row = rt * 16 + lk + 4 * rr;
       if (row < N) {
-        const double rv = rs[row * 16 + li];
-        if (li < nmu) z[(long)s * NM + row * nmu + li] = T[rr];
-        prod[row * 16 + li] = T[rr] * rv;
-        prod[(N + row) * 16 + li] = rv * rv;
+        const double rv = rs[row * NC + col];
+        if (col < nmu) z[(long)s * NM + row * nmu + col] = T[rr];
+        prod[row * NC + col] = T[rr] * rv;
+        prod[(N + row) * NC + col] = rv * rv;
       }
     }
   }
@@ -1673,8 +1682,8 @@ __global__ __launch_bounds__(256) void k_bcg_update_mfma(int N, int nmu, const d
   if (tid < nmu) {
     double a = 0.0, b = 0.0;
     for (int row = 0; row < N; ++row) {
-      a += prod[row * 16 + tid];
-      b += prod[(N + row) * 16 + tid];
+      a += prod[row * NC + tid];
+      b += prod[(N + row) * NC + tid];
     }
     partial[(long)tid * gridDim.x + s] = a;
     partial2[(long)tid * gridDim.x + s] = b;
@@ -1693,11 +1702,15 @@ __global__ __launch_bounds__(256) void k_bcg_init(long total, int nmu, const dou
 
 // doubles of work per group of <= 16 parameters of the batched reduced solve: u (groups of a multi-group call solve into their
 // own [S][N][nm] array), r, z, p0, p1, y, two partial arrays, scalars
-static long reduced_batch_group_size(long S, int N) { return 6 * S * N * 16 + 2 * S * 16 + 4 * BMAX; }
+// (sized for the widest group, 32 parameters)
+static long reduced_batch_group_size(long S, int N) { return 6 * S * N * BMAX + 2 * S * BMAX + 4 * BMAX; }
+// parameters per group (= columns of the MFMA panel): calls of more than 16 parameters run panels of 32 -- every projected block
+// streamed by the panel matvec then serves 32 solves -- unless the VALU cross-check form is asked for (its kernels hold <= 16)
+static int reduced_batch_group_width(const lrbms_ctx* ctx, int nmu) { return (nmu > 16 && ctx->opt_solve_valu == 0) ? 32 : 16; }
 
 int64_t reduced_solve_batch_work_size(lrbms_ctx* ctx, int N, int nmu) {
   const long S = ctx->S;
-  return S * 5 * N * N + S * N * N + (long)((nmu + 15) / 16) * reduced_batch_group_size(S, N) + 16;
+  return S * 5 * N * N + S * N * N + (long)((nmu + 15) / 16) * reduced_batch_group_size(S, N) + 16;      // (room for either width)
 }
 
 namespace {
@@ -1719,7 +1732,8 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   if (N > 64 || nmu < 1 || nmu > 64)
     return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve_batch: need N <= 64, nmu <= 64");
   const int S = ctx->S;
-  const int ng = (nmu + 15) / 16;
+  const int GW = reduced_batch_group_width(ctx, nmu);
+  const int ng = (nmu + GW - 1) / GW;
   const long per_q = (long)S * 5 * N * N;
   QVec mean;
   for (int q = 0; q < 8; ++q) mean.v[q] = 0.0;
@@ -1735,12 +1749,12 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
     double *ug, *r, *z, *pin, *pout, *y, *partial, *partial2, *scal;
     hipStream_t st;
     bool done;
-    double rel, rr0[16];
+    double rel, rr0[BMAX];
   } g[4];
   for (int k = 0; k < ng; ++k) {
     Group& G = g[k];
-    G.m0 = 16 * k;
-    G.nm = nmu - G.m0 < 16 ? nmu - G.m0 : 16;
+    G.m0 = GW * k;
+    G.nm = nmu - G.m0 < GW ? nmu - G.m0 : GW;
     G.st = k == 0 ? st : ctx->aux[k - 1];
     G.it = 0;
     G.done = false;
@@ -1748,14 +1762,14 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
     const long vec = (long)S * N * G.nm;
     double* w = gwork + k * gsize;
     G.ug = ng == 1 ? u : w;                             // a single group solves straight into the caller's array
-    G.r = w + (long)S * N * 16;
+    G.r = w + (long)S * N * BMAX;
     G.z = G.r + vec;
     G.pin = G.z + vec;
     G.pout = G.pin + vec;
     G.y = G.pout + vec;
-    G.partial = w + 6L * S * N * 16;
-    G.partial2 = G.partial + (long)S * 16;
-    G.scal = G.partial2 + (long)S * 16;                 // rz, alpha, beta, rr (BMAX each)
+    G.partial = w + 6L * S * N * BMAX;
+    G.partial2 = G.partial + (long)S * BMAX;
+    G.scal = G.partial2 + (long)S * BMAX;               // rz, alpha, beta, rr (BMAX each)
     for (int m = 0; m < BMAX; ++m)
       for (int q = 0; q < 8; ++q) G.th.v[m * 8 + q] = (m < G.nm && q < Q) ? theta[(G.m0 + m) * Q + q] : 0.0;
   }
@@ -1775,14 +1789,20 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   // matrix-core form of the panel matvec and of the preconditioner (LRBMS_OPT_SOLVE_VALU forces the VALU form)
   const int kp = (N + 3) & ~3, ldb = N + ((4 - N % 8) + 8) % 8;
   const size_t bs_lds = (size_t)(N + 1) * ldb > (size_t)N * 16 ? (size_t)(N + 1) * ldb : (size_t)N * 16;   // block, later the products
-  const size_t lds_mfma = sizeof(double) * ((size_t)5 * kp * 16 + bs_lds);
+  const size_t bs_lds_w = (size_t)(N + 1) * ldb > (size_t)N * GW ? (size_t)(N + 1) * ldb : (size_t)N * GW;
+  const size_t lds_mfma = sizeof(double) * ((size_t)5 * kp * GW + (GW == 16 ? bs_lds : bs_lds_w));
   const bool use_mfma = ctx->opt_solve_valu == 0;
-  if (use_mfma && lds_mfma > 64 * 1024)
-    LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
+  if (use_mfma && lds_mfma > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve_batch: panels exceed the LDS");
+  if (use_mfma && lds_mfma > 64 * 1024) {
+    if (GW == 16)
+      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_mfma<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
+    else
+      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_mfma<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
+  }
   const size_t lds_mv = sizeof(double) * (5 * (size_t)N * 16 + (size_t)N * N + 256);
   if (!use_mfma && lds_mv > 64 * 1024)
     LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec<BCG_KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mv));
-  const size_t lds_upd_mfma = sizeof(double) * ((size_t)kp * 16 + (size_t)2 * N * 16);
+  const size_t lds_upd_mfma = sizeof(double) * ((size_t)kp * GW + (size_t)2 * N * GW);
   if (ng > 1) {
     LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
     for (int k = 1; k < ng; ++k) LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(g[k].st, ctx->ev_fork, 0));
@@ -1796,13 +1816,16 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   };
   auto update = [&](Group& G, int first) {
     const size_t lds_upd = sizeof(double) * 3 * (size_t)N * G.nm;
-    if (use_mfma)
-      hipLaunchKernelGGL(k_bcg_update_mfma, dim3(S), dim3(256), lds_upd_mfma, G.st, N, G.nm, Dinv, G.scal, first, G.ug, G.r,
+    if (use_mfma && GW == 32)
+      hipLaunchKernelGGL(k_bcg_update_mfma<32>, dim3(S), dim3(512), lds_upd_mfma, G.st, N, G.nm, Dinv, G.scal, first, G.ug, G.r,
+                         first ? G.pin : G.pout, G.y, G.z, G.partial, G.partial2);
+    else if (use_mfma)
+      hipLaunchKernelGGL(k_bcg_update_mfma<16>, dim3(S), dim3(256), lds_upd_mfma, G.st, N, G.nm, Dinv, G.scal, first, G.ug, G.r,
                          first ? G.pin : G.pout, G.y, G.z, G.partial, G.partial2);
     else
       hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, G.st, N, G.nm, Dinv, G.scal, first, G.ug, G.r,
                          first ? G.pin : G.pout, G.y, G.z, G.partial, G.partial2);
-    if (A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16), dim3(1024), 0, G.st, S, N, G.nm, A0inv, G.r, G.z, G.partial);
+    if (A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16, (G.nm + 15) / 16), dim3(1024), 0, G.st, S, N, G.nm, A0inv, G.r, G.z, G.partial);
     hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, G.st, S, G.nm, G.partial, G.partial2, G.scal, first ? 0 : 2);
   };
   double host[4][4 * BMAX];
@@ -1836,8 +1859,11 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
         if (G.done || G.it >= max_iter) continue;
         const int first = G.it == 0 ? 1 : 0;
         const long NM = (long)N * G.nm;
-        if (use_mfma)
-          hipLaunchKernelGGL(k_bcg_matvec_mfma, dim3(S), dim3(256), lds_mfma, G.st, S, ctx->nbr, Q, N, G.nm, G.th, B_sys, G.z, G.pin,
+        if (use_mfma && GW == 32)
+          hipLaunchKernelGGL(k_bcg_matvec_mfma<32>, dim3(S), dim3(512), lds_mfma, G.st, S, ctx->nbr, Q, N, G.nm, G.th, B_sys, G.z, G.pin,
+                             G.scal + 2 * BMAX, first, G.pout, G.y, G.partial);
+        else if (use_mfma)
+          hipLaunchKernelGGL(k_bcg_matvec_mfma<16>, dim3(S), dim3(256), lds_mfma, G.st, S, ctx->nbr, Q, N, G.nm, G.th, B_sys, G.z, G.pin,
                              G.scal + 2 * BMAX, first, G.pout, G.y, G.partial);
         else if (NM <= 768)   // three outputs per thread: fewer registers, measurably faster for the usual batch of 16
           hipLaunchKernelGGL(k_bcg_matvec<3>, dim3(S), dim3(256), lds_mv, G.st, S, ctx->nbr, Q, N, G.nm, G.th, B_sys, G.z, G.pin,
