@@ -1366,10 +1366,11 @@ int launch_reduced_reconstruction_terms(lrbms_ctx* ctx, int Q, int N, int L, con
 // Vectors are [S][N][nmu] (mu fastest); all reductions are fixed-order (per-subdomain partials + one-workgroup sum).
 namespace {
 
-constexpr int BMAX = 32;   // max parameters per batch
+constexpr int BMAX = 64;   // max parameters per group of the batched solve (stride of its scalar arrays)
+constexpr int TBMAX = 32;  // parameters a by-value ThetaBatch holds (the VALU cross-check kernels and the estimate passes use <= 16)
 constexpr int BCG_KMAX = 5;   // outputs per thread of the batched matvec: N * nmu <= 256 * BCG_KMAX = 1280
 
-struct ThetaBatch { double v[BMAX * 8]; };   // theta[m][q], q < 8
+struct ThetaBatch { double v[TBMAX * 8]; };   // theta[m][q], q < 8
 
 // direction + matvec:  p_new = z + beta p_old (own + neighbour rows, into LDS; own rows written to p_out),
 // y_s = sum_slot sum_q theta_q B_q[s][slot] p_new[nbr(s, slot)],  partial[s][m] = p_new_s . y_s
@@ -1457,6 +1458,9 @@ __global__ __launch_bounds__(256) void k_bcg_matvec(int S, const int* __restrict
 // NC = 32 (round 4): panels of 32 parameters -- every block read serves twice as many solves; eight waves: wave & 3 = row tile,
 // wave >> 2 = column half (the same per-wave work as the 16-column form, twice the waves to hide the block loads behind).
 typedef double d4m __attribute__((ext_vector_type(4)));
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt(0), i.e. it waits for the block loads just
+// requested for the NEXT step -- the prefetch would overlap with nothing (the same idiom as lds_barrier in fused.hip).
+__device__ inline void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int NC>
 __global__ __launch_bounds__(16 * NC) void k_bcg_matvec_mfma(int S, const int* __restrict__ nbr, int Q, int N, int nmu, ThetaBatch th,
                                                          const double* __restrict__ B_sys, const double* __restrict__ z,
@@ -1551,12 +1555,175 @@ __global__ __launch_bounds__(16 * NC) void k_bcg_matvec_mfma(int S, const int* _
   }
 }
 
+// Round 4: the panel matvec for panels of 32 and 64 parameters.
+// The 16-column kernel above keeps the direction panels of all five slots in LDS (40 KB at N = 40); at 32 columns that is 65 KB
+// per workgroup, two workgroups per CU with ONE 12.8 KB block in flight each, and the kernel got slower per block than it gained
+// per parameter (72 us for 32 columns against 40 us for 16: 1.8 TB/s).  Here a wave owns (row tile rt, column tile ch); the
+// direction panel of ONE slot at a time is staged in LDS ([N][NC], two copies: the next slot's rows are requested with contiguous
+// loads -- z + beta p_old, N nmu consecutive doubles -- at the first block of the current slot and parked after its MFMAs), every
+// wave takes its B operand P_slot[k][its 16 columns] into KP / 4 registers once per slot, and two copies of the current block
+// give ONE barrier per block.  69 KB of LDS at N = 40 and 64 columns: two workgroups of 16 waves per CU.  Every projected block
+// then serves 64 solves per read instead of 16.  theta comes from device memory (a by-value table of 64 x 8 doubles would fill
+// the kernel arguments).  (First attempt, dropped: the B operands straight from global memory into registers, one slot ahead --
+// 2 x 3 x KP / 4 registers per lane; 217 VGPRs, or spills under the 128 of a 1 024-thread workgroup: 382 us per launch.)
+template <int NC, int KSC>      // KSC: k-steps compiled in (4, 8, 10, 12, 16 for N <= 16, 32, 40, 48, 64)
+__global__ __launch_bounds__(16 * NC) void k_bcg_matvec_panel(int S, const int* __restrict__ nbr, int Q, int N, int nmu,
+                                                              const double* __restrict__ theta,      // [nmu][8] device
+                                                              const double* __restrict__ B_sys, const double* __restrict__ z,
+                                                              const double* __restrict__ p_old, const double* __restrict__ beta,
+                                                              int first, double* __restrict__ p_out, double* __restrict__ y,
+                                                              double* __restrict__ partial) {
+  extern __shared__ double lds[];
+  constexpr int NTH = 16 * NC;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), rt = wave & 3, ch = wave >> 2, col = ch * 16 + li;
+  const int NM = N * nmu;
+  const int LDB = N + ((4 - N % 8) + 8) % 8;           // row stride == 4 (mod 8) doubles: conflict-free A-operand reads
+  const int BSZ = (N + 1) * LDB + 16;                  // (+ 16: the k-steps beyond N of the last row read zeros, not the other copy)
+  const int PSZ = 4 * KSC * NC;                        // one direction panel [4 KSC][NC]: rows >= N and columns >= nmu stay zero
+  double* Bs = lds;                                    // [2][N + 1][LDB]: row N and the columns >= N stay zero
+  double* Ps = Bs + 2 * BSZ;                           // [2][4 KSC][NC]
+  double* bl = Ps + 2 * PSZ;                           // [NC] beta | [4][NC] theta_q (Q <= 4 with the wide panels: checked by the launcher)
+  double* tl = bl + NC;                                // | one dump slot (entries beyond the block / the panel)
+  const int DUMP = 2 * BSZ + 2 * PSZ + 5 * NC;
+  for (int i = tid; i < 2 * BSZ + 2 * PSZ; i += NTH) lds[i] = 0.0;
+  if (tid < NC) bl[tid] = (tid < nmu && !first) ? beta[tid] : 0.0;
+  // (theta through LDS, not registers loaded in front of the loop: hipcc's wait-count state at the loop header keeps a load that was
+  // never waited for on the entry path "pending" in every iteration, i.e. a vmcnt(0) in front of its first use -- behind the prefetch)
+  for (int i = tid; i < 4 * NC; i += NTH) tl[i] = (i % NC < nmu) ? theta[(i % NC) * 8 + i / NC] : 0.0;
+  const bool live = col < nmu;
+  constexpr int PF = (16 * KSC * KSC + NTH - 1) / NTH; // N * N <= (4 KSC)^2 <= NTH threads x PF
+  constexpr int PP = (4 * KSC * NC + NTH - 1) / NTH;   // N nmu <= 4 KSC NC <= NTH threads x PP
+  double pf[PF];
+  // LDS offset of this thread's k-th block entry (divisions once); entries beyond the block go to a dump slot UNCONDITIONALLY: a
+  // store under a condition leaves a path without the wait for its load, and hipcc then guards the registers' reuse in the next
+  // step with waits that also cover the loads just issued (seen in the ISA: vmcnt(0) behind every prefetch)
+  int boff[PF];
+#pragma unroll
+  for (int k = 0; k < PF; ++k) {
+    const int i = tid + NTH * k;
+    boff[k] = i < N * N ? (i / N) * LDB + i % N : -1;
+  }
+  auto load_block = [&](int slot, int q) {             // unconditional loads (clamped index): a conditional one compiles to a branch with a wait
+    const double* B = B_sys + ((((long)q * S + s) * 5 + slot) * N) * N;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int i = tid + NTH * k;
+      pf[k] = B[i < N * N ? i : N * N - 1];
+    }
+  };
+  // rows of the direction panel of a slot: element e = c nmu + m of the neighbour's [N][nmu] array, NM consecutive doubles
+  double zz[PP], pp[PP];
+  int poff[PP], pm[PP];                                // LDS offset c NC + m and column m of this thread's k-th panel entry (-1 beyond)
+#pragma unroll
+  for (int k = 0; k < PP; ++k) {
+    const int e = tid + NTH * k, c = e / nmu;
+    pm[k] = e < NM ? e - c * nmu : 0;
+    poff[k] = e < NM ? c * NC + pm[k] : -1;
+  }
+  // neighbour table row and the list of existing slots: wave-uniform scalars read ONCE (a vector load of nbr inside the block loop
+  // would wait, in order, for every block load in flight), the list packed four bits per entry (no dynamically indexed array)
+  const int nb0 = __builtin_amdgcn_readfirstlane(nbr[s * 5]), nb1 = __builtin_amdgcn_readfirstlane(nbr[s * 5 + 1]),
+            nb3 = __builtin_amdgcn_readfirstlane(nbr[s * 5 + 3]), nb4 = __builtin_amdgcn_readfirstlane(nbr[s * 5 + 4]);
+  auto nb_of = [&](int slot) { return slot == 0 ? nb0 : slot == 1 ? nb1 : slot == 2 ? s : slot == 3 ? nb3 : nb4; };
+  int ns = 0, packed = 0;
+#pragma unroll
+  for (int slot = 0; slot < 5; ++slot)
+    if (nb_of(slot) >= 0) packed |= slot << (4 * ns), ++ns;
+  auto slot_at = [&](int i) { return (packed >> (4 * i)) & 7; };
+  auto request_panel = [&](int slot) {
+    const long base = (long)nb_of(slot) * NM;
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      const int e = tid + NTH * k;
+      zz[k] = (z + base)[e < NM ? e : NM - 1];
+      pp[k] = (p_old + base)[e < NM ? e : NM - 1];     // (first: an allocated but unwritten array; the value is dropped)
+    }
+  };
+  auto park_panel = [&](double* dst) {
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      const double v = first ? zz[k] : zz[k] + bl[pm[k]] * pp[k];
+      (poff[k] >= 0 ? dst + poff[k] : lds + DUMP)[0] = v;
+    }
+  };
+  const int nblk = ns * Q;
+  d4m acc = (d4m){0.0, 0.0, 0.0, 0.0};
+  const bool active = rt * 16 < N;                     // this wave's row tile exists
+  double pv[KSC], pown[4] = {0.0, 0.0, 0.0, 0.0};
+  __syncthreads();                                     // the zeros and beta are in place
+  if (nblk > 0) {
+    load_block(slot_at(0), 0);
+    request_panel(slot_at(0));
+    park_panel(Ps);
+  }
+  int si = 0, q = 0, slot = nblk > 0 ? slot_at(0) : 2;
+  for (int b = 0; b < nblk; ++b) {
+    double* Bc = Bs + (b & 1) * BSZ;
+    // (the previous reader of this copy was block b - 2: every wave finished it before it arrived at the barrier of block b - 1)
+#pragma unroll
+    for (int k = 0; k < PF; ++k) lds[boff[k] >= 0 ? (b & 1) * BSZ + boff[k] : DUMP] = pf[k];
+    const int qn = q + 1 < Q ? q + 1 : 0, sin = q + 1 < Q ? si : si + 1;
+    const int slotn = sin < ns ? slot_at(sin) : slot;
+    const bool newslot = q == 0, stage = newslot && si + 1 < ns;
+    const int slot_next = stage ? slot_at(si + 1) : slot;
+    // the next slot's panel rows are requested IN FRONT of the next block: hipcc guards the reuse of the zz / pp registers with
+    // waits that cover every load issued before them (seen in the ISA: vmcnt(0) right behind the block prefetch, which then
+    // overlapped with nothing); in this order those waits see no block load, and parking the rows later needs vmcnt(PF) only
+    if (stage) request_panel(slot_next);               // lands during the MFMAs below
+    if (b + 1 < nblk) load_block(slotn, qn);
+    lds_only_barrier();                                // this block and (first block of a slot) its direction panel are complete
+    if (newslot) {
+      const double* Pc = Ps + (si & 1) * PSZ + lk * NC + col;
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) pv[ks] = Pc[4 * ks * NC];
+      if (slot == 2) {                                 // the own rows of this lane's D elements: P[rt 16 + lk + 4 r][col] = pv[4 rt + r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4)
+            if (4 * t4 + r < KSC && rt == t4) pown[r] = pv[4 * t4 + r];
+      }
+    }
+    if (active) {
+      const double thv = tl[q * NC + col];
+      const double* arow = Bc + (rt * 16 + li < N ? rt * 16 + li : N) * LDB + lk;
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * ks], thv * pv[ks], acc, 0, 0, 0);
+    }
+    // (the other panel copy was last read at the first block of slot si - 1, in front of the barrier every wave has passed since)
+    if (stage) park_panel(Ps + ((si + 1) & 1) * PSZ);
+    q = qn, si = sin, slot = slotn;
+  }
+  __syncthreads();                                     // all reads of Bs are done: it becomes the reduction buffer [4][NC]
+  // D layout: lane holds rows rt 16 + lk + 4 r, column col.  p . A p per column: rows of this lane, the four lk groups of the wave
+  // (shuffles), the four row-tile waves (LDS) -- a fixed order
+  double dot = 0.0;
+  {
+    const long base = (long)s * NM;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rt * 16 + lk + 4 * r;
+      if (active && live && row < N) {
+        (y + base)[row * nmu + col] = acc[r];
+        (p_out + base)[row * nmu + col] = pown[r];       // the new direction of the own slot (the rows this lane took from its panel)
+        dot += acc[r] * pown[r];
+      }
+    }
+  }
+  dot += __shfl_xor(dot, 16, 64);
+  dot += __shfl_xor(dot, 32, 64);
+  if (lk == 0) lds[rt * NC + col] = dot;
+  __syncthreads();
+  if (tid < nmu) partial[(long)tid * gridDim.x + s] = ((lds[tid] + lds[NC + tid]) + lds[2 * NC + tid]) + lds[3 * NC + tid];      // [m][S]
+}
+
 // out[m] = sum_s partial[s][m]; mode 1: pAp -> alpha = rz / pAp; mode 2: rz_new -> beta = rz_new / rz, rz = rz_new;
 // mode 0: rz (initial).  scal layout: rz [BMAX], alpha [BMAX], beta [BMAX], rr [BMAX]
 __global__ __launch_bounds__(1024) void k_bcg_reduce(int S, int nmu, const double* __restrict__ partial,
                                                      const double* __restrict__ partial2, double* __restrict__ scal, int mode) {
-  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  for (int m = threadIdx.x >> 6; m < nmu; m += nw) {       // wave m sums parameter m: lane-strided, then a fixed shuffle tree
+  const int lane = threadIdx.x & 63, nw = (blockDim.x >> 6) * gridDim.x;      // (grid: one workgroup of 16 waves per 16 parameters)
+  for (int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); m < nmu; m += nw) {       // wave m sums parameter m: lane-strided, then a fixed shuffle tree
     double a = 0.0, b = 0.0;
     // all loads of a 1024-entry chunk are issued before the first add (an `a += partial[i]` loop waits one L2 round
     // trip per entry: this single-workgroup kernel took 7.6 us, 19 % of an iteration of the batched solve)
@@ -1702,15 +1869,21 @@ __global__ __launch_bounds__(256) void k_bcg_init(long total, int nmu, const dou
 
 // doubles of work per group of <= 16 parameters of the batched reduced solve: u (groups of a multi-group call solve into their
 // own [S][N][nm] array), r, z, p0, p1, y, two partial arrays, scalars
-// (sized for the widest group, 32 parameters)
-static long reduced_batch_group_size(long S, int N) { return 6 * S * N * BMAX + 2 * S * BMAX + 4 * BMAX; }
+// (sized for the widest group, 64 parameters)
+static long reduced_batch_group_size(long S, int N, int W) { return 6 * S * N * W + 2 * S * W + 4 * BMAX + 8 * BMAX; }
 // parameters per group (= columns of the MFMA panel): calls of more than 16 parameters run panels of 32 -- every projected block
 // streamed by the panel matvec then serves 32 solves -- unless the VALU cross-check form is asked for (its kernels hold <= 16)
-static int reduced_batch_group_width(const lrbms_ctx* ctx, int nmu) { return (nmu > 16 && ctx->opt_solve_valu == 0) ? 32 : 16; }
+static int reduced_batch_group_width(const lrbms_ctx* ctx, int nmu) {
+  if (ctx->opt_solve_valu != 0 || nmu <= 16) return 16;
+  return nmu <= 32 ? 32 : 64;
+}
 
 int64_t reduced_solve_batch_work_size(lrbms_ctx* ctx, int N, int nmu) {
   const long S = ctx->S;
-  return S * 5 * N * N + S * N * N + (long)((nmu + 15) / 16) * reduced_batch_group_size(S, N) + 16;      // (room for either width)
+  // room for either grouping of the call: panels of 16 (LRBMS_OPT_SOLVE_VALU, nmu <= 16) or the width reduced_batch_group_width picks
+  const int W = nmu <= 16 ? 16 : nmu <= 32 ? 32 : 64;
+  const long a = (long)((nmu + 15) / 16) * reduced_batch_group_size(S, N, 16), b = (long)((nmu + W - 1) / W) * reduced_batch_group_size(S, N, W);
+  return S * 5 * N * N + S * N * N + (a > b ? a : b) + 16;
 }
 
 namespace {
@@ -1742,11 +1915,12 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   double* Amu = work;                                   // blocks at the mean theta of the call (only the diagonal is inverted)
   double* Dinv = Amu + per_q;
   double* gwork = Dinv + (long)S * N * N;
-  const long gsize = reduced_batch_group_size(S, N);
+  const long gsize = reduced_batch_group_size(S, N, GW);
   struct Group {
     int nm, m0, it;
     ThetaBatch th;
-    double *ug, *r, *z, *pin, *pout, *y, *partial, *partial2, *scal;
+    double thd[BMAX * 8];                               // theta [m][8] of the group, copied to the device for the wide panels
+    double *ug, *r, *z, *pin, *pout, *y, *partial, *partial2, *scal, *theta_dev;
     hipStream_t st;
     bool done;
     double rel, rr0[BMAX];
@@ -1762,16 +1936,19 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
     const long vec = (long)S * N * G.nm;
     double* w = gwork + k * gsize;
     G.ug = ng == 1 ? u : w;                             // a single group solves straight into the caller's array
-    G.r = w + (long)S * N * BMAX;
+    G.r = w + (long)S * N * GW;
     G.z = G.r + vec;
     G.pin = G.z + vec;
     G.pout = G.pin + vec;
     G.y = G.pout + vec;
-    G.partial = w + 6L * S * N * BMAX;
-    G.partial2 = G.partial + (long)S * BMAX;
-    G.scal = G.partial2 + (long)S * BMAX;               // rz, alpha, beta, rr (BMAX each)
-    for (int m = 0; m < BMAX; ++m)
+    G.partial = w + 6L * S * N * GW;
+    G.partial2 = G.partial + (long)S * GW;
+    G.scal = G.partial2 + (long)S * GW;                 // rz, alpha, beta, rr (BMAX each)
+    G.theta_dev = G.scal + 4 * BMAX;                    // [BMAX][8]
+    for (int m = 0; m < TBMAX; ++m)
       for (int q = 0; q < 8; ++q) G.th.v[m * 8 + q] = (m < G.nm && q < Q) ? theta[(G.m0 + m) * Q + q] : 0.0;
+    for (int m = 0; m < BMAX; ++m)
+      for (int q = 0; q < 8; ++q) G.thd[m * 8 + q] = (m < G.nm && q < Q) ? theta[(G.m0 + m) * Q + q] : 0.0;
   }
   // ---- the preconditioner of the call, on the caller's stream, before the groups fork
   const double* A0inv = nullptr;
@@ -1789,20 +1966,42 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   // matrix-core form of the panel matvec and of the preconditioner (LRBMS_OPT_SOLVE_VALU forces the VALU form)
   const int kp = (N + 3) & ~3, ldb = N + ((4 - N % 8) + 8) % 8;
   const size_t bs_lds = (size_t)(N + 1) * ldb > (size_t)N * 16 ? (size_t)(N + 1) * ldb : (size_t)N * 16;   // block, later the products
-  const size_t bs_lds_w = (size_t)(N + 1) * ldb > (size_t)N * GW ? (size_t)(N + 1) * ldb : (size_t)N * GW;
-  const size_t lds_mfma = sizeof(double) * ((size_t)5 * kp * GW + (GW == 16 ? bs_lds : bs_lds_w));
+  // panels of 16: the direction panels of the five slots in LDS (k_bcg_matvec_mfma); wider panels: in registers, two copies of
+  // the current block in LDS (k_bcg_matvec_panel)
+  const int ksc_n = N <= 16 ? 4 : N <= 32 ? 8 : N <= 40 ? 10 : N <= 48 ? 12 : 16;      // k-steps compiled into k_bcg_matvec_panel
+  const size_t lds_panel = sizeof(double) * (2 * ((size_t)(N + 1) * ldb + 16) + 2 * (size_t)4 * ksc_n * GW + 5 * GW + 1);
+  if (GW > 16 && Q > 4) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve_batch: more than 16 parameters per call need Q <= 4");
+  const size_t lds_mfma = GW == 16 ? sizeof(double) * ((size_t)5 * kp * 16 + bs_lds) : lds_panel;
   const bool use_mfma = ctx->opt_solve_valu == 0;
   if (use_mfma && lds_mfma > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_solve_batch: panels exceed the LDS");
+#define LRBMS_PANEL_DISPATCH(X)                                                                                    \
+  do {                                                                                                             \
+    if (GW == 64) {                                                                                                \
+      if (ksc_n == 4) X(64, 4); else if (ksc_n == 8) X(64, 8); else if (ksc_n == 10) X(64, 10); else if (ksc_n == 12) X(64, 12); else X(64, 16); \
+    } else {                                                                                                       \
+      if (ksc_n == 4) X(32, 4); else if (ksc_n == 8) X(32, 8); else if (ksc_n == 10) X(32, 10); else if (ksc_n == 12) X(32, 12); else X(32, 16); \
+    }                                                                                                              \
+  } while (0)
   if (use_mfma && lds_mfma > 64 * 1024) {
-    if (GW == 16)
+    if (GW == 16) {
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_mfma<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
-    else
-      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_mfma<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
+    } else {
+#define LRBMS_PANEL_ATTR(NCV, KSV) \
+  LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_panel<NCV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma))
+      LRBMS_PANEL_DISPATCH(LRBMS_PANEL_ATTR);
+#undef LRBMS_PANEL_ATTR
+    }
   }
   const size_t lds_mv = sizeof(double) * (5 * (size_t)N * 16 + (size_t)N * N + 256);
   if (!use_mfma && lds_mv > 64 * 1024)
     LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec<BCG_KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mv));
   const size_t lds_upd_mfma = sizeof(double) * ((size_t)kp * GW + (size_t)2 * N * GW);
+  if (use_mfma && lds_upd_mfma > 64 * 1024) {
+    if (GW == 64)
+      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_update_mfma<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd_mfma));
+    else
+      LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_update_mfma<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd_mfma));
+  }
   if (ng > 1) {
     LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
     for (int k = 1; k < ng; ++k) LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(g[k].st, ctx->ev_fork, 0));
@@ -1816,7 +2015,10 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
   };
   auto update = [&](Group& G, int first) {
     const size_t lds_upd = sizeof(double) * 3 * (size_t)N * G.nm;
-    if (use_mfma && GW == 32)
+    if (use_mfma && GW == 64)
+      hipLaunchKernelGGL(k_bcg_update_mfma<64>, dim3(S), dim3(1024), lds_upd_mfma, G.st, N, G.nm, Dinv, G.scal, first, G.ug, G.r,
+                         first ? G.pin : G.pout, G.y, G.z, G.partial, G.partial2);
+    else if (use_mfma && GW == 32)
       hipLaunchKernelGGL(k_bcg_update_mfma<32>, dim3(S), dim3(512), lds_upd_mfma, G.st, N, G.nm, Dinv, G.scal, first, G.ug, G.r,
                          first ? G.pin : G.pout, G.y, G.z, G.partial, G.partial2);
     else if (use_mfma)
@@ -1826,12 +2028,13 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
       hipLaunchKernelGGL(k_bcg_update, dim3(S), dim3(256), lds_upd, G.st, N, G.nm, Dinv, G.scal, first, G.ug, G.r,
                          first ? G.pin : G.pout, G.y, G.z, G.partial, G.partial2);
     if (A0inv) hipLaunchKernelGGL(k_coarse_apply, dim3((S + 15) / 16, (G.nm + 15) / 16), dim3(1024), 0, G.st, S, N, G.nm, A0inv, G.r, G.z, G.partial);
-    hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, G.st, S, G.nm, G.partial, G.partial2, G.scal, first ? 0 : 2);
+    hipLaunchKernelGGL(k_bcg_reduce, dim3((G.nm + 15) / 16), dim3(1024), 0, G.st, S, G.nm, G.partial, G.partial2, G.scal, first ? 0 : 2);
   };
   double host[4][4 * BMAX];
   for (int k = 0; k < ng; ++k) {
     Group& G = g[k];
     const long vec = (long)S * N * G.nm;
+    if (GW > 16) LRBMS_HIP_CHECK(ctx, hipMemcpyAsync(G.theta_dev, G.thd, sizeof(double) * 8 * BMAX, hipMemcpyHostToDevice, G.st));
     hipLaunchKernelGGL(k_bcg_init, dim3((unsigned)((vec + 255) / 256 > 4096 ? 4096 : (vec + 255) / 256)), dim3(256), 0, G.st, vec, G.nm,
                        rhs_red, G.ug, G.r);
     update(G, 1);
@@ -1859,9 +2062,13 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
         if (G.done || G.it >= max_iter) continue;
         const int first = G.it == 0 ? 1 : 0;
         const long NM = (long)N * G.nm;
-        if (use_mfma && GW == 32)
-          hipLaunchKernelGGL(k_bcg_matvec_mfma<32>, dim3(S), dim3(512), lds_mfma, G.st, S, ctx->nbr, Q, N, G.nm, G.th, B_sys, G.z, G.pin,
-                             G.scal + 2 * BMAX, first, G.pout, G.y, G.partial);
+        if (use_mfma && GW > 16) {
+#define LRBMS_PANEL(NCV, KSV)                                                                                                       \
+  hipLaunchKernelGGL((k_bcg_matvec_panel<NCV, KSV>), dim3(S), dim3(16 * NCV), lds_mfma, G.st, S, ctx->nbr, Q, N, G.nm, G.theta_dev, \
+                     B_sys, G.z, G.pin, G.scal + 2 * BMAX, first, G.pout, G.y, G.partial)
+          LRBMS_PANEL_DISPATCH(LRBMS_PANEL);
+#undef LRBMS_PANEL
+        }
         else if (use_mfma)
           hipLaunchKernelGGL(k_bcg_matvec_mfma<16>, dim3(S), dim3(256), lds_mfma, G.st, S, ctx->nbr, Q, N, G.nm, G.th, B_sys, G.z, G.pin,
                              G.scal + 2 * BMAX, first, G.pout, G.y, G.partial);
@@ -1871,7 +2078,7 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
         else
           hipLaunchKernelGGL(k_bcg_matvec<BCG_KMAX>, dim3(S), dim3(256), lds_mv, G.st, S, ctx->nbr, Q, N, G.nm, G.th, B_sys, G.z, G.pin,
                              G.scal + 2 * BMAX, first, G.pout, G.y, G.partial);
-        hipLaunchKernelGGL(k_bcg_reduce, dim3(1), dim3(1024), 0, G.st, S, G.nm, G.partial, (const double*)nullptr, G.scal, 1);
+        hipLaunchKernelGGL(k_bcg_reduce, dim3((G.nm + 15) / 16), dim3(1024), 0, G.st, S, G.nm, G.partial, (const double*)nullptr, G.scal, 1);
         update(G, 0);
         double* tmp = G.pin; G.pin = G.pout; G.pout = tmp;
         ++G.it;
@@ -2346,7 +2553,7 @@ int launch_reduced_estimate_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const d
     const size_t lds = sizeof(double) * ((size_t)(5 * N + 5 * Q * N) * nm + 8 * EB + 4 * 3 * EB);
     if (lds > 160 * 1024) return lrbms_fail(ctx, LRBMS_E_INVALID, "reduced_estimate_batch: coefficient panels exceed the LDS");
     ThetaBatch th;
-    for (int m = 0; m < BMAX; ++m)
+    for (int m = 0; m < TBMAX; ++m)
       for (int q = 0; q < 8; ++q) th.v[m * 8 + q] = (m < nm && q < Q) ? theta[(m0 + m) * Q + q] : 0.0;
     if (Fside != nullptr || ctx->opt_estimate_valu == 0) {   // matrix-core form (default; the only one for the factored layout)
       const size_t ldm = sizeof(double) * ((size_t)(((5 * N + 3) & ~3) + (Fside ? ((Q * N + 3) & ~3) + ((4 * nvs + 3) & ~3) : (5 * Q * N + 3) & ~3)) * 16 +
