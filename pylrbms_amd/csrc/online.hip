@@ -1566,17 +1566,26 @@ __global__ __launch_bounds__(16 * NC) void k_bcg_matvec_mfma(int S, const int* _
 // then serves 64 solves per read instead of 16.  theta comes from device memory (a by-value table of 64 x 8 doubles would fill
 // the kernel arguments).  (First attempt, dropped: the B operands straight from global memory into registers, one slot ahead --
 // 2 x 3 x KP / 4 registers per lane; 217 VGPRs, or spills under the 128 of a 1 024-thread workgroup: 382 us per launch.)
-template <int NC, int KSC>      // KSC: k-steps compiled in (4, 8, 10, 12, 16 for N <= 16, 32, 40, 48, 64)
-__global__ __launch_bounds__(16 * NC) void k_bcg_matvec_panel(int S, const int* __restrict__ nbr, int Q, int N, int nmu,
+// CT column tiles per wave.  Measured at 64 columns: CT = 2 (512 threads, the A operand of a k-step read from LDS once for two
+// MFMAs, two workgroups of 8 waves per CU instead of one of 16) needs 150 VGPRs, spills under the 128 that two workgroups allow,
+// and takes 131 us against 102 us for CT = 1: every instantiation the launcher takes has CT = 1.
+template <int NC, int KSC, int CT>      // KSC: k-steps compiled in (4, 8, 10, 12, 16 for N <= 16, 32, 40, 48, 64)
+// (Forcing two workgroups per CU -- 80 VGPRs at 12 waves per workgroup, 52 bytes of scratch -- was measured: 115 us against 102 us.
+// The launch moves ~380 MB -- 131 MB of blocks, 210 MB of direction rows (z and p_old of five slots), 42 MB of results -- in 102 us,
+// 3.7 TB/s: as fast as any streaming kernel of this library gets from the Infinity Cache / HBM.)
+__global__ __launch_bounds__(64 * (NC / 16 / CT) * ((KSC + 3) / 4)) void k_bcg_matvec_panel(int S, const int* __restrict__ nbr, int Q, int N, int nmu,
                                                               const double* __restrict__ theta,      // [nmu][8] device
                                                               const double* __restrict__ B_sys, const double* __restrict__ z,
                                                               const double* __restrict__ p_old, const double* __restrict__ beta,
                                                               int first, double* __restrict__ p_out, double* __restrict__ y,
                                                               double* __restrict__ partial) {
   extern __shared__ double lds[];
-  constexpr int NTH = 16 * NC;
+  // one wave per (row tile that exists for this KSC, group of CT column tiles); the column group is the FAST index, so that the
+  // waves of a row tile -- and with them the idle lanes of a partial last tile -- spread over the four SIMDs (wave w runs on SIMD
+  // w % 4: with the row tile fast and N = 40 every wave of the empty fourth tile sat on SIMD 3 and the MFMAs on the other three)
+  constexpr int NCG = NC / 16 / CT, RTN = (KSC + 3) / 4, NTH = 64 * NCG * RTN;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), rt = wave & 3, ch = wave >> 2, col = ch * 16 + li;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), rt = wave / NCG, col = (wave % NCG) * 16 * CT + li;      // first of CT columns, 16 apart
   const int NM = N * nmu;
   const int LDB = N + ((4 - N % 8) + 8) % 8;           // row stride == 4 (mod 8) doubles: conflict-free A-operand reads
   const int BSZ = (N + 1) * LDB + 16;                  // (+ 16: the k-steps beyond N of the last row read zeros, not the other copy)
@@ -1591,10 +1600,9 @@ __global__ __launch_bounds__(16 * NC) void k_bcg_matvec_panel(int S, const int* 
   // (theta through LDS, not registers loaded in front of the loop: hipcc's wait-count state at the loop header keeps a load that was
   // never waited for on the entry path "pending" in every iteration, i.e. a vmcnt(0) in front of its first use -- behind the prefetch)
   for (int i = tid; i < 4 * NC; i += NTH) tl[i] = (i % NC < nmu) ? theta[(i % NC) * 8 + i / NC] : 0.0;
-  const bool live = col < nmu;
   constexpr int PF = (16 * KSC * KSC + NTH - 1) / NTH; // N * N <= (4 KSC)^2 <= NTH threads x PF
   constexpr int PP = (4 * KSC * NC + NTH - 1) / NTH;   // N nmu <= 4 KSC NC <= NTH threads x PP
-  double pf[PF];
+  double pf[PF];                                       // (two sets, blocks b + 1 and b + 2 in flight, were measured: no faster -- the loads are not what a step waits for)
   // LDS offset of this thread's k-th block entry (divisions once); entries beyond the block go to a dump slot UNCONDITIONALLY: a
   // store under a condition leaves a path without the wait for its load, and hipcc then guards the registers' reuse in the next
   // step with waits that also cover the loads just issued (seen in the ISA: vmcnt(0) behind every prefetch)
@@ -1648,9 +1656,11 @@ __global__ __launch_bounds__(16 * NC) void k_bcg_matvec_panel(int S, const int* 
     }
   };
   const int nblk = ns * Q;
-  d4m acc = (d4m){0.0, 0.0, 0.0, 0.0};
+  d4m acc[CT];
+  double pv[CT][KSC];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) acc[t] = (d4m){0.0, 0.0, 0.0, 0.0};
   const bool active = rt * 16 < N;                     // this wave's row tile exists
-  double pv[KSC], pown[4] = {0.0, 0.0, 0.0, 0.0};
   __syncthreads();                                     // the zeros and beta are in place
   if (nblk > 0) {
     load_block(slot_at(0), 0);
@@ -1659,37 +1669,40 @@ __global__ __launch_bounds__(16 * NC) void k_bcg_matvec_panel(int S, const int* 
   }
   int si = 0, q = 0, slot = nblk > 0 ? slot_at(0) : 2;
   for (int b = 0; b < nblk; ++b) {
-    double* Bc = Bs + (b & 1) * BSZ;
     // (the previous reader of this copy was block b - 2: every wave finished it before it arrived at the barrier of block b - 1)
 #pragma unroll
     for (int k = 0; k < PF; ++k) lds[boff[k] >= 0 ? (b & 1) * BSZ + boff[k] : DUMP] = pf[k];
+    const double* Bc = Bs + (b & 1) * BSZ;
     const int qn = q + 1 < Q ? q + 1 : 0, sin = q + 1 < Q ? si : si + 1;
     const int slotn = sin < ns ? slot_at(sin) : slot;
     const bool newslot = q == 0, stage = newslot && si + 1 < ns;
     const int slot_next = stage ? slot_at(si + 1) : slot;
-    // the next slot's panel rows are requested IN FRONT of the next block: hipcc guards the reuse of the zz / pp registers with
+    // the next slot's panel rows are requested IN FRONT of the block prefetch: hipcc guards the reuse of the zz / pp registers with
     // waits that cover every load issued before them (seen in the ISA: vmcnt(0) right behind the block prefetch, which then
-    // overlapped with nothing); in this order those waits see no block load, and parking the rows later needs vmcnt(PF) only
+    // overlapped with nothing); in this order those waits see no block load of this step
     if (stage) request_panel(slot_next);               // lands during the MFMAs below
-    if (b + 1 < nblk) load_block(slotn, qn);
+    // UNCONDITIONAL (the last step fetches the last block again): with the prefetch under a condition hipcc counts the waits of
+    // the panel rows below for the path without it, i.e. they also wait for the block loads just issued
+    load_block(slotn, sin < ns ? qn : q);
     lds_only_barrier();                                // this block and (first block of a slot) its direction panel are complete
     if (newslot) {
       const double* Pc = Ps + (si & 1) * PSZ + lk * NC + col;
 #pragma unroll
-      for (int ks = 0; ks < KSC; ++ks) pv[ks] = Pc[4 * ks * NC];
-      if (slot == 2) {                                 // the own rows of this lane's D elements: P[rt 16 + lk + 4 r][col] = pv[4 rt + r]
+      for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4)
-            if (4 * t4 + r < KSC && rt == t4) pown[r] = pv[4 * t4 + r];
-      }
+        for (int ks = 0; ks < KSC; ++ks) pv[t][ks] = Pc[4 * ks * NC + 16 * t];
     }
     if (active) {
-      const double thv = tl[q * NC + col];
+      double thv[CT];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) thv[t] = tl[q * NC + col + 16 * t];
       const double* arow = Bc + (rt * 16 + li < N ? rt * 16 + li : N) * LDB + lk;
 #pragma unroll
-      for (int ks = 0; ks < KSC; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * ks], thv * pv[ks], acc, 0, 0, 0);
+      for (int ks = 0; ks < KSC; ++ks) {
+        const double a = arow[4 * ks];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, thv[t] * pv[t][ks], acc[t], 0, 0, 0);
+      }
     }
     // (the other panel copy was last read at the first block of slot si - 1, in front of the barrier every wave has passed since)
     if (stage) park_panel(Ps + ((si + 1) & 1) * PSZ);
@@ -1698,24 +1711,39 @@ __global__ __launch_bounds__(16 * NC) void k_bcg_matvec_panel(int S, const int* 
   __syncthreads();                                     // all reads of Bs are done: it becomes the reduction buffer [4][NC]
   // D layout: lane holds rows rt 16 + lk + 4 r, column col.  p . A p per column: rows of this lane, the four lk groups of the wave
   // (shuffles), the four row-tile waves (LDS) -- a fixed order
-  double dot = 0.0;
-  {
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int ct = col + 16 * t;
     const long base = (long)s * NM;
+    double dot = 0.0, zo[4], po[4];
+    const int cc = ct < nmu ? ct : nmu - 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                      // the own direction at this lane's D elements, as the panel had it: the same expression, the same bits
+      const int row = rt * 16 + lk + 4 * r, rc = row < N ? row : N - 1;
+      zo[r] = (z + base)[rc * nmu + cc];
+      po[r] = (p_old + base)[rc * nmu + cc];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rt * 16 + lk + 4 * r;
-      if (active && live && row < N) {
-        (y + base)[row * nmu + col] = acc[r];
-        (p_out + base)[row * nmu + col] = pown[r];       // the new direction of the own slot (the rows this lane took from its panel)
-        dot += acc[r] * pown[r];
+      if (active && ct < nmu && row < N) {
+        const double pw = first ? zo[r] : zo[r] + bl[ct] * po[r];
+        (y + base)[row * nmu + ct] = acc[t][r];
+        (p_out + base)[row * nmu + ct] = pw;             // the new direction of the own slot
+        dot += acc[t][r] * pw;
       }
     }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    if (lk == 0) lds[rt * NC + ct] = dot;
   }
-  dot += __shfl_xor(dot, 16, 64);
-  dot += __shfl_xor(dot, 32, 64);
-  if (lk == 0) lds[rt * NC + col] = dot;
   __syncthreads();
-  if (tid < nmu) partial[(long)tid * gridDim.x + s] = ((lds[tid] + lds[NC + tid]) + lds[2 * NC + tid]) + lds[3 * NC + tid];      // [m][S]
+  if (tid < nmu) {
+    double sum = 0.0;
+#pragma unroll
+    for (int r = 0; r < RTN; ++r) sum += lds[r * NC + tid];
+    partial[(long)tid * gridDim.x + s] = sum;          // [m][S]
+  }
 }
 
 // out[m] = sum_s partial[s][m]; mode 1: pAp -> alpha = rz / pAp; mode 2: rz_new -> beta = rz_new / rz, rz = rz_new;
@@ -1830,6 +1858,8 @@ __global__ __launch_bounds__(16 * NC) void k_bcg_update_mfma(int N, int nmu, con
     const int ra = rt * 16 + li < N ? rt * 16 + li : N - 1;
     const double* D = Dinv + ((long)s * N + ra) * N;
     d4m T = (d4m){0.0, 0.0, 0.0, 0.0};
+    // (requesting all k-steps of the row strip in front of the first MFMA was measured: 41 vs 35 us at 64 columns -- the kernel moves
+    // 160 MB of vectors per launch and is bound by that, not by this chain)
     for (int kk = 0; kk < KP; kk += 4) {
       const bool in = kk + lk < N;
       T = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? D[kk + lk] : 0.0, rs[(kk + lk) * NC + col], T, 0, 0, 0);
@@ -1977,17 +2007,17 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
 #define LRBMS_PANEL_DISPATCH(X)                                                                                    \
   do {                                                                                                             \
     if (GW == 64) {                                                                                                \
-      if (ksc_n == 4) X(64, 4); else if (ksc_n == 8) X(64, 8); else if (ksc_n == 10) X(64, 10); else if (ksc_n == 12) X(64, 12); else X(64, 16); \
+      if (ksc_n == 4) X(64, 4, 1); else if (ksc_n == 8) X(64, 8, 1); else if (ksc_n == 10) X(64, 10, 1); else if (ksc_n == 12) X(64, 12, 1); else X(64, 16, 1); \
     } else {                                                                                                       \
-      if (ksc_n == 4) X(32, 4); else if (ksc_n == 8) X(32, 8); else if (ksc_n == 10) X(32, 10); else if (ksc_n == 12) X(32, 12); else X(32, 16); \
+      if (ksc_n == 4) X(32, 4, 1); else if (ksc_n == 8) X(32, 8, 1); else if (ksc_n == 10) X(32, 10, 1); else if (ksc_n == 12) X(32, 12, 1); else X(32, 16, 1); \
     }                                                                                                              \
   } while (0)
   if (use_mfma && lds_mfma > 64 * 1024) {
     if (GW == 16) {
       LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_mfma<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
     } else {
-#define LRBMS_PANEL_ATTR(NCV, KSV) \
-  LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_panel<NCV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma))
+#define LRBMS_PANEL_ATTR(NCV, KSV, CTV) \
+  LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_bcg_matvec_panel<NCV, KSV, CTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma))
       LRBMS_PANEL_DISPATCH(LRBMS_PANEL_ATTR);
 #undef LRBMS_PANEL_ATTR
     }
@@ -2063,9 +2093,9 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
         const int first = G.it == 0 ? 1 : 0;
         const long NM = (long)N * G.nm;
         if (use_mfma && GW > 16) {
-#define LRBMS_PANEL(NCV, KSV)                                                                                                       \
-  hipLaunchKernelGGL((k_bcg_matvec_panel<NCV, KSV>), dim3(S), dim3(16 * NCV), lds_mfma, G.st, S, ctx->nbr, Q, N, G.nm, G.theta_dev, \
-                     B_sys, G.z, G.pin, G.scal + 2 * BMAX, first, G.pout, G.y, G.partial)
+#define LRBMS_PANEL(NCV, KSV, CTV)                                                                                                  \
+  hipLaunchKernelGGL((k_bcg_matvec_panel<NCV, KSV, CTV>), dim3(S), dim3(64 * (NCV / 16 / CTV) * ((KSV + 3) / 4)), lds_mfma, G.st, S, ctx->nbr, Q, N, G.nm,   \
+                     G.theta_dev, B_sys, G.z, G.pin, G.scal + 2 * BMAX, first, G.pout, G.y, G.partial)
           LRBMS_PANEL_DISPATCH(LRBMS_PANEL);
 #undef LRBMS_PANEL
         }
