@@ -439,12 +439,32 @@ def main():
         t_est = time.perf_counter() - t2
         dt = time.perf_counter() - t1 - t_warm
         eng.ctx.reduced_precond_use(None)
+        # roofline of the solve loop: what one CG iteration of a 64-parameter call moves and multiplies.  Panel matvec: every
+        # projected block of B_sys once (existing neighbour slots x Q x N^2 doubles), the direction rows of every slot (z and p_old,
+        # N x 64 doubles each), the results y and p; update + preconditioner: x, r, p, y read, x, r, z written, the inverse diagonal
+        # blocks; coarse level: the dense S x S inverse.  Flops: the MFMA products of the panel matvec and of Dinv r (padding excluded).
+        nslots = int((eng.nbr >= 0).sum())
+        Qn = eng.Q
+        it_bytes = 8 * (nslots * Qn * N * N + 2 * nslots * N * nb + 2 * eng.S * N * nb      # matvec: blocks, direction rows, y + p
+                        + 7 * eng.S * N * nb + eng.S * N * N                                # update: x r p y in, x r z out, Dinv
+                        + eng.S * eng.S + 2 * eng.S * nb)                                   # coarse apply
+        it_flops = 2.0 * nb * N * N * (nslots * Qn + eng.S) + 2.0 * nb * eng.S * eng.S
+        ncalls = (len(mus) + nb - 1) // nb
+        t_solve = dt - t_est - t_pc
+        online_roof = {'bound': 'hbm', 'unit': 'GB/s', 'peak': 8000.0,
+                       'bytes_per_cg_iteration': it_bytes, 'bytes_per_solve_and_iteration': it_bytes / nb,
+                       'achieved': 1e-9 * ncalls * iters * it_bytes / t_solve, 'frac': 1e-9 * ncalls * iters * it_bytes / t_solve / 8000.0,
+                       'mfma_flops_per_cg_iteration': it_flops, 'mfma_TFLOPs': 1e-12 * ncalls * iters * it_flops / t_solve,
+                       'mfma_frac': 1e-12 * ncalls * iters * it_flops / t_solve / 78.6,
+                       'basis': 'algorithmic bytes of one CG iteration of a {}-parameter call (B_sys blocks once per call and iteration, direction '
+                                'rows, solver vectors, coarse inverse) x {} iterations x {} calls / the solve time without the preconditioner '
+                                'build ({:.2f} ms); iterations counted as the slowest parameter of a call needs'.format(nb, iters, ncalls, 1e3 * t_solve)}
         online = {'metric': 'online reduced solves (O1)', 'value': len(mus) / (dt - t_est), 'unit': 'mu-solves/s',
                   'solve_plus_estimate_per_s': len(mus) / dt, 'estimates_per_s': len(mus) / t_est, 'parameters': len(mus),
                   'batch': nb, 'reduced_dim': S_total * N, 'cg_iterations_max': iters, 'relative_residual_max': worst,
-                  'preconditioner_build_ms': 1e3 * t_pc, 'groups_in_flight': 4,
-                  'solver': 'PCG on the block-sparse reduced system, rtol 1e-12, 64 parameters per call (four groups of 16 on four streams, '
-                            'inside the library), preconditioner = inverse diagonal blocks + coarse '
+                  'preconditioner_build_ms': 1e3 * t_pc, 'groups_in_flight': 1, 'roofline': online_roof,
+                  'solver': 'PCG on the block-sparse reduced system, rtol 1e-12, 64 parameters per call as ONE panel of 64 columns (every '
+                            'projected block read once per iteration for all 64), preconditioner = inverse diagonal blocks + coarse '
                             'level on the first local basis vectors, built once at mu = 0.55 (time included in value); '
                             'estimates: lrbms_reduced_estimate_batch (local nc / r / df terms of every subdomain)'}
 

@@ -249,9 +249,10 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
  *   LRBMS_OPT_STREAMS          -1 (default): the fused pass forks its small kernels over the library streams below 192
  *                              subdomains per rank; 0: never; 1: always
  *   LRBMS_OPT_F1_KSPLIT        0 (default): workgroups per subdomain of the dense projection kernel chosen from S; 1, 2, 4: forced
- *   LRBMS_OPT_F1_FORM          0 (default): the leanest form of that kernel the shape allows (k_f1v: even N <= 40 at Q = 2;
- *                              else k_f1u; N > 48 or Q > 2: k_f1); 1: the producer / consumer form k_f1 for every shape;
- *                              2: no k_f1v (cross-check of the forms against each other)
+ *   LRBMS_OPT_F1_FORM          0 (default): the leanest form of that kernel the shape allows (k_f1w, the rank-2 form of the
+ *                              df_aa / df_ab groups: Q = 2, even N in [34, 40], with LRBMS_OPT_PREP_LDS; k_f1v: other even N <= 40
+ *                              at Q = 2; else k_f1u; N > 48 or Q > 2: k_f1); 1: the producer / consumer form k_f1 for every shape;
+ *                              2: neither k_f1w nor k_f1v; 3: no k_f1w (cross-checks of the forms against each other)
  *   LRBMS_OPT_COARSE           coarse level of the reduced solvers' preconditioner: 1 (default) hand-written block-tridiagonal
  *                              factorisation where the band allows it; 0: none (block-Jacobi); 2: rocSOLVER always
  *   LRBMS_OPT_SOLVE_VALU       1: VALU form of the batched solver's panel matvec (cross-check of the matrix-core form)

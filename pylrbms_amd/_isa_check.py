@@ -199,7 +199,7 @@ def check_fused_isa(asm_path):
     report, problems = [], []
     seen = 0
     for name, lines in fns.items():
-        m = re.search(r'\dk_f(1u|1v|1|2)I((?:Li\d+E)+)E', name)
+        m = re.search(r'\dk_f(1u|1v|1|2)I((?:Li\d+E)+)E', name) or re.search(r'\dk_f(1w)()E4Tmpl', name)      # (k_f1w is no template)
         if not m:
             continue
         kernel = 'k_f{}<{}>'.format(m.group(1), ','.join(re.findall(r'Li(\d+)E', m.group(2))))
@@ -229,7 +229,7 @@ def check_fused_isa(asm_path):
         if scratch_lines and first_asm_load is not None and max(scratch_lines) >= first_asm_load:
             problems.append('{}: scratch instruction behind the first asm-managed load (line {} >= {})'.format(
                 kernel, max(scratch_lines), first_asm_load))
-        lean = m.group(1) == '1v'      # k_f1v: ONE register set per wave, completed by an asm vmcnt(0) at the start of a stage
+        lean = m.group(1) in ('1v', '1w')      # k_f1v / k_f1w: ONE register set per wave, completed by an asm vmcnt(0) at the start of a stage
         uses_asm_prefetch = any(';;#ASMSTART' in ln for ln in lines) and \
             any('global_load' in ln for ln in lines if True) and \
             any(re.search(r'^\s+s_waitcnt vmcnt\((?!0\))\d+\)\s*$' if not lean else r'^\s+s_waitcnt vmcnt\(0\)\s*$', ln) for ln in lines)

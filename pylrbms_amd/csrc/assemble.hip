@@ -475,6 +475,19 @@ int launch_assemble_products(lrbms_ctx* ctx, int Q, const double* theta_bar, con
   hipLaunchKernelGGL(k_assemble_products, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->t, ctx->qdev, ctx->S,
                      ctx->S_ext, ctx->nbr, Q, tb, lam, lam_df, lbar, lhat, P_diag, ebar, caa, Aab, Bbb);
   LRBMS_LAUNCH_CHECK(ctx);
+  // the rank-2 factors of the df_ab blocks (k_f1w), an assembled quantity: kept by the context, tagged with the Aab they belong to
+  const long need = (long)Q * ctx->S * ctx->t.nT * 6;
+  if (ctx->wab_cap < need) {
+    if (ctx->wab) LRBMS_HIP_CHECK(ctx, hipFree(ctx->wab));
+    ctx->wab = nullptr;
+    ctx->wab_cap = 0;
+    LRBMS_HIP_CHECK(ctx, hipMalloc(&ctx->wab, sizeof(double) * (size_t)need));
+    ctx->wab_cap = need;
+  }
+  ctx->wab_src = nullptr;
+  if (int rc = launch_wab(ctx, Q, Aab, ctx->wab, st)) return rc;
+  ctx->wab_src = Aab;
+  ctx->wab_Q = Q;
   return LRBMS_OK;
 }
 

@@ -141,6 +141,7 @@ int lrbms_ctx_destroy(lrbms_ctx* ctx) {
   if (ctx->ksp_part) (void)hipFree(ctx->ksp_part);
   if (ctx->ksp_ticket) (void)hipFree(ctx->ksp_ticket);
   if (ctx->subset) (void)hipFree(ctx->subset);
+  if (ctx->wab) (void)hipFree(ctx->wab);
   for (int i = 0; i < 3; ++i) {
     if (ctx->aux[i]) lrbms_side_stream_release(ctx->device, i);
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
@@ -164,7 +165,8 @@ int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value) {
   int lo = 0, hi = 1;
   if (option == LRBMS_OPT_STREAMS) lo = -1;
   if (option == LRBMS_OPT_F1_KSPLIT) hi = 4;
-  if (option == LRBMS_OPT_COARSE || option == LRBMS_OPT_F1_FORM || option == LRBMS_OPT_PREP_LDS) hi = 2;
+  if (option == LRBMS_OPT_COARSE || option == LRBMS_OPT_PREP_LDS) hi = 2;
+  if (option == LRBMS_OPT_F1_FORM) hi = 3;
   if (value < lo || value > hi || (option == LRBMS_OPT_F1_KSPLIT && value == 3))
     return lrbms_fail(ctx, LRBMS_E_INVALID, "set_option: value out of range for this option");
   switch (option) {
@@ -335,6 +337,7 @@ int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* d, int32_t S, int32
     ctx->diag_explicit = false;
   }
   ctx->subset_n = 0;
+  ctx->wab_src = nullptr;      // (factors of another mesh)
   ctx->S = S;
   ctx->S_ext = S_ext;
   if ((rc = build_template_tables(ctx))) return rc;

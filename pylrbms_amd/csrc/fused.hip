@@ -2272,6 +2272,480 @@ __global__ __launch_bounds__(512, 2) void k_f1v(Tmpl t, F1Args a, GrpTable gt) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// F1, rank-2 form (k_f1w; round 4): Q = 2, three row tiles, even N in [34, 40] -- the shape of BASELINE config 3.
+// Every element block of df_aa (c_T^{qq'} K_T) and of df_ab (A_ab,T^q) acts through the TWO gradient directions of the P1 shape
+// functions: with kappa = L L^T and G_T = [g_0 g_1 g_2],  K_T = Z_T^T Z_T (Z_T = L^T G_T, 2 x 3)  and  A_ab,T = G_T^T W_T, so
+//   G_aa^{qq'} = sum_T (Z_T V_T)^T (c_T^{qq'} Z_T V_T),      G_ab^q[:, self] = sum_T (Z_T V_T)^T (W'^q_T R_T),   W' = L^-1 W:
+// seven of the eleven column groups (three G_aa pairs, four G_ab) have TWO K rows per element instead of three when the X operand
+// is Z V (two rows) instead of V.  A chunk of four elements is then 3 k-steps for the tiles of B_sys / E_red / M_red and 2 k-steps
+// for the others: 150 instead of 204 projection MFMAs per chunk.  What changes against k_f1v:
+//   * role A's stacked apply carries the two rows of Z_T (template table t.lgz) where it carried the three rows of K_T: Z V leaves
+//     the matrix pipe with the system rows, is stored once as the second X operand (Zs) and, times c^{qq'}, as the Y rows of the
+//     three G_aa groups;
+//   * role B multiplies W'^q_T (2 x 3 per component; k_prep_lds forms it from A_ab with the template table t.hab) with the three
+//     flux rows: four A-operand rows, one accumulator register;
+//   * the column tiles come in two kinds (3 or 2 K rows per element) and three classes (row tiles needed); which SIMD owns which
+//     is a compile-time plan (F1wPlan) that balances the MFMA count: 38 / 38 / 37 / 37 per chunk and SIMD.
+struct F1wPlan {
+  static constexpr int NL = 7, LA = 2;                 // levels (four column tiles each: tile 4 l + e on SIMD e); role A takes the first LA
+  // v = e >> 1 (SIMDs 0, 1 / 2, 3).  level 0: block 0 of the four K3 symmetric groups; 1: their block 1; 2: v0 their packed tails,
+  // v1 block 1 of G_aa[0][0] / [1][1]; 3: v0 block 0 of those, v1 K2 tiles of class 3; 4 .. 6: K2 tiles of class 3
+  static constexpr int cls(int l, int v) { return l == 0 ? 1 : l == 1 ? 2 : l == 2 ? (v == 0 ? 3 : 2) : l == 3 ? (v == 0 ? 1 : 3) : 3; }
+  static constexpr int kr(int l, int v) { return l < 2 ? 3 : l == 2 ? (v == 0 ? 3 : 2) : 2; }      // K rows per element
+  static constexpr int first(int role) { return role == 0 ? 0 : LA; }
+  static constexpr int count(int role) { return role == 0 ? LA : NL - LA; }
+  static constexpr int slots_before(int role, int v, int jt) {
+    int n = 0;
+    for (int k = 0; k < jt; ++k) n += cls(first(role) + k, v);
+    return n;
+  }
+  static constexpr int slots(int role, int v) { return slots_before(role, v, count(role)); }
+  static constexpr int max_slots(int role) { return slots(role, 0) > slots(role, 1) ? slots(role, 0) : slots(role, 1); }
+};
+template <int V> struct F1wV { static constexpr int value = V; };
+
+template <int ROLE>
+__device__ __forceinline__ void f1w_body(const Tmpl& t, const F1Args& a, const double* __restrict__ Wab, double* __restrict__ Xs,
+                                         double* __restrict__ Zs, double* __restrict__ Ys, double* __restrict__ red,
+                                         int* __restrict__ flag, const int* __restrict__ colmap, const Grp* grp) {
+  using LV = F1wPlan;
+  constexpr int NTX = 3, QP = 2, NTYS = LV::NL;
+  constexpr int LDX = padded_ld(NTX);
+  constexpr int LDY = 4 * NTYS * 16 + 16;
+  constexpr int NT = LV::count(ROLE), LV0 = LV::first(ROLE);
+  constexpr int NS = LV::max_slots(ROLE);
+  static_assert(NS <= F1V_SLOTS, "K-split partial layout");
+  constexpr int NP = QP * (QP + 1) / 2;
+  constexpr int NPAIR = NTX / 2, NSING = NTX % 2;
+  const int s = subdomain_of(t, blockIdx.x), tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = uniform(tid >> 6), e = wave & 3;
+  const int N = a.N, S = a.S, QN = QP * N;
+  const int ksplit = gridDim.z;
+  const int nchunks = t.nT / EC / ksplit;
+  const int T0 = blockIdx.z * nchunks * EC;
+  auto pos = [&](int g, int c) { return grp[g].cb[c >> 4] + (c & 15); };
+  auto colc = [&](int ct) {
+    return ct < 2 * NPAIR ? (32 * (ct >> 1) + 2 * li + 1 < N ? 32 * (ct >> 1) + 2 * li : N - 2) + (ct & 1) : (16 * ct + li < N ? 16 * ct + li : N - 1);
+  };
+  const double* Vs = (const double*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(a.V + (long)s * t.n * N) >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)(a.V + (long)s * t.n * N)));
+
+  d4 acc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  // the projection of one chunk: 3 k-steps over the V rows for the tiles of kind 3, 2 k-steps over the Z rows for the tiles of kind 2
+  auto mfma_phase = [&](int c, auto vtag) {
+    constexpr int V = decltype(vtag)::value;
+    const double* Xb = Xs + (c & 1) * 3 * EC * LDX;
+    const double* Zb = Zs + (c & 1) * 2 * EC * LDX;
+    const double* Yb = Ys + (c & 1) * 3 * EC * LDY;
+    constexpr bool any3 = LV::kr(LV0, V) == 3 || LV::kr(LV0 + (NT > 1 ? 1 : 0), V) == 3;      // (kind-3 tiles are the first of a role's list)
+    if constexpr (any3) {
+#pragma unroll
+      for (int kk = 0; kk < 3 * EC; kk += 4) {
+        double av[NTX];
+#pragma unroll
+        for (int i = 0; i < NTX; ++i) av[i] = Xb[(kk + lk) * LDX + i * 16 + li];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          if (LV::kr(LV0 + jt, V) == 3) {      // (compile time once the loop is unrolled)
+            const double bv = Yb[(kk + lk) * LDY + (4 * (LV0 + jt) + e) * 16 + li];
+#pragma unroll
+            for (int i = 0; i < LV::cls(LV0 + jt, V); ++i)
+              acc[LV::slots_before(ROLE, V, jt) + i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[LV::slots_before(ROLE, V, jt) + i], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if constexpr (ROLE == 1) {
+#pragma unroll
+      for (int kk = 0; kk < 2 * EC; kk += 4) {
+        double av[NTX];
+#pragma unroll
+        for (int i = 0; i < NTX; ++i) av[i] = Zb[(kk + lk) * LDX + i * 16 + li];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          if (LV::kr(LV0 + jt, V) == 2) {
+            const double bv = Yb[(kk + lk) * LDY + (4 * (LV0 + jt) + e) * 16 + li];
+#pragma unroll
+            for (int i = 0; i < LV::cls(LV0 + jt, V); ++i)
+              acc[LV::slots_before(ROLE, V, jt) + i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv, acc[LV::slots_before(ROLE, V, jt) + i], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  auto tie = [](double& v) { asm volatile("" : "+v"(v)); };
+  auto tie2 = [](d2& v) { asm volatile("" : "+v"(v)); };
+  double rhs_part[NTX];
+#pragma unroll
+  for (int ct = 0; ct < NTX; ++ct) rhs_part[ct] = 0.0;
+  // rows of role A's stacked apply: 0 .. 8 A_0, A_1, P; 9 .. 11 M; 12, 13 Z; 14 b; 15 zero
+  constexpr int R_GRP = 3 * (QP + 2);                   // rows 0 .. R_GRP - 1: A_q V, P V, M V  (column groups 0 .. Q + 1)
+  constexpr int R_B = R_GRP + 2, RRZ = R_GRP / 4, KQB = R_B % 4;
+  static_assert(R_GRP % 4 == 0 && R_B / 4 == RRZ && R_B < 16, "the Z rows and b . V in one accumulator register");
+
+  if constexpr (ROLE == 0) {
+    struct Set {
+      double A[3];
+      d2 Bp[3][NPAIR];
+      double Bs[3];
+    };
+    const int r16 = li, kq = lk;
+    const double* ap[3];
+    unsigned ainc = 0;
+    int bbk[3];
+    unsigned lcp[3][NPAIR], lcs[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const int k = 4 * ks + kq, bb = k / 3, cc = k - 3 * bb;
+      bbk[ks] = bb;
+      const double* src = t.zero64;
+      unsigned stride = r16 < R_GRP ? 9 : r16 < R_B ? 6 : r16 == R_B ? 3 : 0;
+      if (r16 < 3 * (QP + 1)) {
+        const int g = r16 / 3, i = r16 % 3;
+        src = (g < QP ? a.A_diag + ((long)g * S + s) * t.nT * 36 : a.P_diag + (long)s * t.nT * 36) + bb * 9 + i * 3 + cc;
+        stride = 36;
+      } else if (bb == 0 && r16 < R_GRP) {
+        src = t.mass9 + (r16 - 3 * (QP + 1)) * 3 + cc;
+      } else if (bb == 0 && r16 < R_B) {
+        src = t.lgz + (r16 - R_GRP) * 3 + cc;
+      } else if (bb == 0 && r16 == R_B) {
+        src = a.b + (long)s * t.n + cc;
+      }
+      ap[ks] = src + (long)(T0 + e) * stride;
+      ainc = 8u * EC * stride;
+#pragma unroll
+      for (int pp = 0; pp < NPAIR; ++pp) {
+        const int col = 32 * pp + 2 * li + 1 < N ? 32 * pp + 2 * li : N - 2;
+        lcp[ks][pp] = 8u * (unsigned)(cc * N + col);
+      }
+      const int cs = 16 * (NTX - 1) + li < N ? 16 * (NTX - 1) + li : N - 1;
+      lcs[ks] = 8u * (unsigned)(cc * N + cs);
+    }
+    const unsigned rs3 = 24u * (unsigned)N;
+    // LDS offsets (doubles) of the apply's outputs (see k_f1v: lanes beyond N hold duplicates of a column < N and store the same
+    // value to the same address).  Rows 0 .. 11 (registers 0 .. 2): every lane has a row; register 3: lanes kq < 2 hold a Z row
+    int xoff[NTX], zoff[NTX], yoff[3][NTX], koff[NP][NTX];
+    const bool zrow = kq < 2;
+#pragma unroll
+    for (int ct = 0; ct < NTX; ++ct) {
+      const int col = colc(ct);
+      xoff[ct] = (3 * e + (kq < 3 ? kq : 0)) * LDX + col;
+      zoff[ct] = (2 * e + (zrow ? kq : 0)) * LDX + col;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        const int r = kq + 4 * rr;
+        yoff[rr][ct] = (3 * e + r % 3) * LDY + pos(r / 3, col);
+      }
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) koff[pr][ct] = (2 * e + (zrow ? kq : 0)) * LDY + pos(QP + 2 + pr, col);
+    }
+    const cint_p nbc = (cint_p)t.nb_elem;
+    struct Sc {
+      int nb[3];
+      double cc[NP];
+    };
+    auto load_sc = [&](int T, Sc& x) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) x.nb[f] = nbc[T * 3 + f];
+      int pr = 0;
+#pragma unroll
+      for (int q = 0; q < QP; ++q)
+#pragma unroll
+        for (int q2 = q; q2 < QP; ++q2) x.cc[pr++] = ((cdbl_p)(a.caa + ((long)(q * QP + q2) * S + s) * t.nT))[T];
+    };
+    auto load_set = [&](int T, const Sc& sc, Set& x) {
+      unsigned eo[4];
+      eo[0] = (unsigned)T * rs3;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) eo[1 + f] = (unsigned)(sc.nb[f] >= 0 ? sc.nb[f] : T) * rs3;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) x.A[ks] = gload_f64(ap[ks]);
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const unsigned eoff = bbk[ks] == 0 ? eo[0] : bbk[ks] == 1 ? eo[1] : bbk[ks] == 2 ? eo[2] : eo[3];
+#pragma unroll
+        for (int pp = 0; pp < NPAIR; ++pp) x.Bp[ks][pp] = gload_s128(Vs, eoff + lcp[ks][pp]);
+        if (NSING) x.Bs[ks] = gload_s64(Vs, eoff + lcs[ks]);
+      }
+    };
+    auto tie_set = [&](Set& x) {
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        tie(x.A[ks]);
+#pragma unroll
+        for (int pp = 0; pp < NPAIR; ++pp) tie2(x.Bp[ks][pp]);
+        if (NSING) tie(x.Bs[ks]);
+      }
+    };
+    auto bop = [&](const Set& x, int ks, int ct) { return ct < 2 * NPAIR ? x.Bp[ks][ct >> 1][ct & 1] : x.Bs[ks]; };
+    auto stage = [&](int c, Set& cur, const Sc& sc_cur, Sc& sc_nxt) {
+      const int T = T0 + c * EC + e;
+      const bool more = c + 1 < nchunks;
+      double* Xb = Xs + (c & 1) * 3 * EC * LDX;
+      double* Zb = Zs + (c & 1) * 2 * EC * LDX;
+      double* Yb = Ys + (c & 1) * 3 * EC * LDY;
+      load_sc(more ? T + EC : T, sc_nxt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tie_set(cur);
+      d4 D[NTX];
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) D[ct] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) D[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.A[ks], bop(cur, ks, ct), D[ct], 0, 0, 0);
+      if (kq < 3) {
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) Xb[xoff[ct]] = bop(cur, 0, ct);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) Yb[yoff[rr][ct]] = D[ct][rr];
+      if (zrow) {                                  // lane constant: one exec region for the Z rows and the c^{qq'} Z V stores
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) Zb[zoff[ct]] = D[ct][RRZ];
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+          for (int ct = 0; ct < NTX; ++ct) Yb[koff[pr][ct]] = sc_cur.cc[pr] * D[ct][RRZ];
+      }
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) rhs_part[ct] += D[ct][RRZ];      // meaningful on the lanes kq == KQB
+      if (more) {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) ap[ks] = (const double*)((const char*)ap[ks] + ainc);
+        load_set(T + EC, sc_nxt, cur);
+      }
+    };
+    Set s0;
+    Sc c0, c1;
+    load_sc(T0 + e, c0);
+    load_set(T0 + e, c0, s0);
+    auto round = [&](int c, Sc& x0, Sc& x1) {
+      stage(c, s0, x0, x1);
+      lds_barrier();
+      mfma_phase(c, F1wV<0>{});                  // (role A's tiles are the same for every SIMD)
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+      round(c, c0, c1);
+      round(c + 1, c1, c0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie_set(s0);
+    if (a.rhs_red != nullptr && kq == KQB) {
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) {
+        const int nat = ct < 2 * NPAIR ? 32 * (ct >> 1) + 2 * li + (ct & 1) : 16 * ct + li;
+        if (nat < N) red[e * 64 + nat] = rhs_part[ct];
+      }
+    }
+  } else {
+    // ------------------------------------------------------------- role B: Y^{q,q2} = W'^q_T R_T^{q2}, two rows per element
+    struct Set {
+      double A;
+      d2 Bp[QP][NPAIR];
+      double Bs[QP];
+    };
+    const double* Rs = (const double*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(a.Rself + (long)s * t.nrt * QN) >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)(a.Rself + (long)s * t.nrt * QN)));
+    const int r16 = li, kq = lk;
+    const double* ap = t.zero64;                        // lanes without an entry walk through the zero table with the same stride
+    if (r16 < 2 * QP && kq < 3) ap = Wab + ((long)(r16 >> 1) * S + s) * t.nT * 6 + (r16 & 1) * 3 + kq;
+    ap += (long)(T0 + e) * 6;
+    unsigned lcp[QP][NPAIR], lcs[QP];
+    int yo[QP][NTX];                                   // LDS offsets of accumulator register 0: row kq = (q, d) = (kq >> 1, kq & 1)
+#pragma unroll
+    for (int q2 = 0; q2 < QP; ++q2) {
+#pragma unroll
+      for (int pp = 0; pp < NPAIR; ++pp) lcp[q2][pp] = 8u * (unsigned)(q2 * N + (32 * pp + 2 * li + 1 < N ? 32 * pp + 2 * li : N - 2));
+      lcs[q2] = 8u * (unsigned)(q2 * N + (16 * (NTX - 1) + li < N ? 16 * (NTX - 1) + li : N - 1));
+#pragma unroll
+      for (int ct = 0; ct < NTX; ++ct) yo[q2][ct] = (2 * e + (kq & 1)) * LDY + pos(QP + 2 + NP + (kq >> 1) * QP + q2, colc(ct));
+    }
+    const unsigned rsr = 8u * (unsigned)QN;
+    const cint_p rtc = (cint_p)t.elem_rt;
+    struct Sc {
+      int rt[3];
+    };
+    auto load_sc = [&](int T, Sc& x) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) x.rt[f] = rtc[T * 3 + f];
+    };
+    auto load_set = [&](const Sc& sc, Set& x) {
+      const unsigned ro = (unsigned)(kq == 1 ? sc.rt[1] : kq == 2 ? sc.rt[2] : sc.rt[0]) * rsr;
+      x.A = gload_f64(ap);
+#pragma unroll
+      for (int q2 = 0; q2 < QP; ++q2) {
+#pragma unroll
+        for (int pp = 0; pp < NPAIR; ++pp) x.Bp[q2][pp] = gload_s128(Rs, ro + lcp[q2][pp]);
+        if (NSING) x.Bs[q2] = gload_s64(Rs, ro + lcs[q2]);
+      }
+    };
+    auto tie_set = [&](Set& x) {
+      tie(x.A);
+#pragma unroll
+      for (int q2 = 0; q2 < QP; ++q2) {
+#pragma unroll
+        for (int pp = 0; pp < NPAIR; ++pp) tie2(x.Bp[q2][pp]);
+        if (NSING) tie(x.Bs[q2]);
+      }
+    };
+    auto bop = [&](const Set& x, int q2, int ct) { return ct < 2 * NPAIR ? x.Bp[q2][ct >> 1][ct & 1] : x.Bs[q2]; };
+    auto stage = [&](int c, Set& cur, Sc& sc_nxt) {
+      const int T = T0 + c * EC + e;
+      const bool more = c + 1 < nchunks;
+      double* Yb = Ys + (c & 1) * 3 * EC * LDY;
+      load_sc(more ? T + EC : T, sc_nxt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tie_set(cur);
+#pragma unroll
+      for (int q2 = 0; q2 < QP; ++q2) {
+        d4 D[NTX];
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct)
+          D[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.A, bop(cur, q2, ct), (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < NTX; ++ct) Yb[yo[q2][ct]] = D[ct][0];
+      }
+      if (more) {
+        ap += 6 * EC;
+        load_set(sc_nxt, cur);
+      }
+    };
+    // One staging loop per tile plan (SIMDs 0, 1 / 2, 3), each with its OWN prologue behind the wave-uniform branch: with the
+    // prologue's asm-managed loads live across the branch, hipcc moved the set's registers on the out-of-line side before the first
+    // vmcnt(0), and chunk 0 of SIMDs 2, 3 multiplied what the registers held before the loads had landed (their elements'
+    // contributions to G_ab were missing; the ISA guard walks the loops, not the prologue).  (Both plans in ONE loop: 101 spilled VGPRs.)
+    auto run = [&](auto vtag) {
+      Set s0;
+      Sc c0;
+      load_sc(T0 + e, c0);
+      load_set(c0, s0);
+      for (int c = 0; c < nchunks; ++c) {
+        stage(c, s0, c0);
+        lds_barrier();
+        mfma_phase(c, vtag);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tie_set(s0);
+    };
+    if (e < 2) run(F1wV<0>{});
+    else run(F1wV<1>{});
+  }
+  // ---- K-split (see f1u_body: partial tiles written through, the last arriver sums them in the fixed order of the parts)
+  if (ksplit > 1) {
+    constexpr int PW = F1V_SLOTS * 4 * 64;
+    const long wg = 8L * PW + 64;
+    double* mine = a.part + ((long)s * ksplit + blockIdx.z) * wg;
+    double* pw = mine + (long)wave * PW + 2 * lane;
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) store_sc1_b128(pw + (i * 2 + h) * 128, acc[i][2 * h], acc[i][2 * h + 1]);
+    __syncthreads();
+    if (a.rhs_red != nullptr && tid < N) {
+      double sum = 0.0;
+      for (int w = 0; w < EC; ++w) sum += red[w * 64 + tid];
+      store_sc1_b64(mine + 8L * PW + tid, sum);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) *flag = __hip_atomic_fetch_add(a.ticket + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != ksplit - 1) return;
+    if (tid == 0) __hip_atomic_store(a.ticket + s, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double* all = a.part + (long)s * ksplit * wg;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int z = 0; z < ksplit; ++z) {
+      const double* pz = all + z * wg + (long)wave * PW + 2 * lane;
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] += load_sc1_b64(pz + (i * 2 + r / 2) * 128 + r % 2);
+    }
+    if (a.rhs_red != nullptr && tid < N) {
+      double sum = 0.0;
+      for (int z = 0; z < ksplit; ++z) sum += load_sc1_b64(all + z * wg + 8L * PW + tid);
+      a.rhs_red[(long)s * N + tid] = sum;
+    }
+  }
+  // ---- epilogue (as k_f1v): scatter the tiles through the column map; symmetric groups deliver row <= column and the mirror image
+  auto epilogue = [&](auto vtag) {
+    constexpr int V = decltype(vtag)::value;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const int m = colmap[(4 * (LV0 + jt) + e) * 16 + li];
+      const bool live = m >= 0;
+      const int g = live ? m >> 8 : 0, jj = m & 255;
+      const int ld = grp[g].ld;
+      const bool sym = grp[g].sym != 0;
+      double* base = grp[g].dst + (long)s * grp[g].sstride;
+      double* base_t = grp[g].dst_t ? grp[g].dst_t + (long)s * grp[g].sstride : nullptr;
+#pragma unroll
+      for (int i = 0; i < LV::cls(LV0 + jt, V); ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i * 16 + lk + 4 * r;
+          const double val = acc[LV::slots_before(ROLE, V, jt) + i][r];
+          if (live && row < N && (!sym || row <= jj)) {
+            base[(long)row * ld + jj] = val;
+            if (sym && row < jj) base[(long)jj * ld + row] = val;
+            if (base_t) base_t[(long)jj * ld + row] = val;
+          }
+        }
+      }
+    }
+  };
+  if (ROLE == 0 || e < 2) epilogue(F1wV<0>{});
+  else epilogue(F1wV<1>{});
+}
+
+__global__ __launch_bounds__(512, 2) void k_f1w(Tmpl t, F1Args a, GrpTable gt, const double* __restrict__ Wab) {
+  constexpr int NTX = 3, NTYS = F1wPlan::NL;
+  constexpr int LDX = padded_ld(NTX);
+  constexpr int LDY = 4 * NTYS * 16 + 16;
+  __shared__ double Xs[2 * 3 * EC * LDX];
+  __shared__ double Zs[2 * 2 * EC * LDX];
+  __shared__ double Ys[2 * 3 * EC * LDY];
+  __shared__ double red[EC * 64];
+  __shared__ int colmap[4 * NTYS * 16];
+  __shared__ Grp grp[F1_MAXG];
+  __shared__ int flag;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int g = 0; g < F1_MAXG; ++g)
+    if (tid == g) grp[g] = gt.g[g];
+  for (int i = tid; i < 2 * 3 * EC * LDX; i += 512) Xs[i] = 0.0;
+  for (int i = tid; i < 2 * 2 * EC * LDX; i += 512) Zs[i] = 0.0;
+  for (int i = tid; i < 2 * 3 * EC * LDY; i += 512) Ys[i] = 0.0;
+  for (int i = tid; i < 4 * NTYS * 16; i += 512) colmap[i] = -1;
+  if (tid < EC * 64) red[tid] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < gt.n * a.N; i += 512) {
+    const int g = i / a.N, c = i - g * a.N;
+    colmap[grp[g].cb[c >> 4] + (c & 15)] = (g << 8) | c;
+  }
+  __syncthreads();
+  if (uniform(tid >> 6) < EC)
+    f1w_body<0>(t, a, Wab, Xs, Zs, Ys, red, &flag, colmap, grp);
+  else
+    f1w_body<1>(t, a, Wab, Xs, Zs, Ys, red, &flag, colmap, grp);
+  if (gridDim.z == 1 && a.rhs_red != nullptr) {
+    __syncthreads();
+    if (tid < a.N) {
+      double sum = 0.0;
+      for (int w = 0; w < EC; ++w) sum += red[w * 64 + tid];
+      a.rhs_red[(long)subdomain_of(t, blockIdx.x) * a.N + tid] = sum;
+    }
+  }
+}
+
 // Zeroes every output of k_f1 (the destination blocks of its column groups and rhs_red) before a K-split launch.
 __global__ __launch_bounds__(256) void k_f1_zero(GrpTable gt, int S, int N, double* __restrict__ rhs_red, const int* __restrict__ sub_list) {
   const int s = sub_list ? sub_list[blockIdx.x] : blockIdx.x;
@@ -3445,7 +3919,8 @@ int64_t fused_work_size(lrbms_ctx* ctx, int Q, int N) {
   const Tmpl& t = ctx->t;
   const long nvs = t.nvx > t.nvy ? t.nvx : t.nvy;
   return (long)ctx->S * t.nrt * Q * N + (long)ctx->S * 4 * t.ncf * Q * N + (long)ctx->S * t.nv * N + (long)ctx->S * 4 * nvs * N +
-         (long)ctx->S * 4 * t.ncf * fside_ld(Q, N);   // side factors of the dense layout (the factored layout returns them)
+         (long)ctx->S * 4 * t.ncf * fside_ld(Q, N) +   // side factors of the dense layout (the factored layout returns them)
+         (long)Q * ctx->S * t.nT * 6;                  // W'^q_T, the rank-2 factors of the df_ab element blocks (k_prep_lds -> k_f1w)
 }
 
 int64_t fused_fside_size(lrbms_ctx* ctx, int Q, int N) { return (long)ctx->S * 4 * ctx->t.ncf * fside_ld(Q, N); }
@@ -3506,6 +3981,28 @@ __global__ __launch_bounds__(256) void k_build_tables(Tmpl t, double* __restrict
     double* mass9 = stiff + 9 * t.nT;
     const double m = t.area[i] * (1.0 / 12.0);
     for (int k = 0; k < 9; ++k) mass9[i * 9 + k] = (k % 4 == 0) ? m + m : m;
+    // rank-2 factors of the element blocks that act through the gradients (k_f1w): kappa = L L^T (lower Cholesky factor of the
+    // symmetrised tensor), Z = L^T G and H = L^-1 (G G^T)^-1 G with G = [g_0 g_1 g_2] (2 x 3)
+    double* lgz = stiff + 27 * t.nT + 64;
+    double* hab = lgz + 6 * t.nT;
+    const double ksym = 0.5 * (t.kappa[1] + t.kappa[2]);
+    const double l00 = sqrt(t.kappa[0]), l10 = ksym / l00, l11 = sqrt(t.kappa[3] - l10 * l10);
+    double gx[3], gy[3], m00 = 0.0, m01 = 0.0, m11 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      gx[k] = t.grad[(i * 3 + k) * 2];
+      gy[k] = t.grad[(i * 3 + k) * 2 + 1];
+      m00 += gx[k] * gx[k];
+      m01 += gx[k] * gy[k];
+      m11 += gy[k] * gy[k];
+    }
+    const double det = m00 * m11 - m01 * m01;
+    for (int k = 0; k < 3; ++k) {
+      lgz[i * 6 + k] = l00 * gx[k] + l10 * gy[k];
+      lgz[i * 6 + 3 + k] = l11 * gy[k];
+      const double ux = (m11 * gx[k] - m01 * gy[k]) / det, uy = (m00 * gy[k] - m01 * gx[k]) / det;      // (G G^T)^-1 g_k
+      hab[i * 6 + k] = ux / l00;                                                                            // L^-1 u: forward substitution
+      hab[i * 6 + 3 + k] = (uy - l10 * (ux / l00)) / l11;
+    }
   }
   for (int k = i; k < 9 * t.nT + 64; k += gridDim.x * blockDim.x) stiff[18 * t.nT + k] = 0.0;
   if (i < 4 * t.ntouch) {
@@ -3537,7 +4034,7 @@ int build_template_tables(lrbms_ctx* ctx) {
   Tmpl& t = ctx->t;
   double* stiff = nullptr;
   int *tvtx = nullptr, *tpos = nullptr, *tmask = nullptr;
-  LRBMS_HIP_CHECK(ctx, hipMalloc(&stiff, sizeof(double) * (27 * (size_t)t.nT + 64)));   // stiff | mass9 | zeros [9 nT + 64]
+  LRBMS_HIP_CHECK(ctx, hipMalloc(&stiff, sizeof(double) * (39 * (size_t)t.nT + 64)));   // stiff | mass9 | zeros [9 nT + 64] | lgz [6 nT] | hab [6 nT]
   ctx->owned.push_back(stiff);
   LRBMS_HIP_CHECK(ctx, hipMalloc(&tvtx, sizeof(int) * 12 * (size_t)t.ntouch));
   ctx->owned.push_back(tvtx);
@@ -3562,6 +4059,8 @@ int build_template_tables(lrbms_ctx* ctx) {
   t.stiff = stiff;
   t.mass9 = stiff + 9 * (size_t)t.nT;
   t.zero64 = stiff + 18 * (size_t)t.nT;
+  t.lgz = stiff + 27 * (size_t)t.nT + 64;
+  t.hab = t.lgz + 6 * (size_t)t.nT;
   t.touch_vtx = tvtx;
   t.touch_pos = tpos;
   t.touch_mask = tmask;
@@ -3614,6 +4113,59 @@ static bool f1v_layout(std::vector<Grp>& groups, int N, int ntx, int lv[3]) {
   return true;
 }
 
+// W'^q_T = hab_T A_ab,T^q: one thread per (q, s, T, d, f).  Launched by lrbms_assemble_products beside Aab, and by a fused pass that
+// is handed an Aab the context holds no factors for.
+namespace {
+__global__ __launch_bounds__(256) void k_wab(Tmpl t, long total, const double* __restrict__ Aab, double* __restrict__ Wab) {
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+    const long blk = it / 6;                           // (q, s, T)
+    const int k = (int)(it - blk * 6), d = k / 3, f = k - d * 3, T = (int)(blk % t.nT);
+    const double* ab = Aab + blk * 9;
+    const double* h = t.hab + T * 6 + d * 3;
+    Wab[it] = (h[0] * ab[f] + h[1] * ab[3 + f]) + h[2] * ab[6 + f];
+  }
+}
+}  // namespace
+int launch_wab(lrbms_ctx* ctx, int Q, const double* Aab, double* Wab, hipStream_t st) {
+  const long total = (long)Q * ctx->S * ctx->t.nT * 6;
+  KScope ks(ctx, "k_wab", st);
+  hipLaunchKernelGGL(k_wab, dim3(grid_for(total)), dim3(256), 0, st, ctx->t, total, Aab, Wab);
+  LRBMS_LAUNCH_CHECK(ctx);
+  return LRBMS_OK;
+}
+
+static bool f1w_usable(lrbms_ctx* ctx, int Q, int N) { return Q == 2 && N % 2 == 0; }
+
+// Column layout of Y for k_f1w (Q = 2, three row tiles, even N in [34, 40]): the tiles of F1wPlan.  Symmetric groups of kind 3
+// (B_sys diagonal q = 0, 1, E_red, M_red; index si): block 0 -> tile si (level 0), block 1 -> tile 4 + si (level 1), the tails packed
+// into tiles 8, 9 (level 2, SIMDs 0, 1).  Symmetric groups of kind 2 (G_aa[0][0], G_aa[1][1]; index sj): block 0 -> tile 12 + sj
+// (level 3, SIMDs 0, 1), block 1 -> tile 10 + sj (level 2, SIMDs 2, 3), the tails packed into tile 14.  The unsymmetric groups
+// (G_aa[0][1], the four G_ab) contiguously from tile 15 on.  false if the shape is not the plan's.
+static bool f1w_layout(std::vector<Grp>& groups, int N, int Q) {
+  const int ntx = (N + 15) / 16, tail = N - 32;
+  if (Q != 2 || ntx != 3 || N % 2 != 0 || tail < 2 || tail > 8 || groups.size() != 11) return false;
+  int s3 = 0, s2 = 0, ui = 0;
+  for (Grp& g : groups) {
+    g.sym = (g.kind == G_SYS || g.kind == G_ENERGY || g.kind == G_MASS || (g.kind == G_AA && g.q == g.q2)) ? 1 : 0;
+    for (int j = 0; j < 4; ++j) g.cb[j] = 0;
+    if (g.sym && g.kind != G_AA) {
+      g.cb[0] = 16 * s3;
+      g.cb[1] = 16 * (4 + s3);
+      g.cb[2] = 16 * 8 + s3 * tail;
+      ++s3;
+    } else if (g.sym) {
+      g.cb[0] = 16 * (12 + s2);
+      g.cb[1] = 16 * (10 + s2);
+      g.cb[2] = 16 * 14 + s2 * tail;
+      ++s2;
+    } else {
+      for (int j = 0; j < 4; ++j) g.cb[j] = 16 * 15 + ui * N + 16 * j;
+      ++ui;
+    }
+  }
+  return s3 == 4 && s2 == 2 && ui == 5 && 16 * 15 + 5 * N <= 16 * 28;
+}
+
 // v_mfma_f64_16x16x4_f64 instructions the dense projection kernel (k_f1v / k_f1u / k_f1, whichever the launcher takes for this
 // shape and these options) executes per subdomain; 0 if the fused pass does not support the shape.  For the roofline of bench.py.
 long f1_mfma_per_subdomain(lrbms_ctx* ctx, int Q, int N) {
@@ -3631,6 +4183,8 @@ long f1_mfma_per_subdomain(lrbms_ctx* ctx, int Q, int N) {
   const bool one_slice = ng <= std::min(F1_MAXG, (4 * F1_NTY * 16) / N);
   const bool unified = (Q == 1 || Q == 2) && one_slice && ntx <= 3 && ctx->opt_f1_legacy != 1;
   int lv[3] = {0, 0, 0};
+  if (unified && ctx->opt_f1_legacy == 0 && f1w_usable(ctx, Q, N) && f1w_layout(groups, N, Q))
+    return (long)nch * 150 + (long)t.nT * (3 * ntx + Q * ntx);      // k_f1w: 18 tile rows x 3 + 48 x 2 k-steps per chunk; the two applies
   if (unified && ctx->opt_f1_legacy != 2 && N % 2 == 0 && N >= 2 && f1v_layout(groups, N, ntx, lv) && f1v_instantiated(ntx, Q, lv))
     return (long)nch * 3 * 4 * (lv[0] + 2 * lv[1] + 3 * lv[2]) + (long)t.nT * (3 * ntx + Q * ntx);      // projection + the two applies
   const int tiles = (ng * N + 15) / 16;                         // k_f1u skips the column tiles beyond the last column
@@ -3738,6 +4292,24 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   const bool gnc_fold = prep_ok && ctx->opt_prep_lds != 2 && ntx_p <= 3 && prep_lds_bytes(t, Q, N, true) <= 160 * 1024;
   const size_t prep_lds = prep_lds_bytes(t, Q, N, gnc_fold);
   const bool prep_from_lds = prep_ok && prep_lds <= 160 * 1024;
+  // the rank-2 form of the projection kernel (k_f1w; LRBMS_OPT_F1_FORM 0 only) and the factors W' it multiplies the flux rows with:
+  // those lrbms_assemble_products left with the context for this Aab, or formed here (work buffer) for any other
+  const double* Wab = nullptr;
+  bool f1w_ok = false;
+  if (ctx->opt_f1_legacy == 0 && do_a) {
+    std::vector<Grp> probe;
+    for (int i = 0; i < 11; ++i) probe.push_back({i < 2 ? G_SYS : i == 2 ? G_ENERGY : i == 3 ? G_MASS : i < 7 ? G_AA : G_AB, i == 6 ? 1 : 0, i == 5 || i == 6 ? 1 : 0});
+    f1w_ok = Q == 2 && f1w_layout(probe, N, Q);
+    if (f1w_ok) {
+      if (ctx->wab != nullptr && ctx->wab_src == Aab && ctx->wab_Q == Q) {
+        Wab = ctx->wab;
+      } else {
+        double* wloc = AvgSide + (long)S * 4 * nvs * N + (long)S * 4 * t.ncf * fside_ld(Q, N);
+        if (int rc = launch_wab(ctx, Q, Aab, wloc, st)) return rc;
+        Wab = wloc;
+      }
+    }
+  }
   if (do_prep) {
     if (prep_from_lds) {
       KScope ks(ctx, "k_prep_lds", st);
@@ -3872,8 +4444,9 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       const bool unified = (Q == 1 || Q == 2) && one_slice && ntx <= 3 && !legacy;
       // the lean form (k_f1v): even N, and one of the instantiated (row tiles, Q, column tiles per SIMD) combinations
       int lv[3] = {0, 0, 0};
-      const bool lean = unified && ctx->opt_f1_legacy != 2 && N % 2 == 0 && N >= 2 && f1v_layout(groups, N, ntx, lv) &&
-                        f1v_instantiated(ntx, Q, lv);
+      const bool lean2 = unified && f1w_ok && f1w_layout(groups, N, Q);      // the rank-2 form (config 3's shape)
+      const bool lean = lean2 || (unified && ctx->opt_f1_legacy != 2 && N % 2 == 0 && N >= 2 && f1v_layout(groups, N, ntx, lv) &&
+                                  f1v_instantiated(ntx, Q, lv));
       if (lean)
         for (int i = 0; i < gt[0].n; ++i) gt[0].g[i] = groups[g0 + i];      // with the column map filled in
       // K-split: a rank with few subdomains spreads the element range of a subdomain over up to four workgroups (k_f1u:
@@ -3924,7 +4497,12 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       }
       const dim3 grid(Sg, nsl, ksplit);
       // the timing name tells the form that ran (tests assert it; bench.py files all three under k_f1)
-      KScope ks(ctx, lean ? "k_f1v" : unified ? "k_f1u" : "k_f1", st);
+      KScope ks(ctx, lean2 ? "k_f1w" : lean ? "k_f1v" : unified ? "k_f1u" : "k_f1", st);
+      if (lean2) {
+        hipLaunchKernelGGL(k_f1w, grid, dim3(512), 0, st, t, a, gt[0], Wab);
+        LRBMS_LAUNCH_CHECK(ctx);
+        continue;
+      }
       if (lean) {
 #define LRBMS_F1V(A, B, C, D, E)                                               \
   if (ntx == A && Q == B && lv[0] == C && lv[1] == D && lv[2] == E)            \

@@ -23,6 +23,8 @@ struct Tmpl {
   const double* stiff;       // [nT][9]            K_T[i][j] = grad phi_i . kappa grad phi_j
   const double* mass9;       // [nT][9]            M_T[i][j] = |T| / 12 (1 + delta_ij)   (P1 mass block)
   const double* zero64;      // [9 nT + 64] zeros: operand lanes of k_f1v that must read 0.0 walk through here
+  const double* lgz;         // [nT][2][3]         L^T G_T (kappa = L L^T, G_T = the gradients of the three P1 shape functions): K_T = (L^T G_T)^T (L^T G_T)
+  const double* hab;         // [nT][2][3]         L^-1 (G_T G_T^T)^-1 G_T: A_ab,T = G_T^T W_T  =>  W'_T = hab_T A_ab,T = L^-1 W_T (k_f1w)
   const int* touch_vtx;      // [4][ntouch][3]     lattice vertex of local DoF i of the p-th element touching side sd
   const int* touch_pos;      // [4][ntouch][3][4]  its position along side sd', or -1 if it is not on that side
   const int* touch_mask;     // [4][ntouch]        bit sd' set if the element has a vertex on side sd'
@@ -88,6 +90,12 @@ struct lrbms_ctx {
   long ksp_part_cap = 0;
   int* ksp_ticket = nullptr;
   long ksp_ticket_cap = 0;
+  // W'^q_T = hab_T A_ab,T^q [Q][S][nT][2][3], the rank-2 factors of the df_ab element blocks k_f1w multiplies with the flux rows: written
+  // by lrbms_assemble_products beside Aab (wab_src = the Aab it belongs to); a pass that is handed another Aab forms them itself
+  double* wab = nullptr;
+  long wab_cap = 0;
+  const double* wab_src = nullptr;
+  int wab_Q = 0;
   bool diag_explicit = false;         // lrbms_set_diagonal_neighbours was called (needed with the vertex patch when S_ext > S)
   int* subset = nullptr;              // lrbms_fused_set_subset: device copy of the list (ctx-owned), subset_n == 0: no restriction
   int subset_n = 0, subset_cap = 0;
@@ -150,6 +158,7 @@ struct KScope {
 };
 
 int build_template_tables(lrbms_ctx* ctx);
+int launch_wab(lrbms_ctx* ctx, int Q, const double* Aab, double* Wab, hipStream_t st);   // fused.hip: W' = hab A_ab
 long f1_mfma_per_subdomain(lrbms_ctx* ctx, int Q, int N);   // fused.hip: executed MFMAs of the dense projection kernel
 // dense coarse level of the Krylov preconditioners (online.hip)
 int coarse_begin(lrbms_ctx* ctx, double** A0_out, hipStream_t st);

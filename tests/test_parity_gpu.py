@@ -222,13 +222,31 @@ def test_forms_of_the_projection_kernel_agree(shape, kc, N):
     V = eng.ctx.from_numpy(make_bases(eng.S, eng.t.n, N, seed=6))
     outs = {}
     try:
-        for form in (0, 2, 1):
+        for form in (0, 2, 1, 3):      # 0: the leanest form (k_f1w at N = 34 .. 40, else k_f1v), 3: k_f1v where 0 took k_f1w
             eng.ctx.set_option('f1_form', form)
+            eng.ctx.kernel_timing(True)
             buf = eng.project_and_estimate(V)
+            ran = {k for k, _ in eng.ctx.kernel_timing_read()}
+            eng.ctx.kernel_timing(False)
+            want = {0: 'k_f1w' if 34 <= N <= 40 and eng.Q == 2 else 'k_f1v', 2: 'k_f1u', 1: 'k_f1', 3: 'k_f1v'}[form]
+            assert want in ran, (form, sorted(ran))
             outs[form] = [x.clone() for x in buf['sys']] + [x.clone() for x in buf['grams']]
+        if 34 <= N <= 40 and eng.Q == 2:
+            # k_f1w multiplies the flux rows with W' = hab A_ab, which lrbms_assemble_products leaves with the context for ITS Aab; a
+            # pass that is handed any other array forms the factors itself (k_wab) -- the same bits
+            eng.ctx.set_option('f1_form', 0)
+            eng.Aab = eng.Aab.clone()
+            eng.__dict__.pop('_bound_pass', None)
+            eng.ctx.kernel_timing(True)
+            buf = eng.project_and_estimate(V)
+            ran = {k for k, _ in eng.ctx.kernel_timing_read()}
+            eng.ctx.kernel_timing(False)
+            assert 'k_wab' in ran and 'k_f1w' in ran, sorted(ran)
+            for a, b in zip(outs[0], list(buf['sys']) + list(buf['grams'])):
+                assert torch.equal(a, b)
     finally:
         eng.ctx.set_option('f1_form', 0)
-    for form in (2, 1):
+    for form in (2, 1, 3):
         for a, b in zip(outs[0], outs[form]):
             assert float((a - b).abs().max()) <= 1e-12 * float(a.abs().max()), form
     B_sys, rhs_red, E_red, M_red = outs[0][:4]
@@ -326,8 +344,8 @@ def test_vertex_patch_of_the_oswald_interpolation(shape, kc, N):
 def test_launch_matrix_against_one_oracle_checked_result():
     """Every launch combination of the fused pass against ONE result that is itself compared with the oracle: layout {factored,
     dense} x launch policy {one stream, forked over the library streams} x preparation {streaming sweeps + k_f3, LDS slab with the
-    G_nc fold, LDS slab without it} x projection kernel {k_f1v, k_f1 (producer / consumer), k_f1u} x {whole pass, phase 1 then
-    phase 2}: 72 cells on a 5 x 4 grid of the config-3 template (k_c = 4, N = 40).  Outputs AND the work buffer are poisoned with NaN
+    G_nc fold, LDS slab without it} x projection kernel {k_f1w, k_f1 (producer / consumer), k_f1u, k_f1v} x {whole pass, phase 1 then
+    phase 2}: 96 cells on a 5 x 4 grid of the config-3 template (k_c = 4, N = 40).  Outputs AND the work buffer are poisoned with NaN
     in front of every cell, so a cell that forgets a launch (round 3: k_vertex_side in factored x unforked x phase 2) cannot pass on
     what the cell before left behind.  Reference: the unfused kernels' result, compared with the oracle's reductor at 1e-11; every
     cell against it at 1e-12 (dense-layout arrays; factored cells expanded)."""
@@ -351,7 +369,7 @@ def test_launch_matrix_against_one_oracle_checked_result():
     bufs = {True: eng.alloc_reduce_buffers(N, factored=True), False: eng.alloc_reduce_buffers(N, factored=False)}
     failures, seen = [], set()
     try:
-        for factored, streams, prep, form, phased in itertools.product((True, False), (0, 1), (0, 1, 2), (0, 1, 2), (False, True)):
+        for factored, streams, prep, form, phased in itertools.product((True, False), (0, 1), (0, 1, 2), (0, 1, 2, 3), (False, True)):
             eng.ctx.set_option('streams', streams)
             eng.ctx.set_option('prep_lds', prep)
             eng.ctx.set_option('f1_form', form)
@@ -377,7 +395,7 @@ def test_launch_matrix_against_one_oracle_checked_result():
             eng.ctx.set_option(k, v)
     assert not failures, failures[:12]
     # the matrix did reach every kernel variant it is meant to enumerate
-    for k in ('k_f1v', 'k_f1u', 'k_f1', 'k_prep_lds', 'k_prep_lds<side>', 'k_prep', 'k_prep_side', 'k_flux_compact', 'k_vertex_avg',
+    for k in ('k_f1w', 'k_f1v', 'k_f1u', 'k_f1', 'k_prep_lds', 'k_prep_lds<side>', 'k_prep', 'k_prep_side', 'k_flux_compact', 'k_vertex_avg',
               'k_flux_side', 'k_vertex_side', 'k_f2', 'k_f3', 'k_thin3', 'k_thin', 'k_thin_nc', 'k_thin_rt', 'k_coupling', 'k_thin_expand'):
         assert k in seen, (k, sorted(seen))
 

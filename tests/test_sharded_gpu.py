@@ -141,7 +141,7 @@ def _worker(rank, world, port, ref_path, shape, results):
             for mode, names_ran in ran.items():
                 if mode == 'False':
                     continue
-                ok &= 'k_f1v' in names_ran and 'k_f1u' not in names_ran and 'k_f1' not in names_ran
+                ok &= 'k_f1w' in names_ran and 'k_f1v' not in names_ran and 'k_f1u' not in names_ran and 'k_f1' not in names_ran
                 if 'streaming' in mode:
                     ok &= 'k_prep_lds' not in names_ran and ('k_flux_side' in names_ran or 'k_prep_side' in names_ran)
                 else:
