@@ -383,7 +383,7 @@ def main():
         eng.ctx.kernel_timing(False)
         kernel_ms = {}
         for name, ms in rows:
-            kernel_ms.setdefault({'k_f1v': 'k_f1', 'k_f1u': 'k_f1'}.get(name, name), []).append(ms)   # the forms of one step
+            kernel_ms.setdefault({'k_f1w': 'k_f1', 'k_f1v': 'k_f1', 'k_f1u': 'k_f1'}.get(name, name), []).append(ms)   # the forms of one step
         kernel_ms = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
 
     # the same pass writing the DENSE block-compact layout (G_rdd / G_bb [S][9][QN][QN], G_nc [S][5N][5N]: what rd.operators hands a

@@ -24,7 +24,7 @@ for d in sys.argv[3:]:
     for r in csv.DictReader(open(f)):
         m = re.search(r'(k_[a-z0-9_]+)', r['Kernel_Name'])
         k = m.group(1) if m else r['Kernel_Name'][:24]
-        k = {'k_f1u': 'k_f1', 'k_f1v': 'k_f1'}.get(k, k)   # the forms of the projection kernel are the same step of the pass (bench.py: k_f1)
+        k = {'k_f1u': 'k_f1', 'k_f1v': 'k_f1', 'k_f1w': 'k_f1'}.get(k, k)   # the forms of the projection kernel are the same step of the pass (bench.py: k_f1)
         if r['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
             tot[k][r['Counter_Name']] += float(r['Counter_Value'])
             calls[(k, r['Counter_Name'])] += 1
