@@ -240,7 +240,8 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
  *       reproduces the nonconformity value the reference prints (linearelliptic_block_swipdg_decomp.py:41: 1.66e-01).
  *       Factored layout of the fused pass only (rows of F_nc grow by N columns, lrbms_fused_fnc_ld); the dense layout and the
  *       unfused kernels have five slots per neighbourhood and refuse it.  Sharded grids (S_ext > S): the diagonal subdomains must
- *       be halo slabs and lrbms_set_diagonal_neighbours must name them */
+ *       be halo slabs and lrbms_set_diagonal_neighbours must name them.  Frozen once a fused pass has run on the context
+ *       (LRBMS_E_STATE): it decides the row length of F_nc buffers the caller has sized */
 #define LRBMS_OPT_OSWALD_VERTEX_PATCH 9
 #define LRBMS_OPT_OSWALD_ZERO_ON_SUBDOMAIN_BOUNDARY 1
 #define LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q 2

@@ -107,7 +107,7 @@ def _operands(line):
     return parts[0], [t.strip() for t in re.split(r'[,\s]+', parts[1]) if t.strip()]
 
 
-def _inflight_register_hazards(lines, tags, region=None, max_states=400000):
+def _inflight_register_hazards(lines, tags, region=None, max_states=400000, prologue_of=None):
     """An asm-managed load writes its destination VGPRs some hundred cycles after it was issued, and the compiler does not know:
     between the load and the ``s_waitcnt vmcnt(n)`` that completes it, no instruction the COMPILER emitted may read or write
     those registers (a copy, a live-range split, an early use would see stale data).  Exact, path-sensitive walk
@@ -116,7 +116,12 @@ def _inflight_register_hazards(lines, tags, region=None, max_states=400000):
     ``vmcnt(n)`` only the n youngest are pending), every (block, state) pair is visited once.  ``region``: the line indices of ONE
     loop (as _producer_loops returns them) -- the walk starts at its header with nothing in flight and never leaves it; the
     straight-line tail rounds behind the unrolled loops are copies of its rounds guarded by correlated branches (c < nchunks, ++c)
-    that a CFG walk cannot correlate, so they are not walked.  Returns a sorted list of offending instructions."""
+    that a CFG walk cannot correlate, so they are not walked.  Returns a sorted list of offending instructions.
+    ``prologue_of`` (a set of line indices: all producer loops of the function; with ``region=None``): walk from the function's entry
+    instead -- the asm loads of the prologue (``load_set`` in front of a staging loop) are in flight when the loop is entered -- and
+    give a path up where it stands inside a producer loop with nothing in flight (from there on the per-loop walks apply).  Catches
+    what round 4 hit in k_f1w: with the prologue's loads live across a wave-uniform branch hipcc moved the set's registers on the
+    out-of-line side, in front of the first vmcnt(0)."""
     inside = set(region) if region is not None else None
     starts = sorted({0} | {i for i, ln in enumerate(lines) if re.match(r'^\.LBB\d+_\d+:', ln)})
     label_at = {}
@@ -176,15 +181,21 @@ def _inflight_register_hazards(lines, tags, region=None, max_states=400000):
         pending = list(state)
         ev, succ = blocks[b]
         live = frozenset().union(*pending) if pending else frozenset()
+        settled = False
         for e in ev:
             if e[0] == 'W':
                 pending = pending[len(pending) - e[1]:] if e[1] else []
                 live = frozenset().union(*pending) if pending else frozenset()
+                if prologue_of is not None and not pending and b in prologue_of:
+                    settled = True      # inside a staging loop with nothing in flight: the per-loop walk covers the rest
+                    break
             elif e[0] == 'L':
                 pending = (pending + [e[1]])[-63:]      # vmcnt is a 6-bit counter
                 live = live | e[1]
             elif live and e[1] & live:
                 bad.add(e[2])
+        if settled:
+            continue
         out = tuple(pending)
         for t in succ:
             if (t, out) not in seen:
@@ -242,6 +253,17 @@ def check_fused_isa(asm_path):
             problems.append('{}: no producer loop with asm-managed prefetch found'.format(kernel))
             continue
         seen += 1
+        if lean:
+            # the prologue: from the function's entry up to the first completed wait inside a staging loop
+            loop_blocks = set()
+            starts_all = sorted({0} | {i for i, ln in enumerate(lines) if re.match(r'^\.LBB\d+_\d+:', ln)})
+            for idx in loops:
+                members = set(idx)
+                loop_blocks |= {b for b in starts_all if b in members}
+            hz = _inflight_register_hazards(lines, tags, region=None, prologue_of=loop_blocks)
+            if hz:
+                problems.append('{}: compiler-emitted instruction touches the destination of an asm load of the PROLOGUE still in flight: {}'.format(
+                    kernel, hz[:3]))
         for idx in loops:
             hazards = _inflight_register_hazards(lines, tags, region=idx)
             if hazards:

@@ -172,7 +172,12 @@ int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value) {
   switch (option) {
     case LRBMS_OPT_OSWALD_ZERO_ON_SUBDOMAIN_BOUNDARY: ctx->t.opt_oswald_subdomain = value; break;
     case LRBMS_OPT_ACCUMULATE_COUPLING_ACROSS_Q: ctx->t.opt_accumulate_coupling = value; break;
-    case LRBMS_OPT_OSWALD_VERTEX_PATCH: ctx->t.opt_oswald_vertex = value; break;
+    case LRBMS_OPT_OSWALD_VERTEX_PATCH:
+      // the option changes lrbms_fused_fnc_ld, i.e. the shape of F_nc buffers a caller may already have sized
+      if (ctx->pass_ran && ctx->t.opt_oswald_vertex != value)
+        return lrbms_fail(ctx, LRBMS_E_STATE, "set_option: LRBMS_OPT_OSWALD_VERTEX_PATCH cannot change after a fused pass has run on this context");
+      ctx->t.opt_oswald_vertex = value;
+      break;
     case LRBMS_OPT_STREAMS: ctx->opt_streams = value; break;
     case LRBMS_OPT_F1_KSPLIT: ctx->opt_f1_ksplit = value; break;
     case LRBMS_OPT_F1_FORM: ctx->opt_f1_legacy = value; break;
@@ -338,6 +343,7 @@ int lrbms_mesh_upload(lrbms_ctx* ctx, const lrbms_mesh_desc* d, int32_t S, int32
   }
   ctx->subset_n = 0;
   ctx->wab_src = nullptr;      // (factors of another mesh)
+  ctx->pass_ran = false;
   ctx->S = S;
   ctx->S_ext = S_ext;
   if ((rc = build_template_tables(ctx))) return rc;

@@ -4245,6 +4245,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // k_f3), so that a host can record an event between them and start phase 2 on another stream as soon as the halo has
   // arrived, while the dense kernels are still running (Engine.project_and_estimate with `halo=`).
   if (phase < 0 || phase > 4) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: phase must be 0 .. 4");
+  ctx->pass_ran = true;
   const bool do_prep = phase == 0 || phase == 1 || phase == 3;
   const bool do_a = phase == 0 || phase == 1 || phase == 4;      // the dense, halo-independent kernels
   const bool do_b = phase == 0 || phase == 2;

@@ -96,6 +96,7 @@ struct lrbms_ctx {
   long wab_cap = 0;
   const double* wab_src = nullptr;
   int wab_Q = 0;
+  bool pass_ran = false;              // a fused pass has run: conventions that change buffer shapes (the vertex patch: F_nc rows) are frozen
   bool diag_explicit = false;         // lrbms_set_diagonal_neighbours was called (needed with the vertex patch when S_ext > S)
   int* subset = nullptr;              // lrbms_fused_set_subset: device copy of the list (ctx-owned), subset_n == 0: no restriction
   int subset_n = 0, subset_cap = 0;
