@@ -726,7 +726,7 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
       const int row = 16 * ti + (ln >> 4) + 4 * r, col = 16 * tj + (ln & 15);
       if (row < N && col < N) {
         g[(long)row * ga.gld + col] = sum;
-        if (ti != tj) g[(long)col * ga.gld + row] = sum;      // mirror: the stored operator is exactly symmetric
+        if (ti != tj) g[(long)col * ga.gld + row] = sum;      // mirror: exactly symmetric across the off-diagonal tiles (inside a diagonal tile both halves are sums of their own: symmetric to rounding)
       }
     }
   }
@@ -2945,7 +2945,7 @@ __global__ __launch_bounds__(64 * (F2_NCW + EC)) void k_f2(Tmpl t, F2Args a) {
         if (col < QN && row < QN) {
           gb[(long)row * QN + col] = vb;
           gd[(long)row * QN + col] = vd;
-          if (ti[k] != tj[k]) {                    // mirror: the stored operator is exactly symmetric
+          if (ti[k] != tj[k]) {                    // mirror: exactly symmetric across the off-diagonal tiles (inside a diagonal tile both halves are sums of their own: symmetric to rounding)
             gb[(long)col * QN + row] = vb;
             gd[(long)col * QN + row] = vd;
           }
@@ -3067,7 +3067,7 @@ __global__ __launch_bounds__(256) void k_f3(Tmpl t, F3Args a) {
       const int row = ti[k] * 16 + lk + 4 * r;
       if (col < N && row < N) {
         g[(long)row * gld + col] = acc[k][r];
-        if (ti[k] != tj[k]) g[(long)col * gld + row] = acc[k][r];   // mirror: the stored operator is exactly symmetric
+        if (ti[k] != tj[k]) g[(long)col * gld + row] = acc[k][r];   // mirror: exactly symmetric across the off-diagonal tiles (inside a diagonal tile both halves are sums of their own: symmetric to rounding)
       }
     }
   }
@@ -4293,6 +4293,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   const bool gnc_fold = prep_ok && ctx->opt_prep_lds != 2 && ntx_p <= 3 && prep_lds_bytes(t, Q, N, true) <= 160 * 1024;
   const size_t prep_lds = prep_lds_bytes(t, Q, N, gnc_fold);
   const bool prep_from_lds = prep_ok && prep_lds <= 160 * 1024;
+  bool side_from_lds = false;      // phase 2: k_prep_lds<side> wrote R_side AND Avg_side
   // the rank-2 form of the projection kernel (k_f1w; LRBMS_OPT_F1_FORM 0 only) and the factors W' it multiplies the flux rows with:
   // those lrbms_assemble_products left with the context for this Aab, or formed here (work buffer) for any other
   const double* Wab = nullptr;
@@ -4351,7 +4352,10 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     // (recorded below, where the fork event of a forked call -- the same point of the stream -- serves as well)
   } else if (do_b) {
     LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->prep_done ? ctx->prep_done : ctx->ev_prep, 0));      // (a no-op if never recorded / same stream)
-    if (prep_ok && prep_lds_bytes(t, Q, N, false) - prep_lds_slab_bytes(t, N, false) <= 64 * 1024) {
+    // (the same predicate as the whole pass and phase 1: where THEY prepare by the streaming sweeps -- a slab beyond the LDS -- the
+    // neighbours' shares come from the streaming code too, so "1 then 2 == 0" compares one code with itself)
+    if (prep_from_lds && prep_lds_bytes(t, Q, N, false) - prep_lds_slab_bytes(t, N, false) <= 64 * 1024) {
+      side_from_lds = true;
       // the neighbours' shares by the side threads' code of k_prep_lds in its slab-less form (one 256-thread workgroup per subdomain,
       // per-vertex data and row tables resolved once per workgroup; several workgroups per CU, so it also fits beside the dense
       // kernels) -- bit-identical to the whole pass by construction
@@ -4588,7 +4592,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   }
   if (do_b && !merge_thin) {
     hipStream_t side = s_nc;
-    if (!do_prep && !merge_prep) {
+    if (!do_prep && !merge_prep && !side_from_lds) {
       KScope ks(ctx, "k_vertex_side", side);
       hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)Sg * 4 * nvs * N)), dim3(256), 0, side, t, S, ctx->nbr, N, V, AvgSide);
     }

@@ -2036,13 +2036,31 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
     LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
     for (int k = 1; k < ng; ++k) LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(g[k].st, ctx->ev_fork, 0));
   }
-  auto join = [&]() -> int {                             // every return below leaves the side streams joined into the caller's
+  auto join = [&]() -> int {                             // the side streams joined into the caller's
     for (int k = 1; k < ng; ++k) {
       LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[k - 1], g[k].st));
       LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_join[k - 1], 0));
     }
     return LRBMS_OK;
   };
+  // every EARLY return below (a failed HIP call between the fork and the join) leaves through this guard: the group streams are
+  // drained -- their asynchronous copies target `host` in this stack frame -- and joined into the caller's stream, which the
+  // fused pass and the next call share with them
+  struct ExitGuard {
+    lrbms_ctx* ctx;
+    hipStream_t st;
+    hipStream_t gs[4];
+    int ng;
+    bool armed;
+    ~ExitGuard() {
+      if (!armed) return;
+      for (int k = 0; k < ng; ++k) (void)hipStreamSynchronize(gs[k]);
+      for (int k = 1; k < ng; ++k) {
+        (void)hipEventRecord(ctx->ev_join[k - 1], gs[k]);
+        (void)hipStreamWaitEvent(st, ctx->ev_join[k - 1], 0);
+      }
+    }
+  } guard{ctx, st, {g[0].st, ng > 1 ? g[1].st : st, ng > 2 ? g[2].st : st, ng > 3 ? g[3].st : st}, ng, true};
   auto update = [&](Group& G, int first) {
     const size_t lds_upd = sizeof(double) * 3 * (size_t)N * G.nm;
     if (use_mfma && GW == 64)
@@ -2151,6 +2169,7 @@ int launch_reduced_solve_batch(lrbms_ctx* ctx, int Q, int N, int nmu, const doub
     }
   LRBMS_LAUNCH_CHECK(ctx);
   if (int jrc = join()) return jrc;
+  guard.armed = false;
   int it = 0;
   double rel = 0.0;
   for (int k = 0; k < ng; ++k) {
