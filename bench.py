@@ -618,6 +618,11 @@ def main():
         elif kernel_ms and roofline.get('dominant_kernel', {}).get('mfma_TFLOPs'):
             roofline['achieved'] = roofline['dominant_kernel']['mfma_TFLOPs']
             roofline['frac'] = roofline['dominant_kernel']['mfma_frac']
+        # the pass as a whole against the matrix peak: every executed fp64-MFMA flop (the dense kernels, the G_nc fold of the
+        # preparation kernel; padding included, as the library counts them) over the time of the whole pass
+        pass_flops = sum(f for k, (r, w, f) in model.items() if f and (kernel_ms is None or k in kernel_ms))
+        roofline['pass_executed_mfma_flops'] = pass_flops
+        roofline['pass_mfma_frac'] = pass_flops / dev_s_per_step / 1e12 / PEAK_FP64_MFMA_TFLOPS
         out = {'metric': 'offline project+estimate throughput', 'value': value, 'unit': 'subdomains/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
