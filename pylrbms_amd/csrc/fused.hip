@@ -347,20 +347,6 @@ __global__ __launch_bounds__(256) void k_vertex_avg(Tmpl t, int S, const int* __
                   V + (long)s * t.n * N);   // grid (S, chunks of n_v * N)
 }
 
-// both preparation sweeps in one launch: grid (S, gy_flux + gy_vtx)
-__global__ __launch_bounds__(256) void k_prep(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
-                                              const double* __restrict__ F, const double* __restrict__ V,
-                                              double* __restrict__ Rself, double* __restrict__ Rside,
-                                              double* __restrict__ AvgSelf, double* __restrict__ AvgSide, int write_side,
-                                              int gy_flux) {
-  const int s = subdomain_of(t, blockIdx.x);
-  if ((int)blockIdx.y < gy_flux)
-    flux_compact_body(t, S, nbr, Q, N, F, V, Rself, Rside, write_side, s, blockIdx.y, gy_flux, V + (long)s * t.n * N);
-  else
-    vertex_avg_body(t, S, nbr, N, V, AvgSelf, AvgSide, write_side, s, blockIdx.y - gy_flux, gridDim.y - gy_flux,
-                    V + (long)s * t.n * N);
-}
-
 // Both preparation sweeps from ONE copy of the subdomain's basis slab in LDS (round 3).  The streaming sweeps above are bound by
 // memory latency, not bandwidth: every item waits for a chain of dependent loads (row tables -> coefficients / basis rows), and
 // every basis row is fetched ~3 times by the flux sweep and ~twice by the vertex averages through L1 / L2.  Here one workgroup
@@ -776,16 +762,6 @@ __device__ __forceinline__ void vertex_side_body(const Tmpl& t, int S, const int
 __global__ __launch_bounds__(256) void k_vertex_side(Tmpl t, int S, const int* __restrict__ nbr, int N,
                                                      const double* __restrict__ V, double* __restrict__ AvgSide) {
   vertex_side_body(t, S, nbr, N, V, AvgSide, blockIdx.x, gridDim.x);
-}
-
-// both halo-dependent preparation sweeps in one launch: 1-D grid, the first gx_flux workgroups take R_side
-__global__ __launch_bounds__(256) void k_prep_side(Tmpl t, int S, const int* __restrict__ nbr, int Q, int N,
-                                                   const double* __restrict__ F, const double* __restrict__ V,
-                                                   double* __restrict__ Rside, double* __restrict__ AvgSide, int gx_flux) {
-  if ((int)blockIdx.x < gx_flux)
-    flux_side_body(t, S, nbr, Q, N, F, V, Rside, blockIdx.x, gx_flux);
-  else
-    vertex_side_body(t, S, nbr, N, V, AvgSide, blockIdx.x - gx_flux, gridDim.x - gx_flux);
 }
 
 // Oswald interpolation error rows of one element, one column: slot 2 = own basis, other slots = neighbour images
@@ -4071,8 +4047,9 @@ int build_template_tables(lrbms_ctx* ctx) {
 }
 
 // (row tiles, Q, levels with 1 / 2 / 3 live row tiles) combinations of the lean projection kernel k_f1v that are compiled in;
-// everything else runs k_f1u.  Q = 2: N = 36 .. 40 (config 3), N = 34, N = 20 (config 2).
-#define LRBMS_F1V_LIST(X) X(3, 2, 1, 2, 4) X(3, 2, 1, 2, 3) X(2, 2, 1, 3, 0)
+// everything else runs k_f1u.  Q = 2, N = 20 (config 2).  (Round 3 also compiled <3,2,1,2,4> and <3,2,1,2,3> for N = 34 .. 40: that
+// shape is k_f1w's now -- the rank-2 form, same structure, 26 % fewer projection MFMAs -- and the two instantiations are retired.)
+#define LRBMS_F1V_LIST(X) X(2, 2, 1, 3, 0)
 static bool f1v_instantiated(int ntx, int Q, const int lv[3]) {
 #define LRBMS_F1V_HAS(A, B, C, D, E) if (ntx == A && Q == B && lv[0] == C && lv[1] == D && lv[2] == E) return true;
   LRBMS_F1V_LIST(LRBMS_F1V_HAS)
@@ -4285,7 +4262,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // (k_prep only there: at 1 024 subdomains it takes 182 us against 113 + 59 us for the two sweeps on their own)
   // factored layout: the three thin kernels are 256-thread workgroups and always share one launch (k_thin3: 141 us at
   // 1 024 subdomains against 65 + 49 + 41 us one after the other -- they are latency-bound and fill each other's gaps)
-  const bool merge_prep = forked, merge_thin = forked || factored;
+  const bool merge_thin = forked || factored;
   // LRBMS_OPT_PREP_LDS: the preparation sweeps from one copy of the basis slab in LDS; with it G_nc[self, self] is folded into the same
   // kernel (k_f3 is not launched) whenever N <= 48 and the call covers both the preparation and the dense kernels
   const int ntx_p = (N + 15) / 16;
@@ -4333,11 +4310,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       else if (ntx_p == 2) LRBMS_PREP(2);
       else LRBMS_PREP(3);
 #undef LRBMS_PREP
-    } else if (merge_prep) {
-      KScope ks(ctx, "k_prep", st);
-      hipLaunchKernelGGL(k_prep, dim3(Sg, gy_flux + gy_vtx), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
-                         AvgSide, phase == 0 ? 1 : 0, gy_flux);
-    } else {
+    } else {      // (odd N, or a slab beyond the LDS: the two streaming sweeps, at every subdomain count -- their merged form k_prep is retired)
       {
         KScope ks(ctx, "k_flux_compact", st);
         hipLaunchKernelGGL(k_flux_compact, dim3(Sg, gy_flux), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside,
@@ -4364,10 +4337,6 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       const size_t side_lds = prep_lds_bytes(t, Q, N, false) - prep_lds_slab_bytes(t, N, false);      // tables + coefficients: no slab
       hipLaunchKernelGGL((k_prep_lds<1, 256>), dim3(Sg, 1), dim3(256), side_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
                          AvgSide, 2, ga);
-    } else if (merge_prep) {
-      const unsigned gxf = grid_for((long)Sg * 4 * t.ncf * N), gxv = grid_for((long)Sg * 4 * nvs * N);
-      KScope ks(ctx, "k_prep_side", st);
-      hipLaunchKernelGGL(k_prep_side, dim3(gxf + gxv), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside, AvgSide, (int)gxf);
     } else {
       {
         KScope ks(ctx, "k_flux_side", st);
@@ -4377,7 +4346,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       // layout the reader is k_thin3, which is launched from the merged branch -- so it goes out here.  (Round 3: it went out
       // NOWHERE in that combination -- factored layout, >= 192 subdomains per rank, phase 2 -- and the phased-vs-whole test did not
       // see it because it reused a work buffer that still held the averages of the whole pass.)
-      if (merge_thin) {
+      if (merge_thin) {      // (forked or factored: the reader is k_thin / k_thin3)
         KScope ks(ctx, "k_vertex_side", st);
         hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)Sg * 4 * nvs * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSide);
       }
@@ -4592,7 +4561,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   }
   if (do_b && !merge_thin) {
     hipStream_t side = s_nc;
-    if (!do_prep && !merge_prep && !side_from_lds) {
+    if (!do_prep && !side_from_lds) {
       KScope ks(ctx, "k_vertex_side", side);
       hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)Sg * 4 * nvs * N)), dim3(256), 0, side, t, S, ctx->nbr, N, V, AvgSide);
     }

@@ -143,7 +143,7 @@ def _worker(rank, world, port, ref_path, shape, results):
                     continue
                 ok &= 'k_f1w' in names_ran and 'k_f1v' not in names_ran and 'k_f1u' not in names_ran and 'k_f1' not in names_ran
                 if 'streaming' in mode:
-                    ok &= 'k_prep_lds' not in names_ran and ('k_flux_side' in names_ran or 'k_prep_side' in names_ran)
+                    ok &= 'k_prep_lds' not in names_ran and 'k_flux_side' in names_ran and 'k_vertex_side' in names_ran
                 else:
                     ok &= 'k_prep_lds' in names_ran and 'k_f3' not in names_ran
                     if mode != 'True':

@@ -2,7 +2,7 @@
 kernel of the pass (the last complete pass in the trace).  usage: python tools/pass_timeline.py TRACE.csv [first-kernel-prefix]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-first = sys.argv[2] if len(sys.argv) > 2 else 'k_prep'
+first = sys.argv[2] if len(sys.argv) > 2 else 'k_prep_lds'
 ks = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:40], r.get('Stream_Id', r.get('Queue_Id', '?'))) for r in rows]
 ks.sort()
 starts = [i for i, k in enumerate(ks) if k[2].startswith(first)]

@@ -32,7 +32,7 @@ print('{:24s} {:>6s} {:>18s} {:>18s}'.format('kernel', 'calls', 'FETCH_SIZE MiB/
 sf = sw = 0.0
 # the kernels of ONE pass in the factored layout (the timed region of bench.py); bench.py also times the dense layout once
 # (k_thin_nc, k_thin_rt, k_coupling, k_thin_expand instead of k_thin3): listed in the table, not part of the per-pass sum
-PASS_KERNELS = ('k_flux_compact', 'k_vertex_avg', 'k_f1', 'k_f2', 'k_f3', 'k_thin3', 'k_prep', 'k_prep_lds')
+PASS_KERNELS = ('k_flux_compact', 'k_vertex_avg', 'k_f1', 'k_f2', 'k_f3', 'k_thin3', 'k_prep_lds')
 per_kernel = {}
 for k, v in sorted(tot.items()):
     nf, nw = calls[(k, 'FETCH_SIZE')], calls[(k, 'WRITE_SIZE')]
