@@ -1,4 +1,4 @@
-"""Times the fused pass whole vs in two phases on a bench config.  usage: phase_time.py CONFIG"""
+"""Times the fused pass whole vs in two phases on a bench config.  usage: phase_time.py CONFIG [name=value ...]   (context options)"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -10,6 +10,9 @@ p = multiscale_problem.init_grid_and_problem({'num_subdomains': cfg['num_subdoma
 lam = p['lambda']
 tb = np.array([c.evaluate(p['mu_bar']) for c in lam['coefficients']])
 eng = Engine(p['grid'], lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], tb).assemble()
+for o in sys.argv[2:]:
+    k, v = o.split('=')
+    eng.ctx.set_option(k, int(v))
 N = cfg['N']
 V = eng.ctx.from_numpy(bench.make_bases_host(eng.local, eng.t.n, N))
 buf = eng.alloc_reduce_buffers(N)
