@@ -220,7 +220,11 @@ int lrbms_project_estimate_fused(lrbms_ctx* ctx, int32_t Q, int32_t N, const dou
  * buffers (including `work`) must be passed to both halves.  phase 3 / 4 split phase 1 into its preparation kernels and
  * its dense kernels: phase 2 depends on 3 and on the halo only, so it may run on another stream beside 4 -- and beside the dense
  * kernels of a phase-1 call: phases 1 and 3 record a library-owned event behind the preparation on their stream, and phase 2 makes
- * ITS stream wait for that event before its first kernel (the caller orders only the halo in front of phase 2). */
+ * ITS stream wait for that event before its first kernel (the caller orders only the halo in front of phase 2).
+ * phase 5 = 1 and 2 in ONE call, for a rank with few subdomains whose step is bound by the host: phase 1 goes on `stream`, phase 2 on
+ * library stream 0 (lrbms_ctx_aux_stream(ctx, 0)) BEHIND whatever the caller has queued there -- the wait for the halo exchange and
+ * its unpack -- and behind the preparation; both are joined into `stream` before the call returns (one fork and one join per step).
+ * `stream` must not be library stream 0.  The same kernels with the same arguments: bit-identical to 1 followed by 2. */
 /* The i-th (0..2) library-owned HIP stream of the context (a hipStream_t).  A host that overlaps its halo exchange with
  * the pass runs the halo-dependent phase on stream 0 (HIP multiplexes streams onto few hardware queues: a further host
  * stream may land on the queue of the caller's stream and serialise behind the dense kernels). */

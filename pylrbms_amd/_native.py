@@ -416,8 +416,8 @@ class NativeContext:
         fn = self.lib.lrbms_project_estimate_fused_factored if factored else self.lib.lrbms_project_estimate_fused_phase
         handle, cur, dev = self.handle, self.torch.cuda.current_stream, self.device
 
-        def run(phase=0, _keep=keep):
-            rc = fn(handle, phase, Q, N, *ptrs, c_vp(cur(dev).cuda_stream))
+        def run(phase=0, stream=None, _keep=keep):      # stream: a raw HIP stream handle (default: torch's current stream)
+            rc = fn(handle, phase, Q, N, *ptrs, c_vp(cur(dev).cuda_stream if stream is None else stream))
             if rc != 0:
                 self._check(rc, 'lrbms_project_estimate_fused_phase')
         return run

@@ -33,6 +33,8 @@
 // written exactly once (zeros included); all reductions have a fixed order (the 2-way K-split meets by atomic add, which
 // is order-independent for two contributions).
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "lrbms_dev.h"
@@ -4201,6 +4203,19 @@ bool fused_supported(lrbms_ctx* ctx, int Q, int N, bool factored) {
   return true;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is sticky per (device, kernel): raised once per process, not set on every launch of the
+// pass (a runtime call of ~2 us on the chain preparation -> projection kernel of every step)
+static hipError_t raise_max_lds(int device, const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> raised;
+  std::lock_guard<std::mutex> lock(mu);
+  int& cur = raised[{device, fn}];
+  if (cur >= bytes) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) cur = bytes;
+  return e;
+}
+
 int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V, const double* F, const double* A_diag,
                                   const double* A_cpl, const double* P_diag, const double* b, const double* ebar,
                                   const double* caa, const double* Aab, const double* Bbb, double* work, double* B_sys,
@@ -4221,11 +4236,18 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // phase 3 / 4: phase 1 split once more into its preparation (R_self, Avg_self) and its dense kernels (k_f1, k_f2,
   // k_f3), so that a host can record an event between them and start phase 2 on another stream as soon as the halo has
   // arrived, while the dense kernels are still running (Engine.project_and_estimate with `halo=`).
-  if (phase < 0 || phase > 4) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: phase must be 0 .. 4");
+  // phase 5: 1 and 2 in ONE call for the sharded step -- phase 1 on the caller's stream, phase 2 on library stream 0 behind whatever
+  // the caller has queued there (the wait for the halo exchange and its unpack), both joined into the caller's stream at the end:
+  // one fork and one join for the step instead of a fork / join per call and an event pair of the host's (the host side of a step is
+  // what bounds a rank with few subdomains, tools/host_step_time.py).  The same kernels with the same arguments as 1 then 2.
+  if (phase < 0 || phase > 5) return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: phase must be 0 .. 5");
+  if (phase == 5 && st == ctx->aux[0])
+    return lrbms_fail(ctx, LRBMS_E_INVALID, "fused pass: phase 5 runs its halo-dependent half on library stream 0; the caller's stream must be another one");
   ctx->pass_ran = true;
-  const bool do_prep = phase == 0 || phase == 1 || phase == 3;
-  const bool do_a = phase == 0 || phase == 1 || phase == 4;      // the dense, halo-independent kernels
-  const bool do_b = phase == 0 || phase == 2;
+  const bool both = phase == 5;
+  const bool do_prep = phase == 0 || phase == 1 || phase == 3 || both;
+  const bool do_a = phase == 0 || phase == 1 || phase == 4 || both;      // the dense, halo-independent kernels
+  const bool do_b = phase == 0 || phase == 2 || both;
   // incremental re-projection (lrbms_fused_set_subset): Sg workgroup rows for the listed subdomains; S stays the stride of every
   // array.  Launch POLICY (forked launches, two preparation workgroups per subdomain) follows Sg -- every policy gives the same
   // bits --, the K-split of the projection kernel follows S: a split changes the summation order, and a subset pass must
@@ -4302,7 +4324,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
                        factored ? 0 : 10 * N * N + 2 * N};
 #define LRBMS_PREP(NTXV)                                                                                                              \
   do {                                                                                                                                \
-    LRBMS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_prep_lds<NTXV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds)); \
+    LRBMS_HIP_CHECK(ctx, raise_max_lds(ctx->device, (const void*)k_prep_lds<NTXV>, (int)prep_lds));                                   \
     hipLaunchKernelGGL(k_prep_lds<NTXV>, dim3(Sg, prep_parts), dim3(PREP_LDS_THREADS), prep_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf, \
                        AvgSide, phase == 0 ? 1 : 0, ga);                                                                              \
   } while (0)
@@ -4323,8 +4345,9 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     // sharded pass: phase 2 (on another stream, once the halo is there) reads what the preparation wrote; the library orders
     // the two itself, so that the host needs neither a call boundary nor an event of its own between preparation and dense kernels
     // (recorded below, where the fork event of a forked call -- the same point of the stream -- serves as well)
-  } else if (do_b) {
-    LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->prep_done ? ctx->prep_done : ctx->ev_prep, 0));      // (a no-op if never recorded / same stream)
+  }
+  // the neighbours' shares of the flux image and of the vertex averages (phase 2; phase 5: on library stream 0, behind the fork)
+  auto side_prep = [&](hipStream_t ss) -> int {
     // (the same predicate as the whole pass and phase 1: where THEY prepare by the streaming sweeps -- a slab beyond the LDS -- the
     // neighbours' shares come from the streaming code too, so "1 then 2 == 0" compares one code with itself)
     if (prep_from_lds && prep_lds_bytes(t, Q, N, false) - prep_lds_slab_bytes(t, N, false) <= 64 * 1024) {
@@ -4332,25 +4355,30 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       // the neighbours' shares by the side threads' code of k_prep_lds in its slab-less form (one 256-thread workgroup per subdomain,
       // per-vertex data and row tables resolved once per workgroup; several workgroups per CU, so it also fits beside the dense
       // kernels) -- bit-identical to the whole pass by construction
-      KScope ks(ctx, "k_prep_lds<side>", st);
+      KScope ks(ctx, "k_prep_lds<side>", ss);
       const GncArgs ga{ebar, nullptr, 0, 0, 0};
       const size_t side_lds = prep_lds_bytes(t, Q, N, false) - prep_lds_slab_bytes(t, N, false);      // tables + coefficients: no slab
-      hipLaunchKernelGGL((k_prep_lds<1, 256>), dim3(Sg, 1), dim3(256), side_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
+      hipLaunchKernelGGL((k_prep_lds<1, 256>), dim3(Sg, 1), dim3(256), side_lds, ss, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
                          AvgSide, 2, ga);
     } else {
       {
-        KScope ks(ctx, "k_flux_side", st);
-        hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)Sg * 4 * t.ncf * N)), dim3(256), 0, st, t, S, ctx->nbr, Q, N, F, V, Rside);
+        KScope ks(ctx, "k_flux_side", ss);
+        hipLaunchKernelGGL(k_flux_side, dim3(grid_for((long)Sg * 4 * t.ncf * N)), dim3(256), 0, ss, t, S, ctx->nbr, Q, N, F, V, Rside);
       }
       // Avg_side: the dense layout launches k_vertex_side right in front of its only reader, k_thin_nc (below); in the factored
       // layout the reader is k_thin3, which is launched from the merged branch -- so it goes out here.  (Round 3: it went out
       // NOWHERE in that combination -- factored layout, >= 192 subdomains per rank, phase 2 -- and the phased-vs-whole test did not
       // see it because it reused a work buffer that still held the averages of the whole pass.)
       if (merge_thin) {      // (forked or factored: the reader is k_thin / k_thin3)
-        KScope ks(ctx, "k_vertex_side", st);
-        hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)Sg * 4 * nvs * N)), dim3(256), 0, st, t, S, ctx->nbr, N, V, AvgSide);
+        KScope ks(ctx, "k_vertex_side", ss);
+        hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)Sg * 4 * nvs * N)), dim3(256), 0, ss, t, S, ctx->nbr, N, V, AvgSide);
       }
     }
+    return LRBMS_OK;
+  };
+  if (phase == 2) {
+    LRBMS_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->prep_done ? ctx->prep_done : ctx->ev_prep, 0));      // (a no-op if never recorded / same stream)
+    if (int rc = side_prep(st)) return rc;
   }
   LRBMS_LAUNCH_CHECK(ctx);
   // fork: F2 / F3, the thin kernels and the coupling projection are independent of each other and of F1 (they all read
@@ -4359,19 +4387,20 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // Measured on MI355X / ROCm 7.2 (config 3 tiles): S = 128: 0.32 ms forked vs 0.41 ms serial (no kernel fills 256 CUs alone);
   // S = 256: 0.53 vs 0.51; S = 512: 0.97 vs 0.93; S = 1024: 1.92 vs 1.81 -> fork only below 192 subdomains per rank.
   // LRBMS_OPT_STREAMS 0 / 1 overrides.
-  const bool multi = (do_a || do_b) && forked;
+  const bool multi = (do_a || do_b) && forked;      // (phase 5: its halo-dependent half goes to library stream 0 under either policy)
   // forked: caller's stream k_f1 | aux0 k_thin (nonconformity side blocks, coupling projection, flux side factors), k_f3 |
   // aux1 k_f2.  k_f3 goes behind k_thin on library stream 0, not on a stream of its own: one join less, and k_f2 (one long
   // workgroup per subdomain) is not crowded out of the CUs k_f1 leaves free (128 subdomains: 171 vs 178 / 185 us per pass
   // with k_f3 behind k_f2 / on a third stream)
-  hipStream_t s_rt = multi ? ctx->aux[0] : st, s_f23 = multi ? ctx->aux[1] : st, s_nc = multi ? ctx->aux[0] : st;
+  hipStream_t s_rt = multi || both ? ctx->aux[0] : st, s_f23 = multi ? ctx->aux[1] : st, s_nc = multi || both ? ctx->aux[0] : st;
+  hipStream_t s_f3 = multi ? ctx->aux[0] : st;
   // only the library streams that get work in this call are forked and joined (an event operation costs host time, and
   // a sharded step makes three calls on ~0.2 ms of device work); a library stream that IS the caller's stream (the
   // sharded choreography runs phase 2 on stream 0) needs neither.
   // (Replaying the phases as captured hipGraphs instead was measured too: one graph launch costs ~35 us of host time and
   // the replay loses the overlap between the branches, 272 us per step.)
   const bool f3_runs = do_a && !(prep_from_lds && gnc_fold);      // library stream 0 carries the thin kernels and k_f3
-  const bool use_aux[3] = {multi && (do_b || f3_runs) && ctx->aux[0] != st, multi && do_a && ctx->aux[1] != st, false};
+  const bool use_aux[3] = {(both || (multi && (do_b || f3_runs))) && ctx->aux[0] != st, multi && do_a && ctx->aux[1] != st, false};
   const bool forks = use_aux[0] || use_aux[1] || use_aux[2];
   if (forks) {
     LRBMS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
@@ -4511,6 +4540,8 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   }
   }
   // ---- thin parts
+  if (both)      // library stream 0 is behind the preparation (the fork) and behind the caller's halo; the projection kernel is out already
+    if (int rc = side_prep(ctx->aux[0])) return rc;
   if (do_b && merge_thin) {
     const int ntx = (N + 15) / 16;
     ThinRtArgs a{V, Rself, Rside, Bbb, Aab, b, ctx->nbr, Fside, r_fd, Q, N, S};
@@ -4561,7 +4592,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   }
   if (do_b && !merge_thin) {
     hipStream_t side = s_nc;
-    if (!do_prep && !side_from_lds) {
+    if (phase != 0 && !side_from_lds) {      // (phase 0: the preparation wrote the neighbours' shares as well)
       KScope ks(ctx, "k_vertex_side", side);
       hipLaunchKernelGGL(k_vertex_side, dim3(grid_for((long)Sg * 4 * nvs * N)), dim3(256), 0, side, t, S, ctx->nbr, N, V, AvgSide);
     }
@@ -4642,12 +4673,12 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
     F3Args a{V, ebar, AvgSelf, AvgSide, G_nc, N, S, factored ? (long)N * N : 25L * N * N, factored ? N : 5 * N,
              factored ? 0 : 10 * N * N + 2 * N};
     const int ntx = (N + 15) / 16;
-    KScope ks(ctx, "k_f3", s_nc);
+    KScope ks(ctx, "k_f3", s_f3);
     switch (ntx) {
-      case 1: hipLaunchKernelGGL(k_f3<1>, dim3(Sg), dim3(256), 0, s_nc, t, a); break;
-      case 2: hipLaunchKernelGGL(k_f3<2>, dim3(Sg), dim3(256), 0, s_nc, t, a); break;
-      case 3: hipLaunchKernelGGL(k_f3<3>, dim3(Sg), dim3(256), 0, s_nc, t, a); break;
-      default: hipLaunchKernelGGL(k_f3<4>, dim3(Sg), dim3(256), 0, s_nc, t, a); break;
+      case 1: hipLaunchKernelGGL(k_f3<1>, dim3(Sg), dim3(256), 0, s_f3, t, a); break;
+      case 2: hipLaunchKernelGGL(k_f3<2>, dim3(Sg), dim3(256), 0, s_f3, t, a); break;
+      case 3: hipLaunchKernelGGL(k_f3<3>, dim3(Sg), dim3(256), 0, s_f3, t, a); break;
+      default: hipLaunchKernelGGL(k_f3<4>, dim3(Sg), dim3(256), 0, s_f3, t, a); break;
     }
     LRBMS_LAUNCH_CHECK(ctx);
   }

@@ -265,20 +265,23 @@ class Engine:
                     return buf
                 main = torch.cuda.current_stream()
                 side = c.aux_stream(0)     # a library stream, not a fresh one: HIP maps streams onto few hardware queues
-                if '_step_events' not in self.__dict__:
-                    self._step_events = (torch.cuda.Event(),)
-                done, = self._step_events
+                if main.cuda_stream == side.cuda_stream:    # (the caller works on library stream 0 itself: nothing to run beside)
+                    finish = halo.start(V)
+                    run(1)
+                    finish()
+                    run(2)
+                    return buf
                 finish = halo.start(V)                      # pack on the main stream + asynchronous collective
-                run(1)                                      # preparation of the own basis + the dense kernels (local slabs only), ONE
-                                                            # call: the library records its own event behind the preparation
-                torch.cuda.set_stream(side)                 # beside them, as soon as the halo is there (set_stream pair and
-                try:                                        # persistent events: the context manager + wait_stream cost 20 us)
-                    finish()                                # side stream waits for the collective, unpacks into V[S:]
-                    run(2)                                  # R_side, Avg_side, thin kernels, coupling blocks (the library makes
-                    done.record(side)                       # this stream wait for the preparation)
+                torch.cuda.set_stream(side)                 # (a set_stream pair: the context manager + wait_stream cost 20 us)
+                try:
+                    finish()                                # library stream 0 waits for the collective, unpacks into V[S:]
                 finally:
                     torch.cuda.set_stream(main)
-                main.wait_event(done)
+                # ONE library call for the step: preparation of the own basis + the dense kernels (local slabs only) on the main
+                # stream; R_side, Avg_side, the thin kernels and the coupling blocks on library stream 0, behind the unpack and
+                # behind the preparation, as soon as the halo is there; joined into the main stream (tools/host_step_time.py: 24 + 19
+                # us of host time for the two calls and 5 for the host's own event pair before, against ~30 for this one)
+                run(5, main.cuda_stream)
             return buf
         if halo is not None:
             halo(V)

@@ -346,7 +346,7 @@ def test_launch_matrix_against_one_oracle_checked_result():
     """Every launch combination of the fused pass against ONE result that is itself compared with the oracle: layout {factored,
     dense} x launch policy {one stream, forked over the library streams} x preparation {streaming sweeps + k_f3, LDS slab with the
     G_nc fold, LDS slab without it} x projection kernel {k_f1w, k_f1 (producer / consumer), k_f1u, k_f1u again (form 3: k_f1v where it is instantiated)} x {whole pass, phase 1 then
-    phase 2}: 96 cells on a 5 x 4 grid of the config-3 template (k_c = 4, N = 40).  Outputs AND the work buffer are poisoned with NaN
+    phase 2, phase 5 = both halves in one call with the halo-dependent one on library stream 0}: 144 cells on a 5 x 4 grid of the config-3 template (k_c = 4, N = 40).  Outputs AND the work buffer are poisoned with NaN
     in front of every cell, so a cell that forgets a launch (round 3: k_vertex_side in factored x unforked x phase 2) cannot pass on
     what the cell before left behind.  Reference: the unfused kernels' result, compared with the oracle's reductor at 1e-11; every
     cell against it at 1e-12 (dense-layout arrays; factored cells expanded)."""
@@ -370,7 +370,7 @@ def test_launch_matrix_against_one_oracle_checked_result():
     bufs = {True: eng.alloc_reduce_buffers(N, factored=True), False: eng.alloc_reduce_buffers(N, factored=False)}
     failures, seen = [], set()
     try:
-        for factored, streams, prep, form, phased in itertools.product((True, False), (0, 1), (0, 1, 2), (0, 1, 2, 3), (False, True)):
+        for factored, streams, prep, form, phased in itertools.product((True, False), (0, 1), (0, 1, 2), (0, 1, 2, 3), (0, 1, 5)):
             eng.ctx.set_option('streams', streams)
             eng.ctx.set_option('prep_lds', prep)
             eng.ctx.set_option('f1_form', form)
@@ -380,11 +380,11 @@ def test_launch_matrix_against_one_oracle_checked_result():
             args = (Vd, eng.F, eng.A_diag, eng.A_cpl, eng.P_diag, eng.b, eng.ebar, eng.caa, eng.Aab, eng.Bbb, buf['work'], buf['sys'],
                     buf['grams'])
             eng.ctx.kernel_timing(True)
-            if phased:
+            if phased == 1:
                 eng.ctx.project_estimate_fused(*args, phase=1)
                 eng.ctx.project_estimate_fused(*args, phase=2)
             else:
-                eng.ctx.project_estimate_fused(*args, phase=0)
+                eng.ctx.project_estimate_fused(*args, phase=phased)
             seen.update(k for k, _ in eng.ctx.kernel_timing_read())
             eng.ctx.kernel_timing(False)
             for name, got in zip(names, list(buf['sys']) + list(expand_factored_grams(buf['grams']))):
@@ -440,6 +440,12 @@ def test_full_size_properties_config3(monkeypatch):
             x.fill_(float('nan'))
         eng.ctx.project_estimate_fused(*args, phase=1)
         eng.ctx.project_estimate_fused(*args, phase=2)
+        for a, b in zip(ref, list(buf['sys']) + list(buf['grams'])):
+            assert torch.equal(a, b)
+        # ... and so do both halves in ONE call (phase 5: the halo-dependent one on library stream 0)
+        for x in list(buf['sys']) + list(buf['grams']) + [buf['work']]:
+            x.fill_(float('nan'))
+        eng.ctx.project_estimate_fused(*args, phase=5)
         if prep == 0:
             for a, b in zip(ref, list(buf['sys']) + list(buf['grams'])):
                 assert torch.equal(a, b)
