@@ -265,7 +265,9 @@ void* lrbms_ctx_aux_stream(lrbms_ctx* ctx, int32_t i);
  *   LRBMS_OPT_PREP_LDS         1 (default): the preparation sweeps of the fused pass (flux image, vertex averages) run from one copy of
  *                              the subdomain's basis slab in LDS whenever it fits (k_prep_lds), with G_nc[self, self] folded into the
  *                              same kernel; 2: the LDS form without that fold (k_f3 computes G_nc[self, self]); 0: the two streaming
- *                              sweeps */
+ *                              sweeps.  With more subdomains than CUs k_prep_lds runs one persistent workgroup per CU that takes its
+ *                              subdomains one after the other and prefetches the next slab into registers; 3: as 1 with one workgroup
+ *                              per subdomain at every count (the same bits; cross-check) */
 #define LRBMS_OPT_STREAMS 3
 #define LRBMS_OPT_F1_KSPLIT 4
 #define LRBMS_OPT_F1_FORM 5

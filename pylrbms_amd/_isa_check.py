@@ -1,4 +1,4 @@
-"""Build-time guard for the hand-scheduled prefetch of k_f1 / k_f2 (csrc/fused.hip).
+"""Build-time guard for the hand-scheduled prefetch of k_f1 / k_f2 and of the persistent k_prep_lds (csrc/fused.hip).
 
 The producer waves of both kernels prefetch with inline-asm ``global_load_dwordx2`` that the compiler does not track
 and complete them with a hand-counted ``s_waitcnt vmcnt(n)``.  That is correct only while (i) the compiler emits no
@@ -288,6 +288,31 @@ def check_fused_isa(asm_path):
 
             report.append('{}: producer loop [{}..{}] waits {}, VGPRs {}, scratch {}'.format(
                 kernel, a, b, asm_waits, md.get('vgpr_count'), md.get('private_segment_fixed_size')))
+    # k_prep_lds (1 024 threads, persistent form): the next subdomain's slab is requested by asm loads that stay in flight through
+    # whole phases of compiler-scheduled code; 128 VGPRs is all a wave of a 1 024-thread workgroup gets.  No spill (a reload is a
+    # vector-memory load whose wait drains the prefetch), and on every path from the kernel's entry no compiler-emitted instruction
+    # touches a destination of those loads before a vmcnt wait has completed them.
+    nprep = 0
+    for name, lines in fns.items():
+        m = re.search(r'\dk_prep_ldsILi(\d+)ELi1024EE', name)
+        if not m:
+            continue
+        nprep += 1
+        kernel = 'k_prep_lds<{},1024>'.format(m.group(1))
+        md = meta.get(name, {})
+        if md.get('vgpr_spill_count', 0) or md.get('private_segment_fixed_size', 0) or any(re.match(r'\s+scratch_', ln) for ln in lines):
+            problems.append('{}: scratch {} bytes, {} spilled VGPRs'.format(kernel, md.get('private_segment_fixed_size'), md.get('vgpr_spill_count')))
+        _, tags = _producer_loops(lines)
+        nasm = sum(1 for k, ln in enumerate(lines) if tags[k] and 'global_load_dwordx4' in ln)
+        if nasm == 0:
+            problems.append('{}: no asm-managed prefetch found'.format(kernel))
+            continue
+        hz = _inflight_register_hazards(lines, tags)
+        if hz:
+            problems.append('{}: compiler-emitted instruction touches the destination of a prefetch load still in flight: {}'.format(kernel, hz[:3]))
+        report.append('{}: {} asm prefetch loads, VGPRs {}, scratch {}'.format(kernel, nasm, md.get('vgpr_count'), md.get('private_segment_fixed_size')))
+    if nprep == 0:
+        problems.append('no k_prep_lds<*,1024> instantiation found in {}'.format(asm_path))
     if seen == 0:
         problems.append('no k_f1 / k_f2 instantiation with asm-managed prefetch found in {}'.format(asm_path))
     if problems:

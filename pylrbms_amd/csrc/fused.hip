@@ -129,6 +129,16 @@ __device__ inline double gload_f64(const double* p) {
   asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+__device__ inline double gload_s64(const double* base, unsigned off) {      // base: wave-uniform (SGPR pair); off: bytes
+  double v;
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+  return v;
+}
+__device__ inline d2 gload_s128(const double* base, unsigned off) {
+  d2 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+  return v;
+}
 
 // Broadcast lane `l` of a per-lane double to the whole wave as an SGPR pair (two v_readlane_b32, no LDS round trip).
 __device__ inline double bcast_d(double v, int l) {
@@ -162,7 +172,8 @@ struct OsInfo {
   int vdiag, corner, sda, sdb;
 };
 
-__device__ inline OsInfo oswald_vertex(const Tmpl& t, const int* nbr_s, int v) {
+template <typename IP>
+__device__ inline OsInfo oswald_vertex(const Tmpl& t, const int* nbr_s, int v, IP vdof_ptr) {      // vdof_ptr: t.vdof_ptr or a copy of it (LDS)
   OsInfo o;
   const int lx = v % t.nvx, ly = v / t.nvx;
   o.vside[0] = (ly == 0) ? lx + t.nvx * (t.nvy - 1) : -1;
@@ -171,14 +182,14 @@ __device__ inline OsInfo oswald_vertex(const Tmpl& t, const int* nbr_s, int v) {
   o.vside[3] = (ly == t.nvy - 1) ? lx : -1;
   o.pos[0] = o.pos[3] = lx;
   o.pos[1] = o.pos[2] = ly;
-  int cnt = t.vdof_ptr[v + 1] - t.vdof_ptr[v];
+  int cnt = vdof_ptr[v + 1] - vdof_ptr[v];
   bool dirichlet = false;
   for (int sd = 0; sd < 4; ++sd) {
     if (o.vside[sd] < 0) continue;
     if (nbr_s[side_to_slot(sd)] < 0 || t.opt_oswald_subdomain)
       dirichlet = true;
     else
-      cnt += t.vdof_ptr[o.vside[sd] + 1] - t.vdof_ptr[o.vside[sd]];
+      cnt += vdof_ptr[o.vside[sd] + 1] - vdof_ptr[o.vside[sd]];
   }
   o.vdiag = o.corner = o.sda = o.sdb = -1;
   const bool cx = lx == 0 || lx == t.nvx - 1, cy = ly == 0 || ly == t.nvy - 1;
@@ -189,11 +200,12 @@ __device__ inline OsInfo oswald_vertex(const Tmpl& t, const int* nbr_s, int v) {
     o.sda = ly == 0 ? 0 : 3;
     o.sdb = lx == 0 ? 1 : 2;
     o.vdiag = (lx == 0 ? t.nvx - 1 : 0) + t.nvx * (ly == 0 ? t.nvy - 1 : 0);
-    cnt += t.vdof_ptr[o.vdiag + 1] - t.vdof_ptr[o.vdiag];
+    cnt += vdof_ptr[o.vdiag + 1] - vdof_ptr[o.vdiag];
   }
   o.inv = dirichlet ? 0.0 : 1.0 / (double)cnt;
   return o;
 }
+__device__ inline OsInfo oswald_vertex(const Tmpl& t, const int* nbr_s, int v) { return oswald_vertex(t, nbr_s, v, t.vdof_ptr); }
 
 __device__ inline int face_sign_at(const Tmpl& t, const int* nbr_s, int e, int f) {
   const int nb = t.nb_elem[e * 3 + f];
@@ -382,6 +394,16 @@ static size_t prep_lds_bytes(const Tmpl& t, int Q, int N, bool gnc) {
   const size_t avg = gnc ? sizeof(double) * (size_t)t.nv * N : 0;
   return prep_lds_slab_bytes(t, N, gnc) + prep_lds_tab_bytes(t, gnc) + (flux > avg ? flux : avg);
 }
+// persistent form (a workgroup takes several subdomains): the row tables rinfo / srow stay valid across them, BEHIND region B =
+// max(Fl, Al) instead of inside it
+__host__ __device__ inline size_t prep_lds_region_b_bytes(const Tmpl& t, int Q, int N, bool gnc) {
+  const size_t fl = sizeof(double) * (size_t)Q * t.nrt * 6, avg = gnc ? sizeof(double) * (size_t)t.nv * N : 0;
+  return ((fl > avg ? fl : avg) + 15) & ~(size_t)15;
+}
+static size_t prep_lds_bytes_persistent(const Tmpl& t, int Q, int N, bool gnc) {
+  return prep_lds_slab_bytes(t, N, gnc) + prep_lds_tab_bytes(t, gnc) + prep_lds_region_b_bytes(t, Q, N, gnc) +
+         sizeof(int) * (4 * (size_t)t.nrt + 4 * t.ncf);
+}
 
 // G_nc[self, self] folded into k_prep_lds (below): the tiles a wave owns.  Even waves: the first row of tiles, odd waves: the rest.
 template <int NTX>
@@ -413,9 +435,17 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
                                                                const double* __restrict__ F, const double* __restrict__ V,
                                                                double* __restrict__ Rself, double* __restrict__ Rside,
                                                                double* __restrict__ AvgSelf, double* __restrict__ AvgSide,
-                                                               int write_side, GncArgs ga) {
+                                                               int write_side, GncArgs ga, int persistent) {
   extern __shared__ double Vl[];
-  const int s = subdomain_of(t, blockIdx.x), tid = threadIdx.x, N2 = N / 2, QN = Q * N, nvs = nvs_of(t);
+  const int tid = threadIdx.x, N2 = N / 2, QN = Q * N, nvs = nvs_of(t);
+  // persistent != 0 (the launcher: more subdomains than CUs, the slab in one round of loads, room for the row tables behind region B):
+  // gridDim.x < count workgroups, workgroup b takes the subdomains b, b + gridDim.x, ... of the list, and while it works on one it
+  // holds the NEXT one's slab and flux coefficients in registers (requested right behind the barrier that opens the LDS copy to
+  // readers): the 22 k cycles in which all workgroups of a round used to wait for their 150 KB with nothing to overlap (of 60 k per
+  // subdomain) are hidden behind the 38 k of LDS work.  The template's tables stay in LDS across the subdomains of a workgroup.
+  const int count = t.sub_list ? t.sub_count : S, G = gridDim.x;
+  int idx = blockIdx.x;
+  int s = subdomain_of(t, idx);
   // gridDim.y == 2 (ranks with at most half as many subdomains as the chip has CUs): the work of a subdomain is dealt to TWO workgroups
   // that each load the slab -- part 0 the flux image, part 1 the vertex averages and G_nc -- instead of leaving half of the CUs idle
   const bool do_flux = gridDim.y == 1 || blockIdx.y == 0, do_avg = gridDim.y == 1 || blockIdx.y == 1;      // workgroup-uniform
@@ -433,21 +463,24 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
   int* dvt = vidx + t.n;
   double* Fl = reinterpret_cast<double*>(reinterpret_cast<char*>(vinfo) + prep_lds_tab_bytes(t, gnc));
   double* Al = Fl;                               // with the fold: the vertex averages, once the flux rows are done
-  int4* rinfo = reinterpret_cast<int4*>(Fl + Q * t.nrt * 6);
+  // the row tables: behind the coefficients (the averages overwrite them, a workgroup with one subdomain) or behind region B (persistent)
+  int4* rinfo = reinterpret_cast<int4*>(persistent ? reinterpret_cast<char*>(Fl) + prep_lds_region_b_bytes(t, Q, N, gnc)
+                                                   : reinterpret_cast<char*>(Fl + Q * t.nrt * 6));
   int* srow = reinterpret_cast<int*>(rinfo + t.nrt);
   // ---- every global load of the own-rows work, issued together: the row tables first (a chain of two dependent loads whose
   // second step is requested while the slab is in flight), then the slab, the coefficients and the vertex tables
-  const int nb0 = nbr[s * 5], nb1 = nbr[s * 5 + 1], nb3 = nbr[s * 5 + 3], nb4 = nbr[s * 5 + 4];      // wave-uniform: scalar loads
+  int nb0 = nbr[s * 5], nb1 = nbr[s * 5 + 1], nb3 = nbr[s * 5 + 3], nb4 = nbr[s * 5 + 4];      // wave-uniform: scalar loads
   auto nbr_slot = [&](int slot) { return slot == 0 ? nb0 : slot == 1 ? nb1 : slot == 3 ? nb3 : nb4; };
   const int sc0 = t.side_count[0], sc1 = t.side_count[1], sc2 = t.side_count[2], sc3 = t.side_count[3];
+  constexpr int U = 8, FU = 2;                   // 16-byte pieces per thread of the slab / of the flux coefficients (persistent form)
+  static_assert(NTHR != 1024 || NTHR * U * 2 >= 384 * 40, "config 3: the slab in one round of loads");
+  const int total2 = t.n * N2;
+  const int f2 = t.nrt * 3;                      // 16-byte pieces of one component's coefficient rows
   {
     const d2* src = reinterpret_cast<const d2*>(V + (long)s * t.n * N);
     d2* dst = reinterpret_cast<d2*>(Vl);
-    const int total2 = t.n * N2;
     int e0 = 0, e1 = 0, side = -1, f0 = 0;
     if (do_flux && tid < t.nrt) e0 = t.rt_e0[tid], e1 = t.rt_e1[tid], side = t.rt_side[tid], f0 = t.rt_f0[tid];
-    constexpr int U = 8;
-    static_assert(NTHR != 1024 || NTHR * U * 2 >= 384 * 40, "config 3: the slab in one round of loads");
     for (int base = 0; base < (side_only ? 1 : total2); base += U * NTHR) {
       d2 tmp[U];
 #pragma unroll
@@ -474,7 +507,6 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
             Lg[T * 6 + 3 + k] = l11 * gy;
           }
         }
-        const int f2 = t.nrt * 3;                    // 16-byte pieces of one component's coefficient rows
         for (int i = tid; do_flux && i < Q * f2; i += NTHR) {
           const int q = i / f2, k = i - q * f2;
           reinterpret_cast<d2*>(Fl)[i] = reinterpret_cast<const d2*>(F + ((long)q * S + s) * t.nrt * 6)[k];
@@ -494,17 +526,69 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
     }
   }
   PREP_STAMP(1);
-  __syncthreads();
-  PREP_STAMP(2);
   const d2* Vl2 = reinterpret_cast<const d2*>(Vl);
   const int nmain = side_only ? 0 : (write_side ? NTHR - NTHR / 2 : NTHR);
   const int ts = tid - nmain, nst = NTHR - nmain;      // side threads: index, count
+  // nmain is a multiple of the wave size: a wave is either one of the own rows (MAIN) or one of the neighbours' shares, and each kind
+  // runs its OWN copy of the loop over the workgroup's subdomains (same barriers, in the same order).  With both kinds in one body --
+  // under an exec mask or behind two scalar branches -- hipcc's wait-count pass carries the loads still pending at the exits of the
+  // neighbours' code into the own rows' code, finds their registers reused there and drains vmcnt(0) in front of the flux loop: the
+  // prefetch would be waited for as soon as it is requested.
+  const bool mainw = uniform(tid >> 6) * 64 < nmain;
   const d2* V2 = reinterpret_cast<const d2*>(V);
+  d2 pre[U], fpre[FU];                                 // persistent form: the next subdomain's slab and coefficients (written by
+                                                       // request_next before they are read; no initialisation: it would keep 40
+                                                       // registers alive through the first load phase)
+  auto request_next = [&](int sn) {                    // clamped addresses, every load unconditional
+    // (the thread index through an opaque move: hipcc otherwise hoists the sixteen clamped offsets of these loads and of the LDS
+    // stores at the end of the loop out of the loop, keeps them alive through every phase and spills -- and a spill reload in the
+    // middle of a phase is a vector-memory load whose wait also waits for the prefetch)
+    // asm loads (gload_s128: wave-uniform base + 32-bit byte offset), completed by the asm vmcnt(0) in front of the LDS stores at the
+    // end of the loop: loads hipcc can see make its wait-count pass drain vmcnt(0) in the preheader of the flux and average loops
+    // (loops with stores and no loads: SIInsertWaitcnts flushes in front of them whenever it believes a pending register is used
+    // inside), i.e. right behind the request.  pylrbms_amd/_isa_check.py walks the emitted code: no compiler instruction may touch
+    // these registers while the loads are in flight, and the kernel may not spill.
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const double* src = V + (long)sn * t.n * N;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = u * NTHR + tl;
+      pre[u] = gload_s128(src, 16u * (unsigned)(i < total2 ? i : total2 - 1));
+    }
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+      int i = u * NTHR + tl;
+      i = i < Q * f2 ? i : Q * f2 - 1;
+      const int q = i / f2, k = i - q * f2;
+      fpre[u] = gload_s128(F, (unsigned)(((long)q * S + sn) * t.nrt * 48 + 16 * k));      // (the launcher: Q S n_rt 48 < 2^31)
+    }
+  };
+  auto subdomains = [&](auto role) {
+  constexpr bool MAIN = decltype(role)::value;
+  // (a wait hipcc can see: whatever its wait-count pass still carries as pending from the load phase above would otherwise reach the
+  // preheaders of the flux and average loops -- loops with stores and no loads -- and be flushed THERE with vmcnt(0), behind the request)
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0), gfx9 encoding
+  for (;;) {
+  __syncthreads();
+  PREP_STAMP(2);
+  const int idx_n = idx + G;
+  const bool more = persistent && idx_n < count;       // workgroup-uniform
+  const int s_n = more ? subdomain_of(t, idx_n) : s;
+  // Where the request goes (each placement measured, k_prep_lds at config 3: 127 us with one subdomain per workgroup; 111 us with the
+  // request here, right behind the barrier; 108.5 us as below): hipcc protects the operand registers of the stores still in flight with
+  // vmcnt waits of its own (gfx950 has no separate store counter) and flushes vmcnt(0) in the preheader of every loop that overwrites
+  // such a register -- the flux loop, the average loop, the Z rows, the MFMA loop -- and any of those waits also waits for the
+  // prefetch.  So the waves of the own rows request INSIDE the first round of the flux loop (behind its flush; the next flush, in
+  // front of the averages, comes 11 k cycles later), the waves of the neighbours' shares -- whose items wait for global loads of
+  // their own all along -- once those are done.
   if (!do_flux) {
-  } else if (tid < nmain) {
+  } else if (MAIN) {
     // ---- R_self: one item per (RT0 row, pair of columns)
     d2* R2 = reinterpret_cast<d2*>(Rself + (long)s * t.nrt * QN);
-    for (int it = tid; it < t.nrt * N2; it += nmain) {
+    for (int it = tid;; it += nmain) {           // (ONE request site, reached by every thread -- also one without a flux item:
+      if (more && it == tid) request_next(s_n);  //  with several sites hipcc may give the set different registers and move them)
+      if (it >= t.nrt * N2) break;
       const int r = it / N2, j2 = it - r * N2;
       const int4 ri = rinfo[r];
       d2 v0[3], v1[3];
@@ -554,10 +638,10 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
   }
   PREP_STAMP(3);
   // (the barriers of the fold order LDS traffic only: __syncthreads() would also wait for the global stores of the rows just written)
-  if (!do_avg) return;
-  if (gnc) lds_barrier();                        // Fl, rinfo, srow are dead: the averages may overwrite them
+  if (do_avg) {
+  if (gnc) lds_barrier();                        // Fl (and, in a workgroup with one subdomain, rinfo, srow) are dead: the averages may overwrite them
   PREP_STAMP(4);
-  if (tid < nmain) {
+  if (MAIN) {
     // ---- Avg_self: one item per (lattice vertex, pair of columns); the values at a vertex summed in the order of its DoF list
     d2* A2 = reinterpret_cast<d2*>(AvgSelf + (long)s * t.nv * N);
     for (int it = tid; it < t.nv * N2; it += nmain) {
@@ -631,7 +715,8 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
     }
     }
   PREP_STAMP(5);
-  if (!gnc) return;
+  if (more && !MAIN) request_next(s_n);          // the neighbours' shares are done: these waves' part of the next slab
+  if (gnc) {
   // ---- G_nc[self, self] = W^T E W, W = V - P Avg (the Oswald interpolation error of the own basis), E_T = ebar_T K_T.
   // K_T = G_T^T kappa G_T has rank 2 (G_T: the gradients of the three P1 shape functions): with kappa = L L^T,
   //   G_nc = sum_T ebar_T Z_T^T Z_T,   Z_T = L^T G_T W_T   (2 rows per element instead of 3),
@@ -719,6 +804,45 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
     }
   }
   PREP_STAMP(12);
+  }      // gnc
+  }      // do_avg
+  if (!more) break;
+  // ---- the next subdomain of this workgroup: its slab and coefficients are in registers (or on their way), the template's tables in LDS
+  __syncthreads();                               // every reader of the LDS copy is done (and every prefetch has landed)
+  idx = idx_n;
+  s = s_n;
+  nb0 = nbr[s * 5], nb1 = nbr[s * 5 + 1], nb3 = nbr[s * 5 + 3], nb4 = nbr[s * 5 + 4];
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the prefetch has landed
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // (the same wait where hipcc can see it: its wait-count pass then knows that the
+                                                          //  stores of this subdomain are done as well and carries nothing around the loop)
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(pre[u]));
+#pragma unroll
+    for (int u = 0; u < FU; ++u) asm volatile("" : "+v"(fpre[u]));
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    d2* dst = reinterpret_cast<d2*>(Vl);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = u * NTHR + tl;
+      if (i < total2) dst[i] = pre[u];
+    }
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+      const int i = u * NTHR + tl;
+      if (i < Q * f2) reinterpret_cast<d2*>(Fl)[i] = fpre[u];
+    }
+    for (int v = tid; v < t.nv; v += NTHR) {     // the same arithmetic on the LDS copy of the DoF-list offsets: the same bits
+      const OsInfo o = oswald_vertex(t, nbr + s * 5, v, vptr);
+      const int p0 = vptr[v];
+      vinfo[v] = VInfo{o.inv, p0, vptr[v + 1] - p0};
+    }
+  }
+  }      // subdomains of this workgroup
+  };
+  if (mainw) subdomains(std::true_type{});
+  else subdomains(std::false_type{});
 }
 
 // Avg_side alone (the halo-dependent phase of a sharded pass): one item per (subdomain, side, side vertex, column).
@@ -1757,16 +1881,6 @@ __global__ __launch_bounds__(512, 2) void k_f1u(Tmpl t, F1Args a, GrpTable gt) {
 //   * the number of column tiles per SIMD is a template parameter chosen on the host from Q N: no liveness test in the MFMA loop
 //     (at most three tiles beyond the last column multiply zeros).
 // Needs even N (adjacent-column pairs).  Everything else (odd N, N > 48 ...) runs k_f1u / k_f1.
-__device__ inline double gload_s64(const double* base, unsigned off) {      // base: wave-uniform (SGPR pair); off: bytes
-  double v;
-  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
-  return v;
-}
-__device__ inline d2 gload_s128(const double* base, unsigned off) {
-  d2 v;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
-  return v;
-}
 
 constexpr int F1V_SLOTS = 16;      // most accumulator tiles one wave of k_f1v owns
 constexpr long f1v_part_size(int) { return 8L * F1V_SLOTS * 4 * 64 + 64; }
@@ -4289,7 +4403,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   // kernel (k_f3 is not launched) whenever N <= 48 and the call covers both the preparation and the dense kernels
   const int ntx_p = (N + 15) / 16;
   const bool prep_ok = ctx->opt_prep_lds != 0 && N % 2 == 0;
-  const bool gnc_fold = prep_ok && ctx->opt_prep_lds != 2 && ntx_p <= 3 && prep_lds_bytes(t, Q, N, true) <= 160 * 1024;
+  const bool gnc_fold = prep_ok && ctx->opt_prep_lds != 2 && ntx_p <= 3 && prep_lds_bytes(t, Q, N, true) <= 160 * 1024;      // (3: as 1)
   const size_t prep_lds = prep_lds_bytes(t, Q, N, gnc_fold);
   const bool prep_from_lds = prep_ok && prep_lds <= 160 * 1024;
   bool side_from_lds = false;      // phase 2: k_prep_lds<side> wrote R_side AND Avg_side
@@ -4322,11 +4436,19 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       const int prep_parts = 2 * Sg <= ctx->num_cus ? 2 : 1;      // one workgroup per CU: two per subdomain while that leaves none waiting
       const GncArgs ga{ebar, gnc_fold ? G_nc : nullptr, factored ? (long)N * N : (long)25 * N * N, factored ? N : 5 * N,
                        factored ? 0 : 10 * N * N + 2 * N};
+      // More subdomains than CUs: one workgroup per CU that takes its subdomains one after the other and requests the next slab
+      // while it works on the current one (see the kernel); LRBMS_OPT_PREP_LDS 3 keeps one workgroup per subdomain (the same bits).
+      const size_t prep_lds_p = prep_lds_bytes_persistent(t, Q, N, gnc_fold);
+      const bool persist = prep_parts == 1 && Sg > ctx->num_cus && ctx->opt_prep_lds != 3 && prep_lds_p <= 160 * 1024 &&
+                           (size_t)t.n * (N / 2) <= 8 * (size_t)PREP_LDS_THREADS && (size_t)Q * t.nrt * 3 <= 2 * (size_t)PREP_LDS_THREADS &&
+                           (size_t)Q * S * t.nrt * 48 < ((size_t)1 << 31);
+      const size_t lds_used = persist ? prep_lds_p : prep_lds;
+      const int gx = persist ? ctx->num_cus : Sg;
 #define LRBMS_PREP(NTXV)                                                                                                              \
   do {                                                                                                                                \
-    LRBMS_HIP_CHECK(ctx, raise_max_lds(ctx->device, (const void*)k_prep_lds<NTXV>, (int)prep_lds));                                   \
-    hipLaunchKernelGGL(k_prep_lds<NTXV>, dim3(Sg, prep_parts), dim3(PREP_LDS_THREADS), prep_lds, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf, \
-                       AvgSide, phase == 0 ? 1 : 0, ga);                                                                              \
+    LRBMS_HIP_CHECK(ctx, raise_max_lds(ctx->device, (const void*)k_prep_lds<NTXV>, (int)lds_used));                                   \
+    hipLaunchKernelGGL(k_prep_lds<NTXV>, dim3(gx, prep_parts), dim3(PREP_LDS_THREADS), lds_used, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf, \
+                       AvgSide, phase == 0 ? 1 : 0, ga, persist ? 1 : 0);                                                             \
   } while (0)
       if (ntx_p == 1) LRBMS_PREP(1);
       else if (ntx_p == 2) LRBMS_PREP(2);
@@ -4359,7 +4481,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       const GncArgs ga{ebar, nullptr, 0, 0, 0};
       const size_t side_lds = prep_lds_bytes(t, Q, N, false) - prep_lds_slab_bytes(t, N, false);      // tables + coefficients: no slab
       hipLaunchKernelGGL((k_prep_lds<1, 256>), dim3(Sg, 1), dim3(256), side_lds, ss, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf,
-                         AvgSide, 2, ga);
+                         AvgSide, 2, ga, 0);
     } else {
       {
         KScope ks(ctx, "k_flux_side", ss);

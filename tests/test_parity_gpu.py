@@ -290,6 +290,78 @@ def test_forms_of_the_preparation_agree(shape, kc, N):
                 assert torch.equal(a, b), (form, i)
 
 
+@pytest.mark.parametrize('shape, kc, N, vertex_patch', [((20, 16), 2, 10, False), ((20, 15), 4, 40, False), ((18, 16), 2, 6, True)])
+def test_persistent_preparation_equals_one_workgroup_per_subdomain(shape, kc, N, vertex_patch):
+    """More subdomains than CUs: k_prep_lds runs one workgroup per CU that takes its subdomains one after the other and holds the next
+    one's slab in registers while it works on the current one (asm prefetch, template tables kept in LDS).  Bit for bit the result of
+    one workgroup per subdomain (LRBMS_OPT_PREP_LDS 3) -- whole pass, the two phases, an incremental subset -- with outputs and work
+    buffer poisoned in front of every run; on the small template (k_c = 2: fewer flux items than threads, a single tile) also against
+    the streaming sweeps and, through compare_all, against the oracle."""
+    import torch
+    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd.engine import Engine
+    p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(shape), 'coarse_per_subdomain': kc})
+    lam = p['lambda']
+    eng = Engine(p['grid'], lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], theta_bar_of(p),
+                 conventions={'oswald_vertex_patch': True} if vertex_patch else None).assemble()
+    assert eng.S > 256
+    V = eng.ctx.from_numpy(make_bases(eng.S, eng.t.n, N, seed=31))
+    buf = eng.alloc_reduce_buffers(N)
+    args = (V, eng.F, eng.A_diag, eng.A_cpl, eng.P_diag, eng.b, eng.ebar, eng.caa, eng.Aab, eng.Bbb, buf['work'], buf['sys'], buf['grams'])
+    everything = lambda: list(buf['sys']) + list(buf['grams'])
+
+    def run(prep, how):
+        eng.ctx.set_option('prep_lds', prep)
+        for x in everything() + [buf['work']]:
+            x.fill_(float('nan'))
+        if how == 'whole':
+            eng.ctx.project_estimate_fused(*args, phase=0)
+        elif how == 'phases':
+            eng.ctx.project_estimate_fused(*args, phase=1)
+            eng.ctx.project_estimate_fused(*args, phase=2)
+        else:
+            eng.ctx.project_estimate_fused(*args, phase=5)
+        return [x.clone() for x in everything()]
+
+    try:
+        ref = run(3, 'whole')
+        assert all(bool(torch.isfinite(x).all()) for x in ref)
+        for how in ('whole', 'phases', 'one call'):
+            got = run(1, how)
+            for i, (a, b) in enumerate(zip(ref, got)):
+                assert torch.equal(a, b), (how, i)
+        # an incremental subset of more subdomains than CUs: persistent as well, the other rows untouched
+        subset = [i for i in range(eng.S) if i % 16 != 3]
+        assert len(subset) > 256
+        for x in everything():
+            x.fill_(7.0)
+        buf['work'].fill_(float('nan'))
+        eng.project_and_estimate(V, buf, subset=subset)
+        rest = torch.tensor([i for i in range(eng.S) if i % 16 == 3], device=V.device)
+        sub = torch.tensor(subset, device=V.device)
+        for i, (a, b) in enumerate(zip(ref, everything())):
+            sdim = 1 if (a.dim() >= 2 and a.shape[0] == eng.Q and a.shape[1] == eng.S) else 0
+            if a.dim() >= 3 and a.shape[0] == eng.Q and a.shape[1] == eng.Q and a.shape[2] == eng.S:
+                sdim = 2
+            assert torch.equal(a.index_select(sdim, sub), b.index_select(sdim, sub)), i
+            assert bool((b.index_select(sdim, rest) == 7.0).all()), i
+        if kc == 2 and not vertex_patch:
+            stream = run(0, 'whole')
+            for i, (a, b) in enumerate(zip(ref, stream)):
+                if i == 4:          # G_nc: another summation (test_forms_of_the_preparation_agree)
+                    assert float((a - b).abs().max()) <= 1e-12 * float(a.abs().max())
+                else:
+                    assert torch.equal(a, b), i
+    finally:
+        eng.ctx.set_option('prep_lds', 1)
+    if kc == 2 and not vertex_patch:
+        d = oracle_from_problem(p)
+        Vh = energy_orthonormalize(make_bases(d.S, d.n, N, seed=32), d)
+        res = compare_all(p, eng, Vh, 0.6, oracle=d, do_solve=False)
+        bad = {k: v for k, v in res.items() if not v < TOL}
+        assert not bad, bad
+
+
 @pytest.mark.parametrize('shape, kc, N', [((3, 3), 2, 5), ((4, 3), 1, 2), ((2, 2), 2, 40)])
 def test_vertex_patch_of_the_oswald_interpolation(shape, kc, N):
     """LRBMS_OPT_OSWALD_VERTEX_PATCH (conventions={'oswald_vertex_patch': True}): the Oswald average at a cross point runs over
@@ -428,7 +500,7 @@ def test_full_size_properties_config3(monkeypatch):
     # missing k_vertex_side launch in round 3)
     args = (V, eng.F, eng.A_diag, eng.A_cpl, eng.P_diag, eng.b, eng.ebar, eng.caa, eng.Aab, eng.Bbb, buf['work'], buf['sys'],
             buf['grams'])
-    for prep in (0, 1):
+    for prep in (0, 1, 3):      # streaming sweeps; LDS copy (1 024 subdomains: one persistent workgroup per CU); one workgroup per subdomain
         eng.ctx.set_option('prep_lds', prep)
         ref = serial
         if prep == 0:          # the streaming sweeps + k_f3: G_nc is another summation (test_forms_of_the_preparation_agree)
