@@ -96,7 +96,7 @@ extern "C" int lrbms_debug_thin_trace(unsigned long long* host) {
 __device__ unsigned long long g_prep_trace[2][16];
 #define PREP_STAMP(k)                                                                                          \
   do {                                                                                                         \
-    if (blockIdx.x == 5 && (threadIdx.x == 0 || threadIdx.x == PREP_LDS_THREADS - 64))                         \
+    if (blockIdx.x == 5 && prep_trace_on && (threadIdx.x == 0 || threadIdx.x == PREP_LDS_THREADS - 64))        \
       g_prep_trace[threadIdx.x == 0 ? 0 : 1][k] = __builtin_amdgcn_s_memtime();                               \
   } while (0)
 extern "C" int lrbms_debug_prep_trace(unsigned long long* host) {
@@ -445,6 +445,9 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
   // subdomain) are hidden behind the 38 k of LDS work.  The template's tables stay in LDS across the subdomains of a workgroup.
   const int count = t.sub_list ? t.sub_count : S, G = gridDim.x;
   int idx = blockIdx.x;
+#ifdef PREP_TRACE
+  bool prep_trace_on = true;                     // (persistent form: the stamps of the workgroup's THIRD subdomain, steady state)
+#endif
   int s = subdomain_of(t, idx);
   // gridDim.y == 2 (ranks with at most half as many subdomains as the chip has CUs): the work of a subdomain is dealt to TWO workgroups
   // that each load the slab -- part 0 the flux image, part 1 the vertex averages and G_nc -- instead of leaving half of the CUs idle
@@ -527,7 +530,9 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
   }
   PREP_STAMP(1);
   const d2* Vl2 = reinterpret_cast<const d2*>(Vl);
-  const int nmain = side_only ? 0 : (write_side ? NTHR - NTHR / 2 : NTHR);
+  const int nside_x = persistent >> 8;             // EXPERIMENT: threads of the neighbours' shares
+  persistent &= 1;
+  const int nmain = side_only ? 0 : (write_side ? NTHR - (nside_x ? nside_x : NTHR / 2) : NTHR);
   const int ts = tid - nmain, nst = NTHR - nmain;      // side threads: index, count
   // nmain is a multiple of the wave size: a wave is either one of the own rows (MAIN) or one of the neighbours' shares, and each kind
   // runs its OWN copy of the loop over the workgroup's subdomains (same barriers, in the same order).  With both kinds in one body --
@@ -570,6 +575,10 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
   // preheaders of the flux and average loops -- loops with stores and no loads -- and be flushed THERE with vmcnt(0), behind the request)
   __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0), gfx9 encoding
   for (;;) {
+#ifdef PREP_TRACE
+  prep_trace_on = !persistent || idx == (int)blockIdx.x + 2 * G;
+#endif
+  PREP_STAMP(13);
   __syncthreads();
   PREP_STAMP(2);
   const int idx_n = idx + G;
@@ -616,23 +625,40 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
   } else {
     // ---- the neighbours' share of the flux image (write_side only): the last NTHR / 2 threads.  Every item of theirs waits
     // for global loads (the neighbours' rows)
+    // (two items per round, the neighbour's rows of both requested before the first is used: these waves are the critical path of
+    // the workgroup -- every item of theirs is a chain LDS tables -> global rows -- and a round trip costs the same for six loads
+    // as for three; every load unconditional, from a clamped address)
     d2* Rs2 = reinterpret_cast<d2*>(Rside + (long)s * 4 * t.ncf * QN);
-    for (int it = ts; it < 4 * t.ncf * N2; it += nst) {
-      const int sp = it / N2, j2 = it - sp * N2;
+    const int nitems = 4 * t.ncf * N2;
+    auto flux_item = [&](int it, int& sp, int& j2, int& r, int& s2) -> bool {      // false: a side with fewer than ncf faces
+      sp = it / N2, j2 = it - sp * N2;
       const int sd = sp / t.ncf;
-      if (sp - sd * t.ncf >= (sd == 0 ? sc0 : sd == 1 ? sc1 : sd == 2 ? sc2 : sc3)) continue;      // a side with fewer than ncf faces
-      const int r = srow[sp];
-      const int4 ri = rinfo[r];
-      const int s2 = nbr_slot(side_to_slot(sd));
-      d2 v1[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
-      if (s2 >= 0)
+      const bool ok = sp - sd * t.ncf < (sd == 0 ? sc0 : sd == 1 ? sc1 : sd == 2 ? sc2 : sc3);
+      r = ok ? srow[sp] : 0;
+      s2 = nbr_slot(side_to_slot(sd));
+      return ok;
+    };
+    for (int it0 = ts; it0 < nitems; it0 += 2 * nst) {
+      d2 v1[2][3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) v1[i] = V2[((long)s2 * t.n + 3 * ri.y + i) * N2 + j2];
-      for (int q = 0; q < Q; ++q) {
-        const double* f = Fl + (q * t.nrt + r) * 6;
-        const double ox = f[3] * v1[0].x + f[4] * v1[1].x + f[5] * v1[2].x;
-        const double oy = f[3] * v1[0].y + f[4] * v1[1].y + f[5] * v1[2].y;
-        Rs2[(sp * QN + q * N) / 2 + j2] = s2 >= 0 ? (d2){ox, oy} : (d2){0.0, 0.0};
+      for (int b = 0; b < 2; ++b) {
+        int sp, j2, r, s2;
+        const bool use = flux_item(it0 + b * nst < nitems ? it0 + b * nst : it0, sp, j2, r, s2) && it0 + b * nst < nitems && s2 >= 0;
+        const long row0 = (long)(use ? s2 : s) * t.n + 3 * (use ? rinfo[r].y : 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v1[b][i] = V2[(row0 + i) * N2 + j2];
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (it0 + b * nst >= nitems) continue;
+        int sp, j2, r, s2;
+        if (!flux_item(it0 + b * nst, sp, j2, r, s2)) continue;
+        for (int q = 0; q < Q; ++q) {
+          const double* f = Fl + (q * t.nrt + r) * 6;
+          const double ox = f[3] * v1[b][0].x + f[4] * v1[b][1].x + f[5] * v1[b][2].x;
+          const double oy = f[3] * v1[b][0].y + f[4] * v1[b][1].y + f[5] * v1[b][2].y;
+          Rs2[(sp * QN + q * N) / 2 + j2] = s2 >= 0 ? (d2){ox, oy} : (d2){0.0, 0.0};
+        }
       }
     }
   }
@@ -665,33 +691,64 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
     }
   } else {
     // ---- the neighbours' shares of the vertex averages, beside the own ones
+    // (two items per round as for the flux rows: the first four DoFs of both items' vertices requested together -- a side vertex of
+    // the neighbour has three; the sum runs in the order of the DoF list, item by item: the same additions as one item at a time)
     d2* As2 = reinterpret_cast<d2*>(AvgSide + (long)s * 4 * nvs * N);
-    for (int it = ts; it < 4 * nvs * N2; it += nst) {
-      const int sp = it / N2, j2 = it - sp * N2;
+    const int nitems = 4 * nvs * N2;
+    // (everything about an item but the loaded rows is recomputed from its index in the second half: integers and LDS reads are
+    // cheap, registers are not -- 128 per wave, and a spill reload would be a vector-memory load in front of the prefetch)
+    auto avg_item = [&](int it, int& sp, int& j2, int& q0, int& q1, int& s2, double& inv) -> bool {      // false: no such side vertex
+      sp = it / N2, j2 = it - sp * N2;
       const int sd = sp / nvs, pos = sp - sd * nvs;
-      if (pos >= ((sd == 0 || sd == 3) ? t.nvx : t.nvy)) continue;
-      const int v = sd == 0 ? pos : sd == 1 ? pos * t.nvx : sd == 2 ? pos * t.nvx + t.nvx - 1 : (t.nvy - 1) * t.nvx + pos;
-      const VInfo o = vinfo[v];
-      const int s2 = nbr_slot(side_to_slot(sd));
-      d2 a2 = {0.0, 0.0};
-      if (s2 >= 0 && o.inv != 0.0) {
-        // the matching lattice vertex of the neighbour across side sd (oswald_vertex: vside)
-        const int v2 = sd == 0 ? pos + t.nvx * (t.nvy - 1) : sd == 1 ? (t.nvx - 1) + t.nvx * pos : sd == 2 ? t.nvx * pos : pos;
-        const int q0 = vinfo[v2].p0, q1 = q0 + vinfo[v2].cnt;
-        for (int pb = q0; pb < q1; pb += 8) {
-          d2 val[8];
+      const bool ok = pos < ((sd == 0 || sd == 3) ? t.nvx : t.nvy);
+      const int posc = ok ? pos : 0;
+      const int v = sd == 0 ? posc : sd == 1 ? posc * t.nvx : sd == 2 ? posc * t.nvx + t.nvx - 1 : (t.nvy - 1) * t.nvx + posc;
+      inv = vinfo[v].inv;
+      s2 = nbr_slot(side_to_slot(sd));
+      // the matching lattice vertex of the neighbour across side sd (oswald_vertex: vside)
+      const int v2 = sd == 0 ? posc + t.nvx * (t.nvy - 1) : sd == 1 ? (t.nvx - 1) + t.nvx * posc : sd == 2 ? t.nvx * posc : posc;
+      q0 = vinfo[v2].p0, q1 = q0 + vinfo[v2].cnt;
+      return ok;
+    };
+    for (int it0 = ts; it0 < nitems; it0 += 2 * nst) {
+      d2 val[2][4];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) val[k] = V2[((long)s2 * t.n + vidx[pb + k < q1 ? pb + k : q1 - 1]) * N2 + j2];
+      for (int b = 0; b < 2; ++b) {
+        int sp, j2, q0, q1, s2;
+        double inv;
+        const bool ok = avg_item(it0 + b * nst < nitems ? it0 + b * nst : it0, sp, j2, q0, q1, s2, inv) && it0 + b * nst < nitems;
+        const long slab = (long)(ok && s2 >= 0 && inv != 0.0 ? s2 : s) * t.n;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            a2.x += pb + k < q1 ? val[k].x : 0.0;
-            a2.y += pb + k < q1 ? val[k].y : 0.0;
-          }
-        }
-        a2.x *= o.inv;
-        a2.y *= o.inv;
+        for (int k = 0; k < 4; ++k) val[b][k] = V2[(slab + vidx[q0 + k < q1 ? q0 + k : q1 - 1]) * N2 + j2];
       }
-      As2[sp * N2 + j2] = a2;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (it0 + b * nst >= nitems) continue;
+        int sp, j2, q0, q1, s2;
+        double inv;
+        if (!avg_item(it0 + b * nst, sp, j2, q0, q1, s2, inv)) continue;
+        d2 a2 = {0.0, 0.0};
+        if (s2 >= 0 && inv != 0.0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            a2.x += q0 + k < q1 ? val[b][k].x : 0.0;
+            a2.y += q0 + k < q1 ? val[b][k].y : 0.0;
+          }
+          for (int pb = q0 + 4; pb < q1; pb += 4) {      // (a vertex with more than four DoFs in its patch)
+            d2 more4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) more4[k] = V2[((long)s2 * t.n + vidx[pb + k < q1 ? pb + k : q1 - 1]) * N2 + j2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              a2.x += pb + k < q1 ? more4[k].x : 0.0;
+              a2.y += pb + k < q1 ? more4[k].y : 0.0;
+            }
+          }
+          a2.x *= inv;
+          a2.y *= inv;
+        }
+        As2[sp * N2 + j2] = a2;
+      }
     }
     if (t.opt_oswald_vertex) {                   // the diagonal subdomains' shares at the four corners: Avg_corner [S][4][N]
       d2* Ac2 = reinterpret_cast<d2*>(AvgSide + (long)S * 4 * nvs * N + (long)s * 4 * N);
@@ -715,7 +772,6 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
     }
     }
   PREP_STAMP(5);
-  if (more && !MAIN) request_next(s_n);          // the neighbours' shares are done: these waves' part of the next slab
   if (gnc) {
   // ---- G_nc[self, self] = W^T E W, W = V - P Avg (the Oswald interpolation error of the own basis), E_T = ebar_T K_T.
   // K_T = G_T^T kappa G_T has rank 2 (G_T: the gradients of the three P1 shape functions): with kappa = L L^T,
@@ -774,6 +830,9 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
           }
           if (k < ntile) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, eb * bv, acc[k], 0, 0, 0);
         }
+      // the waves of the neighbours' shares: behind the LAST vmcnt flush of the subdomain (hipcc puts one in front of this loop for
+      // the stores of the averages; requested before it, the prefetch stalled these waves 5.5 k cycles in front of their MFMAs)
+      if (more && !MAIN && st == st0) request_next(s_n);
     }
     PREP_STAMP(9);
     lds_barrier();                               // every wave is done with the Z rows: the slab region takes the partial tiles
@@ -807,6 +866,7 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
   }      // gnc
   }      // do_avg
   if (!more) break;
+  PREP_STAMP(14);
   // ---- the next subdomain of this workgroup: its slab and coefficients are in registers (or on their way), the template's tables in LDS
   __syncthreads();                               // every reader of the LDS copy is done (and every prefetch has landed)
   idx = idx_n;
@@ -4439,7 +4499,10 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
       // More subdomains than CUs: one workgroup per CU that takes its subdomains one after the other and requests the next slab
       // while it works on the current one (see the kernel); LRBMS_OPT_PREP_LDS 3 keeps one workgroup per subdomain (the same bits).
       const size_t prep_lds_p = prep_lds_bytes_persistent(t, Q, N, gnc_fold);
-      const bool persist = prep_parts == 1 && Sg > ctx->num_cus && ctx->opt_prep_lds != 3 && prep_lds_p <= 160 * 1024 &&
+      // (with the G_nc fold only, and every wave with a K part of its own in it: the waves of the neighbours' shares request from
+      // inside its MFMA loop)
+      const bool persist = prep_parts == 1 && Sg > ctx->num_cus && ctx->opt_prep_lds != 3 && prep_lds_p <= 160 * 1024 && gnc_fold &&
+                           7 * ((t.nT / 2 + 7) / 8) < t.nT / 2 &&
                            (size_t)t.n * (N / 2) <= 8 * (size_t)PREP_LDS_THREADS && (size_t)Q * t.nrt * 3 <= 2 * (size_t)PREP_LDS_THREADS &&
                            (size_t)Q * S * t.nrt * 48 < ((size_t)1 << 31);
       const size_t lds_used = persist ? prep_lds_p : prep_lds;
@@ -4448,7 +4511,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   do {                                                                                                                                \
     LRBMS_HIP_CHECK(ctx, raise_max_lds(ctx->device, (const void*)k_prep_lds<NTXV>, (int)lds_used));                                   \
     hipLaunchKernelGGL(k_prep_lds<NTXV>, dim3(gx, prep_parts), dim3(PREP_LDS_THREADS), lds_used, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf, \
-                       AvgSide, phase == 0 ? 1 : 0, ga, persist ? 1 : 0);                                                             \
+                       AvgSide, phase == 0 ? 1 : 0, ga, (persist ? 1 : 0) | ((ctx->opt_prep_lds == 4 ? 256 : ctx->opt_prep_lds == 5 ? 128 : 0) << 8));                                                             \
   } while (0)
       if (ntx_p == 1) LRBMS_PREP(1);
       else if (ntx_p == 2) LRBMS_PREP(2);

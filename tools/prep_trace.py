@@ -30,8 +30,15 @@ lib.lrbms_debug_prep_trace.argtypes = [ctypes.c_void_p]
 rc = lib.lrbms_debug_prep_trace(out.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0, rc
 names = ['start', 'loads issued + staged', 'barrier 0', 'flux rows done', 'barrier 1 (Fl dead)', 'averages done', 'barrier 2 (Al complete)',
-         'Z rows done', 'barrier 3', 'MFMA done', 'barrier 4', 'partials written + barrier 5', 'end']
+         'Z rows done', 'barrier 3', 'MFMA done', 'barrier 4', 'partials written + barrier 5', 'end', 'top of the loop (persistent form: third subdomain)',
+         'G_nc stored, in front of the refill']
 t0 = int(out[0, 0])
 print('k_prep_lds, workgroup 5: s_memtime stamps relative to the start of wave 0 (wave 0: own rows | last wave: neighbours\' shares)')
-for k, nm in enumerate(names):
+order = list(range(len(names)))
+if int(out[0, 13]) > int(out[0, 1]):       # persistent form: the stamps 2 .. 14 belong to the workgroup's third subdomain
+    order = [0, 1, 13] + list(range(2, 13)) + [14]
+    t0 = int(out[0, 13])
+    print('(persistent: relative to the top of the loop for the third subdomain; 0 / 1 are the first subdomain\'s load phase)')
+for k in order:
+    nm = names[k]
     print('{:2d} {:32s} {:10d} {:10d}'.format(k, nm, int(out[0, k]) - t0, int(out[1, k]) - t0))
