@@ -166,7 +166,7 @@ int lrbms_ctx_set_option(lrbms_ctx* ctx, int32_t option, int32_t value) {
   if (option == LRBMS_OPT_STREAMS) lo = -1;
   if (option == LRBMS_OPT_F1_KSPLIT) hi = 4;
   if (option == LRBMS_OPT_COARSE) hi = 2;
-  if (option == LRBMS_OPT_PREP_LDS) hi = 5;
+  if (option == LRBMS_OPT_PREP_LDS) hi = 3;
   if (option == LRBMS_OPT_F1_FORM) hi = 3;
   if (value < lo || value > hi || (option == LRBMS_OPT_F1_KSPLIT && value == 3))
     return lrbms_fail(ctx, LRBMS_E_INVALID, "set_option: value out of range for this option");

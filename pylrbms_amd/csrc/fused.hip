@@ -530,9 +530,9 @@ __global__ __launch_bounds__(NTHR) void k_prep_lds(Tmpl t, int S, const int* __r
   }
   PREP_STAMP(1);
   const d2* Vl2 = reinterpret_cast<const d2*>(Vl);
-  const int nside_x = persistent >> 8;             // EXPERIMENT: threads of the neighbours' shares
-  persistent &= 1;
-  const int nmain = side_only ? 0 : (write_side ? NTHR - (nside_x ? nside_x : NTHR / 2) : NTHR);
+  // (half of the threads for the neighbours' shares: with 256 / 128 of the 1 024 the kernel takes 121 / 136 us instead of 111 --
+  // their items are chains of dependent loads, the longer chain of the workgroup)
+  const int nmain = side_only ? 0 : (write_side ? NTHR - NTHR / 2 : NTHR);
   const int ts = tid - nmain, nst = NTHR - nmain;      // side threads: index, count
   // nmain is a multiple of the wave size: a wave is either one of the own rows (MAIN) or one of the neighbours' shares, and each kind
   // runs its OWN copy of the loop over the workgroup's subdomains (same barriers, in the same order).  With both kinds in one body --
@@ -4511,7 +4511,7 @@ int launch_project_estimate_fused(lrbms_ctx* ctx, int Q, int N, const double* V,
   do {                                                                                                                                \
     LRBMS_HIP_CHECK(ctx, raise_max_lds(ctx->device, (const void*)k_prep_lds<NTXV>, (int)lds_used));                                   \
     hipLaunchKernelGGL(k_prep_lds<NTXV>, dim3(gx, prep_parts), dim3(PREP_LDS_THREADS), lds_used, st, t, S, ctx->nbr, Q, N, F, V, Rself, Rside, AvgSelf, \
-                       AvgSide, phase == 0 ? 1 : 0, ga, (persist ? 1 : 0) | ((ctx->opt_prep_lds == 4 ? 256 : ctx->opt_prep_lds == 5 ? 128 : 0) << 8));                                                             \
+                       AvgSide, phase == 0 ? 1 : 0, ga, persist ? 1 : 0);                                                             \
   } while (0)
       if (ntx_p == 1) LRBMS_PREP(1);
       else if (ntx_p == 2) LRBMS_PREP(2);
