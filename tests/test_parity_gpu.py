@@ -290,7 +290,8 @@ def test_forms_of_the_preparation_agree(shape, kc, N):
                 assert torch.equal(a, b), (form, i)
 
 
-@pytest.mark.parametrize('shape, kc, N, vertex_patch', [((20, 16), 2, 10, False), ((20, 15), 4, 40, False), ((18, 16), 2, 6, True)])
+@pytest.mark.parametrize('shape, kc, N, vertex_patch', [((20, 16), 2, 10, False), ((20, 15), 4, 40, False), ((18, 16), 2, 6, True),
+                                                        ((17, 17), -34, 8, False)])
 def test_persistent_preparation_equals_one_workgroup_per_subdomain(shape, kc, N, vertex_patch):
     """More subdomains than CUs: k_prep_lds runs one workgroup per CU that takes its subdomains one after the other and holds the next
     one's slab in registers while it works on the current one (asm prefetch, template tables kept in LDS).  Bit for bit the result of
@@ -298,9 +299,13 @@ def test_persistent_preparation_equals_one_workgroup_per_subdomain(shape, kc, N,
     buffer poisoned in front of every run; on the small template (k_c = 2: fewer flux items than threads, a single tile) also against
     the streaming sweeps and, through compare_all, against the oracle."""
     import torch
-    from pylrbms_amd import multiscale_problem
+    from pylrbms_amd import multiscale_problem, thermalblock_problem
     from pylrbms_amd.engine import Engine
-    p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(shape), 'coarse_per_subdomain': kc})
+    if kc < 0:      # the thermal block problem: Q = 4 affine components (the coefficient prefetch over four component blocks); -kc: the GLOBAL
+                    # number of coarse squares per direction (grid.py:24-25), two per subdomain here
+        p = thermalblock_problem.init_grid_and_problem({'num_subdomains': list(shape), 'half_num_fine_elements_per_subdomain_and_dim': -kc})
+    else:
+        p = multiscale_problem.init_grid_and_problem({'num_subdomains': list(shape), 'coarse_per_subdomain': kc})
     lam = p['lambda']
     eng = Engine(p['grid'], lam['functions'], p['kappa'], p['f'], p['lambda_bar'], p['lambda_hat'], theta_bar_of(p),
                  conventions={'oswald_vertex_patch': True} if vertex_patch else None).assemble()
